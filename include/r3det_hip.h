@@ -1,0 +1,138 @@
+/* r3det_hip.h -- C ABI of libr3det_hip.so: the MI355X (gfx950) implementation of the
+ * r3det custom-op hot path.
+ *
+ * One entry point per pybind function of the reference (paths relative to
+ * /root/reference/r3det/ops); each declaration cites the interface it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 / int64 / uint8 data, row-major, contiguous;
+ *     tensors are borrowed for the duration of the call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every function
+ *     only enqueues work on it and returns without synchronising;
+ *   - no allocation happens inside the library: NMS takes a caller-provided workspace whose
+ *     size comes from r3det_nms_workspace_bytes();
+ *   - return value: 0 on success, a negative R3DET_E* code otherwise; nothing is thrown
+ *     across the ABI.  r3det_error_string() names a code.
+ *   - boxes are [cx, cy, w, h, theta(rad)] exactly as in the reference.
+ */
+#ifndef R3DET_HIP_H_
+#define R3DET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R3DET_OK 0
+#define R3DET_EINVAL (-1)  /* bad argument (null pointer, negative size, bad enum)      */
+#define R3DET_ELAUNCH (-2) /* hipLaunch / hipMemsetAsync reported an error              */
+#define R3DET_EWS (-3)     /* workspace too small                                       */
+
+/* geometry variants (angle conventions of the three operator families) */
+#define R3DET_GEOM_V1 1 /* rbbox_geo / rnms: vertex+segment algorithm                   */
+#define R3DET_GEOM_V2 2 /* mmcv / ml_nms_rotated: hull algorithm, standard vertex sign  */
+#define R3DET_GEOM_V3 3 /* box_iou_rotated / nms_rotated: hull algorithm, negated sign  */
+
+int r3det_abi_version(void);
+const char* r3det_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------
+ * Rotated IoU
+ * ------------------------------------------------------------------------------------- */
+
+/* rbbox_geo_cuda.mat_iou_iof(rb1, rb2, iof)            rbbox_geo/src/rbbox_geo_cuda.cpp:13-18
+ * kernel rbbox_geo/src/rbbox_geo_kernel.cu:231-268.   rb1 (n1,5), rb2 (n2,5) -> out (n1,n2). */
+int r3det_rbbox_geo_mat_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
+                                float* out, void* stream);
+
+/* rbbox_geo_cuda.vec_iou_iof(rb1, rb2, iof)            rbbox_geo/src/rbbox_geo_cuda.cpp:19-24
+ * kernel rbbox_geo_kernel.cu:271-309.  out (max(n1,n2),), out[i] = f(rb1[i % n1], rb2[i % n2]). */
+int r3det_rbbox_geo_vec_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
+                                float* out, void* stream);
+
+/* box_iou_rotated_ext.overlaps(b1, b2, iou_or_iof)     box_iou_rotated/src/box_iou_rotated_ext.cpp:17-32
+ * kernel box_iou_rotated/src/box_iou_rotated_cuda.cu:14-63.  iou_or_iof != 0 selects IoU,
+ * 0 selects IoF (intersection / area of b1).  out (n1,n2). */
+int r3det_box_iou_rotated_overlaps(const float* b1, int n1, const float* b2, int n2,
+                                   int iou_or_iof, float* out, void* stream);
+
+/* Pairwise companion of the call above: out[i] = overlap(b1[i], b2[i]), i < n.  Serves
+ * obb_overlaps(is_aligned=True) (box_iou_rotated_wrapper.py:48-49), whose reference
+ * implementation is a differentiable torch composition + convex_sort. */
+int r3det_box_iou_rotated_overlaps_aligned(const float* b1, const float* b2, int n,
+                                           int iou_or_iof, float* out, void* stream);
+
+/* mmcv.ops.box_iou_rotated(b1, b2, mode, aligned)      call site core/bbox/iou_calculators/
+ * rotate_iou2d_calculator.py:156 (third-party op; geometry restated from
+ * ml_nms_rotated/src/box_iou_rotated_utils.h).  mode_flag 0 = iou, 1 = iof.
+ * aligned == 0: out (n1,n2); aligned != 0: n1 must equal n2, out (n1,). */
+int r3det_mmcv_box_iou_rotated(const float* b1, int n1, const float* b2, int n2, int mode_flag,
+                               int aligned, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Rotated NMS.  As in mmcv's ext signature the score sort stays with the caller: `order`
+ * holds the n original indices sorted by score (descending, stable); boxes are passed in
+ * ORIGINAL order and gathered through `order` on the device.  `keep_out` (int64, capacity
+ * n) receives original indices in score order, `count_out` (int32, 1 element, device) their
+ * number.  Suppression uses the CUDA comparison IoU > thr.
+ * ------------------------------------------------------------------------------------- */
+size_t r3det_nms_workspace_bytes(int n);
+
+/* rnms_ext.rnms(dets, thr)                             rnms/src/rnms_ext.cpp:11-19
+ * host rnms/src/rcuda/rnms_kernel.cu:270-335.  dets6 (n,6) = [box5, score].  The reference
+ * returns keep sorted ascending; with sort_ascending != 0 keep_out is rewritten in ascending
+ * index order on the device (rnms_kernel.cu:331-334). */
+int r3det_rnms(const float* dets6, const int64_t* order, int n, float thr, int sort_ascending,
+               void* ws, size_t ws_bytes, int64_t* keep_out, int32_t* count_out, void* stream);
+
+/* nms_rotated_ext.nms_rotated(dets, scores, thr)       nms_rotated/src/nms_rotated_ext.cpp:24-35
+ * host nms_rotated/src/nms_rotated_cuda.cu:71-134.  dets5 (n,5). */
+int r3det_nms_rotated(const float* dets5, const int64_t* order, int n, float thr, void* ws,
+                      size_t ws_bytes, int64_t* keep_out, int32_t* count_out, void* stream);
+
+/* ml_nms_rotated_cuda.ml_nms_rotated(dets, scores, labels, thr)
+ *                                                      ml_nms_rotated/src/nms_rotated.h:23-39
+ * host ml_nms_rotated/src/nms_rotated_cuda.cu:74-137.  labels (n,) int64; IoU of boxes with
+ * different labels is 0 (box_iou_rotated_utils.h:316-322). */
+int r3det_ml_nms_rotated(const float* dets5, const int64_t* labels, const int64_t* order, int n,
+                         float thr, void* ws, size_t ws_bytes, int64_t* keep_out,
+                         int32_t* count_out, void* stream);
+
+/* mmcv.ops.nms_rotated(dets, scores, thr, labels)      call site core/post_processing/
+ * bbox_nms_rotated.py:86 (third-party; v2 geometry, optional label column).
+ * labels may be NULL (single-label). */
+int r3det_mmcv_nms_rotated(const float* dets5, const int64_t* labels, const int64_t* order, int n,
+                           float thr, void* ws, size_t ws_bytes, int64_t* keep_out,
+                           int32_t* count_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Feature refinement (rotated feature-align sampler)
+ * ------------------------------------------------------------------------------------- */
+
+/* feature_refine_cuda.forward(features, best_bboxes, spatial_scale, points, output)
+ *                                                      fr/src/feature_refine_cuda.cpp:24-42
+ * kernel fr/src/feature_refine_kernel.cu:112-163.  features/output (N,C,H,W) NCHW,
+ * best_bboxes (N*H*W,5); points in {1,5}.  output is caller-allocated and fully overwritten. */
+int r3det_feature_refine_forward(const float* features, const float* best_bboxes, int N, int C,
+                                 int H, int W, float spatial_scale, int points, float* output,
+                                 void* stream);
+
+/* feature_refine_cuda.backward(top_grad, best_bboxes, spatial_scale, points, bottom_grad)
+ *                                                      fr/src/feature_refine_cuda.cpp:44-66
+ * kernel feature_refine_kernel.cu:165-230.  Accumulates into bottom_grad (the reference caller
+ * zero-fills it, fr/feature_refine_module.py:36).  With overwrite != 0 the library writes the
+ * full gradient instead (no zero-fill needed, no read of bottom_grad). */
+int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxes, int N, int C,
+                                  int H, int W, float spatial_scale, int points,
+                                  float* bottom_grad, int overwrite, void* stream);
+
+/* Kernel-selection knobs for A/B measurements (not part of the reference surface).
+ * r3det_set_option("fr_impl", 0 auto | 1 generic | 2 lds-plane), ("iou_impl", ...). */
+int r3det_set_option(const char* name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R3DET_HIP_H_ */

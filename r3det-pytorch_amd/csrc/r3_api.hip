@@ -1,0 +1,135 @@
+// r3_api.hip -- extern "C" entry points declared in include/r3det_hip.h.
+// Argument validation + dispatch only; kernels live in r3_iou.hip / r3_nms.hip / r3_fr.hip.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/r3det_hip.h"
+#include "r3_kernels.h"
+
+int g_r3_iou_impl = 0;
+int g_r3_nms_impl = 0;
+
+namespace {
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int rc(int k) {
+  switch (k) {
+    case 0: return R3DET_OK;
+    case -1: return R3DET_EINVAL;
+    case -2: return R3DET_ELAUNCH;
+    case -3: return R3DET_EWS;
+    default: return R3DET_EINVAL;
+  }
+}
+inline bool bad_iou_args(const float* b1, int n1, const float* b2, int n2, const float* out) {
+  if (n1 < 0 || n2 < 0) return true;
+  if (n1 > 0 && n2 > 0 && (!b1 || !b2 || !out)) return true;
+  return false;
+}
+}  // namespace
+
+extern "C" {
+
+int r3det_abi_version(void) { return 1; }
+
+const char* r3det_error_string(int code) {
+  switch (code) {
+    case R3DET_OK: return "ok";
+    case R3DET_EINVAL: return "invalid argument";
+    case R3DET_ELAUNCH: return "HIP launch failure";
+    case R3DET_EWS: return "workspace too small";
+    default: return "unknown error";
+  }
+}
+
+int r3det_rbbox_geo_mat_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
+                                float* out, void* stream) {
+  if (bad_iou_args(rb1, n1, rb2, n2, out)) return R3DET_EINVAL;
+  return rc(r3k_iou_mat(R3DET_GEOM_V1, iof != 0, rb1, n1, rb2, n2, out, S(stream)));
+}
+
+int r3det_rbbox_geo_vec_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
+                                float* out, void* stream) {
+  if (bad_iou_args(rb1, n1, rb2, n2, out)) return R3DET_EINVAL;
+  return rc(r3k_iou_vec(R3DET_GEOM_V1, iof != 0, rb1, n1, rb2, n2, out, S(stream)));
+}
+
+int r3det_box_iou_rotated_overlaps(const float* b1, int n1, const float* b2, int n2,
+                                   int iou_or_iof, float* out, void* stream) {
+  if (bad_iou_args(b1, n1, b2, n2, out)) return R3DET_EINVAL;
+  return rc(r3k_iou_mat(R3DET_GEOM_V3, iou_or_iof == 0, b1, n1, b2, n2, out, S(stream)));
+}
+
+int r3det_box_iou_rotated_overlaps_aligned(const float* b1, const float* b2, int n,
+                                           int iou_or_iof, float* out, void* stream) {
+  if (bad_iou_args(b1, n, b2, n, out)) return R3DET_EINVAL;
+  return rc(r3k_iou_vec(R3DET_GEOM_V3, iou_or_iof == 0, b1, n, b2, n, out, S(stream)));
+}
+
+int r3det_mmcv_box_iou_rotated(const float* b1, int n1, const float* b2, int n2, int mode_flag,
+                               int aligned, float* out, void* stream) {
+  if (bad_iou_args(b1, n1, b2, n2, out)) return R3DET_EINVAL;
+  if (mode_flag != 0 && mode_flag != 1) return R3DET_EINVAL;
+  if (aligned) {
+    if (n1 != n2) return R3DET_EINVAL;
+    return rc(r3k_iou_vec(R3DET_GEOM_V2, mode_flag, b1, n1, b2, n2, out, S(stream)));
+  }
+  return rc(r3k_iou_mat(R3DET_GEOM_V2, mode_flag, b1, n1, b2, n2, out, S(stream)));
+}
+
+size_t r3det_nms_workspace_bytes(int n) { return r3k_nms_workspace_bytes(n); }
+
+int r3det_rnms(const float* dets6, const int64_t* order, int n, float thr, int sort_ascending,
+               void* ws, size_t ws_bytes, int64_t* keep_out, int32_t* count_out, void* stream) {
+  return rc(r3k_nms(R3DET_GEOM_V1, dets6, 6, nullptr, order, n, thr, sort_ascending, ws, ws_bytes,
+                    keep_out, count_out, S(stream)));
+}
+
+int r3det_nms_rotated(const float* dets5, const int64_t* order, int n, float thr, void* ws,
+                      size_t ws_bytes, int64_t* keep_out, int32_t* count_out, void* stream) {
+  return rc(r3k_nms(R3DET_GEOM_V3, dets5, 5, nullptr, order, n, thr, 0, ws, ws_bytes, keep_out,
+                    count_out, S(stream)));
+}
+
+int r3det_ml_nms_rotated(const float* dets5, const int64_t* labels, const int64_t* order, int n,
+                         float thr, void* ws, size_t ws_bytes, int64_t* keep_out,
+                         int32_t* count_out, void* stream) {
+  if (n > 0 && !labels) return R3DET_EINVAL;
+  return rc(r3k_nms(R3DET_GEOM_V2, dets5, 5, labels, order, n, thr, 0, ws, ws_bytes, keep_out,
+                    count_out, S(stream)));
+}
+
+int r3det_mmcv_nms_rotated(const float* dets5, const int64_t* labels, const int64_t* order, int n,
+                           float thr, void* ws, size_t ws_bytes, int64_t* keep_out,
+                           int32_t* count_out, void* stream) {
+  return rc(r3k_nms(R3DET_GEOM_V2, dets5, 5, labels, order, n, thr, 0, ws, ws_bytes, keep_out,
+                    count_out, S(stream)));
+}
+
+int r3det_feature_refine_forward(const float* features, const float* best_bboxes, int N, int C,
+                                 int H, int W, float spatial_scale, int points, float* output,
+                                 void* stream) {
+  if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
+  if ((size_t)N * C * H * W > 0 && (!features || !best_bboxes || !output)) return R3DET_EINVAL;
+  return rc(r3k_fr_forward(features, best_bboxes, N, C, H, W, spatial_scale, points, output,
+                           S(stream)));
+}
+
+int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxes, int N, int C,
+                                  int H, int W, float spatial_scale, int points,
+                                  float* bottom_grad, int overwrite, void* stream) {
+  if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
+  if ((size_t)N * C * H * W > 0 && (!top_grad || !best_bboxes || !bottom_grad)) return R3DET_EINVAL;
+  return rc(r3k_fr_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, points, bottom_grad,
+                            overwrite, S(stream)));
+}
+
+int r3det_set_option(const char* name, int value) {
+  if (!name) return R3DET_EINVAL;
+  if (!strcmp(name, "fr_impl")) g_r3_fr_impl = value;
+  else if (!strcmp(name, "iou_impl")) g_r3_iou_impl = value;
+  else if (!strcmp(name, "nms_impl")) g_r3_nms_impl = value;
+  else return R3DET_EINVAL;
+  return R3DET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,28 @@
+// r3_kernels.h -- internal launch functions behind the C ABI (include/r3det_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// return 0 ok, -1 bad argument, -2 launch failure, -3 workspace too small
+int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
+                hipStream_t stream);
+int r3k_iou_vec(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
+                hipStream_t stream);
+
+size_t r3k_nms_workspace_bytes(int n);
+// dets: (n, det_stride) original order; labels: int64 (n,) or null; order: int64 (n,)
+int r3k_nms(int geom, const float* dets, int det_stride, const int64_t* labels,
+            const int64_t* order, int n, float thr, int sort_ascending, void* ws, size_t ws_bytes,
+            int64_t* keep_out, int32_t* count_out, hipStream_t stream);
+
+int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, int W, float scale,
+                   int points, float* out, hipStream_t stream);
+int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W,
+                    float scale, int points, float* bottom_grad, int overwrite,
+                    hipStream_t stream);
+
+// A/B knobs (r3det_set_option)
+extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane
+extern int g_r3_iou_impl;  // 0 auto
+extern int g_r3_nms_impl;  // 0 auto

@@ -1,0 +1,84 @@
+"""ctypes binding of libr3det_hip.so (include/r3det_hip.h).
+
+There is NO fallback: if the library is missing, or a tensor is not a contiguous fp32 HIP
+tensor, the call raises.  PyTorch only supplies device memory and the current stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libr3det_hip.so")
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> argtypes; the list doubles as the export table checked by tests/test_abi.py
+SIGNATURES = {
+    "r3det_rbbox_geo_mat_iou_iof": [_vp, _i, _vp, _i, _i, _vp, _vp],
+    "r3det_rbbox_geo_vec_iou_iof": [_vp, _i, _vp, _i, _i, _vp, _vp],
+    "r3det_box_iou_rotated_overlaps": [_vp, _i, _vp, _i, _i, _vp, _vp],
+    "r3det_box_iou_rotated_overlaps_aligned": [_vp, _vp, _i, _i, _vp, _vp],
+    "r3det_mmcv_box_iou_rotated": [_vp, _i, _vp, _i, _i, _i, _vp, _vp],
+    "r3det_rnms": [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp],
+    "r3det_nms_rotated": [_vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
+    "r3det_ml_nms_rotated": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
+    "r3det_mmcv_nms_rotated": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
+    "r3det_feature_refine_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp],
+    "r3det_feature_refine_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
+    "r3det_set_option": [ctypes.c_char_p, _i],
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950). r3det.ops has no CPU / PyTorch fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _i
+        L.r3det_nms_workspace_bytes.argtypes = [_i]
+        L.r3det_nms_workspace_bytes.restype = _sz
+        L.r3det_error_string.argtypes = [_i]
+        L.r3det_error_string.restype = ctypes.c_char_p
+        L.r3det_abi_version.restype = _i
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what}: {lib().r3det_error_string(code).decode()} ({code})")
+
+
+def need_hip(t, name, dtype=torch.float32):
+    """Mirror of the reference's CHECK_CUDA / CHECK_CONTIGUOUS (e.g. rbbox_geo_cuda.cpp:6-11)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor (HIP device tensor on ROCm)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def set_option(name, value):
+    check(lib().r3det_set_option(name.encode(), int(value)), "r3det_set_option")

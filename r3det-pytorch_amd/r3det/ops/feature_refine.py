@@ -1,0 +1,123 @@
+"""Feature Refinement Module (rotated feature-align sampler).
+
+Host-side mirror of r3det/ops/fr/feature_refine_module.py:13-127 over
+r3det_feature_refine_forward / _backward (include/r3det_hip.h).  Module, parameter and
+state-dict names (``conv_5_1``, ``conv_1_5``, ``conv_1_1``, ``fr``) are the reference's.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _C
+
+
+def fr_forward(features, best_rbboxes, spatial_scale, points, output):
+    """feature_refine_cuda.forward (feature_refine_cuda.cpp:24-42): fills ``output``, returns 1."""
+    f = _C.need_hip(features, "features")
+    b = _C.need_hip(best_rbboxes, "best_bboxes")
+    o = _C.need_hip(output, "output")
+    N, C, H, W = f.shape
+    if b.numel() != N * H * W * 5:
+        raise RuntimeError(f"best_bboxes must hold N*H*W x 5 values, got {tuple(b.shape)}")
+    with torch.cuda.device(f.device):
+        _C.check(_C.lib().r3det_feature_refine_forward(_C.ptr(f), _C.ptr(b), N, C, H, W, float(spatial_scale),
+                                                       int(points), _C.ptr(o), _C.stream()), "fr_forward")
+    return 1
+
+
+def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, overwrite=False):
+    """feature_refine_cuda.backward (feature_refine_cuda.cpp:44-66): accumulates into
+    ``bottom_grad`` (``overwrite=True``: writes it, no zero-fill needed)."""
+    g = _C.need_hip(top_grad, "top_grad")
+    b = _C.need_hip(best_rbboxes, "best_bboxes")
+    o = _C.need_hip(bottom_grad, "bottom_grad")
+    N, C, H, W = g.shape
+    with torch.cuda.device(g.device):
+        _C.check(_C.lib().r3det_feature_refine_backward(_C.ptr(g), _C.ptr(b), N, C, H, W, float(spatial_scale),
+                                                        int(points), _C.ptr(o), int(bool(overwrite)),
+                                                        _C.stream()), "fr_backward")
+    return 1
+
+
+class FeatureRefineFunction(Function):
+    """autograd wrapper (feature_refine_module.py:10-40); no gradient flows to the boxes."""
+
+    @staticmethod
+    def forward(ctx, features, best_rbboxes, spatial_scale, points=1):
+        ctx.spatial_scale = spatial_scale
+        ctx.points = points
+        ctx.save_for_backward(best_rbboxes)
+        assert points in [1, 5]
+        assert features.is_cuda
+        features = features.contiguous()
+        output = torch.empty_like(features)  # the kernel overwrites every element
+        fr_forward(features, best_rbboxes.contiguous(), spatial_scale, points, output)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        best_rbboxes = ctx.saved_tensors[0]
+        assert grad_output.is_cuda
+        grad_input = None
+        if ctx.needs_input_grad[0]:
+            grad_output = grad_output.contiguous()
+            grad_input = torch.empty_like(grad_output)
+            fr_backward(grad_output, best_rbboxes.contiguous(), ctx.spatial_scale, ctx.points, grad_input,
+                        overwrite=True)
+        return grad_input, None, None, None
+
+
+feature_refine = FeatureRefineFunction.apply
+
+
+class FR(nn.Module):
+    """One pyramid level's sampler (feature_refine_module.py:46-63)."""
+
+    def __init__(self, spatial_scale, points=1):
+        super().__init__()
+        self.spatial_scale = float(spatial_scale)
+        self.points = points
+
+    def forward(self, features, best_rbboxes):
+        return feature_refine(features, best_rbboxes, self.spatial_scale, self.points)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}(spatial_scale={self.spatial_scale}, points={self.points})'
+
+
+class FeatureRefineModule(nn.Module):
+    """conv(5x1 o 1x5) + conv1x1 -> FR sampler -> residual, per level
+    (feature_refine_module.py:66-127)."""
+
+    def __init__(self, in_channels, featmap_strides, conv_cfg=None, norm_cfg=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.featmap_strides = featmap_strides
+        self.conv_cfg = conv_cfg
+        self.norm_cfg = norm_cfg
+        self._init_layers()
+
+    def _init_layers(self):
+        c = self.in_channels
+        self.fr = nn.ModuleList([FR(spatial_scale=1 / s) for s in self.featmap_strides])
+        self.conv_5_1 = nn.Conv2d(c, c, kernel_size=(5, 1), stride=1, padding=(2, 0))
+        self.conv_1_5 = nn.Conv2d(c, c, kernel_size=(1, 5), stride=1, padding=(0, 2))
+        self.conv_1_1 = nn.Conv2d(c, c, kernel_size=1)
+
+    def init_weights(self):
+        # mmcv.cnn.normal_init(m, std=0.01): weight ~ N(0, 0.01), bias = 0
+        for m in (self.conv_5_1, self.conv_1_5, self.conv_1_1):
+            nn.init.normal_(m.weight, 0, 0.01)
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, x, best_rbboxes):
+        """x: list of per-level (N,C,H,W); best_rbboxes: list over images of lists over levels
+        of (H*W, 5)."""
+        per_level = [torch.cat(lvl) for lvl in zip(*best_rbboxes)]
+        out = []
+        for feat, boxes, fr in zip(x, per_level, self.fr):
+            mixed = self.conv_5_1(self.conv_1_5(feat)) + self.conv_1_1(feat)
+            out.append(feat + fr(mixed, boxes))
+        return out

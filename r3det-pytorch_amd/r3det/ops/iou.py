@@ -1,0 +1,137 @@
+"""Rotated-box IoU operators.
+
+Host-side mirror of the reference wrappers
+  r3det/ops/rbbox_geo/rbbox_geo.py:4-9                     (rbbox_iou, geometry v1)
+  r3det/ops/box_iou_rotated/box_iou_rotated_wrapper.py:8-64 (obb_overlaps, geometry v3)
+  mmcv.ops.box_iou_rotated (call site rotate_iou2d_calculator.py:156, geometry v2)
+over the C ABI in include/r3det_hip.h.  Same names, argument meaning and error behaviour;
+the arithmetic runs in libr3det_hip.so only.
+"""
+import numpy as np
+import torch
+
+from .. import _C
+
+
+def _as_boxes(t, name):
+    t = _C.need_hip(t, name)
+    if t.dim() != 2 or (t.numel() > 0 and t.size(1) != 5):
+        raise RuntimeError(f"{name} must have shape (n, 5), got {tuple(t.shape)}")
+    return t
+
+
+def rbbox_iou(rb1, rb2, vec=False, iof=False):
+    """IoU (or IoF) of rotated boxes with the v1 vertex/segment geometry.
+
+    ``vec=False`` -> (n1, n2) matrix (mat_iou_iof); ``vec=True`` -> (max(n1, n2),) with modulo
+    broadcast (vec_iou_iof).  Inputs must be contiguous fp32 device tensors, as the
+    reference's CHECK_INPUT demands (rbbox_geo_cuda.cpp:6-18).
+    """
+    rb1, rb2 = _as_boxes(rb1, "rb1"), _as_boxes(rb2, "rb2")
+    n1, n2 = rb1.size(0), rb2.size(0)
+    L = _C.lib()
+    with torch.cuda.device(rb1.device):
+        if vec:
+            out = rb1.new_empty((max(n1, n2),))
+            if n1 and n2:
+                _C.check(L.r3det_rbbox_geo_vec_iou_iof(_C.ptr(rb1), n1, _C.ptr(rb2), n2, int(bool(iof)),
+                                                       _C.ptr(out), _C.stream()), "vec_iou_iof")
+        else:
+            out = rb1.new_empty((n1, n2))
+            if n1 and n2:
+                _C.check(L.r3det_rbbox_geo_mat_iou_iof(_C.ptr(rb1), n1, _C.ptr(rb2), n2, int(bool(iof)),
+                                                       _C.ptr(out), _C.stream()), "mat_iou_iof")
+    return out
+
+
+def box_iou_rotated_v3(b1, b2, iou=True):
+    """box_iou_rotated_ext.overlaps(b1, b2, iou_or_iof) (box_iou_rotated_ext.cpp:17-32)."""
+    b1 = _as_boxes(b1.contiguous(), "boxes1")
+    b2 = _as_boxes(b2.contiguous(), "boxes2")
+    n1, n2 = b1.size(0), b2.size(0)
+    out = b1.new_empty((n1, n2))
+    if n1 and n2:
+        with torch.cuda.device(b1.device):
+            _C.check(_C.lib().r3det_box_iou_rotated_overlaps(_C.ptr(b1), n1, _C.ptr(b2), n2, int(bool(iou)),
+                                                             _C.ptr(out), _C.stream()), "overlaps")
+    return out
+
+
+def box_iou_rotated(bboxes1, bboxes2, mode='iou', aligned=False):
+    """Stand-in for ``mmcv.ops.box_iou_rotated`` (v2 / standard vertex sign).
+
+    mmcv is not part of the reference tree; the geometry follows the in-tree statement of the
+    same convention, ml_nms_rotated/src/box_iou_rotated_utils.h.
+    """
+    assert mode in ['iou', 'iof']
+    b1 = _as_boxes(bboxes1.contiguous(), "bboxes1")
+    b2 = _as_boxes(bboxes2.contiguous(), "bboxes2")
+    n1, n2 = b1.size(0), b2.size(0)
+    if aligned:
+        assert n1 == n2
+        out = b1.new_empty((n1,))
+    else:
+        out = b1.new_empty((n1, n2))
+    if n1 and n2:
+        with torch.cuda.device(b1.device):
+            _C.check(_C.lib().r3det_mmcv_box_iou_rotated(_C.ptr(b1), n1, _C.ptr(b2), n2,
+                                                         0 if mode == 'iou' else 1, int(bool(aligned)),
+                                                         _C.ptr(out), _C.stream()), "box_iou_rotated")
+    return out
+
+
+def _to_device_tensor(a, device_id):
+    dev = torch.device('cuda', torch.cuda.current_device() if device_id is None else device_id)
+    return torch.from_numpy(np.ascontiguousarray(a)).float().to(dev)
+
+
+def obb_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, device_id=None):
+    """Overlaps of oriented boxes, geometry v3 (box_iou_rotated_wrapper.py:8-64).
+
+    Tensor or numpy inputs; numpy goes to ``cuda:device_id`` (current device when None --
+    this build has no CPU path) and comes back as numpy.  Boxes with min(w, h) < 1e-3 get
+    their row / column zeroed after the kernel, as in the reference (:53-60).
+    """
+    assert mode in ['iou', 'iof']
+    assert type(bboxes1) is type(bboxes2)
+    if is_aligned:
+        assert bboxes1.shape[0] == bboxes2.shape[0]
+    if isinstance(bboxes1, torch.Tensor):
+        is_numpy = False
+        b1, b2 = bboxes1, bboxes2
+    elif isinstance(bboxes1, np.ndarray):
+        is_numpy = True
+        b1, b2 = _to_device_tensor(bboxes1, device_id), _to_device_tensor(bboxes2, device_id)
+    else:
+        raise TypeError(f'bboxes must be either a Tensor or numpy array, but got {type(bboxes1)}')
+
+    if b1.numel() == 0 or b2.numel() == 0:
+        rows, cols = b1.size(0), b2.size(0)
+        out = b1.new_zeros(rows, 1) if is_aligned else b1.new_zeros(rows, cols)
+    elif is_aligned:
+        out = aligned_obb_overlaps(b1, b2, mode)
+    else:
+        out = box_iou_rotated_v3(b1, b2, mode == 'iou')
+        small1 = b1[:, 2:4].min(1)[0] < 0.001
+        small2 = b2[:, 2:4].min(1)[0] < 0.001
+        # branch-free form of the reference's `if any(): outputs[inds] = 0` (no host sync)
+        out = out.masked_fill(small1[:, None] | small2[None, :], 0.)
+    return out.cpu().numpy() if is_numpy else out
+
+
+def aligned_obb_overlaps(bboxes1, bboxes2, mode='iou'):
+    """Pairwise (aligned) overlaps, shape (m, 1) like the reference (:67-92).
+
+    The reference builds this case from differentiable torch ops + convex_sort; here the pair
+    list runs through the same v3 kernel arithmetic as the matrix case (forward value only).
+    """
+    C = _C
+    b1 = _as_boxes(bboxes1.contiguous(), "bboxes1")
+    b2 = _as_boxes(bboxes2.contiguous(), "bboxes2")
+    n = b1.size(0)
+    out = b1.new_empty((n,))
+    # aligned v3 == diagonal of the matrix; computed as a vec launch of the v3 geometry
+    with torch.cuda.device(b1.device):
+        C.check(C.lib().r3det_box_iou_rotated_overlaps_aligned(
+            C.ptr(b1), C.ptr(b2), n, int(mode == 'iou'), C.ptr(out), C.stream()), "overlaps_aligned")
+    return out[:, None]

@@ -1,0 +1,120 @@
+"""GPU parity: Feature Refinement forward / backward through the C ABI vs the oracle.
+Forward: bit-exact vs the twin oracle (tolerance bar of north_star is 1e-5).  Backward sums
+floating-point atomics in nondeterministic order => tolerance 1e-5 relative to the gradient
+scale, written below."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import fr_boxes
+from oracle import api as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(params=[1, 2], ids=["generic", "lds-plane"])
+def impl(request):
+    from r3det import _C
+    _C.set_option("fr_impl", request.param)
+    yield request.param
+    _C.set_option("fr_impl", 0)
+
+
+SHAPES = [(2, 8, 16, 16, 8), (1, 5, 7, 13, 16), (2, 3, 128, 128, 8), (1, 40, 32, 32, 32), (3, 2, 1, 1, 128),
+          (1, 2, 8, 8, 128)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("points", [1, 5])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_forward_bit_exact(impl, shape, points, adversarial):
+    from r3det.ops.feature_refine import fr_forward
+    N, C, H, W, stride = shape
+    r = np.random.default_rng(5)
+    feat = r.normal(size=(N, C, H, W)).astype(np.float32)
+    boxes = fr_boxes(N, H, W, stride, 6, adversarial=adversarial)
+    with O.twin():
+        want = O.fr_forward(feat, boxes, 1 / stride, points, threads=8)
+    out = torch.full((N, C, H, W), float('nan'), device='cuda')
+    assert fr_forward(dev(feat), dev(boxes), 1 / stride, points, out) == 1
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("shape", SHAPES[:5])
+@pytest.mark.parametrize("points", [1, 5])
+def test_backward(impl, shape, points):
+    from r3det.ops.feature_refine import fr_backward
+    N, C, H, W, stride = shape
+    r = np.random.default_rng(7)
+    top = r.normal(size=(N, C, H, W)).astype(np.float32)
+    boxes = fr_boxes(N, H, W, stride, 8)
+    with O.twin():
+        want = O.fr_backward(top, boxes, 1 / stride, points)
+    tol = 1e-5 * max(1.0, np.abs(want).max())
+    # reference calling convention: accumulate into a zero-filled buffer
+    g = torch.zeros((N, C, H, W), device='cuda')
+    fr_backward(dev(top), dev(boxes), 1 / stride, points, g)
+    assert np.abs(g.cpu().numpy() - want).max() <= tol
+    # accumulation really accumulates
+    fr_backward(dev(top), dev(boxes), 1 / stride, points, g)
+    assert np.abs(g.cpu().numpy() - 2 * want).max() <= 2 * tol
+    # overwrite mode needs no zero fill
+    g2 = torch.full((N, C, H, W), float('nan'), device='cuda')
+    fr_backward(dev(top), dev(boxes), 1 / stride, points, g2, overwrite=True)
+    assert np.abs(g2.cpu().numpy() - want).max() <= tol
+
+
+def test_plane_too_large_falls_back_to_generic():
+    """200 x 200 planes (160 KB padded) exceed the LDS budget: auto mode must still be right."""
+    from r3det.ops.feature_refine import fr_forward
+    N, C, H, W, stride = 1, 2, 200, 200, 8
+    feat = np.random.default_rng(1).normal(size=(N, C, H, W)).astype(np.float32)
+    boxes = fr_boxes(N, H, W, stride, 2)
+    with O.twin():
+        want = O.fr_forward(feat, boxes, 1 / stride, 1, threads=8)
+    out = torch.empty((N, C, H, W), device='cuda')
+    fr_forward(dev(feat), dev(boxes), 1 / stride, 1, out)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_autograd_and_module_config3_shapes():
+    """R3Det FRM on the 5 pyramid levels of a 1024 x 1024 input, N = 2 (reduced C to keep the
+    CPU oracle in seconds): module output == x + FR(conv mix), gradients flow to x and convs."""
+    from r3det.ops import FeatureRefineModule
+    strides = [8, 16, 32, 64, 128]
+    N, C = 2, 8
+    torch.manual_seed(0)
+    m = FeatureRefineModule(C, strides).cuda()
+    m.init_weights()
+    xs = [torch.randn(N, C, 1024 // s, 1024 // s, device='cuda', requires_grad=True) for s in strides]
+    rois = [[dev(fr_boxes(1, 1024 // s, 1024 // s, s, 10 * i + j)) for j, s in enumerate(strides)]
+            for i in range(N)]
+    outs = m(xs, rois)
+    for lvl, (x, o, s) in enumerate(zip(xs, outs, strides)):
+        mixed = m.conv_5_1(m.conv_1_5(x)) + m.conv_1_1(x)
+        boxes = torch.cat([rois[i][lvl] for i in range(N)]).cpu().numpy()
+        with O.twin():
+            want = O.fr_forward(mixed.detach().cpu().numpy(), boxes, 1 / s, 1, threads=8)
+        assert np.abs((o - x).detach().cpu().numpy() - want).max() <= 1e-5
+    sum(o.square().sum() for o in outs).backward()
+    assert all(x.grad is not None and torch.isfinite(x.grad).all() for x in xs)
+    assert m.conv_1_1.weight.grad.abs().sum() > 0
+
+
+def test_gradcheck_against_oracle_backward():
+    from r3det.ops.feature_refine import feature_refine
+    N, C, H, W, stride = 1, 2, 6, 6, 8
+    r = np.random.default_rng(3)
+    x = dev(r.normal(size=(N, C, H, W)).astype(np.float32)).requires_grad_(True)
+    boxes = fr_boxes(N, H, W, stride, 4)
+    top = r.normal(size=(N, C, H, W)).astype(np.float32)
+    y = feature_refine(x, dev(boxes), 1 / stride, 5)
+    y.backward(dev(top))
+    want = O.fr_backward(top, boxes, 1 / stride, 5)
+    assert np.abs(x.grad.cpu().numpy() - want).max() <= 1e-5 * max(1, np.abs(want).max())
+    with pytest.raises(AssertionError):
+        feature_refine(x, dev(boxes), 1 / stride, 3)  # points must be 1 or 5
