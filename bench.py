@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- r3det custom-op hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one pass of the inference hot path of r3det_r50_fpn_1x (v1) over one batch of
+4 synthetic 1024 x 1024 tiles per GPU (BASELINE.json configs[2]), inputs resident in HBM:
+
+  * Feature-Refinement sampler (FR forward) on the 5 FPN levels, N=4, C=256
+    (r3det/ops/fr, reference feature_refine_kernel.cu:112-163);
+  * per image, multiclass_nms_rotated with the config default nms type 'v1'
+    (score_thr 0.05, iou_thr 0.1, max_per_img 2000) on the refine head's 5344-box pool
+    (bbox_nms_rotated.py:7-131 -> batched_rnms -> rnms);
+  * N > 1: image-parallel, one RCCL all_gather of the padded detections per step.
+
+Rank 0 prints ONE JSON line.  `value` = images/s over all ranks for this hot path (NOT the
+conv backbone: see DESIGN.md "measurement").  `roofline` is for the dominant HBM-bound kernel
+(FR forward, level 0), timed with stream events inside the timed region.  `cpu_baseline` times
+the oracle / oracle/_ref on a bounded sample on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+BATCH = 4
+C = 256
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+NMS_CFG = dict(iou_thr=0.1)  # type absent -> 'v1' (bbox_nms_rotated.py:43)
+SCORE_THR, MAX_PER_IMG = 0.05, 2000
+
+
+def build_workload(device, seed):
+    from r3det import synthetic as syn
+    feats, boxes = syn.fr_pyramid(BATCH, C, seed, device=device)
+    outs = [torch.empty_like(f) for f in feats]
+    pools = [syn.nms_pool(syn.R3DET_POOL, seed * 1000 + i, device=device) for i in range(BATCH)]
+    return dict(feats=feats, boxes=boxes, outs=outs, pools=pools)
+
+
+def hot_path_step(wl, ev=None):
+    from r3det import dist_infer as di
+    from r3det.core.post_processing import multiclass_nms_rotated
+    from r3det.ops.feature_refine import fr_forward
+    from r3det.synthetic import STRIDES
+    for lvl, (f, b, o, s) in enumerate(zip(wl["feats"], wl["boxes"], wl["outs"], STRIDES)):
+        if ev is not None and lvl == 0:
+            ev[0].record()
+        fr_forward(f, b, 1.0 / s, 1, o)
+        if ev is not None and lvl == 0:
+            ev[1].record()
+    dets, labels = [], []
+    for mb, ms in wl["pools"]:
+        d, l = multiclass_nms_rotated(mb, ms, SCORE_THR, NMS_CFG, MAX_PER_IMG)
+        dets.append(d)
+        labels.append(l)
+    packed, counts = di.pack_detections(dets, labels, MAX_PER_IMG)
+    di.gather_detections(packed, counts)
+    return counts
+
+
+def op_rates(device):
+    """Op-level rates quoted by BASELINE.json's metric (Mpairs/s, Mboxes/s), bounded runs."""
+    from r3det import synthetic as syn
+    from r3det.ops import batched_rnms, rbbox_iou
+    out = {}
+
+    def timeit(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+    anchors = syn.anchor_grid(device=device)
+    gt = syn.dota_like_rboxes(128, 5, device=device)
+    dt = timeit(lambda: rbbox_iou(gt, anchors), 20)
+    out["iou_v1_128x196416_Mpairs_s"] = round(128 * anchors.size(0) / dt / 1e6, 1)
+    out["iou_v1_128x196416_GBs"] = round((4 * 128 * anchors.size(0) + 20 * (128 + anchors.size(0))) / dt / 1e9, 1)
+    a, g = syn.rand_rboxes(1000, 0, device=device), syn.rand_rboxes(128, 1, device=device)
+    dt = timeit(lambda: rbbox_iou(a, g), 50)
+    out["iou_v1_1000x128_Mpairs_s"] = round(128000 / dt / 1e6, 1)
+    for n in (2000, 8576):
+        mb, ms = syn.nms_pool(n * 10 // 6, 77 + n, device=device)
+        sc, lab = ms[:, :-1].max(1)
+        idx = torch.nonzero(sc > SCORE_THR).squeeze(1)[:n]
+        b, s, l = mb[idx].contiguous(), sc[idx].contiguous(), lab[idx].contiguous()
+        dt = timeit(lambda: batched_rnms(b, s, l, 0.1), 10)
+        out[f"nms_v1_{b.size(0)}_Mboxes_s"] = round(b.size(0) / dt / 1e6, 3)
+    return out
+
+
+def cpu_baseline():
+    """Hot path of ONE image on the host: FR forward (oracle, OpenMP) + NMS v1 (reference CPU
+    code from oracle/_ref when present, else the oracle)."""
+    import numpy as np
+    from oracle import api as O
+    from r3det import synthetic as syn
+    cores = max(1, len(os.sched_getaffinity(0)))
+    feats, boxes = syn.fr_pyramid(1, C, 1234)
+    mb, ms = syn.nms_pool(syn.R3DET_POOL, 4321)
+    mbn, msn = mb.numpy(), ms.numpy()
+    t0 = time.perf_counter()
+    reps = 0
+    use_ref = O.ref_available()
+    while True:
+        for f, b, s in zip(feats, boxes, syn.STRIDES):
+            O.fr_forward(f.numpy(), b.numpy(), 1.0 / s, 1, threads=cores)
+        sc = msn[:, :-1]
+        valid = sc > SCORE_THR
+        idx = np.argwhere(valid)
+        bx, scv, lab = mbn[idx[:, 0]], sc[valid], idx[:, 1]
+        sh = bx.copy()
+        sh[:, :2] += (lab.astype(np.float32) * (bx.max() + 1))[:, None]
+        if use_ref:
+            O.ref_v1_rnms(np.hstack([sh, scv[:, None]]), 0.1)
+        else:
+            O.nms(O.V1, sh, scv, 0.1, ascending=True)
+        reps += 1
+        if time.perf_counter() - t0 > 12 or reps >= 20:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(1.0 / dt, 3), "unit": "img/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{reps} x (FR forward 5 levels N=1 C=256 on {cores} threads [oracle port; the "
+                      f"reference has no CPU FR] + NMS v1 on a 5344-box pool, 1 thread "
+                      f"[{'reference rnms_cpu via oracle/_ref' if use_ref else 'oracle port'}])"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from r3det import _C
+    from r3det import dist_infer as di
+    _C.lib()  # fail loudly if the HIP library is missing
+    rank, local_rank, world = di.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    di.init(device=device)
+
+    wl = build_workload(device, seed=100 + rank)
+    for _ in range(args.warmup):
+        hot_path_step(wl)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    di.barrier(device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        counts = hot_path_step(wl, evs[k])
+    torch.cuda.synchronize()
+    di.barrier(device)
+    torch.cuda.synchronize()
+    elapsed = di.max_over_ranks(time.perf_counter() - t0, device)
+
+    if rank == 0:
+        fr_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        H = W = 128
+        alg_bytes = 2 * 4 * BATCH * C * H * W + 20 * BATCH * H * W  # 8 B/elem + 20 B/pos
+        achieved = alg_bytes / (fr_ms * 1e-3) / 1e9
+        line = {
+            "metric": "img/s, r3det_r50_fpn_1x v1 inference custom-op hot path (FR sampler x5 levels + "
+                      "multiclass rotated NMS v1), 1024x1024 tiles",
+            "value": round(world * BATCH * args.steps / elapsed, 2),
+            "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: r3det_r50_fpn_1x v1 + FeatureRefineModule, "
+                                   "batch=4 x 1024x1024 per GPU, inference hot path only (no conv backbone)",
+                       "batch_per_gpu": BATCH, "channels": C, "nms_pool": 5344, "nms_type": "v1",
+                       "parallelism": f"image-parallel x{world}, all_gather of detections"},
+            "roofline": {"bound": "hbm", "kernel": "fr_forward_plane<1> (level 0: 4x256x128x128)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(fr_ms * 1e3, 2)},
+            "kept_per_image": [int(c) for c in counts.tolist()],
+        }
+        line["ops"] = op_rates(device)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        di.barrier(device)
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
