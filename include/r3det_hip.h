@@ -45,7 +45,14 @@ const char* r3det_error_string(int code);
 /* rbbox_geo_cuda.mat_iou_iof(rb1, rb2, iof)            rbbox_geo/src/rbbox_geo_cuda.cpp:13-18
  * kernel rbbox_geo/src/rbbox_geo_kernel.cu:231-268.   rb1 (n1,5), rb2 (n2,5) -> out (n1,n2). */
 int r3det_rbbox_geo_mat_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
-                                float* out, void* stream);
+                                float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* Optional scratch for the three (n1,n2) matrix entry points.  With ws == NULL the matrix is
+ * produced by one kernel; with a workspace of at least this many bytes the library runs a
+ * streaming kernel + a load-balanced drain kernel over a global queue of the overlapping
+ * pairs (several times faster on assignment-shaped inputs).  The size is a worst case
+ * (4 bytes per pair); only the part actually used is touched. */
+size_t r3det_iou_workspace_bytes(int n1, int n2);
 
 /* rbbox_geo_cuda.vec_iou_iof(rb1, rb2, iof)            rbbox_geo/src/rbbox_geo_cuda.cpp:19-24
  * kernel rbbox_geo_kernel.cu:271-309.  out (max(n1,n2),), out[i] = f(rb1[i % n1], rb2[i % n2]). */
@@ -56,7 +63,8 @@ int r3det_rbbox_geo_vec_iou_iof(const float* rb1, int n1, const float* rb2, int 
  * kernel box_iou_rotated/src/box_iou_rotated_cuda.cu:14-63.  iou_or_iof != 0 selects IoU,
  * 0 selects IoF (intersection / area of b1).  out (n1,n2). */
 int r3det_box_iou_rotated_overlaps(const float* b1, int n1, const float* b2, int n2,
-                                   int iou_or_iof, float* out, void* stream);
+                                   int iou_or_iof, float* out, void* ws, size_t ws_bytes,
+                                   void* stream);
 
 /* Pairwise companion of the call above: out[i] = overlap(b1[i], b2[i]), i < n.  Serves
  * obb_overlaps(is_aligned=True) (box_iou_rotated_wrapper.py:48-49), whose reference
@@ -69,7 +77,7 @@ int r3det_box_iou_rotated_overlaps_aligned(const float* b1, const float* b2, int
  * ml_nms_rotated/src/box_iou_rotated_utils.h).  mode_flag 0 = iou, 1 = iof.
  * aligned == 0: out (n1,n2); aligned != 0: n1 must equal n2, out (n1,). */
 int r3det_mmcv_box_iou_rotated(const float* b1, int n1, const float* b2, int n2, int mode_flag,
-                               int aligned, float* out, void* stream);
+                               int aligned, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Rotated NMS.  As in mmcv's ext signature the score sort stays with the caller: `order`

@@ -41,10 +41,12 @@ const char* r3det_error_string(int code) {
   }
 }
 
+size_t r3det_iou_workspace_bytes(int n1, int n2) { return r3k_iou_workspace_bytes(n1, n2); }
+
 int r3det_rbbox_geo_mat_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
-                                float* out, void* stream) {
+                                float* out, void* ws, size_t ws_bytes, void* stream) {
   if (bad_iou_args(rb1, n1, rb2, n2, out)) return R3DET_EINVAL;
-  return rc(r3k_iou_mat(R3DET_GEOM_V1, iof != 0, rb1, n1, rb2, n2, out, S(stream)));
+  return rc(r3k_iou_mat(R3DET_GEOM_V1, iof != 0, rb1, n1, rb2, n2, out, ws, ws_bytes, S(stream)));
 }
 
 int r3det_rbbox_geo_vec_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
@@ -54,9 +56,10 @@ int r3det_rbbox_geo_vec_iou_iof(const float* rb1, int n1, const float* rb2, int 
 }
 
 int r3det_box_iou_rotated_overlaps(const float* b1, int n1, const float* b2, int n2,
-                                   int iou_or_iof, float* out, void* stream) {
+                                   int iou_or_iof, float* out, void* ws, size_t ws_bytes,
+                                   void* stream) {
   if (bad_iou_args(b1, n1, b2, n2, out)) return R3DET_EINVAL;
-  return rc(r3k_iou_mat(R3DET_GEOM_V3, iou_or_iof == 0, b1, n1, b2, n2, out, S(stream)));
+  return rc(r3k_iou_mat(R3DET_GEOM_V3, iou_or_iof == 0, b1, n1, b2, n2, out, ws, ws_bytes, S(stream)));
 }
 
 int r3det_box_iou_rotated_overlaps_aligned(const float* b1, const float* b2, int n,
@@ -66,14 +69,14 @@ int r3det_box_iou_rotated_overlaps_aligned(const float* b1, const float* b2, int
 }
 
 int r3det_mmcv_box_iou_rotated(const float* b1, int n1, const float* b2, int n2, int mode_flag,
-                               int aligned, float* out, void* stream) {
+                               int aligned, float* out, void* ws, size_t ws_bytes, void* stream) {
   if (bad_iou_args(b1, n1, b2, n2, out)) return R3DET_EINVAL;
   if (mode_flag != 0 && mode_flag != 1) return R3DET_EINVAL;
   if (aligned) {
     if (n1 != n2) return R3DET_EINVAL;
     return rc(r3k_iou_vec(R3DET_GEOM_V2, mode_flag, b1, n1, b2, n2, out, S(stream)));
   }
-  return rc(r3k_iou_mat(R3DET_GEOM_V2, mode_flag, b1, n1, b2, n2, out, S(stream)));
+  return rc(r3k_iou_mat(R3DET_GEOM_V2, mode_flag, b1, n1, b2, n2, out, ws, ws_bytes, S(stream)));
 }
 
 size_t r3det_nms_workspace_bytes(int n) { return r3k_nms_workspace_bytes(n); }

@@ -160,13 +160,52 @@ __global__ __launch_bounds__(FR_BLOCK) void fr_backward_generic(const float* __r
 }
 
 // ----------------------------------------------------------------------------------------
-// lds-plane kernels: one workgroup owns CPB consecutive (n,c) planes, staged in LDS
+// lds-plane kernels: one workgroup owns CPB consecutive (n,c) planes, staged in LDS.
+// A thread owns QUADS of 4 adjacent positions: its 4 boxes are one contiguous 80-byte read
+// (5 x 16 B), the 4 results one 16-byte store; all global loads of a round are issued before
+// the first use so a wave keeps >= 4 (stage) / 5 (boxes) requests in flight.
 // ----------------------------------------------------------------------------------------
-constexpr int FRP_BLOCK = 512;
+constexpr int FRP_BLOCK = 1024;
 constexpr int FRP_LDS_FLOATS = 17 * 1024;  // 68 KB: 128 x 129 plane (66 KB) fits, 2 WGs / CU
+constexpr int FRP_STAGE_UNROLL = 4;
 
-// forward: stage, then out = plane + taps
-template <int POINTS>
+// global (contiguous nc planes of HW floats) -> LDS planes with row pitch W+1
+template <bool VEC>
+__device__ __forceinline__ void stage_planes(const float* __restrict__ src, float* lds, int nc, int HW,
+                                             int W, int pitch, int psz) {
+  const int total = nc * HW;
+  if (VEC) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    const int total4 = total >> 2;
+    for (int base = threadIdx.x; base < total4; base += FRP_BLOCK * FRP_STAGE_UNROLL) {
+      float4 v[FRP_STAGE_UNROLL];
+#pragma unroll
+      for (int k = 0; k < FRP_STAGE_UNROLL; k++) {
+        int i = base + k * FRP_BLOCK;
+        if (i < total4) v[k] = s4[i];
+      }
+#pragma unroll
+      for (int k = 0; k < FRP_STAGE_UNROLL; k++) {
+        int i = base + k * FRP_BLOCK;
+        if (i < total4) {
+          int e = i << 2;
+          int ch = e / HW, r = e - ch * HW;
+          int y = r / W, x = r - y * W;
+          float* d = lds + ch * psz + y * pitch + x;
+          d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+        }
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < total; e += FRP_BLOCK) {
+      int ch = e / HW, r = e - ch * HW;
+      int y = r / W, x = r - y * W;
+      lds[ch * psz + y * pitch + x] = src[e];
+    }
+  }
+}
+
+template <int POINTS, bool VEC>
 __global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __restrict__ feat,
                                                               const float* __restrict__ boxes,
                                                               int C, int H, int W, float scale,
@@ -180,44 +219,57 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __res
   const int nc = min(cpb, C - c0);
   const float* src = feat + ((size_t)n * C + c0) * HW;
   float* dst = out + ((size_t)n * C + c0) * HW;
-  const int total = nc * HW;
-  // coalesced stage: consecutive threads read consecutive floats (16 B per lane when aligned)
-  if ((HW & 3) == 0 && (W & 3) == 0) {
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-    for (int i = threadIdx.x; i < total / 4; i += FRP_BLOCK) {
-      float4 v = s4[i];
-      int e = i * 4;
-      int ch = e / HW, r = e - ch * HW;
-      int y = r / W, x = r - y * W;
-      float* d = lds + ch * psz + y * pitch + x;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  stage_planes<VEC>(src, lds, nc, HW, W, pitch, psz);
+  __syncthreads();
+  if (VEC) {
+    const float4* bx4 = reinterpret_cast<const float4*>(boxes + (size_t)n * HW * 5);
+    const int quads = HW >> 2;
+    for (int qd = threadIdx.x; qd < quads; qd += FRP_BLOCK) {
+      float bq[20];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        float4 t = bx4[qd * 5 + k];
+        bq[4 * k] = t.x; bq[4 * k + 1] = t.y; bq[4 * k + 2] = t.z; bq[4 * k + 3] = t.w;
+      }
+      const int hw0 = qd << 2;
+      const int y = hw0 / W, x = hw0 - y * W;  // W % 4 == 0: the quad stays in one row
+      const int self = y * pitch + x;
+      Tap taps[4][POINTS];
+#pragma unroll
+      for (int j = 0; j < 4; j++) make_taps<POINTS>(bq + 5 * j, scale, H, W, pitch, taps[j]);
+      for (int ch = 0; ch < nc; ch++) {
+        const float* plane = lds + ch * psz;
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float v = plane[self + j];
+#pragma unroll
+          for (int p = 0; p < POINTS; p++) v += tap_value(taps[j][p], plane);
+          r[j] = v;
+        }
+        *reinterpret_cast<float4*>(dst + (size_t)ch * HW + hw0) = make_float4(r[0], r[1], r[2], r[3]);
+      }
     }
   } else {
-    for (int e = threadIdx.x; e < total; e += FRP_BLOCK) {
-      int ch = e / HW, r = e - ch * HW;
-      int y = r / W, x = r - y * W;
-      lds[ch * psz + y * pitch + x] = src[e];
-    }
-  }
-  __syncthreads();
-  for (int hw = threadIdx.x; hw < HW; hw += FRP_BLOCK) {
-    Tap taps[POINTS];
-    make_taps<POINTS>(boxes + ((size_t)n * HW + hw) * 5, scale, H, W, pitch, taps);
-    const int y = hw / W, x = hw - y * W;
-    const int self = y * pitch + x;
-    for (int ch = 0; ch < nc; ch++) {
-      const float* plane = lds + ch * psz;
-      float v = plane[self];
+    for (int hw = threadIdx.x; hw < HW; hw += FRP_BLOCK) {
+      Tap taps[POINTS];
+      make_taps<POINTS>(boxes + ((size_t)n * HW + hw) * 5, scale, H, W, pitch, taps);
+      const int y = hw / W, x = hw - y * W;
+      const int self = y * pitch + x;
+      for (int ch = 0; ch < nc; ch++) {
+        const float* plane = lds + ch * psz;
+        float v = plane[self];
 #pragma unroll
-      for (int p = 0; p < POINTS; p++) v += tap_value(taps[p], plane);
-      dst[(size_t)ch * HW + hw] = v;
+        for (int p = 0; p < POINTS; p++) v += tap_value(taps[p], plane);
+        dst[(size_t)ch * HW + hw] = v;
+      }
     }
   }
 }
 
 // backward: accumulate the plane's gradient in LDS (ds_add_f32), then one coalesced
 // read-modify-write (or plain write when overwrite) of bottom_grad.
-template <int POINTS>
+template <int POINTS, bool VEC>
 __global__ __launch_bounds__(FRP_BLOCK) void fr_backward_plane(const float* __restrict__ top,
                                                                const float* __restrict__ boxes,
                                                                int C, int H, int W, float scale,
@@ -234,34 +286,88 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_backward_plane(const float* __re
   float* dst = bottom + ((size_t)n * C + c0) * HW;
   for (int i = threadIdx.x; i < nc * psz; i += FRP_BLOCK) lds[i] = 0.f;
   __syncthreads();
-  for (int hw = threadIdx.x; hw < HW; hw += FRP_BLOCK) {
-    Tap taps[POINTS];
-    make_taps<POINTS>(boxes + ((size_t)n * HW + hw) * 5, scale, H, W, pitch, taps);
-    const int y = hw / W, x = hw - y * W;
-    const int self = y * pitch + x;
-    for (int ch = 0; ch < nc; ch++) {
-      float* plane = lds + ch * psz;
-      float g = src[(size_t)ch * HW + hw];
-      atomicAdd(plane + self, g);
+  if (VEC) {
+    const float4* bx4 = reinterpret_cast<const float4*>(boxes + (size_t)n * HW * 5);
+    const int quads = HW >> 2;
+    for (int qd = threadIdx.x; qd < quads; qd += FRP_BLOCK) {
+      float bq[20];
 #pragma unroll
-      for (int p = 0; p < POINTS; p++) {
-        const Tap& t = taps[p];
-        if (t.valid) {
-          atomicAdd(plane + t.o00, g * t.w1);
-          atomicAdd(plane + t.o01, g * t.w2);
-          atomicAdd(plane + t.o10, g * t.w3);
-          atomicAdd(plane + t.o11, g * t.w4);
+      for (int k = 0; k < 5; k++) {
+        float4 t = bx4[qd * 5 + k];
+        bq[4 * k] = t.x; bq[4 * k + 1] = t.y; bq[4 * k + 2] = t.z; bq[4 * k + 3] = t.w;
+      }
+      const int hw0 = qd << 2;
+      const int y = hw0 / W, x = hw0 - y * W;
+      const int self = y * pitch + x;
+      Tap taps[4][POINTS];
+#pragma unroll
+      for (int j = 0; j < 4; j++) make_taps<POINTS>(bq + 5 * j, scale, H, W, pitch, taps[j]);
+      for (int ch = 0; ch < nc; ch++) {
+        float* plane = lds + ch * psz;
+        const float4 g4 = *reinterpret_cast<const float4*>(src + (size_t)ch * HW + hw0);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          atomicAdd(plane + self + j, g[j]);
+#pragma unroll
+          for (int p = 0; p < POINTS; p++) {
+            const Tap& t = taps[j][p];
+            if (t.valid) {
+              atomicAdd(plane + t.o00, g[j] * t.w1);
+              atomicAdd(plane + t.o01, g[j] * t.w2);
+              atomicAdd(plane + t.o10, g[j] * t.w3);
+              atomicAdd(plane + t.o11, g[j] * t.w4);
+            }
+          }
+        }
+      }
+    }
+  } else {
+    for (int hw = threadIdx.x; hw < HW; hw += FRP_BLOCK) {
+      Tap taps[POINTS];
+      make_taps<POINTS>(boxes + ((size_t)n * HW + hw) * 5, scale, H, W, pitch, taps);
+      const int y = hw / W, x = hw - y * W;
+      const int self = y * pitch + x;
+      for (int ch = 0; ch < nc; ch++) {
+        float* plane = lds + ch * psz;
+        float g = src[(size_t)ch * HW + hw];
+        atomicAdd(plane + self, g);
+#pragma unroll
+        for (int p = 0; p < POINTS; p++) {
+          const Tap& t = taps[p];
+          if (t.valid) {
+            atomicAdd(plane + t.o00, g * t.w1);
+            atomicAdd(plane + t.o01, g * t.w2);
+            atomicAdd(plane + t.o10, g * t.w3);
+            atomicAdd(plane + t.o11, g * t.w4);
+          }
         }
       }
     }
   }
   __syncthreads();
   const int total = nc * HW;
-  for (int e = threadIdx.x; e < total; e += FRP_BLOCK) {
-    int ch = e / HW, r = e - ch * HW;
-    int y = r / W, x = r - y * W;
-    float v = lds[ch * psz + y * pitch + x];
-    dst[e] = overwrite ? v : dst[e] + v;
+  if (VEC) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i = threadIdx.x; i < (total >> 2); i += FRP_BLOCK) {
+      int e = i << 2;
+      int ch = e / HW, r = e - ch * HW;
+      int y = r / W, x = r - y * W;
+      const float* p = lds + ch * psz + y * pitch + x;
+      float4 v = make_float4(p[0], p[1], p[2], p[3]);
+      if (!overwrite) {
+        float4 o = d4[i];
+        v.x = o.x + v.x; v.y = o.y + v.y; v.z = o.z + v.z; v.w = o.w + v.w;
+      }
+      d4[i] = v;
+    }
+  } else {
+    for (int e = threadIdx.x; e < total; e += FRP_BLOCK) {
+      int ch = e / HW, r = e - ch * HW;
+      int y = r / W, x = r - y * W;
+      float v = lds[ch * psz + y * pitch + x];
+      dst[e] = overwrite ? v : dst[e] + v;
+    }
   }
 }
 
@@ -272,6 +378,8 @@ inline void allow_big_lds(K kernel) {
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             FRP_LDS_FLOATS * (int)sizeof(float));
 }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 inline int plane_cpb(int C, int H, int W) {
   int psz = H * (W + 1);
@@ -297,12 +405,15 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
     while (cpb > 1 && (size_t)N * ((C + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
     dim3 grid((C + cpb - 1) / cpb, N);
     size_t lds = (size_t)cpb * H * (W + 1) * sizeof(float);
-    static bool once = (allow_big_lds(fr_forward_plane<1>), allow_big_lds(fr_forward_plane<5>), true);
+    static bool once = (allow_big_lds(fr_forward_plane<1, true>), allow_big_lds(fr_forward_plane<1, false>),
+                        allow_big_lds(fr_forward_plane<5, false>), true);
     (void)once;
-    if (points == 1)
-      hipLaunchKernelGGL(fr_forward_plane<1>, grid, dim3(FRP_BLOCK), lds, stream, feat, boxes, C, H, W, scale, cpb, out);
-    else
-      hipLaunchKernelGGL(fr_forward_plane<5>, grid, dim3(FRP_BLOCK), lds, stream, feat, boxes, C, H, W, scale, cpb, out);
+    const bool vec = (W % 4 == 0) && aligned16(feat) && aligned16(boxes) && aligned16(out);
+#define R3_FWD(P, V) hipLaunchKernelGGL((fr_forward_plane<P, V>), grid, dim3(FRP_BLOCK), lds, stream, feat, boxes, C, H, W, scale, cpb, out)
+    // points = 5 keeps 5 taps per position live: the quad form would spill, use the scalar form
+    if (points == 1) { if (vec) R3_FWD(1, true); else R3_FWD(1, false); }
+    else R3_FWD(5, false);
+#undef R3_FWD
   } else {
     int HW = H * W;
     int xb = (HW + FR_BLOCK - 1) / FR_BLOCK;
@@ -331,12 +442,14 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
     while (cpb > 1 && (size_t)N * ((C + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
     dim3 grid((C + cpb - 1) / cpb, N);
     size_t lds = (size_t)cpb * H * (W + 1) * sizeof(float);
-    static bool once = (allow_big_lds(fr_backward_plane<1>), allow_big_lds(fr_backward_plane<5>), true);
+    static bool once = (allow_big_lds(fr_backward_plane<1, true>), allow_big_lds(fr_backward_plane<1, false>),
+                        allow_big_lds(fr_backward_plane<5, false>), true);
     (void)once;
-    if (points == 1)
-      hipLaunchKernelGGL(fr_backward_plane<1>, grid, dim3(FRP_BLOCK), lds, stream, top_grad, boxes, C, H, W, scale, cpb, overwrite, bottom_grad);
-    else
-      hipLaunchKernelGGL(fr_backward_plane<5>, grid, dim3(FRP_BLOCK), lds, stream, top_grad, boxes, C, H, W, scale, cpb, overwrite, bottom_grad);
+    const bool vec = (W % 4 == 0) && aligned16(top_grad) && aligned16(boxes) && aligned16(bottom_grad);
+#define R3_BWD(P, V) hipLaunchKernelGGL((fr_backward_plane<P, V>), grid, dim3(FRP_BLOCK), lds, stream, top_grad, boxes, C, H, W, scale, cpb, overwrite, bottom_grad)
+    if (points == 1) { if (vec) R3_BWD(1, true); else R3_BWD(1, false); }
+    else R3_BWD(5, false);
+#undef R3_BWD
   } else {
     if (overwrite) {
       if (hipMemsetAsync(bottom_grad, 0, (size_t)N * C * H * W * sizeof(float), stream) != hipSuccess)

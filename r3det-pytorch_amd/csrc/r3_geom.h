@@ -20,7 +20,7 @@
 
 #include "r3_trig.h"
 
-#define R3_REC 12  // floats per box record (48 B, three 16-B loads)
+#define R3_REC 16  // floats per box record (64 B, four 16-B loads)
 
 struct Pt {
   float x, y;
@@ -31,9 +31,11 @@ __device__ __forceinline__ Pt subp(Pt a, Pt b) { return Pt{a.x - b.x, a.y - b.y}
 __device__ __forceinline__ Pt addp(Pt a, Pt b) { return Pt{a.x + b.x, a.y + b.y}; }
 
 // Box record.
-//   v1  : f[0..7] = vertices (x0,y0,..,x3,y3)  f[8] = w*h   f[9],f[10] = cx,cy  f[11] = radius
+//   v1  : f[0..7] = vertices (x0,y0,..,x3,y3)  f[8] = w*h
 //   hull: f[0],f[1] = cx,cy  f[2] = sin/2*h  f[3] = cos/2*w  f[4] = cos/2*h  f[5] = sin/2*w
-//         f[6] = w*h  f[7] = label (as float)  f[8] = unused  f[9],f[10] = cx,cy  f[11] = radius
+//         f[6] = w*h  f[7] = label (as float)
+//   both: f[9],f[10] = cx,cy   f[11] = inflated circumscribed radius
+//         f[12],f[13] = inflated half extents of the axis-aligned bounding box
 struct BoxRec {
   float f[R3_REC];
 };
@@ -77,6 +79,21 @@ __device__ __forceinline__ void make_record(const float* __restrict__ b, float l
   r.f[9] = x;
   r.f[10] = y;
   r.f[11] = r3_radius(x, y, w, h);
+  // axis-aligned half extents |c|*w/2 + |s|*h/2, |s|*w/2 + |c|*h/2 with the same inflation
+  float ac = fabsf(c), as = fabsf(s), aw = 0.5f * fabsf(w), ah = 0.5f * fabsf(h);
+  float slack = 2e-6f * (fabsf(x) + fabsf(y)) + 1e-6f;
+  r.f[12] = (ac * aw + as * ah) * 1.001f + slack;
+  r.f[13] = (as * aw + ac * ah) * 1.001f + slack;
+  r.f[14] = 0.f;
+  r.f[15] = 0.f;
+}
+
+// Conservative disjointness test on two records: separated circumscribed circles OR
+// separated axis-aligned bounding boxes (each inflated).  NaN / Inf => false.
+__device__ __forceinline__ bool boxes_apart(const float* A, const float* B) {
+  float dx = A[9] - B[9], dy = A[10] - B[10];
+  float rr = A[11] + B[11];
+  return (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > A[12] + B[12]) | (fabsf(dy) > A[13] + B[13]);
 }
 
 // true when the pair certainly has no candidate intersection point (result exactly 0).

@@ -1,22 +1,33 @@
 // r3_iou.hip -- rotated IoU matrix / vector kernels for gfx950.
 //
 // Matrix kernel (replaces mat_iou_iof_kernel rbbox_geo_kernel.cu:231-268 and
-// box_iou_rotated_cuda_kernel box_iou_rotated_cuda.cu:14-63):
-//   * lane <-> output column, so one wavefront writes 64 consecutive floats of an output
-//     row (the reference maps threadIdx.x to the row and writes with stride n2);
-//   * the row operand is staged once per workgroup as prepared records in LDS (broadcast
-//     reads), the column operand lives in registers as a prepared record;
-//   * per pair: circle test (~10 VALU) -> store 0; only surviving pairs clip.
-// The kernel is HBM-write-bound on assignment-shaped inputs (4 B per pair).
+// box_iou_rotated_cuda_kernel box_iou_rotated_cuda.cu:14-63).
+//
+// Shape of the problem: in anchor assignment (K GT x 196 416 anchors) > 95 % of the pairs are
+// disjoint and the kernel is bound by WRITING 4 bytes per pair; the few overlapping pairs cost
+// ~1000x more ALU each.  A one-thread-per-pair kernel therefore idles 63 lanes of a wavefront
+// whenever one lane clips.  Design:
+//   * tile = 32 rows x 1024 columns per workgroup; lane <-> 4 adjacent columns, so a
+//     wavefront writes 1 KB contiguous per output row with 16-byte stores (the reference maps
+//     threadIdx.x to the ROW and writes with stride n2);
+//   * phase A (streaming): per pair a conservative disjointness test (inflated circumscribed
+//     circles + axis-aligned bounds) -> store 0; surviving pairs are NOT computed in place but
+//     appended to an LDS work queue (wave-aggregated: one LDS atomic per wavefront);
+//   * phase B (compacted): the queue is drained with all 256 lanes busy, one pair per lane,
+//     candidate points in LDS ([slot][lane], conflict-free), result scattered with a 4-byte
+//     store.  Every output element is written exactly once.
+//   * row operand records are staged once per workgroup in LDS (broadcast reads); trig is
+//     evaluated per box, never per pair.
 #include <hip/hip_runtime.h>
 
-#include "r3_geom.h"
+#include "r3_geom_lds.h"
 #include "r3_kernels.h"
 
 namespace {
 
-constexpr int IOU_BLOCK = 256;   // columns per workgroup (4 wavefronts)
-constexpr int IOU_ROWS = 128;    // row records staged in LDS per workgroup (6 KB)
+// ------------------------------------------------------------------ v1 kernel (simple, kept for A/B)
+constexpr int IOU_BLOCK = 256;
+constexpr int IOU_ROWS = 128;
 
 template <int GEOM>
 __global__ __launch_bounds__(IOU_BLOCK) void iou_mat_kernel(const float* __restrict__ b1, int n1,
@@ -26,7 +37,6 @@ __global__ __launch_bounds__(IOU_BLOCK) void iou_mat_kernel(const float* __restr
   const int col = blockIdx.x * IOU_BLOCK + threadIdx.x;
   const int row0 = blockIdx.y * IOU_ROWS;
   const int nrows = min(IOU_ROWS, n1 - row0);
-
   for (int r = threadIdx.x; r < nrows; r += IOU_BLOCK) {
     BoxRec rec;
     make_record<GEOM>(b1 + (size_t)(row0 + r) * 5, 0.f, rec);
@@ -36,7 +46,6 @@ __global__ __launch_bounds__(IOU_BLOCK) void iou_mat_kernel(const float* __restr
   if (col < n2) make_record<GEOM>(b2 + (size_t)col * 5, 0.f, mine);
   __syncthreads();
   if (col >= n2) return;
-
   float* o = out + (size_t)row0 * n2 + col;
   for (int r = 0; r < nrows; r++) {
     const BoxRec& A = rows[r];
@@ -53,33 +62,330 @@ __global__ __launch_bounds__(IOU_BLOCK) void iou_mat_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------ compacted kernel
+constexpr int T_THREADS = 256;
+constexpr int T_CPT = 4;                       // columns per thread
+constexpr int T_COLS = T_THREADS * T_CPT;      // 1024
+constexpr int T_ROWS = 32;                     // rows per workgroup
+constexpr int T_SUB = 8;                       // rows per phase-A/phase-B round
+constexpr int T_QCAP = T_SUB * T_COLS;         // 8192 entries: a round can never overflow
+
+template <int GEOM, bool VEC>
+__global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float* __restrict__ b1, int n1,
+                                                                    const float* __restrict__ b2, int n2,
+                                                                    int iof, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float rows[T_ROWS][R3_REC];
+  __shared__ unsigned short queue[T_QCAP];
+  __shared__ int qcount[2];
+  __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int colbase = blockIdx.x * T_COLS;
+  const int col0 = colbase + tid * T_CPT;
+  const int row0 = blockIdx.y * T_ROWS;
+  const int nrows = min(T_ROWS, n1 - row0);
+
+  if (tid < nrows) {
+    BoxRec rec;
+    make_record<GEOM>(b1 + (size_t)(row0 + tid) * 5, 0.f, rec);
+#pragma unroll
+    for (int k = 0; k < R3_REC; k++) rows[tid][k] = rec.f[k];
+  }
+  if (tid < 2) qcount[tid] = 0;
+
+  // reject data of my 4 columns (cx, cy, radius, aabb half extents)
+  float cq[T_CPT][5];
+  bool cvalid[T_CPT];
+#pragma unroll
+  for (int c = 0; c < T_CPT; c++) {
+    cvalid[c] = (col0 + c) < n2;
+    if (cvalid[c]) {
+      const float* b = b2 + (size_t)(col0 + c) * 5;
+      float x = b[0], y = b[1], w = b[2], h = b[3], a = b[4];
+      float s, co;
+      r3_sincos(a, s, co);
+      float ac = fabsf(co), as = fabsf(s), aw = 0.5f * fabsf(w), ah = 0.5f * fabsf(h);
+      float slack = 2e-6f * (fabsf(x) + fabsf(y)) + 1e-6f;
+      cq[c][0] = x;
+      cq[c][1] = y;
+      cq[c][2] = r3_radius(x, y, w, h);
+      cq[c][3] = (ac * aw + as * ah) * 1.001f + slack;
+      cq[c][4] = (as * aw + ac * ah) * 1.001f + slack;
+    } else {
+      cq[c][0] = cq[c][1] = cq[c][2] = cq[c][3] = cq[c][4] = 0.f;
+    }
+  }
+  const bool all_valid = cvalid[T_CPT - 1];
+  __syncthreads();
+
+  const LanePts<T_THREADS> lp{pts + tid};
+  for (int sub = 0; sub * T_SUB < nrows; sub++) {
+    const int rbase = sub * T_SUB;
+    const int rcount = min(T_SUB, nrows - rbase);
+    int* qc = &qcount[sub & 1];
+    // ---------------- phase A: stream zeros, enqueue survivors
+    for (int r = 0; r < rcount; r++) {
+      const float* A = rows[rbase + r];
+      const float ax = A[9], ay = A[10], ar = A[11], aex = A[12], aey = A[13];
+      bool pend[T_CPT];
+      bool any = false;
+#pragma unroll
+      for (int c = 0; c < T_CPT; c++) {
+        float dx = ax - cq[c][0], dy = ay - cq[c][1];
+        float rr = ar + cq[c][2];
+        bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + cq[c][3]) |
+                     (fabsf(dy) > aey + cq[c][4]);
+        pend[c] = cvalid[c] && !apart;
+        any |= pend[c];
+      }
+      float* o = out + (size_t)(row0 + rbase + r) * n2 + col0;
+      if (VEC && all_valid && !any) {
+        *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+#pragma unroll
+        for (int c = 0; c < T_CPT; c++)
+          if (cvalid[c] && !pend[c]) o[c] = 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < T_CPT; c++) {
+        unsigned long long m = __ballot(pend[c]);
+        if (m) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(qc, __popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (pend[c]) {
+            int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+            queue[slot] = (unsigned short)((r << 10) | (tid * T_CPT + c));
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---------------- phase B: drain the queue, one pair per lane
+    const int total = *qc;
+    if (tid == 0) qcount[(sub + 1) & 1] = 0;
+    for (int q = tid; q < total; q += T_THREADS) {
+      const unsigned e = queue[q];
+      const int r = e >> 10;
+      const int col = colbase + (int)(e & 1023u);
+      BoxRec Bc;
+      make_record<GEOM>(b2 + (size_t)col * 5, 0.f, Bc);
+      const float v = pair_slow_lds<GEOM, T_THREADS>(rows[rbase + r], Bc.f, iof != 0, lp);
+      out[(size_t)(row0 + rbase + r) * n2 + col] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ global-queue pipeline
+// The compacted kernel above balances lanes inside a workgroup, but pairs that survive the
+// disjointness test are clustered (all 576 coarse-level anchors overlap every GT), so a few
+// workgroups own most of the clipping and set the kernel's duration.  With a caller-provided
+// workspace the work is split in two launches:
+//   stream : phase A only -- zeros are streamed out, survivors go to a per-workgroup LDS
+//            queue that is flushed to ONE global queue (one global atomic per workgroup);
+//            workgroup row 0 / column 0 also publish the prepared box records;
+//   drain  : a grid-stride loop over the global queue, one pair per lane, perfectly
+//            balanced over the chip.
+constexpr int S_ROWS = 16;
+constexpr int S_QCAP = S_ROWS * T_COLS;  // 16384 entries (u16): a tile can never overflow
+
+template <int GEOM, bool VEC>
+__global__ __launch_bounds__(T_THREADS) void iou_stream_kernel(const float* __restrict__ b1, int n1,
+                                                               const float* __restrict__ b2, int n2,
+                                                               float* __restrict__ out,
+                                                               BoxRec* __restrict__ recsA,
+                                                               BoxRec* __restrict__ recsB,
+                                                               unsigned* __restrict__ gqueue,
+                                                               unsigned* __restrict__ counter) {
+  __shared__ __attribute__((aligned(16))) float rows[S_ROWS][8];  // cx, cy, rad, ex, ey
+  __shared__ unsigned short queue[S_QCAP];
+  __shared__ int qcount;
+  __shared__ unsigned qbase;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int colbase = blockIdx.x * T_COLS;
+  const int col0 = colbase + tid * T_CPT;
+  const int row0 = blockIdx.y * S_ROWS;
+  const int nrows = min(S_ROWS, n1 - row0);
+
+  if (tid < nrows) {
+    BoxRec rec;
+    make_record<GEOM>(b1 + (size_t)(row0 + tid) * 5, 0.f, rec);
+#pragma unroll
+    for (int k = 0; k < 5; k++) rows[tid][k] = rec.f[9 + k];
+    if (blockIdx.x == 0) recsA[row0 + tid] = rec;
+  }
+  if (tid == 0) qcount = 0;
+
+  float cq[T_CPT][5];
+  bool cvalid[T_CPT];
+#pragma unroll
+  for (int c = 0; c < T_CPT; c++) {
+    cvalid[c] = (col0 + c) < n2;
+    if (cvalid[c]) {
+      BoxRec rec;
+      make_record<GEOM>(b2 + (size_t)(col0 + c) * 5, 0.f, rec);
+#pragma unroll
+      for (int k = 0; k < 5; k++) cq[c][k] = rec.f[9 + k];
+      if (blockIdx.y == 0) recsB[col0 + c] = rec;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) cq[c][k] = 0.f;
+    }
+  }
+  const bool all_valid = cvalid[T_CPT - 1];
+  __syncthreads();
+
+  for (int r = 0; r < nrows; r++) {
+    const float* A = rows[r];
+    const float ax = A[0], ay = A[1], ar = A[2], aex = A[3], aey = A[4];
+    bool pend[T_CPT];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < T_CPT; c++) {
+      float dx = ax - cq[c][0], dy = ay - cq[c][1];
+      float rr = ar + cq[c][2];
+      bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + cq[c][3]) |
+                   (fabsf(dy) > aey + cq[c][4]);
+      pend[c] = cvalid[c] && !apart;
+      any |= pend[c];
+    }
+    float* o = out + (size_t)(row0 + r) * n2 + col0;
+    if (VEC && all_valid && !any) {
+      *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int c = 0; c < T_CPT; c++)
+        if (cvalid[c] && !pend[c]) o[c] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < T_CPT; c++) {
+      unsigned long long m = __ballot(pend[c]);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&qcount, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (pend[c]) {
+          int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+          queue[slot] = (unsigned short)((r << 10) | (tid * T_CPT + c));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int total = qcount;
+  if (total == 0) return;
+  if (tid == 0) qbase = atomicAdd(counter, (unsigned)total);
+  __syncthreads();
+  const unsigned base = qbase;
+  for (int q = tid; q < total; q += T_THREADS) {
+    const unsigned e = queue[q];
+    gqueue[base + q] = (unsigned)(row0 + (e >> 10)) * (unsigned)n2 + (unsigned)(colbase + (e & 1023u));
+  }
+}
+
+template <int GEOM>
+__global__ __launch_bounds__(T_THREADS) void iou_drain_kernel(const BoxRec* __restrict__ recsA,
+                                                              const BoxRec* __restrict__ recsB, int n2,
+                                                              int iof, const unsigned* __restrict__ gqueue,
+                                                              const unsigned* __restrict__ counter,
+                                                              float* __restrict__ out) {
+  __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
+  const LanePts<T_THREADS> lp{pts + threadIdx.x};
+  const unsigned total = *counter;
+  for (unsigned q = blockIdx.x * T_THREADS + threadIdx.x; q < total; q += gridDim.x * T_THREADS) {
+    const unsigned e = gqueue[q];
+    const unsigned r = e / (unsigned)n2;
+    const unsigned c = e - r * (unsigned)n2;
+    const BoxRec A = recsA[r];
+    const BoxRec B = recsB[c];
+    out[e] = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, iof != 0, lp);
+  }
+}
+
 // vec_iou_iof_kernel (rbbox_geo_kernel.cu:271-309): out[i] = f(b1[i % n1], b2[i % n2]).
 template <int GEOM>
 __global__ __launch_bounds__(256) void iou_vec_kernel(const float* __restrict__ b1, int n1,
                                                       const float* __restrict__ b2, int n2,
                                                       int iof, float* __restrict__ out) {
+  __shared__ float2 pts[pts_slots<GEOM>() * 256];
+  const LanePts<256> lp{pts + threadIdx.x};
   const int n = max(n1, n2);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
     BoxRec A, B;
     make_record<GEOM>(b1 + (size_t)(i % n1) * 5, 0.f, A);
     make_record<GEOM>(b2 + (size_t)(i % n2) * 5, 0.f, B);
-    out[i] = pair_iou<GEOM, false>(A, B, iof != 0);
+    float v = 0.f;
+    if (!boxes_apart(A.f, B.f)) v = pair_slow_lds<GEOM, 256>(A.f, B.f, iof != 0, lp);
+    out[i] = v;
   }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <int GEOM>
+int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float* out, void* ws,
+               size_t ws_bytes, hipStream_t stream) {
+  const bool vec = (n2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  if (g_r3_iou_impl == 1) {
+    dim3 grid((n2 + IOU_BLOCK - 1) / IOU_BLOCK, (n1 + IOU_ROWS - 1) / IOU_ROWS);
+    hipLaunchKernelGGL(iou_mat_kernel<GEOM>, grid, dim3(IOU_BLOCK), 0, stream, b1, n1, b2, n2, iof, out);
+    return 0;
+  }
+  const bool fits32 = (unsigned long long)n1 * (unsigned long long)n2 < 0xffffffffULL;
+  const bool queued = ws && fits32 && ws_bytes >= r3k_iou_workspace_bytes(n1, n2) && g_r3_iou_impl != 2;
+  if (!queued) {
+    dim3 grid((n2 + T_COLS - 1) / T_COLS, (n1 + T_ROWS - 1) / T_ROWS);
+    if (vec)
+      hipLaunchKernelGGL((iou_mat_compact_kernel<GEOM, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, out);
+    else
+      hipLaunchKernelGGL((iou_mat_compact_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, out);
+    return 0;
+  }
+  char* p = (char*)ws;
+  unsigned* counter = (unsigned*)p;
+  p += 256;
+  BoxRec* recsA = (BoxRec*)p;
+  p += align256((size_t)n1 * sizeof(BoxRec));
+  BoxRec* recsB = (BoxRec*)p;
+  p += align256((size_t)n2 * sizeof(BoxRec));
+  unsigned* gqueue = (unsigned*)p;
+  if (hipMemsetAsync(counter, 0, sizeof(unsigned), stream) != hipSuccess) return -2;
+  dim3 grid((n2 + T_COLS - 1) / T_COLS, (n1 + S_ROWS - 1) / S_ROWS);
+  if (vec)
+    hipLaunchKernelGGL((iou_stream_kernel<GEOM, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, recsA, recsB, gqueue, counter);
+  else
+    hipLaunchKernelGGL((iou_stream_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, recsA, recsB, gqueue, counter);
+  // drain: enough workgroups to fill the chip at the kernel's occupancy; grid-stride inside
+  unsigned long long pairs = (unsigned long long)n1 * n2;
+  int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(iou_drain_kernel<GEOM>, dim3(blocks), dim3(T_THREADS), 0, stream, recsA, recsB, n2, iof, gqueue, counter, out);
+  return 0;
 }
 
 }  // namespace
 
+size_t r3k_iou_workspace_bytes(int n1, int n2) {
+  if (n1 <= 0 || n2 <= 0) return 256;
+  return 256 + ((size_t)n1 * sizeof(BoxRec) + 255) / 256 * 256 + ((size_t)n2 * sizeof(BoxRec) + 255) / 256 * 256 +
+         (size_t)n1 * (size_t)n2 * sizeof(unsigned) + 256;
+}
+
 int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
-                hipStream_t stream) {
+                void* ws, size_t ws_bytes, hipStream_t stream) {
   if (n1 == 0 || n2 == 0) return 0;
-  dim3 grid((n2 + IOU_BLOCK - 1) / IOU_BLOCK, (n1 + IOU_ROWS - 1) / IOU_ROWS);
-  dim3 block(IOU_BLOCK);
+  int rc;
   switch (geom) {
-    case 1: hipLaunchKernelGGL(iou_mat_kernel<1>, grid, block, 0, stream, b1, n1, b2, n2, iof, out); break;
-    case 2: hipLaunchKernelGGL(iou_mat_kernel<2>, grid, block, 0, stream, b1, n1, b2, n2, iof, out); break;
-    case 3: hipLaunchKernelGGL(iou_mat_kernel<3>, grid, block, 0, stream, b1, n1, b2, n2, iof, out); break;
+    case 1: rc = launch_mat<1>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream); break;
+    case 2: rc = launch_mat<2>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream); break;
+    case 3: rc = launch_mat<3>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream); break;
     default: return -1;
   }
+  if (rc) return rc;
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -15,11 +15,11 @@ _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_
 
 # name -> argtypes; the list doubles as the export table checked by tests/test_abi.py
 SIGNATURES = {
-    "r3det_rbbox_geo_mat_iou_iof": [_vp, _i, _vp, _i, _i, _vp, _vp],
+    "r3det_rbbox_geo_mat_iou_iof": [_vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp],
     "r3det_rbbox_geo_vec_iou_iof": [_vp, _i, _vp, _i, _i, _vp, _vp],
-    "r3det_box_iou_rotated_overlaps": [_vp, _i, _vp, _i, _i, _vp, _vp],
+    "r3det_box_iou_rotated_overlaps": [_vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp],
     "r3det_box_iou_rotated_overlaps_aligned": [_vp, _vp, _i, _i, _vp, _vp],
-    "r3det_mmcv_box_iou_rotated": [_vp, _i, _vp, _i, _i, _i, _vp, _vp],
+    "r3det_mmcv_box_iou_rotated": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp],
     "r3det_rnms": [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp],
     "r3det_nms_rotated": [_vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
     "r3det_ml_nms_rotated": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
@@ -47,6 +47,8 @@ def lib():
             fn.restype = _i
         L.r3det_nms_workspace_bytes.argtypes = [_i]
         L.r3det_nms_workspace_bytes.restype = _sz
+        L.r3det_iou_workspace_bytes.argtypes = [_i, _i]
+        L.r3det_iou_workspace_bytes.restype = _sz
         L.r3det_error_string.argtypes = [_i]
         L.r3det_error_string.restype = ctypes.c_char_p
         L.r3det_abi_version.restype = _i
@@ -78,6 +80,13 @@ def ptr(t):
 
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def iou_workspace(n1, n2, device):
+    """Scratch for the stream + drain IoU pipeline (worst-case sized, mostly untouched; the
+    caching allocator makes the per-call allocation free)."""
+    nbytes = int(lib().r3det_iou_workspace_bytes(n1, n2))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
 def set_option(name, value):

@@ -39,8 +39,9 @@ def rbbox_iou(rb1, rb2, vec=False, iof=False):
         else:
             out = rb1.new_empty((n1, n2))
             if n1 and n2:
+                ws, wsb = _C.iou_workspace(n1, n2, rb1.device)
                 _C.check(L.r3det_rbbox_geo_mat_iou_iof(_C.ptr(rb1), n1, _C.ptr(rb2), n2, int(bool(iof)),
-                                                       _C.ptr(out), _C.stream()), "mat_iou_iof")
+                                                       _C.ptr(out), _C.ptr(ws), wsb, _C.stream()), "mat_iou_iof")
     return out
 
 
@@ -52,8 +53,9 @@ def box_iou_rotated_v3(b1, b2, iou=True):
     out = b1.new_empty((n1, n2))
     if n1 and n2:
         with torch.cuda.device(b1.device):
+            ws, wsb = _C.iou_workspace(n1, n2, b1.device)
             _C.check(_C.lib().r3det_box_iou_rotated_overlaps(_C.ptr(b1), n1, _C.ptr(b2), n2, int(bool(iou)),
-                                                             _C.ptr(out), _C.stream()), "overlaps")
+                                                             _C.ptr(out), _C.ptr(ws), wsb, _C.stream()), "overlaps")
     return out
 
 
@@ -74,9 +76,11 @@ def box_iou_rotated(bboxes1, bboxes2, mode='iou', aligned=False):
         out = b1.new_empty((n1, n2))
     if n1 and n2:
         with torch.cuda.device(b1.device):
+            ws, wsb = (None, 0) if aligned else _C.iou_workspace(n1, n2, b1.device)
             _C.check(_C.lib().r3det_mmcv_box_iou_rotated(_C.ptr(b1), n1, _C.ptr(b2), n2,
                                                          0 if mode == 'iou' else 1, int(bool(aligned)),
-                                                         _C.ptr(out), _C.stream()), "box_iou_rotated")
+                                                         _C.ptr(out), _C.ptr(ws) if ws is not None else None, wsb,
+                                                         _C.stream()), "box_iou_rotated")
     return out
 
 

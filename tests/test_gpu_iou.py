@@ -34,9 +34,19 @@ def same(a, b):
     return np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["queue", "simple", "compact"])
+def iou_impl(request):
+    """0 = stream + drain over a global queue (default), 1 = one thread per pair, 2 = single
+    kernel with an in-workgroup queue (the no-workspace path)."""
+    from r3det import _C
+    _C.set_option("iou_impl", request.param)
+    yield request.param
+    _C.set_option("iou_impl", 0)
+
+
 @pytest.mark.parametrize("geom", [O.V1, O.V2, O.V3])
 @pytest.mark.parametrize("iof", [False, True])
-def test_mat_bit_exact_vs_twin_dense(geom, iof):
+def test_mat_bit_exact_vs_twin_dense(geom, iof, iou_impl):
     a = rand_boxes(700, 11, span=220.0, amin=-np.pi, amax=np.pi)
     b = rand_boxes(333, 12, span=220.0)
     with O.twin():
@@ -76,6 +86,18 @@ def test_mat_degenerate(geom):
         # boxes 30/31 carry |theta| = 7 / 100 rad: still inside the trig twin's accurate range
         assert np.abs(got[ok] - ref[ok]).max() <= TOL
         assert same(np.isnan(got[ref != -2.0]), np.isnan(ref[ref != -2.0]))
+
+
+def test_odd_shapes_and_unaligned(iou_impl):
+    """n2 not a multiple of 4 (scalar-store path), single row / column, > 1 column tile."""
+    for (m, n) in [(1, 1), (3, 1027), (37, 2051), (130, 5)]:
+        a, b = rand_boxes(m, 51 + m, span=90.0), rand_boxes(n, 52 + n, span=90.0)
+        with O.twin():
+            want = O.iou_mat(O.V1, a, b, threads=8)
+        assert same(run(O.V1, a, b), want), (m, n)
+        with O.twin():
+            want = O.iou_mat(O.V3, a, b, threads=8)
+        assert same(run(O.V3, a, b), want), (m, n)
 
 
 def test_assignment_shape_full_size():
