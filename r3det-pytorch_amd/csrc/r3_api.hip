@@ -8,6 +8,7 @@
 
 int g_r3_iou_impl = 0;
 int g_r3_nms_impl = 0;
+int g_r3_nms_qcap = 0;
 
 namespace {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -131,6 +132,7 @@ int r3det_set_option(const char* name, int value) {
   if (!strcmp(name, "fr_impl")) g_r3_fr_impl = value;
   else if (!strcmp(name, "iou_impl")) g_r3_iou_impl = value;
   else if (!strcmp(name, "nms_impl")) g_r3_nms_impl = value;
+  else if (!strcmp(name, "nms_qcap")) g_r3_nms_qcap = value;
   else return R3DET_EINVAL;
   return R3DET_OK;
 }

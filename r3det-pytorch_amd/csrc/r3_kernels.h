@@ -27,4 +27,5 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
 // A/B knobs (r3det_set_option)
 extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane
 extern int g_r3_iou_impl;  // 0 auto
-extern int g_r3_nms_impl;  // 0 auto
+extern int g_r3_nms_impl;  // 0 auto (queue pipeline), 1 tile kernels
+extern int g_r3_nms_qcap;  // 0 default; > 0 caps the global pair queue (tests the overflow path)

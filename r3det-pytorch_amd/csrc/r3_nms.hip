@@ -3,19 +3,30 @@
 //
 // Replaces nmsr_kernel + host scan (rnms/src/rcuda/rnms_kernel.cu:229-335),
 // nms_rotated_cuda_kernel + host scan (nms_rotated/src/nms_rotated_cuda.cu:13-134) and the
-// ml variant (ml_nms_rotated/src/nms_rotated_cuda.cu:14-137).  Differences by design:
-//   * boxes are gathered through `order` and turned into prepared records once (trig per
-//     box, not per pair);
-//   * only tiles with col_block >= row_block are computed (the reference computes both
-//     triangles, nms_rotated_cuda.cu:23);
-//   * the n x ceil(n/64) bitmask never leaves the device: one workgroup walks the rows in
-//     score order (wave 0 resolves a 64-row block on its diagonal word with scalar ops, the
-//     other waves OR the surviving rows into the running `removed` words held in LDS) and
-//     emits the keep list and its length.  The reference copies the whole mask to the host
-//     (9.2 MB at n = 8576) and scans it there.
+// ml variant (ml_nms_rotated/src/nms_rotated_cuda.cu:14-137).  Pipeline (all on one stream,
+// nothing but the keep count ever crosses PCIe):
+//
+//   prepare : gather boxes through `order`, one prepared record per box (trig per box);
+//   stream  : every 64x64 tile with col_block >= row_block (the reference computes both
+//             triangles, nms_rotated_cuda.cu:23) runs only the conservative disjointness
+//             test (labels, circles, axis-aligned bounds); surviving pairs go to an LDS
+//             queue and from there to one global queue;
+//   drain   : the global queue is clipped one pair per lane, chip-wide balanced; IoU > thr
+//             sets bit j of mask[i][j/64] (atomicOr) and flags the word in a per-row
+//             "non-zero word" bitmap nz[i];
+//   reduce  : ONE workgroup walks the rows in score order.  Wave 0 resolves a 64-row block on
+//             its diagonal word with scalar ops; the other lanes OR only the NON-ZERO words of
+//             the surviving rows (found through nz) into the running `removed` words in LDS;
+//             the next block's words are prefetched speculatively one block ahead.  Emits the
+//             keep list and its length.  The reference copies the whole n x n/64 mask to the
+//             host (9.2 MB at n = 8576) and scans it there.
+//   ascending (v1 only): rnms returns keep sorted by index (rnms_kernel.cu:331-334).
+//
+// The original tile kernel (mask computed in place, dense reduction) is kept as impl 1: it
+// serves thr < 0, n >= 65536 and the A/B measurements.
 #include <hip/hip_runtime.h>
 
-#include "r3_geom.h"
+#include "r3_geom_lds.h"
 #include "r3_kernels.h"
 
 namespace {
@@ -23,7 +34,8 @@ namespace {
 typedef unsigned long long u64;
 
 constexpr int TILE = 64;        // one wavefront = one 64-wide bitmask word
-constexpr int MASK_WAVES = 4;   // tiles per workgroup of the mask kernel
+constexpr int MASK_WAVES = 4;   // tiles per workgroup of the tile kernels
+constexpr int NT = TILE * MASK_WAVES;
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -32,8 +44,10 @@ __global__ __launch_bounds__(256) void nms_prepare_kernel(const float* __restric
                                                           int det_stride,
                                                           const int64_t* __restrict__ labels,
                                                           const int64_t* __restrict__ order, int n,
-                                                          BoxRec* __restrict__ recs) {
+                                                          BoxRec* __restrict__ recs,
+                                                          unsigned* __restrict__ counter) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && counter) *counter = 0;
   if (i >= n) return;
   int64_t src = order[i];
   float lab = labels ? (float)labels[src] : 0.f;  // at::cat({dets, labels}) promotes to float
@@ -42,11 +56,11 @@ __global__ __launch_bounds__(256) void nms_prepare_kernel(const float* __restric
   recs[i] = r;
 }
 
+// ---------------------------------------------------------------------------- impl 1 (tiles)
 // mask[row * cb + c] bit i  <=>  IoU(box_row, box_{64c+i}) > thr, for c >= row / 64.
 template <int GEOM, bool LABEL>
-__global__ __launch_bounds__(TILE* MASK_WAVES) void nms_mask_kernel(const BoxRec* __restrict__ recs,
-                                                                    int n, int cb, float thr,
-                                                                    u64* __restrict__ mask) {
+__global__ __launch_bounds__(NT) void nms_mask_kernel(const BoxRec* __restrict__ recs, int n, int cb,
+                                                      float thr, u64* __restrict__ mask) {
   __shared__ BoxRec cols[MASK_WAVES][TILE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rb = blockIdx.y;
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(TILE* MASK_WAVES) void nms_mask_kernel(const BoxRec
   BoxRec A = recs[row];
   u64 t = 0;
   int start = (rb == cblk) ? lane + 1 : 0;
-  // thr < 0 would make IoU == 0 suppress; the circle shortcut is only valid for thr >= 0
+  // thr < 0 would make IoU == 0 suppress; the disjointness shortcut is only valid for thr >= 0
   const bool shortcut = thr >= 0.f;
   for (int i = start; i < col_size; i++) {
     const BoxRec& B = cols[wave][i];
@@ -89,12 +103,24 @@ __device__ __forceinline__ u64 readlane64(u64 v, int k) {
   return ((u64)hi << 32) | lo;
 }
 
-// Greedy scan of the bitmask (host loops rnms_kernel.cu:316-327, nms_rotated_cuda.cu:117-128)
-// by ONE workgroup.  remv[] (ceil(n/64) words) lives in dynamic LDS.
-__global__ __launch_bounds__(1024) void nms_reduce_kernel(const u64* __restrict__ mask, int n,
-                                                          int cb, const int64_t* __restrict__ order,
-                                                          int64_t* __restrict__ keep_out,
-                                                          int32_t* __restrict__ count_out) {
+// greedy scan of one 64-row block on its diagonal word, all-scalar (host loops
+// rnms_kernel.cu:316-327, nms_rotated_cuda.cu:117-128).  `cur` = bits already removed.
+__device__ __forceinline__ u64 scan_block(u64 diag, u64 cur, int nvalid) {
+  u64 kb = 0;
+  for (int k = 0; k < nvalid; k++) {
+    u64 dk = readlane64(diag, k);
+    if (!((cur >> k) & 1ULL)) {
+      kb |= 1ULL << k;
+      cur |= dk;
+    }
+  }
+  return kb;
+}
+
+__global__ __launch_bounds__(1024) void nms_reduce_dense_kernel(const u64* __restrict__ mask, int n,
+                                                                int cb, const int64_t* __restrict__ order,
+                                                                int64_t* __restrict__ keep_out,
+                                                                int32_t* __restrict__ count_out) {
   extern __shared__ __attribute__((aligned(16))) u64 remv[];  // cb words + 1 (kept-bits slot)
   u64* kb_slot = remv + cb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -106,15 +132,7 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const u64* __restrict_
       const int row = b * TILE + lane;
       u64 diag = (row < n) ? mask[(size_t)row * cb + b] : 0ULL;
       u64 cur = readlane64(remv[b], 0);
-      const int nvalid = min(TILE, n - b * TILE);
-      u64 kb = 0;
-      for (int k = 0; k < nvalid; k++) {
-        u64 dk = readlane64(diag, k);
-        if (!((cur >> k) & 1ULL)) {
-          kb |= 1ULL << k;
-          cur |= dk;
-        }
-      }
+      u64 kb = scan_block(diag, cur, min(TILE, n - b * TILE));
       if ((kb >> lane) & 1ULL) {
         int pos = cnt + __popcll(kb & ((1ULL << lane) - 1ULL));
         keep_out[pos] = order[row];
@@ -146,6 +164,211 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const u64* __restrict_
   if (tid == 0) *count_out = cnt;
 }
 
+// ---------------------------------------------------------------------------- queue pipeline
+constexpr int SQ_CAP = MASK_WAVES * TILE * TILE;  // 16384 u16 entries: a workgroup cannot overflow
+
+// stream: reject tests only.  Entry in the global queue: (i << 16) | j, i < j sorted positions.
+template <int GEOM, bool LABEL>
+__global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict__ recs, int n, int cb,
+                                                        float thr, unsigned* __restrict__ gqueue,
+                                                        unsigned qcap, unsigned* __restrict__ counter,
+                                                        u64* __restrict__ mask, u64* __restrict__ nz,
+                                                        int nzw) {
+  __shared__ float cols[MASK_WAVES][TILE][8];  // cx, cy, rad, ex, ey, label
+  __shared__ unsigned short queue[SQ_CAP];
+  __shared__ int qcount;
+  __shared__ unsigned qbase;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rb = blockIdx.y;
+  const int cblk = blockIdx.x * MASK_WAVES + wave;
+  const bool active = (cblk < cb) && (cblk >= rb);
+  if (tid == 0) qcount = 0;
+  int col_size = 0;
+  if (active) {
+    col_size = min(n - cblk * TILE, TILE);
+    if (lane < col_size) {
+      const float* f = recs[cblk * TILE + lane].f;
+#pragma unroll
+      for (int k = 0; k < 5; k++) cols[wave][lane][k] = f[9 + k];
+      cols[wave][lane][5] = (GEOM != 1) ? f[7] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int row = rb * TILE + lane;
+  if (active && row < n) {
+    const float* f = recs[row].f;
+    const float ax = f[9], ay = f[10], ar = f[11], aex = f[12], aey = f[13];
+    const float alab = (GEOM != 1) ? f[7] : 0.f;
+    const int start = (rb == cblk) ? lane + 1 : 0;
+    for (int i = 0; i < col_size; i++) {  // uniform trip count: ballots below need all lanes
+      const float* B = cols[wave][i];
+      float dx = ax - B[0], dy = ay - B[1], rr = ar + B[2];
+      bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + B[3]) | (fabsf(dy) > aey + B[4]);
+      if (GEOM != 1 && LABEL) apart |= (alab != B[5]);
+      const bool pend = (i >= start) && !apart;
+      u64 m = __ballot(pend);
+      if (m) {
+        int base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&qcount, __popcll(m));
+        base = __builtin_amdgcn_readlane(base, __ffsll((long long)m) - 1);
+        if (pend) {
+          int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+          queue[slot] = (unsigned short)((wave << 12) | (lane << 6) | i);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int total = qcount;
+  if (total == 0) return;
+  if (tid == 0) qbase = atomicAdd(counter, (unsigned)total);
+  __syncthreads();
+  const unsigned base = qbase;
+  for (int q = tid; q < total; q += NT) {
+    const unsigned e = queue[q];
+    const unsigned w = e >> 12, lr = (e >> 6) & 63u, lc = e & 63u;
+    const unsigned i = rb * TILE + lr;
+    const unsigned j = (blockIdx.x * MASK_WAVES + w) * TILE + lc;
+    if (base + q < qcap) {
+      gqueue[base + q] = (i << 16) | j;
+    } else {
+      // global queue exhausted (pathologically dense input): clip here, still exact
+      const BoxRec A = recs[i];
+      const BoxRec B = recs[j];
+      float v;  // scratch-array variant: this path is a safety net, not a hot path
+      if (GEOM == 1) v = v1_pair_slow(A, B, false);
+      else if (GEOM == 2) v = hull_pair_slow<true>(A, B, true);
+      else v = hull_pair_slow<false>(A, B, true);
+      if (v > thr) {
+        const unsigned wj = j >> 6;
+        atomicOr(&mask[(size_t)i * cb + wj], 1ULL << (j & 63u));
+        atomicOr(&nz[(size_t)i * nzw + (wj >> 6)], 1ULL << (wj & 63u));
+      }
+    }
+  }
+}
+
+template <int GEOM>
+__global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict__ recs, int cb, float thr,
+                                                        const unsigned* __restrict__ gqueue, unsigned qcap,
+                                                        const unsigned* __restrict__ counter,
+                                                        u64* __restrict__ mask, u64* __restrict__ nz,
+                                                        int nzw) {
+  __shared__ float2 pts[pts_slots<GEOM>() * 256];
+  const LanePts<256> lp{pts + threadIdx.x};
+  unsigned total = *counter;
+  if (total > qcap) total = qcap;
+  for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
+    const unsigned e = gqueue[q];
+    const unsigned i = e >> 16, j = e & 0xffffu;
+    const BoxRec A = recs[i];
+    const BoxRec B = recs[j];
+    const float v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
+    if (v > thr) {
+      const unsigned wj = j >> 6;
+      atomicOr(&mask[(size_t)i * cb + wj], 1ULL << (j & 63u));
+      atomicOr(&nz[(size_t)i * nzw + (wj >> 6)], 1ULL << (wj & 63u));
+    }
+  }
+}
+
+// k-th (0-based) set bit position among the nz words of a row, restricted to word indices
+// > b.  Returns -1 when the row has fewer such words.
+__device__ __forceinline__ int kth_word(const u64* nzrow, int nzw, int b, int k) {
+  for (int q = b >> 6; q < nzw; q++) {
+    u64 m = nzrow[q];
+    if (q == (b >> 6)) {
+      const int sh = (b & 63) + 1;
+      m = (sh >= 64) ? 0ULL : (m >> sh) << sh;
+    }
+    const int c = __popcll(m);
+    if (k < c) {
+      for (int t = 0; t < k; t++) m &= m - 1;
+      return q * 64 + (__ffsll((long long)m) - 1);
+    }
+    k -= c;
+  }
+  return -1;
+}
+
+constexpr int RSLOTS = 16;  // speculative word slots per row: 64 rows x 16 = 1024 threads
+
+__global__ __launch_bounds__(1024) void nms_reduce_sparse_kernel(const u64* __restrict__ mask,
+                                                                 const u64* __restrict__ nz, int nzw,
+                                                                 int n, int cb,
+                                                                 const int64_t* __restrict__ order,
+                                                                 int64_t* __restrict__ keep_out,
+                                                                 int32_t* __restrict__ count_out) {
+  extern __shared__ __attribute__((aligned(16))) u64 smem[];
+  u64* remv = smem;                 // cb words
+  u64* kb_slot = smem + cb;         // 1 word
+  u64* nzbuf = smem + cb + 1;       // 2 x 64 x nzw words (double buffer, block parity)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int myrow = tid >> 4, myk = tid & (RSLOTS - 1);
+  for (int j = tid; j < cb; j += blockDim.x) remv[j] = 0;
+  // nz rows of block 0
+  for (int t = tid; t < TILE * nzw; t += blockDim.x) {
+    int r = t / nzw;
+    nzbuf[t] = (r < n) ? nz[(size_t)r * nzw + (t - r * nzw)] : 0ULL;
+  }
+  u64 diag_next = 0;
+  if (wave == 0) diag_next = (lane < n) ? mask[(size_t)lane * cb] : 0ULL;
+  __syncthreads();
+  // speculative first-16 non-zero words of block 0's rows
+  int wcur_w = kth_word(nzbuf + myrow * nzw, nzw, 0, myk);
+  u64 wcur = (wcur_w >= 0 && myrow < n) ? mask[(size_t)myrow * cb + wcur_w] : 0ULL;
+
+  int cnt = 0;
+  for (int b = 0; b < cb; b++) {
+    const int par = b & 1;
+    u64* nzb = nzbuf + par * TILE * nzw;         // nz rows of block b
+    u64* nzn = nzbuf + (par ^ 1) * TILE * nzw;   // nz rows of block b + 1 (filled below)
+    // ---- stage 1: wave 0 scans block b; the others fetch nz rows of block b + 1
+    if (wave == 0) {
+      const int row = b * TILE + lane;
+      const u64 diag = diag_next;
+      const int nrow = row + TILE;
+      diag_next = (b + 1 < cb && nrow < n) ? mask[(size_t)nrow * cb + (b + 1)] : 0ULL;
+      const u64 cur = readlane64(remv[b], 0);
+      const u64 kb = scan_block(diag, cur, min(TILE, n - b * TILE));
+      if ((kb >> lane) & 1ULL) {
+        int pos = cnt + __popcll(kb & ((1ULL << lane) - 1ULL));
+        keep_out[pos] = order[row];
+      }
+      cnt += __popcll(kb);
+      if (lane == 0) *kb_slot = kb;
+    } else if (b + 1 < cb) {
+      for (int t = tid - 64; t < TILE * nzw; t += blockDim.x - 64) {
+        int r = t / nzw;
+        int gr = (b + 1) * TILE + r;
+        nzn[t] = (gr < n) ? nz[(size_t)gr * nzw + (t - r * nzw)] : 0ULL;
+      }
+    }
+    __syncthreads();
+    // ---- stage 2: OR the non-zero words of the kept rows into remv; prefetch block b + 1
+    const u64 kb = *kb_slot;
+    const bool kept = (kb >> myrow) & 1ULL;
+    if (kept && wcur_w >= 0) {
+      if (wcur) atomicOr(&remv[wcur_w], wcur);
+      // rows with more than RSLOTS non-zero words: the rest on demand
+      for (int k = myk + RSLOTS;; k += RSLOTS) {
+        int w = kth_word(nzb + myrow * nzw, nzw, b, k);
+        if (w < 0) break;
+        u64 v = mask[(size_t)(b * TILE + myrow) * cb + w];
+        if (v) atomicOr(&remv[w], v);
+      }
+    }
+    if (b + 1 < cb) {
+      const int gr = (b + 1) * TILE + myrow;
+      wcur_w = kth_word(nzn + myrow * nzw, nzw, b + 1, myk);
+      wcur = (wcur_w >= 0 && gr < n) ? mask[(size_t)gr * cb + wcur_w] : 0ULL;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count_out = cnt;
+}
+
 // rnms returns keep sorted by original index (rnms_kernel.cu:331-334): mark kept originals,
 // then an ordered compaction by one workgroup.
 __global__ __launch_bounds__(1024) void nms_ascending_kernel(int n, uint8_t* __restrict__ flags,
@@ -164,8 +387,7 @@ __global__ __launch_bounds__(1024) void nms_ascending_kernel(int n, uint8_t* __r
   for (int i = lo; i < hi; i++) c += flags[i];
   part[tid] = c;
   __syncthreads();
-  // exclusive scan over 1024 partials (Hillis-Steele in LDS)
-  for (int off = 1; off < 1024; off <<= 1) {
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
     int v = (tid >= off) ? part[tid - off] : 0;
     __syncthreads();
     part[tid] += v;
@@ -176,14 +398,77 @@ __global__ __launch_bounds__(1024) void nms_ascending_kernel(int n, uint8_t* __r
     if (flags[i]) keep_out[pos++] = i;
 }
 
+struct Layout {
+  BoxRec* recs;
+  u64* mask;
+  u64* nz;
+  unsigned* counter;
+  unsigned* gqueue;
+  unsigned qcap;
+  uint8_t* flags;
+  int cb, nzw;
+};
+
+inline size_t queue_entries(int n) {
+  // generous for real pools (tens of candidate pairs per box); denser inputs spill to the
+  // in-kernel path of nms_stream_kernel
+  size_t tri = (size_t)n * (size_t)(n - 1) / 2;
+  size_t cap = (size_t)n * 64 + 65536;
+  return tri < cap ? tri : cap;
+}
+
+inline size_t layout(int n, void* ws, Layout* L) {
+  const size_t cb = (n + TILE - 1) / TILE;
+  const size_t nzw = (cb + 63) / 64;
+  size_t off = 0;
+  char* p = (char*)ws;
+  auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
+  char* recs = take((size_t)n * sizeof(BoxRec));
+  char* mask = take((size_t)n * cb * sizeof(u64));  // mask and nz are zeroed together
+  char* nz = take((size_t)n * nzw * sizeof(u64));
+  char* counter = take(256);
+  char* gq = take(queue_entries(n) * sizeof(unsigned));
+  char* flags = take((size_t)n);
+  if (L) {
+    L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz; L->counter = (unsigned*)counter;
+    L->gqueue = (unsigned*)gq; L->qcap = (unsigned)queue_entries(n); L->flags = (uint8_t*)flags;
+    // test hook: a tiny capacity forces the in-kernel overflow path of nms_stream_kernel
+    if (g_r3_nms_qcap > 0 && (unsigned)g_r3_nms_qcap < L->qcap) L->qcap = (unsigned)g_r3_nms_qcap;
+    L->cb = (int)cb; L->nzw = (int)nzw;
+  }
+  return off + 256;
+}
+
 template <int GEOM, bool LABEL>
-int launch_nms(const float* dets, int det_stride, const int64_t* labels, const int64_t* order, int n,
-               float thr, BoxRec* recs, u64* mask, int cb, hipStream_t stream) {
+int run_nms(const float* dets, int det_stride, const int64_t* labels, const int64_t* order, int n,
+            float thr, const Layout& L, int64_t* keep_out, int32_t* count_out, hipStream_t stream) {
+  const int cb = L.cb;
+  const bool tiles = (g_r3_nms_impl == 1) || !(thr >= 0.f) || n >= 65536;
   hipLaunchKernelGGL((nms_prepare_kernel<GEOM>), dim3((n + 255) / 256), dim3(256), 0, stream, dets,
-                     det_stride, labels, order, n, recs);
+                     det_stride, labels, order, n, L.recs, tiles ? nullptr : L.counter);
   dim3 grid((cb + MASK_WAVES - 1) / MASK_WAVES, cb);
-  hipLaunchKernelGGL((nms_mask_kernel<GEOM, LABEL>), grid, dim3(TILE * MASK_WAVES), 0, stream, recs,
-                     n, cb, thr, mask);
+  if (tiles) {
+    hipLaunchKernelGGL((nms_mask_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, thr, L.mask);
+    size_t lds = (size_t)(cb + 1) * sizeof(u64);
+    if (lds > 64 * 1024) return -1;  // n > ~524 k boxes: not a rotated-NMS workload
+    hipLaunchKernelGGL(nms_reduce_dense_kernel, dim3(1), dim3(1024), lds, stream, L.mask, n, cb, order,
+                       keep_out, count_out);
+    return 0;
+  }
+  // mask + nz are adjacent: one fill
+  size_t zbytes = (size_t)((char*)L.counter - (char*)L.mask);
+  if (hipMemsetAsync(L.mask, 0, zbytes, stream) != hipSuccess) return -2;
+  hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, thr,
+                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw);
+  size_t qe = L.qcap;
+  int blocks = (int)((qe + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dim3(blocks), dim3(256), 0, stream, L.recs, cb, thr, L.gqueue,
+                     L.qcap, L.counter, L.mask, L.nz, L.nzw);
+  size_t lds = (size_t)(cb + 1 + 2 * TILE * L.nzw) * sizeof(u64);
+  hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1), dim3(1024), lds, stream, L.mask, L.nz, L.nzw, n, cb,
+                     order, keep_out, count_out);
   return 0;
 }
 
@@ -191,9 +476,7 @@ int launch_nms(const float* dets, int det_stride, const int64_t* labels, const i
 
 size_t r3k_nms_workspace_bytes(int n) {
   if (n <= 0) return 256;
-  size_t cb = (n + TILE - 1) / TILE;
-  return align256((size_t)n * sizeof(BoxRec)) + align256((size_t)n * cb * sizeof(u64)) +
-         align256((size_t)n) + 256;
+  return layout(n, nullptr, nullptr);
 }
 
 int r3k_nms(int geom, const float* dets, int det_stride, const int64_t* labels,
@@ -205,27 +488,17 @@ int r3k_nms(int geom, const float* dets, int det_stride, const int64_t* labels,
   }
   if (!dets || !order || !ws || !keep_out) return -1;
   if (ws_bytes < r3k_nms_workspace_bytes(n)) return -3;
-  const int cb = (n + TILE - 1) / TILE;
-  char* p = (char*)ws;
-  BoxRec* recs = (BoxRec*)p;
-  p += align256((size_t)n * sizeof(BoxRec));
-  u64* mask = (u64*)p;
-  p += align256((size_t)n * cb * sizeof(u64));
-  uint8_t* flags = (uint8_t*)p;
-
-  if (geom == 1) launch_nms<1, false>(dets, det_stride, nullptr, order, n, thr, recs, mask, cb, stream);
-  else if (geom == 2 && labels) launch_nms<2, true>(dets, det_stride, labels, order, n, thr, recs, mask, cb, stream);
-  else if (geom == 2) launch_nms<2, false>(dets, det_stride, nullptr, order, n, thr, recs, mask, cb, stream);
-  else if (geom == 3 && labels) launch_nms<3, true>(dets, det_stride, labels, order, n, thr, recs, mask, cb, stream);
-  else if (geom == 3) launch_nms<3, false>(dets, det_stride, nullptr, order, n, thr, recs, mask, cb, stream);
+  Layout L;
+  layout(n, ws, &L);
+  int rc;
+  if (geom == 1) rc = run_nms<1, false>(dets, det_stride, nullptr, order, n, thr, L, keep_out, count_out, stream);
+  else if (geom == 2 && labels) rc = run_nms<2, true>(dets, det_stride, labels, order, n, thr, L, keep_out, count_out, stream);
+  else if (geom == 2) rc = run_nms<2, false>(dets, det_stride, nullptr, order, n, thr, L, keep_out, count_out, stream);
+  else if (geom == 3 && labels) rc = run_nms<3, true>(dets, det_stride, labels, order, n, thr, L, keep_out, count_out, stream);
+  else if (geom == 3) rc = run_nms<3, false>(dets, det_stride, nullptr, order, n, thr, L, keep_out, count_out, stream);
   else return -1;
-
-  size_t lds = (size_t)(cb + 1) * sizeof(u64);
-  if (lds > 64 * 1024) return -1;  // n > ~524 k boxes: not a rotated-NMS workload
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(1024), lds, stream, mask, n, cb, order,
-                     keep_out, count_out);
+  if (rc) return rc;
   if (sort_ascending)
-    hipLaunchKernelGGL(nms_ascending_kernel, dim3(1), dim3(1024), 0, stream, n, flags, keep_out,
-                       count_out);
+    hipLaunchKernelGGL(nms_ascending_kernel, dim3(1), dim3(1024), 0, stream, n, L.flags, keep_out, count_out);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

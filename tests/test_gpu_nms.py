@@ -22,10 +22,38 @@ def case(n, seed, span):
     return b, r.uniform(0.05, 1, n).astype(np.float32), r.integers(0, 15, n)
 
 
+@pytest.fixture(params=["queue", "tiles", "overflow"])
+def nms_impl(request):
+    """queue = stream/drain/sparse-reduce pipeline (default); tiles = in-place tile mask +
+    dense reduce; overflow = queue pipeline with a 100-entry global queue, which forces the
+    in-kernel clipping path of the stream kernel."""
+    from r3det import _C
+    _C.set_option("nms_impl", 1 if request.param == "tiles" else 0)
+    _C.set_option("nms_qcap", 100 if request.param == "overflow" else 0)
+    yield request.param
+    _C.set_option("nms_impl", 0)
+    _C.set_option("nms_qcap", 0)
+
+
+def test_dense_single_class(nms_impl):
+    """Crowded single-class pools: long suppression lists (> 16 non-zero words per row)."""
+    from r3det.ops import obb_nms, rnms
+    for n, span in [(3000, 150.), (4500, 400.)]:
+        b = rand_boxes(n, 500 + n, span=span)
+        s = np.random.default_rng(n).uniform(0.05, 1, n).astype(np.float32)
+        d6 = np.hstack([b, s[:, None]])
+        for thr in (0.1, 0.7):
+            with O.twin():
+                w1 = O.nms(O.V1, b, s, thr, strict=True, ascending=True)
+                w3 = O.nms(O.V3, b, s, thr, strict=True)
+            assert np.array_equal(rnms(dev(d6), thr)[1].cpu().numpy(), w1)
+            assert np.array_equal(obb_nms(dev(d6), thr)[1].cpu().numpy(), w3)
+
+
 @pytest.mark.parametrize("n,span", [(1, 100.), (63, 120.), (64, 120.), (65, 120.), (129, 150.),
                                     (1000, 400.), (2000, 600.), (5344, 1000.)])
 @pytest.mark.parametrize("thr", [0.1, 0.5])
-def test_keep_exact_vs_twin(n, span, thr):
+def test_keep_exact_vs_twin(n, span, thr, nms_impl):
     from r3det.ops import ml_nms_rotated, nms_rotated, obb_nms, rnms
     b, s, lab = case(n, 300 + n, span)
     d6 = np.hstack([b, s[:, None]])
