@@ -201,21 +201,22 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
     const float ax = f[9], ay = f[10], ar = f[11], aex = f[12], aey = f[13];
     const float alab = (GEOM != 1) ? f[7] : 0.f;
     const int start = (rb == cblk) ? lane + 1 : 0;
-    for (int i = 0; i < col_size; i++) {  // uniform trip count: ballots below need all lanes
+    // 64 reject tests into one per-lane bit mask (no cross-lane traffic in the loop) ...
+    u64 pm = 0;
+    for (int i = 0; i < col_size; i++) {
       const float* B = cols[wave][i];
       float dx = ax - B[0], dy = ay - B[1], rr = ar + B[2];
       bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + B[3]) | (fabsf(dy) > aey + B[4]);
       if (GEOM != 1 && LABEL) apart |= (alab != B[5]);
-      const bool pend = (i >= start) && !apart;
-      u64 m = __ballot(pend);
-      if (m) {
-        int base = 0;
-        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&qcount, __popcll(m));
-        base = __builtin_amdgcn_readlane(base, __ffsll((long long)m) - 1);
-        if (pend) {
-          int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
-          queue[slot] = (unsigned short)((wave << 12) | (lane << 6) | i);
-        }
+      if ((i >= start) && !apart) pm |= 1ULL << i;
+    }
+    // ... then ONE LDS atomic per lane that has survivors (rare) reserves its queue slots
+    if (pm) {
+      int slot = atomicAdd(&qcount, __popcll(pm));
+      while (pm) {
+        const int i = __ffsll((long long)pm) - 1;
+        pm &= pm - 1;
+        queue[slot++] = (unsigned short)((wave << 12) | (lane << 6) | i);
       }
     }
   }
@@ -292,9 +293,30 @@ __device__ __forceinline__ int kth_word(const u64* nzrow, int nzw, int b, int k)
   return -1;
 }
 
-constexpr int RSLOTS = 16;  // speculative word slots per row: 64 rows x 16 = 1024 threads
+constexpr int RSLOTS = 16;  // speculative word slots per row: 64 rows x 16 = 1024 threads (4 slots measured 25-45 % slower: clusters of duplicates give ~10 non-zero words per row)
+constexpr int RTHREADS = TILE * RSLOTS;
+constexpr int NZRING = 4;   // nz rows are fetched 3 blocks ahead of their use
 
-__global__ __launch_bounds__(1024) void nms_reduce_sparse_kernel(const u64* __restrict__ mask,
+// Greedy scan of one 64-row block.  Only rows whose diagonal word is non-zero can remove
+// anybody inside the block, and a row's word only has bits of LATER rows, so it suffices to
+// visit those rows in ascending order; every row's fate is final once all earlier rows were
+// visited: kept = ~removed.  All of it runs on the scalar unit (~10 SALU per visited row).
+__device__ __forceinline__ u64 scan_block_sparse(u64 diag, u64 cur, u64 valid) {
+  u64 m = __ballot(diag != 0ULL);
+  while (m) {
+    const int k = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    if (!((cur >> k) & 1ULL)) cur |= readlane64(diag, k);
+  }
+  return ~cur & valid;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every
+// outstanding global load (s_waitcnt vmcnt(0)), which would serialise the prefetches below
+// behind a full memory round trip per 64-row block.
+#define R3_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__global__ __launch_bounds__(RTHREADS) void nms_reduce_sparse_kernel(const u64* __restrict__ mask,
                                                                  const u64* __restrict__ nz, int nzw,
                                                                  int n, int cb,
                                                                  const int64_t* __restrict__ order,
@@ -302,71 +324,110 @@ __global__ __launch_bounds__(1024) void nms_reduce_sparse_kernel(const u64* __re
                                                                  int32_t* __restrict__ count_out) {
   extern __shared__ __attribute__((aligned(16))) u64 smem[];
   u64* remv = smem;                 // cb words
-  u64* kb_slot = smem + cb;         // 1 word
-  u64* nzbuf = smem + cb + 1;       // 2 x 64 x nzw words (double buffer, block parity)
+  u64* kb_slot = smem + cb;         // [0] kept bits of the current block, [1] final count
+  u64* nzbuf = smem + cb + 2;       // NZRING x 64 x nzw words
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int myrow = tid >> 4, myk = tid & (RSLOTS - 1);
+  const int myrow = tid / RSLOTS, myk = tid % RSLOTS;
+  const int slot_words = TILE * nzw;  // <= 1024 because n < 65536 (nzw <= 16)
+  // elements of a 64 x nzw nz slot owned by this thread: tid, tid + 256, ... (<= 4)
+  constexpr int NZPT = 1024 / RTHREADS;
+
+  struct NzRegs { u64 v[NZPT]; };
+  auto load_nz = [&](int blk) -> NzRegs {
+    NzRegs r;
+#pragma unroll
+    for (int q = 0; q < NZPT; q++) {
+      const int t = tid + q * RTHREADS;
+      const int rr = t / nzw;
+      const int gr = blk * TILE + rr;
+      r.v[q] = (t < slot_words && blk < cb && gr < n) ? nz[(size_t)gr * nzw + (t - rr * nzw)] : 0ULL;
+    }
+    return r;
+  };
+  auto store_nz = [&](int slot, const NzRegs& r) {
+#pragma unroll
+    for (int q = 0; q < NZPT; q++) {
+      const int t = tid + q * RTHREADS;
+      if (t < slot_words) nzbuf[slot * slot_words + t] = r.v[q];
+    }
+  };
+  auto diag_of = [&](int blk) -> u64 {
+    const int r = blk * TILE + lane;
+    return (blk < cb && r < n) ? mask[(size_t)r * cb + blk] : 0ULL;
+  };
+  // speculative load of this thread's (row, k-th non-zero word beyond the diagonal) of a block
+  auto spec_word = [&](int blk, int& widx) -> u64 {
+    widx = -1;
+    if (blk >= cb) return 0ULL;
+    const int gr = blk * TILE + myrow;
+    if (gr >= n) return 0ULL;
+    widx = kth_word(nzbuf + (blk % NZRING) * slot_words + myrow * nzw, nzw, blk, myk);
+    return widx >= 0 ? mask[(size_t)gr * cb + widx] : 0ULL;
+  };
+
   for (int j = tid; j < cb; j += blockDim.x) remv[j] = 0;
-  // nz rows of block 0
-  for (int t = tid; t < TILE * nzw; t += blockDim.x) {
-    int r = t / nzw;
-    nzbuf[t] = (r < n) ? nz[(size_t)r * nzw + (t - r * nzw)] : 0ULL;
+  for (int blk = 0; blk < NZRING; blk++) store_nz(blk, load_nz(blk));
+  NzRegs nz_inflight = load_nz(NZRING);  // block 4: stored to the ring at iteration 1
+  u64 d0 = 0, d1 = 0, d2 = 0;
+  if (wave == 0) {
+    d0 = diag_of(0);
+    d1 = diag_of(1);
+    d2 = diag_of(2);
   }
-  u64 diag_next = 0;
-  if (wave == 0) diag_next = (lane < n) ? mask[(size_t)lane * cb] : 0ULL;
   __syncthreads();
-  // speculative first-16 non-zero words of block 0's rows
-  int wcur_w = kth_word(nzbuf + myrow * nzw, nzw, 0, myk);
-  u64 wcur = (wcur_w >= 0 && myrow < n) ? mask[(size_t)myrow * cb + wcur_w] : 0ULL;
+  int wa_i, wb_i;
+  u64 wa = spec_word(0, wa_i);
+  u64 wb = spec_word(1, wb_i);
 
   int cnt = 0;
   for (int b = 0; b < cb; b++) {
-    const int par = b & 1;
-    u64* nzb = nzbuf + par * TILE * nzw;         // nz rows of block b
-    u64* nzn = nzbuf + (par ^ 1) * TILE * nzw;   // nz rows of block b + 1 (filled below)
-    // ---- stage 1: wave 0 scans block b; the others fetch nz rows of block b + 1
+    // ---- stage 1: wave 0 resolves block b
     if (wave == 0) {
-      const int row = b * TILE + lane;
-      const u64 diag = diag_next;
-      const int nrow = row + TILE;
-      diag_next = (b + 1 < cb && nrow < n) ? mask[(size_t)nrow * cb + (b + 1)] : 0ULL;
+      const int nvalid = min(TILE, n - b * TILE);
+      const u64 valid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1ULL);
       const u64 cur = readlane64(remv[b], 0);
-      const u64 kb = scan_block(diag, cur, min(TILE, n - b * TILE));
-      if ((kb >> lane) & 1ULL) {
-        int pos = cnt + __popcll(kb & ((1ULL << lane) - 1ULL));
-        keep_out[pos] = order[row];
-      }
+      const u64 kb = scan_block_sparse(d0, cur, valid);
+      if ((kb >> lane) & 1ULL)
+        keep_out[cnt + __popcll(kb & ((1ULL << lane) - 1ULL))] = b * TILE + lane;  // sorted position
       cnt += __popcll(kb);
-      if (lane == 0) *kb_slot = kb;
-    } else if (b + 1 < cb) {
-      for (int t = tid - 64; t < TILE * nzw; t += blockDim.x - 64) {
-        int r = t / nzw;
-        int gr = (b + 1) * TILE + r;
-        nzn[t] = (gr < n) ? nz[(size_t)gr * nzw + (t - r * nzw)] : 0ULL;
-      }
+      if (lane == 0) kb_slot[0] = kb;
+      d0 = d1;
+      d1 = d2;
+      d2 = diag_of(b + 3);
     }
-    __syncthreads();
-    // ---- stage 2: OR the non-zero words of the kept rows into remv; prefetch block b + 1
-    const u64 kb = *kb_slot;
-    const bool kept = (kb >> myrow) & 1ULL;
-    if (kept && wcur_w >= 0) {
-      if (wcur) atomicOr(&remv[wcur_w], wcur);
+    // nz rows: block b+3 (loaded one iteration ago) enters the ring, block b+4 is requested.
+    // Ring slot (b+3)%4 held block b-1, last read in iteration b-1.
+    if (b >= 1) {
+      store_nz((b + 3) % NZRING, nz_inflight);
+      nz_inflight = load_nz(b + 4);
+    }
+    R3_LDS_BARRIER();
+    // ---- stage 2: OR the non-zero words of the kept rows into remv; request block b + 2's words
+    const u64 kb = kb_slot[0];
+    if (((kb >> myrow) & 1ULL) && wa_i >= 0) {
+      if (wa) atomicOr(&remv[wa_i], wa);
       // rows with more than RSLOTS non-zero words: the rest on demand
+      const u64* nzb = nzbuf + (b % NZRING) * slot_words + myrow * nzw;
       for (int k = myk + RSLOTS;; k += RSLOTS) {
-        int w = kth_word(nzb + myrow * nzw, nzw, b, k);
+        const int w = kth_word(nzb, nzw, b, k);
         if (w < 0) break;
-        u64 v = mask[(size_t)(b * TILE + myrow) * cb + w];
+        const u64 v = mask[(size_t)(b * TILE + myrow) * cb + w];
         if (v) atomicOr(&remv[w], v);
       }
     }
-    if (b + 1 < cb) {
-      const int gr = (b + 1) * TILE + myrow;
-      wcur_w = kth_word(nzn + myrow * nzw, nzw, b + 1, myk);
-      wcur = (wcur_w >= 0 && gr < n) ? mask[(size_t)gr * cb + wcur_w] : 0ULL;
-    }
-    __syncthreads();
+    wa = wb;
+    wa_i = wb_i;
+    wb = spec_word(b + 2, wb_i);
+    R3_LDS_BARRIER();
   }
-  if (tid == 0) *count_out = cnt;
+  if (tid == 0) {
+    kb_slot[1] = (u64)cnt;
+    *count_out = cnt;
+  }
+  __syncthreads();
+  // sorted position -> original index, in parallel (kept off the serial path above)
+  const int total = (int)kb_slot[1];
+  for (int i = tid; i < total; i += blockDim.x) keep_out[i] = order[keep_out[i]];
 }
 
 // rnms returns keep sorted by original index (rnms_kernel.cu:331-334): mark kept originals,
@@ -466,8 +527,8 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dim3(blocks), dim3(256), 0, stream, L.recs, cb, thr, L.gqueue,
                      L.qcap, L.counter, L.mask, L.nz, L.nzw);
-  size_t lds = (size_t)(cb + 1 + 2 * TILE * L.nzw) * sizeof(u64);
-  hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1), dim3(1024), lds, stream, L.mask, L.nz, L.nzw, n, cb,
+  size_t lds = (size_t)(cb + 2 + NZRING * TILE * L.nzw) * sizeof(u64);
+  hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.nzw, n, cb,
                      order, keep_out, count_out);
   return 0;
 }
