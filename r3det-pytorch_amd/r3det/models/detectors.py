@@ -1,0 +1,90 @@
+"""R3Det / RRetinaNet detectors, inference path (models/detectors/r3det.py:112-143,
+rretinanet.py:23-46)."""
+import torch
+import torch.nn as nn
+
+from ..ops import FeatureRefineModule
+from .backbone import FPN, ResNet50
+from .heads import RRetinaHead, RRetinaRefineHead
+
+TEST_CFG = dict(nms_pre=2000, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=2000)
+
+
+class RRetinaNet(nn.Module):
+    def __init__(self, num_classes=15, test_cfg=None):
+        super().__init__()
+        self.test_cfg = dict(test_cfg or TEST_CFG)
+        self.backbone = ResNet50()
+        self.neck = FPN()
+        self.bbox_head = RRetinaHead(num_classes, test_cfg=self.test_cfg)
+
+    def extract_feat(self, img):
+        return self.neck(self.backbone(img))
+
+    @torch.no_grad()
+    def simple_test(self, img):
+        x = self.extract_feat(img)
+        cls, reg = self.bbox_head(x)
+        return self.bbox_head.get_bboxes(cls, reg, img.shape[-2:], self.test_cfg)
+
+
+class R3Det(nn.Module):
+    """num_refine_stages x (FeatureRefineModule -> RRetinaRefineHead) after the base head;
+    state-dict names follow the reference (backbone / neck / bbox_head / feat_refine_module.i /
+    refine_head.i)."""
+
+    def __init__(self, num_classes=15, num_refine_stages=1, frm_cfgs=None, test_cfg=None):
+        super().__init__()
+        self.test_cfg = dict(test_cfg or TEST_CFG)
+        self.num_refine_stages = num_refine_stages
+        self.backbone = ResNet50()
+        self.neck = FPN()
+        self.bbox_head = RRetinaHead(num_classes, test_cfg=self.test_cfg)
+        frm_cfgs = frm_cfgs or [dict(in_channels=256, featmap_strides=[8, 16, 32, 64, 128])] * num_refine_stages
+        self.feat_refine_module = nn.ModuleList(FeatureRefineModule(**c) for c in frm_cfgs)
+        self.refine_head = nn.ModuleList(RRetinaRefineHead(num_classes, test_cfg=self.test_cfg)
+                                         for _ in range(num_refine_stages))
+        for m in self.feat_refine_module:
+            m.init_weights()
+
+    def extract_feat(self, img):
+        return self.neck(self.backbone(img))
+
+    @torch.no_grad()
+    def simple_test(self, img):
+        x = self.extract_feat(img)
+        cls, reg = self.bbox_head(x)
+        rois = self.bbox_head.filter_bboxes(cls, reg)
+        for i in range(self.num_refine_stages):
+            x_refine = self.feat_refine_module[i](x, rois)
+            cls, reg = self.refine_head[i](x_refine)
+            if i + 1 < self.num_refine_stages:
+                rois = self.refine_head[i].refine_bboxes(cls, reg, rois)
+        return self.refine_head[-1].get_bboxes(cls, reg, img.shape[-2:], self.test_cfg, rois=rois)
+
+
+def build_detector(cfg):
+    """dict(type='R3Det' | 'RRetinaNet', ...) -> module (subset of mmdet's build_detector)."""
+    cfg = dict(cfg)
+    typ = cfg.pop('type')
+    return {'R3Det': R3Det, 'RRetinaNet': RRetinaNet}[typ](**cfg)
+
+
+@torch.no_grad()
+def calibrate_score_bias(model, img, frac=0.01):
+    """Synthetic-weight runs give sigmoid ~ 0.01 < score_thr everywhere, i.e.
+    an empty NMS pool.  Shift the last head's classification bias so that `frac` of the
+    (position, class) scores exceed score_thr -- the sparsity of a trained detector."""
+    head = model.refine_head[-1] if isinstance(model, R3Det) else model.bbox_head
+    x = model.extract_feat(img)
+    if isinstance(model, R3Det):
+        cls, reg = model.bbox_head(x)
+        rois = model.bbox_head.filter_bboxes(cls, reg)
+        x = model.feat_refine_module[-1](x, rois)
+    cls, _ = head(x)
+    logits = torch.cat([c.flatten() for c in cls])
+    k = max(1, int(logits.numel() * frac))
+    kth = logits.float().topk(k)[0][-1]
+    thr = model.test_cfg['score_thr']
+    target = torch.log(torch.tensor(thr / (1 - thr)))
+    head.retina_cls.bias.add_(float(target - kth) + 1e-3)

@@ -12,6 +12,12 @@ from torch.autograd.function import once_differentiable
 from .. import _C
 
 
+# bench.py hook: when set to a list, (start, end) stream events are recorded around every
+# forward launch whose plane is >= PROFILE_MIN_HW (the level-0 launch of a 1024^2 input)
+profile_events = None
+PROFILE_MIN_HW = 128 * 128
+
+
 def fr_forward(features, best_rbboxes, spatial_scale, points, output):
     """feature_refine_cuda.forward (feature_refine_cuda.cpp:24-42): fills ``output``, returns 1."""
     f = _C.need_hip(features, "features")
@@ -21,8 +27,15 @@ def fr_forward(features, best_rbboxes, spatial_scale, points, output):
     if b.numel() != N * H * W * 5:
         raise RuntimeError(f"best_bboxes must hold N*H*W x 5 values, got {tuple(b.shape)}")
     with torch.cuda.device(f.device):
+        ev = None
+        if profile_events is not None and H * W >= PROFILE_MIN_HW:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _C.check(_C.lib().r3det_feature_refine_forward(_C.ptr(f), _C.ptr(b), N, C, H, W, float(spatial_scale),
                                                        int(points), _C.ptr(o), _C.stream()), "fr_forward")
+        if ev is not None:
+            ev[1].record()
+            profile_events.append(ev)
     return 1
 
 
