@@ -125,7 +125,12 @@ int r3det_mmcv_nms_rotated(const float* dets5, const int64_t* labels, const int6
  * best_bboxes (N*H*W,5); points in {1,5}.  output is caller-allocated and fully overwritten. */
 int r3det_feature_refine_forward(const float* features, const float* best_bboxes, int N, int C,
                                  int H, int W, float spatial_scale, int points, float* output,
-                                 void* stream);
+                                 void* ws, size_t ws_bytes, void* stream);
+
+/* Optional scratch for the forward sampler (20 bytes per sample point).  With it the box ->
+ * (tap offsets, bilinear weights) conversion runs once per position instead of once per
+ * channel plane; results are bit-identical.  ws == NULL selects the workspace-free kernels. */
+size_t r3det_fr_workspace_bytes(int N, int H, int W, int points);
 
 /* feature_refine_cuda.backward(top_grad, best_bboxes, spatial_scale, points, bottom_grad)
  *                                                      fr/src/feature_refine_cuda.cpp:44-66

@@ -109,13 +109,17 @@ int r3det_mmcv_nms_rotated(const float* dets5, const int64_t* labels, const int6
                     count_out, S(stream)));
 }
 
+size_t r3det_fr_workspace_bytes(int N, int H, int W, int points) {
+  return r3k_fr_workspace_bytes(N, H, W, points);
+}
+
 int r3det_feature_refine_forward(const float* features, const float* best_bboxes, int N, int C,
                                  int H, int W, float spatial_scale, int points, float* output,
-                                 void* stream) {
+                                 void* ws, size_t ws_bytes, void* stream) {
   if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
   if ((size_t)N * C * H * W > 0 && (!features || !best_bboxes || !output)) return R3DET_EINVAL;
-  return rc(r3k_fr_forward(features, best_bboxes, N, C, H, W, spatial_scale, points, output,
-                           S(stream)));
+  return rc(r3k_fr_forward(features, best_bboxes, N, C, H, W, spatial_scale, points, output, ws,
+                           ws_bytes, S(stream)));
 }
 
 int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxes, int N, int C,
@@ -130,6 +134,7 @@ int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxe
 int r3det_set_option(const char* name, int value) {
   if (!name) return R3DET_EINVAL;
   if (!strcmp(name, "fr_impl")) g_r3_fr_impl = value;
+  else if (!strcmp(name, "fr_dbg")) g_r3_fr_dbg = value;
   else if (!strcmp(name, "iou_impl")) g_r3_iou_impl = value;
   else if (!strcmp(name, "nms_impl")) g_r3_nms_impl = value;
   else if (!strcmp(name, "nms_qcap")) g_r3_nms_qcap = value;

@@ -3,24 +3,29 @@
 // Replaces feature_refine_forward_kernel / feature_refine_backward_kernel
 // (fr/src/feature_refine_kernel.cu:112-230).  The reference runs one thread per output
 // ELEMENT (n,c,h,w) and re-derives the sample point from the 20-byte box for each of the
-// C channels; here a thread owns one POSITION (n,h,w): it turns the box into tap offsets
-// and weights once and then streams over channels.
+// C channels; here the box -> (tap offsets, bilinear weights) conversion is per POSITION.
 //
-// Two implementations of each direction:
-//   generic   : taps gathered from global memory (L1/L2) -- any H x W.
-//   lds-plane : the (n,c) plane (H x (W+1) floats, padded) is staged in LDS with coalesced
-//               16-byte loads and every tap is an LDS read.  Because the reference samples
-//               row <- x_ctr*scale, column <- y_ctr*scale (feature_refine_kernel.cu:131-132)
-//               the gather of a well-behaved box field is a TRANSPOSE of the plane: adjacent
-//               lanes hit adjacent rows, i.e. a different cache line per lane.  Through LDS
-//               that costs nothing (odd row pitch => conflict-free), and HBM sees exactly one
-//               read and one write per element.
+// Because the reference samples row <- x_ctr*scale, column <- y_ctr*scale
+// (feature_refine_kernel.cu:131-132) the gather of a well-behaved box field is a TRANSPOSE
+// of the plane: adjacent lanes hit adjacent rows, i.e. a different cache line per lane.
+// Staging the (n,c) plane in LDS (row pitch W+1) turns that into cheap LDS reads and HBM sees
+// exactly one read and one write per element (PMC: FETCH+WRITE = 1.05 x algorithmic bytes).
+//
+// Forward implementations (r3det_set_option("fr_impl", k)):
+//   1 generic  : taps gathered from global memory (L1/L2); any H x W, no LDS.
+//   2 plane    : one workgroup per tile of planes, taps derived in the kernel (no workspace).
+//   5 persist  : (default when a workspace is given) one workgroup per CU walks over its tiles
+//     6 (consec) with two LDS buffers; taps come from a 20-byte-per-position table built once by
+//                fr_taps_kernel.  5 = a lane owns 4 adjacent positions, 6 = lanes own consecutive
+//                positions (bank-conflict-free gathers) + in-register 4x4 transposes.
+// All of them produce bit-identical outputs (tests/test_gpu_fr.py).
 #include <hip/hip_runtime.h>
 
 #include "r3_kernels.h"
 #include "r3_trig.h"
 
 int g_r3_fr_impl = 0;
+int g_r3_fr_dbg = 0;  // ablation bits for fr_forward_persist<.., true> (tools/fr_ablate.py)
 
 namespace {
 
@@ -93,11 +98,14 @@ __device__ __forceinline__ void make_taps(const float* __restrict__ box, float s
   }
 }
 
+// Branch-free: an invalid tap has offsets 0 (always readable) and its value is discarded by
+// a select, so the four reads of every tap can be issued back to back (an `if (valid)` around
+// them costs one exposed LDS round trip per tap: measured 2.9 -> 4.4 TB/s-equivalent).
 template <typename P>
 __device__ __forceinline__ float tap_value(const Tap& t, P plane) {
-  if (!t.valid) return 0.f;
   float lt = plane[t.o00], rt = plane[t.o01], lb = plane[t.o10], rb = plane[t.o11];
-  return (t.w1 * lt + t.w2 * rt + t.w3 * lb + t.w4 * rb);
+  float v = (t.w1 * lt + t.w2 * rt + t.w3 * lb + t.w4 * rb);
+  return t.valid ? v : 0.f;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -160,13 +168,13 @@ __global__ __launch_bounds__(FR_BLOCK) void fr_backward_generic(const float* __r
 }
 
 // ----------------------------------------------------------------------------------------
-// lds-plane kernels: one workgroup owns CPB consecutive (n,c) planes, staged in LDS.
+// lds-plane kernels (no workspace): one workgroup owns CPB consecutive (n,c) planes.
 // A thread owns QUADS of 4 adjacent positions: its 4 boxes are one contiguous 80-byte read
 // (5 x 16 B), the 4 results one 16-byte store; all global loads of a round are issued before
-// the first use so a wave keeps >= 4 (stage) / 5 (boxes) requests in flight.
+// the first use.
 // ----------------------------------------------------------------------------------------
 constexpr int FRP_BLOCK = 1024;
-constexpr int FRP_LDS_FLOATS = 17 * 1024;  // 68 KB: 128 x 129 plane (66 KB) fits, 2 WGs / CU
+constexpr int FRP_LDS_FLOATS = 17 * 1024;  // 68 KB: a 128 x 129 plane (66 KB) fits
 constexpr int FRP_STAGE_UNROLL = 4;
 
 // global (contiguous nc planes of HW floats) -> LDS planes with row pitch W+1
@@ -205,7 +213,11 @@ __device__ __forceinline__ void stage_planes(const float* __restrict__ src, floa
   }
 }
 
-template <int POINTS, bool VEC>
+// NC > 0: planes per workgroup known at compile time.  Matters for more than unrolling: gfx950
+// has ONE in-order vmcnt queue for loads and stores, so "wait for the next quad's boxes" also
+// waits for every store issued before them unless the boxes were requested BEFORE those stores
+// and the compiler can count the younger stores (s_waitcnt vmcnt(NC) instead of vmcnt(0)).
+template <int POINTS, bool VEC, int NC>
 __global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __restrict__ feat,
                                                               const float* __restrict__ boxes,
                                                               int C, int H, int W, float scale,
@@ -216,20 +228,29 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __res
   const int psz = H * pitch;
   const int n = blockIdx.y;
   const int c0 = blockIdx.x * cpb;
-  const int nc = min(cpb, C - c0);
+  const int nc = NC > 0 ? NC : min(cpb, C - c0);
   const float* src = feat + ((size_t)n * C + c0) * HW;
   float* dst = out + ((size_t)n * C + c0) * HW;
-  stage_planes<VEC>(src, lds, nc, HW, W, pitch, psz);
-  __syncthreads();
   if (VEC) {
     const float4* bx4 = reinterpret_cast<const float4*>(boxes + (size_t)n * HW * 5);
     const int quads = HW >> 2;
+    float4 nb[5];  // boxes of this thread's first quad: requested before staging
+    if ((int)threadIdx.x < quads) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) nb[k] = bx4[threadIdx.x * 5 + k];
+    }
+    stage_planes<true>(src, lds, nc, HW, W, pitch, psz);
+    __syncthreads();
     for (int qd = threadIdx.x; qd < quads; qd += FRP_BLOCK) {
       float bq[20];
 #pragma unroll
       for (int k = 0; k < 5; k++) {
-        float4 t = bx4[qd * 5 + k];
-        bq[4 * k] = t.x; bq[4 * k + 1] = t.y; bq[4 * k + 2] = t.z; bq[4 * k + 3] = t.w;
+        bq[4 * k] = nb[k].x; bq[4 * k + 1] = nb[k].y; bq[4 * k + 2] = nb[k].z; bq[4 * k + 3] = nb[k].w;
+      }
+      const int nq = qd + FRP_BLOCK;
+      if (nq < quads) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) nb[k] = bx4[nq * 5 + k];  // next quad: before this quad's stores
       }
       const int hw0 = qd << 2;
       const int y = hw0 / W, x = hw0 - y * W;  // W % 4 == 0: the quad stays in one row
@@ -237,20 +258,25 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __res
       Tap taps[4][POINTS];
 #pragma unroll
       for (int j = 0; j < 4; j++) make_taps<POINTS>(bq + 5 * j, scale, H, W, pitch, taps[j]);
-      for (int ch = 0; ch < nc; ch++) {
-        const float* plane = lds + ch * psz;
-        float r[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          float v = plane[self + j];
+      for (int ch = 0; ch < (NC > 0 ? NC : 1); ch++) {
+        for (int c2 = ch; c2 < nc; c2 += (NC > 0 ? NC : 1)) {
+          const float* plane = lds + c2 * psz;
+          float r[4];
 #pragma unroll
-          for (int p = 0; p < POINTS; p++) v += tap_value(taps[j][p], plane);
-          r[j] = v;
+          for (int j = 0; j < 4; j++) {
+            float v = plane[self + j];
+#pragma unroll
+            for (int p = 0; p < POINTS; p++) v += tap_value(taps[j][p], plane);
+            r[j] = v;
+          }
+          *reinterpret_cast<float4*>(dst + (size_t)c2 * HW + hw0) = make_float4(r[0], r[1], r[2], r[3]);
         }
-        *reinterpret_cast<float4*>(dst + (size_t)ch * HW + hw0) = make_float4(r[0], r[1], r[2], r[3]);
       }
     }
   } else {
+    stage_planes<false>(src, lds, nc, HW, W, pitch, psz);
+    __syncthreads();
     for (int hw = threadIdx.x; hw < HW; hw += FRP_BLOCK) {
       Tap taps[POINTS];
       make_taps<POINTS>(boxes + ((size_t)n * HW + hw) * 5, scale, H, W, pitch, taps);
@@ -371,12 +397,215 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_backward_plane(const float* __re
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// tap table (needs a caller workspace): every position is converted ONCE into a 20-byte
+// record -- the same bytes a kernel would read for the box -- instead of once per channel
+// plane.   record = { packed, w1, w2, w3, w4 }
+//          packed = o00 | dx << 20 | dy << 21 | valid << 22   (o00 < H * (W + 1) <= 17 408)
+// ----------------------------------------------------------------------------------------
+template <int POINTS>
+__global__ __launch_bounds__(256) void fr_taps_kernel(const float* __restrict__ boxes, int total, int H,
+                                                      int W, float scale, float* __restrict__ table) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= total) return;
+  const int pitch = W + 1;
+  Tap taps[POINTS];
+  make_taps<POINTS>(boxes + (size_t)pos * 5, scale, H, W, pitch, taps);
+#pragma unroll
+  for (int p = 0; p < POINTS; p++) {
+    const Tap& t = taps[p];
+    int packed = 0;
+    if (t.valid) packed = t.o00 | ((t.o01 - t.o00) << 20) | ((t.o10 != t.o00 ? 1 : 0) << 21) | (1 << 22);
+    float* d = table + ((size_t)pos * POINTS + p) * 5;
+    d[0] = __int_as_float(packed);
+    d[1] = t.w1; d[2] = t.w2; d[3] = t.w3; d[4] = t.w4;
+  }
+}
+
+__device__ __forceinline__ Tap unpack_tap(const float* d, int pitch) {
+  Tap t;
+  const int packed = __float_as_int(d[0]);
+  t.o00 = packed & 0xFFFFF;
+  const int dx = (packed >> 20) & 1, dy = (packed >> 21) & 1;
+  t.o01 = t.o00 + dx;
+  t.o10 = t.o00 + (dy ? pitch : 0);
+  t.o11 = t.o10 + dx;
+  t.valid = (packed >> 22) & 1;
+  t.w1 = d[1]; t.w2 = d[2]; t.w3 = d[3]; t.w4 = d[4];
+  return t;
+}
+
+// 4 x 4 transpose inside every group of 4 adjacent lanes (register index <-> lane index),
+// two DPP quad_perm exchanges.  In: lane 4q+c holds r[j] = value(j, c).  Out: lane 4q+j holds
+// r[c] = value(j, c).
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));  // [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));  // [2,3,0,1]
+}
+__device__ __forceinline__ void quad_transpose(float (&r)[4], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float s0 = dpp_xor1(b0 ? r[0] : r[1]);
+  float s1 = dpp_xor1(b0 ? r[2] : r[3]);
+  if (b0) { r[0] = s0; r[2] = s1; } else { r[1] = s0; r[3] = s1; }
+  float u0 = dpp_xor2(b1 ? r[0] : r[2]);
+  float u1 = dpp_xor2(b1 ? r[1] : r[3]);
+  if (b1) { r[0] = u0; r[1] = u1; } else { r[2] = u0; r[3] = u1; }
+}
+
+// four positions of one lane: 4 identity reads + 16 tap reads issued together, then the math
+__device__ __forceinline__ void sample4(const float* plane, const int (&self)[4], const Tap (&tp)[4],
+                                        float (&r)[4], bool gather) {
+  float idv[4], lt[4], rt[4], lb[4], rb[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    idv[j] = plane[self[j]];
+    lt[j] = plane[tp[j].o00]; rt[j] = plane[tp[j].o01];
+    lb[j] = plane[tp[j].o10]; rb[j] = plane[tp[j].o11];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    float v = (tp[j].w1 * lt[j] + tp[j].w2 * rt[j] + tp[j].w3 * lb[j] + tp[j].w4 * rb[j]);
+    v = (tp[j].valid && gather) ? v : 0.f;
+    r[j] = idv[j] + v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// Persistent, double-buffered forward (points = 1, power-of-two W, H*W % 256 == 0).
+// ONE workgroup per CU walks over its share of tiles (a tile = cpb planes) with two LDS
+// buffers: the global loads of tile t+1 are in flight (in registers) while tile t is sampled
+// out of LDS, then written to the other buffer behind a single barrier.
+// DBG: ablation bits (1 no tap-table loads, 2 no gathers, 4 no stores, 8 no plane loads).
+// ----------------------------------------------------------------------------------------
+constexpr int FRQ_MAX_F4 = 4;  // float4 per thread per tile: tiles are <= 16 384 floats
+
+template <bool CONSEC, bool DBG>
+__global__ __launch_bounds__(FRP_BLOCK) void fr_forward_persist(const float* __restrict__ feat,
+                                                                const float* __restrict__ table, int C, int H,
+                                                                int logW, int logHW, int cpb, int tiles,
+                                                                int bufsz, float* __restrict__ out, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int W = 1 << logW, HW = 1 << logHW;
+  const int pitch = W + 1;
+  const int psz = H * pitch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tpb = (tiles + gridDim.x - 1) / gridDim.x;
+  const int t0 = blockIdx.x * tpb;
+  const int t1 = min(tiles, t0 + tpb);
+  if (t0 >= t1) return;
+  const int tile_f4 = (cpb * HW) >> 2;  // float4 per tile (<= 4096)
+  const int tiles_per_img = C / cpb;    // C % cpb == 0 is a launch precondition
+  const bool no_taps = DBG && (dbg & 1), no_gather = DBG && (dbg & 2), no_store = DBG && (dbg & 4),
+             no_load = DBG && (dbg & 8);
+
+  float4 v[FRQ_MAX_F4];
+  auto load_tile = [&](int t) {
+    const float4* s4 = reinterpret_cast<const float4*>(feat + (size_t)t * cpb * HW);
+#pragma unroll
+    for (int k = 0; k < FRQ_MAX_F4; k++) {
+      const int i = tid + k * FRP_BLOCK;
+      if (i < tile_f4) v[k] = s4[i];
+    }
+  };
+  auto write_tile = [&](float* buf) {
+#pragma unroll
+    for (int k = 0; k < FRQ_MAX_F4; k++) {
+      const int i = tid + k * FRP_BLOCK;
+      if (i < tile_f4) {
+        const int e = i << 2;
+        const int ch = e >> logHW, r = e & (HW - 1);
+        float* d = buf + ch * psz + (r >> logW) * pitch + (r & (W - 1));
+        d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+      }
+    }
+  };
+
+  load_tile(t0);
+  write_tile(lds);
+  __syncthreads();
+  for (int t = t0; t < t1; t++) {
+    const float* buf = lds + ((t - t0) & 1) * bufsz;
+    float* nbuf = lds + (((t - t0) & 1) ^ 1) * bufsz;
+    if (t + 1 < t1 && !no_load) load_tile(t + 1);
+    const int n = t / tiles_per_img;
+    const float* tb = table + (size_t)n * HW * 5;
+    float* dst = out + (size_t)t * cpb * HW;
+    if (CONSEC) {
+      // a wavefront owns 256 consecutive positions; for j = 0..3 lane l works on position
+      // 64 j + l: the 64 lanes of every LDS instruction address 64 consecutive rows (or columns)
+      // of the pitch-(W+1) plane => distinct banks.  Results are transposed inside 4-lane
+      // groups so that every lane still issues one 16-byte store.
+      const int chunks = HW >> 8;
+      constexpr int NWAVES = FRP_BLOCK / 64;
+      for (int chunk = wave; chunk < chunks; chunk += NWAVES) {
+        Tap tp[4];
+        int self[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int p = (chunk << 8) + 64 * j + lane;
+          self[j] = (p >> logW) * pitch + (p & (W - 1));
+          if (no_taps) {
+            tp[j].o00 = tp[j].o01 = tp[j].o10 = tp[j].o11 = self[j];
+            tp[j].w1 = tp[j].w2 = tp[j].w3 = tp[j].w4 = 0.25f;
+            tp[j].valid = true;
+          } else {
+            tp[j] = unpack_tap(tb + (size_t)p * 5, pitch);
+          }
+        }
+        const int store_off = (chunk << 8) + 64 * (lane & 3) + (lane & ~3);
+        for (int ch = 0; ch < cpb; ch++) {
+          float r[4];
+          sample4(buf + ch * psz, self, tp, r, !no_gather);
+          quad_transpose(r, lane);
+          if (!no_store || r[0] == 12345.678f)
+            *reinterpret_cast<float4*>(dst + ((size_t)ch << logHW) + store_off) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+      }
+    } else {
+      const float4* tb4 = reinterpret_cast<const float4*>(tb);
+      const int quads = HW >> 2;
+      for (int qd = tid; qd < quads; qd += FRP_BLOCK) {
+        const int hw0 = qd << 2;
+        const int s0 = (hw0 >> logW) * pitch + (hw0 & (W - 1));
+        const int self[4] = {s0, s0 + 1, s0 + 2, s0 + 3};
+        Tap tp[4];
+        if (no_taps) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            tp[j].o00 = tp[j].o01 = tp[j].o10 = tp[j].o11 = self[j];
+            tp[j].w1 = tp[j].w2 = tp[j].w3 = tp[j].w4 = 0.25f;
+            tp[j].valid = true;
+          }
+        } else {
+          float td[20];
+#pragma unroll
+          for (int k = 0; k < 5; k++) {
+            const float4 q = tb4[qd * 5 + k];
+            td[4 * k] = q.x; td[4 * k + 1] = q.y; td[4 * k + 2] = q.z; td[4 * k + 3] = q.w;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) tp[j] = unpack_tap(td + 5 * j, pitch);
+        }
+        for (int ch = 0; ch < cpb; ch++) {
+          float r[4];
+          sample4(buf + ch * psz, self, tp, r, !no_gather);
+          if (!no_store || r[0] == 12345.678f)
+            *reinterpret_cast<float4*>(dst + ((size_t)ch << logHW) + hw0) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+      }
+    }
+    if (t + 1 < t1) write_tile(nbuf);
+    __syncthreads();
+  }
+}
+
 // dynamic LDS above 64 KB has to be opted into once per kernel
 template <typename K>
-inline void allow_big_lds(K kernel) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            FRP_LDS_FLOATS * (int)sizeof(float));
+inline void allow_big_lds(K kernel, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            bytes);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -386,33 +615,104 @@ inline int plane_cpb(int C, int H, int W) {
   if (psz > FRP_LDS_FLOATS) return 0;
   int cpb = FRP_LDS_FLOATS / psz;
   if (cpb > C) cpb = C;
-  // keep at least ~1024 workgroups in flight when the level is large enough
   return cpb < 1 ? 0 : cpb;
+}
+
+inline int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) l++;
+  return l;
+}
+
+inline int cu_count() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  return n_cu;
 }
 
 }  // namespace
 
+size_t r3k_fr_workspace_bytes(int N, int H, int W, int points) {
+  if (N <= 0 || H <= 0 || W <= 0 || points <= 0) return 256;
+  return ((size_t)N * H * W * points * 5 * sizeof(float) + 255) / 256 * 256 + 256;
+}
+
 int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, int W, float scale,
-                   int points, float* out, hipStream_t stream) {
+                   int points, float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (points != 1 && points != 5) return -1;
   if (N == 0 || C == 0 || H == 0 || W == 0) return 0;
   int cpb = plane_cpb(C, H, W);
-  bool plane = (g_r3_fr_impl == 2) || (g_r3_fr_impl == 0);
-  if (cpb == 0) plane = false;
+  const bool plane = g_r3_fr_impl != 1 && cpb > 0;
+  const int logW = ilog2_exact(W), logHW = ilog2_exact(H * W);
+  // Measured on MI355X (tools/microbench.py fr, tools/fr_ablate.py; level 0 = 4x256x128x128):
+  // plane 47 us, persist-quad 53 us, persist-consec 49 us; with HBM loads OR stores disabled the
+  // persistent kernel drops to 32-34 us, with both to 25 us: a wave that stores and then waits
+  // for its next loads also waits for the store acknowledgements (one in-order vmcnt queue), which
+  // costs the persistent form what double buffering gains.  The plain plane kernel (workgroups
+  // exit right after their stores) is therefore the default; 5 / 6 select the persistent forms.
+  const bool persist = plane && (g_r3_fr_impl == 5 || g_r3_fr_impl == 6) && points == 1 && ws && logW >= 2 && logHW >= 8 &&
+                       ws_bytes >= r3k_fr_workspace_bytes(N, H, W, points) && aligned16(feat) &&
+                       aligned16(out) && aligned16(ws);
+  if (persist) {
+    // planes per tile: a power of two, tile <= 16 384 floats, >= 512 tiles when the level allows
+    int pc = 1;
+    while (pc * 2 * H * W <= 16384 && pc * 2 * H * (W + 1) <= FRP_LDS_FLOATS && C % (pc * 2) == 0 &&
+           (size_t)N * C / (pc * 2) >= 512)
+      pc *= 2;
+    float* table = reinterpret_cast<float*>(ws);
+    const int total = N * H * W;
+    hipLaunchKernelGGL(fr_taps_kernel<1>, dim3((total + 255) / 256), dim3(256), 0, stream, boxes, total, H, W,
+                       scale, table);
+    const int tiles = N * C / pc;
+    const int bufsz = ((pc * H * (W + 1)) + 3) & ~3;
+    const size_t lds = (size_t)2 * bufsz * sizeof(float);
+    static bool once = (allow_big_lds(fr_forward_persist<false, false>, 160 * 1024),
+                        allow_big_lds(fr_forward_persist<true, false>, 160 * 1024),
+                        allow_big_lds(fr_forward_persist<false, true>, 160 * 1024),
+                        allow_big_lds(fr_forward_persist<true, true>, 160 * 1024), true);
+    (void)once;
+    const int grid = tiles < cu_count() ? tiles : cu_count();
+    const bool consec = g_r3_fr_impl == 6;
+#define R3_PERSIST(CS, DB)                                                                                   \
+  hipLaunchKernelGGL((fr_forward_persist<CS, DB>), dim3(grid), dim3(FRP_BLOCK), lds, stream, feat, table, C, \
+                     H, logW, logHW, pc, tiles, bufsz, out, g_r3_fr_dbg)
+    if (g_r3_fr_dbg) { if (consec) R3_PERSIST(true, true); else R3_PERSIST(false, true); }
+    else { if (consec) R3_PERSIST(true, false); else R3_PERSIST(false, false); }
+#undef R3_PERSIST
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   if (plane) {
     // spread small levels over more workgroups: cap planes per workgroup so that the grid
     // has >= 512 workgroups when possible
     while (cpb > 1 && (size_t)N * ((C + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
     dim3 grid((C + cpb - 1) / cpb, N);
     size_t lds = (size_t)cpb * H * (W + 1) * sizeof(float);
-    static bool once = (allow_big_lds(fr_forward_plane<1, true>), allow_big_lds(fr_forward_plane<1, false>),
-                        allow_big_lds(fr_forward_plane<5, false>), true);
+    static bool once = (allow_big_lds(fr_forward_plane<1, true, 1>, FRP_LDS_FLOATS * 4),
+                        allow_big_lds(fr_forward_plane<1, true, 2>, FRP_LDS_FLOATS * 4),
+                        allow_big_lds(fr_forward_plane<1, true, 0>, FRP_LDS_FLOATS * 4),
+                        allow_big_lds(fr_forward_plane<1, false, 0>, FRP_LDS_FLOATS * 4),
+                        allow_big_lds(fr_forward_plane<5, false, 0>, FRP_LDS_FLOATS * 4), true);
     (void)once;
     const bool vec = (W % 4 == 0) && aligned16(feat) && aligned16(boxes) && aligned16(out);
-#define R3_FWD(P, V) hipLaunchKernelGGL((fr_forward_plane<P, V>), grid, dim3(FRP_BLOCK), lds, stream, feat, boxes, C, H, W, scale, cpb, out)
+    const bool full = (C % cpb) == 0;  // every workgroup owns exactly cpb planes
+#define R3_FWD(P, V, K) hipLaunchKernelGGL((fr_forward_plane<P, V, K>), grid, dim3(FRP_BLOCK), lds, stream, feat, boxes, C, H, W, scale, cpb, out)
     // points = 5 keeps 5 taps per position live: the quad form would spill, use the scalar form
-    if (points == 1) { if (vec) R3_FWD(1, true); else R3_FWD(1, false); }
-    else R3_FWD(5, false);
+    if (points == 1 && vec) {
+      if (full && cpb == 1) R3_FWD(1, true, 1);
+      else if (full && cpb == 2) R3_FWD(1, true, 2);
+      else R3_FWD(1, true, 0);
+    } else if (points == 1) {
+      R3_FWD(1, false, 0);
+    } else {
+      R3_FWD(5, false, 0);
+    }
 #undef R3_FWD
   } else {
     int HW = H * W;
@@ -436,14 +736,14 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
   if (points != 1 && points != 5) return -1;
   if (N == 0 || C == 0 || H == 0 || W == 0) return 0;
   int cpb = plane_cpb(C, H, W);
-  bool plane = (g_r3_fr_impl == 2) || (g_r3_fr_impl == 0);
-  if (cpb == 0) plane = false;
+  const bool plane = g_r3_fr_impl != 1 && cpb > 0;
   if (plane) {
     while (cpb > 1 && (size_t)N * ((C + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
     dim3 grid((C + cpb - 1) / cpb, N);
     size_t lds = (size_t)cpb * H * (W + 1) * sizeof(float);
-    static bool once = (allow_big_lds(fr_backward_plane<1, true>), allow_big_lds(fr_backward_plane<1, false>),
-                        allow_big_lds(fr_backward_plane<5, false>), true);
+    static bool once = (allow_big_lds(fr_backward_plane<1, true>, FRP_LDS_FLOATS * 4),
+                        allow_big_lds(fr_backward_plane<1, false>, FRP_LDS_FLOATS * 4),
+                        allow_big_lds(fr_backward_plane<5, false>, FRP_LDS_FLOATS * 4), true);
     (void)once;
     const bool vec = (W % 4 == 0) && aligned16(top_grad) && aligned16(boxes) && aligned16(bottom_grad);
 #define R3_BWD(P, V) hipLaunchKernelGGL((fr_backward_plane<P, V>), grid, dim3(FRP_BLOCK), lds, stream, top_grad, boxes, C, H, W, scale, cpb, overwrite, bottom_grad)

@@ -18,14 +18,17 @@ int r3k_nms(int geom, const float* dets, int det_stride, const int64_t* labels,
             const int64_t* order, int n, float thr, int sort_ascending, void* ws, size_t ws_bytes,
             int64_t* keep_out, int32_t* count_out, hipStream_t stream);
 
+size_t r3k_fr_workspace_bytes(int N, int H, int W, int points);
+// ws may be null (taps derived per channel plane); with a workspace: tap table + unpack kernel
 int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, int W, float scale,
-                   int points, float* out, hipStream_t stream);
+                   int points, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
 int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W,
                     float scale, int points, float* bottom_grad, int overwrite,
                     hipStream_t stream);
 
 // A/B knobs (r3det_set_option)
-extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane
+extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane, 3/4 tap-table, 5/6 persistent
+extern int g_r3_fr_dbg;    // ablation bits for the persistent forward kernel
 extern int g_r3_iou_impl;  // 0 auto
 extern int g_r3_nms_impl;  // 0 auto (queue pipeline), 1 tile kernels
 extern int g_r3_nms_qcap;  // 0 default; > 0 caps the global pair queue (tests the overflow path)

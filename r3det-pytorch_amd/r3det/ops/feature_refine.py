@@ -31,8 +31,11 @@ def fr_forward(features, best_rbboxes, spatial_scale, points, output):
         if profile_events is not None and H * W >= PROFILE_MIN_HW:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        _C.check(_C.lib().r3det_feature_refine_forward(_C.ptr(f), _C.ptr(b), N, C, H, W, float(spatial_scale),
-                                                       int(points), _C.ptr(o), _C.stream()), "fr_forward")
+        L = _C.lib()
+        wsb = int(L.r3det_fr_workspace_bytes(N, H, W, int(points)))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=f.device)
+        _C.check(L.r3det_feature_refine_forward(_C.ptr(f), _C.ptr(b), N, C, H, W, float(spatial_scale),
+                                                int(points), _C.ptr(o), _C.ptr(ws), wsb, _C.stream()), "fr_forward")
         if ev is not None:
             ev[1].record()
             profile_events.append(ev)

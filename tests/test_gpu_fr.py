@@ -16,7 +16,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.fixture(params=[1, 2], ids=["generic", "lds-plane"])
+@pytest.fixture(params=[1, 2, 5, 6, 0], ids=["generic", "lds-plane", "persist-quad", "persist-consec", "auto"])
 def impl(request):
     from r3det import _C
     _C.set_option("fr_impl", request.param)

@@ -89,7 +89,9 @@ def bench_fr():
                     else:
                         fr_forward(f, bb, 1.0 / s, 1, o)
                 return run
-            var = {"fwd plane": mk(2, b), "fwd generic": mk(1, b), "fwd plane adv": mk(2, advb[lvl]),
+            var = {"fwd persist csc": mk(6, b), "fwd persist quad": mk(5, b),
+                   "fwd plane": mk(2, b), "fwd generic": mk(1, b),
+                   "fwd auto adv": mk(0, advb[lvl]),
                    "bwd plane": mk(2, b, True), "bwd generic": mk(1, b, True)}
             for k, (med, mn) in time_variants(var).items():
                 print(f"fr   N={N} level{lvl} {tuple(f.shape)} {k:14s} med {med:8.1f} us  min {mn:8.1f} us  "
