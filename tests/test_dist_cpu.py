@@ -1,0 +1,95 @@
+"""CPU, world_size 2 over gloo: the image-parallel plumbing of r3det.dist_infer -- tile
+sharding, packing, the single exchange step (gather of detections) and the max-over-ranks
+timing convention that bench.py uses on RCCL."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_detections(tile):
+    """Deterministic per-tile 'detections' so rank 0 can verify what every rank produced."""
+    g = torch.Generator().manual_seed(1000 + tile)
+    k = 5 + (tile * 7) % 40
+    dets = torch.rand(k, 6, generator=g)
+    labels = torch.randint(0, 15, (k,), generator=g)
+    return dets, labels
+
+
+def _worker(rank, world, port, num_tiles, batch, out_path):
+    for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from r3det import dist_infer as di
+    r, lr, w = di.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    mine = di.shard_tiles(num_tiles, rank, world)
+    collected = {}
+    for b0 in range(0, len(mine), batch):
+        tiles = mine[b0:b0 + batch]
+        dl = [_fake_detections(t) for t in tiles]
+        packed, counts = di.pack_detections([d for d, _ in dl], [l for _, l in dl], max_per_img=64)
+        # ranks may hold a short last batch: pad to the batch size so collectives stay uniform
+        if packed.size(0) < batch:
+            pad = batch - packed.size(0)
+            packed = torch.cat([packed, packed.new_zeros(pad, 64, di.DET_COLS)])
+            counts = torch.cat([counts, counts.new_zeros(pad)])
+        gp, gc = di.gather_detections(packed, counts, dst=0)
+        if rank == 0:
+            for src in range(world):
+                src_tiles = di.shard_tiles(num_tiles, src, world)[b0:b0 + batch]
+                for j, (d, l) in enumerate(di.unpack_detections(gp[src], gc[src])[:len(src_tiles)]):
+                    collected[src_tiles[j]] = (d.clone(), l.clone())
+        else:
+            assert gp is None and gc is None
+    t = di.max_over_ranks(0.25 + rank, torch.device("cpu"))
+    assert t == pytest.approx(0.25 + world - 1)
+    di.barrier()
+    if rank == 0:
+        torch.save(collected, out_path)
+    dist.destroy_process_group()
+
+
+def test_image_parallel_gather_world2(tmp_path):
+    world, num_tiles, batch = 2, 13, 4
+    out = str(tmp_path / "collected.pt")
+    mp.spawn(_worker, args=(world, _free_port(), num_tiles, batch, out), nprocs=world, join=True)
+    got = torch.load(out)
+    assert sorted(got.keys()) == list(range(num_tiles))  # every tile exactly once
+    for t in range(num_tiles):
+        d, l = _fake_detections(t)
+        assert torch.equal(got[t][0], d) and torch.equal(got[t][1], l)
+
+
+def test_shard_and_pack_single_process():
+    sys.path.insert(0, os.path.join(ROOT, "r3det-pytorch_amd"))
+    from r3det import dist_infer as di
+    assert di.shard_tiles(10, 1, 4) == [1, 5, 9]
+    assert sum(len(di.shard_tiles(1024, r, 8)) for r in range(8)) == 1024
+    dets = [torch.rand(3, 6), torch.rand(0, 6), torch.rand(70, 6)]
+    labels = [torch.tensor([1, 2, 3]), torch.zeros(0, dtype=torch.long), torch.arange(70) % 15]
+    packed, counts = di.pack_detections(dets, labels, max_per_img=64)
+    assert packed.shape == (3, 64, 7) and counts.tolist() == [3, 0, 64]  # truncated at max_per_img
+    back = di.unpack_detections(packed, counts)
+    assert torch.equal(back[0][0], dets[0]) and torch.equal(back[0][1], labels[0])
+    assert back[1][0].shape == (0, 6)
+    assert torch.equal(back[2][0], dets[2][:64])
+    gp, gc = di.gather_detections(packed, counts)  # no process group: passthrough
+    assert gp[0] is packed and gc[0] is counts

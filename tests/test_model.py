@@ -1,0 +1,171 @@
+"""Host-side model glue (r3det/models): coder, anchors, best-anchor selection and the batched
+get_bboxes against a per-image / per-level restatement of the reference's loops
+(rotate_retina_head.py:117-179, rotate_anchor_head.py:590-675)."""
+import math
+
+import pytest
+import torch
+
+from r3det.models.coder import bbox2delta_v1, delta2bbox_v1
+from r3det.models.heads import RRetinaHead, RRetinaRefineHead, level_anchors
+from r3det import synthetic as syn
+
+
+def test_coder_roundtrip_and_clamps():
+    g = torch.Generator().manual_seed(0)
+    rois = syn.rand_rboxes(200, 1)
+    gt = syn.rand_rboxes(200, 2)
+    d = bbox2delta_v1(rois, gt)
+    back = delta2bbox_v1(rois, d)
+    assert torch.allclose(back, gt, rtol=1e-4, atol=1e-3)
+    # dw/dh are clamped to |log(16/1000)|, centres to the image when max_shape is given
+    big = torch.zeros(1, 5)
+    big[0, 2] = 100.0
+    out = delta2bbox_v1(torch.tensor([[10., 10., 4., 4., 0.]]), big)
+    assert out[0, 2].item() == pytest.approx(4 * math.exp(abs(math.log(16 / 1000))), rel=1e-6)
+    out = delta2bbox_v1(torch.tensor([[10., 10., 4., 4., 0.]]), torch.tensor([[-100., 500., 0., 0., 0.3]]),
+                        max_shape=(64, 128))
+    assert out[0, 0].item() == 0 and out[0, 1].item() == 63 and out[0, 4].item() == pytest.approx(0.3)
+
+
+def test_anchor_order_matches_grid_helper():
+    per_level = [level_anchors((1024 // s, 1024 // s), s, 'cpu') for s in syn.STRIDES]
+    assert [a.shape[0] for a in per_level] == [147456, 36864, 9216, 2304, 576]
+    assert torch.equal(torch.cat(per_level), syn.anchor_grid())
+    a0 = per_level[0][:9]
+    # ratio-major, scale-minor: first three anchors share ratio 1 (w == h), scales 4, 5.04, 6.35 x stride
+    assert torch.allclose(a0[:3, 2], a0[:3, 3])
+    assert a0[0, 2].item() == pytest.approx(32.0) and a0[2, 2].item() == pytest.approx(8 * 4 * 2 ** (2 / 3), rel=1e-6)
+    assert (a0[3, 2] > a0[3, 3]) and (a0[6, 2] < a0[6, 3])  # ratio 0.5 = h/w, then ratio 2
+    assert (per_level[0][9, :2] == torch.tensor([8., 0.])).all()  # x runs fastest
+
+
+def _loop_filter(head, cls_scores, bbox_preds):
+    """Per-image restatement of filter_bboxes."""
+    N = cls_scores[0].size(0)
+    out = [[] for _ in range(N)]
+    for lvl, (cls, reg) in enumerate(zip(cls_scores, bbox_preds)):
+        anc = level_anchors(cls.shape[-2:], head.strides[lvl], cls.device).reshape(-1, 9, 5)
+        for i in range(N):
+            c = cls[i].permute(1, 2, 0).reshape(-1, 9, head.num_classes)
+            best = c.max(-1)[0].argmax(-1)
+            r = reg[i].permute(1, 2, 0).reshape(-1, 9, 5)
+            idx = torch.arange(r.size(0))
+            out[i].append(delta2bbox_v1(anc[idx, best], r[idx, best]))
+    return out
+
+
+def test_filter_bboxes_matches_loop():
+    torch.manual_seed(3)
+    head = RRetinaHead(num_classes=15, in_channels=8, feat_channels=8, strides=(8, 16))
+    feats = [torch.randn(2, 8, 8, 8), torch.randn(2, 8, 4, 4)]
+    with torch.no_grad():
+        cls, reg = head(feats)
+        cls = [c + torch.randn_like(c) for c in cls]
+        reg = [r + 0.2 * torch.randn_like(r) for r in reg]
+    got = head.filter_bboxes(cls, reg)
+    want = _loop_filter(head, cls, reg)
+    for i in range(2):
+        for l in range(2):
+            assert got[i][l].shape == (feats[l].shape[-1] ** 2, 5)
+            assert torch.equal(got[i][l], want[i][l])
+
+
+def test_state_dict_names_and_param_count():
+    from r3det.models import R3Det
+    m = R3Det()
+    keys = m.state_dict().keys()
+    for k in ["backbone.layer1.0.conv1.weight", "backbone.layer4.2.bn3.running_var", "neck.lateral_convs.0.conv.weight",
+              "neck.fpn_convs.4.conv.bias", "bbox_head.cls_convs.3.conv.weight", "bbox_head.retina_reg.bias",
+              "feat_refine_module.0.conv_5_1.weight", "refine_head.0.retina_cls.weight"]:
+        assert k in keys, k
+    assert m.bbox_head.retina_cls.out_channels == 9 * 15 and m.refine_head[0].retina_cls.out_channels == 15
+    n = sum(p.numel() for p in m.parameters())
+    assert 41e6 < n < 43e6  # ~42 M parameters
+    assert not m.backbone.layer1[0].conv1.weight.requires_grad  # frozen_stages=1
+    assert m.backbone.layer2[0].conv1.weight.requires_grad
+    assert m.bbox_head.retina_cls.bias[0].item() == pytest.approx(-math.log(99), rel=1e-6)
+
+
+def _loop_get_bboxes(head, cls_scores, bbox_preds, img_shape, cfg, rois):
+    """Per-image, per-level restatement (rotate_anchor_head.py:590-675)."""
+    from r3det.core.post_processing import multiclass_nms_rotated
+    N = cls_scores[0].size(0)
+    res = []
+    for i in range(N):
+        mb, ms = [], []
+        for l, (cls, reg) in enumerate(zip(cls_scores, bbox_preds)):
+            scores = cls[i].permute(1, 2, 0).reshape(-1, head.cls_out_channels).sigmoid()
+            pred = reg[i].permute(1, 2, 0).reshape(-1, 5)
+            anc = rois[i][l] if rois is not None else level_anchors(cls.shape[-2:], head.strides[l], cls.device)
+            if 0 < cfg['nms_pre'] < scores.shape[0]:
+                top = scores.max(1)[0].topk(cfg['nms_pre'])[1]
+                anc, pred, scores = anc[top], pred[top], scores[top]
+            mb.append(delta2bbox_v1(anc, pred, max_shape=img_shape))
+            ms.append(scores)
+        mb, ms = torch.cat(mb), torch.cat(ms)
+        ms = torch.cat([ms, ms.new_zeros(ms.shape[0], 1)], 1)
+        res.append(multiclass_nms_rotated(mb, ms, cfg['score_thr'], cfg['nms'], cfg['max_per_img']))
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("refine", [False, True])
+def test_batched_get_bboxes_matches_loop(refine):
+    torch.manual_seed(5)
+    dev = torch.device('cuda')
+    cfg = dict(nms_pre=50, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=2000)
+    head = (RRetinaRefineHead if refine else RRetinaHead)(num_classes=15, in_channels=8, feat_channels=8,
+                                                           strides=(8, 16, 32), test_cfg=cfg).to(dev)
+    sizes = [16, 8, 4]
+    N = 3
+    cls = [torch.randn(N, head.num_anchors * 15, s, s, device=dev) * 2 - 3 for s in sizes]
+    reg = [torch.randn(N, head.num_anchors * 5, s, s, device=dev) * 0.3 for s in sizes]
+    rois = None
+    if refine:
+        rois = [[syn.fr_level_boxes(1, s, s, st, 10 * i + j, device=dev) for j, (s, st) in enumerate(zip(sizes, (8, 16, 32)))]
+                for i in range(N)]
+    got = head.get_bboxes(cls, reg, (128, 128), cfg, rois=rois)
+    want = _loop_get_bboxes(head, cls, reg, (128, 128), cfg, rois)
+    assert len(got) == N
+    for (gd, gl), (wd, wl) in zip(got, want):
+        assert gd.shape[0] > 0
+        assert torch.equal(gd, wd) and torch.equal(gl, wl)
+
+
+@pytest.mark.gpu
+def test_r3det_end_to_end_small():
+    """Full R3Det simple_test on 2 x 256^2 tiles: runs through FRM + refine head + NMS, output
+    format of the reference (dets (k,6), labels (k,)), deterministic, keep lists consistent with
+    a second NMS pass."""
+    from r3det.models import R3Det, RRetinaNet
+    from r3det.models.detectors import calibrate_score_bias
+    from r3det.ops import batched_rnms
+    torch.manual_seed(7)
+    dev = torch.device('cuda')
+    m = R3Det().eval().to(dev)
+    img = torch.randn(2, 3, 256, 256, device=dev)
+    calibrate_score_bias(m, img, frac=0.02)
+    res = m.simple_test(img)
+    assert len(res) == 2
+    # determinism of the custom-op part on fixed conv outputs (MIOpen convs themselves may pick
+    # non-deterministic algorithms between runs, so the whole model is not compared bitwise)
+    with torch.no_grad():
+        x = m.extract_feat(img)
+        cls, reg = m.bbox_head(x)
+        rois = m.bbox_head.filter_bboxes(cls, reg)
+        xr = m.feat_refine_module[0](x, rois)
+        cls, reg = m.refine_head[0](xr)
+        res = m.refine_head[0].get_bboxes(cls, reg, img.shape[-2:], m.test_cfg, rois=rois)
+        res2 = m.refine_head[0].get_bboxes(cls, reg, img.shape[-2:], m.test_cfg, rois=rois)
+    for (d, l), (d2, l2) in zip(res, res2):
+        assert d.dim() == 2 and d.size(1) == 6 and l.shape == (d.size(0),) and l.dtype == torch.long
+        assert 0 < d.size(0) <= 2000 and (d[:, 5] > 0.05).all() and l.min() >= 0 and l.max() < 15
+        assert torch.equal(d, d2) and torch.equal(l, l2)
+        # idempotence: NMS of the kept set keeps everything
+        kept, keep = batched_rnms(d[:, :5].contiguous(), d[:, 5].contiguous(), l, 0.1)
+        assert keep.numel() == d.size(0)
+    r = RRetinaNet().eval().to(dev)
+    calibrate_score_bias(r, img, frac=0.005)
+    out = r.simple_test(img)
+    assert len(out) == 2 and out[0][0].size(1) == 6
