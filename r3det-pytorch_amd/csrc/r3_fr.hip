@@ -473,6 +473,227 @@ __device__ __forceinline__ void sample4(const float* plane, const int (&self)[4]
 }
 
 // ----------------------------------------------------------------------------------------
+// "skew" forward kernel (points = 1; planes of 4096 or 16384 floats, W a power of two): the
+// default for the two large pyramid levels.  It removes the three costs the PMC / ablation
+// runs found in the plane kernels above (profiles/r01_fr_forward_pmc.txt, tools/fr_ablate.py):
+//   * LDS bank conflicts (72 % of LDS-active cycles): a lane owns 4 ADJACENT positions, whose
+//     sample rows are 4 apart; with the usual odd pitch 4 l (W+1) = 4 l (mod 32) only hits 8
+//     banks.  Here element (r, c) lives at r W + c + (r >> 2): rows 4 l + j of one column map
+//     to banks c + l + const -- 32 distinct banks;
+//   * the identity term is not re-read from LDS: the thread that staged float4 #i is the thread
+//     that samples quad #i, so the four values are still in its registers;
+//   * taps come from the 20-byte table (built once per position, not once per channel plane),
+//     requested one quad ahead and BEFORE the current store; the loop is fully unrolled so the
+//     compiler can wait with vmcnt(1) (one in-order queue for loads and stores on gfx950).
+// Table entry for this kernel: packed = x_low | y_low << 10 | dx << 20 | dy << 21 | valid << 22.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fr_taps_xy_kernel(const float* __restrict__ boxes, int total, int H,
+                                                         int W, float scale, float* __restrict__ table) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= total) return;
+  Tap t[1];
+  make_taps<1>(boxes + (size_t)pos * 5, scale, H, W, 1024, t);  // pitch 1024: o00 = y_low << 10 | x_low
+  int packed = 0;
+  if (t[0].valid)
+    packed = t[0].o00 | ((t[0].o01 - t[0].o00) << 20) | ((t[0].o10 != t[0].o00 ? 1 : 0) << 21) | (1 << 22);
+  float* d = table + (size_t)pos * 5;
+  d[0] = __int_as_float(packed);
+  d[1] = t[0].w1; d[2] = t[0].w2; d[3] = t[0].w3; d[4] = t[0].w4;
+}
+
+constexpr int FRS_BLOCK = 512;
+
+template <int F4>  // float4 (= quads) per thread: plane = 4 * F4 * FRS_BLOCK floats
+__global__ __launch_bounds__(FRS_BLOCK) void fr_forward_skew(const float* __restrict__ feat,
+                                                             const float* __restrict__ table, int C, int logW,
+                                                             int logHW, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int W = 1 << logW, HW = 1 << logHW;
+  const int tid = threadIdx.x;
+  const int plane = blockIdx.x;  // n * C + c
+  const int n = plane / C;
+  const float4* s4 = reinterpret_cast<const float4*>(feat + ((size_t)plane << logHW));
+  const float4* tb4 = reinterpret_cast<const float4*>(table + ((size_t)n << logHW) * 5);
+  float4* d4 = reinterpret_cast<float4*>(out + ((size_t)plane << logHW));
+
+  float4 v[F4];
+#pragma unroll
+  for (int k = 0; k < F4; k++) v[k] = s4[tid + k * FRS_BLOCK];
+  float4 tq[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) tq[k] = tb4[tid * 5 + k];
+#pragma unroll
+  for (int k = 0; k < F4; k++) {
+    const int e = (tid + k * FRS_BLOCK) << 2;
+    const int a = e + ((e >> logW) >> 2);
+    lds[a] = v[k].x; lds[a + 1] = v[k].y; lds[a + 2] = v[k].z; lds[a + 3] = v[k].w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < F4; k++) {
+    const int qd = tid + k * FRS_BLOCK;
+    float td[20];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      td[4 * q] = tq[q].x; td[4 * q + 1] = tq[q].y; td[4 * q + 2] = tq[q].z; td[4 * q + 3] = tq[q].w;
+    }
+    if (k + 1 < F4) {
+#pragma unroll
+      for (int q = 0; q < 5; q++) tq[q] = tb4[(qd + FRS_BLOCK) * 5 + q];
+    }
+    const float idv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+    float lt[4], rt[4], lb[4], rb[4];
+    bool valid[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int packed = __float_as_int(td[5 * j]);
+      const int x = packed & 1023, y = (packed >> 10) & 1023;
+      const int dx = (packed >> 20) & 1, dy = (packed >> 21) & 1;
+      valid[j] = (packed >> 22) & 1;
+      const int y1 = y + dy;
+      const int a0 = (y << logW) + x + (y >> 2);
+      const int a1 = (y1 << logW) + x + (y1 >> 2);
+      lt[j] = lds[a0]; rt[j] = lds[a0 + dx];
+      lb[j] = lds[a1]; rb[j] = lds[a1 + dx];
+    }
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float val = (td[5 * j + 1] * lt[j] + td[5 * j + 2] * rt[j] + td[5 * j + 3] * lb[j] + td[5 * j + 4] * rb[j]);
+      r[j] = idv[j] + (valid[j] ? val : 0.f);
+    }
+    d4[qd] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// "chan" forward kernel (points = 1; planes of 16384 or 4096 floats, power-of-two W): the form
+// the diagnosis converged on.  A plain copy THROUGH LDS with the same tiling and barrier runs at
+// the device-copy rate (tools/probes/lds_copy_probe.hip: 6.7 TB/s), so staging is free; what
+// made every per-plane kernel above land at ~44 us is the per-position sample data (box or tap
+// record, 8-20 B) that each of the C channel planes re-reads through the CU's vector-memory
+// path: 2.5 x the HBM traffic.  Here a workgroup owns G consecutive channels of one image and
+// keeps the taps of ALL positions in registers (packed cell + the two fractions, 3 VGPR per
+// position), so they are read once per G planes; planes are double-buffered through LDS in the
+// skewed, conflict-free layout of the skew kernel.
+// Table for this kernel (fr_taps3_kernel), per quad of 4 positions: 12 floats
+//   [packed x4 | ly x4 | lx x4],  packed = x_low | y_low << 10 | dx << 20 | dy << 21 | valid << 22.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fr_taps3_kernel(const float* __restrict__ boxes, int total, int H,
+                                                       int W, float scale, float* __restrict__ table) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= total) return;
+  // same coordinate logic as make_tap (feature_refine_kernel.cu:22-52), keeping ly / lx
+  float y = boxes[(size_t)pos * 5] * scale;      // sic: row <- x_ctr
+  float x = boxes[(size_t)pos * 5 + 1] * scale;  //      col <- y_ctr
+  int packed = 0;
+  float ly = 0.f, lx = 0.f;
+  if (!(y < -1.0 || y > H || x < -1.0 || x > W)) {
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    int y_low = (int)y, x_low = (int)x, dy = 1, dx = 1;
+    if (y_low >= H - 1) { y_low = H - 1; y = (float)y_low; dy = 0; }
+    if (x_low >= W - 1) { x_low = W - 1; x = (float)x_low; dx = 0; }
+    ly = y - y_low;
+    lx = x - x_low;
+    packed = x_low | (y_low << 10) | (dx << 20) | (dy << 21) | (1 << 22);
+  }
+  float* d = table + (size_t)(pos >> 2) * 12 + (pos & 3);
+  d[0] = __int_as_float(packed);
+  d[4] = ly;
+  d[8] = lx;
+}
+
+constexpr int FRC_BLOCK = 1024;
+
+template <int F4>  // quads per thread: plane = 4 * F4 * FRC_BLOCK floats (F4 = 4 -> 128 x 128)
+__global__ __launch_bounds__(FRC_BLOCK) void fr_forward_chan(const float* __restrict__ feat,
+                                                             const float* __restrict__ table, int C, int G,
+                                                             int logW, int logHW, int bufsz,
+                                                             float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HW = 1 << logHW;
+  const int tid = threadIdx.x;
+  const int groups = C / G;
+  const int n = blockIdx.x / groups;
+  const int c0 = (blockIdx.x - n * groups) * G;
+  const size_t plane0 = (size_t)n * C + c0;
+  const float4* tb4 = reinterpret_cast<const float4*>(table + ((size_t)n << logHW) * 3);
+
+  // taps of this thread's F4 quads -> registers (3 per position)
+  int pk[F4][4];
+  float ly[F4][4], lx[F4][4];
+#pragma unroll
+  for (int k = 0; k < F4; k++) {
+    const int qd = tid + k * FRC_BLOCK;
+    const float4 a = tb4[qd * 3], b = tb4[qd * 3 + 1], c = tb4[qd * 3 + 2];
+    pk[k][0] = __float_as_int(a.x); pk[k][1] = __float_as_int(a.y);
+    pk[k][2] = __float_as_int(a.z); pk[k][3] = __float_as_int(a.w);
+    ly[k][0] = b.x; ly[k][1] = b.y; ly[k][2] = b.z; ly[k][3] = b.w;
+    lx[k][0] = c.x; lx[k][1] = c.y; lx[k][2] = c.z; lx[k][3] = c.w;
+  }
+  float4 v[F4];
+  auto load_plane = [&](int c) {
+    const float4* s4 = reinterpret_cast<const float4*>(feat + ((plane0 + c) << logHW));
+#pragma unroll
+    for (int k = 0; k < F4; k++) v[k] = s4[tid + k * FRC_BLOCK];
+  };
+  auto write_plane = [&](float* buf) {
+#pragma unroll
+    for (int k = 0; k < F4; k++) {
+      const int e = (tid + k * FRC_BLOCK) << 2;
+      const int a = e + ((e >> logW) >> 2);
+      buf[a] = v[k].x; buf[a + 1] = v[k].y; buf[a + 2] = v[k].z; buf[a + 3] = v[k].w;
+    }
+  };
+  load_plane(0);
+  write_plane(lds);
+  __syncthreads();
+  for (int c = 0; c < G; c++) {
+    const float* buf = lds + (c & 1) * bufsz;
+    if (c + 1 < G) load_plane(c + 1);  // in flight (in v[]) while plane c is sampled out of LDS
+    float4* d4 = reinterpret_cast<float4*>(out + ((plane0 + c) << logHW));
+#pragma unroll
+    for (int k = 0; k < F4; k++) {
+      const int e = (tid + k * FRC_BLOCK) << 2;
+      const int self = e + ((e >> logW) >> 2);
+      float r[4];
+      // two positions at a time: 10 LDS reads in flight, modest register footprint (the taps of
+      // all F4 quads already hold 12 * F4 VGPRs)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        float idv[2], lt[2], rt[2], lb[2], rb[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          const int j = 2 * h + jj;
+          const int p = pk[k][j];
+          const int x = p & 1023, y = (p >> 10) & 1023;
+          const int dx = (p >> 20) & 1, dy = (p >> 21) & 1;
+          const int y1 = y + dy;
+          const int a0 = (y << logW) + x + (y >> 2);
+          const int a1 = (y1 << logW) + x + (y1 >> 2);
+          idv[jj] = buf[self + j];
+          lt[jj] = buf[a0]; rt[jj] = buf[a0 + dx];
+          lb[jj] = buf[a1]; rb[jj] = buf[a1 + dx];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          const int j = 2 * h + jj;
+          const float hy = (float)(1. - (double)ly[k][j]);
+          const float hx = (float)(1. - (double)lx[k][j]);
+          const float w1 = hy * hx, w2 = hy * lx[k][j], w3 = ly[k][j] * hx, w4 = ly[k][j] * lx[k][j];
+          const float val = (w1 * lt[jj] + w2 * rt[jj] + w3 * lb[jj] + w4 * rb[jj]);
+          r[j] = idv[jj] + (((pk[k][j] >> 22) & 1) ? val : 0.f);
+        }
+      }
+      d4[tid + k * FRC_BLOCK] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+    if (c + 1 < G) write_plane(lds + ((c + 1) & 1) * bufsz);
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // Persistent, double-buffered forward (points = 1, power-of-two W, H*W % 256 == 0).
 // ONE workgroup per CU walks over its share of tiles (a tile = cpb planes) with two LDS
 // buffers: the global loads of tile t+1 are in flight (in registers) while tile t is sampled
@@ -660,6 +881,49 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
   const bool persist = plane && (g_r3_fr_impl == 5 || g_r3_fr_impl == 6) && points == 1 && ws && logW >= 2 && logHW >= 8 &&
                        ws_bytes >= r3k_fr_workspace_bytes(N, H, W, points) && aligned16(feat) &&
                        aligned16(out) && aligned16(ws);
+  // Round-1 status of the forward variants at level 0 (4x256x128x128, tools/microbench.py fr):
+  // plane 43.5 us, chan 43.8 (spills), skew 45.4, persist 49-53; a copy through LDS with the same
+  // tiling runs at 20 us (tools/probes/lds_copy_probe.hip).  None of the workspace variants beats
+  // the workspace-free plane kernel yet, so it stays the default; 5-8 select the others.
+  const bool skew = plane && (g_r3_fr_impl == 7 || g_r3_fr_impl == 8) && points == 1 && ws && logW >= 2 &&
+                    W <= 1024 && H <= 1024 && (logHW == 12 || logHW == 14) &&
+                    ws_bytes >= r3k_fr_workspace_bytes(N, H, W, points) && aligned16(feat) && aligned16(out) &&
+                    aligned16(ws);
+  // channels per workgroup for the chan kernel: a power of two, >= one workgroup per CU
+  int G = 1;
+  while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
+  const bool chan = skew && g_r3_fr_impl == 8 && G >= 2;
+  if (chan) {
+    float* table = reinterpret_cast<float*>(ws);
+    const int total = N * H * W;
+    hipLaunchKernelGGL(fr_taps3_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, boxes, total, H, W,
+                       scale, table);
+    static bool once = (allow_big_lds(fr_forward_chan<4>, 160 * 1024), allow_big_lds(fr_forward_chan<1>, 160 * 1024), true);
+    (void)once;
+    const int bufsz = (H * W + H / 4 + 7) & ~3;
+    const size_t lds = (size_t)2 * bufsz * sizeof(float);
+    if (logHW == 14)
+      hipLaunchKernelGGL(fr_forward_chan<4>, dim3(N * C / G), dim3(FRC_BLOCK), lds, stream, feat, table, C, G, logW,
+                         logHW, bufsz, out);
+    else
+      hipLaunchKernelGGL(fr_forward_chan<1>, dim3(N * C / G), dim3(FRC_BLOCK), lds, stream, feat, table, C, G, logW,
+                         logHW, bufsz, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
+  if (skew) {
+    float* table = reinterpret_cast<float*>(ws);
+    const int total = N * H * W;
+    hipLaunchKernelGGL(fr_taps_xy_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, boxes, total, H, W,
+                       scale, table);
+    static bool once = (allow_big_lds(fr_forward_skew<8>, 68 * 1024), allow_big_lds(fr_forward_skew<2>, 68 * 1024), true);
+    (void)once;
+    const size_t lds = ((size_t)H * W + H / 4 + 4) * sizeof(float);
+    if (logHW == 14)
+      hipLaunchKernelGGL(fr_forward_skew<8>, dim3(N * C), dim3(FRS_BLOCK), lds, stream, feat, table, C, logW, logHW, out);
+    else
+      hipLaunchKernelGGL(fr_forward_skew<2>, dim3(N * C), dim3(FRS_BLOCK), lds, stream, feat, table, C, logW, logHW, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   if (persist) {
     // planes per tile: a power of two, tile <= 16 384 floats, >= 512 tiles when the level allows
     int pc = 1;

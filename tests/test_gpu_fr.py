@@ -16,7 +16,8 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.fixture(params=[1, 2, 5, 6, 0], ids=["generic", "lds-plane", "persist-quad", "persist-consec", "auto"])
+@pytest.fixture(params=[1, 2, 5, 6, 7, 8, 0],
+                ids=["generic", "lds-plane", "persist-quad", "persist-consec", "skew", "chan", "auto"])
 def impl(request):
     from r3det import _C
     _C.set_option("fr_impl", request.param)
@@ -25,7 +26,8 @@ def impl(request):
 
 
 SHAPES = [(2, 8, 16, 16, 8), (1, 5, 7, 13, 16), (2, 3, 128, 128, 8), (1, 40, 32, 32, 32), (3, 2, 1, 1, 128),
-          (1, 2, 8, 8, 128)]
+          (1, 2, 8, 8, 128), (2, 5, 64, 64, 16), (1, 3, 32, 128, 8), (1, 2, 256, 64, 8), (2, 512, 64, 64, 16),
+          (1, 512, 128, 128, 8)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
