@@ -666,7 +666,11 @@ __global__ __launch_bounds__(FRC_BLOCK) void fr_forward_chan(const float* __rest
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
           const int j = 2 * h + jj;
-          const int p = pk[k][j];
+          int p = pk[k][j];
+          // opaque copy: stops LICM from hoisting the 8 addresses + 4 weights of every position out
+          // of the channel loop (16 positions x 12 values do not fit the register file: 356 B/lane
+          // of scratch without this)
+          asm volatile("" : "+v"(p));
           const int x = p & 1023, y = (p >> 10) & 1023;
           const int dx = (p >> 20) & 1, dy = (p >> 21) & 1;
           const int y1 = y + dy;
@@ -679,14 +683,21 @@ __global__ __launch_bounds__(FRC_BLOCK) void fr_forward_chan(const float* __rest
 #pragma unroll
         for (int jj = 0; jj < 2; jj++) {
           const int j = 2 * h + jj;
-          const float hy = (float)(1. - (double)ly[k][j]);
-          const float hx = (float)(1. - (double)lx[k][j]);
-          const float w1 = hy * hx, w2 = hy * lx[k][j], w3 = ly[k][j] * hx, w4 = ly[k][j] * lx[k][j];
+          float fy = ly[k][j], fx = lx[k][j];
+          asm volatile("" : "+v"(fy), "+v"(fx));
+          // 1.f - f == (float)(1. - (double)f) for every f in [0, 1): the double difference is
+          // exact when f >= 2^-29 and both forms round to 1.0f below that, so the reference's
+          // double-typed "1. - ly" (feature_refine_kernel.cu:53-54) needs no fp64 here
+          const float hy = 1.f - fy;
+          const float hx = 1.f - fx;
+          const float w1 = hy * hx, w2 = hy * fx, w3 = fy * hx, w4 = fy * fx;
           const float val = (w1 * lt[jj] + w2 * rt[jj] + w3 * lb[jj] + w4 * rb[jj]);
           r[j] = idv[jj] + (((pk[k][j] >> 22) & 1) ? val : 0.f);
         }
       }
       d4[tid + k * FRC_BLOCK] = make_float4(r[0], r[1], r[2], r[3]);
+      // keep the quads sequential: interleaving all F4 of them for ILP costs > 128 VGPRs (spills)
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (c + 1 < G) write_plane(lds + ((c + 1) & 1) * bufsz);
     __syncthreads();
@@ -885,14 +896,18 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
   // plane 43.5 us, chan 43.8 (spills), skew 45.4, persist 49-53; a copy through LDS with the same
   // tiling runs at 20 us (tools/probes/lds_copy_probe.hip).  None of the workspace variants beats
   // the workspace-free plane kernel yet, so it stays the default; 5-8 select the others.
-  const bool skew = plane && (g_r3_fr_impl == 7 || g_r3_fr_impl == 8) && points == 1 && ws && logW >= 2 &&
+  // ... until the chan kernel kept its taps in registers WITHOUT spilling (an opaque copy stops LICM
+  // from hoisting 12 values per position out of the channel loop): 34 us at level 0 => default for
+  // 128 x 128 planes when the batch gives every workgroup >= 2 channels.
+  const bool skew = plane && (g_r3_fr_impl == 7 || g_r3_fr_impl == 8 || (g_r3_fr_impl == 0 && logHW == 14)) &&
+                    points == 1 && ws && logW >= 2 &&
                     W <= 1024 && H <= 1024 && (logHW == 12 || logHW == 14) &&
                     ws_bytes >= r3k_fr_workspace_bytes(N, H, W, points) && aligned16(feat) && aligned16(out) &&
                     aligned16(ws);
   // channels per workgroup for the chan kernel: a power of two, >= one workgroup per CU
   int G = 1;
   while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
-  const bool chan = skew && g_r3_fr_impl == 8 && G >= 2;
+  const bool chan = skew && (g_r3_fr_impl == 8 || g_r3_fr_impl == 0) && G >= 2;
   if (chan) {
     float* table = reinterpret_cast<float*>(ws);
     const int total = N * H * W;
@@ -910,7 +925,7 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
                          logHW, bufsz, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
-  if (skew) {
+  if (skew && g_r3_fr_impl != 0) {
     float* table = reinterpret_cast<float*>(ws);
     const int total = N * H * W;
     hipLaunchKernelGGL(fr_taps_xy_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, boxes, total, H, W,
