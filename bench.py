@@ -222,15 +222,17 @@ def main():
                                    "to ~1 % candidates",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "nms_type": "v1",
                        "parallelism": f"image-parallel x{world}, all_gather of detections"},
-            "roofline": {"bound": "hbm", "kernel": "fr_forward_plane<1,true> (level 0: 4x256x128x128)",
+            "roofline": {"bound": "hbm", "kernel": "FR forward level 0 (4x256x128x128): fr_cell_table_kernel + "
+                                                   "fr_forward_cell<7,7,1024>, timed together",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(fr_ms * 1e3, 2),
                          "launches_timed": len(events)},
             "kept_per_image": [int(c) for c in counts.tolist()],
         }
-        del model
+        del model, img
         if not args.model_only:
+            torch.cuda.empty_cache()  # drop the model's cached blocks: the op-level runs start clean
             wl = build_hot_workload(device, seed=7)
             dt = timeit(lambda: hot_path_step(wl), 20, warm=3)
             line["hot_path"] = {"what": "custom ops only, same shapes: FR sampler x5 levels (N=4, C=256) + 4 x "

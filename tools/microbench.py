@@ -89,8 +89,7 @@ def bench_fr():
                     else:
                         fr_forward(f, bb, 1.0 / s, 1, o)
                 return run
-            var = {"fwd chan": mk(8, b), "fwd skew": mk(7, b), "fwd persist csc": mk(6, b), "fwd persist quad": mk(5, b),
-                   "fwd plane": mk(2, b), "fwd generic": mk(1, b),
+            var = {"fwd cell": mk(10, b), "fwd plane": mk(2, b), "fwd generic": mk(1, b),
                    "fwd auto adv": mk(0, advb[lvl]),
                    "bwd plane": mk(2, b, True), "bwd generic": mk(1, b, True)}
             for k, (med, mn) in time_variants(var).items():
