@@ -26,6 +26,12 @@
 // serves thr < 0, n >= 65536 and the A/B measurements.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
 #include "r3_geom_lds.h"
 #include "r3_kernels.h"
 
@@ -38,6 +44,14 @@ constexpr int MASK_WAVES = 4;   // tiles per workgroup of the tile kernels
 constexpr int NT = TILE * MASK_WAVES;
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Batched launches (blockIdx.z = image of a detection batch): every per-image array has the same
+// capacity, `counts[img]` is that image's box count and the strides (in elements) separate the
+// images.  counts == nullptr: one problem, n is the kernel argument (the plain operators).
+struct Batch {
+  const int* counts;
+  size_t recs, mask, nz, counter, queue, keep;
+};
 
 template <int GEOM>
 __global__ __launch_bounds__(256) void nms_prepare_kernel(const float* __restrict__ dets,
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
                                                         float thr, unsigned* __restrict__ gqueue,
                                                         unsigned qcap, unsigned* __restrict__ counter,
                                                         u64* __restrict__ mask, u64* __restrict__ nz,
-                                                        int nzw) {
+                                                        int nzw, Batch bt) {
   __shared__ float cols[MASK_WAVES][TILE][8];  // cx, cy, rad, ex, ey, label
   __shared__ unsigned short queue[SQ_CAP];
   __shared__ int qcount;
@@ -181,8 +195,19 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rb = blockIdx.y;
+  if (bt.counts) {  // cb stays the row pitch of mask; the image's own block count bounds the tiles
+    const int img = blockIdx.z;
+    n = bt.counts[img];
+    recs += img * bt.recs;
+    gqueue += img * bt.queue;
+    counter += img * bt.counter;
+    mask += img * bt.mask;
+    nz += img * bt.nz;
+    if (rb * TILE >= n) return;
+  }
+  const int cbn = (n + TILE - 1) / TILE;
   const int cblk = blockIdx.x * MASK_WAVES + wave;
-  const bool active = (cblk < cb) && (cblk >= rb);
+  const bool active = (cblk < cbn) && (cblk >= rb);
   if (tid == 0) qcount = 0;
   int col_size = 0;
   if (active) {
@@ -255,9 +280,17 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
                                                         const unsigned* __restrict__ gqueue, unsigned qcap,
                                                         const unsigned* __restrict__ counter,
                                                         u64* __restrict__ mask, u64* __restrict__ nz,
-                                                        int nzw) {
+                                                        int nzw, Batch bt) {
   __shared__ float2 pts[pts_slots<GEOM>() * 256];
   const LanePts<256> lp{pts + threadIdx.x};
+  if (bt.counts) {
+    const int img = blockIdx.z;
+    recs += img * bt.recs;
+    gqueue += img * bt.queue;
+    counter += img * bt.counter;
+    mask += img * bt.mask;
+    nz += img * bt.nz;
+  }
   unsigned total = *counter;
   if (total > qcap) total = qcap;
   for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
@@ -321,8 +354,17 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_sparse_kernel(const u64* 
                                                                  int n, int cb,
                                                                  const int64_t* __restrict__ order,
                                                                  int64_t* __restrict__ keep_out,
-                                                                 int32_t* __restrict__ count_out) {
+                                                                 int32_t* __restrict__ count_out, Batch bt) {
   extern __shared__ __attribute__((aligned(16))) u64 smem[];
+  if (bt.counts) {  // cb / nzw stay the pitches (and size the LDS arrays); n bounds the walk
+    const int img = blockIdx.z;
+    n = bt.counts[img];
+    mask += img * bt.mask;
+    nz += img * bt.nz;
+    keep_out += img * bt.keep;
+    count_out += img;
+  }
+  const int cbn = (n + TILE - 1) / TILE;
   u64* remv = smem;                 // cb words
   u64* kb_slot = smem + cb;         // [0] kept bits of the current block, [1] final count
   u64* nzbuf = smem + cb + 2;       // NZRING x 64 x nzw words
@@ -380,7 +422,7 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_sparse_kernel(const u64* 
   u64 wb = spec_word(1, wb_i);
 
   int cnt = 0;
-  for (int b = 0; b < cb; b++) {
+  for (int b = 0; b < cbn; b++) {
     // ---- stage 1: wave 0 resolves block b
     if (wave == 0) {
       const int nvalid = min(TILE, n - b * TILE);
@@ -427,7 +469,8 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_sparse_kernel(const u64* 
   __syncthreads();
   // sorted position -> original index, in parallel (kept off the serial path above)
   const int total = (int)kb_slot[1];
-  for (int i = tid; i < total; i += blockDim.x) keep_out[i] = order[keep_out[i]];
+  if (order)  // (the batched detection pipeline maps positions itself)
+    for (int i = tid; i < total; i += blockDim.x) keep_out[i] = order[keep_out[i]];
 }
 
 // rnms returns keep sorted by original index (rnms_kernel.cu:331-334): mark kept originals,
@@ -500,6 +543,13 @@ inline size_t layout(int n, void* ws, Layout* L) {
   return off + 256;
 }
 
+inline int drain_blocks(size_t qcap) {
+  size_t blocks = (qcap + 255) / 256;
+  return blocks > 1024 ? 1024 : blocks < 1 ? 1 : (int)blocks;
+}
+
+inline size_t reduce_lds_bytes(int cb, int nzw) { return (size_t)(cb + 2 + NZRING * TILE * nzw) * sizeof(u64); }
+
 template <int GEOM, bool LABEL>
 int run_nms(const float* dets, int det_stride, const int64_t* labels, const int64_t* order, int n,
             float thr, const Layout& L, int64_t* keep_out, int32_t* count_out, hipStream_t stream) {
@@ -520,20 +570,272 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
   size_t zbytes = (size_t)((char*)L.counter - (char*)L.mask);
   if (hipMemsetAsync(L.mask, 0, zbytes, stream) != hipSuccess) return -2;
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, thr,
-                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw);
-  size_t qe = L.qcap;
-  int blocks = (int)((qe + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dim3(blocks), dim3(256), 0, stream, L.recs, cb, thr, L.gqueue,
-                     L.qcap, L.counter, L.mask, L.nz, L.nzw);
-  size_t lds = (size_t)(cb + 2 + NZRING * TILE * L.nzw) * sizeof(u64);
-  hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.nzw, n, cb,
-                     order, keep_out, count_out);
+                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw, Batch{});
+  hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dim3(drain_blocks(L.qcap)), dim3(256), 0, stream, L.recs, cb, thr,
+                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw, Batch{});
+  hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1), dim3(RTHREADS), reduce_lds_bytes(cb, L.nzw), stream, L.mask,
+                     L.nz, L.nzw, n, cb, order, keep_out, count_out, Batch{});
   return 0;
 }
 
+// ------------------------------------------------------------------ batched detection pipeline
+// multiclass_nms_rotated (core/post_processing/bbox_nms_rotated.py:7-131) + batched_rnms
+// (ops/rnms/rnms_wrapper.py:34-69) for ALL images of a step in one pass of launches:
+//   select  : scores > score_thr, candidates in row-major (anchor, class) order [= boolean-mask
+//             indexing / nonzero()], per-image count and max over the candidate boxes' columns;
+//   (host reads the B counts: the mask workspace is sized by the largest image)
+//   sort    : rocPRIM segmented radix sort, descending and stable (= torch.sort(stable=True));
+//   prepare : x, y += label * (max + 1) in fp32 exactly as the wrapper does, then the v1 record;
+//   stream / drain / reduce : the kernels above with blockIdx.z = image;
+//   finish  : rnms returns keep ascending (rnms_kernel.cu:331-334) and the caller keeps the first
+//             max_num of THAT order: flag kept candidates, ordered compaction, gather
+//             [box, score] and label of the survivors.
+constexpr int SEL_T = 1024;
+
+__global__ __launch_bounds__(SEL_T) void mc_select_kernel(const float* __restrict__ boxes,
+                                                          const float* __restrict__ scores, int n, int K,
+                                                          float thr, int cand_stride,
+                                                          int* __restrict__ cand_row, int* __restrict__ cand_label,
+                                                          float* __restrict__ cand_score, int* __restrict__ counts,
+                                                          float* __restrict__ maxc) {
+  __shared__ int wsum[SEL_T / 64];
+  __shared__ float wmax[SEL_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int img = blockIdx.x;
+  boxes += (size_t)img * n * 5;
+  scores += (size_t)img * n * (K + 1);
+  cand_row += (size_t)img * cand_stride;
+  cand_label += (size_t)img * cand_stride;
+  cand_score += (size_t)img * cand_stride;
+  int base = 0;
+  float mx = -INFINITY;
+  for (int row0 = 0; row0 < n; row0 += SEL_T) {
+    const int row = row0 + tid;
+    const float* s = scores + (size_t)row * (K + 1);  // last column = background, never a candidate
+    int cnt = 0;
+    if (row < n)
+      for (int k = 0; k < K; k++) cnt += s[k] > thr;
+    int incl = cnt;  // wavefront inclusive scan
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_T / 64; w++) {
+      const int t = wsum[w];
+      if (w < wave) woff += t;
+      total += t;
+    }
+    if (cnt) {
+      int pos = base + woff + incl - cnt;
+      for (int k = 0; k < K; k++) {
+        const float v = s[k];
+        if (v > thr) {
+          cand_row[pos] = row;
+          cand_label[pos] = k;
+          cand_score[pos] = v;
+          pos++;
+        }
+      }
+      const float* b = boxes + (size_t)row * 5;
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])), b[4]));
+    }
+    base += total;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  if (lane == 0) wmax[wave] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < SEL_T / 64; w++) mx = fmaxf(mx, wmax[w]);
+    counts[img] = base;
+    maxc[img] = mx;
+  }
+}
+
+__global__ __launch_bounds__(256) void mc_prepare_kernel(const float* __restrict__ boxes, int n,
+                                                         const int* __restrict__ cand_row,
+                                                         const int* __restrict__ cand_label, int cand_stride,
+                                                         const int* __restrict__ sorted_vals,
+                                                         const int* __restrict__ counts,
+                                                         const float* __restrict__ maxc, BoxRec* __restrict__ recs,
+                                                         size_t recs_stride, unsigned* __restrict__ counter,
+                                                         size_t counter_stride) {
+  const int img = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) counter[img * counter_stride] = 0;
+  if (i >= counts[img]) return;
+  const size_t cbase = (size_t)img * cand_stride;
+  const int c = sorted_vals[cbase + i] - (int)cbase;  // values are positions in the whole batch array
+  const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
+  // offsets = labels.to(float) * (bboxes.max() + 1); shifted[:, :2] += offsets (rnms_wrapper.py:58-63)
+  const float off = (float)cand_label[cbase + c] * (maxc[img] + 1.f);
+  const float d[5] = {b[0] + off, b[1] + off, b[2], b[3], b[4]};
+  BoxRec r;
+  make_record<1>(d, 0.f, r);
+  recs[img * recs_stride + i] = r;
+}
+
+__global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict__ boxes, int n,
+                                                         const int* __restrict__ cand_row,
+                                                         const int* __restrict__ cand_label,
+                                                         const float* __restrict__ cand_score, int cand_stride,
+                                                         const int* __restrict__ sorted_vals,
+                                                         const int* __restrict__ counts,
+                                                         const int64_t* __restrict__ keep, size_t keep_stride,
+                                                         const int32_t* __restrict__ kept_count,
+                                                         uint8_t* __restrict__ flags, int out_cap,
+                                                         float* __restrict__ dets_out,
+                                                         int64_t* __restrict__ labels_out,
+                                                         int32_t* __restrict__ counts_out) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.x;
+  const int M = counts[img], cnt = kept_count[img];
+  const size_t cbase = (size_t)img * cand_stride;
+  flags += img * keep_stride;
+  keep += img * keep_stride;
+  for (int i = tid; i < M; i += 1024) flags[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < cnt; i += 1024) flags[sorted_vals[cbase + keep[i]] - (int)cbase] = 1;
+  __syncthreads();
+  const int per = (M + 1023) / 1024;
+  const int lo = min(tid * per, M), hi = min(lo + per, M);
+  int c = 0;
+  for (int i = lo; i < hi; i++) c += flags[i];
+  part[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = (tid >= off) ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - c;
+  for (int i = lo; i < hi && pos < out_cap; i++) {
+    if (!flags[i]) continue;
+    const float* b = boxes + ((size_t)img * n + cand_row[cbase + i]) * 5;
+    float* d = dets_out + ((size_t)img * out_cap + pos) * 6;
+    d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
+    d[5] = cand_score[cbase + i];
+    labels_out[(size_t)img * out_cap + pos] = cand_label[cbase + i];
+    pos++;
+  }
+  if (tid == 0) counts_out[img] = min(cnt, out_cap);
+}
+
+struct SegOffset {  // segment begin (counts == nullptr) / end of image b in the (B, stride) arrays
+  int stride;
+  const int* counts;
+  __host__ __device__ int operator()(int b) const { return b * stride + (counts ? counts[b] : 0); }
+};
+
+struct McLayout {
+  float* skeys;
+  int* svals;
+  BoxRec* recs;
+  u64* mask;
+  u64* nz;
+  unsigned* counter;
+  unsigned* gqueue;
+  int64_t* keep;
+  int32_t* kept;
+  uint8_t* flags;
+  void* sort_tmp;
+  size_t sort_bytes, qcap, zero_bytes;
+  int cb, nzw;
+};
+
+inline hipError_t mc_sort(void* tmp, size_t& bytes, const float* keys, float* skeys, int* svals, int B,
+                          int cand_stride, const int* counts, hipStream_t stream) {
+  auto begin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SegOffset{cand_stride, nullptr});
+  auto end = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SegOffset{cand_stride, counts});
+  return rocprim::segmented_radix_sort_pairs_desc(tmp, bytes, keys, skeys, rocprim::counting_iterator<int>(0), svals,
+                                                  (unsigned)((size_t)B * cand_stride), (unsigned)B, begin, end, 0, 32,
+                                                  stream);
+}
+
+inline size_t mc_layout(int B, int cand_stride, int cap, void* ws, McLayout* L) {
+  const size_t cb = (cap + TILE - 1) / TILE, nzw = (cb + 63) / 64, qcap = queue_entries(cap);
+  size_t sort_bytes = 0;
+  (void)mc_sort(nullptr, sort_bytes, nullptr, nullptr, nullptr, B, cand_stride, nullptr, nullptr);  // size query
+  size_t off = 0;
+  char* p = (char*)ws;
+  auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
+  char* skeys = take((size_t)B * cand_stride * 4);
+  char* svals = take((size_t)B * cand_stride * 4);
+  char* recs = take((size_t)B * cap * sizeof(BoxRec));
+  char* mask = take((size_t)B * cap * cb * 8);  // mask and nz: one fill
+  char* nz = take((size_t)B * cap * nzw * 8);
+  char* counter = take((size_t)B * 256);
+  char* gq = take((size_t)B * qcap * 4);
+  char* keep = take((size_t)B * cap * 8);
+  char* kept = take((size_t)B * 4);
+  char* flags = take((size_t)B * cap);
+  char* tmp = take(sort_bytes);
+  if (L) {
+    L->skeys = (float*)skeys; L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask;
+    L->nz = (u64*)nz; L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->keep = (int64_t*)keep;
+    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->sort_tmp = tmp; L->sort_bytes = sort_bytes;
+    L->qcap = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb; L->nzw = (int)nzw;
+    if (g_r3_nms_qcap > 0 && (size_t)g_r3_nms_qcap < L->qcap) L->qcap = (size_t)g_r3_nms_qcap;
+  }
+  return off + 256;
+}
+
 }  // namespace
+
+int r3k_mcnms_select(const float* boxes, const float* scores, int B, int n, int K, float score_thr,
+                     int* cand_row, int* cand_label, float* cand_score, int* counts, float* maxc,
+                     hipStream_t stream) {
+  if (B <= 0 || n < 0 || K <= 0 || !counts || !maxc) return -1;
+  if (n > 0 && (!boxes || !scores || !cand_row || !cand_label || !cand_score)) return -1;
+  hipLaunchKernelGGL(mc_select_kernel, dim3(B), dim3(SEL_T), 0, stream, boxes, scores, n, K, score_thr, n * K,
+                     cand_row, cand_label, cand_score, counts, maxc);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+size_t r3k_mcnms_workspace_bytes(int B, int n, int K, int cap) {
+  if (B <= 0 || n <= 0 || K <= 0 || cap <= 0) return 256;
+  return mc_layout(B, n * K, cap, nullptr, nullptr);
+}
+
+int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
+                 const float* cand_score, const int* counts, const float* maxc, int cap, float iou_thr,
+                 int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
+                 int32_t* counts_out, hipStream_t stream) {
+  if (B <= 0 || n <= 0 || K <= 0 || cap <= 0 || out_cap <= 0 || cap >= 65536 || !(iou_thr >= 0.f)) return -1;
+  if (!boxes || !cand_row || !cand_label || !cand_score || !counts || !maxc || !ws || !dets_out || !labels_out ||
+      !counts_out)
+    return -1;
+  if (ws_bytes < r3k_mcnms_workspace_bytes(B, n, K, cap)) return -3;
+  const int S = n * K;
+  McLayout L;
+  mc_layout(B, S, cap, ws, &L);
+  if (mc_sort(L.sort_tmp, L.sort_bytes, cand_score, L.skeys, L.svals, B, S, counts, stream) != hipSuccess) return -2;
+  const size_t cbq = (size_t)L.cb;
+  Batch bt{counts, (size_t)cap, (size_t)cap * cbq, (size_t)cap * L.nzw, 64, L.qcap, (size_t)cap};
+  hipLaunchKernelGGL(mc_prepare_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, stream, boxes, n, cand_row,
+                     cand_label, S, L.svals, counts, maxc, L.recs, bt.recs, L.counter, bt.counter);
+  if (hipMemsetAsync(L.mask, 0, L.zero_bytes, stream) != hipSuccess) return -2;
+  dim3 grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
+  hipLaunchKernelGGL((nms_stream_kernel<1, false>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, iou_thr, L.gqueue,
+                     (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt);
+  int dblocks = drain_blocks(L.qcap);
+  if (dblocks > 256) dblocks = 256;  // B images share the chip
+  hipLaunchKernelGGL(nms_drain_kernel<1>, dim3(dblocks, 1, B), dim3(256), 0, stream, L.recs, L.cb, iou_thr,
+                     L.gqueue, (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt);
+  hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1, 1, B), dim3(RTHREADS), reduce_lds_bytes(L.cb, L.nzw), stream,
+                     L.mask, L.nz, L.nzw, 0, L.cb, (const int64_t*)nullptr, L.keep, L.kept, bt);
+  hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label, cand_score,
+                     S, L.svals, counts, L.keep, bt.keep, L.kept, L.flags, out_cap, dets_out, labels_out, counts_out);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 size_t r3k_nms_workspace_bytes(int n) {
   if (n <= 0) return 256;

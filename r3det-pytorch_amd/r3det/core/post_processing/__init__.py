@@ -1,3 +1,3 @@
-from .bbox_nms_rotated import multiclass_nms_rotated
+from .bbox_nms_rotated import multiclass_nms_rotated, multiclass_nms_rotated_batch
 
-__all__ = ['multiclass_nms_rotated']
+__all__ = ['multiclass_nms_rotated', 'multiclass_nms_rotated_batch']

@@ -5,6 +5,7 @@
 """
 import torch
 
+from ... import _C
 from ...ops import batched_rnms, ml_nms_rotated, nms_rotated, obb_batched_nms
 
 
@@ -69,3 +70,54 @@ def multiclass_nms_rotated(multi_bboxes, multi_scores, score_thr, nms, max_num=-
     if max_num > 0:
         dets, keep = dets[:max_num], keep[:max_num]
     return dets, labels[keep]
+
+
+def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max_num=-1):
+    """``[multiclass_nms_rotated(b, s, ...) for b, s in zip(multi_bboxes, multi_scores)]`` for a
+    whole batch -- (B, n, 5) boxes shared by the classes, (B, n, C+1) scores -- with identical
+    results.  nms type 'v1' runs as ONE pass of launches over all images
+    (r3det_mcnms_select / r3det_mcnms_v1 in include/r3det_hip.h: threshold + ordered compaction,
+    stable score sort, class offsets, suppression, ascending keep and the max_num cut on the
+    device; the host reads the per-image candidate counts once in the middle and the per-image
+    detection counts at the end).  Other nms types take the per-image path."""
+    B, n = multi_scores.shape[:2]
+    K = multi_scores.size(2) - 1
+    version = nms.get('type', 'v1')
+    iou_thr = float(_get(nms, 'iou_thr'))
+    fused = (version == 'v1' and multi_bboxes.dim() == 3 and multi_bboxes.size(2) == 5 and n > 0 and K > 0
+             and iou_thr >= 0)
+    if not fused:
+        return [multiclass_nms_rotated(multi_bboxes[i], multi_scores[i], score_thr, nms, max_num) for i in range(B)]
+    boxes = _C.need_hip(multi_bboxes.contiguous(), "multi_bboxes")
+    scores = _C.need_hip(multi_scores.contiguous(), "multi_scores")
+    dev = boxes.device
+    L = _C.lib()
+    with torch.cuda.device(dev):
+        S = n * K
+        cand_row = torch.empty((B, S), dtype=torch.int32, device=dev)
+        cand_label = torch.empty((B, S), dtype=torch.int32, device=dev)
+        cand_score = torch.empty((B, S), dtype=torch.float32, device=dev)
+        counts = torch.empty(B, dtype=torch.int32, device=dev)
+        maxc = torch.empty(B, dtype=torch.float32, device=dev)
+        _C.check(L.r3det_mcnms_select(_C.ptr(boxes), _C.ptr(scores), B, n, K, float(score_thr), _C.ptr(cand_row),
+                                      _C.ptr(cand_label), _C.ptr(cand_score), _C.ptr(counts), _C.ptr(maxc),
+                                      _C.stream()), "r3det_mcnms_select")
+        m = int(counts.max().item())  # sizes the suppression workspace
+        if m == 0:
+            return [(multi_bboxes.new_zeros((0, 6)), multi_bboxes.new_zeros((0, ), dtype=torch.long))
+                    for _ in range(B)]
+        if m >= 65536:  # beyond the pair-queue encoding: per-image operators
+            return [multiclass_nms_rotated(multi_bboxes[i], multi_scores[i], score_thr, nms, max_num)
+                    for i in range(B)]
+        cap = (m + 63) // 64 * 64
+        out_cap = max_num if max_num > 0 else cap
+        ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, n, K, cap))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        dets = torch.empty((B, out_cap, 6), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, out_cap), dtype=torch.int64, device=dev)
+        kept = torch.empty(B, dtype=torch.int32, device=dev)
+        _C.check(L.r3det_mcnms_v1(_C.ptr(boxes), B, n, K, _C.ptr(cand_row), _C.ptr(cand_label), _C.ptr(cand_score),
+                                  _C.ptr(counts), _C.ptr(maxc), cap, iou_thr, out_cap, _C.ptr(ws), ws_bytes,
+                                  _C.ptr(dets), _C.ptr(labels), _C.ptr(kept), _C.stream()), "r3det_mcnms_v1")
+        kept = kept.tolist()
+    return [(dets[i, :kept[i]], labels[i, :kept[i]]) for i in range(B)]

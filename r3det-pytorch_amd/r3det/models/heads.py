@@ -9,7 +9,7 @@ import math
 import torch
 import torch.nn as nn
 
-from ..core.post_processing import multiclass_nms_rotated
+from ..core.post_processing import multiclass_nms_rotated_batch
 from .backbone import ConvModule
 from .coder import delta2bbox_v1
 
@@ -129,8 +129,7 @@ class RRetinaHead(nn.Module):
         boxes = torch.cat(boxes_l, 1)
         scores = torch.cat(scores_l, 1)
         scores = torch.cat([scores, scores.new_zeros(N, scores.shape[1], 1)], 2)  # dummy background
-        return [multiclass_nms_rotated(boxes[i], scores[i], cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
-                for i in range(N)]
+        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
 
 
 class RRetinaRefineHead(RRetinaHead):

@@ -1,0 +1,96 @@
+"""GPU parity: the batched multiclass NMS pipeline (r3det_mcnms_select / r3det_mcnms_v1) against
+(a) outputs recorded from the reference's own multiclass_nms_rotated (tests/golden/wrappers.npz)
+and (b) the per-image operator path, which the other GPU tests pin to the oracle.  Detections are
+gathers of the inputs and labels are integers: everything is compared for exact equality."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(iou_thr=0.1)
+
+
+def pools(B, n, seed, frac_pos=0.6, classes=15):
+    from r3det import synthetic as syn
+    ps = [syn.nms_pool(n, seed + 17 * i, num_classes=classes, frac_pos=frac_pos, device='cuda') for i in range(B)]
+    return torch.stack([p[0] for p in ps]), torch.stack([p[1] for p in ps])
+
+
+def same(batch_out, boxes, scores, thr, cfg, max_num):
+    from r3det.core.post_processing import multiclass_nms_rotated
+    assert len(batch_out) == boxes.size(0)
+    for i, (d, lab) in enumerate(batch_out):
+        rd, rl = multiclass_nms_rotated(boxes[i], scores[i], thr, cfg, max_num)
+        assert d.shape == rd.shape and lab.dtype == torch.int64
+        assert torch.equal(d, rd), f"image {i}: dets differ"
+        assert torch.equal(lab, rl), f"image {i}: labels differ"
+
+
+@pytest.fixture(params=[0, 100], ids=["queue", "overflow"])
+def qcap(request):
+    from r3det import _C
+    _C.set_option("nms_qcap", request.param)
+    yield request.param
+    _C.set_option("nms_qcap", 0)
+
+
+@pytest.mark.parametrize("max_num", [50, 2000, -1])
+def test_golden_reference_wrapper(max_num):
+    """The reference's wrapper ran on these inputs (make_golden_wrappers.py); B = 2 repeats the
+    image so that the image stride of every array is exercised."""
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    g = np.load(os.path.join(GOLDEN, "wrappers.npz"))
+    b = torch.from_numpy(g["mc_boxes"]).cuda()
+    s = torch.from_numpy(g["mc_scores"]).cuda()
+    out = multiclass_nms_rotated_batch(torch.stack([b, b]), torch.stack([s, s]), 0.05, dict(type='v1', iou_thr=0.1),
+                                       max_num)
+    if max_num > 0:
+        for d, lab in out:
+            assert np.array_equal(d.cpu().numpy(), g[f"mc_v1_{max_num}_dets"])
+            assert np.array_equal(lab.cpu().numpy(), g[f"mc_v1_{max_num}_labels"])
+    same(out, torch.stack([b, b]), torch.stack([s, s]), 0.05, dict(type='v1', iou_thr=0.1), max_num)
+
+
+@pytest.mark.parametrize("B,n", [(1, 100), (3, 1000), (4, 5344), (2, 9000)])
+@pytest.mark.parametrize("max_num", [2000, 37])
+def test_matches_per_image_path(B, n, max_num, qcap):
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    boxes, scores = pools(B, n, 1000 + n)
+    same(multiclass_nms_rotated_batch(boxes, scores, 0.05, CFG, max_num), boxes, scores, 0.05, CFG, max_num)
+
+
+def test_ragged_and_empty_images():
+    """Images with very different candidate counts, one with none, in one batch; then all empty."""
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    boxes, scores = pools(4, 2000, 5)
+    scores[1] = 0.01                      # no candidate at all
+    scores[2, 50:] = 0.0                  # a handful
+    scores[3, :, :-1] = scores[3, :, :-1].clamp(min=0.06)  # EVERY (anchor, class) pair: 30 000 candidates
+    out = multiclass_nms_rotated_batch(boxes, scores, 0.05, CFG, 2000)
+    assert out[1][0].shape == (0, 6) and out[1][1].shape == (0,)
+    same(out, boxes, scores, 0.05, CFG, 2000)
+    out = multiclass_nms_rotated_batch(boxes[:2], torch.zeros_like(scores[:2]), 0.05, CFG, 2000)
+    assert all(d.shape == (0, 6) and lab.shape == (0,) and lab.dtype == torch.int64 for d, lab in out)
+
+
+def test_score_ties_keep_candidate_order():
+    """Quantised scores: thousands of exact ties; the stable sort must order them like the
+    per-image path (torch.sort(stable=True))."""
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    boxes, scores = pools(2, 3000, 77)
+    scores = (scores * 8).round() / 8
+    same(multiclass_nms_rotated_batch(boxes, scores, 0.05, CFG, 2000), boxes, scores, 0.05, CFG, 2000)
+
+
+def test_single_class_and_other_types():
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    boxes, scores = pools(2, 800, 9, classes=1)
+    same(multiclass_nms_rotated_batch(boxes, scores, 0.05, CFG, 100), boxes, scores, 0.05, CFG, 100)
+    boxes, scores = pools(2, 800, 10)
+    for cfg in (dict(type='v3', iou_thr=0.1), dict(type='v2', iou_thr=0.1), dict(type='mmcv', iou_thr=0.1)):
+        same(multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 100), boxes, scores, 0.05, cfg, 100)

@@ -1,14 +1,36 @@
-import sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/r3det-pytorch_amd")
-import torch, bench
-dev = torch.device("cuda")
-wl = bench.build_hot_workload(dev, 7)
-from r3det.ops.feature_refine import fr_forward
-from r3det.core.post_processing import multiclass_nms_rotated
-from r3det.synthetic import STRIDES
+"""Custom-op hot path of bench.py split into its two halves (ms per step of 4 images):
+FR forward over the 5 levels, and multiclass NMS per image vs batched."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from r3det.core.post_processing import multiclass_nms_rotated, multiclass_nms_rotated_batch  # noqa: E402
+from r3det.ops.feature_refine import fr_forward  # noqa: E402
+from r3det.synthetic import STRIDES  # noqa: E402
+
+wl = bench.build_hot_workload(torch.device("cuda"), 7)
+pb, ps = wl["pool_boxes"], wl["pool_scores"]
+
+
 def fr():
-    for f, b, o, s in zip(wl["feats"], wl["boxes"], wl["outs"], STRIDES): fr_forward(f, b, 1.0 / s, 1, o)
-def nms():
-    for mb, ms in wl["pools"]: multiclass_nms_rotated(mb, ms, 0.05, dict(iou_thr=0.1), 2000)
-for name, fn in (("fr", fr), ("nms", nms), ("both", lambda: (fr(), nms()))):
-    print(name, round(bench.timeit(fn, 20, 3) * 1e3, 3), "ms")
+    for f, b, o, s in zip(wl["feats"], wl["boxes"], wl["outs"], STRIDES):
+        fr_forward(f, b, 1.0 / s, 1, o)
+
+
+def nms_per_image():
+    for i in range(pb.size(0)):
+        multiclass_nms_rotated(pb[i], ps[i], 0.05, dict(iou_thr=0.1), 2000)
+
+
+def nms_batched():
+    multiclass_nms_rotated_batch(pb, ps, 0.05, dict(iou_thr=0.1), 2000)
+
+
+for name, fn in (("fr x5 levels", fr), ("nms per image x4", nms_per_image), ("nms batched", nms_batched),
+                 ("hot path", lambda: bench.hot_path_step(wl))):
+    print(f"{name:18s} {bench.timeit(fn, 20, 3) * 1e3:8.3f} ms")
