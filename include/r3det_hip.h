@@ -125,21 +125,24 @@ int r3det_mmcv_nms_rotated(const float* dets5, const int64_t* labels, const int6
  *
  *   r3det_mcnms_select : boxes (B,n,5), scores (B,n,K+1; last column = background).
  *       Candidates (score > score_thr) per image in row-major (anchor, class) order:
- *       cand_row / cand_label (int32) / cand_score, each (B, n*K); counts (B) int32,
- *       maxc (B) = max over the candidate boxes' five columns.
+ *       cand_row / cand_label / cand_rank (int32) and cand_score, each (B, n*K) [cand_rank is
+ *       scratch of the second call, zeroed here]; counts (B) int32, maxc (B) = max over the
+ *       candidate boxes' five columns.  ws: r3det_mcnms_select_workspace_bytes(B, n).
  *   r3det_mcnms_v1 : cap >= max(counts), < 65536.  Per image: stable descending score sort,
  *       x, y += label * (maxc + 1), NMS v1 (IoU > iou_thr), keep ASCENDING by candidate
  *       index, first out_cap of them.  dets_out (B,out_cap,6) = [box, score], labels_out
  *       (B,out_cap) int64, counts_out (B) int32; rows beyond counts_out are not written.
+ *       ws: r3det_mcnms_workspace_bytes(B, cap).
  * ------------------------------------------------------------------------------------- */
+size_t r3det_mcnms_select_workspace_bytes(int B, int n);
 int r3det_mcnms_select(const float* boxes, const float* scores, int B, int n, int K, float score_thr,
-                       int32_t* cand_row, int32_t* cand_label, float* cand_score, int32_t* counts,
-                       float* maxc, void* stream);
-size_t r3det_mcnms_workspace_bytes(int B, int n, int K, int cap);
+                       int32_t* cand_row, int32_t* cand_label, float* cand_score, int32_t* cand_rank,
+                       int32_t* counts, float* maxc, void* ws, size_t ws_bytes, void* stream);
+size_t r3det_mcnms_workspace_bytes(int B, int cap);
 int r3det_mcnms_v1(const float* boxes, int B, int n, int K, const int32_t* cand_row,
-                   const int32_t* cand_label, const float* cand_score, const int32_t* counts,
-                   const float* maxc, int cap, float iou_thr, int out_cap, void* ws, size_t ws_bytes,
-                   float* dets_out, int64_t* labels_out, int32_t* counts_out, void* stream);
+                   const int32_t* cand_label, const float* cand_score, int32_t* cand_rank,
+                   const int32_t* counts, const float* maxc, int cap, float iou_thr, int out_cap, void* ws,
+                   size_t ws_bytes, float* dets_out, int64_t* labels_out, int32_t* counts_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Feature refinement (rotated feature-align sampler)

@@ -109,21 +109,23 @@ int r3det_mmcv_nms_rotated(const float* dets5, const int64_t* labels, const int6
                     count_out, S(stream)));
 }
 
+size_t r3det_mcnms_select_workspace_bytes(int B, int n) { return r3k_mcnms_select_workspace_bytes(B, n); }
+
 int r3det_mcnms_select(const float* boxes, const float* scores, int B, int n, int K, float score_thr,
-                       int32_t* cand_row, int32_t* cand_label, float* cand_score, int32_t* counts,
-                       float* maxc, void* stream) {
-  return rc(r3k_mcnms_select(boxes, scores, B, n, K, score_thr, cand_row, cand_label, cand_score, counts, maxc,
-                             S(stream)));
+                       int32_t* cand_row, int32_t* cand_label, float* cand_score, int32_t* cand_rank,
+                       int32_t* counts, float* maxc, void* ws, size_t ws_bytes, void* stream) {
+  return rc(r3k_mcnms_select(boxes, scores, B, n, K, score_thr, cand_row, cand_label, cand_score, cand_rank, counts,
+                             maxc, ws, ws_bytes, S(stream)));
 }
 
-size_t r3det_mcnms_workspace_bytes(int B, int n, int K, int cap) { return r3k_mcnms_workspace_bytes(B, n, K, cap); }
+size_t r3det_mcnms_workspace_bytes(int B, int cap) { return r3k_mcnms_workspace_bytes(B, cap); }
 
 int r3det_mcnms_v1(const float* boxes, int B, int n, int K, const int32_t* cand_row,
-                   const int32_t* cand_label, const float* cand_score, const int32_t* counts,
-                   const float* maxc, int cap, float iou_thr, int out_cap, void* ws, size_t ws_bytes,
-                   float* dets_out, int64_t* labels_out, int32_t* counts_out, void* stream) {
-  return rc(r3k_mcnms_v1(boxes, B, n, K, cand_row, cand_label, cand_score, counts, maxc, cap, iou_thr, out_cap, ws,
-                         ws_bytes, dets_out, labels_out, counts_out, S(stream)));
+                   const int32_t* cand_label, const float* cand_score, int32_t* cand_rank,
+                   const int32_t* counts, const float* maxc, int cap, float iou_thr, int out_cap, void* ws,
+                   size_t ws_bytes, float* dets_out, int64_t* labels_out, int32_t* counts_out, void* stream) {
+  return rc(r3k_mcnms_v1(boxes, B, n, K, cand_row, cand_label, cand_score, cand_rank, counts, maxc, cap, iou_thr,
+                         out_cap, ws, ws_bytes, dets_out, labels_out, counts_out, S(stream)));
 }
 
 size_t r3det_fr_workspace_bytes(int N, int H, int W, int points) {

@@ -20,13 +20,14 @@ int r3k_nms(int geom, const float* dets, int det_stride, const int64_t* labels,
 
 // batched multiclass NMS (v1): select -> [host reads counts] -> sort / prepare / stream / drain /
 // reduce / finish for B images at once.  Candidate arrays have stride n * K per image.
+size_t r3k_mcnms_select_workspace_bytes(int B, int n);
 int r3k_mcnms_select(const float* boxes, const float* scores, int B, int n, int K, float score_thr,
-                     int* cand_row, int* cand_label, float* cand_score, int* counts, float* maxc,
-                     hipStream_t stream);
-size_t r3k_mcnms_workspace_bytes(int B, int n, int K, int cap);
+                     int* cand_row, int* cand_label, float* cand_score, int* cand_rank, int* counts,
+                     float* maxc, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t r3k_mcnms_workspace_bytes(int B, int cap);
 int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
-                 const float* cand_score, const int* counts, const float* maxc, int cap, float iou_thr,
-                 int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
+                 const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
+                 float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
                  int32_t* counts_out, hipStream_t stream);
 
 size_t r3k_fr_workspace_bytes(int N, int H, int W, int points);

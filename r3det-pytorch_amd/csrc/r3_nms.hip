@@ -26,12 +26,6 @@
 // serves thr < 0, n >= 65536 and the A/B measurements.
 #include <hip/hip_runtime.h>
 
-#include <cstring>
-
-#include <rocprim/device/device_segmented_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-
 #include "r3_geom_lds.h"
 #include "r3_kernels.h"
 
@@ -584,101 +578,173 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
 //   select  : scores > score_thr, candidates in row-major (anchor, class) order [= boolean-mask
 //             indexing / nonzero()], per-image count and max over the candidate boxes' columns;
 //   (host reads the B counts: the mask workspace is sized by the largest image)
-//   sort    : rocPRIM segmented radix sort, descending and stable (= torch.sort(stable=True));
+//   sort    : rank by counting, descending and stable (= torch.sort(stable=True)); mc_rank_kernel;
 //   prepare : x, y += label * (max + 1) in fp32 exactly as the wrapper does, then the v1 record;
 //   stream / drain / reduce : the kernels above with blockIdx.z = image;
 //   finish  : rnms returns keep ascending (rnms_kernel.cu:331-334) and the caller keeps the first
 //             max_num of THAT order: flag kept candidates, ordered compaction, gather
 //             [box, score] and label of the survivors.
-constexpr int SEL_T = 1024;
+constexpr int SEL_T = 1024;  // rows per workgroup of the select kernels
 
-__global__ __launch_bounds__(SEL_T) void mc_select_kernel(const float* __restrict__ boxes,
-                                                          const float* __restrict__ scores, int n, int K,
-                                                          float thr, int cand_stride,
-                                                          int* __restrict__ cand_row, int* __restrict__ cand_label,
-                                                          float* __restrict__ cand_score, int* __restrict__ counts,
-                                                          float* __restrict__ maxc) {
+__device__ __forceinline__ int block_exclusive_scan(int v, int* wsum, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < SEL_T / 64; w++) {
+    const int t = wsum[w];
+    if (w < wave) woff += t;
+    total += t;
+  }
+  return woff + incl - v;
+}
+
+// select, pass 1: candidates per 1024-row part of an image (+ max over their boxes' columns)
+__global__ __launch_bounds__(SEL_T) void mc_count_kernel(const float* __restrict__ boxes,
+                                                         const float* __restrict__ scores, int n, int K,
+                                                         float thr, int parts, int* __restrict__ part_cnt,
+                                                         float* __restrict__ part_max) {
   __shared__ int wsum[SEL_T / 64];
   __shared__ float wmax[SEL_T / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int img = blockIdx.x;
-  boxes += (size_t)img * n * 5;
-  scores += (size_t)img * n * (K + 1);
-  cand_row += (size_t)img * cand_stride;
-  cand_label += (size_t)img * cand_stride;
-  cand_score += (size_t)img * cand_stride;
-  int base = 0;
+  const int img = blockIdx.y, row = blockIdx.x * SEL_T + tid;
+  int cnt = 0;
   float mx = -INFINITY;
-  for (int row0 = 0; row0 < n; row0 += SEL_T) {
-    const int row = row0 + tid;
-    const float* s = scores + (size_t)row * (K + 1);  // last column = background, never a candidate
-    int cnt = 0;
-    if (row < n)
-      for (int k = 0; k < K; k++) cnt += s[k] > thr;
-    int incl = cnt;  // wavefront inclusive scan
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int woff = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < SEL_T / 64; w++) {
-      const int t = wsum[w];
-      if (w < wave) woff += t;
-      total += t;
-    }
+  if (row < n) {
+    const float* s = scores + ((size_t)img * n + row) * (K + 1);  // last column = background
+    for (int k = 0; k < K; k++) cnt += s[k] > thr;
     if (cnt) {
-      int pos = base + woff + incl - cnt;
-      for (int k = 0; k < K; k++) {
-        const float v = s[k];
-        if (v > thr) {
-          cand_row[pos] = row;
-          cand_label[pos] = k;
-          cand_score[pos] = v;
-          pos++;
-        }
-      }
-      const float* b = boxes + (size_t)row * 5;
-      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])), b[4]));
+      const float* b = boxes + ((size_t)img * n + row) * 5;
+      mx = fmaxf(fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])), b[4]);
     }
-    base += total;
-    __syncthreads();
   }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-  if (lane == 0) wmax[wave] = mx;
+  for (int d = 32; d >= 1; d >>= 1) {
+    cnt += __shfl_xor(cnt, d);
+    mx = fmaxf(mx, __shfl_xor(mx, d));
+  }
+  if (lane == 0) {
+    wsum[wave] = cnt;
+    wmax[wave] = mx;
+  }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < SEL_T / 64; w++) mx = fmaxf(mx, wmax[w]);
-    counts[img] = base;
-    maxc[img] = mx;
+    for (int w = 1; w < SEL_T / 64; w++) {
+      cnt += wsum[w];
+      mx = fmaxf(mx, wmax[w]);
+    }
+    part_cnt[img * parts + blockIdx.x] = cnt;
+    part_max[img * parts + blockIdx.x] = mx;
   }
 }
 
+// select, pass 2: ordered compaction (rows ascending, classes ascending inside a row)
+__global__ __launch_bounds__(SEL_T) void mc_write_kernel(const float* __restrict__ scores, int n, int K, float thr,
+                                                         int parts, const int* __restrict__ part_cnt,
+                                                         const float* __restrict__ part_max, int cand_stride,
+                                                         int* __restrict__ cand_row, int* __restrict__ cand_label,
+                                                         float* __restrict__ cand_score, int* __restrict__ cand_rank,
+                                                         int* __restrict__ counts, float* __restrict__ maxc) {
+  __shared__ int wsum[SEL_T / 64];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.y, row = blockIdx.x * SEL_T + tid;
+  int base = 0;
+  for (int p = 0; p < (int)blockIdx.x; p++) base += part_cnt[img * parts + p];
+  if (blockIdx.x == 0 && tid == 0) {
+    int total = 0;
+    float mx = -INFINITY;
+    for (int p = 0; p < parts; p++) {
+      total += part_cnt[img * parts + p];
+      mx = fmaxf(mx, part_max[img * parts + p]);
+    }
+    counts[img] = total;
+    maxc[img] = mx;
+  }
+  const float* s = scores + ((size_t)img * n + row) * (K + 1);
+  int cnt = 0;
+  if (row < n)
+    for (int k = 0; k < K; k++) cnt += s[k] > thr;
+  int total;
+  int pos = base + block_exclusive_scan(cnt, wsum, total);
+  if (cnt) {
+    const size_t cb = (size_t)img * cand_stride;
+    for (int k = 0; k < K; k++) {
+      const float v = s[k];
+      if (v > thr) {
+        cand_row[cb + pos] = row;
+        cand_label[cb + pos] = k;
+        cand_score[cb + pos] = v;
+        cand_rank[cb + pos] = 0;
+        pos++;
+      }
+    }
+  }
+}
+
+// Stable descending sort of an image's candidates by COUNTING: rank(i) = #{j : s_j > s_i or
+// (s_j == s_i and j < i)} = position of i under torch.sort(descending=True, stable=True).
+// O(M^2) compares, but spread over the chip in one launch with device-side M (M = 3 k: ~5 us,
+// where a segmented radix sort of 4 segments takes 97 us on one workgroup each).
+constexpr int RK_T = 256, RK_J = 1024;
+
+__device__ __forceinline__ unsigned order_key(float f) {  // monotone: a < b  <=>  key(a) < key(b)
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(RK_T) void mc_rank_kernel(const float* __restrict__ cand_score, int cand_stride,
+                                                       const int* __restrict__ counts, int* __restrict__ cand_rank) {
+  __shared__ unsigned keys[RK_J];
+  const int img = blockIdx.z, M = counts[img];
+  const int i0 = blockIdx.x * RK_T, j0 = blockIdx.y * RK_J;
+  if (i0 >= M || j0 >= M) return;
+  const float* sc = cand_score + (size_t)img * cand_stride;
+  const int jn = min(RK_J, M - j0);
+  for (int j = threadIdx.x; j < jn; j += RK_T) keys[j] = order_key(sc[j0 + j]);
+  __syncthreads();
+  const int i = i0 + threadIdx.x;
+  if (i >= M) return;
+  const unsigned ui = order_key(sc[i]);
+  const int before = i - j0;  // j < before  <=>  candidate j0 + j precedes i
+  int cnt = 0;
+  for (int j = 0; j < jn; j++) {
+    const unsigned uj = keys[j];
+    cnt += (uj > ui) | ((uj == ui) & (j < before));
+  }
+  if (cnt) atomicAdd(&cand_rank[(size_t)img * cand_stride + i], cnt);
+}
+
+// one thread per candidate: record at its sorted position, and the inverse permutation
 __global__ __launch_bounds__(256) void mc_prepare_kernel(const float* __restrict__ boxes, int n,
                                                          const int* __restrict__ cand_row,
-                                                         const int* __restrict__ cand_label, int cand_stride,
-                                                         const int* __restrict__ sorted_vals,
+                                                         const int* __restrict__ cand_label,
+                                                         const int* __restrict__ cand_rank, int cand_stride,
                                                          const int* __restrict__ counts,
                                                          const float* __restrict__ maxc, BoxRec* __restrict__ recs,
-                                                         size_t recs_stride, unsigned* __restrict__ counter,
-                                                         size_t counter_stride) {
+                                                         size_t recs_stride, int* __restrict__ sorted_vals,
+                                                         unsigned* __restrict__ counter, size_t counter_stride) {
   const int img = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) counter[img * counter_stride] = 0;
-  if (i >= counts[img]) return;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0) counter[img * counter_stride] = 0;
+  if (c >= counts[img]) return;
   const size_t cbase = (size_t)img * cand_stride;
-  const int c = sorted_vals[cbase + i] - (int)cbase;  // values are positions in the whole batch array
+  const int pos = cand_rank[cbase + c];
   const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
   // offsets = labels.to(float) * (bboxes.max() + 1); shifted[:, :2] += offsets (rnms_wrapper.py:58-63)
   const float off = (float)cand_label[cbase + c] * (maxc[img] + 1.f);
   const float d[5] = {b[0] + off, b[1] + off, b[2], b[3], b[4]};
   BoxRec r;
   make_record<1>(d, 0.f, r);
-  recs[img * recs_stride + i] = r;
+  recs[img * recs_stride + pos] = r;
+  sorted_vals[img * recs_stride + pos] = c;
 }
 
 __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict__ boxes, int n,
@@ -702,7 +768,7 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
   keep += img * keep_stride;
   for (int i = tid; i < M; i += 1024) flags[i] = 0;
   __syncthreads();
-  for (int i = tid; i < cnt; i += 1024) flags[sorted_vals[cbase + keep[i]] - (int)cbase] = 1;
+  for (int i = tid; i < cnt; i += 1024) flags[sorted_vals[img * keep_stride + keep[i]]] = 1;
   __syncthreads();
   const int per = (M + 1023) / 1024;
   const int lo = min(tid * per, M), hi = min(lo + per, M);
@@ -729,14 +795,7 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
   if (tid == 0) counts_out[img] = min(cnt, out_cap);
 }
 
-struct SegOffset {  // segment begin (counts == nullptr) / end of image b in the (B, stride) arrays
-  int stride;
-  const int* counts;
-  __host__ __device__ int operator()(int b) const { return b * stride + (counts ? counts[b] : 0); }
-};
-
 struct McLayout {
-  float* skeys;
   int* svals;
   BoxRec* recs;
   u64* mask;
@@ -746,29 +805,16 @@ struct McLayout {
   int64_t* keep;
   int32_t* kept;
   uint8_t* flags;
-  void* sort_tmp;
-  size_t sort_bytes, qcap, zero_bytes;
+  size_t qcap, zero_bytes;
   int cb, nzw;
 };
 
-inline hipError_t mc_sort(void* tmp, size_t& bytes, const float* keys, float* skeys, int* svals, int B,
-                          int cand_stride, const int* counts, hipStream_t stream) {
-  auto begin = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SegOffset{cand_stride, nullptr});
-  auto end = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), SegOffset{cand_stride, counts});
-  return rocprim::segmented_radix_sort_pairs_desc(tmp, bytes, keys, skeys, rocprim::counting_iterator<int>(0), svals,
-                                                  (unsigned)((size_t)B * cand_stride), (unsigned)B, begin, end, 0, 32,
-                                                  stream);
-}
-
-inline size_t mc_layout(int B, int cand_stride, int cap, void* ws, McLayout* L) {
+inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   const size_t cb = (cap + TILE - 1) / TILE, nzw = (cb + 63) / 64, qcap = queue_entries(cap);
-  size_t sort_bytes = 0;
-  (void)mc_sort(nullptr, sort_bytes, nullptr, nullptr, nullptr, B, cand_stride, nullptr, nullptr);  // size query
   size_t off = 0;
   char* p = (char*)ws;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
-  char* skeys = take((size_t)B * cand_stride * 4);
-  char* svals = take((size_t)B * cand_stride * 4);
+  char* svals = take((size_t)B * cap * 4);
   char* recs = take((size_t)B * cap * sizeof(BoxRec));
   char* mask = take((size_t)B * cap * cb * 8);  // mask and nz: one fill
   char* nz = take((size_t)B * cap * nzw * 8);
@@ -777,51 +823,64 @@ inline size_t mc_layout(int B, int cand_stride, int cap, void* ws, McLayout* L) 
   char* keep = take((size_t)B * cap * 8);
   char* kept = take((size_t)B * 4);
   char* flags = take((size_t)B * cap);
-  char* tmp = take(sort_bytes);
   if (L) {
-    L->skeys = (float*)skeys; L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask;
-    L->nz = (u64*)nz; L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->keep = (int64_t*)keep;
-    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->sort_tmp = tmp; L->sort_bytes = sort_bytes;
+    L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
+    L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->keep = (int64_t*)keep;
+    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags;
     L->qcap = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb; L->nzw = (int)nzw;
     if (g_r3_nms_qcap > 0 && (size_t)g_r3_nms_qcap < L->qcap) L->qcap = (size_t)g_r3_nms_qcap;
   }
   return off + 256;
 }
 
+inline int select_parts(int n) { return (n + SEL_T - 1) / SEL_T; }
+
 }  // namespace
 
+size_t r3k_mcnms_select_workspace_bytes(int B, int n) {
+  if (B <= 0 || n <= 0) return 256;
+  return align256((size_t)B * select_parts(n) * 4) * 2;
+}
+
 int r3k_mcnms_select(const float* boxes, const float* scores, int B, int n, int K, float score_thr,
-                     int* cand_row, int* cand_label, float* cand_score, int* counts, float* maxc,
-                     hipStream_t stream) {
-  if (B <= 0 || n < 0 || K <= 0 || !counts || !maxc) return -1;
-  if (n > 0 && (!boxes || !scores || !cand_row || !cand_label || !cand_score)) return -1;
-  hipLaunchKernelGGL(mc_select_kernel, dim3(B), dim3(SEL_T), 0, stream, boxes, scores, n, K, score_thr, n * K,
-                     cand_row, cand_label, cand_score, counts, maxc);
+                     int* cand_row, int* cand_label, float* cand_score, int* cand_rank, int* counts,
+                     float* maxc, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (B <= 0 || n <= 0 || K <= 0 || !counts || !maxc) return -1;
+  if (!boxes || !scores || !cand_row || !cand_label || !cand_score || !cand_rank || !ws) return -1;
+  if (ws_bytes < r3k_mcnms_select_workspace_bytes(B, n)) return -3;
+  const int parts = select_parts(n);
+  int* part_cnt = (int*)ws;
+  float* part_max = (float*)((char*)ws + align256((size_t)B * parts * 4));
+  hipLaunchKernelGGL(mc_count_kernel, dim3(parts, B), dim3(SEL_T), 0, stream, boxes, scores, n, K, score_thr, parts,
+                     part_cnt, part_max);
+  hipLaunchKernelGGL(mc_write_kernel, dim3(parts, B), dim3(SEL_T), 0, stream, scores, n, K, score_thr, parts,
+                     part_cnt, part_max, n * K, cand_row, cand_label, cand_score, cand_rank, counts, maxc);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-size_t r3k_mcnms_workspace_bytes(int B, int n, int K, int cap) {
-  if (B <= 0 || n <= 0 || K <= 0 || cap <= 0) return 256;
-  return mc_layout(B, n * K, cap, nullptr, nullptr);
+size_t r3k_mcnms_workspace_bytes(int B, int cap) {
+  if (B <= 0 || cap <= 0) return 256;
+  return mc_layout(B, cap, nullptr, nullptr);
 }
 
 int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
-                 const float* cand_score, const int* counts, const float* maxc, int cap, float iou_thr,
-                 int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
+                 const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
+                 float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
                  int32_t* counts_out, hipStream_t stream) {
   if (B <= 0 || n <= 0 || K <= 0 || cap <= 0 || out_cap <= 0 || cap >= 65536 || !(iou_thr >= 0.f)) return -1;
-  if (!boxes || !cand_row || !cand_label || !cand_score || !counts || !maxc || !ws || !dets_out || !labels_out ||
-      !counts_out)
+  if (!boxes || !cand_row || !cand_label || !cand_score || !cand_rank || !counts || !maxc || !ws || !dets_out ||
+      !labels_out || !counts_out)
     return -1;
-  if (ws_bytes < r3k_mcnms_workspace_bytes(B, n, K, cap)) return -3;
+  if (ws_bytes < r3k_mcnms_workspace_bytes(B, cap)) return -3;
   const int S = n * K;
   McLayout L;
-  mc_layout(B, S, cap, ws, &L);
-  if (mc_sort(L.sort_tmp, L.sort_bytes, cand_score, L.skeys, L.svals, B, S, counts, stream) != hipSuccess) return -2;
+  mc_layout(B, cap, ws, &L);
   const size_t cbq = (size_t)L.cb;
   Batch bt{counts, (size_t)cap, (size_t)cap * cbq, (size_t)cap * L.nzw, 64, L.qcap, (size_t)cap};
+  hipLaunchKernelGGL(mc_rank_kernel, dim3((cap + RK_T - 1) / RK_T, (cap + RK_J - 1) / RK_J, B), dim3(RK_T), 0, stream,
+                     cand_score, S, counts, cand_rank);
   hipLaunchKernelGGL(mc_prepare_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, stream, boxes, n, cand_row,
-                     cand_label, S, L.svals, counts, maxc, L.recs, bt.recs, L.counter, bt.counter);
+                     cand_label, cand_rank, S, counts, maxc, L.recs, bt.recs, L.svals, L.counter, bt.counter);
   if (hipMemsetAsync(L.mask, 0, L.zero_bytes, stream) != hipSuccess) return -2;
   dim3 grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
   hipLaunchKernelGGL((nms_stream_kernel<1, false>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, iou_thr, L.gqueue,

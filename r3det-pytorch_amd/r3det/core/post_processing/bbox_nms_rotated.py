@@ -97,11 +97,14 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
         cand_row = torch.empty((B, S), dtype=torch.int32, device=dev)
         cand_label = torch.empty((B, S), dtype=torch.int32, device=dev)
         cand_score = torch.empty((B, S), dtype=torch.float32, device=dev)
+        cand_rank = torch.empty((B, S), dtype=torch.int32, device=dev)
+        sel_bytes = int(L.r3det_mcnms_select_workspace_bytes(B, n))
+        sel_ws = torch.empty(sel_bytes, dtype=torch.uint8, device=dev)
         counts = torch.empty(B, dtype=torch.int32, device=dev)
         maxc = torch.empty(B, dtype=torch.float32, device=dev)
         _C.check(L.r3det_mcnms_select(_C.ptr(boxes), _C.ptr(scores), B, n, K, float(score_thr), _C.ptr(cand_row),
-                                      _C.ptr(cand_label), _C.ptr(cand_score), _C.ptr(counts), _C.ptr(maxc),
-                                      _C.stream()), "r3det_mcnms_select")
+                                      _C.ptr(cand_label), _C.ptr(cand_score), _C.ptr(cand_rank), _C.ptr(counts),
+                                      _C.ptr(maxc), _C.ptr(sel_ws), sel_bytes, _C.stream()), "r3det_mcnms_select")
         m = int(counts.max().item())  # sizes the suppression workspace
         if m == 0:
             return [(multi_bboxes.new_zeros((0, 6)), multi_bboxes.new_zeros((0, ), dtype=torch.long))
@@ -111,13 +114,13 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
                     for i in range(B)]
         cap = (m + 63) // 64 * 64
         out_cap = max_num if max_num > 0 else cap
-        ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, n, K, cap))
+        ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, cap))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         dets = torch.empty((B, out_cap, 6), dtype=torch.float32, device=dev)
         labels = torch.empty((B, out_cap), dtype=torch.int64, device=dev)
         kept = torch.empty(B, dtype=torch.int32, device=dev)
         _C.check(L.r3det_mcnms_v1(_C.ptr(boxes), B, n, K, _C.ptr(cand_row), _C.ptr(cand_label), _C.ptr(cand_score),
-                                  _C.ptr(counts), _C.ptr(maxc), cap, iou_thr, out_cap, _C.ptr(ws), ws_bytes,
+                                  _C.ptr(cand_rank), _C.ptr(counts), _C.ptr(maxc), cap, iou_thr, out_cap, _C.ptr(ws), ws_bytes,
                                   _C.ptr(dets), _C.ptr(labels), _C.ptr(kept), _C.stream()), "r3det_mcnms_v1")
         kept = kept.tolist()
     return [(dets[i, :kept[i]], labels[i, :kept[i]]) for i in range(B)]
