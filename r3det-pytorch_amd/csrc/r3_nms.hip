@@ -45,7 +45,54 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Batch {
   const int* counts;
   size_t recs, mask, nz, counter, queue, keep;
+  size_t rows;  // row capacity of one image's arrays (= n for a single problem): diagT = nz + rows * nzw
 };
+
+inline Batch single_problem(int n) {
+  Batch b{};
+  b.rows = (size_t)n;
+  return b;
+}
+
+// Side tables of one image, in the same allocation as (and zeroed with) the nz bitmap rows:
+//   diagT[r] : in-edges of row r inside its 64-row block (bit i & 63: row i of the block suppresses r)
+//   wcnt[r]  : number of non-zero mask words of row r beyond its diagonal word
+//   wlist[r] : the first WL of those word indices, in arrival order
+// They let the reducer find a row's words without searching the bitmap (which stays authoritative:
+// rows with more than WL words fall back to it).
+constexpr int WL = 16;
+
+struct Side {
+  u64* diagT;
+  int* wcnt;
+  unsigned short* wlist;
+};
+
+__host__ __device__ inline size_t nz_side_words(size_t rows, int nzw) {  // u64 words: bitmap + side tables
+  return rows * (size_t)(nzw + 1) + (rows + 1) / 2 + (rows * WL + 3) / 4;
+}
+
+__host__ __device__ inline Side side_tables(u64* nz, size_t rows, int nzw) {
+  Side s;
+  s.diagT = nz + rows * nzw;
+  s.wcnt = reinterpret_cast<int*>(s.diagT + rows);
+  s.wlist = reinterpret_cast<unsigned short*>(s.diagT + rows + (rows + 1) / 2);
+  return s;
+}
+
+// pair (i, j), i < j in score order, suppresses: all the bookkeeping of one mask bit
+__device__ __forceinline__ void mark_pair(u64* mask, u64* nz, const Side& sd, unsigned i, unsigned j, int cb,
+                                          int nzw) {
+  const unsigned wj = j >> 6;
+  const u64 old = atomicOr(&mask[(size_t)i * cb + wj], 1ULL << (j & 63u));
+  atomicOr(&nz[(size_t)i * nzw + (wj >> 6)], 1ULL << (wj & 63u));
+  if ((i >> 6) == wj) {
+    atomicOr(&sd.diagT[j], 1ULL << (i & 63u));
+  } else if (old == 0ULL) {  // first bit of this word: register the word once
+    const int s = atomicAdd(&sd.wcnt[i], 1);
+    if (s < WL) sd.wlist[(size_t)i * WL + s] = (unsigned short)wj;
+  }
+}
 
 template <int GEOM>
 __global__ __launch_bounds__(256) void nms_prepare_kernel(const float* __restrict__ dets,
@@ -199,6 +246,7 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
     nz += img * bt.nz;
     if (rb * TILE >= n) return;
   }
+  const Side sd = side_tables(nz, bt.rows, nzw);
   const int cbn = (n + TILE - 1) / TILE;
   const int cblk = blockIdx.x * MASK_WAVES + wave;
   const bool active = (cblk < cbn) && (cblk >= rb);
@@ -260,11 +308,7 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
       if (GEOM == 1) v = v1_pair_slow(A, B, false);
       else if (GEOM == 2) v = hull_pair_slow<true>(A, B, true);
       else v = hull_pair_slow<false>(A, B, true);
-      if (v > thr) {
-        const unsigned wj = j >> 6;
-        atomicOr(&mask[(size_t)i * cb + wj], 1ULL << (j & 63u));
-        atomicOr(&nz[(size_t)i * nzw + (wj >> 6)], 1ULL << (wj & 63u));
-      }
+      if (v > thr) mark_pair(mask, nz, sd, i, j, cb, nzw);
     }
   }
 }
@@ -285,6 +329,7 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
     mask += img * bt.mask;
     nz += img * bt.nz;
   }
+  const Side sd = side_tables(nz, bt.rows, nzw);
   unsigned total = *counter;
   if (total > qcap) total = qcap;
   for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
@@ -293,11 +338,7 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
     const BoxRec A = recs[i];
     const BoxRec B = recs[j];
     const float v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
-    if (v > thr) {
-      const unsigned wj = j >> 6;
-      atomicOr(&mask[(size_t)i * cb + wj], 1ULL << (j & 63u));
-      atomicOr(&nz[(size_t)i * nzw + (wj >> 6)], 1ULL << (wj & 63u));
-    }
+    if (v > thr) mark_pair(mask, nz, sd, i, j, cb, nzw);
   }
 }
 
@@ -467,6 +508,158 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_sparse_kernel(const u64* 
     for (int i = tid; i < total; i += blockDim.x) keep_out[i] = order[keep_out[i]];
 }
 
+// Greedy scan of one 64-row block by DEPENDENCY ROUNDS instead of row by row.  Lane k holds its
+// in-edges (bit j: an earlier row j of the block suppresses k).  A row is removed as soon as one
+// of its suppressors is known to be kept, and kept as soon as all of them are known to be removed;
+// the lowest undecided row always decides, so this terminates with exactly the sequential greedy
+// answer -- after 2-4 rounds of ~15 instructions on real pools (suppression chains are short)
+// where the row-by-row form costs ~30 scalar instructions for each of up to 64 rows.
+__device__ __forceinline__ u64 scan_block_rounds(u64 in, u64 removed, u64 valid) {
+  u64 R = removed & valid, K = 0;
+  while ((K | R) != valid) {
+    R |= __ballot((in & K) != 0ULL) & valid;
+    K |= __ballot((in & ~R) == 0ULL) & ~R & valid;
+  }
+  return K;
+}
+
+// ---------------------------------------------------------------------------- reduce, pipelined
+// Same algorithm as nms_reduce_sparse_kernel, restructured so that neither a memory wait nor a
+// bitmap search sits on the serial chain (measured there per 64-row block: ~1.6 us, of which the
+// compiler's s_waitcnt vmcnt(0) at the top of every iteration -- shifting prefetch registers and
+// conditional loads defeat its counting -- and the k-th-set-bit search for the word addresses were
+// the two largest parts):
+//   * every stream is a FIFO of RP statically indexed registers (walk unrolled by RP), every load
+//     is unconditional (clamped address, validity applied at the use) and the keep list is written
+//     after the walk: the loop body is straight-line, the compiler waits vmcnt(4 RP - k);
+//   * a row's word indices come from the drain kernel's per-row list (Side::wlist), requested
+//     2 RP blocks ahead; the words themselves RP blocks ahead; rows with more than WL words
+//     re-apply all of their words through the bitmap (rare);
+//   * the 64-row block is resolved by dependency rounds on the in-edge words (scan_block_rounds).
+constexpr int RP = 4;  // request distance in 64-row blocks
+static_assert(RSLOTS == WL, "one thread per (row, listed word)");
+
+__global__ __launch_bounds__(RTHREADS) void nms_reduce_pipe_kernel(const u64* __restrict__ mask,
+                                                                   const u64* __restrict__ nz, int nzw, int n,
+                                                                   int cb, const int64_t* __restrict__ order,
+                                                                   int64_t* __restrict__ keep_out,
+                                                                   int32_t* __restrict__ count_out, Batch bt) {
+  extern __shared__ __attribute__((aligned(16))) u64 smem[];
+  if (bt.counts) {
+    const int img = blockIdx.z;
+    n = bt.counts[img];
+    mask += img * bt.mask;
+    nz += img * bt.nz;
+    keep_out += img * bt.keep;
+    count_out += img;
+  }
+  const int cbn = (n + TILE - 1) / TILE;
+  u64* remv = smem;        // cb words: bits removed so far
+  u64* kbits = smem + cb;  // cb words: kept bits per block (the keep list is built after the walk)
+  int* pre = reinterpret_cast<int*>(smem + 2 * cb);  // 1024 partial sums of the epilogue
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int myrow = tid / RSLOTS, myk = tid % RSLOTS;
+  const Side sd = side_tables(const_cast<u64*>(nz), bt.rows, nzw);
+
+  auto diag_load = [&](int blk) -> u64 {  // in-edges of row (blk, lane) from earlier rows of its block
+    const int r = blk * TILE + lane;
+    return sd.diagT[r < n ? r : 0];
+  };
+  auto list_load = [&](int blk, int& cnt) -> unsigned {  // this thread's listed word index, and the row's count
+    const int gr = blk * TILE + myrow;
+    const size_t r = gr < n ? gr : 0;
+    cnt = sd.wcnt[r];
+    return sd.wlist[r * WL + myk];
+  };
+  // request of word (blk, myrow, myk-th listed); widx < 0: nothing to apply; over: the row needs the bitmap
+  auto word_load = [&](int blk, unsigned w, int cnt, int& widx, bool& over) -> u64 {
+    const int gr = blk * TILE + myrow;
+    const bool row_ok = gr < n;
+    over = row_ok && cnt > WL;
+    widx = (row_ok && myk < cnt) ? (int)w : -1;
+    return mask[widx >= 0 ? (size_t)gr * cb + widx : 0];
+  };
+
+  for (int j = tid; j < cb; j += RTHREADS) remv[j] = 0;
+  u64 Dq[RP], Wq[RP];
+  unsigned Lw[RP];
+  int Lc[RP], Wi[RP];
+  bool Wo[RP];
+#pragma unroll
+  for (int s = 0; s < RP; s++) {
+    int cnt;
+    const unsigned w = list_load(s, cnt);
+    Wq[s] = word_load(s, w, cnt, Wi[s], Wo[s]);
+    Dq[s] = diag_load(s);
+    Lw[s] = list_load(RP + s, Lc[s]);
+  }
+  __syncthreads();
+
+  auto step = [&](int b, auto slot_c) {
+    constexpr int s = decltype(slot_c)::value;
+    // ---- stage 1: wave 0 resolves block b on its in-edge words
+    if (wave == 0) {
+      const int nvalid = min(TILE, n - b * TILE);
+      const u64 valid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1ULL);
+      const u64 in = (b * TILE + lane < n) ? Dq[s] : 0ULL;
+      const u64 kb = scan_block_rounds(in, readlane64(remv[b], 0), valid);
+      if (lane == 0) kbits[b] = kb;
+    }
+    Dq[s] = diag_load(b + RP);
+    R3_LDS_BARRIER();
+    // ---- stage 2: OR the words of the kept rows into remv
+    const u64 kb = kbits[b];
+    if ((kb >> myrow) & 1ULL) {
+      if (Wi[s] >= 0 && Wq[s]) atomicOr(&remv[Wi[s]], Wq[s]);
+      if (Wo[s]) {  // more than WL words: all of them through the bitmap (rare)
+        const size_t gr = (size_t)b * TILE + myrow;
+        for (int k = myk;; k += RSLOTS) {
+          const int w = kth_word(nz + gr * nzw, nzw, b, k);
+          if (w < 0) break;
+          const u64 v = mask[gr * cb + w];
+          if (v) atomicOr(&remv[w], v);
+        }
+      }
+    }
+    Wq[s] = word_load(b + RP, Lw[s], Lc[s], Wi[s], Wo[s]);
+    Lw[s] = list_load(b + 2 * RP, Lc[s]);
+    R3_LDS_BARRIER();
+  };
+  for (int b = 0; b < cbn; b += RP) {
+    step(b, std::integral_constant<int, 0>{});
+    if (b + 1 >= cbn) break;
+    step(b + 1, std::integral_constant<int, 1>{});
+    if (b + 2 >= cbn) break;
+    step(b + 2, std::integral_constant<int, 2>{});
+    if (b + 3 >= cbn) break;
+    step(b + 3, std::integral_constant<int, 3>{});
+  }
+  static_assert(RP == 4, "the walk above is unrolled by hand");
+  __syncthreads();
+  // keep list: block counts -> exclusive scan -> sorted positions (or original indices)
+  int c = 0;
+  for (int b = tid; b < cbn; b += RTHREADS) c += __popcll(kbits[b]);  // cbn <= 1024: one block per thread
+  pre[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < RTHREADS; off <<= 1) {
+    const int v = (tid >= off) ? pre[tid - off] : 0;
+    __syncthreads();
+    pre[tid] += v;
+    __syncthreads();
+  }
+  if (tid < cbn) {
+    int pos = pre[tid] - c;
+    u64 kb = kbits[tid];
+    while (kb) {
+      const int k = __ffsll((long long)kb) - 1;
+      kb &= kb - 1;
+      const int p = tid * TILE + k;
+      keep_out[pos++] = order ? order[p] : (int64_t)p;
+    }
+  }
+  if (tid == RTHREADS - 1) *count_out = pre[tid];
+}
+
 // rnms returns keep sorted by original index (rnms_kernel.cu:331-334): mark kept originals,
 // then an ordered compaction by one workgroup.
 __global__ __launch_bounds__(1024) void nms_ascending_kernel(int n, uint8_t* __restrict__ flags,
@@ -523,7 +716,7 @@ inline size_t layout(int n, void* ws, Layout* L) {
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
   char* recs = take((size_t)n * sizeof(BoxRec));
   char* mask = take((size_t)n * cb * sizeof(u64));  // mask and nz are zeroed together
-  char* nz = take((size_t)n * nzw * sizeof(u64));
+  char* nz = take(nz_side_words((size_t)n, (int)nzw) * sizeof(u64));  // bitmap rows + side tables
   char* counter = take(256);
   char* gq = take(queue_entries(n) * sizeof(unsigned));
   char* flags = take((size_t)n);
@@ -543,6 +736,19 @@ inline int drain_blocks(size_t qcap) {
 }
 
 inline size_t reduce_lds_bytes(int cb, int nzw) { return (size_t)(cb + 2 + NZRING * TILE * nzw) * sizeof(u64); }
+
+// greedy reduction of `images` problems (blockIdx.z); nms_impl 2 selects the older register-shifting form
+inline void launch_reduce(int images, const u64* mask, const u64* nz, int nzw, int n, int cb, const int64_t* order,
+                          int64_t* keep_out, int32_t* count_out, const Batch& bt, hipStream_t stream) {
+  if (g_r3_nms_impl == 2) {
+    hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1, 1, images), dim3(RTHREADS), reduce_lds_bytes(cb, nzw), stream,
+                       mask, nz, nzw, n, cb, order, keep_out, count_out, bt);
+    return;
+  }
+  const size_t lds = (size_t)2 * cb * sizeof(u64) + RTHREADS * sizeof(int);
+  hipLaunchKernelGGL(nms_reduce_pipe_kernel, dim3(1, 1, images), dim3(RTHREADS), lds, stream, mask, nz, nzw, n, cb,
+                     order, keep_out, count_out, bt);
+}
 
 template <int GEOM, bool LABEL>
 int run_nms(const float* dets, int det_stride, const int64_t* labels, const int64_t* order, int n,
@@ -564,11 +770,10 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
   size_t zbytes = (size_t)((char*)L.counter - (char*)L.mask);
   if (hipMemsetAsync(L.mask, 0, zbytes, stream) != hipSuccess) return -2;
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, thr,
-                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw, Batch{});
+                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw, single_problem(n));
   hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dim3(drain_blocks(L.qcap)), dim3(256), 0, stream, L.recs, cb, thr,
-                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw, Batch{});
-  hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1), dim3(RTHREADS), reduce_lds_bytes(cb, L.nzw), stream, L.mask,
-                     L.nz, L.nzw, n, cb, order, keep_out, count_out, Batch{});
+                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw, single_problem(n));
+  launch_reduce(1, L.mask, L.nz, L.nzw, n, cb, order, keep_out, count_out, single_problem(n), stream);
   return 0;
 }
 
@@ -817,7 +1022,7 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* svals = take((size_t)B * cap * 4);
   char* recs = take((size_t)B * cap * sizeof(BoxRec));
   char* mask = take((size_t)B * cap * cb * 8);  // mask and nz: one fill
-  char* nz = take((size_t)B * cap * nzw * 8);
+  char* nz = take((size_t)B * nz_side_words((size_t)cap, (int)nzw) * 8);  // per image: bitmap rows, side tables
   char* counter = take((size_t)B * 256);
   char* gq = take((size_t)B * qcap * 4);
   char* keep = take((size_t)B * cap * 8);
@@ -876,7 +1081,8 @@ int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, c
   McLayout L;
   mc_layout(B, cap, ws, &L);
   const size_t cbq = (size_t)L.cb;
-  Batch bt{counts, (size_t)cap, (size_t)cap * cbq, (size_t)cap * L.nzw, 64, L.qcap, (size_t)cap};
+  Batch bt{counts, (size_t)cap, (size_t)cap * cbq, nz_side_words((size_t)cap, L.nzw), 64, L.qcap, (size_t)cap,
+           (size_t)cap};
   hipLaunchKernelGGL(mc_rank_kernel, dim3((cap + RK_T - 1) / RK_T, (cap + RK_J - 1) / RK_J, B), dim3(RK_T), 0, stream,
                      cand_score, S, counts, cand_rank);
   hipLaunchKernelGGL(mc_prepare_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, stream, boxes, n, cand_row,
@@ -889,8 +1095,7 @@ int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, c
   if (dblocks > 256) dblocks = 256;  // B images share the chip
   hipLaunchKernelGGL(nms_drain_kernel<1>, dim3(dblocks, 1, B), dim3(256), 0, stream, L.recs, L.cb, iou_thr,
                      L.gqueue, (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt);
-  hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1, 1, B), dim3(RTHREADS), reduce_lds_bytes(L.cb, L.nzw), stream,
-                     L.mask, L.nz, L.nzw, 0, L.cb, (const int64_t*)nullptr, L.keep, L.kept, bt);
+  launch_reduce(B, L.mask, L.nz, L.nzw, 0, L.cb, nullptr, L.keep, L.kept, bt, stream);
   hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label, cand_score,
                      S, L.svals, counts, L.keep, bt.keep, L.kept, L.flags, out_cap, dets_out, labels_out, counts_out);
   return hipGetLastError() == hipSuccess ? 0 : -2;
