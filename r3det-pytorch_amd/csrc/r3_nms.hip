@@ -898,7 +898,7 @@ __global__ __launch_bounds__(SEL_T) void mc_write_kernel(const float* __restrict
 // (s_j == s_i and j < i)} = position of i under torch.sort(descending=True, stable=True).
 // O(M^2) compares, but spread over the chip in one launch with device-side M (M = 3 k: ~5 us,
 // where a segmented radix sort of 4 segments takes 97 us on one workgroup each).
-constexpr int RK_T = 256, RK_J = 1024;
+constexpr int RK_T = 256, RK_J = 256;
 
 __device__ __forceinline__ unsigned order_key(float f) {  // monotone: a < b  <=>  key(a) < key(b)
   const unsigned u = __float_as_uint(f);
@@ -907,22 +907,46 @@ __device__ __forceinline__ unsigned order_key(float f) {  // monotone: a < b  <=
 
 __global__ __launch_bounds__(RK_T) void mc_rank_kernel(const float* __restrict__ cand_score, int cand_stride,
                                                        const int* __restrict__ counts, int* __restrict__ cand_rank) {
-  __shared__ unsigned keys[RK_J];
+  __shared__ __attribute__((aligned(16))) unsigned keys[RK_J];
   const int img = blockIdx.z, M = counts[img];
   const int i0 = blockIdx.x * RK_T, j0 = blockIdx.y * RK_J;
   if (i0 >= M || j0 >= M) return;
   const float* sc = cand_score + (size_t)img * cand_stride;
   const int jn = min(RK_J, M - j0);
-  for (int j = threadIdx.x; j < jn; j += RK_T) keys[j] = order_key(sc[j0 + j]);
+  // key 0 (the bit pattern of a NaN, never a candidate) pads the tile: it is below every real key
+  for (int j = threadIdx.x; j < RK_J; j += RK_T) keys[j] = j < jn ? order_key(sc[j0 + j]) : 0u;
   __syncthreads();
   const int i = i0 + threadIdx.x;
   if (i >= M) return;
   const unsigned ui = order_key(sc[i]);
   const int before = i - j0;  // j < before  <=>  candidate j0 + j precedes i
   int cnt = 0;
-  for (int j = 0; j < jn; j++) {
-    const unsigned uj = keys[j];
-    cnt += (uj > ui) | ((uj == ui) & (j < before));
+  const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+  const int jn4 = (jn + 3) >> 2;
+  // A tile entirely before / after this workgroup's candidates needs one compare per key (ties
+  // count / do not count); only the tile on the diagonal needs the per-lane tie rule.
+  if (j0 + RK_J <= i0) {
+#pragma unroll 8
+    for (int q = 0; q < jn4; q++) {  // broadcast b128 reads: 4 keys per LDS instruction
+      const uint4 u = k4[q];
+      cnt += (u.x >= ui) + (u.y >= ui) + (u.z >= ui) + (u.w >= ui);
+    }
+  } else if (j0 >= i0 + RK_T) {
+#pragma unroll 8
+    for (int q = 0; q < jn4; q++) {
+      const uint4 u = k4[q];
+      cnt += (u.x > ui) + (u.y > ui) + (u.z > ui) + (u.w > ui);
+    }
+  } else {
+#pragma unroll 4
+    for (int q = 0; q < jn4; q++) {
+      const uint4 u = k4[q];
+      const int j = q * 4;
+      cnt += (u.x > ui) | ((u.x == ui) & (j < before));
+      cnt += (u.y > ui) | ((u.y == ui) & (j + 1 < before));
+      cnt += (u.z > ui) | ((u.z == ui) & (j + 2 < before));
+      cnt += (u.w > ui) | ((u.w == ui) & (j + 3 < before));
+    }
   }
   if (cnt) atomicAdd(&cand_rank[(size_t)img * cand_stride + i], cnt);
 }
