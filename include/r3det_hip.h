@@ -171,8 +171,16 @@ int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxe
                                   float* bottom_grad, int overwrite, void* stream);
 
 /* Kernel-selection knobs for A/B measurements (not part of the reference surface).
- * r3det_set_option("fr_impl", 0 auto | 1 generic | 2 lds-plane), ("iou_impl", ...). */
+ * r3det_set_option("fr_impl", 0 auto | 1 generic | 2 lds-plane | 10 cell), ("iou_impl", ...),
+ * ("nms_impl", 0 | 1 tiles | 2 older reducer), ("nms_qcap", n), ("fr_profile", 0 | 1). */
 int r3det_set_option(const char* name, int value);
+
+/* Measurement aid for bench.py (not part of the reference surface).  With option "fr_profile" = 1
+ * the launches of the cell path of r3det_feature_refine_forward carry their own start / stop
+ * events (up to 512 calls).  This call waits for them, writes one record of 4 floats per call
+ * {N, H, table_kernel_us, cell_kernel_us} (at most `capacity` records), empties the ring and
+ * returns the number of records written. */
+int r3det_fr_profile_read(float* records, int capacity);
 
 #ifdef __cplusplus
 }

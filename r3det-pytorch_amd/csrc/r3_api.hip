@@ -150,10 +150,16 @@ int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxe
                             overwrite, S(stream)));
 }
 
+int r3det_fr_profile_read(float* records, int capacity) {
+  if (capacity < 0 || (capacity > 0 && !records)) return 0;
+  return r3k_fr_profile_read(records, capacity);
+}
+
 int r3det_set_option(const char* name, int value) {
   if (!name) return R3DET_EINVAL;
   if (!strcmp(name, "fr_impl")) g_r3_fr_impl = value;
   else if (!strcmp(name, "fr_dbg")) g_r3_fr_dbg = value;
+  else if (!strcmp(name, "fr_profile")) g_r3_fr_profile = value;
   else if (!strcmp(name, "iou_impl")) g_r3_iou_impl = value;
   else if (!strcmp(name, "nms_impl")) g_r3_nms_impl = value;
   else if (!strcmp(name, "nms_qcap")) g_r3_nms_qcap = value;

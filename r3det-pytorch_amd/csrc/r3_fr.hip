@@ -22,6 +22,7 @@
 // removed (skewed layouts, persistent tile walkers, 12-byte tap records, two-plane-deep
 // prefetch) are described with their measurements in DESIGN.md 4.3.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <type_traits>
 
@@ -30,6 +31,7 @@
 
 int g_r3_fr_impl = 0;
 int g_r3_fr_dbg = 0;  // spare switch for kernel experiments (unused by the shipped kernels)
+int g_r3_fr_profile = 0;  // 1: cell-path launches record their own start / stop events
 
 namespace {
 
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
   // back to back (measured: 2.5 + 4.6 = 7.1 us per plane).  Instead element k + D of the stream is
   // requested while position k is sampled, and element k is written to the idle LDS buffer D
   // positions after its request: one load, one store and one LDS write per position, no bursts.
-  constexpr int D = K > 1 ? K / 2 : 0;
+  constexpr int D = K > 1 ? K / 2 : 0;  // (3K/4 measured the same cold and 4 % slower warm)
   float v[K], vd = 0.f;
   {
     const float* src = feat + (plane0 << (LOGW + LOGH));
@@ -564,6 +566,31 @@ inline void allow_big_lds(K kernel, int bytes) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Kernel-exact timing of the cell path for bench.py's roofline line: a ring of event quadruples
+// (table start / stop, cell start / stop) attached to the launches themselves.
+struct FrProfileSlot {
+  hipEvent_t ev[4];
+  int N, H;
+  bool used;
+};
+constexpr int FR_PROFILE_SLOTS = 512;
+FrProfileSlot g_fr_prof[FR_PROFILE_SLOTS];
+int g_fr_prof_count = 0;
+
+inline FrProfileSlot* fr_profile_next(int N, int H) {
+  if (g_fr_prof_count >= FR_PROFILE_SLOTS) return nullptr;  // ring full: later launches run untimed
+  FrProfileSlot* s = &g_fr_prof[g_fr_prof_count];
+  if (!s->used) {
+    for (auto& e : s->ev)
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    s->used = true;
+  }
+  s->N = N;
+  s->H = H;
+  g_fr_prof_count++;
+  return s;
+}
+
 inline int plane_cpb(int C, int H, int W) {
   int psz = H * (W + 1);
   if (psz > FRP_LDS_FLOATS) return 0;
@@ -617,16 +644,21 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
       ws_bytes >= r3k_fr_workspace_bytes(N, H, W, points) && aligned16(feat) && aligned16(out) && aligned16(ws)) {
     float* table = reinterpret_cast<float*>(ws);
     const int total = N * H * W;
-    hipLaunchKernelGGL(fr_cell_table_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, boxes, N, H, W, scale,
-                       table);
     static bool once = (allow_big_lds(fr_forward_cell<7, 7, 1024>, 160 * 1024), true);
     (void)once;
     const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
+    // profiling mode (r3det_set_option("fr_profile", 1)): the two launches carry their own start /
+    // stop events, so the recorded durations are the kernels' and not the host's launch gaps
+    FrProfileSlot* ps = g_r3_fr_profile ? fr_profile_next(N, H) : nullptr;
+    hipExtLaunchKernelGGL(fr_cell_table_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
+                          ps ? ps->ev[0] : nullptr, ps ? ps->ev[1] : nullptr, 0, boxes, N, H, W, scale, table);
     // (64 x 64 with 512- or 256-thread workgroups, several per CU, measured 1-5 % slower than 1024)
     if (W == 128)
-      hipLaunchKernelGGL((fr_forward_cell<7, 7, 1024>), dim3(N * C / G), dim3(1024), lds, stream, feat, table, C, G, out);
+      hipExtLaunchKernelGGL((fr_forward_cell<7, 7, 1024>), dim3(N * C / G), dim3(1024), lds, stream,
+                            ps ? ps->ev[2] : nullptr, ps ? ps->ev[3] : nullptr, 0, feat, table, C, G, out);
     else
-      hipLaunchKernelGGL((fr_forward_cell<6, 6, 1024>), dim3(N * C / G), dim3(1024), lds, stream, feat, table, C, G, out);
+      hipExtLaunchKernelGGL((fr_forward_cell<6, 6, 1024>), dim3(N * C / G), dim3(1024), lds, stream,
+                            ps ? ps->ev[2] : nullptr, ps ? ps->ev[3] : nullptr, 0, feat, table, C, G, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (plane) {
@@ -708,4 +740,26 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
       hipLaunchKernelGGL(fr_backward_generic<5>, grid, dim3(FR_BLOCK), 0, stream, top_grad, boxes, C, H, W, scale, cpbk, bottom_grad);
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Drains the profiling ring: waits for the recorded launches, writes up to `capacity` records
+// {N, H, table_us, cell_us} (4 floats each) and returns their number.
+int r3k_fr_profile_read(float* records, int capacity) {
+  int n = 0;
+  for (int i = 0; i < g_fr_prof_count; i++) {
+    FrProfileSlot& s = g_fr_prof[i];
+    if (hipEventSynchronize(s.ev[3]) != hipSuccess) continue;
+    float t_ms = 0.f, c_ms = 0.f;
+    if (hipEventElapsedTime(&t_ms, s.ev[0], s.ev[1]) != hipSuccess) continue;
+    if (hipEventElapsedTime(&c_ms, s.ev[2], s.ev[3]) != hipSuccess) continue;
+    if (n < capacity && records) {
+      records[4 * n + 0] = (float)s.N;
+      records[4 * n + 1] = (float)s.H;
+      records[4 * n + 2] = t_ms * 1e3f;
+      records[4 * n + 3] = c_ms * 1e3f;
+      n++;
+    }
+  }
+  g_fr_prof_count = 0;
+  return n;
 }

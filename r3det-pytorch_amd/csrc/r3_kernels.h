@@ -38,6 +38,10 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
                     float scale, int points, float* bottom_grad, int overwrite,
                     hipStream_t stream);
 
+// profiling ring of the FR cell path (see r3det_fr_profile_read)
+int r3k_fr_profile_read(float* records, int capacity);
+extern int g_r3_fr_profile;
+
 // A/B knobs (r3det_set_option)
 extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane, 3/4 tap-table, 5/6 persistent
 extern int g_r3_fr_dbg;    // ablation bits for the persistent forward kernel

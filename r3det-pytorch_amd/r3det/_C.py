@@ -29,6 +29,7 @@ SIGNATURES = {
     "r3det_feature_refine_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp],
     "r3det_feature_refine_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "r3det_set_option": [ctypes.c_char_p, _i],
+    "r3det_fr_profile_read": [_vp, _i],
 }
 
 _lib = None
@@ -95,6 +96,13 @@ def iou_workspace(n1, n2, device):
     caching allocator makes the per-call allocation free)."""
     nbytes = int(lib().r3det_iou_workspace_bytes(n1, n2))
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+def fr_profile_read(capacity=512):
+    """Drain the FR cell-path profiling ring: list of (N, H, table_kernel_us, cell_kernel_us)."""
+    buf = (ctypes.c_float * (4 * capacity))()
+    n = lib().r3det_fr_profile_read(ctypes.cast(buf, ctypes.c_void_p), capacity)
+    return [(int(buf[4 * i]), int(buf[4 * i + 1]), float(buf[4 * i + 2]), float(buf[4 * i + 3])) for i in range(n)]
 
 
 def set_option(name, value):

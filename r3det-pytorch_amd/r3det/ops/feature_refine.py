@@ -134,6 +134,10 @@ class FeatureRefineModule(nn.Module):
         per_level = [torch.cat(lvl) for lvl in zip(*best_rbboxes)]
         out = []
         for feat, boxes, fr in zip(x, per_level, self.fr):
+            # The sampler reads NCHW planes: in a channels_last pipeline the module switches layout
+            # once, at its input, so that its three convolutions already produce what FR consumes
+            # (a no-op for NCHW callers, like the reference).
+            feat = feat.contiguous()
             mixed = self.conv_5_1(self.conv_1_5(feat)) + self.conv_1_1(feat)
             out.append(feat + fr(mixed, boxes))
         return out
