@@ -116,6 +116,28 @@ int r3det_mmcv_nms_rotated(const float* dets5, const int64_t* labels, const int6
                            int32_t* count_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fused assignment.  The anchor heads hand (gt_bboxes, anchors) to mmdet's
+ * MaxIoUAssigner with iou_calculator = RBboxOverlaps2D_v1 (models/dense_heads/
+ * rotate_anchor_head.py:220-231 -> core/bbox/iou_calculators/rotate_iou2d_calculator.py:51-80),
+ * which reduces the (n_gt x n_boxes) overlaps to per-box max / argmax, per-gt max / argmax and
+ * the assignment.  This call produces those results without materialising the overlaps
+ * (100 MB at 128 x 196 416).  The assigner itself is third-party (mmdet 2.19
+ * core/bbox/assigners/max_iou_assigner.py, not in the reference tree); its rules as restated:
+ *   a = -1;  if 0 <= max < neg_iou_thr: a = 0;  if max >= pos_iou_thr: a = argmax + 1;
+ *   if match_low_quality: for gt i in order, if gt_max[i] >= min_pos_iou:
+ *       gt_max_assign_all ? a[overlaps[i] == gt_max[i]] = i + 1 : a[gt_argmax[i]] = i + 1
+ * argmax ties resolve to the smaller index.  geom: R3DET_GEOM_V1 / _V2 / _V3 (plain IoU, no
+ * wrapper-level zeroing of thin boxes).  argmax_overlaps and the two gt_* outputs may be NULL
+ * (both gt_* or neither).  ws: r3det_rbbox_assign_workspace_bytes(n_gt, n_boxes).
+ * ------------------------------------------------------------------------------------- */
+size_t r3det_rbbox_assign_workspace_bytes(int n_gt, int n_boxes);
+int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes, int n_boxes, float pos_iou_thr,
+                       float neg_iou_thr, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
+                       int64_t* assigned_gt_inds, float* max_overlaps, int64_t* argmax_overlaps,
+                       float* gt_max_overlaps, int64_t* gt_argmax_overlaps, void* ws, size_t ws_bytes,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Batched post-processing: multiclass_nms_rotated for all images of a step.
  * Replaces, for nms type 'v1' and boxes shared by the classes, the per-image Python sequence
  *   core/post_processing/bbox_nms_rotated.py:31-53,97-131  (threshold, mask indexing, labels)

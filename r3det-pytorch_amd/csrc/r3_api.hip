@@ -80,6 +80,20 @@ int r3det_mmcv_box_iou_rotated(const float* b1, int n1, const float* b2, int n2,
   return rc(r3k_iou_mat(R3DET_GEOM_V2, mode_flag, b1, n1, b2, n2, out, ws, ws_bytes, S(stream)));
 }
 
+size_t r3det_rbbox_assign_workspace_bytes(int n_gt, int n_boxes) {
+  return r3k_iou_assign_workspace_bytes(n_gt, n_boxes);
+}
+
+int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes, int n_boxes, float pos_iou_thr,
+                       float neg_iou_thr, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
+                       int64_t* assigned_gt_inds, float* max_overlaps, int64_t* argmax_overlaps,
+                       float* gt_max_overlaps, int64_t* gt_argmax_overlaps, void* ws, size_t ws_bytes,
+                       void* stream) {
+  return rc(r3k_iou_assign(geom, gts, n_gt, boxes, n_boxes, pos_iou_thr, neg_iou_thr, min_pos_iou,
+                           match_low_quality, gt_max_assign_all, assigned_gt_inds, max_overlaps, argmax_overlaps,
+                           gt_max_overlaps, gt_argmax_overlaps, ws, ws_bytes, S(stream)));
+}
+
 size_t r3det_nms_workspace_bytes(int n) { return r3k_nms_workspace_bytes(n); }
 
 int r3det_rnms(const float* dets6, const int64_t* order, int n, float thr, int sort_ascending,

@@ -253,13 +253,15 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream_kernel(const float* __re
       pend[c] = cvalid[c] && !apart;
       any |= pend[c];
     }
-    float* o = out + (size_t)(row0 + r) * n2 + col0;
-    if (VEC && all_valid && !any) {
-      *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
+    if (out) {  // (the fused assignment has no matrix: out == nullptr)
+      float* o = out + (size_t)(row0 + r) * n2 + col0;
+      if (VEC && all_valid && !any) {
+        *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
 #pragma unroll
-      for (int c = 0; c < T_CPT; c++)
-        if (cvalid[c] && !pend[c]) o[c] = 0.f;
+        for (int c = 0; c < T_CPT; c++)
+          if (cvalid[c] && !pend[c]) o[c] = 0.f;
+      }
     }
 #pragma unroll
     for (int c = 0; c < T_CPT; c++) {
@@ -304,6 +306,131 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain_kernel(const BoxRec* __re
     const BoxRec B = recsB[c];
     out[e] = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, iof != 0, lp);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused assignment: what MaxIoUAssigner needs from the K x N overlap matrix of
+// (gt, anchors) -- per-anchor max / argmax, per-gt max / argmax and the low-quality matches --
+// without ever writing the matrix (100 MB at 128 x 196 416).  stream (no zero fill) -> drain:
+// every clipped pair updates a packed (iou bits << 32 | ~index) key per column and per row with
+// a 64-bit atomicMax (larger IoU wins, then the SMALLER index: the torch-CPU / numpy tie rule)
+// and keeps its IoU next to its queue entry; a second sweep over the queue finds the pairs that
+// equal their gt's maximum; the last kernel applies the thresholds.
+typedef unsigned long long u64k;
+
+__device__ __forceinline__ u64k pack_key(float iou, unsigned idx) {
+  return ((u64k)__float_as_uint(iou) << 32) | (u64k)(0xffffffffu - idx);
+}
+__device__ __forceinline__ float key_iou(u64k k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ unsigned key_idx(u64k k) { return 0xffffffffu - (unsigned)(k & 0xffffffffu); }
+
+__global__ __launch_bounds__(256) void assign_init_kernel(u64k* __restrict__ rowkey, int n1, u64k* __restrict__ colkey,
+                                                          int* __restrict__ lowq, int n2,
+                                                          unsigned* __restrict__ counter) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *counter = 0;
+  if (i < n1) rowkey[i] = pack_key(0.f, 0);  // all-zero row / column: max 0 at index 0
+  if (i < n2) {
+    colkey[i] = pack_key(0.f, 0);
+    lowq[i] = 0;
+  }
+}
+
+template <int GEOM>
+__global__ __launch_bounds__(T_THREADS) void assign_drain_kernel(const BoxRec* __restrict__ recsA,
+                                                                 const BoxRec* __restrict__ recsB, int n2,
+                                                                 const unsigned* __restrict__ gqueue,
+                                                                 const unsigned* __restrict__ counter,
+                                                                 float* __restrict__ qiou, u64k* __restrict__ rowkey,
+                                                                 u64k* __restrict__ colkey, int n1_lds) {
+  __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
+  extern __shared__ __attribute__((aligned(16))) u64k rowbest[];  // n1_lds entries (0 = none): per-workgroup row maxima
+  const LanePts<T_THREADS> lp{pts + threadIdx.x};
+  const unsigned total = *counter;
+  for (int i = threadIdx.x; i < n1_lds; i += T_THREADS) rowbest[i] = 0;
+  __syncthreads();
+  for (unsigned q = blockIdx.x * T_THREADS + threadIdx.x; q < total; q += gridDim.x * T_THREADS) {
+    const unsigned e = gqueue[q];
+    const unsigned r = e / (unsigned)n2;
+    const unsigned c = e - r * (unsigned)n2;
+    const BoxRec A = recsA[r];
+    const BoxRec B = recsB[c];
+    const float v = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, false, lp);
+    qiou[q] = v;
+    if (v > 0.f) {
+      // The few hundred gt rows take ~5 k updates each: global atomics on 128 addresses serialise
+      // (0.6 ms).  Rows are reduced in LDS first and flushed once per workgroup; columns (anchors)
+      // are many and rarely contended: look (the keys only grow), then atomicMax.
+      const u64k kc = pack_key(v, r), kr = pack_key(v, c);
+      if (kc > __builtin_nontemporal_load(&colkey[c])) atomicMax(&colkey[c], kc);
+      if ((int)r < n1_lds) atomicMax(&rowbest[r], kr);
+      else if (kr > __builtin_nontemporal_load(&rowkey[r])) atomicMax(&rowkey[r], kr);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n1_lds; i += T_THREADS) {
+    const u64k k = rowbest[i];
+    if (k && k > __builtin_nontemporal_load(&rowkey[i])) atomicMax(&rowkey[i], k);
+  }
+}
+
+// pairs whose IoU equals their gt's maximum (MaxIoUAssigner step 4): the LAST such gt wins in the
+// reference's sequential loop = the largest gt index = an atomicMax of (index + 1)
+__global__ __launch_bounds__(256) void assign_lowq_kernel(const unsigned* __restrict__ gqueue,
+                                                          const unsigned* __restrict__ counter,
+                                                          const float* __restrict__ qiou, int n2,
+                                                          const u64k* __restrict__ rowkey, float min_pos_iou,
+                                                          int assign_all, int* __restrict__ lowq) {
+  const unsigned total = *counter;
+  for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
+    const float v = qiou[q];
+    if (!(v > 0.f)) continue;
+    const unsigned e = gqueue[q];
+    const unsigned r = e / (unsigned)n2;
+    const unsigned c = e - r * (unsigned)n2;
+    const u64k rk = rowkey[r];
+    if (v == key_iou(rk) && v >= min_pos_iou && (assign_all || key_idx(rk) == c)) atomicMax(&lowq[c], (int)r + 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void assign_final_kernel(const u64k* __restrict__ rowkey, int n1,
+                                                           const u64k* __restrict__ colkey,
+                                                           const int* __restrict__ lowq, int n2, float pos_thr,
+                                                           float neg_thr, float min_pos_iou, int match_low,
+                                                           int assign_all, int64_t* __restrict__ assigned,
+                                                           float* __restrict__ max_overlaps,
+                                                           int64_t* __restrict__ argmax,
+                                                           float* __restrict__ gt_max, int64_t* __restrict__ gt_argmax) {
+  __shared__ int zmax;  // largest gt index whose best IoU is 0 (it matches every anchor with IoU 0 = all)
+  if (threadIdx.x == 0) zmax = -1;
+  __syncthreads();
+  int z = -1;
+  for (int i = threadIdx.x; i < n1; i += 256)
+    if (key_iou(rowkey[i]) == 0.f) z = max(z, i);
+  if (z >= 0) atomicMax(&zmax, z);
+  __syncthreads();
+  z = zmax;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n1 && gt_max) {
+    gt_max[j] = key_iou(rowkey[j]);
+    gt_argmax[j] = key_idx(rowkey[j]);
+  }
+  if (j >= n2) return;
+  const u64k ck = colkey[j];
+  const float mo = key_iou(ck);
+  int a = -1;
+  if (mo >= 0.f && mo < neg_thr) a = 0;
+  if (mo >= pos_thr) a = (int)key_idx(ck) + 1;
+  if (match_low) {
+    int cand = lowq[j];
+    // a gt with no overlap at all has max 0 >= min_pos_iou when min_pos_iou <= 0: `overlaps[i] == 0`
+    // then selects every anchor (or, without gt_max_assign_all, its argmax = anchor 0)
+    if (z >= 0 && 0.f >= min_pos_iou && (assign_all || j == 0)) cand = max(cand, z + 1);
+    if (cand > 0) a = cand;
+  }
+  assigned[j] = a;
+  max_overlaps[j] = mo;
+  if (argmax) argmax[j] = key_idx(ck);
 }
 
 // vec_iou_iof_kernel (rbbox_geo_kernel.cu:271-309): out[i] = f(b1[i % n1], b2[i % n2]).
@@ -386,6 +513,87 @@ int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int
     default: return -1;
   }
   if (rc) return rc;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+namespace {
+
+struct AssignLayout {
+  unsigned* counter;
+  BoxRec *recsA, *recsB;
+  unsigned* gqueue;
+  float* qiou;
+  u64k *rowkey, *colkey;
+  int* lowq;
+};
+
+inline size_t assign_layout(int n1, int n2, void* ws, AssignLayout* L) {
+  size_t off = 0;
+  char* p = (char*)ws;
+  auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
+  char* counter = take(256);
+  char* ra = take((size_t)n1 * sizeof(BoxRec));
+  char* rb = take((size_t)n2 * sizeof(BoxRec));
+  char* gq = take((size_t)n1 * n2 * 4);
+  char* qi = take((size_t)n1 * n2 * 4);
+  char* rk = take((size_t)n1 * 8);
+  char* ck = take((size_t)n2 * 8);
+  char* lq = take((size_t)n2 * 4);
+  if (L) {
+    L->counter = (unsigned*)counter; L->recsA = (BoxRec*)ra; L->recsB = (BoxRec*)rb; L->gqueue = (unsigned*)gq;
+    L->qiou = (float*)qi; L->rowkey = (u64k*)rk; L->colkey = (u64k*)ck; L->lowq = (int*)lq;
+  }
+  return off + 256;
+}
+
+template <int GEOM>
+void launch_assign(const float* gts, int n1, const float* boxes, int n2, const AssignLayout& L, float min_pos_iou,
+                   int match_low, int assign_all, hipStream_t stream) {
+  const int nmax = n1 > n2 ? n1 : n2;
+  hipLaunchKernelGGL(assign_init_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, L.rowkey, n1, L.colkey,
+                     L.lowq, n2, L.counter);
+  dim3 grid((n2 + T_COLS - 1) / T_COLS, (n1 + S_ROWS - 1) / S_ROWS);
+  hipLaunchKernelGGL((iou_stream_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
+                     (float*)nullptr, L.recsA, L.recsB, L.gqueue, L.counter);
+  unsigned long long pairs = (unsigned long long)n1 * n2;
+  int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
+  if (blocks > 1024) blocks = 1024;
+  const int n1_lds = n1 < 2048 ? n1 : 2048;  // rows reduced in LDS (16 KB); the rest goes straight to global
+  hipLaunchKernelGGL(assign_drain_kernel<GEOM>, dim3(blocks < 512 ? blocks : 512), dim3(T_THREADS),
+                     (size_t)n1_lds * sizeof(u64k), stream, L.recsA, L.recsB, n2, L.gqueue, L.counter, L.qiou, L.rowkey,
+                     L.colkey, n1_lds);
+  if (match_low)
+    hipLaunchKernelGGL(assign_lowq_kernel, dim3(blocks), dim3(256), 0, stream, L.gqueue, L.counter, L.qiou, n2,
+                       L.rowkey, min_pos_iou, assign_all, L.lowq);
+}
+
+}  // namespace
+
+size_t r3k_iou_assign_workspace_bytes(int n1, int n2) {
+  if (n1 <= 0 || n2 <= 0) return 256;
+  return assign_layout(n1, n2, nullptr, nullptr);
+}
+
+int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n2, float pos_thr, float neg_thr,
+                   float min_pos_iou, int match_low, int assign_all, int64_t* assigned, float* max_overlaps,
+                   int64_t* argmax, float* gt_max, int64_t* gt_argmax, void* ws, size_t ws_bytes,
+                   hipStream_t stream) {
+  if (n1 <= 0 || n2 <= 0 || !gts || !boxes || !assigned || !max_overlaps || !ws) return -1;
+  if ((gt_max == nullptr) != (gt_argmax == nullptr)) return -1;
+  if ((unsigned long long)n1 * (unsigned long long)n2 >= 0xffffffffULL) return -1;
+  if (ws_bytes < r3k_iou_assign_workspace_bytes(n1, n2)) return -3;
+  AssignLayout L;
+  assign_layout(n1, n2, ws, &L);
+  switch (geom) {
+    case 1: launch_assign<1>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream); break;
+    case 2: launch_assign<2>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream); break;
+    case 3: launch_assign<3>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream); break;
+    default: return -1;
+  }
+  const int nmax = n1 > n2 ? n1 : n2;
+  hipLaunchKernelGGL(assign_final_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, L.rowkey, n1, L.colkey, L.lowq,
+                     n2, pos_thr, neg_thr, min_pos_iou, match_low, assign_all, assigned, max_overlaps, argmax, gt_max,
+                     gt_argmax);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -12,6 +12,13 @@ int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int
 int r3k_iou_vec(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
                 hipStream_t stream);
 
+// fused MaxIoU assignment on the (gts x boxes) overlaps without materialising them
+size_t r3k_iou_assign_workspace_bytes(int n1, int n2);
+int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n2, float pos_thr, float neg_thr,
+                   float min_pos_iou, int match_low, int assign_all, int64_t* assigned, float* max_overlaps,
+                   int64_t* argmax, float* gt_max, int64_t* gt_argmax, void* ws, size_t ws_bytes,
+                   hipStream_t stream);
+
 size_t r3k_nms_workspace_bytes(int n);
 // dets: (n, det_stride) original order; labels: int64 (n,) or null; order: int64 (n,)
 int r3k_nms(int geom, const float* dets, int det_stride, const int64_t* labels,

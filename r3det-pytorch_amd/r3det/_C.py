@@ -20,6 +20,7 @@ SIGNATURES = {
     "r3det_box_iou_rotated_overlaps": [_vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp],
     "r3det_box_iou_rotated_overlaps_aligned": [_vp, _vp, _i, _i, _vp, _vp],
     "r3det_mmcv_box_iou_rotated": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "r3det_rbbox_assign": [_i, _vp, _i, _vp, _i, _f, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "r3det_rnms": [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp],
     "r3det_nms_rotated": [_vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
     "r3det_ml_nms_rotated": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
@@ -50,6 +51,8 @@ def lib():
             fn.restype = _i
         L.r3det_nms_workspace_bytes.argtypes = [_i]
         L.r3det_nms_workspace_bytes.restype = _sz
+        L.r3det_rbbox_assign_workspace_bytes.argtypes = [_i, _i]
+        L.r3det_rbbox_assign_workspace_bytes.restype = _sz
         L.r3det_mcnms_workspace_bytes.argtypes = [_i, _i]
         L.r3det_mcnms_workspace_bytes.restype = _sz
         L.r3det_mcnms_select_workspace_bytes.argtypes = [_i, _i]

@@ -1,0 +1,135 @@
+"""MaxIoUAssigner for rotated boxes -- the consumer of the (gt x anchors) overlaps on the training
+path (models/dense_heads/rotate_anchor_head.py:220-231 builds it from
+``dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1,
+iou_calculator=dict(type='RBboxOverlaps2D_v1'))``, configs/r3det/r3det_r50_fpn_1x_dota_v1.py).
+
+The class is third-party in the reference stack (mmdet 2.19
+``mmdet/core/bbox/assigners/max_iou_assigner.py``, not under the reference tree), so its rules are
+restated here: ``assign_wrt_overlaps`` is that restatement on a dense overlap matrix;
+``assign`` runs the fused device path (``r3det_rbbox_assign``: no K x N matrix, SURVEY.md 8f
+rank 3) whenever the configuration allows it and must return the same result
+(tests/test_gpu_assign.py).  argmax ties resolve to the smaller index.
+"""
+import torch
+
+from .... import _C
+from ....registry import build_iou_calculator
+from .. import iou_calculators  # noqa: F401  (registers RBboxOverlaps2D_v1/_v2/_v3)
+
+_GEOM = {'RBboxOverlaps2D_v1': 1, 'RBboxOverlaps2D_v2': 2, 'RBboxOverlaps2D_v3': 3}
+
+
+class AssignResult:
+    """num_gts, gt_inds (0 = negative, -1 = ignore, i + 1 = gt i), max_overlaps, labels."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts = num_gts
+        self.gt_inds = gt_inds
+        self.max_overlaps = max_overlaps
+        self.labels = labels
+
+    @property
+    def num_preds(self):
+        return len(self.gt_inds)
+
+
+class MaxIoUAssigner:
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True, ignore_iof_thr=-1,
+                 ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1,
+                 iou_calculator=dict(type='RBboxOverlaps2D_v1')):
+        self.pos_iou_thr = pos_iou_thr
+        self.neg_iou_thr = neg_iou_thr
+        self.min_pos_iou = min_pos_iou
+        self.gt_max_assign_all = gt_max_assign_all
+        self.ignore_iof_thr = ignore_iof_thr
+        self.ignore_wrt_candidates = ignore_wrt_candidates
+        self.match_low_quality = match_low_quality
+        self.gpu_assign_thr = gpu_assign_thr
+        self.iou_calculator = build_iou_calculator(iou_calculator)
+
+    # ------------------------------------------------------------------ fused device path
+    def _fusable(self, bboxes, gt_bboxes, gt_bboxes_ignore):
+        geom = _GEOM.get(type(self.iou_calculator).__name__)
+        if geom is None or not isinstance(self.neg_iou_thr, float) or not bboxes.is_cuda:
+            return None
+        if self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0:
+            return None
+        if gt_bboxes.size(0) == 0 or bboxes.size(0) == 0:
+            return None
+        if geom == 3:
+            # obb_overlaps zeroes rows / columns of boxes thinner than 1e-3 after its kernel
+            if (gt_bboxes[:, 2:4].min() < 1e-3) or (bboxes[:, 2:4].min() < 1e-3):
+                return None
+        return geom
+
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None, with_gt_stats=False):
+        geom = self._fusable(bboxes, gt_bboxes, gt_bboxes_ignore)
+        if geom is None:
+            overlaps = self.iou_calculator(gt_bboxes, bboxes)
+            # (gt_bboxes_ignore / ignore_iof_thr: disabled in the rotated configs, ignore_iof_thr = -1)
+            return self.assign_wrt_overlaps(overlaps, gt_labels)
+        b = _C.need_hip(bboxes[:, :5].contiguous().float(), "bboxes")
+        g = _C.need_hip(gt_bboxes[:, :5].contiguous().float(), "gt_bboxes")
+        n1, n2 = g.size(0), b.size(0)
+        L = _C.lib()
+        with torch.cuda.device(b.device):
+            nbytes = int(L.r3det_rbbox_assign_workspace_bytes(n1, n2))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+            gt_inds = torch.empty(n2, dtype=torch.int64, device=b.device)
+            max_ov = torch.empty(n2, dtype=torch.float32, device=b.device)
+            argmax = torch.empty(n2, dtype=torch.int64, device=b.device)
+            gmax = torch.empty(n1, dtype=torch.float32, device=b.device)
+            gargmax = torch.empty(n1, dtype=torch.int64, device=b.device)
+            _C.check(L.r3det_rbbox_assign(geom, _C.ptr(g), n1, _C.ptr(b), n2, float(self.pos_iou_thr),
+                                          float(self.neg_iou_thr), float(self.min_pos_iou),
+                                          int(self.match_low_quality), int(self.gt_max_assign_all), _C.ptr(gt_inds),
+                                          _C.ptr(max_ov), _C.ptr(argmax), _C.ptr(gmax), _C.ptr(gargmax), _C.ptr(ws),
+                                          nbytes, _C.stream()), "r3det_rbbox_assign")
+        res = AssignResult(n1, gt_inds, max_ov, self._labels(gt_inds, gt_labels))
+        if with_gt_stats:
+            res.argmax_overlaps, res.gt_max_overlaps, res.gt_argmax_overlaps = argmax, gmax, gargmax
+        return res
+
+    # ------------------------------------------------------------------ dense restatement
+    @staticmethod
+    def _labels(gt_inds, gt_labels):
+        if gt_labels is None:
+            return None
+        labels = gt_inds.new_full((gt_inds.numel(), ), -1)
+        pos = torch.nonzero(gt_inds > 0, as_tuple=False).squeeze(1)
+        if pos.numel() > 0:
+            labels[pos] = gt_labels[gt_inds[pos] - 1]
+        return labels
+
+    def assign_wrt_overlaps(self, overlaps, gt_labels=None):
+        num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
+        gt_inds = overlaps.new_full((num_bboxes, ), -1, dtype=torch.long)
+        if num_gts == 0 or num_bboxes == 0:
+            max_overlaps = overlaps.new_zeros((num_bboxes, ))
+            if num_gts == 0:
+                gt_inds[:] = 0
+            labels = None if gt_labels is None else overlaps.new_full((num_bboxes, ), -1, dtype=torch.long)
+            return AssignResult(num_gts, gt_inds, max_overlaps, labels)
+        # first maximum on ties (torch's CPU rule; the device reductions of the stack leave it open)
+        max_overlaps = overlaps.max(dim=0)[0]
+        argmax_overlaps = (overlaps == max_overlaps[None]).int().argmax(dim=0)
+        gt_max_overlaps = overlaps.max(dim=1)[0]
+        gt_argmax_overlaps = (overlaps == gt_max_overlaps[:, None]).int().argmax(dim=1)
+        if isinstance(self.neg_iou_thr, float):
+            gt_inds[(max_overlaps >= 0) & (max_overlaps < self.neg_iou_thr)] = 0
+        elif isinstance(self.neg_iou_thr, tuple):
+            assert len(self.neg_iou_thr) == 2
+            gt_inds[(max_overlaps >= self.neg_iou_thr[0]) & (max_overlaps < self.neg_iou_thr[1])] = 0
+        pos = max_overlaps >= self.pos_iou_thr
+        gt_inds[pos] = argmax_overlaps[pos] + 1
+        if self.match_low_quality:
+            for i in range(num_gts):
+                if gt_max_overlaps[i] >= self.min_pos_iou:
+                    if self.gt_max_assign_all:
+                        gt_inds[overlaps[i, :] == gt_max_overlaps[i]] = i + 1
+                    else:
+                        gt_inds[gt_argmax_overlaps[i]] = i + 1
+        res = AssignResult(num_gts, gt_inds, max_overlaps, self._labels(gt_inds, gt_labels))
+        res.argmax_overlaps, res.gt_max_overlaps, res.gt_argmax_overlaps = argmax_overlaps, gt_max_overlaps, \
+            gt_argmax_overlaps
+        return res

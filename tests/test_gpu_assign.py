@@ -1,0 +1,104 @@
+"""GPU parity: fused MaxIoU assignment (r3det_rbbox_assign: no K x N matrix) against
+(a) the restated assigner rules applied to the dense overlaps of the same library and
+(b) a numpy restatement applied to the ORACLE's overlap matrix (small sizes).
+gt_inds / argmax are integers and max_overlaps are the kernel's own IoUs: exact equality."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rand_boxes
+from oracle import api as O
+
+pytestmark = pytest.mark.gpu
+
+CALCS = ['RBboxOverlaps2D_v1', 'RBboxOverlaps2D_v2', 'RBboxOverlaps2D_v3']
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def make(calc, **kw):
+    from r3det.core.bbox.assigners import MaxIoUAssigner
+    cfg = dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0., ignore_iof_thr=-1, iou_calculator=dict(type=calc))
+    cfg.update(kw)
+    return MaxIoUAssigner(**cfg)
+
+
+def check_same(asg, boxes, gts, labels=None):
+    fused = asg.assign(boxes, gts, gt_labels=labels, with_gt_stats=True)
+    dense = asg.assign_wrt_overlaps(asg.iou_calculator(gts, boxes), labels)
+    assert torch.equal(fused.gt_inds, dense.gt_inds)
+    assert torch.equal(fused.max_overlaps, dense.max_overlaps)
+    assert torch.equal(fused.argmax_overlaps, dense.argmax_overlaps)
+    assert torch.equal(fused.gt_max_overlaps, dense.gt_max_overlaps)
+    assert torch.equal(fused.gt_argmax_overlaps, dense.gt_argmax_overlaps)
+    if labels is not None:
+        assert torch.equal(fused.labels, dense.labels)
+    return fused
+
+
+@pytest.mark.parametrize("calc", CALCS)
+@pytest.mark.parametrize("k,n,span", [(1, 100, 150.), (5, 1000, 300.), (37, 5000, 600.), (128, 20000, 1000.)])
+def test_matches_dense_rules(calc, k, n, span):
+    gts = dev(rand_boxes(k, 10 + k, span=span))
+    boxes = dev(rand_boxes(n, 20 + n, span=span))
+    labels = torch.randint(0, 15, (k,), device='cuda')
+    for kw in (dict(), dict(min_pos_iou=0.3), dict(gt_max_assign_all=False), dict(match_low_quality=False),
+               dict(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.1)):
+        check_same(make(calc, **kw), boxes, gts, labels)
+
+
+def test_assignment_shape_full_size():
+    """128 DOTA-like gts against the real 196 416-anchor grid (BASELINE training-step shape)."""
+    from r3det import synthetic as syn
+    anchors = syn.anchor_grid(device='cuda')
+    gts = syn.dota_like_rboxes(128, 5, device='cuda')
+    res = check_same(make('RBboxOverlaps2D_v1'), anchors, gts, torch.randint(0, 15, (128,), device='cuda'))
+    assert (res.gt_inds > 0).sum() >= 128 * 0.6  # most gts own at least their best anchor
+
+
+def test_gt_without_any_overlap_takes_every_anchor():
+    """min_pos_iou = 0 (the shipped config): a gt whose best IoU is 0 satisfies `overlaps[i] == gt_max[i]`
+    on EVERY anchor; later gts then re-take their own best anchors.  The fused path must reproduce it."""
+    boxes = dev(rand_boxes(3000, 3, span=400.))
+    gts = rand_boxes(6, 4, span=400.)
+    gts[2, :2] += 5000.   # far away from every box
+    gts[4, :2] -= 7000.
+    gts = dev(gts)
+    for kw in (dict(), dict(gt_max_assign_all=False)):
+        res = check_same(make('RBboxOverlaps2D_v1', **kw), boxes, gts)
+        if kw == dict():
+            assert (res.gt_inds > 0).all()                       # nobody stays negative
+            assert (res.gt_inds == 5).sum() > 2000               # the last zero-overlap gt (index 4) wins them
+    res = check_same(make('RBboxOverlaps2D_v1', min_pos_iou=0.01), boxes, gts)
+    assert (res.gt_inds == 5).sum() == 0
+
+
+@pytest.mark.parametrize("calc,geom", [('RBboxOverlaps2D_v1', O.V1), ('RBboxOverlaps2D_v3', O.V3)])
+def test_against_oracle_matrix(calc, geom):
+    """Independent of the library's own IoU kernels: numpy rules on the oracle's matrix."""
+    k, n = 9, 700
+    g, b = rand_boxes(k, 77, span=260.), rand_boxes(n, 78, span=260.)
+    with O.twin():
+        ov = O.iou_mat(geom, g, b)
+    mo, am = ov.max(0), ov.argmax(0)
+    gm = ov.max(1)
+    want = np.full(n, -1, dtype=np.int64)
+    want[(mo >= 0) & (mo < 0.4)] = 0
+    want[mo >= 0.5] = am[mo >= 0.5] + 1
+    for i in range(k):
+        if gm[i] >= 0.:
+            want[ov[i] == gm[i]] = i + 1
+    res = make(calc).assign(dev(b), dev(g))
+    assert np.array_equal(res.gt_inds.cpu().numpy(), want)
+    assert np.array_equal(res.max_overlaps.cpu().numpy(), mo)
+
+
+def test_degenerate_inputs_take_the_dense_path():
+    asg = make('RBboxOverlaps2D_v1')
+    boxes = dev(rand_boxes(50, 1))
+    res = asg.assign(boxes, boxes.new_zeros((0, 5)))
+    assert (res.gt_inds == 0).all() and res.num_gts == 0
+    res = asg.assign(boxes.new_zeros((0, 5)), boxes[:3])
+    assert res.gt_inds.numel() == 0

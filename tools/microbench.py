@@ -69,6 +69,22 @@ def bench_iou():
     _C.set_option("iou_impl", 0)
 
 
+def bench_assign():
+    """MaxIoU assignment on the training-step shapes: fused (no matrix) vs dense (IoU matrix +
+    torch reductions + the per-gt loop)."""
+    from r3det.core.bbox.assigners import MaxIoUAssigner
+    dev = torch.device("cuda")
+    anchors = syn.anchor_grid(device=dev)
+    for k in (32, 128):
+        gts = syn.dota_like_rboxes(k, 5, device=dev)
+        asg = MaxIoUAssigner(0.5, 0.4, 0., iou_calculator=dict(type='RBboxOverlaps2D_v1'))
+        var = {"fused": lambda: asg.assign(anchors, gts),
+               "dense": lambda: asg.assign_wrt_overlaps(asg.iou_calculator(gts, anchors)),
+               "iou matrix only": lambda: asg.iou_calculator(gts, anchors)}
+        for name, (med, mn) in time_variants(var, rounds=5, reps=5).items():
+            print(f"assign {k}x{anchors.size(0)} {name:16s} med {med:9.1f} us  min {mn:9.1f} us", flush=True)
+
+
 def bench_fr():
     from r3det.ops.feature_refine import fr_backward, fr_forward
     dev = torch.device("cuda")
@@ -123,6 +139,8 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["iou", "fr", "nms"]
     if "iou" in what:
         bench_iou()
+    if "assign" in what:
+        bench_assign()
     if "fr" in what:
         bench_fr()
     if "nms" in what:
