@@ -192,6 +192,21 @@ int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxe
                                   int H, int W, float spatial_scale, int points,
                                   float* bottom_grad, int overwrite, void* stream);
 
+/* Producer of the FR boxes: RRetinaHead.filter_bboxes
+ * (models/dense_heads/rotate_retina_head.py:117-179) and, with num_anchors = 1 and
+ * anchors_per_image = 1, RRetinaRefineHead.refine_bboxes (rotate_retina_refine_head.py:56-97),
+ * both ending in delta2bbox_v1 (core/bbox/coder/delta_xywha_rbbox_coder.py:142-211, means 0,
+ * stds 1, no max_shape).  cls_score (N, A*C, H, W) and bbox_pred (N, A*5, H, W) are read through
+ * their element strides {n, c, h, w} (host arrays of 4), so NCHW and channels_last maps both work;
+ * cls_score may be NULL when num_anchors == 1.  anchors: (H*W*A, 5), or (N, H*W*A, 5) with
+ * anchors_per_image != 0.  Per position: best anchor = first argmax over anchors of the max class
+ * logit; boxes_out (N, H*W, 5) = decode(anchor, deltas), the layout FR reads.
+ * max_ratio = |log(wh_ratio_clip)|. */
+int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, const float* bbox_pred,
+                        const long long* pred_strides, const float* anchors, int anchors_per_image, int N,
+                        int num_anchors, int num_classes, int H, int W, float max_ratio, float* boxes_out,
+                        void* stream);
+
 /* Kernel-selection knobs for A/B measurements (not part of the reference surface).
  * r3det_set_option("fr_impl", 0 auto | 1 generic | 2 lds-plane | 10 cell), ("iou_impl", ...),
  * ("nms_impl", 0 | 1 tiles | 2 older reducer), ("nms_qcap", n), ("fr_profile", 0 | 1). */

@@ -164,6 +164,14 @@ int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxe
                             overwrite, S(stream)));
 }
 
+int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, const float* bbox_pred,
+                        const long long* pred_strides, const float* anchors, int anchors_per_image, int N,
+                        int num_anchors, int num_classes, int H, int W, float max_ratio, float* boxes_out,
+                        void* stream) {
+  return rc(r3k_filter_bboxes(cls_score, cls_strides, bbox_pred, pred_strides, anchors, anchors_per_image, N,
+                              num_anchors, num_classes, H, W, max_ratio, boxes_out, S(stream)));
+}
+
 int r3det_fr_profile_read(float* records, int capacity) {
   if (capacity < 0 || (capacity > 0 && !records)) return 0;
   return r3k_fr_profile_read(records, capacity);

@@ -45,6 +45,11 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
                     float scale, int points, float* bottom_grad, int overwrite,
                     hipStream_t stream);
 
+// FR box producers: best anchor per position + delta2bbox_v1, strided (NCHW or channels_last) inputs
+int r3k_filter_bboxes(const float* cls, const long long* cls_strides, const float* reg,
+                      const long long* reg_strides, const float* anchors, int per_image, int N, int A, int C,
+                      int H, int W, float max_ratio, float* out, hipStream_t stream);
+
 // profiling ring of the FR cell path (see r3det_fr_profile_read)
 int r3k_fr_profile_read(float* records, int capacity);
 extern int g_r3_fr_profile;

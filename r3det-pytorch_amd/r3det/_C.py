@@ -27,6 +27,7 @@ SIGNATURES = {
     "r3det_mmcv_nms_rotated": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
     "r3det_mcnms_select": [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "r3det_mcnms_v1": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp],
+    "r3det_filter_bboxes": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "r3det_feature_refine_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp],
     "r3det_feature_refine_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "r3det_set_option": [ctypes.c_char_p, _i],

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ..core.post_processing import multiclass_nms_rotated_batch
+from ..ops import fr_boxes
 from .backbone import ConvModule
 from .coder import delta2bbox_v1
 
@@ -85,7 +86,21 @@ class RRetinaHead(nn.Module):
     @torch.no_grad()
     def filter_bboxes(self, cls_scores, bbox_preds):
         """Best-scoring anchor per position, decoded (rotate_retina_head.py:117-179).
-        Returns list[img][lvl] of (H*W, 5)."""
+        Returns list[img][lvl] of (H*W, 5).  One fused launch per level on the device
+        (ops/fr_boxes.py); ``filter_bboxes_torch`` is the op-by-op form the tests compare with."""
+        if not cls_scores[0].is_cuda:
+            return self.filter_bboxes_torch(cls_scores, bbox_preds)
+        N = cls_scores[0].size(0)
+        anchors = self.anchors([c.shape[-2:] for c in cls_scores], cls_scores[0].device)
+        out = [[] for _ in range(N)]
+        for cls, reg, anc in zip(cls_scores, bbox_preds, anchors):
+            boxes = fr_boxes.filter_bboxes(cls, reg, anc, self.num_anchors, self.cls_out_channels)
+            for i in range(N):
+                out[i].append(boxes[i])
+        return out
+
+    @torch.no_grad()
+    def filter_bboxes_torch(self, cls_scores, bbox_preds):
         N = cls_scores[0].size(0)
         anchors = self.anchors([c.shape[-2:] for c in cls_scores], cls_scores[0].device)
         out = [[] for _ in range(N)]
@@ -142,6 +157,18 @@ class RRetinaRefineHead(RRetinaHead):
 
     @torch.no_grad()
     def refine_bboxes(self, cls_scores, bbox_preds, rois):
+        if not bbox_preds[0].is_cuda:
+            return self.refine_bboxes_torch(cls_scores, bbox_preds, rois)
+        N = cls_scores[0].size(0)
+        out = [[] for _ in range(N)]
+        for l, reg in enumerate(bbox_preds):
+            ref = fr_boxes.refine_bboxes(reg, torch.stack([rois[i][l] for i in range(N)]))
+            for i in range(N):
+                out[i].append(ref[i])
+        return out
+
+    @torch.no_grad()
+    def refine_bboxes_torch(self, cls_scores, bbox_preds, rois):
         N = cls_scores[0].size(0)
         out = [[] for _ in range(N)]
         for l, reg in enumerate(bbox_preds):

@@ -1,0 +1,68 @@
+"""GPU parity: fused FR box producers (r3det_filter_bboxes) against the op-by-op torch form of
+RRetinaHead.filter_bboxes / RRetinaRefineHead.refine_bboxes on the same device, for NCHW and
+channels_last head outputs.  The best-anchor choice is an integer decision (exact); the decoded
+boxes go through exp: tolerance 1e-6 relative (north_star: 1e-5), written below."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def heads():
+    from r3det.models.heads import RRetinaHead, RRetinaRefineHead
+    torch.manual_seed(3)
+    return RRetinaHead().cuda().eval(), RRetinaRefineHead().cuda().eval()
+
+
+def close(a, b):
+    assert a.shape == b.shape
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("sizes", [[(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)], [(128, 128), (64, 64), (13, 7)]])
+def test_filter_bboxes(channels_last, sizes):
+    head, _ = heads()
+    head.strides = head.strides[:len(sizes)]
+    N, A, C = 3, head.num_anchors, head.cls_out_channels
+    g = torch.Generator(device='cuda').manual_seed(5)
+    cls = [torch.randn(N, A * C, h, w, device='cuda', generator=g) for h, w in sizes]
+    reg = [torch.randn(N, A * 5, h, w, device='cuda', generator=g) * 0.5 for h, w in sizes]
+    reg[0][0, 2::5] = 9.0    # dw far beyond the wh_ratio clip
+    reg[0][1, 3::5] = -9.0
+    cls[0][2, :, 0, 0] = 0.25  # a position where every anchor ties: the first one must win
+    if channels_last:
+        cls = [c.contiguous(memory_format=torch.channels_last) for c in cls]
+        reg = [r.contiguous(memory_format=torch.channels_last) for r in reg]
+    got = head.filter_bboxes(cls, reg)
+    want = head.filter_bboxes_torch(cls, reg)
+    for i in range(N):
+        for l in range(len(sizes)):
+            close(got[i][l], want[i][l])
+    # the integer decision, checked on its own: decoded centre = anchor centre + anchor size * delta
+    anc = head.anchors([c.shape[-2:] for c in cls], 'cuda')[0].reshape(-1, A, 5)
+    c0 = cls[0].permute(0, 2, 3, 1).reshape(N, -1, A, C)
+    best = c0.max(-1)[0].argmax(-1)
+    assert best[2, 0] == 0
+    aw = anc[torch.arange(anc.size(0)), best[2], 2]
+    assert torch.allclose(got[2][0][:, 2] / aw, (reg[0].permute(0, 2, 3, 1).reshape(N, -1, A, 5)[2][
+        torch.arange(anc.size(0)), best[2], 2]).clamp(-4.135166556742356, 4.135166556742356).exp(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_refine_bboxes(channels_last):
+    _, ref = heads()
+    sizes = [(32, 32), (16, 16), (5, 9)]
+    ref.strides = ref.strides[:len(sizes)]
+    N = 2
+    g = torch.Generator(device='cuda').manual_seed(7)
+    reg = [torch.randn(N, 5, h, w, device='cuda', generator=g) * 0.3 for h, w in sizes]
+    cls = [torch.randn(N, 15, h, w, device='cuda', generator=g) for h, w in sizes]
+    rois = [[torch.rand(h * w, 5, device='cuda', generator=g) * 100 + 1 for h, w in sizes] for _ in range(N)]
+    if channels_last:
+        reg = [r.contiguous(memory_format=torch.channels_last) for r in reg]
+    got = ref.refine_bboxes(cls, reg, rois)
+    want = ref.refine_bboxes_torch(cls, reg, rois)
+    for i in range(N):
+        for l in range(len(sizes)):
+            close(got[i][l], want[i][l])
