@@ -40,6 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achiev
 NMS_CFG = dict(iou_thr=0.1)  # type absent -> 'v1' (bbox_nms_rotated.py:43)
 SCORE_THR, MAX_PER_IMG = 0.05, 2000
 CHANNELS_LAST = os.environ.get("R3DET_BENCH_NCHW", "0") != "1"  # activation layout of the conv stack
+FUSE = os.environ.get("R3DET_BENCH_NOFUSE", "0") != "1"          # conv+BN folding and fused epilogues
 PROFILE_PMC = os.path.join(ROOT, "profiles", "r01_fr_forward_pmc.json")
 
 
@@ -48,6 +49,11 @@ def build_model(device, seed):
     from r3det.models.detectors import calibrate_score_bias
     torch.manual_seed(seed)
     model = R3Det().eval().to(device)
+    if FUSE:
+        # what the reference's benchmark does with --fuse-conv-bn (tools/analysis_tools/benchmark.py:88-89),
+        # plus one-pass bias / ReLU / residual epilogues (r3det_bias_act) instead of 2-3 elementwise launches
+        from r3det.models.fuse import fuse_for_inference
+        fuse_for_inference(model)
     g = torch.Generator(device="cpu")
     g.manual_seed(seed + 1)
     img = torch.randn(BATCH, 3, IMG, IMG, generator=g).to(device)
@@ -256,6 +262,18 @@ def main():
             line["hot_path"] = {"what": "custom ops only, same shapes: FR sampler x5 levels (N=4, C=256) + batched "
                                         "multiclass_nms_rotated(v1) on 4 x 5344-box pools",
                                 "ms_per_step": round(dt * 1e3, 3), "img_s": round(BATCH / dt, 1)}
+            # the roofline kernel once more, in this loop (no convolutions around it: what the kernel does
+            # when its planes are not competing with the conv stack's dirty lines for the Infinity Cache)
+            _C.fr_profile_read()
+            _C.set_option("fr_profile", 1)
+            timeit(lambda: hot_path_step(wl), 20, warm=0)
+            _C.set_option("fr_profile", 0)
+            hp = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
+            if hp:
+                us = sum(r[2] + r[3] for r in hp) / len(hp)
+                line["roofline"]["hot_path_context"] = {
+                    "avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
+                    "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(hp)}
         if not args.no_ops:
             line["ops"] = op_rates(device)
         if world == 1 and not args.no_cpu_baseline:

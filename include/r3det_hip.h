@@ -207,6 +207,16 @@ int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, co
                         int num_anchors, int num_classes, int H, int W, float max_ratio, float* boxes_out,
                         void* stream);
 
+/* Convolution epilogue of the inference model around the hot path (not one of the reference's
+ * extension ops): y = act(y + bias[c] (+ residual)) in place, one pass.  The reference's benchmark
+ * folds BatchNorm into the convolutions (tools/analysis_tools/benchmark.py:88-89, mmcv fuse_conv_bn);
+ * this replaces the bias add / ReLU / residual add launches that remain.  y holds outer x C x inner
+ * elements (NCHW: outer = N, inner = H*W; channels_last: outer = N*H*W, inner = 1, C % 4 == 0);
+ * residual has the same shape and layout or is NULL.  Returns R3DET_EINVAL for shapes it does not
+ * take (the caller then uses its own elementwise ops). */
+int r3det_bias_act(float* y, const float* bias, const float* residual, long long outer, int C, long long inner,
+                   int relu, void* stream);
+
 /* Kernel-selection knobs for A/B measurements (not part of the reference surface).
  * r3det_set_option("fr_impl", 0 auto | 1 generic | 2 lds-plane | 10 cell), ("iou_impl", ...),
  * ("nms_impl", 0 | 1 tiles | 2 older reducer), ("nms_qcap", n), ("fr_profile", 0 | 1). */

@@ -172,6 +172,11 @@ int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, co
                               num_anchors, num_classes, H, W, max_ratio, boxes_out, S(stream)));
 }
 
+int r3det_bias_act(float* y, const float* bias, const float* residual, long long outer, int C, long long inner,
+                   int relu, void* stream) {
+  return rc(r3k_bias_act(y, bias, residual, outer, C, inner, relu, S(stream)));
+}
+
 int r3det_fr_profile_read(float* records, int capacity) {
   if (capacity < 0 || (capacity > 0 && !records)) return 0;
   return r3k_fr_profile_read(records, capacity);

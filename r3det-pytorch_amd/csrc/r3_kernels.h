@@ -50,6 +50,10 @@ int r3k_filter_bboxes(const float* cls, const long long* cls_strides, const floa
                       const long long* reg_strides, const float* anchors, int per_image, int N, int A, int C,
                       int H, int W, float max_ratio, float* out, hipStream_t stream);
 
+// convolution epilogue of the inference model: y = act(y + bias[c] (+ residual)), in place
+int r3k_bias_act(float* y, const float* bias, const float* residual, long long outer, int C, long long inner, int relu,
+                 hipStream_t stream);
+
 // profiling ring of the FR cell path (see r3det_fr_profile_read)
 int r3k_fr_profile_read(float* records, int capacity);
 extern int g_r3_fr_profile;

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libr3det_hip.so")
+# R3DET_HIP_LIB: alternative build of the same ABI (kernel A/B experiments, tools/fr_lib_ab.py)
+LIB_PATH = os.environ.get("R3DET_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libr3det_hip.so")
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -27,6 +28,7 @@ SIGNATURES = {
     "r3det_mmcv_nms_rotated": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
     "r3det_mcnms_select": [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "r3det_mcnms_v1": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp],
+    "r3det_bias_act": [_vp, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_longlong, _i, _vp],
     "r3det_filter_bboxes": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "r3det_feature_refine_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp],
     "r3det_feature_refine_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],

@@ -169,3 +169,71 @@ def test_r3det_end_to_end_small():
     calibrate_score_bias(r, img, frac=0.005)
     out = r.simple_test(img)
     assert len(out) == 2 and out[0][0].size(1) == 6
+
+
+def _randomise_bn(model, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+
+def test_fuse_conv_bn_and_epilogues_cpu():
+    """BatchNorm folded into the convolutions (the reference benchmark's --fuse-conv-bn) and the
+    one-pass epilogues (torch fallback on CPU) reproduce the eval-mode network up to rounding."""
+    from r3det.models.backbone import FPN, ResNet50
+    from r3det.models.fuse import fuse_conv_bn, fuse_epilogues
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(ResNet50(), FPN()).eval()
+    _randomise_bn(net)
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        want = net(x)
+        fuse_conv_bn(net)
+        assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in net.modules())
+        got1 = net(x)
+        fuse_epilogues(net)
+        got2 = net(x)
+    for w, a, b in zip(want, got1, got2):
+        scale = w.abs().max().item()
+        assert (a - w).abs().max().item() <= 1e-5 * scale
+        assert (b - w).abs().max().item() <= 1e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_fused_inference_model_gpu(channels_last):
+    """r3det_bias_act (NCHW and channels_last) inside the fused model: same feature maps up to rounding."""
+    from r3det.models.backbone import FPN, ResNet50
+    from r3det.models.fuse import fuse_for_inference
+    from r3det.ops.epilogue import bias_act_
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(ResNet50(), FPN()).eval()
+    _randomise_bn(net)
+    net = net.cuda()
+    x = torch.randn(2, 3, 256, 192, device='cuda')
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    with torch.no_grad():
+        want = net(x)
+        fuse_for_inference(net)
+        net = net.to(memory_format=fmt)
+        got = net(x.contiguous(memory_format=fmt))
+    for w, a in zip(want, got):
+        assert (a - w).abs().max().item() <= 2e-5 * w.abs().max().item()
+    # the op itself, against its definition, exactly (adds in the same order)
+    for shape in [(2, 8, 5, 7), (3, 64, 16, 16), (1, 256, 1, 1)]:
+        y = torch.randn(shape, device='cuda').contiguous(memory_format=fmt)
+        b = torch.randn(shape[1], device='cuda')
+        r = torch.randn(shape, device='cuda').contiguous(memory_format=fmt)
+        for res in (None, r):
+            for relu in (False, True):
+                ref = y + b.view(1, -1, 1, 1)
+                if res is not None:
+                    ref = ref + res
+                if relu:
+                    ref = ref.relu()
+                out = bias_act_(y.clone(memory_format=torch.preserve_format), b, res, relu)
+                assert torch.equal(out, ref)
