@@ -207,6 +207,33 @@ int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, co
                         int num_anchors, int num_classes, int H, int W, float max_ratio, float* boxes_out,
                         void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Exported ops outside the shipped training / inference configs
+ * ------------------------------------------------------------------------------------- */
+
+/* polygon_geo_cpu.polygon_iou(a, b)                 polygon_geo/src/polygon_geo_cpu.cpp:272-287
+ * (CPU-only in the reference).  a (na,8), b (nb,8) = 4 vertices each -> out (na,nb). */
+int r3det_polygon_iou(const float* polys_a, int na, const float* polys_b, int nb, float* out, void* stream);
+
+/* nms_rotated_ext.nms_poly(dets9, thr)              nms_rotated/src/nms_rotated_ext.cpp:38-51,
+ * kernel + host scan nms_rotated/src/poly_nms_cuda.cu:142-261.  dets9 (n,9) = 8 coordinates +
+ * score, in ORIGINAL order; order = indices by descending score (stable).  keep_out (int64,
+ * capacity n) = original indices in score order, count_out (int32, device).  Suppression on
+ * devPolyIoU > thr.  r3det_poly_iou_mat exposes that IoU as a matrix (rows of `stride` floats,
+ * the first 8 are used) for tests. */
+size_t r3det_poly_nms_workspace_bytes(int n);
+int r3det_nms_poly(const float* dets9, const int64_t* order, int n, float thr, void* ws, size_t ws_bytes,
+                   int64_t* keep_out, int32_t* count_out, void* stream);
+int r3det_poly_iou_mat(const float* a, int na, int stride_a, const float* b, int nb, int stride_b, float* out,
+                       void* stream);
+
+/* convex_ext.convex_sort(pts, masks, circular)       convex/src/convex_ext.cpp:13-27, kernel + tensor
+ * prologue convex/src/convex_cuda.cu:13-123.  pts (B,P,2) fp32, masks (B,P) bytes (0 / non-0) ->
+ * index_out (B, P + (circular != 0)) int64, padded with -1.  Equal sort keys are visited in index
+ * order (the reference leaves that to torch.argsort).  ws: B * P * 4 bytes. */
+int r3det_convex_sort(const float* pts, const unsigned char* masks, int B, int P, int circular, void* ws,
+                      size_t ws_bytes, int64_t* index_out, void* stream);
+
 /* Convolution epilogue of the inference model around the hot path (not one of the reference's
  * extension ops): y = act(y + bias[c] (+ residual)) in place, one pass.  The reference's benchmark
  * folds BatchNorm into the convolutions (tools/analysis_tools/benchmark.py:88-89, mmcv fuse_conv_bn);

@@ -211,3 +211,74 @@ def ref_v2_nms(dets6, scores, thr):
     L.ref_v2_nms.restype = ctypes.c_int
     k = L.ref_v2_nms(_fp(dets6), _fp(scores), n, float(thr), keep.ctypes.data_as(_I64))
     return keep[:k].copy()
+
+
+# ----------------------------------------------------------------------------------------
+# "rank 4" ops: convex_sort, polygon_iou (pinned by oracle/_ref), poly_nms (parity unpinned:
+# CUDA-only in the reference)
+# ----------------------------------------------------------------------------------------
+def polygon_iou(a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    L = lib()
+    L.orc_polygon_iou.argtypes = [_F, ctypes.c_int, _F, ctypes.c_int, _F]
+    L.orc_polygon_iou(_fp(a), a.shape[0], _fp(b), b.shape[0], _fp(out))
+    return out
+
+
+def poly_iou_mat(a, b):
+    """devPolyIoU of poly_nms as a matrix; rows of a / b hold >= 8 coordinates."""
+    a, b = _f32(a), _f32(b)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    L = lib()
+    L.orc_poly_iou_mat.argtypes = [_F, ctypes.c_int, ctypes.c_int, _F, ctypes.c_int, ctypes.c_int, _F]
+    L.orc_poly_iou_mat(_fp(a), a.shape[0], a.shape[1], _fp(b), b.shape[0], b.shape[1], _fp(out))
+    return out
+
+
+def poly_nms(dets9, thr):
+    dets9 = _f32(dets9)
+    n = dets9.shape[0]
+    keep = np.empty((max(n, 1),), np.int64)
+    L = lib()
+    L.orc_poly_nms.argtypes = [_F, ctypes.c_int, ctypes.c_float, _I64]
+    L.orc_poly_nms.restype = ctypes.c_int
+    k = L.orc_poly_nms(_fp(dets9), n, float(thr), keep.ctypes.data_as(_I64))
+    return keep[:k].copy()
+
+
+def convex_sort(pts, masks, circular=True):
+    pts = _f32(pts)
+    m = np.ascontiguousarray(np.asarray(masks).astype(np.float32))
+    B, P = pts.shape[:2]
+    out = np.empty((B, P + 1 if circular else P), np.int64)
+    L = lib()
+    L.orc_convex_sort.argtypes = [_F, _F, ctypes.c_int, ctypes.c_int, ctypes.c_int, _I64]
+    L.orc_convex_sort(_fp(pts), _fp(m), B, P, int(circular), out.ctypes.data_as(_I64))
+    return out
+
+
+def ref_rank4_available():
+    return all(os.path.exists(os.path.join(_build.OUT_REF, n)) for n in ("libref_convex.so", "libref_polygon.so")) \
+        or _build.ref_available()
+
+
+def ref_polygon_iou(a, b):
+    L = _ref_lib("libref_polygon.so")
+    a, b = _f32(a), _f32(b)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    L.ref_polygon_iou.argtypes = [_F, ctypes.c_int, _F, ctypes.c_int, _F]
+    L.ref_polygon_iou(_fp(a), a.shape[0], _fp(b), b.shape[0], _fp(out))
+    return out
+
+
+def ref_convex_sort(pts, masks, circular=True):
+    L = _ref_lib("libref_convex.so")
+    pts = _f32(pts)
+    m = np.ascontiguousarray(np.asarray(masks).astype(np.uint8))
+    B, P = pts.shape[:2]
+    out = np.empty((B, P + 1 if circular else P), np.int64)
+    L.ref_convex_sort.argtypes = [_F, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int, ctypes.c_int, _I64]
+    L.ref_convex_sort(_fp(pts), m.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), B, P, int(circular),
+                      out.ctypes.data_as(_I64))
+    return out

@@ -87,6 +87,15 @@ def build_ref(force=False):
             defs=['-DREF_ML_UTILS_H="%s"' % os.path.join(
                 REF_OPS, "ml_nms_rotated/src/box_iou_rotated_utils.h")],
             deps=[os.path.join(REF_OPS, "ml_nms_rotated/src/box_iou_rotated_utils.h")]),
+        "libref_convex.so": dict(
+            srcs=[os.path.join(H, "harness_rank4.cpp"), os.path.join(REF_OPS, "convex/src/convex_cpu.cpp")],
+            defs=["-DHARNESS_CONVEX"], deps=[]),
+        "libref_polygon.so": dict(
+            srcs=[os.path.join(H, "harness_rank4.cpp")],
+            defs=["-DHARNESS_POLYGON", "-DTORCH_EXTENSION_NAME=ref_polygon_geo",
+                  '-DREF_POLYGON_CPP="%s"' % os.path.join(REF_OPS, "polygon_geo/src/polygon_geo_cpu.cpp")],
+            deps=[os.path.join(REF_OPS, "polygon_geo/src/polygon_geo_cpu.cpp")],
+            libs=["-ltorch_python"]),  # the file's PYBIND11_MODULE block needs the Tensor casters
     }
     out = {}
     for name, j in jobs.items():
@@ -100,7 +109,7 @@ def build_ref(force=False):
             _run(["g++"] + cflags + j["defs"] + ["-c", s, "-o", o])
             objs.append(o)
         # -Bsymbolic: each .so binds its own copies of the reference's inline templates
-        _run(["g++", "-shared", "-Wl,-Bsymbolic", "-o", target] + objs + ldflags)
+        _run(["g++", "-shared", "-Wl,-Bsymbolic", "-o", target] + objs + ldflags + j.get("libs", []))
         for o in objs:
             os.remove(o)
     return out

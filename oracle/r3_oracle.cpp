@@ -514,6 +514,138 @@ void fr_points(const float* box, float scale, int points, float* px, float* py) 
   }
 }
 
+// ===========================================================================
+// polygon_iou (polygon_geo/src/polygon_geo_cpu.cpp): the v1 machinery on general
+// 4-point polygons.  Pinned by oracle/_ref (the reference file compiles verbatim).
+// ===========================================================================
+// polygon2points (:137-158): vertices 2 and 3 insertion-sorted around vertex 0.
+void poly_points(const float* poly, P1* vs) {
+  for (int i = 0; i < 4; i++) vs[i] = P1{poly[2 * i], poly[2 * i + 1]};
+  for (int i = 2; i < 4; i++) {
+    P1 pt = vs[i];
+    int j;
+    for (j = i - 1; less1(sub1(pt, vs[0]), sub1(vs[j], vs[0])); j--) vs[j + 1] = vs[j];
+    vs[j + 1] = pt;
+  }
+}
+
+// vertex_in_polygon (:160-184): v1[i] is kept unless some edge of v2 has it on its right.
+int poly_vertex_in(const P1* v1, const P1* v2, P1* ps, int room) {
+  int cnt = 0;
+  for (int i = 0; i < 4; i++) {
+    bool inside = true;
+    for (int j = 0; j < 4; j++) {
+      P1 pr = sub1(v1[i], v2[j]);
+      P1 pb = sub1(v2[(j + 1) % 4], v2[j]);
+      if (less1(pr, pb)) {
+        inside = false;
+        break;
+      }
+    }
+    if (inside) {
+      if (cnt < room) ps[cnt] = v1[i];
+      cnt++;
+    }
+  }
+  return cnt;
+}
+
+// polygon_iou_kernel pair body (:241-266); candidate points beyond the reference's 16-slot
+// scratch are dropped (it would write out of bounds there), as in v1_pair.
+float poly_pair(const float* a, const float* b) {
+  P1 v1[4], v2[4], u[V1_CAP];
+  poly_points(a, v1);
+  poly_points(b, v2);
+  int cnt = 0;
+  cnt += poly_vertex_in(v1, v2, u + cnt, V1_CAP - cnt);
+  if (cnt > V1_CAP) cnt = V1_CAP;
+  cnt += poly_vertex_in(v2, v1, u + cnt, V1_CAP - cnt);
+  if (cnt > V1_CAP) cnt = V1_CAP;
+  cnt += v1_border(v1, v2, u + cnt, V1_CAP - cnt);
+  if (cnt > V1_CAP) cnt = V1_CAP;
+  if (cnt >= 3) {
+    float s1 = v1_area(v1, 4);
+    float s2 = v1_area(v2, 4);
+    float su = v1_area(u, cnt);
+    su = std::min(su, s1);
+    su = std::min(su, s2);
+    su = std::max(su, 0.0f);
+    return su / (s1 + s2 - su);
+  }
+  return 0.0f;
+}
+
+// ===========================================================================
+// poly_nms IoU (nms_rotated/src/poly_nms_cuda.cu:21-140): signed triangle-fan clipping.
+// CUDA-only in the reference (poly_nms_cpu.cpp is a stub): PARITY UNPINNED, restated from
+// the source text.  float arithmetic, eps compared in double as the source does.
+// ===========================================================================
+struct F2 {
+  float x, y;
+};
+const double PN_EPS = 1E-8;
+inline int pn_sig(float d) { return (d > PN_EPS) - (d < -PN_EPS); }
+inline bool pn_eq(F2 a, F2 b) { return pn_sig(a.x - b.x) == 0 && pn_sig(a.y - b.y) == 0; }
+inline float pn_cross(F2 o, F2 a, F2 b) { return (a.x - o.x) * (b.y - o.y) - (b.x - o.x) * (a.y - o.y); }
+inline float pn_area(F2* ps, int n) {
+  ps[n] = ps[0];
+  float res = 0;
+  for (int i = 0; i < n; i++) res += ps[i].x * ps[i + 1].y - ps[i].y * ps[i + 1].x;
+  return res / 2.0;
+}
+inline int pn_line_cross(F2 a, F2 b, F2 c, F2 d, F2& p) {
+  float s1 = pn_cross(a, b, c), s2 = pn_cross(a, b, d);
+  if (pn_sig(s1) == 0 && pn_sig(s2) == 0) return 2;
+  if (pn_sig(s2 - s1) == 0) return 0;
+  p.x = (c.x * s2 - d.x * s1) / (s2 - s1);
+  p.y = (c.y * s2 - d.y * s1) / (s2 - s1);
+  return 1;
+}
+inline void pn_cut(F2* p, int& n, F2 a, F2 b, F2* pp) {
+  int m = 0;
+  p[n] = p[0];
+  for (int i = 0; i < n; i++) {
+    if (pn_sig(pn_cross(a, b, p[i])) > 0) pp[m++] = p[i];
+    if (pn_sig(pn_cross(a, b, p[i])) != pn_sig(pn_cross(a, b, p[i + 1]))) pn_line_cross(a, b, p[i], p[i + 1], pp[m++]);
+  }
+  n = 0;
+  for (int i = 0; i < m; i++)
+    if (!i || !pn_eq(pp[i], pp[i - 1])) p[n++] = pp[i];
+  while (n > 1 && pn_eq(p[n - 1], p[0])) n--;
+}
+inline float pn_tri(F2 a, F2 b, F2 c, F2 d) {
+  F2 o{0, 0};
+  int s1 = pn_sig(pn_cross(o, a, b)), s2 = pn_sig(pn_cross(o, c, d));
+  if (s1 == 0 || s2 == 0) return 0.0;
+  if (s1 == -1) std::swap(a, b);
+  if (s2 == -1) std::swap(c, d);
+  F2 p[10] = {o, a, b};
+  int n = 3;
+  F2 pp[10] = {};  // (the source leaves it uninitialised; a skipped lineCross then keeps garbage)
+  pn_cut(p, n, o, c, pp);
+  pn_cut(p, n, c, d, pp);
+  pn_cut(p, n, d, o, pp);
+  float res = std::fabs(pn_area(p, n));
+  if (s1 * s2 == -1) res = -res;
+  return res;
+}
+float pn_iou(const float* p, const float* q) {
+  F2 ps1[10], ps2[10];
+  for (int i = 0; i < 4; i++) {
+    ps1[i] = F2{p[2 * i], p[2 * i + 1]};
+    ps2[i] = F2{q[2 * i], q[2 * i + 1]};
+  }
+  if (pn_area(ps1, 4) < 0) std::reverse(ps1, ps1 + 4);
+  if (pn_area(ps2, 4) < 0) std::reverse(ps2, ps2 + 4);
+  ps1[4] = ps1[0];
+  ps2[4] = ps2[0];
+  float inter = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) inter += pn_tri(ps1[i], ps1[i + 1], ps2[j], ps2[j + 1]);
+  float uni = std::fabs(pn_area(ps1, 4)) + std::fabs(pn_area(ps2, 4)) - inter;
+  return uni == 0 ? (inter + 1) / (uni + 1) : inter / uni;
+}
+
 inline float pair_iou(int geom, const float* a, const float* b, bool iof, bool with_label) {
   if (geom == 1) return v1_pair(a, b, iof);
   return hull_pair(a, b, geom == 2, !iof, with_label);
@@ -587,6 +719,105 @@ int orc_nms(int geom, const float* boxes, int stride, const float* scores, int n
   }
   if (ascending) std::sort(keep_out, keep_out + cnt);
   return cnt;
+}
+
+// polygon_iou (polygon_geo_cpu.cpp:231-287): (na, 8) x (nb, 8) -> (na, nb)
+void orc_polygon_iou(const float* a, int na, const float* b, int nb, float* out) {
+  for (int i = 0; i < na; i++)
+    for (int j = 0; j < nb; j++) out[(size_t)i * nb + j] = poly_pair(a + (size_t)i * 8, b + (size_t)j * 8);
+}
+
+// devPolyIoU as a matrix (test aid) and poly_nms_cuda (poly_nms_cuda.cu:142-261): dets (n, 9) =
+// 8 coordinates + score; stable descending score sort; suppress on IoU > thr; keep in score order.
+void orc_poly_iou_mat(const float* a, int na, int sa, const float* b, int nb, int sb, float* out) {
+  for (int i = 0; i < na; i++)
+    for (int j = 0; j < nb; j++) out[(size_t)i * nb + j] = pn_iou(a + (size_t)i * sa, b + (size_t)j * sb);
+}
+
+int orc_poly_nms(const float* dets9, int n, float thr, int64_t* keep_out) {
+  if (n == 0) return 0;
+  std::vector<int64_t> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return dets9[a * 9 + 8] > dets9[b * 9 + 8]; });
+  std::vector<uint8_t> sup(n, 0);
+  int cnt = 0;
+  for (int _i = 0; _i < n; _i++) {
+    int64_t i = order[_i];
+    if (sup[i]) continue;
+    keep_out[cnt++] = i;
+    for (int _j = _i + 1; _j < n; _j++) {
+      int64_t j = order[_j];
+      if (!sup[j] && pn_iou(dets9 + i * 9, dets9 + j * 9) > thr) sup[j] = 1;
+    }
+  }
+  return cnt;
+}
+
+// convex_sort (convex/src/convex_cpu.cpp:8-90): pts (B, P, 2), masks (B, P) as 0/1 floats ->
+// (B, P + circular) int64 padded with -1.  The tensor prologue (:19-31) in fp32: start = first
+// argmin of the masked y; key = (x - sx) / sqrt((x - sx)^2 + (y - sy)^2 + 1e-6); stable
+// descending order of the keys; then the scan (:42-86).
+void orc_convex_sort(const float* pts, const float* masks, int B, int P, int circular, int64_t* out) {
+  const int isz = circular ? P + 1 : P;
+  const float INF_ = 10000000.f, EPS_ = 0.000001f;
+  std::vector<float> key(P);
+  std::vector<int64_t> order(P);
+  for (int b = 0; b < B; b++) {
+    const float* p = pts + (size_t)b * P * 2;
+    const float* m = masks + (size_t)b * P;
+    int64_t* ci = out + (size_t)b * isz;
+    for (int k = 0; k < isz; k++) ci[k] = -1;
+    if (P == 0) continue;
+    int64_t start = 0;
+    float best = 0;
+    for (int k = 0; k < P; k++) {
+      float my = m[k] * p[2 * k + 1] + (1 - m[k]) * INF_;
+      if (k == 0 || my < best) {
+        best = my;
+        start = k;
+      }
+    }
+    const float sx = p[2 * start], sy = p[2 * start + 1];
+    for (int k = 0; k < P; k++) {
+      float dx = p[2 * k] - sx, dy = p[2 * k + 1] - sy;
+      key[k] = dx / std::sqrt(dx * dx + dy * dy + EPS_);
+    }
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return key[a] > key[c]; });
+    ci[0] = start;
+    int64_t c_i = 0;
+    for (int _j = 0; _j < P; _j++) {
+      const int64_t j = order[_j];
+      if (j == start) continue;
+      if (m[j] < 0.5) continue;
+      const float x0 = p[2 * j], y0 = p[2 * j + 1];
+      float x1 = p[2 * ci[c_i]], y1 = p[2 * ci[c_i] + 1];
+      const float d = (x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0);
+      if (d < 0.000001) continue;  // (the source compares with the double literal)
+      if (c_i < 2) {
+        ci[++c_i] = j;
+      } else {
+        float x2 = p[2 * ci[c_i - 1]], y2 = p[2 * ci[c_i - 1] + 1];
+        while (true) {
+          const float t = (x1 - x2) * (y0 - y2) - (y1 - y2) * (x0 - x2);
+          if (t >= 0) {
+            ci[++c_i] = j;
+            break;
+          }
+          if (c_i <= 1) {
+            ci[c_i] = j;
+            break;
+          }
+          c_i--;
+          x1 = p[2 * ci[c_i]];
+          y1 = p[2 * ci[c_i] + 1];
+          x2 = p[2 * ci[c_i - 1]];
+          y2 = p[2 * ci[c_i - 1] + 1];
+        }
+      }
+    }
+    if (circular) ci[++c_i] = ci[0];
+  }
 }
 
 // feature_refine_forward_kernel (feature_refine_kernel.cu:112-163)

@@ -172,6 +172,27 @@ int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, co
                               num_anchors, num_classes, H, W, max_ratio, boxes_out, S(stream)));
 }
 
+int r3det_polygon_iou(const float* polys_a, int na, const float* polys_b, int nb, float* out, void* stream) {
+  return rc(r3k_polygon_iou(polys_a, na, polys_b, nb, out, S(stream)));
+}
+
+int r3det_poly_iou_mat(const float* a, int na, int stride_a, const float* b, int nb, int stride_b, float* out,
+                       void* stream) {
+  return rc(r3k_poly_iou_mat(a, na, stride_a, b, nb, stride_b, out, S(stream)));
+}
+
+size_t r3det_poly_nms_workspace_bytes(int n) { return r3k_poly_nms_workspace_bytes(n); }
+
+int r3det_nms_poly(const float* dets9, const int64_t* order, int n, float thr, void* ws, size_t ws_bytes,
+                   int64_t* keep_out, int32_t* count_out, void* stream) {
+  return rc(r3k_poly_nms(dets9, order, n, thr, ws, ws_bytes, keep_out, count_out, S(stream)));
+}
+
+int r3det_convex_sort(const float* pts, const unsigned char* masks, int B, int P, int circular, void* ws,
+                      size_t ws_bytes, int64_t* index_out, void* stream) {
+  return rc(r3k_convex_sort(pts, masks, B, P, circular, ws, ws_bytes, index_out, S(stream)));
+}
+
 int r3det_bias_act(float* y, const float* bias, const float* residual, long long outer, int C, long long inner,
                    int relu, void* stream) {
   return rc(r3k_bias_act(y, bias, residual, outer, C, inner, relu, S(stream)));

@@ -45,6 +45,17 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
                     float scale, int points, float* bottom_grad, int overwrite,
                     hipStream_t stream);
 
+// polygon ops outside the shipped configs (r3_poly.hip)
+int r3k_nms_reduce_dense(const unsigned long long* mask, int n, int cb, const int64_t* order, int64_t* keep_out,
+                         int32_t* count_out, hipStream_t stream);
+int r3k_polygon_iou(const float* a, int na, const float* b, int nb, float* out, hipStream_t stream);
+int r3k_poly_iou_mat(const float* a, int na, int sa, const float* b, int nb, int sb, float* out, hipStream_t stream);
+size_t r3k_poly_nms_workspace_bytes(int n);
+int r3k_poly_nms(const float* dets9, const int64_t* order, int n, float thr, void* ws, size_t ws_bytes,
+                 int64_t* keep_out, int32_t* count_out, hipStream_t stream);
+int r3k_convex_sort(const float* pts, const unsigned char* masks, int B, int P, int circular, void* ws,
+                    size_t ws_bytes, int64_t* out, hipStream_t stream);
+
 // FR box producers: best anchor per position + delta2bbox_v1, strided (NCHW or channels_last) inputs
 int r3k_filter_bboxes(const float* cls, const long long* cls_strides, const float* reg,
                       const long long* reg_strides, const float* anchors, int per_image, int N, int A, int C,

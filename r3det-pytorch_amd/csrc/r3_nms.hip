@@ -1125,6 +1125,15 @@ int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, c
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// greedy reduction of a dense upper-triangle mask (rows in score order); used by poly_nms
+int r3k_nms_reduce_dense(const unsigned long long* mask, int n, int cb, const int64_t* order, int64_t* keep_out,
+                         int32_t* count_out, hipStream_t stream) {
+  const size_t lds = (size_t)(cb + 1) * sizeof(u64);
+  if (lds > 64 * 1024) return -1;
+  hipLaunchKernelGGL(nms_reduce_dense_kernel, dim3(1), dim3(1024), lds, stream, mask, n, cb, order, keep_out, count_out);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 size_t r3k_nms_workspace_bytes(int n) {
   if (n <= 0) return 256;
   return layout(n, nullptr, nullptr);

@@ -28,6 +28,10 @@ SIGNATURES = {
     "r3det_mmcv_nms_rotated": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
     "r3det_mcnms_select": [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "r3det_mcnms_v1": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp],
+    "r3det_polygon_iou": [_vp, _i, _vp, _i, _vp, _vp],
+    "r3det_poly_iou_mat": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
+    "r3det_nms_poly": [_vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
+    "r3det_convex_sort": [_vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp],
     "r3det_bias_act": [_vp, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_longlong, _i, _vp],
     "r3det_filter_bboxes": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "r3det_feature_refine_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp],
@@ -54,6 +58,8 @@ def lib():
             fn.restype = _i
         L.r3det_nms_workspace_bytes.argtypes = [_i]
         L.r3det_nms_workspace_bytes.restype = _sz
+        L.r3det_poly_nms_workspace_bytes.argtypes = [_i]
+        L.r3det_poly_nms_workspace_bytes.restype = _sz
         L.r3det_rbbox_assign_workspace_bytes.argtypes = [_i, _i]
         L.r3det_rbbox_assign_workspace_bytes.restype = _sz
         L.r3det_mcnms_workspace_bytes.argtypes = [_i, _i]

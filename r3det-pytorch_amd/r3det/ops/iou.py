@@ -124,17 +124,88 @@ def obb_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, device_id=None)
 
 
 def aligned_obb_overlaps(bboxes1, bboxes2, mode='iou'):
-    """Pairwise (aligned) overlaps, shape (m, 1) like the reference (:67-92).
+    """Pairwise (aligned) overlaps (m, 1), DIFFERENTIABLE w.r.t. the boxes like the reference's
+    (box_iou_rotated_wrapper.py:67-92): corners -> edge-edge intersection points + contained
+    vertices (24 candidates per pair) -> convex_sort -> shoelace; everything but the index sort
+    is torch autograd math.  ``aligned_obb_overlaps_kernel`` is the forward-only value from
+    the v3 clipping kernel."""
+    area1 = bboxes1[:, 2] * bboxes1[:, 3]
+    area2 = bboxes2[:, 2] * bboxes2[:, 3]
+    n = bboxes1.size(0)
+    p1 = obb2poly(bboxes1).view(n, -1, 2)
+    p2 = obb2poly(bboxes2).view(n, -1, 2)
+    pts, masks = poly_intersection(p1, p2, area1, area2)
+    inter = convex_areas(pts, masks)
+    out = inter / (area1 + area2 - inter) if mode == 'iou' else inter / area1
+    return out[..., None]
 
-    The reference builds this case from differentiable torch ops + convex_sort; here the pair
-    list runs through the same v3 kernel arithmetic as the matrix case (forward value only).
-    """
+
+def obb2poly(obboxes):
+    """(…, 5) [cx, cy, w, h, theta] -> (…, 8) corners, the reference's sign convention (:95-113):
+    half axes (w/2 cos, -w/2 sin) and (-h/2 sin, -h/2 cos)."""
+    ctr, w, h, theta = torch.split(obboxes, [2, 1, 1, 1], dim=-1)
+    c, s = torch.cos(theta), torch.sin(theta)
+    u = torch.cat([w / 2 * c, -w / 2 * s], dim=-1)
+    v = torch.cat([-h / 2 * s, -h / 2 * c], dim=-1)
+    return torch.cat([ctr + u + v, ctr + u - v, ctr - u - v, ctr - u + v], dim=-1)
+
+
+def shoelace(pts):
+    """Areas of the polygons (…, P, 2) (:116-127)."""
+    prev = torch.roll(pts, 1, dims=-2)
+    return 0.5 * (pts[..., 0] * prev[..., 1] - prev[..., 0] * pts[..., 1]).sum(dim=-1).abs()
+
+
+def convex_areas(pts, masks):
+    """Area of the convex polygon spanned by the valid points of each row (:130-152): order them with
+    convex_sort (closed ring, -1 padding redirected to an appended origin point), shoelace."""
+    from .misc import convex_sort
+    B, P, _ = pts.shape
+    index = convex_sort(pts, masks)
+    index = torch.where(index < 0, torch.full_like(index, P), index)
+    ring = torch.gather(torch.cat([pts, pts.new_zeros((B, 1, 2))], dim=1), 1, index[..., None].expand(-1, -1, 2))
+    cross = ring[:, :-1, 0] * ring[:, 1:, 1] - ring[:, :-1, 1] * ring[:, 1:, 0]
+    return 0.5 * cross.sum(dim=-1).abs()
+
+
+def poly_intersection(pts1, pts2, areas1=None, areas2=None, eps=1e-6):
+    """Candidate points of the intersection of two aligned batches of quadrilaterals (B, 4, 2)
+    (:155-216): the 16 line-line intersections (valid when both parameters lie in (0, 1)), the
+    vertices of each polygon that lie inside the other one (triangle-area test, 1e-3 relative).
+    Returns points (B, 24, 2) and the validity mask (B, 24); the masks carry no gradient."""
+    e1 = torch.cat([pts1, torch.roll(pts1, -1, dims=1)], dim=2).unsqueeze(2)   # (B, 4, 1, 4)
+    e2 = torch.cat([pts2, torch.roll(pts2, -1, dims=1)], dim=2).unsqueeze(1)   # (B, 1, 4, 4)
+    x1, y1, x2, y2 = e1.unbind(dim=-1)
+    x3, y3, x4, y4 = e2.unbind(dim=-1)
+    num = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4)
+    den_t = (x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4)
+    with torch.no_grad():
+        den_u = (x2 - x1) * (y1 - y3) - (y2 - y1) * (x1 - x3)
+        t, u = den_t / num, den_u / num
+        hit = (t > 0) & (t < 1) & (u > 0) & (u < 1)
+    t = den_t / (num + eps)
+    cross_pts = torch.stack([x1 + t * (x2 - x1), y1 + t * (y2 - y1)], dim=-1)
+    B = pts1.size(0)
+    with torch.no_grad():
+        a1 = shoelace(pts1) if areas1 is None else areas1
+        a2 = shoelace(pts2) if areas2 is None else areas2
+        tri1 = 0.5 * ((x3 - x1) * (y4 - y1) - (y3 - y1) * (x4 - x1)).abs()    # vertex of 1 with the edges of 2
+        in1 = (tri1.sum(dim=-1) - a2[..., None]).abs() < 1e-3 * a2[..., None]
+        tri2 = 0.5 * ((x1 - x3) * (y2 - y3) - (x2 - x3) * (y1 - y3)).abs()    # vertex of 2 with the edges of 1
+        in2 = (tri2.sum(dim=-2) - a1[..., None]).abs() < 1e-3 * a1[..., None]
+    pts = torch.cat([cross_pts.view(B, -1, 2), pts1, pts2], dim=1)
+    masks = torch.cat([hit.view(B, -1), in1, in2], dim=1)
+    return pts, masks
+
+
+def aligned_obb_overlaps_kernel(bboxes1, bboxes2, mode='iou'):
+    """Forward-only pairwise overlaps (m, 1) through the v3 clipping kernel (exact polygon clipping;
+    differs from the differentiable form above by its 1e-3 containment tolerance)."""
     C = _C
     b1 = _as_boxes(bboxes1.contiguous(), "bboxes1")
     b2 = _as_boxes(bboxes2.contiguous(), "bboxes2")
     n = b1.size(0)
     out = b1.new_empty((n,))
-    # aligned v3 == diagonal of the matrix; computed as a vec launch of the v3 geometry
     with torch.cuda.device(b1.device):
         C.check(C.lib().r3det_box_iou_rotated_overlaps_aligned(
             C.ptr(b1), C.ptr(b2), n, int(mode == 'iou'), C.ptr(out), C.stream()), "overlaps_aligned")

@@ -188,7 +188,45 @@ def obb_batched_nms(bboxes, scores, inds, nms_thr, class_agnostic=False):
     return torch.cat([bboxes[keep], dets[:, -1:]], -1), keep
 
 
+def nms_rotated_ext_nms_poly(dets9, thr):
+    """nms_rotated_ext.nms_poly(dets (n,9), thr) -> keep in score order (nms_rotated_ext.cpp:38-51;
+    empty input -> CPU int64(0) like the reference)."""
+    dets9 = _C.need_hip(dets9.contiguous(), "dets")
+    n = dets9.size(0)
+    if n == 0:
+        return torch.empty(0, dtype=torch.long, device='cpu')
+    if dets9.dim() != 2 or dets9.size(1) != 9:
+        raise RuntimeError(f"dets must have shape (n, 9), got {tuple(dets9.shape)}")
+    order = _order(dets9[:, 8])
+    L = _C.lib()
+    with torch.cuda.device(dets9.device):
+        ws_bytes = int(L.r3det_poly_nms_workspace_bytes(n))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dets9.device)
+        keep = torch.empty(n, dtype=torch.int64, device=dets9.device)
+        count = torch.empty(1, dtype=torch.int32, device=dets9.device)
+        _C.check(L.r3det_nms_poly(_C.ptr(dets9), _C.ptr(order), n, float(thr), _C.ptr(ws), ws_bytes, _C.ptr(keep),
+                                  _C.ptr(count), _C.stream()), "r3det_nms_poly")
+        k = int(count.item())
+    return keep[:k]
+
+
 def poly_nms(dets, iou_thr, device_id=None):
-    """8-point polygon NMS (nms_rotated_wrapper.py:56-75; poly_nms_cuda.cu).  Only the DOTA v2
-    result merge uses it (datasets/dota1.py:654); SURVEY section 8f lists it as a later row."""
-    raise NotImplementedError("poly_nms is scheduled after the hot-path rows (SURVEY.md 8f rank 4)")
+    """NMS of 8-coordinate polygons, dets (n, 9) = 8 coordinates + score -> (dets[keep], keep) in
+    score order (nms_rotated_wrapper.py:56-75; poly_nms_cuda.cu).  Used by the DOTA result merge
+    (datasets/dota1.py:654).  Like the reference, CPU tensors are refused (NotImplementedError);
+    numpy input is staged on ``cuda:device_id``."""
+    if isinstance(dets, torch.Tensor):
+        is_numpy, d = False, dets
+    elif isinstance(dets, np.ndarray):
+        is_numpy = True
+        if device_id is None:
+            raise NotImplementedError  # the reference maps device_id=None to 'cpu', which it refuses
+        d = torch.from_numpy(dets).to(torch.device('cuda', device_id))
+    else:
+        raise TypeError(f'dets must be eithr a Tensor or numpy array, but got {type(dets)}')
+    if d.device.type == 'cpu':
+        raise NotImplementedError
+    inds = nms_rotated_ext_nms_poly(d.float(), iou_thr).to(d.device)
+    if is_numpy:
+        inds = inds.cpu().numpy()
+    return dets[inds, :], inds
