@@ -21,6 +21,12 @@
 //   FR fwd/bwd      : the reference has only a CUDA implementation and no
 //                     tests => "parity unpinned" by any reference fixture; the
 //                     restatement follows fr/src/feature_refine_kernel.cu.
+//   polygon_iou     : pinned against polygon_geo/src/polygon_geo_cpu.cpp (CPU)
+//   convex_sort     : pinned against convex/src/convex_cpu.cpp (CPU) on inputs
+//                     whose sort keys are distinct; for equal keys the reference
+//                     inherits torch.argsort's unstable order, here: index order
+//   poly_nms        : CUDA-only in the reference (poly_nms_cpu.cpp is a stub)
+//                     => "parity unpinned"; follows nms_rotated/src/poly_nms_cuda.cu.
 //
 // Two switches make the oracle usable both as a reference-faithful CPU model
 // and as the bit-exact twin of the HIP kernels:
