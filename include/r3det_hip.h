@@ -183,6 +183,18 @@ int r3det_feature_refine_forward(const float* features, const float* best_bboxes
  * channel plane; results are bit-identical.  ws == NULL selects the workspace-free kernels. */
 size_t r3det_fr_workspace_bytes(int N, int H, int W, int points);
 
+/* Split form of the forward (points = 1; levels of 128 x 128 or 64 x 64, for which
+ * r3det_fr_table_bytes returns non-zero): r3det_feature_refine_prepare turns the boxes of a level
+ * into the sampler's tap table (8 bytes per position) -- e.g. for every pyramid level before the
+ * module's convolutions run -- and r3det_feature_refine_forward_prepared is then a single launch.
+ * Same results as r3det_feature_refine_forward.  R3DET_EINVAL for shapes / channel counts the
+ * sampler kernel does not take (use the one-call form). */
+size_t r3det_fr_table_bytes(int N, int H, int W);
+int r3det_feature_refine_prepare(const float* best_bboxes, int N, int H, int W, float spatial_scale, float* table,
+                                 void* stream);
+int r3det_feature_refine_forward_prepared(const float* features, const float* table, int N, int C, int H, int W,
+                                          float* output, void* stream);
+
 /* feature_refine_cuda.backward(top_grad, best_bboxes, spatial_scale, points, bottom_grad)
  *                                                      fr/src/feature_refine_cuda.cpp:44-66
  * kernel feature_refine_kernel.cu:165-230.  Accumulates into bottom_grad (the reference caller
@@ -251,9 +263,11 @@ int r3det_set_option(const char* name, int value);
 
 /* Measurement aid for bench.py (not part of the reference surface).  With option "fr_profile" = 1
  * the launches of the cell path of r3det_feature_refine_forward carry their own start / stop
- * events (up to 512 calls).  This call waits for them, writes one record of 4 floats per call
- * {N, H, table_kernel_us, cell_kernel_us} (at most `capacity` records), empties the ring and
- * returns the number of records written. */
+ * events (up to 512 calls).  This call waits for them, writes one record of 5 floats per call
+ * {N, H, table_kernel_us, cell_kernel_us, span_us = table start -> cell stop} (at most `capacity`
+ * records), empties the ring and returns the number of records written.  A start/stop event pair
+ * reads ~4 us longer than rocprofv3's duration of the same kernel, so span_us (one pair for both
+ * kernels, their gap included) is the figure that agrees with the profiler's sum. */
 int r3det_fr_profile_read(float* records, int capacity);
 
 #ifdef __cplusplus

@@ -155,6 +155,18 @@ int r3det_feature_refine_forward(const float* features, const float* best_bboxes
                            ws_bytes, S(stream)));
 }
 
+size_t r3det_fr_table_bytes(int N, int H, int W) { return r3k_fr_table_bytes(N, H, W); }
+
+int r3det_feature_refine_prepare(const float* best_bboxes, int N, int H, int W, float spatial_scale, float* table,
+                                 void* stream) {
+  return rc(r3k_fr_prepare(best_bboxes, N, H, W, spatial_scale, table, S(stream)));
+}
+
+int r3det_feature_refine_forward_prepared(const float* features, const float* table, int N, int C, int H, int W,
+                                          float* output, void* stream) {
+  return rc(r3k_fr_forward_prepared(features, table, N, C, H, W, output, S(stream)));
+}
+
 int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxes, int N, int C,
                                   int H, int W, float spatial_scale, int points,
                                   float* bottom_grad, int overwrite, void* stream) {

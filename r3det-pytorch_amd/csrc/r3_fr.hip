@@ -428,15 +428,12 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_backward_plane(const float* __re
 //   * weights in packed fp32: {w1, w2} = hy * {hx, lx}, {w3, w4} = ly * {hx, lx}; products and
 //     the left-to-right sum keep the reference's operation order (bit-identical results).
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fr_cell_table_kernel(const float* __restrict__ boxes, int N, int H, int W,
-                                                            float scale, float* __restrict__ table) {
-  const int HW = H * W;
-  const int pos = blockIdx.x * 256 + threadIdx.x;
-  if (pos >= N * HW) return;
-  float y = boxes[(size_t)pos * 5] * scale;      // sic: row <- x_ctr
-  float x = boxes[(size_t)pos * 5 + 1] * scale;  //      col <- y_ctr
+// sample coordinates (row y <- x_ctr * scale, column x <- y_ctr * scale) -> the tap the cell kernel
+// keeps: the clamps of bilinear_interpolate (feature_refine_kernel.cu:22-47) applied once; an
+// out-of-range sample points at the zero cell (row H + 1)
+__device__ __forceinline__ void cell_tap(float y, float x, int H, int W, float& ty, float& tx) {
   if (y < -1.0 || y > H || x < -1.0 || x > W) {
-    y = (float)(H + 1);  // the zero cell
+    y = (float)(H + 1);
     x = 0.f;
   } else {
     if (y <= 0) y = 0;
@@ -444,6 +441,17 @@ __global__ __launch_bounds__(256) void fr_cell_table_kernel(const float* __restr
     if ((int)y >= H - 1) y = (float)(H - 1);
     if ((int)x >= W - 1) x = (float)(W - 1);
   }
+  ty = y;
+  tx = x;
+}
+
+__global__ __launch_bounds__(256) void fr_cell_table_kernel(const float* __restrict__ boxes, int N, int H, int W,
+                                                            float scale, float* __restrict__ table) {
+  const int HW = H * W;
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= N * HW) return;
+  float y, x;
+  cell_tap(boxes[(size_t)pos * 5] * scale, boxes[(size_t)pos * 5 + 1] * scale, H, W, y, x);  // sic: row <- x_ctr
   const int n = pos / HW, p = pos - n * HW;
   table[(size_t)n * 2 * HW + p] = y;  // per image: [y: HW floats][x: HW floats]
   table[(size_t)n * 2 * HW + HW + p] = x;
@@ -451,10 +459,13 @@ __global__ __launch_bounds__(256) void fr_cell_table_kernel(const float* __restr
 
 typedef float fr_f2 __attribute__((ext_vector_type(2)));
 
-template <int LOGW, int LOGH, int THREADS>
+// FROM_BOXES: `table` is the (N*H*W, 5) box array itself and the taps are derived in the prologue
+// (no table kernel, no dependent launch: worth ~6 us per call at N = 4, where the table kernel
+// plus the gap to this one cost as much as a quarter of this kernel).
+template <int LOGW, int LOGH, int THREADS, bool FROM_BOXES>
 __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restrict__ feat,
                                                            const float* __restrict__ table, int C, int G,
-                                                           float* __restrict__ out) {
+                                                           float scale, float* __restrict__ out) {
   constexpr int FRC_BLOCK = THREADS;
   static_assert(THREADS >= 2 * ((1 << LOGW) + 1) && THREADS >= (1 << LOGW) + (1 << LOGH) + 1, "helper threads");
   constexpr int W = 1 << LOGW, H = 1 << LOGH, HW = W * H, K = HW / FRC_BLOCK, PITCH = W + 1;
@@ -472,8 +483,18 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
   float ty[K], tx[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    ty[k] = ty_g[tid + k * FRC_BLOCK];
-    tx[k] = ty_g[HW + tid + k * FRC_BLOCK];
+    if (FROM_BOXES) {
+      const float* bp = table + ((size_t)n * HW + tid + k * FRC_BLOCK) * 5;
+      ty[k] = bp[0];
+      tx[k] = bp[1];
+    } else {
+      ty[k] = ty_g[tid + k * FRC_BLOCK];
+      tx[k] = ty_g[HW + tid + k * FRC_BLOCK];
+    }
+  }
+  if (FROM_BOXES) {
+#pragma unroll
+    for (int k = 0; k < K; k++) cell_tap(ty[k] * scale, tx[k] * scale, H, W, ty[k], tx[k]);
   }
   const int self0 = tid + (tid >> LOGW);
   // the H + W + 1 duplicate words are staged by the first threads (one extra element each)
@@ -568,9 +589,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // Kernel-exact timing of the cell path for bench.py's roofline line: a ring of event quadruples
 // (table start / stop, cell start / stop) attached to the launches themselves.
+// fr_profile = 1: all four events; 2: only table start and cell stop (no event packets between the
+// two kernels: the span then carries one event pair's overhead and the kernels' natural gap).
 struct FrProfileSlot {
   hipEvent_t ev[4];
-  int N, H;
+  int N, H, mode;
   bool used;
 };
 constexpr int FR_PROFILE_SLOTS = 512;
@@ -587,6 +610,7 @@ inline FrProfileSlot* fr_profile_next(int N, int H) {
   }
   s->N = N;
   s->H = H;
+  s->mode = g_r3_fr_profile;
   g_fr_prof_count++;
   return s;
 }
@@ -636,29 +660,39 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
   while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
   const bool cell_shape = (W == 128 && H == 128) || (W == 64 && H == 64);
   // cell is the default for 128 x 128 planes (level 0 of a 1024^2 input): 25.8 us at N = 4 against
-  // chan 34, plane 44 and a device copy of the same bytes at 20.8 (tools/probes/persist_copy_probe);
-  // 64 x 64 planes: two launches (table + cell) cost more than they save until the level holds
-  // >= 2048 planes (N = 4: plane 13.7 us vs cell 16.3; N = 16: 35.9 vs 25.4)
-  const bool cell_auto = g_r3_fr_impl == 0 && (W == 128 || (size_t)N * C >= 2048);
-  if ((g_r3_fr_impl == 10 || cell_auto) && points == 1 && ws && cell_shape && G >= 2 &&
-      ws_bytes >= r3k_fr_workspace_bytes(N, H, W, points) && aligned16(feat) && aligned16(out) && aligned16(ws)) {
+  // plane 44 and a device copy of the same bytes at 20.8 (tools/probes/persist_copy_probe), and for
+  // 64 x 64 planes (with the taps derived in its prologue: one launch, 12.7 us vs plane 13.7)
+  const bool cell_auto = g_r3_fr_impl == 0;
+  // taps from a table built by a first kernel (needs the workspace) or derived from the boxes in the
+  // cell kernel's own prologue (fr_dbg 1 / 2 force one form)
+  const bool have_ws = ws && ws_bytes >= r3k_fr_workspace_bytes(N, H, W, points) && aligned16(ws);
+  // measured at N = 4 (tools/fr_dbg_sweep.py): 128 x 128 table 26.4 us vs boxes 27.2 (the 20-byte-strided box
+  // reads make the prologue 2.5 x heavier than the 8-byte table); 64 x 64 boxes 12.7 vs table 15.6, plane 13.7
+  const bool from_boxes = g_r3_fr_dbg == 2 || (g_r3_fr_dbg != 1 && W == 64) || !have_ws;
+  if ((g_r3_fr_impl == 10 || cell_auto) && points == 1 && cell_shape && G >= 2 && aligned16(feat) && aligned16(out)) {
     float* table = reinterpret_cast<float*>(ws);
     const int total = N * H * W;
-    static bool once = (allow_big_lds(fr_forward_cell<7, 7, 1024>, 160 * 1024), true);
+    static bool once = (allow_big_lds(fr_forward_cell<7, 7, 1024, false>, 160 * 1024),
+                        allow_big_lds(fr_forward_cell<7, 7, 1024, true>, 160 * 1024), true);
     (void)once;
     const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
-    // profiling mode (r3det_set_option("fr_profile", 1)): the two launches carry their own start /
+    // profiling mode (r3det_set_option("fr_profile", 1 | 2)): the launches carry their own start /
     // stop events, so the recorded durations are the kernels' and not the host's launch gaps
     FrProfileSlot* ps = g_r3_fr_profile ? fr_profile_next(N, H) : nullptr;
-    hipExtLaunchKernelGGL(fr_cell_table_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
-                          ps ? ps->ev[0] : nullptr, ps ? ps->ev[1] : nullptr, 0, boxes, N, H, W, scale, table);
+    const bool each = ps && ps->mode == 1 && !from_boxes;
+    hipEvent_t t0 = ps ? ps->ev[0] : nullptr, t1 = each ? ps->ev[1] : nullptr;
+    hipEvent_t c0 = (each || (ps && from_boxes)) ? ps->ev[from_boxes ? 0 : 2] : nullptr, c1 = ps ? ps->ev[3] : nullptr;
+    if (ps) ps->mode = from_boxes ? 3 : ps->mode;  // 3: one kernel (events 0 and 3)
+    const dim3 grid(N * C / G), block(1024);
+    if (!from_boxes)
+      hipExtLaunchKernelGGL(fr_cell_table_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t0, t1, 0, boxes, N,
+                            H, W, scale, table);
     // (64 x 64 with 512- or 256-thread workgroups, several per CU, measured 1-5 % slower than 1024)
-    if (W == 128)
-      hipExtLaunchKernelGGL((fr_forward_cell<7, 7, 1024>), dim3(N * C / G), dim3(1024), lds, stream,
-                            ps ? ps->ev[2] : nullptr, ps ? ps->ev[3] : nullptr, 0, feat, table, C, G, out);
-    else
-      hipExtLaunchKernelGGL((fr_forward_cell<6, 6, 1024>), dim3(N * C / G), dim3(1024), lds, stream,
-                            ps ? ps->ev[2] : nullptr, ps ? ps->ev[3] : nullptr, 0, feat, table, C, G, out);
+#define R3_CELL(LW, LH, FB, SRC) \
+  hipExtLaunchKernelGGL((fr_forward_cell<LW, LH, 1024, FB>), grid, block, lds, stream, c0, c1, 0, feat, SRC, C, G, scale, out)
+    if (W == 128) { if (from_boxes) R3_CELL(7, 7, true, boxes); else R3_CELL(7, 7, false, table); }
+    else { if (from_boxes) R3_CELL(6, 6, true, boxes); else R3_CELL(6, 6, false, table); }
+#undef R3_CELL
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (plane) {
@@ -703,6 +737,43 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// Split form of the cell path: the tap table of a level is built ahead of time (for instance for all
+// pyramid levels before the module's convolutions run), the sampler launch is then the cell kernel
+// alone -- no dependent launch in front of it.
+size_t r3k_fr_table_bytes(int N, int H, int W) {
+  const bool cell_shape = (W == 128 && H == 128) || (W == 64 && H == 64);
+  return (cell_shape && N > 0) ? (size_t)N * H * W * 2 * sizeof(float) : 0;
+}
+
+int r3k_fr_prepare(const float* boxes, int N, int H, int W, float scale, float* table, hipStream_t stream) {
+  if (!r3k_fr_table_bytes(N, H, W) || !boxes || !table || !aligned16(table)) return -1;
+  const int total = N * H * W;
+  hipLaunchKernelGGL(fr_cell_table_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, boxes, N, H, W, scale, table);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int r3k_fr_forward_prepared(const float* feat, const float* table, int N, int C, int H, int W, float* out,
+                            hipStream_t stream) {
+  if (!r3k_fr_table_bytes(N, H, W) || !feat || !table || !out || C <= 0) return -1;
+  int G = 1;
+  while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
+  if (G < 2 || !aligned16(feat) || !aligned16(out) || !aligned16(table)) return -1;
+  static bool once = (allow_big_lds(fr_forward_cell<7, 7, 1024, false>, 160 * 1024), true);
+  (void)once;
+  const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
+  FrProfileSlot* ps = g_r3_fr_profile ? fr_profile_next(N, H) : nullptr;
+  if (ps) ps->mode = 3;
+  hipEvent_t e0 = ps ? ps->ev[0] : nullptr, e1 = ps ? ps->ev[3] : nullptr;
+  const dim3 grid(N * C / G), block(1024);
+  if (W == 128)
+    hipExtLaunchKernelGGL((fr_forward_cell<7, 7, 1024, false>), grid, block, lds, stream, e0, e1, 0, feat, table, C, G,
+                          0.f, out);
+  else
+    hipExtLaunchKernelGGL((fr_forward_cell<6, 6, 1024, false>), grid, block, lds, stream, e0, e1, 0, feat, table, C, G,
+                          0.f, out);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W,
                     float scale, int points, float* bottom_grad, int overwrite,
                     hipStream_t stream) {
@@ -743,20 +814,26 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
 }
 
 // Drains the profiling ring: waits for the recorded launches, writes up to `capacity` records
-// {N, H, table_us, cell_us} (4 floats each) and returns their number.
+// {N, H, table_us, cell_us, span_us} (5 floats each) and returns their number.
 int r3k_fr_profile_read(float* records, int capacity) {
   int n = 0;
   for (int i = 0; i < g_fr_prof_count; i++) {
     FrProfileSlot& s = g_fr_prof[i];
     if (hipEventSynchronize(s.ev[3]) != hipSuccess) continue;
-    float t_ms = 0.f, c_ms = 0.f;
-    if (hipEventElapsedTime(&t_ms, s.ev[0], s.ev[1]) != hipSuccess) continue;
-    if (hipEventElapsedTime(&c_ms, s.ev[2], s.ev[3]) != hipSuccess) continue;
+    float t_ms = 0.f, c_ms = 0.f, all_ms = 0.f;
+    if (s.mode == 1) {
+      if (hipEventElapsedTime(&t_ms, s.ev[0], s.ev[1]) != hipSuccess) continue;
+      if (hipEventElapsedTime(&c_ms, s.ev[2], s.ev[3]) != hipSuccess) continue;
+    } else if (s.mode == 3) {  // single kernel: its own duration is the span
+      if (hipEventElapsedTime(&c_ms, s.ev[0], s.ev[3]) != hipSuccess) continue;
+    }
+    if (hipEventElapsedTime(&all_ms, s.ev[0], s.ev[3]) != hipSuccess) continue;
     if (n < capacity && records) {
-      records[4 * n + 0] = (float)s.N;
-      records[4 * n + 1] = (float)s.H;
-      records[4 * n + 2] = t_ms * 1e3f;
-      records[4 * n + 3] = c_ms * 1e3f;
+      records[5 * n + 0] = (float)s.N;
+      records[5 * n + 1] = (float)s.H;
+      records[5 * n + 2] = t_ms * 1e3f;
+      records[5 * n + 3] = c_ms * 1e3f;
+      records[5 * n + 4] = all_ms * 1e3f;  // table start -> cell stop: ONE event pair's overhead, gap included
       n++;
     }
   }

@@ -65,6 +65,12 @@ int r3k_filter_bboxes(const float* cls, const long long* cls_strides, const floa
 int r3k_bias_act(float* y, const float* bias, const float* residual, long long outer, int C, long long inner, int relu,
                  hipStream_t stream);
 
+// split form of the FR forward cell path: tap table ahead of time, then the sampler kernel alone
+size_t r3k_fr_table_bytes(int N, int H, int W);
+int r3k_fr_prepare(const float* boxes, int N, int H, int W, float scale, float* table, hipStream_t stream);
+int r3k_fr_forward_prepared(const float* feat, const float* table, int N, int C, int H, int W, float* out,
+                            hipStream_t stream);
+
 // profiling ring of the FR cell path (see r3det_fr_profile_read)
 int r3k_fr_profile_read(float* records, int capacity);
 extern int g_r3_fr_profile;

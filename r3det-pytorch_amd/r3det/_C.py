@@ -35,6 +35,8 @@ SIGNATURES = {
     "r3det_bias_act": [_vp, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_longlong, _i, _vp],
     "r3det_filter_bboxes": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "r3det_feature_refine_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp],
+    "r3det_feature_refine_prepare": [_vp, _i, _i, _i, _f, _vp, _vp],
+    "r3det_feature_refine_forward_prepared": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "r3det_feature_refine_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "r3det_set_option": [ctypes.c_char_p, _i],
     "r3det_fr_profile_read": [_vp, _i],
@@ -66,6 +68,8 @@ def lib():
         L.r3det_mcnms_workspace_bytes.restype = _sz
         L.r3det_mcnms_select_workspace_bytes.argtypes = [_i, _i]
         L.r3det_mcnms_select_workspace_bytes.restype = _sz
+        L.r3det_fr_table_bytes.argtypes = [_i, _i, _i]
+        L.r3det_fr_table_bytes.restype = _sz
         L.r3det_fr_workspace_bytes.argtypes = [_i, _i, _i, _i]
         L.r3det_fr_workspace_bytes.restype = _sz
         L.r3det_iou_workspace_bytes.argtypes = [_i, _i]
@@ -111,10 +115,11 @@ def iou_workspace(n1, n2, device):
 
 
 def fr_profile_read(capacity=512):
-    """Drain the FR cell-path profiling ring: list of (N, H, table_kernel_us, cell_kernel_us)."""
-    buf = (ctypes.c_float * (4 * capacity))()
+    """Drain the FR cell-path profiling ring: list of (N, H, table_kernel_us, cell_kernel_us, span_us)."""
+    buf = (ctypes.c_float * (5 * capacity))()
     n = lib().r3det_fr_profile_read(ctypes.cast(buf, ctypes.c_void_p), capacity)
-    return [(int(buf[4 * i]), int(buf[4 * i + 1]), float(buf[4 * i + 2]), float(buf[4 * i + 3])) for i in range(n)]
+    return [(int(buf[5 * i]), int(buf[5 * i + 1]), float(buf[5 * i + 2]), float(buf[5 * i + 3]), float(buf[5 * i + 4]))
+            for i in range(n)]
 
 
 def set_option(name, value):

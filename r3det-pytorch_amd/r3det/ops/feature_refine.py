@@ -42,6 +42,35 @@ def fr_forward(features, best_rbboxes, spatial_scale, points, output):
     return 1
 
 
+def fr_prepare(best_rbboxes, N, H, W, spatial_scale, points=1):
+    """Tap table of one level for ``fr_forward_prepared`` (r3det_feature_refine_prepare), or None
+    when the level has no split form (then use ``fr_forward``)."""
+    if points != 1 or not best_rbboxes.is_cuda:
+        return None
+    L = _C.lib()
+    nbytes = int(L.r3det_fr_table_bytes(N, H, W))
+    if nbytes == 0:
+        return None
+    b = _C.need_hip(best_rbboxes.contiguous(), "best_bboxes")
+    with torch.cuda.device(b.device):
+        table = torch.empty(nbytes // 4, dtype=torch.float32, device=b.device)
+        _C.check(L.r3det_feature_refine_prepare(_C.ptr(b), N, H, W, float(spatial_scale), _C.ptr(table),
+                                                _C.stream()), "fr_prepare")
+    return table
+
+
+def fr_forward_prepared(features, table, output):
+    """The sampler launch alone (r3det_feature_refine_forward_prepared).  Returns False when the
+    library does not take this shape in the split form (nothing was launched)."""
+    f = _C.need_hip(features, "features")
+    o = _C.need_hip(output, "output")
+    N, C, H, W = f.shape
+    with torch.cuda.device(f.device):
+        rc = _C.lib().r3det_feature_refine_forward_prepared(_C.ptr(f), _C.ptr(table), N, C, H, W, _C.ptr(o),
+                                                            _C.stream())
+    return rc == 0
+
+
 def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, overwrite=False):
     """feature_refine_cuda.backward (feature_refine_cuda.cpp:44-66): accumulates into
     ``bottom_grad`` (``overwrite=True``: writes it, no zero-fill needed)."""
@@ -60,7 +89,7 @@ class FeatureRefineFunction(Function):
     """autograd wrapper (feature_refine_module.py:10-40); no gradient flows to the boxes."""
 
     @staticmethod
-    def forward(ctx, features, best_rbboxes, spatial_scale, points=1):
+    def forward(ctx, features, best_rbboxes, spatial_scale, points=1, table=None):
         ctx.spatial_scale = spatial_scale
         ctx.points = points
         ctx.save_for_backward(best_rbboxes)
@@ -68,7 +97,8 @@ class FeatureRefineFunction(Function):
         assert features.is_cuda
         features = features.contiguous()
         output = torch.empty_like(features)  # the kernel overwrites every element
-        fr_forward(features, best_rbboxes.contiguous(), spatial_scale, points, output)
+        if table is None or not fr_forward_prepared(features, table, output):
+            fr_forward(features, best_rbboxes.contiguous(), spatial_scale, points, output)
         return output
 
     @staticmethod
@@ -82,7 +112,7 @@ class FeatureRefineFunction(Function):
             grad_input = torch.empty_like(grad_output)
             fr_backward(grad_output, best_rbboxes.contiguous(), ctx.spatial_scale, ctx.points, grad_input,
                         overwrite=True)
-        return grad_input, None, None, None
+        return grad_input, None, None, None, None
 
 
 feature_refine = FeatureRefineFunction.apply
@@ -96,8 +126,9 @@ class FR(nn.Module):
         self.spatial_scale = float(spatial_scale)
         self.points = points
 
-    def forward(self, features, best_rbboxes):
-        return feature_refine(features, best_rbboxes, self.spatial_scale, self.points)
+    def forward(self, features, best_rbboxes, table=None):
+        """``table``: optional result of ``fr_prepare`` for these boxes (not in the reference's signature)."""
+        return feature_refine(features, best_rbboxes, self.spatial_scale, self.points, table)
 
     def __repr__(self):
         return f'{self.__class__.__name__}(spatial_scale={self.spatial_scale}, points={self.points})'
@@ -132,12 +163,16 @@ class FeatureRefineModule(nn.Module):
         """x: list of per-level (N,C,H,W); best_rbboxes: list over images of lists over levels
         of (H*W, 5)."""
         per_level = [torch.cat(lvl) for lvl in zip(*best_rbboxes)]
+        # tap tables of all levels first: each sampler call below is then a single launch with no
+        # dependent launch in front of it
+        tables = [fr_prepare(b, f.size(0), f.size(2), f.size(3), fr.spatial_scale, fr.points)
+                  for f, b, fr in zip(x, per_level, self.fr)]
         out = []
-        for feat, boxes, fr in zip(x, per_level, self.fr):
+        for feat, boxes, fr, table in zip(x, per_level, self.fr, tables):
             # The sampler reads NCHW planes: in a channels_last pipeline the module switches layout
             # once, at its input, so that its three convolutions already produce what FR consumes
             # (a no-op for NCHW callers, like the reference).
             feat = feat.contiguous()
             mixed = self.conv_5_1(self.conv_1_5(feat)) + self.conv_1_1(feat)
-            out.append(feat + fr(mixed, boxes))
+            out.append(feat + fr(mixed, boxes, table))
         return out

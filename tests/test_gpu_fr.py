@@ -89,6 +89,28 @@ def test_cell_kernel_long_channel_runs(shape):
         assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("shape", [(1, 512, 128, 128, 8), (2, 512, 64, 64, 16), (2, 8, 64, 64, 16), (1, 4, 32, 32, 32)])
+def test_split_form_prepare_then_sample(shape):
+    """r3det_feature_refine_prepare + _forward_prepared == the one-call form (and the autograd function
+    falls back to the one-call form where the split form does not apply)."""
+    from r3det.ops.feature_refine import feature_refine, fr_forward, fr_forward_prepared, fr_prepare
+    N, C, H, W, stride = shape
+    r = np.random.default_rng(21)
+    feat = dev(r.normal(size=(N, C, H, W)).astype(np.float32))
+    boxes = dev(fr_boxes(N, H, W, stride, 3, adversarial=True))
+    want = torch.empty_like(feat)
+    fr_forward(feat, boxes, 1 / stride, 1, want)
+    table = fr_prepare(boxes, N, H, W, 1 / stride)
+    assert (table is not None) == (H in (64, 128))
+    if table is not None:
+        out = torch.full_like(feat, float('nan'))
+        if fr_forward_prepared(feat, table, out):
+            assert C >= 256 and torch.equal(out, want)
+        else:
+            assert C < 256          # too few planes for the channel-group kernel
+    assert torch.equal(feature_refine(feat, boxes, 1 / stride, 1, table), want)
+
+
 def test_plane_too_large_falls_back_to_generic():
     """200 x 200 planes (160 KB padded) exceed the LDS budget: auto mode must still be right."""
     from r3det.ops.feature_refine import fr_forward
