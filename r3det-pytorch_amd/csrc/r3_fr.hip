@@ -578,6 +578,110 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
   phase(c + 1, std::false_type{}, std::false_type{});
 }
 
+// ----------------------------------------------------------------------------------------
+// "cell" BACKWARD kernel (points = 1, overwrite mode): the forward kernel's structure with the
+// gather turned into a scatter.  feature_refine_backward_kernel (feature_refine_kernel.cu:165-230)
+// does 5 global atomics per element; the plane kernel above accumulates a plane in LDS but
+// re-derives the taps per plane from the boxes (426 us at level 0).  Here, per plane c of the
+// workgroup's G channels, ONE barrier:
+//   readout  plane c-1 : bottom[p] = acc[(c-1)&1][p]                 (this thread's own cells)
+//   init     plane c+1 : acc[(c+1)&1][p] = top[c+1][p]  (identity term; same cells, same buffer)
+//   scatter  plane c   : 4 x ds_add_f32 of g * w into acc[c&1] at the position's cell
+// with the top-gradient planes streamed by the same rolling load pipeline and the plane's own g
+// values kept in registers (the accumulator cell already holds other positions' contributions).
+// The duplicate column / row and the zero cell of the layout only ever receive contributions
+// that the reference adds with weight 0 or skips (clamped neighbours, out-of-range samples); they
+// are never read back.  Summation order of the atomics is not deterministic (as in the reference).
+// ----------------------------------------------------------------------------------------
+template <int LOGW, int LOGH, int THREADS>
+__global__ __launch_bounds__(THREADS) void fr_backward_cell(const float* __restrict__ top,
+                                                            const float* __restrict__ boxes, int C, int G,
+                                                            float scale, float* __restrict__ bottom) {
+  constexpr int FRC_BLOCK = THREADS;
+  constexpr int W = 1 << LOGW, H = 1 << LOGH, HW = W * H, K = HW / FRC_BLOCK, PITCH = W + 1;
+  constexpr int BUF = ((H + 3) * PITCH + 3) & ~3;
+  constexpr int KSTEP = FRC_BLOCK + FRC_BLOCK / W;
+  constexpr int D = K > 1 ? K / 2 : 0;
+  static_assert(K >= 1 && W <= FRC_BLOCK, "shape");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int groups = C / G;
+  const int n = blockIdx.x / groups;
+  const int c0 = (blockIdx.x - n * groups) * G;
+  const size_t plane0 = (size_t)n * C + c0;
+  float ty[K], tx[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const float* bp = boxes + ((size_t)n * HW + tid + k * FRC_BLOCK) * 5;
+    ty[k] = bp[0];
+    tx[k] = bp[1];
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) cell_tap(ty[k] * scale, tx[k] * scale, H, W, ty[k], tx[k]);
+  const int self0 = tid + (tid >> LOGW);
+  for (int i = tid; i < 2 * BUF; i += FRC_BLOCK) lds[i] = 0.f;  // incl. the never-read helper cells
+  float v[K], g[K];
+  {
+    const float* src = top + (plane0 << (LOGW + LOGH));
+#pragma unroll
+    for (int k = 0; k < K; k++) g[k] = src[tid + k * FRC_BLOCK];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) lds[self0 + k * KSTEP] = g[k];
+    src += HW;
+#pragma unroll
+    for (int k = 0; k < D; k++) v[k] = src[tid + k * FRC_BLOCK];
+  }
+  __syncthreads();
+  auto phase = [&](int c, auto l1, auto l2, auto first) {
+    constexpr bool L1 = decltype(l1)::value, L2 = decltype(l2)::value, FIRST = decltype(first)::value;
+    float* acc = lds + (c & 1) * BUF;
+    float* other = lds + ((c + 1) & 1) * BUF;  // holds plane c - 1 (read out), then plane c + 1 (initialised)
+    const float* src1 = top + ((plane0 + c + 1) << (LOGW + LOGH));
+    float* dst = bottom + ((plane0 + c - 1) << (LOGW + LOGH));
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      if (k + D < K) {
+        if (L1) v[k + D] = src1[tid + (k + D) * FRC_BLOCK];
+      } else {
+        if (L2) v[k + D - K] = src1[HW + tid + (k + D - K) * FRC_BLOCK];
+      }
+      if (!FIRST) dst[tid + k * FRC_BLOCK] = other[self0 + k * KSTEP];
+      if (L1) other[self0 + k * KSTEP] = v[k];
+      float y = ty[k], x = tx[k];
+      asm volatile("" : "+v"(y), "+v"(x));  // (see fr_forward_cell)
+      const int yi = (int)y, xi = (int)x;
+      const float fy = __builtin_amdgcn_fractf(y), fx = __builtin_amdgcn_fractf(x);
+      const int a = (yi << LOGW) + yi + xi;
+      const float gk = g[k];
+      const fr_f2 hf = {1.f - fx, fx};
+      const fr_f2 wt = (1.f - fy) * hf, wb = fy * hf;  // {w1, w2}, {w3, w4}
+      atomicAdd(&acc[a], gk * wt.x);
+      atomicAdd(&acc[a + 1], gk * wt.y);
+      atomicAdd(&acc[a + PITCH], gk * wb.x);
+      atomicAdd(&acc[a + PITCH + 1], gk * wb.y);
+      if (L1) g[k] = v[k];
+    }
+    __syncthreads();
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  if (G > 2) phase(0, T{}, T{}, T{}); else phase(0, T{}, F{}, T{});
+  int c = 1;
+  for (; c + 2 < G; c++) phase(c, T{}, T{}, F{});
+  if (c + 1 < G) {
+    phase(c, T{}, F{}, F{});
+    c++;
+  }
+  phase(c, F{}, F{}, F{});
+  {  // plane G - 1
+    const float* acc = lds + ((G - 1) & 1) * BUF;
+    float* dst = bottom + ((plane0 + G - 1) << (LOGW + LOGH));
+#pragma unroll
+    for (int k = 0; k < K; k++) dst[tid + k * FRC_BLOCK] = acc[self0 + k * KSTEP];
+  }
+}
+
 // dynamic LDS above 64 KB has to be opted into once per kernel
 template <typename K>
 inline void allow_big_lds(K kernel, int bytes) {
@@ -781,6 +885,25 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
   if (N == 0 || C == 0 || H == 0 || W == 0) return 0;
   int cpb = plane_cpb(C, H, W);
   const bool plane = g_r3_fr_impl != 1 && cpb > 0;
+  {
+    // cell backward (overwrite mode, points = 1, 128 x 128 / 64 x 64): level 0 at N = 4 426 -> ~40 us
+    int G = 1;
+    while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
+    const bool cell_shape = (W == 128 && H == 128) || (W == 64 && H == 64);
+    if ((g_r3_fr_impl == 0 || g_r3_fr_impl == 10) && overwrite && points == 1 && cell_shape && G >= 2 &&
+        aligned16(top_grad) && aligned16(bottom_grad)) {
+      static bool once = (allow_big_lds(fr_backward_cell<7, 7, 1024>, 160 * 1024), true);
+      (void)once;
+      const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
+      if (W == 128)
+        hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024>), dim3(N * C / G), dim3(1024), lds, stream, top_grad, boxes,
+                           C, G, scale, bottom_grad);
+      else
+        hipLaunchKernelGGL((fr_backward_cell<6, 6, 1024>), dim3(N * C / G), dim3(1024), lds, stream, top_grad, boxes,
+                           C, G, scale, bottom_grad);
+      return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+  }
   if (plane) {
     while (cpb > 1 && (size_t)N * ((C + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
     dim3 grid((C + cpb - 1) / cpb, N);

@@ -89,6 +89,31 @@ def test_cell_kernel_long_channel_runs(shape):
         assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("shape", [(1, 512, 128, 128, 8), (1, 1024, 128, 128, 8), (2, 512, 64, 64, 16),
+                                   (3, 512, 64, 64, 16)])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_backward_cell_kernel(shape, adversarial):
+    """The channel-group backward kernel (overwrite mode; G = 2, 4 channels per workgroup) against the
+    oracle and against the plane kernel; tolerance as in test_backward (atomics sum in any order)."""
+    from r3det import _C
+    from r3det.ops.feature_refine import fr_backward
+    N, C, H, W, stride = shape
+    r = np.random.default_rng(17)
+    top = r.normal(size=(N, C, H, W)).astype(np.float32)
+    boxes = fr_boxes(N, H, W, stride, 8, adversarial=adversarial)
+    with O.twin():
+        want = O.fr_backward(top[:, :8], boxes, 1 / stride, 1)       # the oracle is serial: first 8 channels
+    tol = 1e-5 * max(1.0, np.abs(want).max())
+    g = torch.full((N, C, H, W), float('nan'), device='cuda')
+    fr_backward(dev(top), dev(boxes), 1 / stride, 1, g, overwrite=True)
+    assert np.abs(g[:, :8].cpu().numpy() - want).max() <= tol
+    _C.set_option("fr_impl", 2)
+    g2 = torch.empty_like(g)
+    fr_backward(dev(top), dev(boxes), 1 / stride, 1, g2, overwrite=True)
+    _C.set_option("fr_impl", 0)
+    assert (g - g2).abs().max().item() <= 1e-5 * max(1.0, g2.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(1, 512, 128, 128, 8), (2, 512, 64, 64, 16), (2, 8, 64, 64, 16), (1, 4, 32, 32, 32)])
 def test_split_form_prepare_then_sample(shape):
     """r3det_feature_refine_prepare + _forward_prepared == the one-call form (and the autograd function
