@@ -153,8 +153,13 @@ int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes,
  *   r3det_mcnms_v1 : cap >= max(counts), < 65536.  Per image: stable descending score sort,
  *       x, y += label * (maxc + 1), NMS v1 (IoU > iou_thr), keep ASCENDING by candidate
  *       index, first out_cap of them.  dets_out (B,out_cap,6) = [box, score], labels_out
- *       (B,out_cap) int64, counts_out (B) int32; rows beyond counts_out are not written.
+ *       (B,out_cap) int64, keep_idx_out (B,out_cap) int64 = the kept candidate indices (may be
+ *       NULL), counts_out (B) int32; rows beyond counts_out are not written.
  *       ws: r3det_mcnms_workspace_bytes(B, cap).
+ *       The candidate arrays need not come from r3det_mcnms_select: with cand_row = 0..n-1,
+ *       K = 1, caller-provided labels / scores and counts = n the call is batched_rnms
+ *       (ops/rnms/rnms_wrapper.py:34-69) of one image: dets_out = cat(bboxes[keep], scores[keep]),
+ *       keep_idx_out = keep.
  * ------------------------------------------------------------------------------------- */
 size_t r3det_mcnms_select_workspace_bytes(int B, int n);
 int r3det_mcnms_select(const float* boxes, const float* scores, int B, int n, int K, float score_thr,
@@ -164,7 +169,8 @@ size_t r3det_mcnms_workspace_bytes(int B, int cap);
 int r3det_mcnms_v1(const float* boxes, int B, int n, int K, const int32_t* cand_row,
                    const int32_t* cand_label, const float* cand_score, int32_t* cand_rank,
                    const int32_t* counts, const float* maxc, int cap, float iou_thr, int out_cap, void* ws,
-                   size_t ws_bytes, float* dets_out, int64_t* labels_out, int32_t* counts_out, void* stream);
+                   size_t ws_bytes, float* dets_out, int64_t* labels_out, int64_t* keep_idx_out,
+                   int32_t* counts_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Feature refinement (rotated feature-align sampler)

@@ -987,6 +987,7 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
                                                          uint8_t* __restrict__ flags, int out_cap,
                                                          float* __restrict__ dets_out,
                                                          int64_t* __restrict__ labels_out,
+                                                         int64_t* __restrict__ keep_idx_out,
                                                          int32_t* __restrict__ counts_out) {
   __shared__ int part[1024];
   const int tid = threadIdx.x;
@@ -1019,6 +1020,7 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
     d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
     d[5] = cand_score[cbase + i];
     labels_out[(size_t)img * out_cap + pos] = cand_label[cbase + i];
+    if (keep_idx_out) keep_idx_out[(size_t)img * out_cap + pos] = i;  // candidate index, ascending
     pos++;
   }
   if (tid == 0) counts_out[img] = min(cnt, out_cap);
@@ -1095,7 +1097,7 @@ size_t r3k_mcnms_workspace_bytes(int B, int cap) {
 int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
                  const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
                  float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
-                 int32_t* counts_out, hipStream_t stream) {
+                 int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream) {
   if (B <= 0 || n <= 0 || K <= 0 || cap <= 0 || out_cap <= 0 || cap >= 65536 || !(iou_thr >= 0.f)) return -1;
   if (!boxes || !cand_row || !cand_label || !cand_score || !cand_rank || !counts || !maxc || !ws || !dets_out ||
       !labels_out || !counts_out)
@@ -1121,7 +1123,8 @@ int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, c
                      L.gqueue, (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt);
   launch_reduce(B, L.mask, L.nz, L.nzw, 0, L.cb, nullptr, L.keep, L.kept, bt, stream);
   hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label, cand_score,
-                     S, L.svals, counts, L.keep, bt.keep, L.kept, L.flags, out_cap, dets_out, labels_out, counts_out);
+                     S, L.svals, counts, L.keep, bt.keep, L.kept, L.flags, out_cap, dets_out, labels_out, keep_idx_out,
+                     counts_out);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -121,6 +121,6 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
         kept = torch.empty(B, dtype=torch.int32, device=dev)
         _C.check(L.r3det_mcnms_v1(_C.ptr(boxes), B, n, K, _C.ptr(cand_row), _C.ptr(cand_label), _C.ptr(cand_score),
                                   _C.ptr(cand_rank), _C.ptr(counts), _C.ptr(maxc), cap, iou_thr, out_cap, _C.ptr(ws), ws_bytes,
-                                  _C.ptr(dets), _C.ptr(labels), _C.ptr(kept), _C.stream()), "r3det_mcnms_v1")
+                                  _C.ptr(dets), _C.ptr(labels), None, _C.ptr(kept), _C.stream()), "r3det_mcnms_v1")
         kept = kept.tolist()
     return [(dets[i, :kept[i]], labels[i, :kept[i]]) for i in range(B)]

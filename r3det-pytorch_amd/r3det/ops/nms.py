@@ -134,6 +134,9 @@ def batched_rnms(bboxes, scores, inds, nms_thr, class_agnostic=False):
     Offset = label * (max over ALL five box columns + 1), added to cx, cy.  Returns
     (cat(bboxes[keep], scores[keep]), keep) with keep ascending.
     """
+    fast = _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic)
+    if fast is not None:
+        return fast
     if class_agnostic:
         shifted = bboxes
     else:
@@ -142,6 +145,41 @@ def batched_rnms(bboxes, scores, inds, nms_thr, class_agnostic=False):
         shifted[:, :2] += offs[:, None]
     dets, keep = rnms(torch.cat([shifted, scores[:, None]], -1), nms_thr)
     return torch.cat([bboxes[keep], dets[:, -1:]], -1), keep
+
+
+def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic):
+    """The same result from ONE library call (r3det_mcnms_v1 with caller-made candidates: stable
+    score sort by counting, class offsets, suppression, ascending keep and the gather on the
+    device) instead of max / mul / clone / add / cat / sort / rnms / index launches.  None when the
+    input does not qualify (then the op-by-op form above runs)."""
+    if not (isinstance(bboxes, torch.Tensor) and bboxes.is_cuda and bboxes.dtype == torch.float32
+            and bboxes.dim() == 2 and bboxes.size(1) == 5 and scores.dtype == torch.float32):
+        return None
+    n = bboxes.size(0)
+    if n == 0 or n >= 16384 or not (nms_thr >= 0):  # (32 768 boxes: 1.53 ms here vs 1.45 ms op by op)
+        return None
+    dev = bboxes.device
+    L = _C.lib()
+    with torch.cuda.device(dev):
+        b = bboxes.contiguous()
+        row = torch.arange(n, dtype=torch.int32, device=dev)
+        lab = torch.zeros(n, dtype=torch.int32, device=dev) if class_agnostic else inds.to(torch.int32).contiguous()
+        sc = scores.contiguous()
+        rank = torch.zeros(n, dtype=torch.int32, device=dev)
+        cnt = torch.full((1,), n, dtype=torch.int32, device=dev)
+        mx = b.max().reshape(1)
+        cap = (n + 63) // 64 * 64
+        ws_bytes = int(L.r3det_mcnms_workspace_bytes(1, cap))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        dets = torch.empty((n, 6), dtype=torch.float32, device=dev)
+        labels = torch.empty(n, dtype=torch.int64, device=dev)
+        keep = torch.empty(n, dtype=torch.int64, device=dev)
+        kept = torch.empty(1, dtype=torch.int32, device=dev)
+        _C.check(L.r3det_mcnms_v1(_C.ptr(b), 1, n, 1, _C.ptr(row), _C.ptr(lab), _C.ptr(sc), _C.ptr(rank), _C.ptr(cnt),
+                                  _C.ptr(mx), cap, float(nms_thr), n, _C.ptr(ws), ws_bytes, _C.ptr(dets), _C.ptr(labels),
+                                  _C.ptr(keep), _C.ptr(kept), _C.stream()), "r3det_mcnms_v1")
+        k = int(kept.item())
+    return dets[:k], keep[:k]
 
 
 def obb2hbb(obboxes):
