@@ -264,7 +264,8 @@ int r3det_bias_act(float* y, const float* bias, const float* residual, long long
 
 /* Kernel-selection knobs for A/B measurements (not part of the reference surface).
  * r3det_set_option("fr_impl", 0 auto | 1 generic | 2 lds-plane | 10 cell), ("iou_impl", ...),
- * ("nms_impl", 0 | 1 tiles | 2 older reducer), ("nms_qcap", n), ("fr_profile", 0 | 1). */
+ * ("nms_impl", 0 | 1 tiles), ("nms_qcap", n), ("fr_profile", 0 | 1 every kernel | 2 first start and
+ * last stop only), ("fr_dbg", 0 | 1 taps from the table kernel | 2 taps derived in the sampler). */
 int r3det_set_option(const char* name, int value);
 
 /* Measurement aid for bench.py (not part of the reference surface).  With option "fr_profile" = 1

@@ -12,15 +12,18 @@
 //             test (labels, circles, axis-aligned bounds); surviving pairs go to an LDS
 //             queue and from there to one global queue;
 //   drain   : the global queue is clipped one pair per lane, chip-wide balanced; IoU > thr
-//             sets bit j of mask[i][j/64] (atomicOr) and flags the word in a per-row
-//             "non-zero word" bitmap nz[i];
-//   reduce  : ONE workgroup walks the rows in score order.  Wave 0 resolves a 64-row block on
-//             its diagonal word with scalar ops; the other lanes OR only the NON-ZERO words of
-//             the surviving rows (found through nz) into the running `removed` words in LDS;
-//             the next block's words are prefetched speculatively one block ahead.  Emits the
-//             keep list and its length.  The reference copies the whole n x n/64 mask to the
-//             host (9.2 MB at n = 8576) and scans it there.
+//             sets bit j of mask[i][j/64] (atomicOr), flags the word in a per-row "non-zero
+//             word" bitmap nz[i], records the in-block in-edge and appends the word index to
+//             the row's list (mark_pair);
+//   reduce  : ONE workgroup per problem walks the rows in score order.  Wave 0 resolves a
+//             64-row block by dependency rounds on the in-edge words; the other lanes OR the
+//             listed words of the surviving rows into the running `removed` words in LDS;
+//             lists, words and in-edges are requested 4-8 blocks ahead through register FIFOs
+//             (nms_reduce_pipe_kernel).  Emits the keep list and its length.  The reference
+//             copies the whole n x n/64 mask to the host (9.2 MB at n = 8576) and scans it there.
 //   ascending (v1 only): rnms returns keep sorted by index (rnms_kernel.cu:331-334).
+// The batched detection pipeline at the end of the file (r3det_mcnms_*) runs select / sort /
+// offsets / these kernels with blockIdx.z = image / finish for all images of a step.
 //
 // The original tile kernel (mask computed in place, dense reduction) is kept as impl 1: it
 // serves thr < 0, n >= 65536 and the A/B measurements.
@@ -363,150 +366,11 @@ __device__ __forceinline__ int kth_word(const u64* nzrow, int nzw, int b, int k)
 
 constexpr int RSLOTS = 16;  // speculative word slots per row: 64 rows x 16 = 1024 threads (4 slots measured 25-45 % slower: clusters of duplicates give ~10 non-zero words per row)
 constexpr int RTHREADS = TILE * RSLOTS;
-constexpr int NZRING = 4;   // nz rows are fetched 3 blocks ahead of their use
-
-// Greedy scan of one 64-row block.  Only rows whose diagonal word is non-zero can remove
-// anybody inside the block, and a row's word only has bits of LATER rows, so it suffices to
-// visit those rows in ascending order; every row's fate is final once all earlier rows were
-// visited: kept = ~removed.  All of it runs on the scalar unit (~10 SALU per visited row).
-__device__ __forceinline__ u64 scan_block_sparse(u64 diag, u64 cur, u64 valid) {
-  u64 m = __ballot(diag != 0ULL);
-  while (m) {
-    const int k = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    if (!((cur >> k) & 1ULL)) cur |= readlane64(diag, k);
-  }
-  return ~cur & valid;
-}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every
 // outstanding global load (s_waitcnt vmcnt(0)), which would serialise the prefetches below
 // behind a full memory round trip per 64-row block.
 #define R3_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-__global__ __launch_bounds__(RTHREADS) void nms_reduce_sparse_kernel(const u64* __restrict__ mask,
-                                                                 const u64* __restrict__ nz, int nzw,
-                                                                 int n, int cb,
-                                                                 const int64_t* __restrict__ order,
-                                                                 int64_t* __restrict__ keep_out,
-                                                                 int32_t* __restrict__ count_out, Batch bt) {
-  extern __shared__ __attribute__((aligned(16))) u64 smem[];
-  if (bt.counts) {  // cb / nzw stay the pitches (and size the LDS arrays); n bounds the walk
-    const int img = blockIdx.z;
-    n = bt.counts[img];
-    mask += img * bt.mask;
-    nz += img * bt.nz;
-    keep_out += img * bt.keep;
-    count_out += img;
-  }
-  const int cbn = (n + TILE - 1) / TILE;
-  u64* remv = smem;                 // cb words
-  u64* kb_slot = smem + cb;         // [0] kept bits of the current block, [1] final count
-  u64* nzbuf = smem + cb + 2;       // NZRING x 64 x nzw words
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int myrow = tid / RSLOTS, myk = tid % RSLOTS;
-  const int slot_words = TILE * nzw;  // <= 1024 because n < 65536 (nzw <= 16)
-  // elements of a 64 x nzw nz slot owned by this thread: tid, tid + 256, ... (<= 4)
-  constexpr int NZPT = 1024 / RTHREADS;
-
-  struct NzRegs { u64 v[NZPT]; };
-  auto load_nz = [&](int blk) -> NzRegs {
-    NzRegs r;
-#pragma unroll
-    for (int q = 0; q < NZPT; q++) {
-      const int t = tid + q * RTHREADS;
-      const int rr = t / nzw;
-      const int gr = blk * TILE + rr;
-      r.v[q] = (t < slot_words && blk < cb && gr < n) ? nz[(size_t)gr * nzw + (t - rr * nzw)] : 0ULL;
-    }
-    return r;
-  };
-  auto store_nz = [&](int slot, const NzRegs& r) {
-#pragma unroll
-    for (int q = 0; q < NZPT; q++) {
-      const int t = tid + q * RTHREADS;
-      if (t < slot_words) nzbuf[slot * slot_words + t] = r.v[q];
-    }
-  };
-  auto diag_of = [&](int blk) -> u64 {
-    const int r = blk * TILE + lane;
-    return (blk < cb && r < n) ? mask[(size_t)r * cb + blk] : 0ULL;
-  };
-  // speculative load of this thread's (row, k-th non-zero word beyond the diagonal) of a block
-  auto spec_word = [&](int blk, int& widx) -> u64 {
-    widx = -1;
-    if (blk >= cb) return 0ULL;
-    const int gr = blk * TILE + myrow;
-    if (gr >= n) return 0ULL;
-    widx = kth_word(nzbuf + (blk % NZRING) * slot_words + myrow * nzw, nzw, blk, myk);
-    return widx >= 0 ? mask[(size_t)gr * cb + widx] : 0ULL;
-  };
-
-  for (int j = tid; j < cb; j += blockDim.x) remv[j] = 0;
-  for (int blk = 0; blk < NZRING; blk++) store_nz(blk, load_nz(blk));
-  NzRegs nz_inflight = load_nz(NZRING);  // block 4: stored to the ring at iteration 1
-  u64 d0 = 0, d1 = 0, d2 = 0;
-  if (wave == 0) {
-    d0 = diag_of(0);
-    d1 = diag_of(1);
-    d2 = diag_of(2);
-  }
-  __syncthreads();
-  int wa_i, wb_i;
-  u64 wa = spec_word(0, wa_i);
-  u64 wb = spec_word(1, wb_i);
-
-  int cnt = 0;
-  for (int b = 0; b < cbn; b++) {
-    // ---- stage 1: wave 0 resolves block b
-    if (wave == 0) {
-      const int nvalid = min(TILE, n - b * TILE);
-      const u64 valid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1ULL);
-      const u64 cur = readlane64(remv[b], 0);
-      const u64 kb = scan_block_sparse(d0, cur, valid);
-      if ((kb >> lane) & 1ULL)
-        keep_out[cnt + __popcll(kb & ((1ULL << lane) - 1ULL))] = b * TILE + lane;  // sorted position
-      cnt += __popcll(kb);
-      if (lane == 0) kb_slot[0] = kb;
-      d0 = d1;
-      d1 = d2;
-      d2 = diag_of(b + 3);
-    }
-    // nz rows: block b+3 (loaded one iteration ago) enters the ring, block b+4 is requested.
-    // Ring slot (b+3)%4 held block b-1, last read in iteration b-1.
-    if (b >= 1) {
-      store_nz((b + 3) % NZRING, nz_inflight);
-      nz_inflight = load_nz(b + 4);
-    }
-    R3_LDS_BARRIER();
-    // ---- stage 2: OR the non-zero words of the kept rows into remv; request block b + 2's words
-    const u64 kb = kb_slot[0];
-    if (((kb >> myrow) & 1ULL) && wa_i >= 0) {
-      if (wa) atomicOr(&remv[wa_i], wa);
-      // rows with more than RSLOTS non-zero words: the rest on demand
-      const u64* nzb = nzbuf + (b % NZRING) * slot_words + myrow * nzw;
-      for (int k = myk + RSLOTS;; k += RSLOTS) {
-        const int w = kth_word(nzb, nzw, b, k);
-        if (w < 0) break;
-        const u64 v = mask[(size_t)(b * TILE + myrow) * cb + w];
-        if (v) atomicOr(&remv[w], v);
-      }
-    }
-    wa = wb;
-    wa_i = wb_i;
-    wb = spec_word(b + 2, wb_i);
-    R3_LDS_BARRIER();
-  }
-  if (tid == 0) {
-    kb_slot[1] = (u64)cnt;
-    *count_out = cnt;
-  }
-  __syncthreads();
-  // sorted position -> original index, in parallel (kept off the serial path above)
-  const int total = (int)kb_slot[1];
-  if (order)  // (the batched detection pipeline maps positions itself)
-    for (int i = tid; i < total; i += blockDim.x) keep_out[i] = order[keep_out[i]];
-}
 
 // Greedy scan of one 64-row block by DEPENDENCY ROUNDS instead of row by row.  Lane k holds its
 // in-edges (bit j: an earlier row j of the block suppresses k).  A row is removed as soon as one
@@ -524,11 +388,11 @@ __device__ __forceinline__ u64 scan_block_rounds(u64 in, u64 removed, u64 valid)
 }
 
 // ---------------------------------------------------------------------------- reduce, pipelined
-// Same algorithm as nms_reduce_sparse_kernel, restructured so that neither a memory wait nor a
-// bitmap search sits on the serial chain (measured there per 64-row block: ~1.6 us, of which the
-// compiler's s_waitcnt vmcnt(0) at the top of every iteration -- shifting prefetch registers and
-// conditional loads defeat its counting -- and the k-th-set-bit search for the word addresses were
-// the two largest parts):
+// ONE workgroup per image walks the 64-row blocks in score order.  A first version kept its three
+// prefetch streams in shifting registers (d0 = d1) behind conditional loads and looked the word
+// addresses up in the row bitmap; measured per 64-row block ~1.6 us, of which the compiler's
+// s_waitcnt vmcnt(0) at the top of every iteration (shifting registers and conditional loads defeat
+// its counting) and the k-th-set-bit search were the two largest parts.  This form:
 //   * every stream is a FIFO of RP statically indexed registers (walk unrolled by RP), every load
 //     is unconditional (clamped address, validity applied at the use) and the keep list is written
 //     after the walk: the loop body is straight-line, the compiler waits vmcnt(4 RP - k);
@@ -735,16 +599,9 @@ inline int drain_blocks(size_t qcap) {
   return blocks > 1024 ? 1024 : blocks < 1 ? 1 : (int)blocks;
 }
 
-inline size_t reduce_lds_bytes(int cb, int nzw) { return (size_t)(cb + 2 + NZRING * TILE * nzw) * sizeof(u64); }
-
-// greedy reduction of `images` problems (blockIdx.z); nms_impl 2 selects the older register-shifting form
+// greedy reduction of `images` problems (blockIdx.z)
 inline void launch_reduce(int images, const u64* mask, const u64* nz, int nzw, int n, int cb, const int64_t* order,
                           int64_t* keep_out, int32_t* count_out, const Batch& bt, hipStream_t stream) {
-  if (g_r3_nms_impl == 2) {
-    hipLaunchKernelGGL(nms_reduce_sparse_kernel, dim3(1, 1, images), dim3(RTHREADS), reduce_lds_bytes(cb, nzw), stream,
-                       mask, nz, nzw, n, cb, order, keep_out, count_out, bt);
-    return;
-  }
   const size_t lds = (size_t)2 * cb * sizeof(u64) + RTHREADS * sizeof(int);
   hipLaunchKernelGGL(nms_reduce_pipe_kernel, dim3(1, 1, images), dim3(RTHREADS), lds, stream, mask, nz, nzw, n, cb,
                      order, keep_out, count_out, bt);
