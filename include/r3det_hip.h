@@ -172,6 +172,22 @@ int r3det_mcnms_v1(const float* boxes, int B, int n, int K, const int32_t* cand_
                    size_t ws_bytes, float* dets_out, int64_t* labels_out, int64_t* keep_idx_out,
                    int32_t* counts_out, void* stream);
 
+/* The same pipeline for the other nms types of multiclass_nms_rotated (bbox_nms_rotated.py:42-58):
+ *   nms_type 1 : batched_rnms, identical to r3det_mcnms_v1.
+ *   nms_type 3 : obb_batched_nms (nms_rotated_wrapper.py:23-59): x, y += label * extent with
+ *       extent = (max - min of the candidates' circumscribed horizontal boxes) + 1 per image,
+ *       boxes with min(w, h) < 0.001 never kept and never suppress, IoU v3, keep in SCORE
+ *       order, first out_cap.
+ *   nms_type 2 : ml_nms_rotated (ml_nms_rotated.py:6-36, kernel ml_nms_rotated_cuda.cu:11-73):
+ *       no offsets, pairs of different labels never suppress, IoU v2, keep in SCORE order,
+ *       first out_cap.
+ * maxc is read by nms_type 1 only (may be NULL otherwise).  Outputs as r3det_mcnms_v1 except
+ * the row order. */
+int r3det_mcnms(int nms_type, const float* boxes, int B, int n, int K, const int32_t* cand_row,
+                const int32_t* cand_label, const float* cand_score, int32_t* cand_rank, const int32_t* counts,
+                const float* maxc, int cap, float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out,
+                int64_t* labels_out, int64_t* keep_idx_out, int32_t* counts_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Feature refinement (rotated feature-align sampler)
  * ------------------------------------------------------------------------------------- */

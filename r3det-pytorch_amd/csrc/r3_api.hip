@@ -143,6 +143,14 @@ int r3det_mcnms_v1(const float* boxes, int B, int n, int K, const int32_t* cand_
                          out_cap, ws, ws_bytes, dets_out, labels_out, keep_idx_out, counts_out, S(stream)));
 }
 
+int r3det_mcnms(int nms_type, const float* boxes, int B, int n, int K, const int32_t* cand_row,
+                const int32_t* cand_label, const float* cand_score, int32_t* cand_rank, const int32_t* counts,
+                const float* maxc, int cap, float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out,
+                int64_t* labels_out, int64_t* keep_idx_out, int32_t* counts_out, void* stream) {
+  return rc(r3k_mcnms_run(nms_type, boxes, B, n, K, cand_row, cand_label, cand_score, cand_rank, counts, maxc, cap,
+                          iou_thr, out_cap, ws, ws_bytes, dets_out, labels_out, keep_idx_out, counts_out, S(stream)));
+}
+
 size_t r3det_fr_workspace_bytes(int N, int H, int W, int points) {
   return r3k_fr_workspace_bytes(N, H, W, points);
 }

@@ -36,6 +36,11 @@ int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, c
                  const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
                  float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
                  int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream);
+// geom 1 = v1 (same as above), 3 = obb_batched_nms, 2 = ml_nms_rotated; 2/3 emit score order
+int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
+                  const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
+                  float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
+                  int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream);
 
 size_t r3k_fr_workspace_bytes(int N, int H, int W, int points);
 // ws may be null (taps derived per channel plane); with a workspace: tap table + unpack kernel

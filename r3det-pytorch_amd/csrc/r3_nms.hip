@@ -808,15 +808,59 @@ __global__ __launch_bounds__(RK_T) void mc_rank_kernel(const float* __restrict__
   if (cnt) atomicAdd(&cand_rank[(size_t)img * cand_stride + i], cnt);
 }
 
-// one thread per candidate: record at its sorted position, and the inverse permutation
+// v3 class offsets (obb_batched_nms, nms_rotated_wrapper.py:78-98): label * (hbb.max() - hbb.min() + 1)
+// over the circumscribed horizontal boxes of ALL candidates (obb2hbb :7-20, fp32 cosf / sinf like
+// the torch ops it mirrors).  One workgroup per image; extent[img] = (max - min) + 1.
+__global__ __launch_bounds__(1024) void mc_hbb_extent_kernel(const float* __restrict__ boxes, int n,
+                                                             const int* __restrict__ cand_row, int cand_stride,
+                                                             const int* __restrict__ counts,
+                                                             float* __restrict__ extent) {
+  __shared__ float smin[16], smax[16];
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = counts[img];
+  float lo = INFINITY, hi = -INFINITY;
+  for (int c = tid; c < M; c += 1024) {
+    const float* b = boxes + ((size_t)img * n + cand_row[(size_t)img * cand_stride + c]) * 5;
+    const float cs = cosf(b[4]), sn = sinf(b[4]);
+    const float xb = fabsf(b[2] / 2 * cs) + fabsf(b[3] / 2 * sn);
+    const float yb = fabsf(b[2] / 2 * sn) + fabsf(b[3] / 2 * cs);
+    lo = fminf(lo, fminf(b[0] - xb, b[1] - yb));
+    hi = fmaxf(hi, fmaxf(b[0] + xb, b[1] + yb));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, d));
+    hi = fmaxf(hi, __shfl_xor(hi, d));
+  }
+  if (lane == 0) {
+    smin[wave] = lo;
+    smax[wave] = hi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; w++) {
+      lo = fminf(lo, smin[w]);
+      hi = fmaxf(hi, smax[w]);
+    }
+    extent[img] = hi - lo + 1.f;
+  }
+}
+
+// one thread per candidate: record at its sorted position, and the inverse permutation.
+//   GEOM 1: x, y += label * (max + 1)          (batched_rnms, rnms_wrapper.py:58-63)
+//   GEOM 3: x, y += label * extent; boxes thinner than 1e-3 never take part (obb_nms removes them
+//           before its kernel, nms_rotated_wrapper.py:40-46): flagged dead and moved out of reach
+//   GEOM 2: no offsets, the label rides in the record (ml_nms_rotated: IoU = 0 across labels)
+template <int GEOM>
 __global__ __launch_bounds__(256) void mc_prepare_kernel(const float* __restrict__ boxes, int n,
                                                          const int* __restrict__ cand_row,
                                                          const int* __restrict__ cand_label,
                                                          const int* __restrict__ cand_rank, int cand_stride,
                                                          const int* __restrict__ counts,
-                                                         const float* __restrict__ maxc, BoxRec* __restrict__ recs,
+                                                         const float* __restrict__ scale, BoxRec* __restrict__ recs,
                                                          size_t recs_stride, int* __restrict__ sorted_vals,
-                                                         unsigned* __restrict__ counter, size_t counter_stride) {
+                                                         uint8_t* __restrict__ dead, unsigned* __restrict__ counter,
+                                                         size_t counter_stride) {
   const int img = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c == 0) counter[img * counter_stride] = 0;
@@ -824,13 +868,28 @@ __global__ __launch_bounds__(256) void mc_prepare_kernel(const float* __restrict
   const size_t cbase = (size_t)img * cand_stride;
   const int pos = cand_rank[cbase + c];
   const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
-  // offsets = labels.to(float) * (bboxes.max() + 1); shifted[:, :2] += offsets (rnms_wrapper.py:58-63)
-  const float off = (float)cand_label[cbase + c] * (maxc[img] + 1.f);
-  const float d[5] = {b[0] + off, b[1] + off, b[2], b[3], b[4]};
+  const float lab = (float)cand_label[cbase + c];
+  float d[5] = {b[0], b[1], b[2], b[3], b[4]};
+  bool is_dead = false;
+  if (GEOM == 1) {
+    const float off = lab * (scale[img] + 1.f);
+    d[0] += off;
+    d[1] += off;
+  } else if (GEOM == 3) {
+    const float off = lab * scale[img];
+    d[0] += off;
+    d[1] += off;
+    is_dead = fminf(b[2], b[3]) < 0.001f;
+    if (is_dead) {  // disjoint from every live box and from each other by the stream kernel's tests
+      d[0] = 1e30f;
+      d[1] = (float)c * 1e27f;
+    }
+  }
   BoxRec r;
-  make_record<1>(d, 0.f, r);
+  make_record<GEOM>(d, GEOM == 2 ? lab : 0.f, r);
   recs[img * recs_stride + pos] = r;
   sorted_vals[img * recs_stride + pos] = c;
+  if (GEOM == 3) dead[img * recs_stride + c] = is_dead;
 }
 
 __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict__ boxes, int n,
@@ -883,6 +942,55 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
   if (tid == 0) counts_out[img] = min(cnt, out_cap);
 }
 
+// finish for the score-ordered families (v3 obb_nms, v2 ml_nms_rotated): the keep list already is in
+// score order; drop the dead (too thin, v3) entries, keep the first out_cap, gather.
+__global__ __launch_bounds__(1024) void mc_finish_score_kernel(const float* __restrict__ boxes, int n,
+                                                               const int* __restrict__ cand_row,
+                                                               const int* __restrict__ cand_label,
+                                                               const float* __restrict__ cand_score, int cand_stride,
+                                                               const int* __restrict__ sorted_vals,
+                                                               const int64_t* __restrict__ keep, size_t keep_stride,
+                                                               const int32_t* __restrict__ kept_count,
+                                                               const uint8_t* __restrict__ dead, int out_cap,
+                                                               float* __restrict__ dets_out,
+                                                               int64_t* __restrict__ labels_out,
+                                                               int64_t* __restrict__ keep_idx_out,
+                                                               int32_t* __restrict__ counts_out) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.x;
+  const int cnt = kept_count[img];
+  const size_t cbase = (size_t)img * cand_stride;
+  keep += img * keep_stride;
+  sorted_vals += img * keep_stride;
+  if (dead) dead += img * keep_stride;
+  const int per = (cnt + 1023) / 1024;
+  const int lo = min(tid * per, cnt), hi = min(lo + per, cnt);
+  int c = 0;
+  for (int i = lo; i < hi; i++) c += !(dead && dead[sorted_vals[keep[i]]]);
+  part[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (tid >= off) ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - c;
+  for (int i = lo; i < hi && pos < out_cap; i++) {
+    const int cand = sorted_vals[keep[i]];
+    if (dead && dead[cand]) continue;
+    const float* b = boxes + ((size_t)img * n + cand_row[cbase + cand]) * 5;
+    float* d = dets_out + ((size_t)img * out_cap + pos) * 6;
+    d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
+    d[5] = cand_score[cbase + cand];
+    labels_out[(size_t)img * out_cap + pos] = cand_label[cbase + cand];
+    if (keep_idx_out) keep_idx_out[(size_t)img * out_cap + pos] = cand;
+    pos++;
+  }
+  if (tid == 1023) counts_out[img] = min(part[1023], out_cap);
+}
+
 struct McLayout {
   int* svals;
   BoxRec* recs;
@@ -893,6 +1001,8 @@ struct McLayout {
   int64_t* keep;
   int32_t* kept;
   uint8_t* flags;
+  uint8_t* dead;
+  float* extent;
   size_t qcap, zero_bytes;
   int cb, nzw;
 };
@@ -911,10 +1021,12 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* keep = take((size_t)B * cap * 8);
   char* kept = take((size_t)B * 4);
   char* flags = take((size_t)B * cap);
+  char* dead = take((size_t)B * cap);
+  char* extent = take((size_t)B * 4);
   if (L) {
     L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
     L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->keep = (int64_t*)keep;
-    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags;
+    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->extent = (float*)extent;
     L->qcap = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb; L->nzw = (int)nzw;
     if (g_r3_nms_qcap > 0 && (size_t)g_r3_nms_qcap < L->qcap) L->qcap = (size_t)g_r3_nms_qcap;
   }
@@ -951,13 +1063,16 @@ size_t r3k_mcnms_workspace_bytes(int B, int cap) {
   return mc_layout(B, cap, nullptr, nullptr);
 }
 
-int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
-                 const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
-                 float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
-                 int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream) {
+// geom 1: batched_rnms (v1, keep ascending); 3: obb_batched_nms (v3, score order, thin boxes dropped);
+// 2: ml_nms_rotated (v2, label guard, score order).  maxc is used by geom 1 only.
+int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
+                  const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
+                  float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
+                  int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream) {
+  if (geom < 1 || geom > 3) return -1;
   if (B <= 0 || n <= 0 || K <= 0 || cap <= 0 || out_cap <= 0 || cap >= 65536 || !(iou_thr >= 0.f)) return -1;
-  if (!boxes || !cand_row || !cand_label || !cand_score || !cand_rank || !counts || !maxc || !ws || !dets_out ||
-      !labels_out || !counts_out)
+  if (!boxes || !cand_row || !cand_label || !cand_score || !cand_rank || !counts || !ws || !dets_out ||
+      !labels_out || !counts_out || (geom == 1 && !maxc))
     return -1;
   if (ws_bytes < r3k_mcnms_workspace_bytes(B, cap)) return -3;
   const int S = n * K;
@@ -968,21 +1083,42 @@ int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, c
            (size_t)cap};
   hipLaunchKernelGGL(mc_rank_kernel, dim3((cap + RK_T - 1) / RK_T, (cap + RK_J - 1) / RK_J, B), dim3(RK_T), 0, stream,
                      cand_score, S, counts, cand_rank);
-  hipLaunchKernelGGL(mc_prepare_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, stream, boxes, n, cand_row,
-                     cand_label, cand_rank, S, counts, maxc, L.recs, bt.recs, L.svals, L.counter, bt.counter);
-  if (hipMemsetAsync(L.mask, 0, L.zero_bytes, stream) != hipSuccess) return -2;
-  dim3 grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
-  hipLaunchKernelGGL((nms_stream_kernel<1, false>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, iou_thr, L.gqueue,
-                     (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt);
+  const dim3 pgrid((cap + 255) / 256, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
   int dblocks = drain_blocks(L.qcap);
   if (dblocks > 256) dblocks = 256;  // B images share the chip
-  hipLaunchKernelGGL(nms_drain_kernel<1>, dim3(dblocks, 1, B), dim3(256), 0, stream, L.recs, L.cb, iou_thr,
-                     L.gqueue, (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt);
+  const dim3 dgrid(dblocks, 1, B);
+  if (geom == 3)
+    hipLaunchKernelGGL(mc_hbb_extent_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, S, counts, L.extent);
+  if (hipMemsetAsync(L.mask, 0, L.zero_bytes, stream) != hipSuccess) return -2;
+#define R3_MC(GEOM, LABEL, SCALE)                                                                                  \
+  hipLaunchKernelGGL(mc_prepare_kernel<GEOM>, pgrid, dim3(256), 0, stream, boxes, n, cand_row, cand_label,        \
+                     cand_rank, S, counts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.counter, bt.counter);        \
+  hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, iou_thr,       \
+                     L.gqueue, (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt);                              \
+  hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dgrid, dim3(256), 0, stream, L.recs, L.cb, iou_thr, L.gqueue,        \
+                     (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt)
+  if (geom == 1) { R3_MC(1, false, maxc); }
+  else if (geom == 3) { R3_MC(3, false, L.extent); }
+  else { R3_MC(2, true, (const float*)nullptr); }
+#undef R3_MC
   launch_reduce(B, L.mask, L.nz, L.nzw, 0, L.cb, nullptr, L.keep, L.kept, bt, stream);
-  hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label, cand_score,
-                     S, L.svals, counts, L.keep, bt.keep, L.kept, L.flags, out_cap, dets_out, labels_out, keep_idx_out,
-                     counts_out);
+  if (geom == 1)
+    hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label, cand_score,
+                       S, L.svals, counts, L.keep, bt.keep, L.kept, L.flags, out_cap, dets_out, labels_out,
+                       keep_idx_out, counts_out);
+  else
+    hipLaunchKernelGGL(mc_finish_score_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label,
+                       cand_score, S, L.svals, L.keep, bt.keep, L.kept, geom == 3 ? L.dead : (const uint8_t*)nullptr,
+                       out_cap, dets_out, labels_out, keep_idx_out, counts_out);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
+                 const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
+                 float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
+                 int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream) {
+  return r3k_mcnms_run(1, boxes, B, n, K, cand_row, cand_label, cand_score, cand_rank, counts, maxc, cap, iou_thr,
+                       out_cap, ws, ws_bytes, dets_out, labels_out, keep_idx_out, counts_out, stream);
 }
 
 // greedy reduction of a dense upper-triangle mask (rows in score order); used by poly_nms

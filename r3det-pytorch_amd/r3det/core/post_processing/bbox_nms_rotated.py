@@ -75,16 +75,17 @@ def multiclass_nms_rotated(multi_bboxes, multi_scores, score_thr, nms, max_num=-
 def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max_num=-1):
     """``[multiclass_nms_rotated(b, s, ...) for b, s in zip(multi_bboxes, multi_scores)]`` for a
     whole batch -- (B, n, 5) boxes shared by the classes, (B, n, C+1) scores -- with identical
-    results.  nms type 'v1' runs as ONE pass of launches over all images
-    (r3det_mcnms_select / r3det_mcnms_v1 in include/r3det_hip.h: threshold + ordered compaction,
-    stable score sort, class offsets, suppression, ascending keep and the max_num cut on the
-    device; the host reads the per-image candidate counts once in the middle and the per-image
-    detection counts at the end).  Other nms types take the per-image path."""
+    results.  nms types 'v1', 'v2' and 'v3' run as ONE pass of launches over all images
+    (r3det_mcnms_select / r3det_mcnms in include/r3det_hip.h: threshold + ordered compaction,
+    stable score sort, class offsets or label guard, suppression, keep order and the max_num cut
+    on the device; the host reads the per-image candidate counts once in the middle and the
+    per-image detection counts at the end).  'mmcv' takes the per-image path."""
     B, n = multi_scores.shape[:2]
     K = multi_scores.size(2) - 1
     version = nms.get('type', 'v1')
     iou_thr = float(_get(nms, 'iou_thr'))
-    fused = (version == 'v1' and multi_bboxes.dim() == 3 and multi_bboxes.size(2) == 5 and n > 0 and K > 0
+    geom = {'v1': 1, 'v2': 2, 'v3': 3}.get(version, 0)
+    fused = (geom and multi_bboxes.dim() == 3 and multi_bboxes.size(2) == 5 and n > 0 and K > 0
              and iou_thr >= 0)
     if not fused:
         return [multiclass_nms_rotated(multi_bboxes[i], multi_scores[i], score_thr, nms, max_num) for i in range(B)]
@@ -119,8 +120,10 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
         dets = torch.empty((B, out_cap, 6), dtype=torch.float32, device=dev)
         labels = torch.empty((B, out_cap), dtype=torch.int64, device=dev)
         kept = torch.empty(B, dtype=torch.int32, device=dev)
-        _C.check(L.r3det_mcnms_v1(_C.ptr(boxes), B, n, K, _C.ptr(cand_row), _C.ptr(cand_label), _C.ptr(cand_score),
-                                  _C.ptr(cand_rank), _C.ptr(counts), _C.ptr(maxc), cap, iou_thr, out_cap, _C.ptr(ws), ws_bytes,
-                                  _C.ptr(dets), _C.ptr(labels), None, _C.ptr(kept), _C.stream()), "r3det_mcnms_v1")
+        _C.check(L.r3det_mcnms(geom, _C.ptr(boxes), B, n, K, _C.ptr(cand_row), _C.ptr(cand_label), _C.ptr(cand_score),
+                               _C.ptr(cand_rank), _C.ptr(counts), _C.ptr(maxc), cap, iou_thr, out_cap, _C.ptr(ws), ws_bytes,
+                               _C.ptr(dets), _C.ptr(labels), None, _C.ptr(kept), _C.stream()), "r3det_mcnms")
         kept = kept.tolist()
+        if geom == 2 and max_num <= 0:  # the reference's v2 branch slices [:max_num] whenever kept > max_num (:63-65)
+            kept = [max(k + max_num, 0) if max_num < 0 else 0 for k in kept]
     return [(dets[i, :kept[i]], labels[i, :kept[i]]) for i in range(B)]

@@ -39,34 +39,41 @@ def qcap(request):
     _C.set_option("nms_qcap", 0)
 
 
+@pytest.fixture(params=['v1', 'v3', 'v2'])
+def nms_type(request):
+    return request.param
+
+
 @pytest.mark.parametrize("max_num", [50, 2000, -1])
-def test_golden_reference_wrapper(max_num):
+def test_golden_reference_wrapper(max_num, nms_type):
     """The reference's wrapper ran on these inputs (make_golden_wrappers.py); B = 2 repeats the
     image so that the image stride of every array is exercised."""
     from r3det.core.post_processing import multiclass_nms_rotated_batch
     g = np.load(os.path.join(GOLDEN, "wrappers.npz"))
     b = torch.from_numpy(g["mc_boxes"]).cuda()
     s = torch.from_numpy(g["mc_scores"]).cuda()
-    out = multiclass_nms_rotated_batch(torch.stack([b, b]), torch.stack([s, s]), 0.05, dict(type='v1', iou_thr=0.1),
-                                       max_num)
+    cfg = dict(type=nms_type, iou_thr=0.1)
+    out = multiclass_nms_rotated_batch(torch.stack([b, b]), torch.stack([s, s]), 0.05, cfg, max_num)
     if max_num > 0:
         for d, lab in out:
-            assert np.array_equal(d.cpu().numpy(), g[f"mc_v1_{max_num}_dets"])
-            assert np.array_equal(lab.cpu().numpy(), g[f"mc_v1_{max_num}_labels"])
-    same(out, torch.stack([b, b]), torch.stack([s, s]), 0.05, dict(type='v1', iou_thr=0.1), max_num)
+            assert np.array_equal(d.cpu().numpy(), g[f"mc_{nms_type}_{max_num}_dets"])
+            assert np.array_equal(lab.cpu().numpy(), g[f"mc_{nms_type}_{max_num}_labels"])
+    same(out, torch.stack([b, b]), torch.stack([s, s]), 0.05, cfg, max_num)
 
 
 @pytest.mark.parametrize("B,n", [(1, 100), (3, 1000), (4, 5344), (2, 9000)])
 @pytest.mark.parametrize("max_num", [2000, 37])
-def test_matches_per_image_path(B, n, max_num, qcap):
+def test_matches_per_image_path(B, n, max_num, qcap, nms_type):
     from r3det.core.post_processing import multiclass_nms_rotated_batch
     boxes, scores = pools(B, n, 1000 + n)
-    same(multiclass_nms_rotated_batch(boxes, scores, 0.05, CFG, max_num), boxes, scores, 0.05, CFG, max_num)
+    cfg = dict(type=nms_type, iou_thr=0.1)
+    same(multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, max_num), boxes, scores, 0.05, cfg, max_num)
 
 
-def test_ragged_and_empty_images():
+def test_ragged_and_empty_images(nms_type):
     """Images with very different candidate counts, one with none, in one batch; then all empty."""
     from r3det.core.post_processing import multiclass_nms_rotated_batch
+    CFG = dict(type=nms_type, iou_thr=0.1)
     boxes, scores = pools(4, 2000, 5)
     scores[1] = 0.01                      # no candidate at all
     scores[2, 50:] = 0.0                  # a handful
@@ -78,10 +85,11 @@ def test_ragged_and_empty_images():
     assert all(d.shape == (0, 6) and lab.shape == (0,) and lab.dtype == torch.int64 for d, lab in out)
 
 
-def test_score_ties_keep_candidate_order():
+def test_score_ties_keep_candidate_order(nms_type):
     """Quantised scores: thousands of exact ties; the stable sort must order them like the
     per-image path (torch.sort(stable=True))."""
     from r3det.core.post_processing import multiclass_nms_rotated_batch
+    CFG = dict(type=nms_type, iou_thr=0.1)
     boxes, scores = pools(2, 3000, 77)
     scores = (scores * 8).round() / 8
     same(multiclass_nms_rotated_batch(boxes, scores, 0.05, CFG, 2000), boxes, scores, 0.05, CFG, 2000)
@@ -94,3 +102,31 @@ def test_single_class_and_other_types():
     boxes, scores = pools(2, 800, 10)
     for cfg in (dict(type='v3', iou_thr=0.1), dict(type='v2', iou_thr=0.1), dict(type='mmcv', iou_thr=0.1)):
         same(multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 100), boxes, scores, 0.05, cfg, 100)
+
+
+def test_v3_thin_boxes_never_kept_nor_suppress():
+    """obb_nms drops boxes with min(w, h) < 1e-3 before its kernel (nms_rotated_wrapper.py:40-46):
+    they are not output and cannot suppress; a thin top-score box sits on every fourth box."""
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    boxes, scores = pools(3, 1500, 31)
+    boxes[:, ::4, 3] = 5e-4
+    boxes[1, 1::4, 2] = 0.0
+    cfg = dict(type='v3', iou_thr=0.1)
+    out = multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000)
+    for d, _ in out:
+        assert d.size(0) > 0 and bool((d[:, 2:4].min(1)[0] >= 0.001).all())
+    same(out, boxes, scores, 0.05, cfg, 2000)
+    boxes[2, :, 2] = 0.0  # an image with candidates but no live box
+    out = multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000)
+    assert out[2][0].shape == (0, 6)
+    same(out, boxes, scores, 0.05, cfg, 2000)
+
+
+@pytest.mark.parametrize("max_num", [-1, 0, -3])
+def test_v2_non_positive_max_num_slices_like_reference(max_num):
+    """bbox_nms_rotated.py:63-65 slices [:max_num] whenever kept > max_num: -1 drops the last
+    detection, 0 drops all."""
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    boxes, scores = pools(2, 600, 3)
+    cfg = dict(type='v2', iou_thr=0.1)
+    same(multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, max_num), boxes, scores, 0.05, cfg, max_num)
