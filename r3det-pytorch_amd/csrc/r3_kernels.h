@@ -46,8 +46,11 @@ size_t r3k_fr_workspace_bytes(int N, int H, int W, int points);
 // ws may be null (taps derived per channel plane); with a workspace: tap table + unpack kernel
 int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, int W, float scale,
                    int points, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
+// ws may be null; with r3k_fr_backward_workspace_bytes() of workspace the 128 x 128 / 64 x 64
+// overwrite-mode call runs without LDS float atomics (packed path)
+size_t r3k_fr_backward_workspace_bytes(int N, int H, int W, int points);
 int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W,
-                    float scale, int points, float* bottom_grad, int overwrite,
+                    float scale, int points, float* bottom_grad, int overwrite, void* ws, size_t ws_bytes,
                     hipStream_t stream);
 
 // polygon ops outside the shipped configs (r3_poly.hip)

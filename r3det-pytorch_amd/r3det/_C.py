@@ -39,6 +39,7 @@ SIGNATURES = {
     "r3det_feature_refine_prepare": [_vp, _i, _i, _i, _f, _vp, _vp],
     "r3det_feature_refine_forward_prepared": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "r3det_feature_refine_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
+    "r3det_feature_refine_backward_ws": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _sz, _vp],
     "r3det_set_option": [ctypes.c_char_p, _i],
     "r3det_fr_profile_read": [_vp, _i],
 }
@@ -73,6 +74,8 @@ def lib():
         L.r3det_fr_table_bytes.restype = _sz
         L.r3det_fr_workspace_bytes.argtypes = [_i, _i, _i, _i]
         L.r3det_fr_workspace_bytes.restype = _sz
+        L.r3det_fr_backward_workspace_bytes.argtypes = [_i, _i, _i, _i]
+        L.r3det_fr_backward_workspace_bytes.restype = _sz
         L.r3det_iou_workspace_bytes.argtypes = [_i, _i]
         L.r3det_iou_workspace_bytes.restype = _sz
         L.r3det_error_string.argtypes = [_i]

@@ -79,9 +79,12 @@ def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, over
     o = _C.need_hip(bottom_grad, "bottom_grad")
     N, C, H, W = g.shape
     with torch.cuda.device(g.device):
-        _C.check(_C.lib().r3det_feature_refine_backward(_C.ptr(g), _C.ptr(b), N, C, H, W, float(spatial_scale),
-                                                        int(points), _C.ptr(o), int(bool(overwrite)),
-                                                        _C.stream()), "fr_backward")
+        L = _C.lib()
+        wsb = int(L.r3det_fr_backward_workspace_bytes(N, H, W, int(points))) if overwrite else 0
+        ws = torch.empty(wsb, dtype=torch.uint8, device=g.device)
+        _C.check(L.r3det_feature_refine_backward_ws(_C.ptr(g), _C.ptr(b), N, C, H, W, float(spatial_scale),
+                                                    int(points), _C.ptr(o), int(bool(overwrite)), _C.ptr(ws), wsb,
+                                                    _C.stream()), "fr_backward")
     return 1
 
 
