@@ -594,10 +594,9 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
 // are never read back.  Summation order of the atomics is not deterministic (as in the reference).
 // ----------------------------------------------------------------------------------------
 template <int LOGW, int LOGH, int THREADS, int MODE = 0>
-__global__ __launch_bounds__(THREADS) void fr_backward_cell(const float* __restrict__ top,
-                                                            const float* __restrict__ boxes, int C, int G,
-                                                            float scale, float* __restrict__ bottom,
-                                                            const int* __restrict__ flags, int flag_stride) {
+__device__ __forceinline__ void fr_backward_cell_body(const float* __restrict__ top,
+                                                      const float* __restrict__ boxes, int C, int G, float scale,
+                                                      float* __restrict__ bottom) {
   constexpr int FRC_BLOCK = THREADS;
   constexpr int W = 1 << LOGW, H = 1 << LOGH, HW = W * H, K = HW / FRC_BLOCK, PITCH = W + 1;
   constexpr int BUF = ((H + 3) * PITCH + 3) & ~3;
@@ -608,8 +607,6 @@ __global__ __launch_bounds__(THREADS) void fr_backward_cell(const float* __restr
   const int tid = threadIdx.x;
   const int groups = C / G;
   const int n = blockIdx.x / groups;
-  // behind fr_backward_packed: only the images its packing could not take
-  if (flags && !flags[(size_t)n * flag_stride]) return;
   const int c0 = (blockIdx.x - n * groups) * G;
   const size_t plane0 = (size_t)n * C + c0;
   float ty[K], tx[K];
@@ -698,6 +695,22 @@ __global__ __launch_bounds__(THREADS) void fr_backward_cell(const float* __restr
 #pragma unroll
     for (int k = 0; k < K; k++) dst[tid + k * FRC_BLOCK] = acc[self0 + k * KSTEP];
   }
+}
+
+// the same code as a real function: fr_backward_packed calls it for images it cannot pack
+// (inlined there it would share, and overflow, that kernel's register budget)
+template <int LOGW, int LOGH>
+__device__ __attribute__((noinline)) void fr_backward_cell_call(const float* __restrict__ top,
+                                                                const float* __restrict__ boxes, int C, int G,
+                                                                float scale, float* __restrict__ bottom) {
+  fr_backward_cell_body<LOGW, LOGH, 1024, 0>(top, boxes, C, G, scale, bottom);
+}
+
+template <int LOGW, int LOGH, int THREADS, int MODE = 0>
+__global__ __launch_bounds__(THREADS) void fr_backward_cell(const float* __restrict__ top,
+                                                            const float* __restrict__ boxes, int C, int G,
+                                                            float scale, float* __restrict__ bottom) {
+  fr_backward_cell_body<LOGW, LOGH, THREADS, MODE>(top, boxes, C, G, scale, bottom);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -863,7 +876,8 @@ __global__ __launch_bounds__(256) void fr_bwd_place_kernel(const float* __restri
 
 template <int LOGW, int LOGH>
 __global__ __launch_bounds__(1024) void fr_backward_packed(const float* __restrict__ top,
-                                                           const char* __restrict__ table, int C, int G,
+                                                           const char* __restrict__ table,
+                                                           const float* __restrict__ boxes, float scale, int C, int G,
                                                            float* __restrict__ bottom) {
   using P = FrPack<LOGW, LOGH>;
   constexpr int W = P::W, H = P::H, HW = P::HW, K = P::K, PITCH = P::PITCH, KS = P::KS;
@@ -878,7 +892,10 @@ __global__ __launch_bounds__(1024) void fr_backward_packed(const float* __restri
   const int c0 = (blockIdx.x - n * groups) * G;
   const size_t plane0 = (size_t)n * C + c0;
   const char* tb = table + (size_t)n * P::IMAGE_BYTES;
-  if (*reinterpret_cast<const int*>(tb + P::TABLE)) return;  // image left to the atomic kernel
+  if (*reinterpret_cast<const int*>(tb + P::TABLE)) {  // a box field the packing does not take
+    fr_backward_cell_call<LOGW, LOGH>(top, boxes, C, G, scale, bottom);
+    return;
+  }
   int ap[KS];
   float fy[KS], fx[KS];
 #pragma unroll
@@ -1214,10 +1231,8 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
       (void)once;
       const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
       const dim3 grid(N * C / G), block(1024);
-      const int* flags = nullptr;
-      int flag_stride = 0;
-      // packed path (no LDS float atomics) when the caller gave a workspace; images whose box field
-      // it cannot pack are flagged and fall through to the atomic kernel below
+      // packed path (no LDS float atomics) when the caller gave a workspace; an image whose box field
+      // it cannot pack is flagged and its workgroups run the atomic kernel's code instead
       if (ws && ws_bytes >= r3k_fr_backward_workspace_bytes(N, H, W, points) && aligned16(ws) &&
           g_r3_fr_impl == 0 && g_r3_fr_dbg == 0) {
         char* table = static_cast<char*>(ws);
@@ -1226,29 +1241,26 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
           hipLaunchKernelGGL((fr_bwd_pack_kernel<7, 7>), dim3(N), block, P::PACK_LDS_INTS * sizeof(int), stream, boxes,
                              scale, table);
           hipLaunchKernelGGL((fr_bwd_place_kernel<7, 7>), dim3(P::HW / 256, N), dim3(256), 0, stream, boxes, scale, table);
-          hipLaunchKernelGGL((fr_backward_packed<7, 7>), grid, block, lds, stream, top_grad, table, C, G, bottom_grad);
-          flags = reinterpret_cast<const int*>(table + P::TABLE);
-          flag_stride = (int)(P::IMAGE_BYTES / sizeof(int));
+          hipLaunchKernelGGL((fr_backward_packed<7, 7>), grid, block, lds, stream, top_grad, table, boxes, scale, C, G,
+                             bottom_grad);
         } else {
           using P = FrPack<6, 6>;
           hipLaunchKernelGGL((fr_bwd_pack_kernel<6, 6>), dim3(N), block, P::PACK_LDS_INTS * sizeof(int), stream, boxes,
                              scale, table);
           hipLaunchKernelGGL((fr_bwd_place_kernel<6, 6>), dim3(P::HW / 256, N), dim3(256), 0, stream, boxes, scale, table);
-          hipLaunchKernelGGL((fr_backward_packed<6, 6>), grid, block, lds, stream, top_grad, table, C, G, bottom_grad);
-          flags = reinterpret_cast<const int*>(table + P::TABLE);
-          flag_stride = (int)(P::IMAGE_BYTES / sizeof(int));
+          hipLaunchKernelGGL((fr_backward_packed<6, 6>), grid, block, lds, stream, top_grad, table, boxes, scale, C, G,
+                             bottom_grad);
         }
-      }
-      if (W == 128 && g_r3_fr_dbg >= 11 && g_r3_fr_dbg <= 13) {  // probes (wrong results)
-        if (g_r3_fr_dbg == 11) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 1>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad, flags, flag_stride);
-        if (g_r3_fr_dbg == 12) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 2>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad, flags, flag_stride);
-        if (g_r3_fr_dbg == 13) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 3>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad, flags, flag_stride);
+      } else if (W == 128 && g_r3_fr_dbg >= 11 && g_r3_fr_dbg <= 13) {  // probes (wrong results)
+        if (g_r3_fr_dbg == 11) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 1>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad);
+        if (g_r3_fr_dbg == 12) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 2>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad);
+        if (g_r3_fr_dbg == 13) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 3>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad);
       } else if (W == 128)
         hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024>), grid, block, lds, stream, top_grad, boxes, C, G, scale,
-                           bottom_grad, flags, flag_stride);
+                           bottom_grad);
       else
         hipLaunchKernelGGL((fr_backward_cell<6, 6, 1024>), grid, block, lds, stream, top_grad, boxes, C, G, scale,
-                           bottom_grad, flags, flag_stride);
+                           bottom_grad);
       return hipGetLastError() == hipSuccess ? 0 : -2;
     }
   }

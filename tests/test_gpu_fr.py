@@ -114,6 +114,32 @@ def test_backward_cell_kernel(shape, adversarial):
     assert (g - g2).abs().max().item() <= 1e-5 * max(1.0, g2.abs().max().item())
 
 
+@pytest.mark.parametrize("shape", [(2, 512, 128, 128, 8), (2, 512, 64, 64, 16)])
+@pytest.mark.parametrize("pile", [2, 9, 10, 16, 17, 300, -1])
+def test_backward_packed_runs_and_fallback(shape, pile):
+    """The packed backward (no LDS atomics) sorts positions by sampled cell and takes runs up to 16
+    (128 x 128) / 9 (64 x 64) positions per cell; an image with a longer run is handed to the atomic
+    code by the same launch.  `pile` positions of image 1 sample one cell (-1: every position of it),
+    image 0 keeps its regular field: both paths in one call, against the oracle."""
+    from r3det.ops.feature_refine import fr_backward
+    N, C, H, W, stride = shape
+    r = np.random.default_rng(pile + 100)
+    top = r.normal(size=(N, C, H, W)).astype(np.float32)
+    boxes = fr_boxes(N, H, W, stride, 21).reshape(N, H * W, 5)
+    idx = np.arange(H * W) if pile < 0 else r.choice(H * W, pile, replace=False)
+    boxes[1, idx, 0] = 37.0 * stride  # same sampled cell (row 37, column 11), different fractions
+    boxes[1, idx, 1] = 11.6 * stride
+    boxes[1, idx, 0] += r.uniform(0, 0.9 * stride, idx.size).astype(np.float32)
+    boxes = boxes.reshape(-1, 5)
+    with O.twin():
+        want = O.fr_backward(top[:, :4], boxes, 1 / stride, 1)
+    tol = 1e-5 * max(1.0, np.abs(want).max())
+    g = torch.full((N, C, H, W), float('nan'), device='cuda')
+    fr_backward(dev(top), dev(boxes), 1 / stride, 1, g, overwrite=True)
+    assert np.abs(g[:, :4].cpu().numpy() - want).max() <= tol
+    assert bool(torch.isfinite(g).all())
+
+
 @pytest.mark.parametrize("shape", [(1, 512, 128, 128, 8), (2, 512, 64, 64, 16), (2, 8, 64, 64, 16), (1, 4, 32, 32, 32)])
 def test_split_form_prepare_then_sample(shape):
     """r3det_feature_refine_prepare + _forward_prepared == the one-call form (and the autograd function
