@@ -107,7 +107,7 @@ def bench_fr():
                 return run
             var = {"fwd cell": mk(10, b), "fwd plane": mk(2, b), "fwd generic": mk(1, b),
                    "fwd auto adv": mk(0, advb[lvl]),
-                   "bwd cell": mk(10, b, True), "bwd plane": mk(2, b, True), "bwd generic": mk(1, b, True)}
+                   "bwd packed": mk(0, b, True), "bwd cell": mk(10, b, True), "bwd plane": mk(2, b, True), "bwd generic": mk(1, b, True)}
             for k, (med, mn) in time_variants(var).items():
                 print(f"fr   N={N} level{lvl} {tuple(f.shape)} {k:14s} med {med:8.1f} us  min {mn:8.1f} us  "
                       f"{alg / med / 1e3:8.1f} GB/s", flush=True)
