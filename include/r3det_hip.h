@@ -148,7 +148,7 @@ int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes,
  *   r3det_mcnms_select : boxes (B,n,5), scores (B,n,K+1; last column = background).
  *       Candidates (score > score_thr) per image in row-major (anchor, class) order:
  *       cand_row / cand_label / cand_rank (int32) and cand_score, each (B, n*K) [cand_rank is
- *       scratch of the second call, zeroed here]; counts (B) int32, maxc (B) = max over the
+ *       scratch of the second call, which zeroes what it uses]; counts (B) int32, maxc (B) = max over the
  *       candidate boxes' five columns.  ws: r3det_mcnms_select_workspace_bytes(B, n).
  *   r3det_mcnms_v1 : cap >= max(counts), < 65536.  Per image: stable descending score sort,
  *       x, y += label * (maxc + 1), NMS v1 (IoU > iou_thr), keep ASCENDING by candidate

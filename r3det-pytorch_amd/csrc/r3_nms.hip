@@ -1081,6 +1081,11 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   const size_t cbq = (size_t)L.cb;
   Batch bt{counts, (size_t)cap, (size_t)cap * cbq, nz_side_words((size_t)cap, L.nzw), 64, L.qcap, (size_t)cap,
            (size_t)cap};
+  // the rank kernel accumulates into cand_rank: zeroed here so that a caller's stale scratch cannot
+  // send records out of bounds (cap <= S: the first cap entries of each image's row)
+  if (hipMemset2DAsync(cand_rank, (size_t)S * sizeof(int), 0, (size_t)(cap < S ? cap : S) * sizeof(int), B, stream) !=
+      hipSuccess)
+    return -2;
   hipLaunchKernelGGL(mc_rank_kernel, dim3((cap + RK_T - 1) / RK_T, (cap + RK_J - 1) / RK_J, B), dim3(RK_T), 0, stream,
                      cand_score, S, counts, cand_rank);
   const dim3 pgrid((cap + 255) / 256, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);

@@ -212,3 +212,28 @@ def test_gradcheck_against_oracle_backward():
     assert np.abs(x.grad.cpu().numpy() - want).max() <= 1e-5 * max(1, np.abs(want).max())
     with pytest.raises(AssertionError):
         feature_refine(x, dev(boxes), 1 / stride, 3)  # points must be 1 or 5
+
+
+def test_backward_ws_too_small_or_absent_uses_the_atomic_kernel():
+    """r3det_feature_refine_backward_ws with no / a short workspace must not touch it and still
+    give the gradient (the LDS-atomic kernel runs)."""
+    from r3det import _C
+    L = _C.lib()
+    N, C, H, W, stride = 1, 512, 64, 64, 16
+    r = np.random.default_rng(3)
+    top = r.normal(size=(N, C, H, W)).astype(np.float32)
+    boxes = fr_boxes(N, H, W, stride, 4)
+    with O.twin():
+        want = O.fr_backward(top[:, :4], boxes, 1 / stride, 1)
+    tol = 1e-5 * max(1.0, np.abs(want).max())
+    t, b = dev(top), dev(boxes)
+    need = int(L.r3det_fr_backward_workspace_bytes(N, H, W, 1))
+    assert need > 0 and int(L.r3det_fr_backward_workspace_bytes(N, 32, 32, 1)) == 0
+    assert int(L.r3det_fr_backward_workspace_bytes(N, H, W, 5)) == 0
+    guard = torch.full((need,), 7, dtype=torch.uint8, device='cuda')
+    for ws_ptr, ws_bytes in ((None, 0), (_C.ptr(guard), need - 16)):
+        g = torch.full((N, C, H, W), float('nan'), device='cuda')
+        _C.check(L.r3det_feature_refine_backward_ws(_C.ptr(t), _C.ptr(b), N, C, H, W, 1 / stride, 1, _C.ptr(g), 1,
+                                                    ws_ptr, ws_bytes, _C.stream()), "bwd")
+        assert np.abs(g[:, :4].cpu().numpy() - want).max() <= tol
+    assert bool((guard == 7).all())

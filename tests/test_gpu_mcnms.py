@@ -130,3 +130,33 @@ def test_v2_non_positive_max_num_slices_like_reference(max_num):
     boxes, scores = pools(2, 600, 3)
     cfg = dict(type='v2', iou_thr=0.1)
     same(multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, max_num), boxes, scores, 0.05, cfg, max_num)
+
+
+def test_mcnms_argument_errors():
+    """r3det_mcnms refuses what it cannot run instead of guessing: unknown nms type, missing maxc
+    for type 1, too small a workspace."""
+    from r3det import _C
+    L = _C.lib()
+    B, n, K, cap = 1, 64, 1, 64
+    dev = torch.device('cuda')
+    boxes = torch.rand(B, n, 5, device=dev) * 50 + 10
+    i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)  # noqa: E731
+    row, lab, rank, cnt, kept = i32(B, n), i32(B, n), i32(B, n), torch.full((B,), n, dtype=torch.int32, device=dev), i32(B)
+    row[0] = torch.arange(n, dtype=torch.int32, device=dev)
+    sc = torch.rand(B, n, device=dev)
+    mx = torch.full((B,), 60., device=dev)
+    wsb = int(L.r3det_mcnms_workspace_bytes(B, cap))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    dets, labels = torch.empty(B, n, 6, device=dev), torch.empty(B, n, dtype=torch.int64, device=dev)
+
+    def call(t, maxc, ws_bytes):
+        return L.r3det_mcnms(t, _C.ptr(boxes), B, n, K, _C.ptr(row), _C.ptr(lab), _C.ptr(sc), _C.ptr(rank), _C.ptr(cnt),
+                             _C.ptr(maxc) if maxc is not None else None, cap, 0.1, n, _C.ptr(ws), ws_bytes,
+                             _C.ptr(dets), _C.ptr(labels), None, _C.ptr(kept), _C.stream())
+    assert call(0, mx, wsb) != 0 and call(4, mx, wsb) != 0
+    assert call(1, None, wsb) != 0
+    assert call(3, None, wsb - 1) != 0
+    for t in (1, 2, 3):
+        assert call(t, mx, wsb) == 0
+        torch.cuda.synchronize()
+        assert 0 < int(kept[0]) <= n
