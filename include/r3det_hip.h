@@ -237,6 +237,19 @@ int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bb
                                      float spatial_scale, int points, float* bottom_grad, int overwrite, void* ws,
                                      size_t ws_bytes, void* stream);
 
+/* Split form of the call above (overwrite mode, points = 1): the sort of the positions depends on
+ * the boxes only, so a training step can run it when the forward pass has the boxes -- on another
+ * stream, off the backward's critical path (31 of 80 us at N = 4, 128 x 128) -- and hand the
+ * workspace to the backward later.  _prepare: R3DET_EINVAL when the shape has no workspace path
+ * (r3det_fr_backward_workspace_bytes() == 0).  _prepared: same boxes, scale and workspace as the
+ * _prepare call; R3DET_EINVAL when this (shape, C) does not take the packed path (then use
+ * r3det_feature_refine_backward_ws). */
+int r3det_feature_refine_backward_prepare(const float* best_bboxes, int N, int H, int W, float spatial_scale,
+                                          void* ws, size_t ws_bytes, void* stream);
+int r3det_feature_refine_backward_prepared(const float* top_grad, const float* best_bboxes, int N, int C, int H,
+                                           int W, float spatial_scale, float* bottom_grad, void* ws, size_t ws_bytes,
+                                           void* stream);
+
 /* Producer of the FR boxes: RRetinaHead.filter_bboxes
  * (models/dense_heads/rotate_retina_head.py:117-179) and, with num_anchors = 1 and
  * anchors_per_image = 1, RRetinaRefineHead.refine_bboxes (rotate_retina_refine_head.py:56-97),

@@ -182,7 +182,7 @@ int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxe
   if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
   if ((size_t)N * C * H * W > 0 && (!top_grad || !best_bboxes || !bottom_grad)) return R3DET_EINVAL;
   return rc(r3k_fr_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, points, bottom_grad,
-                            overwrite, nullptr, 0, S(stream)));
+                            overwrite, nullptr, 0, 0, S(stream)));
 }
 
 size_t r3det_fr_backward_workspace_bytes(int N, int H, int W, int points) {
@@ -195,7 +195,23 @@ int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bb
   if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
   if ((size_t)N * C * H * W > 0 && (!top_grad || !best_bboxes || !bottom_grad)) return R3DET_EINVAL;
   return rc(r3k_fr_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, points, bottom_grad,
-                            overwrite, ws, ws_bytes, S(stream)));
+                            overwrite, ws, ws_bytes, 0, S(stream)));
+}
+
+int r3det_feature_refine_backward_prepare(const float* best_bboxes, int N, int H, int W, float spatial_scale,
+                                          void* ws, size_t ws_bytes, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0) return R3DET_EINVAL;
+  return rc(r3k_fr_backward_prepare(best_bboxes, N, H, W, spatial_scale, ws, ws_bytes, S(stream)));
+}
+
+int r3det_feature_refine_backward_prepared(const float* top_grad, const float* best_bboxes, int N, int C, int H,
+                                           int W, float spatial_scale, float* bottom_grad, void* ws, size_t ws_bytes,
+                                           void* stream) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || !top_grad || !best_bboxes || !bottom_grad || !ws) return R3DET_EINVAL;
+  if (ws_bytes < r3k_fr_backward_workspace_bytes(N, H, W, 1) || r3k_fr_backward_workspace_bytes(N, H, W, 1) == 0)
+    return R3DET_EINVAL;
+  return rc(r3k_fr_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, 1, bottom_grad, 1, ws, ws_bytes, 1,
+                            S(stream)));
 }
 
 int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, const float* bbox_pred,

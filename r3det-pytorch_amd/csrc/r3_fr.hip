@@ -1208,9 +1208,35 @@ size_t r3k_fr_backward_workspace_bytes(int N, int H, int W, int points) {
   return 0;
 }
 
+// the packing alone (depends on the boxes only: a training step can run it at forward time, off the
+// backward's critical path); -1 when the shape has no packed path
+int r3k_fr_backward_prepare(const float* boxes, int N, int H, int W, float scale, void* ws, size_t ws_bytes,
+                            hipStream_t stream) {
+  const size_t need = r3k_fr_backward_workspace_bytes(N, H, W, 1);
+  if (need == 0 || !boxes || !ws || !aligned16(ws)) return -1;
+  if (ws_bytes < need) return -3;
+  static bool once = (allow_big_lds(fr_bwd_pack_kernel<7, 7>, 160 * 1024), true);
+  (void)once;
+  char* table = static_cast<char*>(ws);
+  if (W == 128) {
+    using P = FrPack<7, 7>;
+    hipLaunchKernelGGL((fr_bwd_pack_kernel<7, 7>), dim3(N), dim3(1024), P::PACK_LDS_INTS * sizeof(int), stream, boxes,
+                       scale, table);
+    hipLaunchKernelGGL((fr_bwd_place_kernel<7, 7>), dim3(P::HW / 256, N), dim3(256), 0, stream, boxes, scale, table);
+  } else {
+    using P = FrPack<6, 6>;
+    hipLaunchKernelGGL((fr_bwd_pack_kernel<6, 6>), dim3(N), dim3(1024), P::PACK_LDS_INTS * sizeof(int), stream, boxes,
+                       scale, table);
+    hipLaunchKernelGGL((fr_bwd_place_kernel<6, 6>), dim3(P::HW / 256, N), dim3(256), 0, stream, boxes, scale, table);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// table_ready: ws already holds the packing of these boxes (r3k_fr_backward_prepare); the call
+// then fails with -1 instead of taking a path that would ignore it
 int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W,
                     float scale, int points, float* bottom_grad, int overwrite, void* ws, size_t ws_bytes,
-                    hipStream_t stream) {
+                    int table_ready, hipStream_t stream) {
   if (points != 1 && points != 5) return -1;
   if (N == 0 || C == 0 || H == 0 || W == 0) return 0;
   int cpb = plane_cpb(C, H, W);
@@ -1227,7 +1253,7 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
                           allow_big_lds(fr_backward_cell<7, 7, 1024, 2>, 160 * 1024),
                           allow_big_lds(fr_backward_cell<7, 7, 1024, 3>, 160 * 1024),
                           allow_big_lds(fr_backward_packed<7, 7>, 160 * 1024),
-                          allow_big_lds(fr_bwd_pack_kernel<7, 7>, 160 * 1024), true);
+                          true);
       (void)once;
       const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
       const dim3 grid(N * C / G), block(1024);
@@ -1236,21 +1262,18 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
       if (ws && ws_bytes >= r3k_fr_backward_workspace_bytes(N, H, W, points) && aligned16(ws) &&
           g_r3_fr_impl == 0 && g_r3_fr_dbg == 0) {
         char* table = static_cast<char*>(ws);
-        if (W == 128) {
-          using P = FrPack<7, 7>;
-          hipLaunchKernelGGL((fr_bwd_pack_kernel<7, 7>), dim3(N), block, P::PACK_LDS_INTS * sizeof(int), stream, boxes,
-                             scale, table);
-          hipLaunchKernelGGL((fr_bwd_place_kernel<7, 7>), dim3(P::HW / 256, N), dim3(256), 0, stream, boxes, scale, table);
+        if (!table_ready) {
+          const int rc = r3k_fr_backward_prepare(boxes, N, H, W, scale, ws, ws_bytes, stream);
+          if (rc) return rc;
+        }
+        if (W == 128)
           hipLaunchKernelGGL((fr_backward_packed<7, 7>), grid, block, lds, stream, top_grad, table, boxes, scale, C, G,
                              bottom_grad);
-        } else {
-          using P = FrPack<6, 6>;
-          hipLaunchKernelGGL((fr_bwd_pack_kernel<6, 6>), dim3(N), block, P::PACK_LDS_INTS * sizeof(int), stream, boxes,
-                             scale, table);
-          hipLaunchKernelGGL((fr_bwd_place_kernel<6, 6>), dim3(P::HW / 256, N), dim3(256), 0, stream, boxes, scale, table);
+        else
           hipLaunchKernelGGL((fr_backward_packed<6, 6>), grid, block, lds, stream, top_grad, table, boxes, scale, C, G,
                              bottom_grad);
-        }
+      } else if (table_ready) {
+        return -1;
       } else if (W == 128 && g_r3_fr_dbg >= 11 && g_r3_fr_dbg <= 13) {  // probes (wrong results)
         if (g_r3_fr_dbg == 11) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 1>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad);
         if (g_r3_fr_dbg == 12) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 2>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad);
@@ -1264,6 +1287,7 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
       return hipGetLastError() == hipSuccess ? 0 : -2;
     }
   }
+  if (table_ready) return -1;  // (no packed path for this call)
   if (plane) {
     while (cpb > 1 && (size_t)N * ((C + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
     dim3 grid((C + cpb - 1) / cpb, N);

@@ -51,7 +51,10 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
 size_t r3k_fr_backward_workspace_bytes(int N, int H, int W, int points);
 int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W,
                     float scale, int points, float* bottom_grad, int overwrite, void* ws, size_t ws_bytes,
-                    hipStream_t stream);
+                    int table_ready, hipStream_t stream);
+// the packing of the boxes alone (then r3k_fr_backward(..., table_ready = 1))
+int r3k_fr_backward_prepare(const float* boxes, int N, int H, int W, float scale, void* ws, size_t ws_bytes,
+                            hipStream_t stream);
 
 // polygon ops outside the shipped configs (r3_poly.hip)
 int r3k_nms_reduce_dense(const unsigned long long* mask, int n, int cb, const int64_t* order, int64_t* keep_out,

@@ -40,6 +40,8 @@ SIGNATURES = {
     "r3det_feature_refine_forward_prepared": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "r3det_feature_refine_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "r3det_feature_refine_backward_ws": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _sz, _vp],
+    "r3det_feature_refine_backward_prepare": [_vp, _i, _i, _i, _f, _vp, _sz, _vp],
+    "r3det_feature_refine_backward_prepared": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp],
     "r3det_set_option": [ctypes.c_char_p, _i],
     "r3det_fr_profile_read": [_vp, _i],
 }

@@ -88,6 +88,57 @@ def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, over
     return 1
 
 
+_pack_streams = {}
+# Sort the backward's positions at forward time on a side stream (split form of the packed backward).
+# Off by default: measured on one MI355X (tools/fr_train_probe.py) the step is 4 us shorter when 3.7 ms
+# of GEMMs sit between the sampler's forward and backward (the pack kernels take 4 CUs from them) and
+# 35 us LONGER when nothing does (events + stream switches on the host).
+PACK_AT_FORWARD = False
+
+
+def fr_backward_prepare_async(best_rbboxes, N, H, W, spatial_scale):
+    """The backward's sort of the positions (r3det_feature_refine_backward_prepare) launched on a side
+    stream as soon as the boxes exist: it depends on the boxes only, so a training step gets it off
+    the backward's critical path.  Returns (workspace, event) or None when the shape has no packed
+    backward."""
+    L = _C.lib()
+    wsb = int(L.r3det_fr_backward_workspace_bytes(N, H, W, 1))
+    if wsb == 0:
+        return None
+    b = _C.need_hip(best_rbboxes, "best_bboxes")
+    dev = b.device
+    with torch.cuda.device(dev):
+        side = _pack_streams.get(dev.index)
+        if side is None:
+            side = _pack_streams[dev.index] = torch.cuda.Stream(device=dev)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))  # the boxes are produced on the current stream
+        import ctypes
+        rc = L.r3det_feature_refine_backward_prepare(_C.ptr(b), N, H, W, float(spatial_scale), _C.ptr(ws), wsb,
+                                                     ctypes.c_void_p(side.cuda_stream))
+        if rc != 0:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(side)
+        ws.record_stream(side)
+        b.record_stream(side)
+    return ws, ev
+
+
+def fr_backward_prepared(top_grad, best_rbboxes, spatial_scale, bottom_grad, pack):
+    """Backward accumulate alone on a packing made by ``fr_backward_prepare_async``; False when the
+    library does not take this call in the split form (nothing was launched)."""
+    ws, ev = pack
+    g = _C.need_hip(top_grad, "top_grad")
+    N, C, H, W = g.shape
+    with torch.cuda.device(g.device):
+        torch.cuda.current_stream(g.device).wait_event(ev)
+        rc = _C.lib().r3det_feature_refine_backward_prepared(_C.ptr(g), _C.ptr(best_rbboxes), N, C, H, W,
+                                                             float(spatial_scale), _C.ptr(bottom_grad), _C.ptr(ws),
+                                                             ws.numel(), _C.stream())
+    return rc == 0
+
+
 class FeatureRefineFunction(Function):
     """autograd wrapper (feature_refine_module.py:10-40); no gradient flows to the boxes."""
 
@@ -102,6 +153,11 @@ class FeatureRefineFunction(Function):
         output = torch.empty_like(features)  # the kernel overwrites every element
         if table is None or not fr_forward_prepared(features, table, output):
             fr_forward(features, best_rbboxes.contiguous(), spatial_scale, points, output)
+        ctx.pack = None
+        if PACK_AT_FORWARD and points == 1 and ctx.needs_input_grad[0]:
+            N, _, H, W = features.shape
+            ctx.boxes_c = best_rbboxes.contiguous()
+            ctx.pack = fr_backward_prepare_async(ctx.boxes_c, N, H, W, spatial_scale)
         return output
 
     @staticmethod
@@ -113,8 +169,10 @@ class FeatureRefineFunction(Function):
         if ctx.needs_input_grad[0]:
             grad_output = grad_output.contiguous()
             grad_input = torch.empty_like(grad_output)
-            fr_backward(grad_output, best_rbboxes.contiguous(), ctx.spatial_scale, ctx.points, grad_input,
-                        overwrite=True)
+            if ctx.pack is None or not fr_backward_prepared(grad_output, ctx.boxes_c, ctx.spatial_scale, grad_input,
+                                                            ctx.pack):
+                fr_backward(grad_output, best_rbboxes.contiguous(), ctx.spatial_scale, ctx.points, grad_input,
+                            overwrite=True)
         return grad_input, None, None, None, None
 
 

@@ -237,3 +237,36 @@ def test_backward_ws_too_small_or_absent_uses_the_atomic_kernel():
                                                     ws_ptr, ws_bytes, _C.stream()), "bwd")
         assert np.abs(g[:, :4].cpu().numpy() - want).max() <= tol
     assert bool((guard == 7).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 128, 128, 8), (2, 512, 64, 64, 16), (1, 8, 64, 64, 16), (2, 16, 32, 32, 32)])
+def test_autograd_backward_uses_packing_from_forward(shape):
+    """With PACK_AT_FORWARD feature_refine(x.requires_grad) sorts the positions on a side stream during the
+    forward and the backward consumes that workspace (split form); shapes / channel counts without a packed path
+    fall back inside the same function.  Gradient against the oracle either way."""
+    import sys
+    from r3det.ops.feature_refine import feature_refine
+    monkey = sys.modules['r3det.ops.feature_refine']
+    N, C, H, W, stride = shape
+    monkey.PACK_AT_FORWARD = True
+    try:
+        _autograd_with_packing(feature_refine, N, C, H, W, stride)
+    finally:
+        monkey.PACK_AT_FORWARD = False
+
+
+def _autograd_with_packing(feature_refine, N, C, H, W, stride):
+    r = np.random.default_rng(5)
+    x = dev(r.normal(size=(N, C, H, W)).astype(np.float32)).requires_grad_(True)
+    top = r.normal(size=(N, C, H, W)).astype(np.float32)
+    boxes = fr_boxes(N, H, W, stride, 9)
+    y = feature_refine(x, dev(boxes), 1 / stride, 1)
+    expect_pack = (H, W) in ((128, 128), (64, 64))
+    assert (y.grad_fn.pack is not None) == expect_pack
+    y.backward(dev(top))
+    with O.twin():
+        want = O.fr_backward(top[:, :4], boxes, 1 / stride, 1)
+    assert np.abs(x.grad[:, :4].cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    # no gradient wanted: no packing
+    y2 = feature_refine(x.detach(), dev(boxes), 1 / stride, 1)
+    assert y2.grad_fn is None and torch.equal(y2, y.detach())
