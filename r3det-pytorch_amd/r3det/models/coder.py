@@ -5,12 +5,24 @@ import math
 import torch
 
 
+_consts = {}
+
+
+def _const(like, values):
+    """means / stds as a device tensor, made once per (device, dtype, values): a host-to-device copy per
+    call would also keep the decoding out of a HIP graph capture."""
+    key = (like.device, like.dtype, tuple(float(v) for v in values))
+    t = _consts.get(key)
+    if t is None:
+        t = _consts[key] = like.new_tensor(values)
+    return t
+
+
 def delta2bbox_v1(rois, deltas, means=(0., 0., 0., 0., 0.), stds=(1., 1., 1., 1., 1.), max_shape=None,
                   wh_ratio_clip=16 / 1000):
     """rois (..., 5), deltas (..., 5) -> boxes (..., 5); dw/dh clamped to |log(wh_ratio_clip)|,
     centres clamped to the image when max_shape=(H, W) is given (:142-211)."""
-    m = deltas.new_tensor(means)
-    s = deltas.new_tensor(stds)
+    m, s = _const(deltas, means), _const(deltas, stds)
     d = deltas * s + m
     max_ratio = abs(math.log(wh_ratio_clip))
     dw = d[..., 2].clamp(min=-max_ratio, max=max_ratio)

@@ -3,6 +3,7 @@ rretinanet.py:23-46)."""
 import torch
 import torch.nn as nn
 
+from ..core.post_processing import multiclass_nms_rotated_batch
 from ..ops import FeatureRefineModule
 from .backbone import FPN, ResNet50
 from .heads import RRetinaHead, RRetinaRefineHead
@@ -52,6 +53,15 @@ class R3Det(nn.Module):
 
     @torch.no_grad()
     def simple_test(self, img):
+        boxes, scores = self.dense_test(img)
+        cfg = self.test_cfg
+        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+
+    @torch.no_grad()
+    def dense_test(self, img):
+        """Network + box decoding: every shape is static and nothing synchronises with the host, so the
+        whole of it can be captured in a HIP graph (GraphedDense); the NMS that follows is not (its
+        workspace is sized from the candidate counts)."""
         x = self.extract_feat(img)
         cls, reg = self.bbox_head(x)
         rois = self.bbox_head.filter_bboxes(cls, reg)
@@ -60,7 +70,43 @@ class R3Det(nn.Module):
             cls, reg = self.refine_head[i](x_refine)
             if i + 1 < self.num_refine_stages:
                 rois = self.refine_head[i].refine_bboxes(cls, reg, rois)
-        return self.refine_head[-1].get_bboxes(cls, reg, img.shape[-2:], self.test_cfg, rois=rois)
+        return self.refine_head[-1].decode_bboxes(cls, reg, img.shape[-2:], self.test_cfg, rois=rois)
+
+
+class GraphedDense:
+    """``model.dense_test(img)`` captured once in a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm)
+    and replayed per step: the ~330 launches of backbone, neck, heads, FRM and the custom ops
+    (r3det_filter_bboxes, r3det_feature_refine_*: they enqueue on the current stream, so stream capture
+    records them) become one graph launch.  Input and outputs live in static buffers; shapes are fixed
+    at capture.  Warm-up runs first so that MIOpen's algorithm search and the library's one-time
+    attribute calls happen outside the capture."""
+
+    def __init__(self, model, example, warmup=3):
+        self.model = model
+        self.static_in = example.clone(memory_format=torch.preserve_format)
+        side = torch.cuda.Stream(device=example.device)
+        side.wait_stream(torch.cuda.current_stream(example.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                model.dense_test(self.static_in)
+        torch.cuda.current_stream(example.device).wait_stream(side)
+        torch.cuda.synchronize(example.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = model.dense_test(self.static_in)
+
+    @torch.no_grad()
+    def __call__(self, img):
+        if img.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(img)
+        self.graph.replay()
+        return self.static_out
+
+    @torch.no_grad()
+    def simple_test(self, img):
+        boxes, scores = self(img)
+        cfg = self.model.test_cfg
+        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
 
 
 def build_detector(cfg):

@@ -122,6 +122,14 @@ class RRetinaHead(nn.Module):
         """rotate_anchor_head.py:499-675 (+ the refine head's rois-as-anchors variant,
         rotate_retina_refine_head.py:147-196).  Returns [(dets (k,6), labels (k,))] per image."""
         cfg = cfg or self.test_cfg
+        boxes, scores = self.decode_bboxes(cls_scores, bbox_preds, img_shape, cfg, rois)
+        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+
+    def decode_bboxes(self, cls_scores, bbox_preds, img_shape, cfg=None, rois=None):
+        """The shape-static part of get_bboxes (everything before the NMS, whose sizes depend on the
+        scores): (N, n, 5) boxes and (N, n, C + 1) scores.  No host synchronisation: capturable in a
+        HIP graph together with the network."""
+        cfg = cfg or self.test_cfg
         N = cls_scores[0].size(0)
         A, C = self.num_anchors, self.cls_out_channels
         if rois is None:
@@ -144,7 +152,7 @@ class RRetinaHead(nn.Module):
         boxes = torch.cat(boxes_l, 1)
         scores = torch.cat(scores_l, 1)
         scores = torch.cat([scores, scores.new_zeros(N, scores.shape[1], 1)], 2)  # dummy background
-        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+        return boxes, scores
 
 
 class RRetinaRefineHead(RRetinaHead):

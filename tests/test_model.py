@@ -237,3 +237,25 @@ def test_fused_inference_model_gpu(channels_last):
                     ref = ref.relu()
                 out = bias_act_(y.clone(memory_format=torch.preserve_format), b, res, relu)
                 assert torch.equal(out, ref)
+
+
+@pytest.mark.gpu
+def test_dense_part_captures_into_a_hip_graph():
+    """Network + decoding (R3Det.dense_test) has static shapes and no host synchronisation: it must
+    stay capturable (the custom ops enqueue on the capturing stream, nothing copies from the host),
+    and the replayed graph must give the eager result up to the convolutions' own run-to-run noise."""
+    from r3det.models import R3Det
+    from r3det.models.detectors import GraphedDense, calibrate_score_bias
+    torch.manual_seed(11)
+    dev = torch.device('cuda')
+    m = R3Det().eval().to(dev)
+    img = torch.randn(2, 3, 256, 256, device=dev)
+    calibrate_score_bias(m, img, frac=0.02)
+    boxes, scores = m.dense_test(img)
+    g = GraphedDense(m, img)
+    for trial in range(2):
+        gb, gs = g(img if trial == 0 else img.clone())
+        assert gb.shape == boxes.shape and gs.shape == scores.shape
+        assert torch.allclose(gs, scores, atol=1e-4) and torch.allclose(gb, boxes, rtol=1e-3, atol=1e-2)
+    res = g.simple_test(img)
+    assert len(res) == 2 and all(d.size(1) == 6 and d.size(0) > 0 for d, _ in res)
