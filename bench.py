@@ -88,10 +88,9 @@ def build_hot_workload(device, seed):
 
 def hot_path_step(wl):
     from r3det.core.post_processing import multiclass_nms_rotated_batch
-    from r3det.ops.feature_refine import fr_forward
+    from r3det.ops.feature_refine import fr_forward_levels
     from r3det.synthetic import STRIDES
-    for f, b, o, s in zip(wl["feats"], wl["boxes"], wl["outs"], STRIDES):
-        fr_forward(f, b, 1.0 / s, 1, o)
+    fr_forward_levels(wl["feats"], wl["boxes"], [1.0 / s for s in STRIDES], 1, wl["outs"])
     res = multiclass_nms_rotated_batch(wl["pool_boxes"], wl["pool_scores"], SCORE_THR, NMS_CFG, MAX_PER_IMG)
     return sum(d.size(0) for d, _ in res)
 

@@ -217,6 +217,16 @@ int r3det_feature_refine_prepare(const float* best_bboxes, int N, int H, int W, 
 int r3det_feature_refine_forward_prepared(const float* features, const float* table, int N, int C, int H, int W,
                                           float* output, void* stream);
 
+/* The per-level loop of FeatureRefineModule.forward (fr/feature_refine_module.py:115-127) in one call:
+ * `levels` sampler launches enqueued back to back (from Python each level costs ~10 us of host time, more
+ * than the kernels of the three coarse levels).  features / best_bboxes / outputs: HOST arrays of `levels`
+ * device pointers; H, W, spatial_scales: host arrays; N, C, points common to the levels.  ws: one block of
+ * r3det_fr_levels_workspace_bytes() bytes (or NULL), carved per level as by r3det_feature_refine_forward. */
+size_t r3det_fr_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points);
+int r3det_feature_refine_forward_levels(int levels, const float* const* features, const float* const* best_bboxes,
+                                        int N, int C, const int* H, const int* W, const float* spatial_scales,
+                                        int points, float* const* outputs, void* ws, size_t ws_bytes, void* stream);
+
 /* feature_refine_cuda.backward(top_grad, best_bboxes, spatial_scale, points, bottom_grad)
  *                                                      fr/src/feature_refine_cuda.cpp:44-66
  * kernel feature_refine_kernel.cu:165-230.  Accumulates into bottom_grad (the reference caller

@@ -176,6 +176,29 @@ int r3det_feature_refine_forward_prepared(const float* features, const float* ta
   return rc(r3k_fr_forward_prepared(features, table, N, C, H, W, output, S(stream)));
 }
 
+size_t r3det_fr_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points) {
+  size_t total = 0;
+  for (int l = 0; l < levels; l++) total += r3k_fr_workspace_bytes(N, H[l], W[l], points);
+  return total;
+}
+
+int r3det_feature_refine_forward_levels(int levels, const float* const* features, const float* const* best_bboxes,
+                                        int N, int C, const int* H, const int* W, const float* spatial_scales,
+                                        int points, float* const* outputs, void* ws, size_t ws_bytes, void* stream) {
+  if (levels < 0 || N < 0 || C < 0 || (levels > 0 && (!features || !best_bboxes || !H || !W || !spatial_scales || !outputs)))
+    return R3DET_EINVAL;
+  if (ws && ws_bytes < r3det_fr_levels_workspace_bytes(levels, N, H, W, points)) return R3DET_EWS;
+  char* p = static_cast<char*>(ws);
+  for (int l = 0; l < levels; l++) {
+    const size_t part = r3k_fr_workspace_bytes(N, H[l], W[l], points);
+    const int k = r3det_feature_refine_forward(features[l], best_bboxes[l], N, C, H[l], W[l], spatial_scales[l], points,
+                                               outputs[l], p, p ? part : 0, stream);
+    if (k != R3DET_OK) return k;
+    if (p) p += part;
+  }
+  return R3DET_OK;
+}
+
 int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxes, int N, int C,
                                   int H, int W, float spatial_scale, int points,
                                   float* bottom_grad, int overwrite, void* stream) {

@@ -42,6 +42,32 @@ def fr_forward(features, best_rbboxes, spatial_scale, points, output):
     return 1
 
 
+def fr_forward_levels(features, best_rbboxes, spatial_scales, points, outputs):
+    """The samplers of all pyramid levels in one library call (r3det_feature_refine_forward_levels):
+    lists over levels of (N,C,H,W) features / outputs and (N*H*W, 5) boxes."""
+    import ctypes
+    n = len(features)
+    fs = [_C.need_hip(f, "features") for f in features]
+    bs = [_C.need_hip(b, "best_bboxes") for b in best_rbboxes]
+    os_ = [_C.need_hip(o, "output") for o in outputs]
+    N, C = fs[0].shape[:2]
+    for f, b in zip(fs, bs):
+        if f.size(0) != N or f.size(1) != C or b.numel() != N * f.size(2) * f.size(3) * 5:
+            raise RuntimeError("levels must share N and C and bring N*H*W x 5 boxes each")
+    arr_p = ctypes.c_void_p * n
+    arr_i = ctypes.c_int * n
+    H, W = arr_i(*[f.size(2) for f in fs]), arr_i(*[f.size(3) for f in fs])
+    sc = (ctypes.c_float * n)(*[float(s) for s in spatial_scales])
+    L = _C.lib()
+    with torch.cuda.device(fs[0].device):
+        wsb = int(L.r3det_fr_levels_workspace_bytes(n, N, H, W, int(points)))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=fs[0].device)
+        _C.check(L.r3det_feature_refine_forward_levels(
+            n, arr_p(*[f.data_ptr() for f in fs]), arr_p(*[b.data_ptr() for b in bs]), N, C, H, W, sc, int(points),
+            arr_p(*[o.data_ptr() for o in os_]), _C.ptr(ws), wsb, _C.stream()), "fr_forward_levels")
+    return 1
+
+
 def fr_prepare(best_rbboxes, N, H, W, spatial_scale, points=1):
     """Tap table of one level for ``fr_forward_prepared`` (r3det_feature_refine_prepare), or None
     when the level has no split form (then use ``fr_forward``)."""

@@ -270,3 +270,21 @@ def _autograd_with_packing(feature_refine, N, C, H, W, stride):
     # no gradient wanted: no packing
     y2 = feature_refine(x.detach(), dev(boxes), 1 / stride, 1)
     assert y2.grad_fn is None and torch.equal(y2, y.detach())
+
+
+@pytest.mark.parametrize("points", [1, 5])
+def test_forward_levels_equals_per_level_calls(points):
+    """r3det_feature_refine_forward_levels = the module's per-level loop: bit-identical outputs."""
+    from r3det import synthetic as syn
+    from r3det.ops.feature_refine import fr_forward, fr_forward_levels
+    N, C = 2, 16
+    feats, boxes = syn.fr_pyramid(N, C, 3, device='cuda')
+    scales = [1.0 / s for s in syn.STRIDES]
+    outs = [torch.full_like(f, float('nan')) for f in feats]
+    fr_forward_levels(feats, boxes, scales, points, outs)
+    for f, b, s, o in zip(feats, boxes, scales, outs):
+        want = torch.empty_like(f)
+        fr_forward(f, b, s, points, want)
+        assert torch.equal(o, want)
+    with pytest.raises(RuntimeError):
+        fr_forward_levels(feats, boxes[::-1], scales, points, outs)

@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 from r3det.core.post_processing import multiclass_nms_rotated, multiclass_nms_rotated_batch  # noqa: E402
-from r3det.ops.feature_refine import fr_forward  # noqa: E402
+from r3det.ops.feature_refine import fr_forward, fr_forward_levels  # noqa: E402
 from r3det.synthetic import STRIDES  # noqa: E402
 
 wl = bench.build_hot_workload(torch.device("cuda"), 7)
@@ -22,6 +22,10 @@ def fr():
         fr_forward(f, b, 1.0 / s, 1, o)
 
 
+def fr_levels():
+    fr_forward_levels(wl["feats"], wl["boxes"], [1.0 / s for s in STRIDES], 1, wl["outs"])
+
+
 def nms_per_image():
     for i in range(pb.size(0)):
         multiclass_nms_rotated(pb[i], ps[i], 0.05, dict(iou_thr=0.1), 2000)
@@ -31,6 +35,6 @@ def nms_batched():
     multiclass_nms_rotated_batch(pb, ps, 0.05, dict(iou_thr=0.1), 2000)
 
 
-for name, fn in (("fr x5 levels", fr), ("nms per image x4", nms_per_image), ("nms batched", nms_batched),
+for name, fn in (("fr x5 levels", fr), ("fr levels call", fr_levels), ("nms per image x4", nms_per_image), ("nms batched", nms_batched),
                  ("hot path", lambda: bench.hot_path_step(wl))):
     print(f"{name:18s} {bench.timeit(fn, 20, 3) * 1e3:8.3f} ms")
