@@ -150,7 +150,9 @@ int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes,
  *       cand_row / cand_label / cand_rank (int32) and cand_score, each (B, n*K) [cand_rank is
  *       scratch of the second call, which zeroes what it uses]; counts (B) int32, maxc (B) = max over the
  *       candidate boxes' five columns.  ws: r3det_mcnms_select_workspace_bytes(B, n).
- *   r3det_mcnms_v1 : cap >= max(counts), < 65536.  Per image: stable descending score sort,
+ *   r3det_mcnms_v1 : cap >= max(counts), < 65536 (an image with more candidates is processed as its
+ *       first cap candidates -- never out of bounds -- so a caller may guess cap, read counts
+ *       afterwards and call again when the guess was short).  Per image: stable descending score sort,
  *       x, y += label * (maxc + 1), NMS v1 (IoU > iou_thr), keep ASCENDING by candidate
  *       index, first out_cap of them.  dets_out (B,out_cap,6) = [box, score], labels_out
  *       (B,out_cap) int64, keep_idx_out (B,out_cap) int64 = the kept candidate indices (may be

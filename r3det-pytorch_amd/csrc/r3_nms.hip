@@ -751,6 +751,13 @@ __global__ __launch_bounds__(SEL_T) void mc_write_kernel(const float* __restrict
   }
 }
 
+__global__ __launch_bounds__(256) void mc_begin_kernel(const int* __restrict__ counts, int cap, int cand_stride,
+                                                       int* __restrict__ cand_rank, int* __restrict__ ccounts) {
+  const int img = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0) ccounts[img] = min(counts[img], cap);
+  if (c < cap && c < cand_stride) cand_rank[(size_t)img * cand_stride + c] = 0;
+}
+
 // Stable descending sort of an image's candidates by COUNTING: rank(i) = #{j : s_j > s_i or
 // (s_j == s_i and j < i)} = position of i under torch.sort(descending=True, stable=True).
 // O(M^2) compares, but spread over the chip in one launch with device-side M (M = 3 k: ~5 us,
@@ -1003,6 +1010,7 @@ struct McLayout {
   uint8_t* flags;
   uint8_t* dead;
   float* extent;
+  int* ccounts;
   size_t qcap, zero_bytes;
   int cb, nzw;
 };
@@ -1023,10 +1031,11 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* flags = take((size_t)B * cap);
   char* dead = take((size_t)B * cap);
   char* extent = take((size_t)B * 4);
+  char* ccounts = take((size_t)B * 4);
   if (L) {
     L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
     L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->keep = (int64_t*)keep;
-    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->extent = (float*)extent;
+    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
     L->qcap = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb; L->nzw = (int)nzw;
     if (g_r3_nms_qcap > 0 && (size_t)g_r3_nms_qcap < L->qcap) L->qcap = (size_t)g_r3_nms_qcap;
   }
@@ -1079,13 +1088,15 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   McLayout L;
   mc_layout(B, cap, ws, &L);
   const size_t cbq = (size_t)L.cb;
-  Batch bt{counts, (size_t)cap, (size_t)cap * cbq, nz_side_words((size_t)cap, L.nzw), 64, L.qcap, (size_t)cap,
+  Batch bt{L.ccounts, (size_t)cap, (size_t)cap * cbq, nz_side_words((size_t)cap, L.nzw), 64, L.qcap, (size_t)cap,
            (size_t)cap};
-  // the rank kernel accumulates into cand_rank: zeroed here so that a caller's stale scratch cannot
-  // send records out of bounds (cap <= S: the first cap entries of each image's row)
-  if (hipMemset2DAsync(cand_rank, (size_t)S * sizeof(int), 0, (size_t)(cap < S ? cap : S) * sizeof(int), B, stream) !=
-      hipSuccess)
-    return -2;
+  // the rank kernel accumulates into cand_rank: zeroed here so that a caller's stale scratch cannot send
+  // records out of bounds; and the counts are clamped to cap for the same reason (an image with more
+  // candidates than cap is processed as its first cap candidates: the caller sizes cap from the counts,
+  // or checks them afterwards and calls again)
+  hipLaunchKernelGGL(mc_begin_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, stream, counts, cap, S, cand_rank,
+                     L.ccounts);
+  counts = L.ccounts;
   hipLaunchKernelGGL(mc_rank_kernel, dim3((cap + RK_T - 1) / RK_T, (cap + RK_J - 1) / RK_J, B), dim3(RK_T), 0, stream,
                      cand_score, S, counts, cand_rank);
   const dim3 pgrid((cap + 255) / 256, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);

@@ -9,6 +9,9 @@ from ... import _C
 from ...ops import batched_rnms, ml_nms_rotated, nms_rotated, obb_batched_nms
 
 
+_last_max = {}  # (device, B, n, K) -> largest candidate count of the last call: next call's workspace guess
+
+
 def _get(nms, key):
     return nms[key] if isinstance(nms, dict) else getattr(nms, key)
 
@@ -78,8 +81,9 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
     results.  nms types 'v1', 'v2' and 'v3' run as ONE pass of launches over all images
     (r3det_mcnms_select / r3det_mcnms in include/r3det_hip.h: threshold + ordered compaction,
     stable score sort, class offsets or label guard, suppression, keep order and the max_num cut
-    on the device; the host reads the per-image candidate counts once in the middle and the
-    per-image detection counts at the end).  'mmcv' takes the per-image path."""
+    on the device; the host reads the per-image candidate counts -- in the middle the first time a
+    shape is seen, afterwards together with the per-image detection counts at the end).  'mmcv' takes
+    the per-image path."""
     B, n = multi_scores.shape[:2]
     K = multi_scores.size(2) - 1
     version = nms.get('type', 'v1')
@@ -106,24 +110,45 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
         _C.check(L.r3det_mcnms_select(_C.ptr(boxes), _C.ptr(scores), B, n, K, float(score_thr), _C.ptr(cand_row),
                                       _C.ptr(cand_label), _C.ptr(cand_score), _C.ptr(cand_rank), _C.ptr(counts),
                                       _C.ptr(maxc), _C.ptr(sel_ws), sel_bytes, _C.stream()), "r3det_mcnms_select")
-        m = int(counts.max().item())  # sizes the suppression workspace
-        if m == 0:
-            return [(multi_bboxes.new_zeros((0, 6)), multi_bboxes.new_zeros((0, ), dtype=torch.long))
-                    for _ in range(B)]
-        if m >= 65536:  # beyond the pair-queue encoding: per-image operators
-            return [multiclass_nms_rotated(multi_bboxes[i], multi_scores[i], score_thr, nms, max_num)
-                    for i in range(B)]
-        cap = (m + 63) // 64 * 64
-        out_cap = max_num if max_num > 0 else cap
-        ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, cap))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        dets = torch.empty((B, out_cap, 6), dtype=torch.float32, device=dev)
-        labels = torch.empty((B, out_cap), dtype=torch.int64, device=dev)
-        kept = torch.empty(B, dtype=torch.int32, device=dev)
-        _C.check(L.r3det_mcnms(geom, _C.ptr(boxes), B, n, K, _C.ptr(cand_row), _C.ptr(cand_label), _C.ptr(cand_score),
-                               _C.ptr(cand_rank), _C.ptr(counts), _C.ptr(maxc), cap, iou_thr, out_cap, _C.ptr(ws), ws_bytes,
-                               _C.ptr(dets), _C.ptr(labels), None, _C.ptr(kept), _C.stream()), "r3det_mcnms")
-        kept = kept.tolist()
+        # cap (>= the largest candidate count) sizes the suppression workspace.  Reading the counts here
+        # costs a host synchronisation in the middle of the pipeline; once a shape has been seen, cap is
+        # guessed from its last counts instead and the counts come back together with the results (the
+        # library clamps an image to cap candidates, so a wrong guess is detected and redone, never unsafe).
+        key = (dev, B, n, K)
+        last = _last_max.get(key)
+        guess = last is not None
+        if guess:
+            cap = min(65472, max(1024, (int(last * 1.3) + 63) // 64 * 64))
+        for _ in (0, 1):
+            if not guess:
+                m = int(counts.max().item())
+                _last_max[key] = m
+                if m == 0:
+                    return [(multi_bboxes.new_zeros((0, 6)), multi_bboxes.new_zeros((0, ), dtype=torch.long))
+                            for _ in range(B)]
+                if m >= 65536:  # beyond the pair-queue encoding: per-image operators
+                    return [multiclass_nms_rotated(multi_bboxes[i], multi_scores[i], score_thr, nms, max_num)
+                            for i in range(B)]
+                cap = (m + 63) // 64 * 64
+            out_cap = max_num if max_num > 0 else cap
+            ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, cap))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            dets = torch.empty((B, out_cap, 6), dtype=torch.float32, device=dev)
+            labels = torch.empty((B, out_cap), dtype=torch.int64, device=dev)
+            kept = torch.empty(B, dtype=torch.int32, device=dev)
+            _C.check(L.r3det_mcnms(geom, _C.ptr(boxes), B, n, K, _C.ptr(cand_row), _C.ptr(cand_label),
+                                   _C.ptr(cand_score), _C.ptr(cand_rank), _C.ptr(counts), _C.ptr(maxc), cap, iou_thr,
+                                   out_cap, _C.ptr(ws), ws_bytes, _C.ptr(dets), _C.ptr(labels), None, _C.ptr(kept),
+                                   _C.stream()), "r3det_mcnms")
+            if not guess:
+                kept = kept.tolist()
+                break
+            both = torch.cat([kept, counts]).tolist()  # the one host read of the guessed run
+            kept, m = both[:B], max(both[B:])
+            _last_max[key] = m
+            if m <= cap:
+                break
+            guess = False  # more candidates than guessed: once more with the exact size
         if geom == 2 and max_num <= 0:  # the reference's v2 branch slices [:max_num] whenever kept > max_num (:63-65)
             kept = [max(k + max_num, 0) if max_num < 0 else 0 for k in kept]
     return [(dets[i, :kept[i]], labels[i, :kept[i]]) for i in range(B)]

@@ -160,3 +160,19 @@ def test_mcnms_argument_errors():
         assert call(t, mx, wsb) == 0
         torch.cuda.synchronize()
         assert 0 < int(kept[0]) <= n
+
+
+def test_guessed_workspace_size_is_checked_and_redone(nms_type):
+    """After the first call of a shape the workspace size is guessed from the previous counts and the
+    counts are read at the end: a batch with 9 x more candidates than the last one must come out right
+    (the library clamps to the guessed capacity, the wrapper notices and runs again), and so must a
+    much smaller one."""
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    cfg = dict(type=nms_type, iou_thr=0.1)
+    boxes, scores = pools(2, 1200, 41)
+    few = scores.clone()
+    few[:, 100:] = 0.0
+    many = scores.clone()
+    many[:, :, :-1] = many[:, :, :-1].clamp(min=0.06)
+    for s in (few, many, few, scores, many):
+        same(multiclass_nms_rotated_batch(boxes, s, 0.05, cfg, 300), boxes, s, 0.05, cfg, 300)
