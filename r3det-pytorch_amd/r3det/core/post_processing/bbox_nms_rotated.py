@@ -105,20 +105,31 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
         cand_rank = torch.empty((B, S), dtype=torch.int32, device=dev)
         sel_bytes = int(L.r3det_mcnms_select_workspace_bytes(B, n))
         sel_ws = torch.empty(sel_bytes, dtype=torch.uint8, device=dev)
-        counts = torch.empty(B, dtype=torch.int32, device=dev)
+        kc = torch.empty(2 * B, dtype=torch.int32, device=dev)  # [detections kept | candidate counts]: one host read
+        kept_d, counts = kc[:B], kc[B:]
         maxc = torch.empty(B, dtype=torch.float32, device=dev)
-        _C.check(L.r3det_mcnms_select(_C.ptr(boxes), _C.ptr(scores), B, n, K, float(score_thr), _C.ptr(cand_row),
-                                      _C.ptr(cand_label), _C.ptr(cand_score), _C.ptr(cand_rank), _C.ptr(counts),
-                                      _C.ptr(maxc), _C.ptr(sel_ws), sel_bytes, _C.stream()), "r3det_mcnms_select")
-        # cap (>= the largest candidate count) sizes the suppression workspace.  Reading the counts here
-        # costs a host synchronisation in the middle of the pipeline; once a shape has been seen, cap is
-        # guessed from its last counts instead and the counts come back together with the results (the
-        # library clamps an image to cap candidates, so a wrong guess is detected and redone, never unsafe).
+
+        def buffers(cap):
+            out_cap = max_num if max_num > 0 else cap
+            ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, cap))
+            return (out_cap, ws_bytes, torch.empty(ws_bytes, dtype=torch.uint8, device=dev),
+                    torch.empty((B, out_cap, 6), dtype=torch.float32, device=dev),
+                    torch.empty((B, out_cap), dtype=torch.int64, device=dev))
+
+        # cap (>= the largest candidate count) sizes the suppression workspace.  Reading the counts after
+        # the selection costs a host synchronisation in the middle of the pipeline; once a shape has been
+        # seen, cap is guessed from its last counts instead, everything is allocated up front, both library
+        # calls go out back to back and the counts come back together with the results (the library clamps
+        # an image to cap candidates, so a short guess is detected and redone, never unsafe).
         key = (dev, B, n, K)
         last = _last_max.get(key)
         guess = last is not None
         if guess:
             cap = min(65472, max(1024, (int(last * 1.3) + 63) // 64 * 64))
+            out_cap, ws_bytes, ws, dets, labels = buffers(cap)
+        _C.check(L.r3det_mcnms_select(_C.ptr(boxes), _C.ptr(scores), B, n, K, float(score_thr), _C.ptr(cand_row),
+                                      _C.ptr(cand_label), _C.ptr(cand_score), _C.ptr(cand_rank), _C.ptr(counts),
+                                      _C.ptr(maxc), _C.ptr(sel_ws), sel_bytes, _C.stream()), "r3det_mcnms_select")
         for _ in (0, 1):
             if not guess:
                 m = int(counts.max().item())
@@ -130,20 +141,12 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
                     return [multiclass_nms_rotated(multi_bboxes[i], multi_scores[i], score_thr, nms, max_num)
                             for i in range(B)]
                 cap = (m + 63) // 64 * 64
-            out_cap = max_num if max_num > 0 else cap
-            ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, cap))
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            dets = torch.empty((B, out_cap, 6), dtype=torch.float32, device=dev)
-            labels = torch.empty((B, out_cap), dtype=torch.int64, device=dev)
-            kept = torch.empty(B, dtype=torch.int32, device=dev)
+                out_cap, ws_bytes, ws, dets, labels = buffers(cap)
             _C.check(L.r3det_mcnms(geom, _C.ptr(boxes), B, n, K, _C.ptr(cand_row), _C.ptr(cand_label),
                                    _C.ptr(cand_score), _C.ptr(cand_rank), _C.ptr(counts), _C.ptr(maxc), cap, iou_thr,
-                                   out_cap, _C.ptr(ws), ws_bytes, _C.ptr(dets), _C.ptr(labels), None, _C.ptr(kept),
+                                   out_cap, _C.ptr(ws), ws_bytes, _C.ptr(dets), _C.ptr(labels), None, _C.ptr(kept_d),
                                    _C.stream()), "r3det_mcnms")
-            if not guess:
-                kept = kept.tolist()
-                break
-            both = torch.cat([kept, counts]).tolist()  # the one host read of the guessed run
+            both = kc.tolist()
             kept, m = both[:B], max(both[B:])
             _last_max[key] = m
             if m <= cap:
