@@ -219,6 +219,15 @@ int r3det_feature_refine_prepare(const float* best_bboxes, int N, int H, int W, 
 int r3det_feature_refine_forward_prepared(const float* features, const float* table, int N, int C, int H, int W,
                                           float* output, void* stream);
 
+/* The sampler with the module's two elementwise passes around it folded in
+ * (fr/feature_refine_module.py:121-126: feat = conv_5_1(conv_1_5(x)) + conv_1_1(x);
+ * out = x + fr(feat, boxes)):  output = residual + ((mixed_a + mixed_b) + sample(mixed_a + mixed_b)), same
+ * operation order, bit-identical to the three launches it replaces; 3 reads + 1 write per element
+ * instead of 8 passes.  Same table and shape rules as r3det_feature_refine_forward_prepared. */
+int r3det_feature_refine_module_prepared(const float* mixed_a, const float* mixed_b, const float* residual,
+                                         const float* table, int N, int C, int H, int W, float* output,
+                                         void* stream);
+
 /* The per-level loop of FeatureRefineModule.forward (fr/feature_refine_module.py:115-127) in one call:
  * `levels` sampler launches enqueued back to back (from Python each level costs ~10 us of host time, more
  * than the kernels of the three coarse levels).  features / best_bboxes / outputs: HOST arrays of `levels`

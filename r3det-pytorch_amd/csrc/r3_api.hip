@@ -173,7 +173,14 @@ int r3det_feature_refine_prepare(const float* best_bboxes, int N, int H, int W, 
 
 int r3det_feature_refine_forward_prepared(const float* features, const float* table, int N, int C, int H, int W,
                                           float* output, void* stream) {
-  return rc(r3k_fr_forward_prepared(features, table, N, C, H, W, output, S(stream)));
+  return rc(r3k_fr_forward_prepared(features, nullptr, nullptr, table, N, C, H, W, output, S(stream)));
+}
+
+int r3det_feature_refine_module_prepared(const float* mixed_a, const float* mixed_b, const float* residual,
+                                         const float* table, int N, int C, int H, int W, float* output,
+                                         void* stream) {
+  if (!mixed_a || !mixed_b || !residual) return R3DET_EINVAL;
+  return rc(r3k_fr_forward_prepared(mixed_a, mixed_b, residual, table, N, C, H, W, output, S(stream)));
 }
 
 size_t r3det_fr_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points) {

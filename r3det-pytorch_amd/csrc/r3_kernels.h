@@ -79,8 +79,9 @@ int r3k_bias_act(float* y, const float* bias, const float* residual, long long o
 // split form of the FR forward cell path: tap table ahead of time, then the sampler kernel alone
 size_t r3k_fr_table_bytes(int N, int H, int W);
 int r3k_fr_prepare(const float* boxes, int N, int H, int W, float scale, float* table, hipStream_t stream);
-int r3k_fr_forward_prepared(const float* feat, const float* table, int N, int C, int H, int W, float* out,
-                            hipStream_t stream);
+// feat2 / res null: the sampler alone; both given: out = res + ((feat + feat2) + sample(feat + feat2))
+int r3k_fr_forward_prepared(const float* feat, const float* feat2, const float* res, const float* table, int N, int C,
+                            int H, int W, float* out, hipStream_t stream);
 
 // profiling ring of the FR cell path (see r3det_fr_profile_read)
 int r3k_fr_profile_read(float* records, int capacity);

@@ -97,6 +97,23 @@ def fr_forward_prepared(features, table, output):
     return rc == 0
 
 
+def fr_module_prepared(mixed_a, mixed_b, residual, table, output):
+    """``residual + fr(mixed_a + mixed_b)`` in one launch (r3det_feature_refine_module_prepared): the
+    module's two elementwise passes folded into the sampler.  False when the library does not take this
+    shape (nothing was launched)."""
+    a = _C.need_hip(mixed_a, "mixed_a")
+    b = _C.need_hip(mixed_b, "mixed_b")
+    r = _C.need_hip(residual, "residual")
+    o = _C.need_hip(output, "output")
+    N, C, H, W = a.shape
+    if b.shape != a.shape or r.shape != a.shape or o.shape != a.shape:
+        raise RuntimeError("mixed_a, mixed_b, residual and output must have one shape")
+    with torch.cuda.device(a.device):
+        rc = _C.lib().r3det_feature_refine_module_prepared(_C.ptr(a), _C.ptr(b), _C.ptr(r), _C.ptr(table), N, C, H,
+                                                           W, _C.ptr(o), _C.stream())
+    return rc == 0
+
+
 def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, overwrite=False):
     """feature_refine_cuda.backward (feature_refine_cuda.cpp:44-66): accumulates into
     ``bottom_grad`` (``overwrite=True``: writes it, no zero-fill needed)."""
@@ -260,6 +277,13 @@ class FeatureRefineModule(nn.Module):
             # once, at its input, so that its three convolutions already produce what FR consumes
             # (a no-op for NCHW callers, like the reference).
             feat = feat.contiguous()
-            mixed = self.conv_5_1(self.conv_1_5(feat)) + self.conv_1_1(feat)
-            out.append(feat + fr(mixed, boxes, table))
+            a, b = self.conv_5_1(self.conv_1_5(feat)), self.conv_1_1(feat)
+            if table is not None and not (torch.is_grad_enabled() and (feat.requires_grad or a.requires_grad)):
+                # inference: the add in front of the sampler and the residual add behind it ride in the
+                # sampler launch (3 reads + 1 write per element instead of 8 passes over three launches)
+                fused = torch.empty_like(feat)
+                if fr_module_prepared(a, b, feat, table, fused):
+                    out.append(fused)
+                    continue
+            out.append(feat + fr(a + b, boxes, table))
         return out

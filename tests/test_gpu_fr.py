@@ -288,3 +288,27 @@ def test_forward_levels_equals_per_level_calls(points):
         assert torch.equal(o, want)
     with pytest.raises(RuntimeError):
         fr_forward_levels(feats, boxes[::-1], scales, points, outs)
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 128, 128, 8), (1, 1024, 128, 128, 8), (3, 512, 64, 64, 16)])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_module_fused_sampler_bit_identical(shape, adversarial):
+    """r3det_feature_refine_module_prepared = residual + fr(a + b) of the module
+    (feature_refine_module.py:121-126) in one launch: bit-identical to the three it replaces."""
+    from r3det.ops.feature_refine import fr_forward, fr_module_prepared, fr_prepare
+    N, C, H, W, stride = shape
+    g = torch.Generator(device='cuda').manual_seed(N * 7 + H)
+    a, b, res = (torch.randn(N, C, H, W, device='cuda', generator=g) for _ in range(3))
+    boxes = dev(fr_boxes(N, H, W, stride, 13, adversarial=adversarial))
+    table = fr_prepare(boxes, N, H, W, 1 / stride)
+    out = torch.full_like(a, float('nan'))
+    assert fr_module_prepared(a, b, res, table, out)
+    mixed = a + b
+    sampled = torch.empty_like(mixed)
+    fr_forward(mixed, boxes, 1 / stride, 1, sampled)
+    assert torch.equal(out, res + sampled)
+    # shapes / channel counts without the cell kernel are refused, nothing is written
+    small = torch.randn(1, 4, H, W, device='cuda')
+    o2 = torch.full_like(small, 5.0)
+    t2 = fr_prepare(boxes[:H * W], 1, H, W, 1 / stride)
+    assert not fr_module_prepared(small, small, small, t2, o2) and bool((o2 == 5.0).all())
