@@ -66,3 +66,19 @@ def test_refine_bboxes(channels_last):
     for i in range(N):
         for l in range(len(sizes)):
             close(got[i][l], want[i][l])
+
+
+@pytest.mark.parametrize("A,C", [(3, 4), (2, 16), (9, 15), (5, 7)])
+def test_filter_bboxes_layouts_agree(A, C):
+    """The channels_last heads take the LDS-staged kernel (templated for 9 x 15, runtime loops otherwise,
+    the strided kernel when a chunk of 64 positions is not 16-byte granular): same boxes as NCHW inputs."""
+    from r3det.ops.fr_boxes import filter_bboxes
+    N, H, W = 2, 24, 20
+    g = torch.Generator(device='cuda').manual_seed(A * 31 + C)
+    cls = torch.randn(N, A * C, H, W, device='cuda', generator=g)
+    reg = torch.randn(N, A * 5, H, W, device='cuda', generator=g) * 0.3
+    anchors = torch.rand(H * W * A, 5, device='cuda', generator=g) * 40 + 4
+    want = filter_bboxes(cls, reg, anchors, A, C)
+    got = filter_bboxes(cls.contiguous(memory_format=torch.channels_last),
+                        reg.contiguous(memory_format=torch.channels_last), anchors, A, C)
+    assert torch.equal(got, want)
