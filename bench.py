@@ -59,11 +59,13 @@ def build_model(device, seed):
     img = torch.randn(BATCH, 3, IMG, IMG, generator=g).to(device)
     if CHANNELS_LAST:
         # MIOpen's fp32 convolutions run ~10 % faster on NHWC activations (tools/cl_probe.py); the FR
-        # sampler takes NCHW planes, FeatureRefineFunction makes its input contiguous (one extra pass
-        # over the level, ~0.1 ms per step) -- same arithmetic, same fp32 everywhere
+        # sampler takes NCHW planes, FeatureRefineModule makes the sampler's three inputs NCHW (its own
+        # convolutions stay channels_last: with NCHW weights MIOpen transposes in and out of every one of
+        # them, 148.7 vs 150.1 img/s) -- same arithmetic, same fp32 everywhere
         model = model.to(memory_format=torch.channels_last)
-        for m in getattr(model, "feat_refine_module", []):
-            m.to(memory_format=torch.contiguous_format)  # the FRM convolutions feed FR: NCHW
+        if os.environ.get("R3DET_BENCH_FRM_NCHW", "0") == "1":
+            for m in getattr(model, "feat_refine_module", []):
+                m.to(memory_format=torch.contiguous_format)
         img = img.contiguous(memory_format=torch.channels_last)
     calibrate_score_bias(model, img, frac=0.01)  # ~3.3 k NMS candidates / image
     return model, img

@@ -276,8 +276,12 @@ class FeatureRefineModule(nn.Module):
             # The sampler reads NCHW planes: in a channels_last pipeline the module switches layout
             # once, at its input, so that its three convolutions already produce what FR consumes
             # (a no-op for NCHW callers, like the reference).
+            # The sampler reads NCHW planes.  The three convolutions run in whatever layout the module's
+            # weights are in (a channels_last module on channels_last features: no layout switch inside
+            # MIOpen); their outputs and the residual are made NCHW here (no-ops for NCHW callers, like the
+            # reference).
+            a, b = self.conv_5_1(self.conv_1_5(feat)).contiguous(), self.conv_1_1(feat).contiguous()
             feat = feat.contiguous()
-            a, b = self.conv_5_1(self.conv_1_5(feat)), self.conv_1_1(feat)
             if table is not None and not (torch.is_grad_enabled() and (feat.requires_grad or a.requires_grad)):
                 # inference: the add in front of the sampler and the residual add behind it ride in the
                 # sampler launch (3 reads + 1 write per element instead of 8 passes over three launches)
