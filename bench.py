@@ -41,7 +41,7 @@ NMS_CFG = dict(iou_thr=0.1)  # type absent -> 'v1' (bbox_nms_rotated.py:43)
 SCORE_THR, MAX_PER_IMG = 0.05, 2000
 CHANNELS_LAST = os.environ.get("R3DET_BENCH_NCHW", "0") != "1"  # activation layout of the conv stack
 FUSE = os.environ.get("R3DET_BENCH_NOFUSE", "0") != "1"          # conv+BN folding and fused epilogues
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r01h_fr_module_pmc.json")
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r01j_fr_residual_pmc.json")
 
 
 def build_model(device, seed):
@@ -223,10 +223,10 @@ def main():
         H = W = 128
         # 8 B per element (read + write once) for the sampler + the per-position sample data,
         # which this kernel reads as an 8-byte tap (the 20-byte boxes are read by the table kernel, 1.3 MB, not
-        # counted here).  In the model the launch also carries the module's two elementwise passes
-        # (r3det_feature_refine_module_prepared): two more reads per element -- the second addend of the
-        # sampled plane and the residual -- i.e. 16 B per element.
-        alg_bytes = 4 * 4 * BATCH * C * H * W + 8 * BATCH * H * W
+        # counted here).  In the model the launch also carries the module's residual add
+        # (r3det_feature_refine_module_prepared with the plane already summed by r3det_frm_mix_nchw): one
+        # more read per element, i.e. 12 B per element.
+        alg_bytes = 3 * 4 * BATCH * C * H * W + 8 * BATCH * H * W
         achieved = alg_bytes / (span_us * 1e-6) / 1e9
         traffic = None
         if os.path.exists(PROFILE_PMC):
@@ -248,11 +248,11 @@ def main():
                                    "to ~1 % candidates",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "nms_type": "v1",
                        "parallelism": f"image-parallel x{world}, all_gather of detections"},
-            "roofline": {"bound": "hbm", "kernel": "fr_forward_cell<7,7,1024,fused> = FR forward level 0 (4x256x128x128) with the "
-                                                   "FeatureRefineModule's add in front and residual add behind folded in (3 reads + 1 "
-                                                   "write per element); its tap table is prepared for all levels ahead of the module's "
-                                                   "convs; duration = the launch's own start/stop HIP events (hipExtLaunchKernelGGL), "
-                                                   "timed steps",
+            "roofline": {"bound": "hbm", "kernel": "fr_forward_cell<7,7,1024,residual> = FR forward level 0 (4x256x128x128) with the "
+                                                   "FeatureRefineModule's residual add folded in (2 reads + 1 write per element; the "
+                                                   "module's other adds ride in the layout-switch kernel in front of it); its tap "
+                                                   "table is prepared for all levels ahead of the module's convs; duration = the "
+                                                   "launch's own start/stop HIP events (hipExtLaunchKernelGGL), timed steps",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(span_us, 2),
@@ -302,6 +302,24 @@ def main():
                     "frac": round(alg_plain / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(ctx["span"]),
                     "table_kernel_us_own_events": round(sum(r[2] for r in ctx["each"]) / max(1, len(ctx["each"])), 2),
                     "cell_kernel_us_own_events": round(sum(r[3] for r in ctx["each"]) / max(1, len(ctx["each"])), 2)}
+            # and the roofline kernel itself (sampler + residual) in a loop of its own: same launch, inputs
+            # not freshly written by the kernels in front of it
+            from r3det.ops.feature_refine import fr_module_prepared, fr_prepare
+            f0, b0 = wl["feats"][0], wl["boxes"][0]
+            table = fr_prepare(b0, BATCH, H, W, 1.0 / 8)
+            res0, out0 = torch.randn_like(f0), torch.empty_like(f0)
+            _C.fr_profile_read()
+            _C.set_option("fr_profile", 2)
+            timeit(lambda: fr_module_prepared(f0, None, res0, table, out0), 20, warm=0)
+            _C.set_option("fr_profile", 0)
+            alone = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
+            if alone:
+                us = sum(r[4] for r in alone) / len(alone)
+                line["roofline"]["kernel_alone_context"] = {
+                    "what": "the same launch (r3det_feature_refine_module_prepared, residual form) repeated on its own",
+                    "avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
+                    "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
+            del res0, out0, table
         if not args.no_ops:
             line["ops"] = op_rates(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -227,6 +227,14 @@ int r3det_feature_refine_forward_prepared(const float* features, const float* ta
 int r3det_feature_refine_module_prepared(const float* mixed_a, const float* mixed_b, const float* residual,
                                          const float* table, int N, int C, int H, int W, float* output,
                                          void* stream);
+/* (mixed_b may be NULL: mixed_a is then the already summed plane, output = residual + fr(mixed_a).)
+ *
+ * For channels_last pipelines: channels_last -> NCHW with the module's work in front of the sampler folded in,
+ * out_nchw[n,c,p] = (a_nhwc[n,p,c] + bias_a[c]) + (b_nhwc[n,p,c] + bias_b[c]), a / b = the raw outputs of
+ * conv_5_1 and conv_1_1 (their bias adds are separate launches after the convolution otherwise).  b_nhwc and
+ * the biases may be NULL (plain layout switch, e.g. for the residual). */
+int r3det_frm_mix_nchw(const float* a_nhwc, const float* b_nhwc, const float* bias_a, const float* bias_b, int N,
+                       int C, int H, int W, float* out_nchw, void* stream);
 
 /* The per-level loop of FeatureRefineModule.forward (fr/feature_refine_module.py:115-127) in one call:
  * `levels` sampler launches enqueued back to back (from Python each level costs ~10 us of host time, more

@@ -176,10 +176,15 @@ int r3det_feature_refine_forward_prepared(const float* features, const float* ta
   return rc(r3k_fr_forward_prepared(features, nullptr, nullptr, table, N, C, H, W, output, S(stream)));
 }
 
+int r3det_frm_mix_nchw(const float* a_nhwc, const float* b_nhwc, const float* bias_a, const float* bias_b, int N,
+                       int C, int H, int W, float* out_nchw, void* stream) {
+  return rc(r3k_mix_to_nchw(a_nhwc, b_nhwc, bias_a, bias_b, N, C, H, W, out_nchw, S(stream)));
+}
+
 int r3det_feature_refine_module_prepared(const float* mixed_a, const float* mixed_b, const float* residual,
                                          const float* table, int N, int C, int H, int W, float* output,
                                          void* stream) {
-  if (!mixed_a || !mixed_b || !residual) return R3DET_EINVAL;
+  if (!mixed_a || !residual) return R3DET_EINVAL;
   return rc(r3k_fr_forward_prepared(mixed_a, mixed_b, residual, table, N, C, H, W, output, S(stream)));
 }
 

@@ -466,7 +466,7 @@ typedef float fr_f2 __attribute__((ext_vector_type(2)));
 // 121-126): the sampled plane is feat + feat2 (= conv_5_1(conv_1_5(x)) + conv_1_1(x)), and the result
 // gets the module's residual, out = res + (plane + sample(plane)), in the reference's operation order.
 // 3 reads + 1 write per element instead of (2r + 1w) + (1r + 1w) + (2r + 1w) over three launches.
-template <int LOGW, int LOGH, int THREADS, bool FROM_BOXES, bool FUSED = false>
+template <int LOGW, int LOGH, int THREADS, bool FROM_BOXES, int FUSED = 0>
 __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restrict__ feat,
                                                            const float* __restrict__ table, int C, int G,
                                                            float scale, float* __restrict__ out,
@@ -526,30 +526,29 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
   // positions after its request: one load, one store and one LDS write per position, no bursts.
   constexpr int D = K > 1 ? K / 2 : 0;  // (3K/4 measured the same cold and 4 % slower warm)
   float v[K], vd = 0.f;
-  float v2[K], vd2 = 0.f, vr[K];  // FUSED: second addend of the plane, the residual of the output plane
+  constexpr bool TWO = FUSED == 1, RES = FUSED != 0;  // FUSED 2: the residual only (the plane is already summed)
+  float v2[K], vd2 = 0.f, vr[K];  // second addend of the plane, the residual of the output plane
   {
     const float* src = feat + (plane0 << (LOGW + LOGH));
-    const float* src2 = FUSED ? feat2 + (plane0 << (LOGW + LOGH)) : nullptr;
+    const float* src2 = TWO ? feat2 + (plane0 << (LOGW + LOGH)) : nullptr;
 #pragma unroll
     for (int k = 0; k < K; k++) {
       v[k] = src[tid + k * FRC_BLOCK];
-      if (FUSED) v2[k] = src2[tid + k * FRC_BLOCK];
+      if (TWO) v2[k] = src2[tid + k * FRC_BLOCK];
     }
     if (dup) {
       vd = src[dsrc];
-      if (FUSED) vd2 = src2[dsrc];
+      if (TWO) vd2 = src2[dsrc];
     }
 #pragma unroll
-    for (int k = 0; k < K; k++) lds[self0 + k * KSTEP] = FUSED ? v[k] + v2[k] : v[k];
-    if (dup) lds[ddst] = FUSED ? vd + vd2 : vd;
+    for (int k = 0; k < K; k++) lds[self0 + k * KSTEP] = TWO ? v[k] + v2[k] : v[k];
+    if (dup) lds[ddst] = TWO ? vd + vd2 : vd;
     src += HW;  // G >= 2 (launcher)
 #pragma unroll
     for (int k = 0; k < D; k++) {
       v[k] = src[tid + k * FRC_BLOCK];
-      if (FUSED) {
-        v2[k] = src2[HW + tid + k * FRC_BLOCK];
-        vr[k] = res[(plane0 << (LOGW + LOGH)) + tid + k * FRC_BLOCK];
-      }
+      if (TWO) v2[k] = src2[HW + tid + k * FRC_BLOCK];
+      if (RES) vr[k] = res[(plane0 << (LOGW + LOGH)) + tid + k * FRC_BLOCK];
     }
   }
   __syncthreads();
@@ -560,23 +559,23 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
     const float* buf = lds + (c & 1) * BUF;
     float* nbuf = lds + ((c + 1) & 1) * BUF;
     const float* src1 = feat + ((plane0 + c + 1) << (LOGW + LOGH));
-    const float* src21 = FUSED ? feat2 + ((plane0 + c + 1) << (LOGW + LOGH)) : nullptr;
-    const float* resc = FUSED ? res + ((plane0 + c) << (LOGW + LOGH)) : nullptr;
+    const float* src21 = TWO ? feat2 + ((plane0 + c + 1) << (LOGW + LOGH)) : nullptr;
+    const float* resc = RES ? res + ((plane0 + c) << (LOGW + LOGH)) : nullptr;
     float* dst = out + ((plane0 + c) << (LOGW + LOGH));
     if (L1 && dup) {
       vd = src1[dsrc];
-      if (FUSED) vd2 = src21[dsrc];
+      if (TWO) vd2 = src21[dsrc];
     }
 #pragma unroll
     for (int k = 0; k < K; k++) {
       if (k + D < K) {
         if (L1) v[k + D] = src1[tid + (k + D) * FRC_BLOCK];
-        if (FUSED && L1) v2[k + D] = src21[tid + (k + D) * FRC_BLOCK];
-        if (FUSED) vr[k + D] = resc[tid + (k + D) * FRC_BLOCK];
+        if (TWO && L1) v2[k + D] = src21[tid + (k + D) * FRC_BLOCK];
+        if (RES) vr[k + D] = resc[tid + (k + D) * FRC_BLOCK];
       } else {
         if (L2) v[k + D - K] = src1[HW + tid + (k + D - K) * FRC_BLOCK];
-        if (FUSED && L2) v2[k + D - K] = src21[HW + tid + (k + D - K) * FRC_BLOCK];
-        if (FUSED && L1) vr[k + D - K] = resc[HW + tid + (k + D - K) * FRC_BLOCK];
+        if (TWO && L2) v2[k + D - K] = src21[HW + tid + (k + D - K) * FRC_BLOCK];
+        if (RES && L1) vr[k + D - K] = resc[HW + tid + (k + D - K) * FRC_BLOCK];
       }
       float y = ty[k], x = tx[k];
       // opaque copies: without them LICM hoists cell / fractions / address of all K positions
@@ -595,10 +594,10 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
       const fr_f2 pt = ((1.f - fy) * hf) * top;  // {w1 * v1, w2 * v2}
       const fr_f2 pb = (fy * hf) * bot;          // {w3 * v3, w4 * v4}
       const float val = (pt.x + pt.y + pb.x + pb.y);
-      dst[tid + k * FRC_BLOCK] = FUSED ? vr[k] + (id + val) : id + val;
-      if (L1) nbuf[self0 + k * KSTEP] = FUSED ? v[k] + v2[k] : v[k];
+      dst[tid + k * FRC_BLOCK] = RES ? vr[k] + (id + val) : id + val;
+      if (L1) nbuf[self0 + k * KSTEP] = TWO ? v[k] + v2[k] : v[k];
     }
-    if (L1 && dup) nbuf[ddst] = FUSED ? vd + vd2 : vd;
+    if (L1 && dup) nbuf[ddst] = TWO ? vd + vd2 : vd;
     __syncthreads();
   };
   int c = 0;
@@ -1209,17 +1208,17 @@ int r3k_fr_prepare(const float* boxes, int N, int H, int W, float scale, float* 
 }
 
 // feat2 / res both null: out = feat + sample(feat) (the sampler alone); both given: the module's fused form
-// out = res + ((feat + feat2) + sample(feat + feat2))
+// out = res + ((feat + feat2) + sample(feat + feat2)); res alone: out = res + (feat + sample(feat))
 int r3k_fr_forward_prepared(const float* feat, const float* feat2, const float* res, const float* table, int N, int C,
                             int H, int W, float* out, hipStream_t stream) {
-  if (!r3k_fr_table_bytes(N, H, W) || !feat || !table || !out || C <= 0 || ((feat2 == nullptr) != (res == nullptr)))
-    return -1;
+  if (!r3k_fr_table_bytes(N, H, W) || !feat || !table || !out || C <= 0 || (feat2 && !res)) return -1;
   int G = 1;
   while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
   if (G < 2 || !aligned16(feat) || !aligned16(out) || !aligned16(table)) return -1;
-  if (feat2 && (!aligned16(feat2) || !aligned16(res))) return -1;
+  if ((feat2 && !aligned16(feat2)) || (res && !aligned16(res))) return -1;
   static bool once = (allow_big_lds(fr_forward_cell<7, 7, 1024, false>, 160 * 1024),
-                      allow_big_lds(fr_forward_cell<7, 7, 1024, false, true>, 160 * 1024), true);
+                      allow_big_lds(fr_forward_cell<7, 7, 1024, false, 1>, 160 * 1024),
+                      allow_big_lds(fr_forward_cell<7, 7, 1024, false, 2>, 160 * 1024), true);
   (void)once;
   const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
   FrProfileSlot* ps = g_r3_fr_profile ? fr_profile_next(N, H) : nullptr;
@@ -1229,8 +1228,8 @@ int r3k_fr_forward_prepared(const float* feat, const float* feat2, const float* 
 #define R3_PREP(LW, FU) \
   hipExtLaunchKernelGGL((fr_forward_cell<LW, LW, 1024, false, FU>), grid, block, lds, stream, e0, e1, 0, feat, table, C, G, \
                         0.f, out, feat2, res)
-  if (W == 128) { if (feat2) R3_PREP(7, true); else R3_PREP(7, false); }
-  else { if (feat2) R3_PREP(6, true); else R3_PREP(6, false); }
+  if (W == 128) { if (feat2) R3_PREP(7, 1); else if (res) R3_PREP(7, 2); else R3_PREP(7, 0); }
+  else { if (feat2) R3_PREP(6, 1); else if (res) R3_PREP(6, 2); else R3_PREP(6, 0); }
 #undef R3_PREP
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -73,6 +73,9 @@ int r3k_filter_bboxes(const float* cls, const long long* cls_strides, const floa
                       int H, int W, float max_ratio, float* out, hipStream_t stream);
 
 // convolution epilogue of the inference model: y = act(y + bias[c] (+ residual)), in place
+// channels_last -> NCHW: out = (a + bias_a[c]) (+ (b + bias_b[c])); b and the biases may be null
+int r3k_mix_to_nchw(const float* a, const float* b, const float* bias_a, const float* bias_b, int N, int C, int H, int W,
+                    float* out, hipStream_t stream);
 int r3k_bias_act(float* y, const float* bias, const float* residual, long long outer, int C, long long inner, int relu,
                  hipStream_t stream);
 

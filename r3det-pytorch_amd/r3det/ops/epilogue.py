@@ -34,3 +34,19 @@ def bias_act_(y, bias, residual=None, relu=True):
     if residual is not None:
         y.add_(residual)
     return y.relu_() if relu else y
+
+
+def mix_to_nchw(a, b=None, bias_a=None, bias_b=None):
+    """channels_last (N, C, H, W) tensors -> a new NCHW-contiguous ``(a + bias_a) + (b + bias_b)``
+    (r3det_frm_mix_nchw); b and the biases are optional.  None when the inputs are not dense
+    channels_last fp32 CUDA tensors (the caller then uses the torch ops)."""
+    ok = lambda t: (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4  # noqa: E731
+                    and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous())
+    if not ok(a) or (b is not None and (not ok(b) or b.shape != a.shape)):
+        return None
+    N, C, H, W = a.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _C.check(_C.lib().r3det_frm_mix_nchw(_C.ptr(a), _C.ptr(b), _C.ptr(bias_a), _C.ptr(bias_b), N, C, H, W,
+                                             _C.ptr(out), _C.stream()), "r3det_frm_mix_nchw")
+    return out

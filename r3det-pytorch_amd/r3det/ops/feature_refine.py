@@ -6,10 +6,12 @@ state-dict names (``conv_5_1``, ``conv_1_5``, ``conv_1_1``, ``fr``) are the refe
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
+from .epilogue import mix_to_nchw
 
 
 # bench.py hook: when set to a list, (start, end) stream events are recorded around every
@@ -102,11 +104,11 @@ def fr_module_prepared(mixed_a, mixed_b, residual, table, output):
     module's two elementwise passes folded into the sampler.  False when the library does not take this
     shape (nothing was launched)."""
     a = _C.need_hip(mixed_a, "mixed_a")
-    b = _C.need_hip(mixed_b, "mixed_b")
+    b = _C.need_hip(mixed_b, "mixed_b") if mixed_b is not None else None  # None: mixed_a is the summed plane
     r = _C.need_hip(residual, "residual")
     o = _C.need_hip(output, "output")
     N, C, H, W = a.shape
-    if b.shape != a.shape or r.shape != a.shape or o.shape != a.shape:
+    if (b is not None and b.shape != a.shape) or r.shape != a.shape or o.shape != a.shape:
         raise RuntimeError("mixed_a, mixed_b, residual and output must have one shape")
     with torch.cuda.device(a.device):
         rc = _C.lib().r3det_feature_refine_module_prepared(_C.ptr(a), _C.ptr(b), _C.ptr(r), _C.ptr(table), N, C, H,
@@ -280,9 +282,25 @@ class FeatureRefineModule(nn.Module):
             # weights are in (a channels_last module on channels_last features: no layout switch inside
             # MIOpen); their outputs and the residual are made NCHW here (no-ops for NCHW callers, like the
             # reference).
+            infer = table is not None and not (torch.is_grad_enabled() and
+                                               (feat.requires_grad or self.conv_1_1.weight.requires_grad))
+            if infer and feat.is_cuda and feat.is_contiguous(memory_format=torch.channels_last) \
+                    and not feat.is_contiguous():
+                # channels_last inference: the two convolutions' bias adds, their sum and the layout switch in
+                # one pass (r3det_frm_mix_nchw), the residual add in the sampler launch
+                res = mix_to_nchw(feat)  # first: written back long before the sampler reads it
+                ra = F.conv2d(self.conv_1_5(feat), self.conv_5_1.weight, None, self.conv_5_1.stride,
+                              self.conv_5_1.padding)
+                rb = F.conv2d(feat, self.conv_1_1.weight, None, self.conv_1_1.stride, self.conv_1_1.padding)
+                mixed = mix_to_nchw(ra, rb, self.conv_5_1.bias, self.conv_1_1.bias)
+                if mixed is not None and res is not None:
+                    fused = torch.empty_like(res)
+                    if fr_module_prepared(mixed, None, res, table, fused):
+                        out.append(fused)
+                        continue
             a, b = self.conv_5_1(self.conv_1_5(feat)).contiguous(), self.conv_1_1(feat).contiguous()
             feat = feat.contiguous()
-            if table is not None and not (torch.is_grad_enabled() and (feat.requires_grad or a.requires_grad)):
+            if infer:
                 # inference: the add in front of the sampler and the residual add behind it ride in the
                 # sampler launch (3 reads + 1 write per element instead of 8 passes over three launches)
                 fused = torch.empty_like(feat)

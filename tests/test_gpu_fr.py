@@ -312,3 +312,49 @@ def test_module_fused_sampler_bit_identical(shape, adversarial):
     o2 = torch.full_like(small, 5.0)
     t2 = fr_prepare(boxes[:H * W], 1, H, W, 1 / stride)
     assert not fr_module_prepared(small, small, small, t2, o2) and bool((o2 == 5.0).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 64, 64), (1, 100, 13, 7), (3, 64, 1, 1), (1, 65, 128, 128)])
+@pytest.mark.parametrize("two", [True, False])
+def test_mix_to_nchw(shape, two):
+    """r3det_frm_mix_nchw: (a + bias_a) + (b + bias_b) of channels_last inputs, written NCHW; exact."""
+    from r3det.ops.epilogue import mix_to_nchw
+    N, C, H, W = shape
+    g = torch.Generator(device='cuda').manual_seed(C + H)
+    a = torch.randn(N, C, H, W, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(N, C, H, W, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    ba, bb = torch.randn(C, device='cuda', generator=g), torch.randn(C, device='cuda', generator=g)
+    if a.is_contiguous():  # (H = W = 1: both layouts at once -> not taken)
+        assert mix_to_nchw(a, b, ba, bb) is None
+        return
+    if two:
+        got = mix_to_nchw(a, b, ba, bb)
+        want = (a + ba.view(1, -1, 1, 1)) + (b + bb.view(1, -1, 1, 1))
+    else:
+        got = mix_to_nchw(a)
+        want = a
+    assert got.is_contiguous() and torch.equal(got, want.contiguous())
+    assert mix_to_nchw(a.contiguous()) is None  # NCHW input: nothing to do here
+
+
+def test_module_channels_last_inference_path():
+    """FeatureRefineModule on channels_last features without grad: raw convolutions + r3det_frm_mix_nchw +
+    the sampler with the residual folded in.  Against the module's own three-step form on the same weights."""
+    from r3det.ops import FeatureRefineModule
+    from r3det import synthetic as syn
+    torch.manual_seed(3)
+    N, C = 2, 256
+    feats, boxes = syn.fr_pyramid(N, C, 5, device='cuda')
+    m = FeatureRefineModule(C, list(syn.STRIDES)).cuda()
+    for conv in (m.conv_5_1, m.conv_1_5, m.conv_1_1):
+        torch.nn.init.normal_(conv.weight, 0, 0.05)
+        torch.nn.init.normal_(conv.bias, 0, 0.5)
+    rois = [[b.view(N, -1, 5)[i] for b in boxes] for i in range(N)]
+    with torch.no_grad():
+        want = m(feats, rois)                         # NCHW module, NCHW features
+        mcl = m.to(memory_format=torch.channels_last)
+        got = mcl([f.contiguous(memory_format=torch.channels_last) for f in feats], rois)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and g.is_contiguous()
+        # different convolution kernels per layout: not bitwise
+        assert torch.allclose(g, w, rtol=1e-4, atol=1e-4), float((g - w).abs().max())

@@ -27,7 +27,13 @@ for lvl in (0, 1):
     def fused():
         fr_module_prepared(a, b, res, table, out)
 
-    for name, fn in (("three launches", three), ("fused", fused), ("three launches", three), ("fused", fused)):
+    mixed = a + b
+
+    def residual():
+        fr_module_prepared(mixed, None, res, table, out)
+
+    for name, fn in (("three launches", three), ("fused", fused), ("residual only", residual),
+                     ("three launches", three), ("fused", fused), ("residual only", residual)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -38,4 +44,6 @@ for lvl in (0, 1):
         e.record()
         torch.cuda.synchronize()
         us = s.elapsed_time(e) * 1e3 / 20
-        print(f"level {lvl} {name:15s} {us:8.1f} us  ({16 * a.numel() / us / 1e3:7.1f} GB/s on 3 reads + 1 write)", flush=True)
+        passes = 3 if name == "residual only" else 4
+        print(f"level {lvl} {name:15s} {us:8.1f} us  ({4 * passes * a.numel() / us / 1e3:7.1f} GB/s on {passes - 1} reads + 1 write)",
+              flush=True)
