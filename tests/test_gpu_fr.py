@@ -358,3 +358,41 @@ def test_module_channels_last_inference_path():
         assert g.shape == w.shape and g.is_contiguous()
         # different convolution kernels per layout: not bitwise
         assert torch.allclose(g, w, rtol=1e-4, atol=1e-4), float((g - w).abs().max())
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 4])
+def test_full_size_properties(level):
+    """BASELINE shapes (N = 4, C = 256, the pyramid of a 1024^2 input), where the oracle is too slow:
+    size-independent properties.  (1) every channel sees the same taps: a plane replicated over the
+    channels gives identical output channels, and equals the first 2 channels' oracle result;
+    (2) linearity of the forward; (3) the backward is the forward's adjoint: <fr(x), g> = <x, fr^T(g)>."""
+    from r3det import synthetic as syn
+    from r3det.ops.feature_refine import fr_backward, fr_forward
+    N, C = 4, 256
+    feats, boxes = syn.fr_pyramid(N, C, 21, device='cuda')
+    x, b, s = feats[level], boxes[level], 1.0 / syn.STRIDES[level]
+    g = torch.Generator(device='cuda').manual_seed(level)
+    y = torch.randn(x.shape, device='cuda', generator=g)
+    fx, fy, fxy = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    fr_forward(x, b, s, 1, fx)
+    fr_forward(y, b, s, 1, fy)
+    # (1)
+    rep = x[:, :1].expand_as(x).contiguous()
+    frep = torch.empty_like(x)
+    fr_forward(rep, b, s, 1, frep)
+    assert torch.equal(frep, frep[:, :1].expand_as(frep))
+    assert torch.equal(frep[:, 0], fx[:, 0])
+    with O.twin():
+        want = O.fr_forward(x[:1, :2].cpu().numpy(), b.view(N, -1, 5)[0].cpu().numpy(), s, 1)
+    assert np.array_equal(fx[:1, :2].cpu().numpy(), want)
+    # (2)
+    fr_forward(0.5 * x - 2.0 * y, b, s, 1, fxy)
+    assert torch.allclose(fxy, 0.5 * fx - 2.0 * fy, rtol=1e-5, atol=1e-5)
+    # (3)
+    gt = torch.randn(x.shape, device='cuda', generator=g)
+    back = torch.empty_like(x)
+    fr_backward(gt, b, s, 1, back, overwrite=True)
+    lhs = (fx.double() * gt.double()).sum().item()
+    rhs = (x.double() * back.double()).sum().item()
+    scale = (fx.double().abs() * gt.double().abs()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * scale, (lhs, rhs, scale)
