@@ -84,8 +84,9 @@ def build_hot_workload(device, seed):
     feats, boxes = syn.fr_pyramid(BATCH, C, seed, device=device)
     outs = [torch.empty_like(f) for f in feats]
     pools = [syn.nms_pool(syn.R3DET_POOL, seed * 1000 + i, device=device) for i in range(BATCH)]
+    from r3det.core.post_processing import CapacityHint
     return dict(feats=feats, boxes=boxes, outs=outs, pool_boxes=torch.stack([p[0] for p in pools]),
-                pool_scores=torch.stack([p[1] for p in pools]))
+                pool_scores=torch.stack([p[1] for p in pools]), nms_hint=CapacityHint())
 
 
 def hot_path_step(wl):
@@ -93,7 +94,8 @@ def hot_path_step(wl):
     from r3det.ops.feature_refine import fr_forward_levels
     from r3det.synthetic import STRIDES
     fr_forward_levels(wl["feats"], wl["boxes"], [1.0 / s for s in STRIDES], 1, wl["outs"])
-    res = multiclass_nms_rotated_batch(wl["pool_boxes"], wl["pool_scores"], SCORE_THR, NMS_CFG, MAX_PER_IMG)
+    res = multiclass_nms_rotated_batch(wl["pool_boxes"], wl["pool_scores"], SCORE_THR, NMS_CFG, MAX_PER_IMG,
+                                       hint=wl["nms_hint"])
     return sum(d.size(0) for d, _ in res)
 
 

@@ -11,6 +11,9 @@
 
 namespace {
 
+// ReLU that propagates NaN like F.relu (fmaxf(NaN, 0) would return 0 and hide a broken activation)
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
 // NHWC (channels_last): channel = fastest index.  One float4 = 4 consecutive channels (C % 4 == 0).
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bias_act_nhwc_kernel(float4* __restrict__ y, const float4* __restrict__ bias,
@@ -24,7 +27,7 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_kernel(float4* __restrict__
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
     if (RELU) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
     }
     y[i] = v;
   }
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* __restrict__ 
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
       if (RELU) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
       }
       reinterpret_cast<float4*>(yp)[i] = v;
     }
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void bias_act_nchw_kernel(float* __restrict__ 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < inner; i += gridDim.x * 256) {
       float v = yp[i] + b;
       if (RES) v += rp[i];
-      if (RELU) v = fmaxf(v, 0.f);
+      if (RELU) v = relu_nan(v);
       yp[i] = v;
     }
   }

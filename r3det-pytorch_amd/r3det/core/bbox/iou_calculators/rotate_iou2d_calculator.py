@@ -5,7 +5,8 @@ Mirror of r3det/core/bbox/iou_calculators/rotate_iou2d_calculator.py:
   RBboxOverlaps2D_v2 :83-124 -> rbbox_overlaps_v2 :127-156 -> mmcv-style box_iou_rotated (v2)
   RBboxOverlaps2D_v3 :159-199-> rbbox_overlaps_v3 :202-231 -> r3det.ops.obb_overlaps     (v3)
 """
-from ....ops import box_iou_rotated, obb_overlaps, rbbox_iou
+from ....ops import obb_overlaps, rbbox_iou
+from ....ops.mmcv_ops import box_iou_rotated
 from ....registry import IOU_CALCULATORS
 
 

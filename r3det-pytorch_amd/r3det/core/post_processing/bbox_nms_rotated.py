@@ -6,10 +6,32 @@
 import torch
 
 from ... import _C
-from ...ops import batched_rnms, ml_nms_rotated, nms_rotated, obb_batched_nms
+from ...ops import batched_rnms, ml_nms_rotated, obb_batched_nms
+from ...ops.mmcv_ops import nms_rotated
 
 
-_last_max = {}  # (device, B, n, K) -> largest candidate count of the last call: next call's workspace guess
+MAX_CAP = 65472  # largest per-image candidate capacity of the batched kernels (pair queue packs (i << 16) | j)
+
+
+class CapacityHint:
+    """Caller-owned memory of the largest per-image candidate count seen for a shape.  With a hint,
+    ``multiclass_nms_rotated_batch`` sizes its workspace from the previous call instead of reading the
+    counts in the middle of the pipeline (one host synchronisation less per step); without one it always
+    reads them.  One hint per caller (a head instance, a benchmark loop): nothing is shared behind the
+    callers' backs; a lock makes concurrent use from several threads safe."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._last = {}
+
+    def get(self, key):
+        with self._lock:
+            return self._last.get(key)
+
+    def put(self, key, value):
+        with self._lock:
+            self._last[key] = value
 
 
 def _get(nms, key):
@@ -75,15 +97,16 @@ def multiclass_nms_rotated(multi_bboxes, multi_scores, score_thr, nms, max_num=-
     return dets, labels[keep]
 
 
-def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max_num=-1):
+def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max_num=-1, hint=None):
     """``[multiclass_nms_rotated(b, s, ...) for b, s in zip(multi_bboxes, multi_scores)]`` for a
     whole batch -- (B, n, 5) boxes shared by the classes, (B, n, C+1) scores -- with identical
     results.  nms types 'v1', 'v2' and 'v3' run as ONE pass of launches over all images
     (r3det_mcnms_select / r3det_mcnms in include/r3det_hip.h: threshold + ordered compaction,
     stable score sort, class offsets or label guard, suppression, keep order and the max_num cut
-    on the device; the host reads the per-image candidate counts -- in the middle the first time a
-    shape is seen, afterwards together with the per-image detection counts at the end).  'mmcv' takes
-    the per-image path."""
+    on the device; the host reads the per-image candidate counts in the middle -- or, when the caller
+    passes its ``hint`` (CapacityHint) and the shape has been seen, together with the per-image detection
+    counts at the end).  'mmcv', and pools with more than MAX_CAP candidates in one image, take the
+    per-image path."""
     B, n = multi_scores.shape[:2]
     K = multi_scores.size(2) - 1
     version = nms.get('type', 'v1')
@@ -122,10 +145,10 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
         # calls go out back to back and the counts come back together with the results (the library clamps
         # an image to cap candidates, so a short guess is detected and redone, never unsafe).
         key = (dev, B, n, K)
-        last = _last_max.get(key)
-        guess = last is not None
+        last = hint.get(key) if hint is not None else None
+        guess = last is not None and last <= MAX_CAP
         if guess:
-            cap = min(65472, max(1024, (int(last * 1.3) + 63) // 64 * 64))
+            cap = min(MAX_CAP, max(1024, (int(last * 1.3) + 63) // 64 * 64))
             out_cap, ws_bytes, ws, dets, labels = buffers(cap)
         _C.check(L.r3det_mcnms_select(_C.ptr(boxes), _C.ptr(scores), B, n, K, float(score_thr), _C.ptr(cand_row),
                                       _C.ptr(cand_label), _C.ptr(cand_score), _C.ptr(cand_rank), _C.ptr(counts),
@@ -133,11 +156,12 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
         for _ in (0, 1):
             if not guess:
                 m = int(counts.max().item())
-                _last_max[key] = m
+                if hint is not None:
+                    hint.put(key, m)
                 if m == 0:
                     return [(multi_bboxes.new_zeros((0, 6)), multi_bboxes.new_zeros((0, ), dtype=torch.long))
                             for _ in range(B)]
-                if m >= 65536:  # beyond the pair-queue encoding: per-image operators
+                if m > MAX_CAP:  # beyond the pair-queue encoding (cap = ceil64(m) must stay < 65536)
                     return [multiclass_nms_rotated(multi_bboxes[i], multi_scores[i], score_thr, nms, max_num)
                             for i in range(B)]
                 cap = (m + 63) // 64 * 64
@@ -148,7 +172,8 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
                                    _C.stream()), "r3det_mcnms")
             both = kc.tolist()
             kept, m = both[:B], max(both[B:])
-            _last_max[key] = m
+            if hint is not None:
+                hint.put(key, m)
             if m <= cap:
                 break
             guess = False  # more candidates than guessed: once more with the exact size

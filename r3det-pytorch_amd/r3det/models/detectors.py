@@ -55,7 +55,8 @@ class R3Det(nn.Module):
     def simple_test(self, img):
         boxes, scores = self.dense_test(img)
         cfg = self.test_cfg
-        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'],
+                                            hint=self.refine_head[-1].nms_hint)
 
     @torch.no_grad()
     def dense_test(self, img):
@@ -106,7 +107,8 @@ class GraphedDense:
     def simple_test(self, img):
         boxes, scores = self(img)
         cfg = self.model.test_cfg
-        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'],
+                                            hint=self.model.refine_head[-1].nms_hint)
 
 
 def build_detector(cfg):

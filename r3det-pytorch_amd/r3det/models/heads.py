@@ -9,7 +9,7 @@ import math
 import torch
 import torch.nn as nn
 
-from ..core.post_processing import multiclass_nms_rotated_batch
+from ..core.post_processing import CapacityHint, multiclass_nms_rotated_batch
 from ..ops import fr_boxes
 from .backbone import ConvModule
 from .coder import delta2bbox_v1
@@ -54,6 +54,7 @@ class RRetinaHead(nn.Module):
         self.retina_cls = nn.Conv2d(feat_channels, num_anchors * num_classes, 3, padding=1)
         self.retina_reg = nn.Conv2d(feat_channels, num_anchors * 5, 3, padding=1)
         self._anchor_cache = {}
+        self.nms_hint = CapacityHint()  # this head's own workspace-size memory for the batched NMS
         self.init_weights()
 
     def init_weights(self):
@@ -123,7 +124,8 @@ class RRetinaHead(nn.Module):
         rotate_retina_refine_head.py:147-196).  Returns [(dets (k,6), labels (k,))] per image."""
         cfg = cfg or self.test_cfg
         boxes, scores = self.decode_bboxes(cls_scores, bbox_preds, img_shape, cfg, rois)
-        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'],
+                                            hint=self.nms_hint)
 
     def decode_bboxes(self, cls_scores, bbox_preds, img_shape, cfg=None, rois=None):
         """The shape-static part of get_bboxes (everything before the NMS, whose sizes depend on the

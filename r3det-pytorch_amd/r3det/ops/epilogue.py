@@ -30,6 +30,8 @@ def bias_act_(y, bias, residual=None, relu=True):
                                              _C.stream())
             if rc == 0:
                 return y
+            if rc != -1:  # R3DET_EINVAL = shape not taken; anything else is a real failure
+                _C.check(rc, "r3det_bias_act")
     y.add_(bias.view(1, -1, 1, 1))
     if residual is not None:
         y.add_(residual)

@@ -20,6 +20,16 @@ profile_events = None
 PROFILE_MIN_HW = 128 * 128
 
 
+def _taken(rc, what):
+    """Split-form entry points answer R3DET_EINVAL (-1) for shapes they do not take (nothing was launched:
+    the caller uses the general form); any other non-zero code is a real failure and raises."""
+    if rc == 0:
+        return True
+    if rc == -1:
+        return False
+    _C.check(rc, what)
+
+
 def fr_forward(features, best_rbboxes, spatial_scale, points, output):
     """feature_refine_cuda.forward (feature_refine_cuda.cpp:24-42): fills ``output``, returns 1."""
     f = _C.need_hip(features, "features")
@@ -96,7 +106,7 @@ def fr_forward_prepared(features, table, output):
     with torch.cuda.device(f.device):
         rc = _C.lib().r3det_feature_refine_forward_prepared(_C.ptr(f), _C.ptr(table), N, C, H, W, _C.ptr(o),
                                                             _C.stream())
-    return rc == 0
+    return _taken(rc, "fr_forward_prepared")
 
 
 def fr_module_prepared(mixed_a, mixed_b, residual, table, output):
@@ -113,7 +123,7 @@ def fr_module_prepared(mixed_a, mixed_b, residual, table, output):
     with torch.cuda.device(a.device):
         rc = _C.lib().r3det_feature_refine_module_prepared(_C.ptr(a), _C.ptr(b), _C.ptr(r), _C.ptr(table), N, C, H,
                                                            W, _C.ptr(o), _C.stream())
-    return rc == 0
+    return _taken(rc, "fr_module_prepared")
 
 
 def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, overwrite=False):
@@ -161,7 +171,7 @@ def fr_backward_prepare_async(best_rbboxes, N, H, W, spatial_scale):
         import ctypes
         rc = L.r3det_feature_refine_backward_prepare(_C.ptr(b), N, H, W, float(spatial_scale), _C.ptr(ws), wsb,
                                                      ctypes.c_void_p(side.cuda_stream))
-        if rc != 0:
+        if not _taken(rc, "fr_backward_prepare"):
             return None
         ev = torch.cuda.Event()
         ev.record(side)
@@ -181,7 +191,7 @@ def fr_backward_prepared(top_grad, best_rbboxes, spatial_scale, bottom_grad, pac
         rc = _C.lib().r3det_feature_refine_backward_prepared(_C.ptr(g), _C.ptr(best_rbboxes), N, C, H, W,
                                                              float(spatial_scale), _C.ptr(bottom_grad), _C.ptr(ws),
                                                              ws.numel(), _C.stream())
-    return rc == 0
+    return _taken(rc, "fr_backward_prepared")
 
 
 class FeatureRefineFunction(Function):
@@ -275,15 +285,13 @@ class FeatureRefineModule(nn.Module):
                   for f, b, fr in zip(x, per_level, self.fr)]
         out = []
         for feat, boxes, fr, table in zip(x, per_level, self.fr, tables):
-            # The sampler reads NCHW planes: in a channels_last pipeline the module switches layout
-            # once, at its input, so that its three convolutions already produce what FR consumes
-            # (a no-op for NCHW callers, like the reference).
             # The sampler reads NCHW planes.  The three convolutions run in whatever layout the module's
             # weights are in (a channels_last module on channels_last features: no layout switch inside
             # MIOpen); their outputs and the residual are made NCHW here (no-ops for NCHW callers, like the
             # reference).
-            infer = table is not None and not (torch.is_grad_enabled() and
-                                               (feat.requires_grad or self.conv_1_1.weight.requires_grad))
+            # the fused forward-only launches build no autograd graph: only when nothing here can need a gradient
+            infer = table is not None and not (torch.is_grad_enabled() and (
+                feat.requires_grad or any(p.requires_grad for p in self.parameters())))
             if infer and feat.is_cuda and feat.is_contiguous(memory_format=torch.channels_last) \
                     and not feat.is_contiguous():
                 # channels_last inference: the two convolutions' bias adds, their sum and the layout switch in

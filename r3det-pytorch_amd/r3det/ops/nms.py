@@ -82,18 +82,28 @@ def ml_nms_rotated(dets, scores, labels, iou_threshold):
                     cnt, st))
 
 
+# mmcv 1.3.15..1.5.0's rotated NMS kernel copies the label column (stride-6 rows when ``labels`` is given)
+# but its pair test ``single_box_iou_rotated(cur_box, block_boxes + i * 6, 0)`` reads the five box
+# values only: with or without labels the suppression is CLASS-AGNOSTIC.  Restated from memory of the
+# mmcv sources (they are not under the reference tree; parity UNPINNED).  True = use the label
+# guard of the in-tree ml_nms_rotated instead (boxes of different labels never suppress each other).
+MMCV_LABEL_GUARD = False
+
+
 def nms_rotated(dets, scores, iou_threshold, labels=None):
-    """Stand-in for ``mmcv.ops.nms_rotated``: returns (cat(dets[keep], scores[keep]), keep).
+    """Stand-in for ``mmcv.ops.nms_rotated``: returns (cat(dets[keep], scores[keep]), keep), keep in
+    score order.
 
     mmcv is outside the reference tree (pinned only as 1.3.15..1.5.0); semantics restated from
-    its call site bbox_nms_rotated.py:86-95 and the in-tree ml_nms_rotated sources.
+    its call site bbox_nms_rotated.py:86-95, the in-tree ml_nms_rotated sources (geometry) and the
+    note on ``MMCV_LABEL_GUARD`` above (labels are accepted and, by default, have no effect).
     """
     if dets.shape[0] == 0:
         return dets, None
     dets_c = _C.need_hip(dets.contiguous(), "dets")
     scores_c = _C.need_hip(scores.contiguous(), "scores")
     lab = None
-    if labels is not None:
+    if labels is not None and MMCV_LABEL_GUARD:
         lab = labels.to(device=dets.device, dtype=torch.int64).contiguous()
     n = dets_c.size(0)
     order = _order(scores_c)

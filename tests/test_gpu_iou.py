@@ -21,7 +21,8 @@ def dev(a):
 
 
 def run(geom, a, b, iof=False):
-    from r3det.ops import box_iou_rotated, rbbox_iou
+    from r3det.ops import rbbox_iou
+    from r3det.ops.mmcv_ops import box_iou_rotated
     from r3det.ops.iou import box_iou_rotated_v3
     if geom == O.V1:
         return rbbox_iou(dev(a), dev(b), False, iof).cpu().numpy()
@@ -130,7 +131,8 @@ def test_transpose_consistency_v3():
 
 @pytest.mark.parametrize("geom", [O.V1, O.V2, O.V3])
 def test_vec_kernels(geom):
-    from r3det.ops import box_iou_rotated, obb_overlaps, rbbox_iou
+    from r3det.ops import obb_overlaps, rbbox_iou
+    from r3det.ops.mmcv_ops import box_iou_rotated
     a, b = rand_boxes(1000, 31, span=120.0), rand_boxes(1000, 32, span=120.0)
     with O.twin():
         want = O.iou_vec(geom, a, b)

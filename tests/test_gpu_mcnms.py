@@ -167,12 +167,39 @@ def test_guessed_workspace_size_is_checked_and_redone(nms_type):
     counts are read at the end: a batch with 9 x more candidates than the last one must come out right
     (the library clamps to the guessed capacity, the wrapper notices and runs again), and so must a
     much smaller one."""
-    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    from r3det.core.post_processing import CapacityHint, multiclass_nms_rotated_batch
     cfg = dict(type=nms_type, iou_thr=0.1)
+    hint = CapacityHint()
     boxes, scores = pools(2, 1200, 41)
     few = scores.clone()
     few[:, 100:] = 0.0
     many = scores.clone()
     many[:, :, :-1] = many[:, :, :-1].clamp(min=0.06)
     for s in (few, many, few, scores, many):
-        same(multiclass_nms_rotated_batch(boxes, s, 0.05, cfg, 300), boxes, s, 0.05, cfg, 300)
+        same(multiclass_nms_rotated_batch(boxes, s, 0.05, cfg, 300, hint=hint), boxes, s, 0.05, cfg, 300)
+    assert len(hint._last) == 1
+
+
+@pytest.mark.parametrize("m_target", [65472, 65500, 65535, 65600])
+def test_pool_at_the_capacity_edge(m_target):
+    """ADVICE r1: candidate counts in 65473..65535 round up to cap = 65536, which the library refuses;
+    the wrapper must take the per-image path from 65473 on and the batched path up to 65472, with and
+    without a capacity hint.  Boxes sit on a sparse grid (no overlaps) so that the 65 k-box NMS is cheap."""
+    from r3det.core.post_processing import CapacityHint, multiclass_nms_rotated_batch
+    n, C = 4400, 15
+    g = torch.Generator().manual_seed(m_target)
+    ij = torch.arange(n)
+    boxes = torch.stack([(ij % 70) * 40.0 + 5, (ij // 70) * 40.0 + 5, torch.full((n,), 12.0),
+                         torch.full((n,), 8.0), -torch.rand(n, generator=g)], 1)
+    scores = torch.zeros(n, C + 1)
+    flat = torch.randperm(n * C, generator=g)[:m_target]
+    scores.view(-1)[(flat // C) * (C + 1) + flat % C] = 0.06 + 0.9 * torch.rand(m_target, generator=g)
+    boxes, scores = boxes.cuda()[None].repeat(2, 1, 1), scores.cuda()[None].repeat(2, 1, 1)
+    scores[1, :, :] = 0
+    scores[1, :50, 0] = 0.5
+    assert int((scores[0, :, :-1] > 0.05).sum()) == m_target
+    hint = CapacityHint()
+    for h in (None, hint, hint):
+        out = multiclass_nms_rotated_batch(boxes, scores, 0.05, CFG, 2000, hint=h)
+        assert out[0][0].shape == (2000, 6) and out[1][0].shape == (50, 6)
+    same(out, boxes, scores, 0.05, CFG, 2000)

@@ -54,7 +54,8 @@ def test_dense_single_class(nms_impl):
                                     (1000, 400.), (2000, 600.), (5344, 1000.)])
 @pytest.mark.parametrize("thr", [0.1, 0.5])
 def test_keep_exact_vs_twin(n, span, thr, nms_impl):
-    from r3det.ops import ml_nms_rotated, nms_rotated, obb_nms, rnms
+    from r3det.ops import ml_nms_rotated, obb_nms, rnms
+    from r3det.ops.mmcv_ops import nms_rotated
     b, s, lab = case(n, 300 + n, span)
     d6 = np.hstack([b, s[:, None]])
     with O.twin():
@@ -70,11 +71,19 @@ def test_keep_exact_vs_twin(n, span, thr, nms_impl):
     assert np.array_equal(k3.cpu().numpy(), w3)
     k2 = ml_nms_rotated(dev(b), dev(s), dev(lab), thr)
     assert np.array_equal(k2.cpu().numpy(), w2)
+    from r3det.ops import nms as nms_mod
+    # mmcv stand-in: labels are carried but (as recalled from mmcv 1.3.15..1.5.0) not compared
     dm, km = nms_rotated(dev(b), dev(s), thr, dev(lab))
-    assert np.array_equal(km.cpu().numpy(), w2)
-    assert np.array_equal(dm.cpu().numpy(), np.hstack([b[w2], s[w2, None]]))
+    assert np.array_equal(km.cpu().numpy(), w2n)
+    assert np.array_equal(dm.cpu().numpy(), np.hstack([b[w2n], s[w2n, None]]))
     dm, km = nms_rotated(dev(b), dev(s), thr)
     assert np.array_equal(km.cpu().numpy(), w2n)
+    nms_mod.MMCV_LABEL_GUARD = True  # opt-in: the ml_nms_rotated guard
+    try:
+        dm, km = nms_rotated(dev(b), dev(s), thr, dev(lab))
+    finally:
+        nms_mod.MMCV_LABEL_GUARD = False
+    assert np.array_equal(km.cpu().numpy(), w2)
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 500, 2000, 8576])
@@ -178,6 +187,10 @@ def np_multiclass(version, mb, ms, score_thr, iou_thr, max_num):
         sh[:, :2] = sh[:, :2] + off[:, None].astype(np.float32)
         with O.twin():
             keep = O.nms(O.V3, sh, sc, iou_thr, strict=True)
+    elif version == 'mmcv':  # class-agnostic v2 geometry (ops/nms.py: MMCV_LABEL_GUARD)
+        with O.twin():
+            keep = O.nms(O.V2, boxes, sc, iou_thr, strict=True)
+        return np.hstack([boxes[keep], sc[keep, None]]), labels[keep]
     else:
         bl = np.hstack([boxes, labels[:, None].astype(np.float32)])
         with O.twin():
@@ -218,7 +231,7 @@ def test_multiclass_mmcv_branch():
     ms = (np.random.default_rng(94).uniform(0, 1, (n, C + 1)) ** 12).astype(np.float32)
     dets, labels, inds = multiclass_nms_rotated(dev(mb), dev(ms), 0.05, dict(type='mmcv', iou_thr=0.1), 100,
                                                 return_inds=True)
-    wd, wl = np_multiclass('v2', mb, ms, 0.05, 0.1, 10 ** 9)
+    wd, wl = np_multiclass('mmcv', mb, ms, 0.05, 0.1, 10 ** 9)
     assert np.array_equal(dets.cpu().numpy(), wd[:100])
     assert np.array_equal(labels.cpu().numpy(), wl[:100])
     assert (np.diff(dets[:, 5].cpu().numpy()) <= 0).all()

@@ -237,6 +237,15 @@ def test_fused_inference_model_gpu(channels_last):
                     ref = ref.relu()
                 out = bias_act_(y.clone(memory_format=torch.preserve_format), b, res, relu)
                 assert torch.equal(out, ref)
+        # non-finite activations must surface, exactly as through F.relu
+        bad = y.clone(memory_format=torch.preserve_format)
+        bad.view(-1)[::7] = float('nan')
+        bad.view(-1)[1::11] = float('inf')
+        bad.view(-1)[2::13] = float('-inf')
+        want_bad = (bad + b.view(1, -1, 1, 1)).relu()
+        got_bad = bias_act_(bad.clone(memory_format=torch.preserve_format), b, None, True)
+        assert torch.equal(torch.isnan(got_bad), torch.isnan(want_bad)) and bool(torch.isnan(got_bad).any())
+        assert torch.equal(torch.nan_to_num(got_bad, nan=-1.0), torch.nan_to_num(want_bad, nan=-1.0))
 
 
 @pytest.mark.gpu

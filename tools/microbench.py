@@ -40,7 +40,8 @@ def time_variants(variants, rounds=7, reps=10):
 
 
 def bench_iou():
-    from r3det.ops import box_iou_rotated, rbbox_iou
+    from r3det.ops import rbbox_iou
+    from r3det.ops.mmcv_ops import box_iou_rotated
     from r3det.ops.iou import box_iou_rotated_v3
     dev = torch.device("cuda")
     anchors = syn.anchor_grid(device=dev)
