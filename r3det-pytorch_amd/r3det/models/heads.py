@@ -1,50 +1,76 @@
 """Rotated RetinaNet heads (models/dense_heads/rotate_retina_head.py,
-rotate_retina_refine_head.py, rotate_anchor_head.py) -- inference side + box selection.
+rotate_retina_refine_head.py, rotate_anchor_head.py): inference side, box selection for the FR
+sampler, and the training side (targets from the fused assignment, focal + smooth-L1 losses).
 
 The per-image / per-level Python loops of the reference are batched over images here (one
 topk / gather / decode per level for the whole batch); the results per image are identical.
+The training targets are built with masks instead of index lists (no ``nonzero``: nothing in
+``loss`` synchronises with the host), which gives the same tensors as the reference's
+``_get_targets_single`` (rotate_anchor_head.py:172-277) for its PseudoSampler configuration.
 """
 import math
 
 import torch
 import torch.nn as nn
 
+from ..core.anchor import RAnchorGenerator, ranchor_inside_flags
+from ..core.bbox.assigners import MaxIoUAssigner
+from ..core.bbox.coder import DeltaXYWHAOBBoxCoder
+from ..core.bbox.rtransforms import obb2hbb
 from ..core.post_processing import CapacityHint, multiclass_nms_rotated_batch
 from ..ops import fr_boxes
 from .backbone import ConvModule
 from .coder import delta2bbox_v1
+from .losses import build_loss
+
+S0_TRAIN_CFG = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0,
+                                  ignore_iof_thr=-1, iou_calculator=dict(type='RBboxOverlaps2D_v1')),
+                    allowed_border=-1, pos_weight=-1, debug=False)
+SR_TRAIN_CFG = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.6, neg_iou_thr=0.5, min_pos_iou=0,
+                                  ignore_iof_thr=-1, iou_calculator=dict(type='RBboxOverlaps2D_v1')),
+                    allowed_border=-1, pos_weight=-1, debug=False)
+
+
+def build_assigner(cfg):
+    cfg = dict(cfg)
+    typ = cfg.pop('type')
+    if typ != 'MaxIoUAssigner':
+        raise KeyError(f'assigner {typ!r}: only MaxIoUAssigner is used by the rotated configs')
+    return MaxIoUAssigner(**cfg)
 
 
 def level_anchors(featmap_size, stride, device, octave_base_scale=4, scales_per_octave=3,
                   ratios=(1.0, 0.5, 2.0)):
-    """RAnchorGenerator.single_level_grid_priors (core/anchor/ranchor_generator.py:11-39) on
-    top of mmdet's AnchorGenerator: (H*W*9, 5) as (cx, cy, w, h, 0), position-major."""
-    H, W = featmap_size
-    scales = torch.tensor([octave_base_scale * 2 ** (i / scales_per_octave) for i in range(scales_per_octave)])
-    r = torch.tensor(ratios)
-    h_r, w_r = r.sqrt(), 1 / r.sqrt()
-    ws = (stride * w_r[:, None] * scales[None, :]).reshape(-1)
-    hs = (stride * h_r[:, None] * scales[None, :]).reshape(-1)
-    ys, xs = torch.meshgrid(torch.arange(H) * stride, torch.arange(W) * stride, indexing='ij')
-    A = ws.numel()
-    a = torch.zeros(H * W, A, 5)
-    a[:, :, 0] = xs.reshape(-1, 1)
-    a[:, :, 1] = ys.reshape(-1, 1)
-    a[:, :, 2] = ws
-    a[:, :, 3] = hs
-    return a.reshape(-1, 5).to(device)
+    """One level of RAnchorGenerator (core/anchor/ranchor_generator.py): (H*W*9, 5) as
+    (cx, cy, w, h, 0), position-major."""
+    gen = RAnchorGenerator([stride], list(ratios), octave_base_scale=octave_base_scale,
+                           scales_per_octave=scales_per_octave)
+    return gen.single_level_grid_priors(featmap_size, 0, device=device)
 
 
 class RRetinaHead(nn.Module):
     """4 x (3x3 conv + ReLU) towers, 9 anchors / position (rotate_retina_head.py:51-115)."""
 
     def __init__(self, num_classes=15, in_channels=256, stacked_convs=4, feat_channels=256, num_anchors=9,
-                 strides=(8, 16, 32, 64, 128), test_cfg=None):
+                 strides=(8, 16, 32, 64, 128), test_cfg=None, train_cfg=None, assign_by_circumhbbox='v1',
+                 bbox_coder=None, loss_cls=None, loss_bbox=None):
         super().__init__()
         self.num_classes, self.num_anchors, self.strides = num_classes, num_anchors, strides
         self.cls_out_channels = num_classes  # use_sigmoid_cls
         self.test_cfg = test_cfg or dict(nms_pre=2000, min_bbox_size=0, score_thr=0.05,
                                          nms=dict(iou_thr=0.1), max_per_img=2000)
+        # training side (rotate_anchor_head.py:33-98); defaults = configs/r3det/r3det_r50_fpn_1x_dota_v1.py
+        self.train_cfg = dict(train_cfg) if train_cfg is not None else dict(S0_TRAIN_CFG)
+        self.assign_by_circumhbbox = assign_by_circumhbbox
+        self.assigner = build_assigner(self.train_cfg['assigner'])
+        coder_cfg = dict(bbox_coder or dict(type='DeltaXYWHAOBBoxCoder'))
+        assert coder_cfg.pop('type') == 'DeltaXYWHAOBBoxCoder'
+        self.bbox_coder = DeltaXYWHAOBBoxCoder(**coder_cfg)
+        self.loss_cls = build_loss(loss_cls or dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25,
+                                                    loss_weight=1.0))
+        self.loss_bbox = build_loss(loss_bbox or dict(type='SmoothL1Loss', beta=0.11, loss_weight=1.0))
+        self.anchor_generator = RAnchorGenerator(list(strides), [1.0, 0.5, 2.0], octave_base_scale=4,
+                                                 scales_per_octave=3)
         self.cls_convs = nn.ModuleList()
         self.reg_convs = nn.ModuleList()
         for i in range(stacked_convs):
@@ -79,10 +105,97 @@ class RRetinaHead(nn.Module):
         return [o[0] for o in outs], [o[1] for o in outs]
 
     def anchors(self, featmap_sizes, device):
-        key = (tuple(map(tuple, featmap_sizes)), str(device))
-        if key not in self._anchor_cache:
-            self._anchor_cache[key] = [level_anchors(fs, s, device) for fs, s in zip(featmap_sizes, self.strides)]
-        return self._anchor_cache[key]
+        return self.anchor_generator.grid_priors([tuple(fs) for fs in featmap_sizes], device=device)
+
+    # ------------------------------------------------------------------ training
+    def get_anchors(self, featmap_sizes, img_metas, device):
+        """list[img] of list[lvl] anchors (shared) and, per image, whether every anchor is valid /
+        the valid flags (rotate_anchor_head.py:143-170).  The flags follow from the padded shape, so
+        the all-valid case is decided on the host."""
+        lvl = self.anchors(featmap_sizes, device)
+        flags = []
+        for meta in img_metas:
+            h, w = meta['pad_shape'][:2]
+            full = all(min(math.ceil(h / s), fh) == fh and min(math.ceil(w / s), fw) == fw
+                       for (fh, fw), s in zip(featmap_sizes, self.strides))
+            flags.append(None if full else torch.cat(self.anchor_generator.valid_flags(
+                [tuple(fs) for fs in featmap_sizes], meta['pad_shape'], device=device)))
+        return [lvl for _ in img_metas], flags
+
+    def _targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta):
+        """rotate_anchor_head.py:172-277 for one image, PseudoSampler configuration: every assigned
+        anchor is a positive, every anchor with gt_inds == 0 a negative.  Returns labels (n,),
+        label_weights (n,), bbox_targets (n, 5), bbox_weights (n, 5), number of positives (0-dim)."""
+        n_all = flat_anchors.size(0)
+        inside = None
+        border = self.train_cfg.get('allowed_border', -1)
+        if valid_flags is not None or border >= 0:
+            vf = valid_flags if valid_flags is not None else flat_anchors.new_ones(n_all, dtype=torch.bool)
+            inside = ranchor_inside_flags(flat_anchors, vf, img_meta['img_shape'][:2], border)
+        anchors = flat_anchors if inside is None else flat_anchors[inside]
+        gt_bboxes = gt_bboxes.to(flat_anchors.dtype)
+        gt_assign = gt_bboxes
+        if self.assign_by_circumhbbox is not None and gt_bboxes.size(0) > 0:
+            gt_assign = obb2hbb(gt_bboxes, self.assign_by_circumhbbox)
+        res = self.assigner.assign(anchors, gt_assign, None, gt_labels)
+        gt_inds = res.gt_inds
+        pos = gt_inds > 0
+        n = anchors.size(0)
+        if gt_bboxes.size(0) > 0:
+            idx = (gt_inds - 1).clamp(min=0)
+            enc = self.bbox_coder.encode(anchors, gt_bboxes[idx])
+            bbox_targets = torch.where(pos[:, None], enc, torch.zeros_like(enc))
+            labels = torch.where(pos, gt_labels[idx], torch.full_like(gt_inds, self.num_classes))
+        else:
+            bbox_targets = torch.zeros_like(anchors)
+            labels = gt_inds.new_full((n,), self.num_classes)
+        bbox_weights = pos[:, None].to(anchors.dtype).expand(n, 5)
+        label_weights = (gt_inds >= 0).to(anchors.dtype)
+        pw = self.train_cfg.get('pos_weight', -1)
+        if pw > 0:
+            label_weights = torch.where(pos, label_weights.new_tensor(float(pw)), label_weights)
+        if inside is not None:  # unmap (:262-272)
+            def unmap(t, fill=0):
+                out = t.new_full((n_all,) + t.shape[1:], fill)
+                out[inside] = t
+                return out
+            labels, label_weights = unmap(labels, self.num_classes), unmap(label_weights)
+            bbox_targets, bbox_weights = unmap(bbox_targets), unmap(bbox_weights)
+        return labels, label_weights, bbox_targets, bbox_weights, pos.sum()
+
+    def get_targets(self, anchor_list, valid_flag_list, gt_bboxes_list, img_metas, gt_labels_list):
+        """rotate_anchor_head.py:279-377: per level (N, n_l[, 5]) targets and
+        ``num_total_pos = sum_i max(#pos_i, 1)`` (a device scalar)."""
+        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        per_img = [self._targets_single(torch.cat(anchor_list[i]), valid_flag_list[i], gt_bboxes_list[i],
+                                        gt_labels_list[i], img_metas[i]) for i in range(len(img_metas))]
+        labels, label_w, bbox_t, bbox_w = (torch.stack([r[k] for r in per_img]) for k in range(4))
+        num_total_pos = torch.stack([r[4] for r in per_img]).clamp(min=1).sum()
+        split = lambda t: list(t.split(num_level_anchors, dim=1))  # noqa: E731  (images_to_levels)
+        return split(labels), split(label_w), split(bbox_t), split(bbox_w), num_total_pos
+
+    def loss_single(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, num_total_samples):
+        """rotate_anchor_head.py:379-427 (reg_decoded_bbox=False)."""
+        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
+        loss_cls = self.loss_cls(cls_score, labels.reshape(-1), label_weights.reshape(-1),
+                                 avg_factor=num_total_samples)
+        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, 5)
+        loss_bbox = self.loss_bbox(bbox_pred, bbox_targets.reshape(-1, 5), bbox_weights.reshape(-1, 5),
+                                   avg_factor=num_total_samples)
+        return loss_cls, loss_bbox
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+        """rotate_anchor_head.py:429-497 -> dict(loss_cls=[per level], loss_bbox=[per level]); the head
+        outputs are taken in fp32 (``force_fp32``)."""
+        featmap_sizes = [f.shape[-2:] for f in cls_scores]
+        assert len(featmap_sizes) == len(self.strides)
+        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, cls_scores[0].device)
+        labels, label_w, bbox_t, bbox_w, num_total_pos = self.get_targets(anchor_list, valid_flag_list, gt_bboxes,
+                                                                        img_metas, gt_labels)
+        avg = num_total_pos.to(torch.float32)
+        out = [self.loss_single(c.float(), r.float(), la, lw, bt, bw, avg)
+               for c, r, la, lw, bt, bw in zip(cls_scores, bbox_preds, labels, label_w, bbox_t, bbox_w)]
+        return dict(loss_cls=[o[0] for o in out], loss_bbox=[o[1] for o in out])
 
     @torch.no_grad()
     def filter_bboxes(self, cls_scores, bbox_preds):
@@ -162,8 +275,33 @@ class RRetinaRefineHead(RRetinaHead):
     (rotate_retina_refine_head.py:20-196)."""
 
     def __init__(self, num_classes=15, in_channels=256, stacked_convs=4, feat_channels=256,
-                 strides=(8, 16, 32, 64, 128), test_cfg=None):
-        super().__init__(num_classes, in_channels, stacked_convs, feat_channels, 1, strides, test_cfg)
+                 strides=(8, 16, 32, 64, 128), test_cfg=None, train_cfg=None, assign_by_circumhbbox=None, **kwargs):
+        super().__init__(num_classes, in_channels, stacked_convs, feat_channels, 1, strides, test_cfg,
+                         train_cfg if train_cfg is not None else SR_TRAIN_CFG, assign_by_circumhbbox, **kwargs)
+        self.bboxes_as_anchors = None
+
+    def get_anchors(self, featmap_sizes, img_metas, device):
+        """The previous stage's boxes are the anchors (rotate_retina_refine_head.py:99-125); the
+        PseudoAnchorGenerator only supplies valid flags (one per position)."""
+        anchor_list = [[b.detach() for b in per_img] for per_img in self.bboxes_as_anchors]
+        flags = []
+        for meta in img_metas:
+            h, w = meta['pad_shape'][:2]
+            full = all(min(math.ceil(h / s), fh) == fh and min(math.ceil(w / s), fw) == fw
+                       for (fh, fw), s in zip(featmap_sizes, self.strides))
+            if full:
+                flags.append(None)
+            else:
+                per = self.anchor_generator.valid_flags([tuple(fs) for fs in featmap_sizes], meta['pad_shape'],
+                                                        device=device)
+                flags.append(torch.cat([f[::9] for f in per]))
+        return anchor_list, flags
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, rois=None, gt_bboxes_ignore=None):
+        """rotate_retina_refine_head.py:127-145."""
+        assert rois is not None
+        self.bboxes_as_anchors = rois
+        return super().loss(cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore)
 
     @torch.no_grad()
     def refine_bboxes(self, cls_scores, bbox_preds, rois):

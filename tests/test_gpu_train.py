@@ -1,0 +1,141 @@
+"""GPU: the training step of BASELINE configs[4] on the device -- R3Det.forward_train with the fused
+assignment (r3det_rbbox_assign), the FR sampler forward and its packed backward in context.
+
+* assignment of both stages == the dense MaxIoUAssigner rules on the full overlap matrix
+* losses finite; the step's targets == the CPU stand-in path's on the same head outputs
+* FRM-convolution gradients with the packed FR backward == those with the generic (global-atomic)
+  backward kernel, 1e-5 relative
+* RRetinaNet (configs[1]'s model) takes the same step
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def batch(n, size, n_gt, seed, device):
+    from r3det import synthetic as syn
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(n, 3, size, size, generator=g).to(device)
+    gtb = [syn.dota_like_rboxes(n_gt, seed * 10 + i, size=size, wmax=size * 0.3).to(device) for i in range(n)]
+    gtl = [torch.randint(0, 15, (n_gt,), generator=g).to(device) for _ in range(n)]
+    return img, gtb, gtl
+
+
+@pytest.fixture(scope="module")
+def model():
+    from r3det.models import R3Det
+    torch.manual_seed(5)
+    return R3Det().train().cuda()
+
+
+def test_stage_assignments_equal_dense_rules(model):
+    """s0 on obb2hbb(gt) x 196 416 anchors, refine stage on gt x 21 824 refined boxes (1024^2 input sizes)."""
+    from r3det import synthetic as syn
+    from r3det.core import obb2hbb
+    dev = torch.device('cuda')
+    gt = syn.dota_like_rboxes(128, 3, device=dev)
+    anchors = torch.cat(model.bbox_head.anchors([(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)], dev))
+    assert anchors.shape == (196416, 5)
+    rois = torch.cat([syn.fr_level_boxes(1, 1024 // s, 1024 // s, s, 50 + i, device=dev)
+                      for i, s in enumerate(syn.STRIDES)])
+    assert rois.shape == (21824, 5)
+    labels = torch.randint(0, 15, (128,), device=dev)
+    for head, boxes, g in ((model.bbox_head, anchors, obb2hbb(gt, 'v1')), (model.refine_head[0], rois, gt)):
+        a = head.assigner
+        fused = a.assign(boxes, g, None, labels)
+        dense = a.assign_wrt_overlaps(a.iou_calculator(g, boxes), labels)
+        assert torch.equal(fused.gt_inds, dense.gt_inds)
+        assert torch.equal(fused.labels, dense.labels)
+        assert torch.equal(fused.max_overlaps, dense.max_overlaps)
+        assert int((fused.gt_inds > 0).sum()) > 0
+
+
+def test_forward_train_full_size_finite_and_frm_grads_match_generic_backward(model):
+    """batch 2 x 1024^2, 128 GT per image."""
+    from r3det import _C
+    from r3det.models.detectors import parse_losses
+    img, gtb, gtl = batch(2, 1024, 128, 11, 'cuda')
+    grads = {}
+    for impl in (0, 1):  # 0: automatic (packed backward at 128^2 / 64^2); 1: generic kernels (global atomics)
+        model.zero_grad(set_to_none=True)
+        _C.set_option("fr_impl", impl)
+        try:
+            losses = model(img, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
+            loss, log_vars = parse_losses(losses)
+            loss.backward()
+        finally:
+            _C.set_option("fr_impl", 0)
+        assert sorted(losses) == ['s0.loss_bbox', 's0.loss_cls', 'sr0.loss_bbox', 'sr0.loss_cls']
+        assert bool(torch.isfinite(loss)) and float(loss.detach()) > 0
+        frm = model.feat_refine_module[0]
+        grads[impl] = {n: p.grad.clone() for n, p in frm.named_parameters()}
+        grads[impl]['neck'] = model.neck.fpn_convs[0].conv.weight.grad.clone()
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all())
+                   for p in model.parameters() if p.requires_grad)
+    for n in grads[0]:
+        scale = float(grads[1][n].abs().max())
+        assert scale > 0
+        assert float((grads[0][n] - grads[1][n]).abs().max()) <= 1e-5 * scale, n
+
+
+def test_targets_on_device_equal_cpu_path():
+    """Same head outputs, same GT: the device step (fused assignment) and the CPU stand-in path (oracle IoU +
+    dense rules) give the same labels / weights and the same encoded targets."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cpu_standins import cpu_kernels
+    from r3det.models.heads import RRetinaHead
+    head = RRetinaHead()
+    g = torch.Generator().manual_seed(3)
+    sizes = [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)]
+    from r3det import synthetic as syn
+    gtb = [syn.dota_like_rboxes(20, 70 + i, size=256, wmax=90.0) for i in range(2)]
+    gtl = [torch.randint(0, 15, (20,), generator=g) for _ in range(2)]
+    metas = [dict(img_shape=(256, 256, 3), pad_shape=(256, 256, 3)) for _ in range(2)]
+    with cpu_kernels():
+        al, fl = head.get_anchors(sizes, metas, 'cpu')
+        want = head.get_targets(al, fl, gtb, metas, gtl)
+    al, fl = head.get_anchors(sizes, metas, torch.device('cuda'))
+    got = head.get_targets(al, fl, [b.cuda() for b in gtb], metas, [l.cuda() for l in gtl])
+    assert int(got[4]) == int(want[4]) > 0
+    for l in range(5):
+        assert torch.equal(got[0][l].cpu(), want[0][l]) and torch.equal(got[1][l].cpu(), want[1][l])
+        assert torch.equal(got[3][l].cpu(), want[3][l])
+        assert torch.allclose(got[2][l].cpu(), want[2][l], rtol=1e-5, atol=1e-6)
+
+
+def test_rretinanet_train_step_and_sgd_update():
+    from r3det import dist_train as dt
+    from r3det.models import RRetinaNet
+    torch.manual_seed(2)
+    m = RRetinaNet().train().cuda()
+    opt = dt.build_optimizer(m)
+    img, gtb, gtl = batch(2, 512, 40, 21, 'cuda')
+    w0 = m.bbox_head.retina_cls.weight.detach().clone()
+    l0, _ = dt.train_step(m, opt, img, gtb, gtl)
+    l1, _ = dt.train_step(m, opt, img, gtb, gtl)
+    assert bool(torch.isfinite(l0)) and bool(torch.isfinite(l1))
+    assert not torch.equal(w0, m.bbox_head.retina_cls.weight)
+    assert float(l1) < float(l0)  # two SGD steps on one batch reduce its loss
+
+
+def test_frm_training_path_not_fused_when_any_parameter_needs_grad():
+    """a frozen conv_1_1 with trainable conv_5_1 must still build the autograd graph."""
+    from r3det import synthetic as syn
+    from r3det.ops import FeatureRefineModule
+    m = FeatureRefineModule(16, [8]).cuda()
+    m.init_weights()
+    m.conv_1_1.weight.requires_grad = False
+    m.conv_1_1.bias.requires_grad = False
+    x = torch.randn(1, 16, 128, 128, device='cuda')
+    boxes = syn.fr_level_boxes(1, 128, 128, 8, 1, device='cuda')
+    out = m([x], [[boxes]])[0]
+    assert out.requires_grad
+    out.sum().backward()
+    assert m.conv_5_1.weight.grad is not None and m.conv_1_1.weight.grad is None
+    with torch.no_grad():
+        fused = m([x], [[boxes]])[0]
+    assert not fused.requires_grad and torch.equal(fused, out.detach())
