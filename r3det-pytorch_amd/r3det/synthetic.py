@@ -38,25 +38,11 @@ def dota_like_rboxes(n, seed, size=IMG, wmin=10.0, wmax=300.0, max_aspect=8.0, d
 
 def anchor_grid(size=IMG, strides=STRIDES, device='cpu'):
     """RetinaNet anchors as (cx, cy, w, h, 0): octave_base_scale 4, 3 scales, ratios [1, .5, 2];
-    position-major (y outer, x inner), anchor-minor (ratio outer, scale inner)
-    (ranchor_generator.py:11-39 on top of mmdet's AnchorGenerator)."""
-    out = []
-    for s in strides:
-        scales = torch.tensor([4 * 2 ** (i / 3) for i in range(3)], dtype=torch.float64)
-        ratios = torch.tensor([1.0, 0.5, 2.0], dtype=torch.float64)
-        h_r = ratios.sqrt()
-        w_r = 1 / h_r
-        ws = (s * w_r[:, None] * scales[None, :]).reshape(-1)
-        hs = (s * h_r[:, None] * scales[None, :]).reshape(-1)
-        f = size // s
-        ys, xs = torch.meshgrid(torch.arange(f) * s, torch.arange(f) * s, indexing='ij')
-        a = torch.zeros(f * f, 9, 5, dtype=torch.float64)
-        a[:, :, 0] = xs.reshape(-1, 1)
-        a[:, :, 1] = ys.reshape(-1, 1)
-        a[:, :, 2] = ws
-        a[:, :, 3] = hs
-        out.append(a.reshape(-1, 5))
-    return torch.cat(out).float().to(device)
+    position-major (y outer, x inner), anchor-minor (ratio outer, scale inner) -- the grid of
+    core/anchor/ranchor_generator.py (fp32 corner arithmetic of mmdet's AnchorGenerator included)."""
+    from .core.anchor import RAnchorGenerator
+    gen = RAnchorGenerator(list(strides), [1.0, 0.5, 2.0], octave_base_scale=4, scales_per_octave=3)
+    return torch.cat(gen.grid_priors([(size // s, size // s) for s in strides], device='cpu')).to(device)
 
 
 def fr_level_boxes(N, H, W, stride, seed, jitter=0.1, adversarial=False, device='cpu'):

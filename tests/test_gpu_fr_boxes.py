@@ -82,3 +82,38 @@ def test_filter_bboxes_layouts_agree(A, C):
     got = filter_bboxes(cls.contiguous(memory_format=torch.channels_last),
                         reg.contiguous(memory_format=torch.channels_last), anchors, A, C)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_producers_vs_reference_goldens(tag, channels_last):
+    """r3det_filter_bboxes against outputs of the REFERENCE's own RRetinaHead.filter_bboxes /
+    RRetinaRefineHead.refine_bboxes (tests/golden/heads.npz from make_golden_heads.py): random head maps
+    with tied anchors at some positions and dw / dh beyond the wh_ratio clip.  The anchor choice is an
+    integer decision: a wrong choice moves a box by whole anchor sizes, so the 1e-5 bar on the boxes
+    (north_star) also pins it; the fused decode differs from torch's op-by-op form by rounding of exp."""
+    import os
+
+    import numpy as np
+
+    from helpers import GOLDEN
+    G = np.load(os.path.join(GOLDEN, "heads.npz"))
+    head, ref = heads()
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+
+    def maps(prefix):
+        return [torch.from_numpy(G[f"{tag}_{prefix}_l{l}"]).cuda().contiguous(memory_format=fmt) for l in range(5)]
+    cls, reg = maps("cls"), maps("reg")
+    assert float(max(r.abs().max() for r in reg)) > 4.2  # the clip is exercised
+    rois = head.filter_bboxes(cls, reg)
+    for i in range(2):
+        for l in range(5):
+            want = torch.from_numpy(G[f"{tag}_rois_{i}_l{l}"]).cuda()
+            assert rois[i][l].shape == want.shape
+            assert torch.allclose(rois[i][l], want, rtol=1e-5, atol=1e-5), (i, l, float((rois[i][l] - want).abs().max()))
+    gold_rois = [[torch.from_numpy(G[f"{tag}_rois_{i}_l{l}"]).cuda() for l in range(5)] for i in range(2)]
+    refined = ref.refine_bboxes(maps("rcls"), maps("rreg"), gold_rois)
+    for i in range(2):
+        for l in range(5):
+            want = torch.from_numpy(G[f"{tag}_refined_{i}_l{l}"]).cuda()
+            assert torch.allclose(refined[i][l], want, rtol=1e-5, atol=1e-5), (i, l)

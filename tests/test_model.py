@@ -32,6 +32,10 @@ def test_anchor_order_matches_grid_helper():
     per_level = [level_anchors((1024 // s, 1024 // s), s, 'cpu') for s in syn.STRIDES]
     assert [a.shape[0] for a in per_level] == [147456, 36864, 9216, 2304, 576]
     assert torch.equal(torch.cat(per_level), syn.anchor_grid())
+    # an independent float64 statement of the same grid (tests/helpers.py); the generator's fp32 corner
+    # arithmetic (x +- w/2, then their difference, as mmdet does) rounds widths by up to ~1e-4
+    from helpers import anchor_grid as np_grid
+    assert torch.allclose(torch.cat(per_level), torch.from_numpy(np_grid()), rtol=0, atol=2e-4)
     a0 = per_level[0][:9]
     # ratio-major, scale-minor: first three anchors share ratio 1 (w == h), scales 4, 5.04, 6.35 x stride
     assert torch.allclose(a0[:3, 2], a0[:3, 3])
