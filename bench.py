@@ -1,26 +1,33 @@
 #!/usr/bin/env python
-"""bench.py -- R3Det R50-FPN 1024x1024 inference on MI355X with the MI355X-native rotated ops.
+"""bench.py -- R3Det R50-FPN 1024x1024 on MI355X with the MI355X-native rotated ops.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python bench.py --gpus N --steps K --warmup W [--mode infer|train|rretinanet]      (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One *step* = one full inference pass of r3det_r50_fpn_1x (v1) over a batch of 4 synthetic
-1024 x 1024 tiles per GPU (BASELINE.json configs[2]; the metric "img/s ... R3Det R50-FPN
-1024x1024" is quoted on this model, configs[3] is the same step on 8 GPUs), inputs resident
-in HBM: ResNet-50 + FPN + RRetinaHead (MIOpen convs, PyTorch-ROCm plumbing) -> filter_bboxes
--> FeatureRefineModule (FR sampler = libr3det_hip.so) -> RRetinaRefineHead -> per-image
-multiclass_nms_rotated, nms type 'v1' (libr3det_hip.so).  Nothing is skipped or cached.
-N > 1: image-parallel, every rank runs its own batch, one RCCL all_gather of the padded
-detections per step (the only exchange of the path).
+--mode infer (default; BASELINE.json's metric).  One *step* = one full inference pass of
+r3det_r50_fpn_1x (v1) over a batch of 4 synthetic 1024 x 1024 tiles per GPU (BASELINE configs[2];
+configs[3] is the same step on 8 GPUs), inputs resident in HBM: ResNet-50 + FPN + RRetinaHead
+(MIOpen convs, PyTorch-ROCm plumbing) -> filter_bboxes -> FeatureRefineModule (FR sampler =
+libr3det_hip.so) -> RRetinaRefineHead -> per-image multiclass_nms_rotated, nms type 'v1'
+(libr3det_hip.so).  Nothing is skipped or cached.  N > 1: image-parallel, every rank runs its own
+batch, one RCCL all_gather of the padded detections per step (the only exchange of the path).
+--mode train: BASELINE configs[4] -- one optimisation step of the same model (batch 2 x 1024^2 per
+GPU, 128 synthetic GT per image): forward_train (fused MaxIoU assignment of 196 416 anchors and of
+21 824 refined boxes per image, focal + smooth-L1 losses, FR sampler forward and packed backward
+through autograd), backward, SGD; N > 1: DistributedDataParallel over RCCL.
+--mode rretinanet: BASELINE configs[1] -- rretinanet_obb_r50_fpn v1 inference, batch 2 x 1024^2.
 
 Rank 0 prints ONE JSON line.  `value` = images/s over all ranks.  `hot_path` repeats the
 measurement for the custom ops alone (same shapes, no convs).  `roofline` is for the dominant
-HBM-bound hand-written kernel (FR forward, level 0), timed with stream events inside the timed
-region.  `cpu_baseline` times the oracle / oracle/_ref on a bounded sample of the hot path on
-the host cores (rank 0, N = 1 only).  `ops` carries the op-level rates BASELINE.json names
-(rotated-IoU Mpairs/s, NMS Mboxes/s).
+HBM-bound hand-written kernel (FR forward, level 0), timed with HIP events attached to the launch
+inside the timed region.  `cpu_baseline` times the oracle / oracle/_ref on a bounded sample of the
+hot path on the host cores (rank 0, N = 1 only), with per-op rows beside it.  `ops` carries the
+op-level rates BASELINE.json names (rotated-IoU Mpairs/s, NMS Mboxes/s), each with its own roofline
+entry.  In the default mode rank 0 of a single-GPU run also adds bounded `train` (configs[4]) and
+`rretinanet` (configs[1]) entries.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,21 +41,30 @@ for _p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
 import torch  # noqa: E402
 
 BATCH = 4
+TRAIN_BATCH = 2       # configs/_base_/datasets/dota1_0.py:31 samples_per_gpu=2
+TRAIN_GT = 128
+RRETINA_BATCH = 2     # BASELINE configs[1]
 C = 256
 IMG = 1024
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 NMS_CFG = dict(iou_thr=0.1)  # type absent -> 'v1' (bbox_nms_rotated.py:43)
 SCORE_THR, MAX_PER_IMG = 0.05, 2000
 CHANNELS_LAST = os.environ.get("R3DET_BENCH_NCHW", "0") != "1"  # activation layout of the conv stack
 FUSE = os.environ.get("R3DET_BENCH_NOFUSE", "0") != "1"          # conv+BN folding and fused epilogues
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r01j_fr_residual_pmc.json")
+PROFILE_PMC = os.path.join(ROOT, "profiles", "roofline_kernel_pmc.json")
+FR_SOURCE = os.path.join(ROOT, "r3det-pytorch_amd", "csrc", "r3_fr.hip")
 
 
-def build_model(device, seed):
-    from r3det.models import R3Det
+def sha16(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------ inference
+def build_model(device, seed, kind="R3Det", batch=BATCH):
+    from r3det.models import R3Det, RRetinaNet
     from r3det.models.detectors import calibrate_score_bias
     torch.manual_seed(seed)
-    model = R3Det().eval().to(device)
+    model = (R3Det if kind == "R3Det" else RRetinaNet)().eval().to(device)
     if FUSE:
         # what the reference's benchmark does with --fuse-conv-bn (tools/analysis_tools/benchmark.py:88-89),
         # plus one-pass bias / ReLU / residual epilogues (r3det_bias_act) instead of 2-3 elementwise launches
@@ -56,12 +72,9 @@ def build_model(device, seed):
         fuse_for_inference(model)
     g = torch.Generator(device="cpu")
     g.manual_seed(seed + 1)
-    img = torch.randn(BATCH, 3, IMG, IMG, generator=g).to(device)
+    img = torch.randn(batch, 3, IMG, IMG, generator=g).to(device)
     if CHANNELS_LAST:
-        # MIOpen's fp32 convolutions run ~10 % faster on NHWC activations (tools/cl_probe.py); the FR
-        # sampler takes NCHW planes, FeatureRefineModule makes the sampler's three inputs NCHW (its own
-        # convolutions stay channels_last: with NCHW weights MIOpen transposes in and out of every one of
-        # them, 148.7 vs 150.1 img/s) -- same arithmetic, same fp32 everywhere
+        # MIOpen's fp32 convolutions run ~10 % faster on NHWC activations (tools/cl_probe.py)
         model = model.to(memory_format=torch.channels_last)
         if os.environ.get("R3DET_BENCH_FRM_NCHW", "0") == "1":
             for m in getattr(model, "feat_refine_module", []):
@@ -79,12 +92,60 @@ def model_step(model, img):
     return counts
 
 
+# ------------------------------------------------------------------------------------ training
+def build_train(device, seed, world):
+    from r3det import dist_train as dt
+    from r3det import synthetic as syn
+    from r3det.models import R3Det
+    torch.manual_seed(seed)
+    model = R3Det().train().to(device)
+    ddp = dt.wrap_ddp(model, device) if world > 1 else model
+    opt = dt.build_optimizer(model)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed + 1)
+    img = torch.randn(TRAIN_BATCH, 3, IMG, IMG, generator=g).to(device)
+    gtb = [syn.dota_like_rboxes(TRAIN_GT, seed * 10 + i, device=device) for i in range(TRAIN_BATCH)]
+    gtl = [torch.randint(0, 15, (TRAIN_GT,), generator=g).to(device) for _ in range(TRAIN_BATCH)]
+    return dict(model=model, ddp=ddp, opt=opt, img=img, gtb=gtb, gtl=gtl)
+
+
+def train_step(tr):
+    from r3det import dist_train as dt
+    return dt.train_step(tr["ddp"], tr["opt"], tr["img"], tr["gtb"], tr["gtl"])[0]
+
+
+def train_custom_op_ms(tr, device):
+    """The custom-op part of the step on its own, same shapes: fused assignment of both stages for both images,
+    FR sampler forward + packed backward over the pyramid (no convolutions, no losses)."""
+    from r3det import synthetic as syn
+    from r3det.core import obb2hbb
+    from r3det.ops.feature_refine import feature_refine
+    m = tr["model"]
+    anchors = torch.cat(m.bbox_head.anchors([(IMG // s, IMG // s) for s in syn.STRIDES], device))
+    feats, boxes = syn.fr_pyramid(TRAIN_BATCH, C, 9, device=device)
+    refined = [torch.cat([b.view(TRAIN_BATCH, -1, 5)[i] for b in boxes]) for i in range(TRAIN_BATCH)]
+    xs = [f.clone().requires_grad_(True) for f in feats]
+    gs = [torch.randn_like(f) for f in feats]
+
+    def assign():
+        for i in range(TRAIN_BATCH):
+            m.bbox_head.assigner.assign(anchors, obb2hbb(tr["gtb"][i], 'v1'), None, tr["gtl"][i])
+            m.refine_head[0].assigner.assign(refined[i], tr["gtb"][i], None, tr["gtl"][i])
+
+    def fr():
+        for x, b, gr, s in zip(xs, boxes, gs, syn.STRIDES):
+            x.grad = None
+            feature_refine(x, b, 1.0 / s, 1).backward(gr)
+    return timeit(assign, 10) * 1e3, timeit(fr, 10) * 1e3
+
+
+# ------------------------------------------------------------------------------------ custom ops alone
 def build_hot_workload(device, seed):
     from r3det import synthetic as syn
+    from r3det.core.post_processing import CapacityHint
     feats, boxes = syn.fr_pyramid(BATCH, C, seed, device=device)
     outs = [torch.empty_like(f) for f in feats]
     pools = [syn.nms_pool(syn.R3DET_POOL, seed * 1000 + i, device=device) for i in range(BATCH)]
-    from r3det.core.post_processing import CapacityHint
     return dict(feats=feats, boxes=boxes, outs=outs, pool_boxes=torch.stack([p[0] for p in pools]),
                 pool_scores=torch.stack([p[1] for p in pools]), nms_hint=CapacityHint())
 
@@ -103,7 +164,7 @@ def timeit(fn, reps, warm=2):
     for _ in range(warm):
         fn()
     best = float("inf")
-    for _ in range(3):  # best of three batches: a fresh box shows one ~50 ms stall per process
+    for _ in range(3):  # best of three batches
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(reps):
@@ -113,32 +174,54 @@ def timeit(fn, reps, warm=2):
     return best
 
 
+def b_iou(m, n):
+    return 4 * m * n + 20 * (m + n)
+
+
+def b_nms(n):
+    w = (n + 63) // 64
+    return 24 * n + 8 * n * w + 8 * n        # boxes + upper-triangle mask written and read + keep
+
+
 def op_rates(device):
-    """Op-level rates quoted by BASELINE.json's metric (Mpairs/s, Mboxes/s), bounded runs."""
+    """Op-level rates quoted by BASELINE.json's metric (Mpairs/s, Mboxes/s) with one roofline entry per
+    op: algorithmic bytes (SURVEY 8d) / time per call (wall clock around back-to-back calls, synchronised;
+    the per-kernel durations of the same calls are in profiles/*_iou_* and *_nms_*)."""
     from r3det import synthetic as syn
     from r3det.ops import batched_rnms, rbbox_iou
     out = {}
     anchors = syn.anchor_grid(device=device)
     gt = syn.dota_like_rboxes(128, 5, device=device)
-    dt = timeit(lambda: rbbox_iou(gt, anchors), 20)
-    out["iou_v1_128x196416_Mpairs_s"] = round(128 * anchors.size(0) / dt / 1e6, 1)
-    out["iou_v1_128x196416_GBs"] = round((4 * 128 * anchors.size(0) + 20 * (128 + anchors.size(0))) / dt / 1e9, 1)
+    refined = torch.cat([syn.fr_level_boxes(1, IMG // s, IMG // s, s, 50 + i, device=device)
+                         for i, s in enumerate(syn.STRIDES)])
     a, g = syn.rand_rboxes(1000, 0, device=device), syn.rand_rboxes(128, 1, device=device)
-    dt = timeit(lambda: rbbox_iou(a, g), 50)
-    out["iou_v1_1000x128_Mpairs_s"] = round(128000 / dt / 1e6, 1)
-    for n in (2000, 8576):
+    for name, b1, b2, reps in (("128x196416", gt, anchors, 20), ("128x21824", gt, refined, 50), ("1000x128", a, g, 50)):
+        dt = timeit(lambda: rbbox_iou(b1, b2), reps)
+        m, n = b1.size(0), b2.size(0)
+        gbs = b_iou(m, n) / dt / 1e9
+        out[f"iou_v1_{name}"] = {"Mpairs_s": round(m * n / dt / 1e6, 1), "us_per_call": round(dt * 1e6, 2),
+                                 "alg_bytes": b_iou(m, n),
+                                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                              "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}}
+    for n in (2000, 5344, 8576):
         mb, ms = syn.nms_pool(n * 10 // 6 + 64, 77 + n, device=device)
         sc, lab = ms[:, :-1].max(1)
         idx = torch.nonzero(sc > SCORE_THR).squeeze(1)[:n]
         b, s, l = mb[idx].contiguous(), sc[idx].contiguous(), lab[idx].contiguous()
         dt = timeit(lambda: batched_rnms(b, s, l, 0.1), 10)
-        out[f"nms_v1_{b.size(0)}_Mboxes_s"] = round(b.size(0) / dt / 1e6, 3)
+        k = b.size(0)
+        gbs = b_nms(k) / dt / 1e9
+        out[f"nms_v1_{k}"] = {"Mboxes_s": round(k / dt / 1e6, 3), "us_per_call": round(dt * 1e6, 1),
+                              "alg_bytes": b_nms(k), "what": "batched_rnms (15 classes) incl. its host read of the count",
+                              "roofline": {"bound": "hbm (latency-bound in practice)", "achieved": round(gbs, 2),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)}}
     return out
 
 
+# ------------------------------------------------------------------------------------ host baselines
 def cpu_baseline():
-    """Hot path of ONE image on the host: FR forward (oracle, OpenMP) + NMS v1 (reference CPU
-    code from oracle/_ref when present, else the oracle)."""
+    """Hot path of ONE image on the host: FR forward (oracle, OpenMP) + NMS v1 (reference CPU code from
+    oracle/_ref when present, else the oracle); `per_op`: the op-level rows of BASELINE.md section 3."""
     import numpy as np
     from oracle import api as O
     from r3det import synthetic as syn
@@ -163,14 +246,105 @@ def cpu_baseline():
         else:
             O.nms(O.V1, sh, scv, 0.1, ascending=True)
         reps += 1
-        if time.perf_counter() - t0 > 12 or reps >= 20:
+        if time.perf_counter() - t0 > 8 or reps >= 20:
             break
     dt = (time.perf_counter() - t0) / reps
+
+    def clock(fn, budget=1.5):
+        fn()
+        t, n = time.perf_counter(), 0
+        while True:
+            fn()
+            n += 1
+            if time.perf_counter() - t > budget or n >= 5:
+                return (time.perf_counter() - t) / n
+    per_op = {}
+    a, g = syn.rand_rboxes(1000, 0).numpy(), syn.rand_rboxes(128, 1).numpy()
+    anchors, gt = syn.anchor_grid().numpy(), syn.dota_like_rboxes(128, 5).numpy()
+    sample = np.ascontiguousarray(anchors[::12])  # every 12th anchor of the grid: 16 368 columns
+    if use_ref:
+        t = clock(lambda: O.ref_v1_iou_mat(a, g))
+        per_op["iou_v1_1000x128"] = {"Mpairs_s_1thread": round(128000 / t / 1e6, 3), "kind": "reference"}
+        t = clock(lambda: O.ref_v1_iou_mat(gt, sample))
+        per_op["iou_v1_128x196416"] = {"Mpairs_s_1thread": round(128 * len(sample) / t / 1e6, 3), "kind": "reference",
+                                       "sample": f"128 x {len(sample)} (every 12th anchor)"}
+    t = clock(lambda: O.iou_mat(O.V1, a, g, threads=cores))
+    per_op.setdefault("iou_v1_1000x128", {})[f"Mpairs_s_openmp_{cores}"] = round(128000 / t / 1e6, 3)
+    t = clock(lambda: O.iou_mat(O.V1, gt, anchors, threads=cores))
+    per_op.setdefault("iou_v1_128x196416", {})[f"Mpairs_s_openmp_{cores}"] = round(128 * len(anchors) / t / 1e6, 3)
+    for n in (2000, 5344, 8576):
+        pb, ps = syn.nms_pool(n * 10 // 6 + 64, 77 + n)
+        sc, lab = ps[:, :-1].max(1)
+        idx = torch.nonzero(sc > SCORE_THR).squeeze(1)[:n]
+        b, s, l = pb[idx].numpy(), sc[idx].numpy(), lab[idx].numpy()
+        sh = b.copy()
+        sh[:, :2] += (l.astype(np.float32) * (b.max() + 1))[:, None]
+        d6 = np.hstack([sh, s[:, None]])
+        t = clock(lambda: O.ref_v1_rnms(d6, 0.1) if use_ref else O.nms(O.V1, sh, s, 0.1, ascending=True))
+        per_op[f"nms_v1_{len(b)}"] = {"Mboxes_s_1thread": round(len(b) / t / 1e6, 4),
+                                      "kind": "reference" if use_ref else "port"}
     return {"value": round(1.0 / dt, 3), "unit": "img/s", "cores": cores,
             "kind": "port",
+            "compare_with": "hot_path.img_s (the custom ops alone on the GPU), not with `value` (full model)",
             "sample": f"{reps} x custom-op hot path of ONE image (no convs): FR forward 5 levels N=1 C=256 on "
                       f"{cores} threads [oracle port; the reference has no CPU FR] + NMS v1 on a 5344-box "
-                      f"pool, 1 thread [{'reference rnms_cpu via oracle/_ref' if use_ref else 'oracle port'}]"}
+                      f"pool, 1 thread [{'reference rnms_cpu via oracle/_ref' if use_ref else 'oracle port'}]",
+            "per_op": per_op}
+
+
+def load_traffic():
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes -- only while the kernel
+    source it was measured on is still the source of this build (the file records sha256(r3_fr.hip))."""
+    if not os.path.exists(PROFILE_PMC):
+        return None, "no PMC file"
+    try:
+        rec = json.load(open(PROFILE_PMC))
+    except Exception:  # noqa: BLE001
+        return None, "unreadable PMC file"
+    if rec.get("kernel_source_sha16") != sha16(FR_SOURCE):
+        return None, (f"stale: measured on r3_fr.hip {rec.get('kernel_source_sha16')} ({rec.get('commit')}), "
+                      f"this build is {sha16(FR_SOURCE)}")
+    return rec.get("hbm_bytes_per_launch"), f"{rec.get('kernel_symbol')} @ {rec.get('commit')}"
+
+
+def _sync(device):
+    if device.type == "cuda":  # (the gloo CPU tests drive this function with a CPU device)
+        torch.cuda.synchronize()
+
+
+def timed_region(step, args, device, di):
+    """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
+    for _ in range(args.warmup):
+        step()
+    _sync(device)
+    di.barrier(device)
+    _sync(device)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    _sync(device)
+    di.barrier(device)
+    _sync(device)
+    mine = time.perf_counter() - t0
+    return di.max_over_ranks(mine, device), mine, last
+
+
+def per_rank_ms(mine, steps, device, world):
+    import torch.distributed as dist
+    if world == 1 or not dist.is_initialized():
+        return [round(mine / steps * 1e3, 3)]
+    t = torch.tensor([mine / steps * 1e3], dtype=torch.float64, device=device)
+    allt = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    return [round(float(x), 3) for x in allt]
+
+
+def dist_info():
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()}
+    return {"backend": None, "rccl_ranks": 1}
 
 
 def main():
@@ -178,14 +352,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["infer", "train", "rretinanet"], default="infer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bounded train / rretinanet entries")
     ap.add_argument("--model-only", action="store_true",
                     help="stop after the timed model steps (used under rocprofv3: the tail of the trace is "
                          "then exactly the timed region)")
     args = ap.parse_args()
     if args.model_only:
-        args.no_ops = args.no_cpu_baseline = True
+        args.no_ops = args.no_cpu_baseline = args.no_extras = True
 
     from r3det import _C
     from r3det import dist_infer as di
@@ -198,23 +374,65 @@ def main():
     di.init(device=device)
     torch.backends.cudnn.benchmark = True  # MIOpen find mode for the backbone convs
 
+    common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+
+    if args.mode == "train":
+        tr = build_train(device, 300 + rank, world)
+        elapsed, mine, loss = timed_region(lambda: train_step(tr), args, device, di)
+        ranks = per_rank_ms(mine, args.steps, device, world)
+        if rank == 0:
+            ms = elapsed / args.steps * 1e3
+            ta, tf = train_custom_op_ms(tr, device)
+            line = dict(common, metric="img/s, R3Det R50-FPN 1024x1024 training step (r3det_r50_fpn_1x v1)",
+                        value=round(world * TRAIN_BATCH * args.steps / elapsed, 2), unit="img/s",
+                        ms_per_step=round(ms, 3), per_rank_ms_per_step=ranks, **dist_info(),
+                        config={"workload": "BASELINE configs[4]: r3det_r50_fpn_1x v1 training step, batch=2 x 1024x1024 per "
+                                            "GPU, 128 synthetic GT per image: forward_train (fused MaxIoU assignment, focal + "
+                                            "smooth-L1, FR forward + packed backward), backward, SGD(momentum); random-init "
+                                            "weights; norm_eval, frozen stem + layer1 as in the config",
+                                "batch_per_gpu": TRAIN_BATCH, "global_batch": TRAIN_BATCH * world,
+                                "parallelism": f"DDP x{world} (RCCL all-reduce of 168 MB fp32 gradients in 48 MB buckets)"},
+                        final_loss=round(float(loss), 4),
+                        custom_ops={"what": "the step's custom ops timed on their own (isolated, same shapes)",
+                                    "assign_ms": round(ta, 3), "fr_fwd_bwd_ms": round(tf, 3),
+                                    "share_of_step": round((ta + tf) / ms, 4)})
+            print(json.dumps(line))
+        if world > 1:
+            di.barrier(device)
+            torch.distributed.destroy_process_group()
+        return
+
+    if args.mode == "rretinanet":
+        model, img = build_model(device, 200 + rank, "RRetinaNet", RRETINA_BATCH)
+        elapsed, mine, counts = timed_region(lambda: model_step(model, img), args, device, di)
+        ranks = per_rank_ms(mine, args.steps, device, world)
+        if rank == 0:
+            print(json.dumps(dict(
+                common, metric="img/s, rretinanet_obb_r50_fpn v1 1024x1024 inference",
+                value=round(world * RRETINA_BATCH * args.steps / elapsed, 2), unit="img/s",
+                ms_per_step=round(elapsed / args.steps * 1e3, 3), per_rank_ms_per_step=ranks, **dist_info(),
+                config={"workload": "BASELINE configs[1]: rretinanet_obb_r50_fpn v1, batch=2 x 1024x1024 per GPU, inference "
+                                    "(9 anchors / position, nms_pre 2000 per level -> 8576-box pools, nms v1)",
+                        "batch_per_gpu": RRETINA_BATCH, "global_batch": RRETINA_BATCH * world},
+                kept_per_image=[int(c) for c in counts.tolist()])))
+        if world > 1:
+            di.barrier(device)
+            torch.distributed.destroy_process_group()
+        return
+
     model, img = build_model(device, seed=100 + rank)
     for _ in range(args.warmup):
         model_step(model, img)
     torch.cuda.synchronize()
     _C.fr_profile_read()                # empty the ring
     _C.set_option("fr_profile", 2)      # the sampler launches of the timed steps carry a start / stop event
-    di.barrier(device)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts = model_step(model, img)
-    torch.cuda.synchronize()
-    di.barrier(device)
-    torch.cuda.synchronize()
-    elapsed = di.max_over_ranks(time.perf_counter() - t0, device)
+    args_w = argparse.Namespace(**vars(args))
+    args_w.warmup = 0
+    elapsed, mine, counts = timed_region(lambda: model_step(model, img), args_w, device, di)
     _C.set_option("fr_profile", 0)
     recs = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
+    ranks = per_rank_ms(mine, args.steps, device, world)
 
     if rank == 0:
         # Events attached to the launch itself (hipExtLaunchKernelGGL), not stream events around the call:
@@ -225,67 +443,57 @@ def main():
         H = W = 128
         # 8 B per element (read + write once) for the sampler + the per-position sample data,
         # which this kernel reads as an 8-byte tap (the 20-byte boxes are read by the table kernel, 1.3 MB, not
-        # counted here).  In the model the launch also carries the module's residual add
-        # (r3det_feature_refine_module_prepared with the plane already summed by r3det_frm_mix_nchw): one
-        # more read per element, i.e. 12 B per element.
+        # counted here).  In the model the launch also carries the module's residual add: one more read per
+        # element, i.e. 12 B per element.
         alg_bytes = 3 * 4 * BATCH * C * H * W + 8 * BATCH * H * W
-        achieved = alg_bytes / (span_us * 1e-6) / 1e9
-        traffic = None
-        if os.path.exists(PROFILE_PMC):
-            try:
-                traffic = json.load(open(PROFILE_PMC)).get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
-        line = {
+        achieved = alg_bytes / (span_us * 1e-6) / 1e9 if recs else 0.0
+        traffic, traffic_src = load_traffic()
+        line = dict(common, **{
             "metric": "img/s, R3Det R50-FPN 1024x1024 inference (r3det_r50_fpn_1x v1)",
             "value": round(world * BATCH * args.steps / elapsed, 2),
             "unit": "img/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "per_rank_ms_per_step": ranks, **dist_info(),
             "config": {"workload": "BASELINE configs[2] (the single-GPU case of the metric's model): "
                                    "r3det_r50_fpn_1x v1 + FeatureRefineModule, batch=4 x 1024x1024 per GPU, "
                                    "full inference incl. backbone, random-init weights, score bias calibrated "
                                    "to ~1 % candidates",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "nms_type": "v1",
                        "parallelism": f"image-parallel x{world}, all_gather of detections"},
-            "roofline": {"bound": "hbm", "kernel": "fr_forward_cell<7,7,1024,residual> = FR forward level 0 (4x256x128x128) with the "
-                                                   "FeatureRefineModule's residual add folded in (2 reads + 1 write per element; the "
-                                                   "module's other adds ride in the layout-switch kernel in front of it); its tap "
-                                                   "table is prepared for all levels ahead of the module's convs; duration = the "
-                                                   "launch's own start/stop HIP events (hipExtLaunchKernelGGL), timed steps",
+            "roofline": {"bound": "hbm", "kernel": "FR forward level 0 (4x256x128x128) with the FeatureRefineModule's residual "
+                                                   "add folded in (2 reads + 1 write per element); duration = the launch's own "
+                                                   "start/stop HIP events (hipExtLaunchKernelGGL), timed steps",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(span_us, 2),
                          "launches_timed": len(recs)},
             "kept_per_image": [int(c) for c in counts.tolist()],
-        }
+        })
         del model, img
         if not args.model_only:
             import gc
             gc.collect()              # the module graph has reference cycles: free it now, not in the timed loop
             torch.cuda.empty_cache()  # drop the model's cached blocks: the op-level runs start clean
             wl = build_hot_workload(device, seed=7)
-            # per-step times (the step ends in a host read anyway); the median is reported because the first
-            # process on a fresh box shows one ~50 ms stall somewhere in the first dozen steps
-            # (tools/hp_after_model.py), the mean is kept beside it
-            per = []
+            per, allocs = [], []
             for i in range(3 + 30):
+                s0 = torch.cuda.memory_stats(device)["num_device_alloc"]
                 torch.cuda.synchronize()
                 t = time.perf_counter()
                 hot_path_step(wl)
                 torch.cuda.synchronize()
                 if i >= 3:
                     per.append(time.perf_counter() - t)
-            per.sort()
-            dt = per[len(per) // 2]
+                    allocs.append(torch.cuda.memory_stats(device)["num_device_alloc"] - s0)
+            worst = max(range(len(per)), key=lambda i: per[i])
+            srt = sorted(per)
+            dt = srt[len(srt) // 2]
             line["hot_path"] = {"what": "custom ops only, same shapes: FR sampler x5 levels (N=4, C=256) + batched "
                                         "multiclass_nms_rotated(v1) on 4 x 5344-box pools",
                                 "ms_per_step": round(dt * 1e3, 3), "img_s": round(BATCH / dt, 1),
-                                "ms_per_step_mean": round(sum(per) / len(per) * 1e3, 3), "steps": len(per)}
-            # the roofline kernel once more, in this loop (no convolutions around it: what the kernel does
-            # when its planes are not competing with the conv stack's dirty lines for the Infinity Cache)
+                                "ms_per_step_mean": round(sum(per) / len(per) * 1e3, 3), "steps": len(per),
+                                "slowest_step": {"index": worst, "ms": round(per[worst] * 1e3, 3),
+                                                 "device_allocs_in_it": allocs[worst]}}
             ctx = {}
             for mode, key in ((2, "span"), (1, "each")):
                 _C.fr_profile_read()
@@ -297,33 +505,66 @@ def main():
                 us = sum(r[4] for r in ctx["span"]) / len(ctx["span"])
                 alg_plain = 2 * 4 * BATCH * C * H * W + 8 * BATCH * H * W  # the sampler alone: 1 read + 1 write
                 line["roofline"]["hot_path_context"] = {
-                    "kernel": "the plain sampler (r3det_feature_refine_forward: table kernel + fr_forward_cell<7,7,1024>), "
-                              "1 read + 1 write per element",
+                    "kernel": "the plain sampler (r3det_feature_refine_forward), 1 read + 1 write per element, in the "
+                              "custom-op loop; its 135 MB working set stays in the 256 MiB Infinity Cache between steps: "
+                              "an L3-assisted figure, not an HBM fraction",
                     "alg_bytes_per_launch": alg_plain,
                     "avg_launch_us": round(us, 2), "achieved": round(alg_plain / us / 1e3, 1),
-                    "frac": round(alg_plain / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(ctx["span"]),
+                    "launches_timed": len(ctx["span"]),
                     "table_kernel_us_own_events": round(sum(r[2] for r in ctx["each"]) / max(1, len(ctx["each"])), 2),
                     "cell_kernel_us_own_events": round(sum(r[3] for r in ctx["each"]) / max(1, len(ctx["each"])), 2)}
-            # and the roofline kernel itself (sampler + residual) in a loop of its own: same launch, inputs
-            # not freshly written by the kernels in front of it
+            # the roofline kernel alone, rotating over four input / output sets (4 x 403 MB): every launch
+            # reads and writes lines that are NOT in the 256 MiB Infinity Cache -> an HBM figure
             from r3det.ops.feature_refine import fr_module_prepared, fr_prepare
             f0, b0 = wl["feats"][0], wl["boxes"][0]
             table = fr_prepare(b0, BATCH, H, W, 1.0 / 8)
-            res0, out0 = torch.randn_like(f0), torch.empty_like(f0)
+            sets = [(torch.randn_like(f0), torch.randn_like(f0), torch.empty_like(f0)) for _ in range(4)]
+            state = [0]
+
+            def rot():
+                a, r, o = sets[state[0] % 4]
+                state[0] += 1
+                fr_module_prepared(a, None, r, table, o)
             _C.fr_profile_read()
             _C.set_option("fr_profile", 2)
-            timeit(lambda: fr_module_prepared(f0, None, res0, table, out0), 20, warm=0)
+            timeit(rot, 20, warm=4)
             _C.set_option("fr_profile", 0)
             alone = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
             if alone:
                 us = sum(r[4] for r in alone) / len(alone)
-                line["roofline"]["kernel_alone_context"] = {
-                    "what": "the same launch (r3det_feature_refine_module_prepared, residual form) repeated on its own",
+                line["roofline"]["kernel_alone_hbm"] = {
+                    "what": "the same launch repeated on its own over 4 rotating buffer sets (1.6 GB: beyond the "
+                            "Infinity Cache)",
                     "avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
                     "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
-            del res0, out0, table
+            del sets, table, wl
         if not args.no_ops:
             line["ops"] = op_rates(device)
+        if world == 1 and not args.no_extras:
+            torch.cuda.empty_cache()
+            ex = argparse.Namespace(steps=5, warmup=3)
+            m2, i2 = build_model(device, 200, "RRetinaNet", RRETINA_BATCH)
+            e2, _, c2 = timed_region(lambda: model_step(m2, i2), ex, device, di)
+            line["rretinanet"] = {"workload": "BASELINE configs[1]: rretinanet_obb_r50_fpn v1, batch=2 x 1024x1024, "
+                                              "inference, 8576-box pools per image, nms v1 (bounded: 5 steps; --mode "
+                                              "rretinanet times it as the main region)",
+                                  "img_s": round(RRETINA_BATCH * ex.steps / e2, 2),
+                                  "ms_per_step": round(e2 / ex.steps * 1e3, 3),
+                                  "kept_per_image": [int(c) for c in c2.tolist()]}
+            del m2, i2
+            torch.cuda.empty_cache()
+            tr = build_train(device, 300, 1)
+            e3, _, loss = timed_region(lambda: train_step(tr), ex, device, di)
+            ta, tf = train_custom_op_ms(tr, device)
+            ms3 = e3 / ex.steps * 1e3
+            line["train"] = {"workload": "BASELINE configs[4] on one GPU: r3det_r50_fpn_1x v1 training step, batch=2 x "
+                                         "1024x1024, 128 GT per image (bounded: 5 steps; --mode train times it as the main "
+                                         "region, with DDP at N > 1)",
+                             "img_s": round(TRAIN_BATCH * ex.steps / e3, 2), "ms_per_step": round(ms3, 3),
+                             "final_loss": round(float(loss), 4),
+                             "custom_ops_isolated": {"assign_ms": round(ta, 3), "fr_fwd_bwd_ms": round(tf, 3),
+                                                     "share_of_step": round((ta + tf) / ms3, 4)}}
+            del tr
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -69,7 +69,7 @@ class RAnchorGenerator:
         return a.reshape(-1, 5).to(device=device, dtype=dtype)
 
     def grid_priors(self, featmap_sizes, device='cuda'):
-        assert len(featmap_sizes) == self.num_levels
+        assert len(featmap_sizes) <= self.num_levels  # (a head used on the first levels only takes a prefix)
         key = (tuple(tuple(int(v) for v in fs) for fs in featmap_sizes), str(device))
         if key not in self._cache:
             self._cache[key] = [self.single_level_grid_priors(fs, i, device=device)

@@ -28,12 +28,15 @@ def _feature_refine(features, best_rbboxes, spatial_scale, points=1, table=None)
 
 
 @contextlib.contextmanager
-def cpu_kernels():
+def cpu_kernels(twin=False):
+    """``twin``: the oracle evaluates the kernels' own deterministic sincos instead of libm (bit-identical
+    IoU to the HIP path: needed when exact ties between anchors decide the assignment)."""
     import r3det.core.bbox.iou_calculators.rotate_iou2d_calculator as calc
     import r3det.ops.feature_refine as frm
     saved = calc.rbbox_iou, frm.feature_refine
     calc.rbbox_iou, frm.feature_refine = _rbbox_iou, _feature_refine
     try:
-        yield
+        with (O.twin() if twin else contextlib.nullcontext()):
+            yield
     finally:
         calc.rbbox_iou, frm.feature_refine = saved

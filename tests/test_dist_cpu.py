@@ -93,3 +93,58 @@ def test_shard_and_pack_single_process():
     assert torch.equal(back[2][0], dets[2][:64])
     gp, gc = di.gather_detections(packed, counts)  # no process group: passthrough
     assert gp[0] is packed and gc[0] is counts
+
+
+class _StubModel:
+    """simple_test of a detector: per-image (dets (k, 6), labels (k,)); rank 1's second image is empty and
+    its batch is one image short (uneven last batch)."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def simple_test(self, img):
+        out = []
+        for i in range(img.size(0)):
+            k = 0 if (self.rank == 1 and i == 1) else 3 + 2 * i + self.rank
+            g = torch.Generator().manual_seed(10 * self.rank + i)
+            out.append((torch.rand(k, 6, generator=g), torch.randint(0, 15, (k,), generator=g)))
+        return out
+
+
+def _bench_worker(rank, world, port, out_path):
+    for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import argparse
+
+    import bench
+    from r3det import dist_infer as di
+    di.init(backend="gloo")
+    dev = torch.device("cpu")
+    model = _StubModel(rank)
+    img = torch.zeros(4 if rank == 0 else 3, 3, 8, 8)
+    counts = bench.model_step(model, img)            # pack + the step's one exchange (gather on rank 0)
+    assert counts.tolist() == ([3, 5, 7, 9] if rank == 0 else [4, 0, 8])
+    elapsed, mine, last = bench.timed_region(lambda: bench.model_step(model, img), argparse.Namespace(steps=3, warmup=1),
+                                             dev, di)
+    assert elapsed >= mine - 1e-9 and torch.equal(last, counts)
+    ranks = bench.per_rank_ms(mine, 3, dev, world)
+    info = bench.dist_info()
+    assert len(ranks) == world and info == {"backend": "gloo", "rccl_ranks": 2}
+    if rank == 0:
+        torch.save(dict(ranks=ranks, info=info, elapsed=elapsed), out_path)
+    di.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_gather_and_rank_metadata_world2(tmp_path):
+    """bench.py's own model_step / timed_region / per-rank times / backend + rank count under gloo,
+    world size 2, with ranks whose batches differ in size (the gather of detections is per rank: shapes
+    need not agree across ranks) and an image without detections."""
+    out = str(tmp_path / "bench.pt")
+    mp.spawn(_bench_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["info"]["rccl_ranks"] == 2 and len(got["ranks"]) == 2
+    assert got["elapsed"] * 1e3 / 3 >= max(got["ranks"]) - 1e-3  # (the per-rank times are rounded to 1 us)

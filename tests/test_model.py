@@ -242,10 +242,10 @@ def test_fused_inference_model_gpu(channels_last):
                 out = bias_act_(y.clone(memory_format=torch.preserve_format), b, res, relu)
                 assert torch.equal(out, ref)
         # non-finite activations must surface, exactly as through F.relu
-        bad = y.clone(memory_format=torch.preserve_format)
-        bad.view(-1)[::7] = float('nan')
-        bad.view(-1)[1::11] = float('inf')
-        bad.view(-1)[2::13] = float('-inf')
+        k = torch.arange(y.numel(), device='cuda').view(y.shape)
+        bad = torch.where(k % 7 == 0, torch.full_like(y, float('nan')), y)
+        bad = torch.where(k % 11 == 1, torch.full_like(y, float('inf')), bad)
+        bad = torch.where(k % 13 == 2, torch.full_like(y, float('-inf')), bad).contiguous(memory_format=fmt)
         want_bad = (bad + b.view(1, -1, 1, 1)).relu()
         got_bad = bias_act_(bad.clone(memory_format=torch.preserve_format), b, None, True)
         assert torch.equal(torch.isnan(got_bad), torch.isnan(want_bad)) and bool(torch.isnan(got_bad).any())
