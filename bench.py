@@ -347,6 +347,16 @@ def dist_info():
     return {"backend": None, "rccl_ranks": 1}
 
 
+_T0 = time.perf_counter()
+
+
+def phase(name):
+    """Wall-clock trace of the run on stderr (the driver clocks the whole command; this says where it went)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write(f"[bench {time.perf_counter() - _T0:7.1f} s] {name}\n")
+        sys.stderr.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,6 +388,7 @@ def main():
               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
 
     if args.mode == "train":
+        phase("train: build")
         tr = build_train(device, 300 + rank, world)
         elapsed, mine, loss = timed_region(lambda: train_step(tr), args, device, di)
         ranks = per_rank_ms(mine, args.steps, device, world)
@@ -421,7 +432,9 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
+    phase("infer: build + calibrate")
     model, img = build_model(device, seed=100 + rank)
+    phase("infer: warm-up + timed steps")
     for _ in range(args.warmup):
         model_step(model, img)
     torch.cuda.synchronize()
@@ -474,6 +487,7 @@ def main():
             import gc
             gc.collect()              # the module graph has reference cycles: free it now, not in the timed loop
             torch.cuda.empty_cache()  # drop the model's cached blocks: the op-level runs start clean
+            phase("hot path (custom ops alone)")
             wl = build_hot_workload(device, seed=7)
             per, allocs = [], []
             for i in range(3 + 30):
@@ -539,10 +553,12 @@ def main():
                     "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
             del sets, table, wl
         if not args.no_ops:
+            phase("op rates")
             line["ops"] = op_rates(device)
         if world == 1 and not args.no_extras:
             torch.cuda.empty_cache()
             ex = argparse.Namespace(steps=5, warmup=3)
+            phase("extra: rretinanet (configs[1])")
             m2, i2 = build_model(device, 200, "RRetinaNet", RRETINA_BATCH)
             e2, _, c2 = timed_region(lambda: model_step(m2, i2), ex, device, di)
             line["rretinanet"] = {"workload": "BASELINE configs[1]: rretinanet_obb_r50_fpn v1, batch=2 x 1024x1024, "
@@ -553,6 +569,7 @@ def main():
                                   "kept_per_image": [int(c) for c in c2.tolist()]}
             del m2, i2
             torch.cuda.empty_cache()
+            phase("extra: train (configs[4])")
             tr = build_train(device, 300, 1)
             e3, _, loss = timed_region(lambda: train_step(tr), ex, device, di)
             ta, tf = train_custom_op_ms(tr, device)
@@ -566,7 +583,9 @@ def main():
                                                      "share_of_step": round((ta + tf) / ms3, 4)}}
             del tr
         if world == 1 and not args.no_cpu_baseline:
+            phase("cpu baseline")
             line["cpu_baseline"] = cpu_baseline()
+        phase("done")
         print(json.dumps(line))
     if world > 1:
         di.barrier(device)

@@ -63,28 +63,32 @@ __global__ __launch_bounds__(IOU_BLOCK) void iou_mat_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ compacted kernel
+// One launch, no workspace: tile = ROWS rows x (256 * CPT) columns per workgroup.  CPT / ROWS are picked per
+// shape (launch_mat): wide tiles for wide matrices (16-byte stores), one column per lane and few rows per tile
+// when the matrix is small, so that a 1000 x 128 call still spreads over ~125 workgroups.
 constexpr int T_THREADS = 256;
-constexpr int T_CPT = 4;                       // columns per thread
+constexpr int T_CPT = 4;                       // columns per thread (wide form)
 constexpr int T_COLS = T_THREADS * T_CPT;      // 1024
-constexpr int T_ROWS = 32;                     // rows per workgroup
 constexpr int T_SUB = 8;                       // rows per phase-A/phase-B round
-constexpr int T_QCAP = T_SUB * T_COLS;         // 8192 entries: a round can never overflow
 
-template <int GEOM, bool VEC>
+template <int GEOM, bool VEC, int CPT, int ROWS>
 __global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float* __restrict__ b1, int n1,
                                                                     const float* __restrict__ b2, int n2,
                                                                     int iof, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float rows[T_ROWS][R3_REC];
-  __shared__ unsigned short queue[T_QCAP];
+  constexpr int COLS = T_THREADS * CPT;
+  constexpr int CSH = CPT == 4 ? 10 : (CPT == 2 ? 9 : 8);  // log2(COLS)
+  constexpr int QCAP = T_SUB * COLS;                        // a round can never overflow
+  __shared__ __attribute__((aligned(16))) float rows[ROWS][R3_REC];
+  __shared__ unsigned short queue[QCAP];
   __shared__ int qcount[2];
   __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int colbase = blockIdx.x * T_COLS;
-  const int col0 = colbase + tid * T_CPT;
-  const int row0 = blockIdx.y * T_ROWS;
-  const int nrows = min(T_ROWS, n1 - row0);
+  const int colbase = blockIdx.x * COLS;
+  const int col0 = colbase + tid * CPT;
+  const int row0 = blockIdx.y * ROWS;
+  const int nrows = min(ROWS, n1 - row0);
 
   if (tid < nrows) {
     BoxRec rec;
@@ -94,11 +98,11 @@ __global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float*
   }
   if (tid < 2) qcount[tid] = 0;
 
-  // reject data of my 4 columns (cx, cy, radius, aabb half extents)
-  float cq[T_CPT][5];
-  bool cvalid[T_CPT];
+  // reject data of my columns (cx, cy, radius, aabb half extents)
+  float cq[CPT][5];
+  bool cvalid[CPT];
 #pragma unroll
-  for (int c = 0; c < T_CPT; c++) {
+  for (int c = 0; c < CPT; c++) {
     cvalid[c] = (col0 + c) < n2;
     if (cvalid[c]) {
       const float* b = b2 + (size_t)(col0 + c) * 5;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float*
       cq[c][0] = cq[c][1] = cq[c][2] = cq[c][3] = cq[c][4] = 0.f;
     }
   }
-  const bool all_valid = cvalid[T_CPT - 1];
+  const bool all_valid = cvalid[CPT - 1];
   __syncthreads();
 
   const LanePts<T_THREADS> lp{pts + tid};
@@ -128,10 +132,10 @@ __global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float*
     for (int r = 0; r < rcount; r++) {
       const float* A = rows[rbase + r];
       const float ax = A[9], ay = A[10], ar = A[11], aex = A[12], aey = A[13];
-      bool pend[T_CPT];
+      bool pend[CPT];
       bool any = false;
 #pragma unroll
-      for (int c = 0; c < T_CPT; c++) {
+      for (int c = 0; c < CPT; c++) {
         float dx = ax - cq[c][0], dy = ay - cq[c][1];
         float rr = ar + cq[c][2];
         bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + cq[c][3]) |
@@ -140,23 +144,25 @@ __global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float*
         any |= pend[c];
       }
       float* o = out + (size_t)(row0 + rbase + r) * n2 + col0;
-      if (VEC && all_valid && !any) {
+      if (VEC && CPT == 4 && all_valid && !any) {
         *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
 #pragma unroll
-        for (int c = 0; c < T_CPT; c++)
+        for (int c = 0; c < CPT; c++)
           if (cvalid[c] && !pend[c]) o[c] = 0.f;
       }
+      if (__ballot(any)) {
 #pragma unroll
-      for (int c = 0; c < T_CPT; c++) {
-        unsigned long long m = __ballot(pend[c]);
-        if (m) {
-          int base = 0;
-          if (lane == 0) base = atomicAdd(qc, __popcll(m));
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (pend[c]) {
-            int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
-            queue[slot] = (unsigned short)((r << 10) | (tid * T_CPT + c));
+        for (int c = 0; c < CPT; c++) {
+          unsigned long long m = __ballot(pend[c]);
+          if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(qc, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (pend[c]) {
+              int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+              queue[slot] = (unsigned short)((r << CSH) | (tid * CPT + c));
+            }
           }
         }
       }
@@ -167,8 +173,8 @@ __global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float*
     if (tid == 0) qcount[(sub + 1) & 1] = 0;
     for (int q = tid; q < total; q += T_THREADS) {
       const unsigned e = queue[q];
-      const int r = e >> 10;
-      const int col = colbase + (int)(e & 1023u);
+      const int r = e >> CSH;
+      const int col = colbase + (int)(e & (unsigned)(COLS - 1));
       BoxRec Bc;
       make_record<GEOM>(b2 + (size_t)col * 5, 0.f, Bc);
       const float v = pair_slow_lds<GEOM, T_THREADS>(rows[rbase + r], Bc.f, iof != 0, lp);
@@ -289,21 +295,222 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream_kernel(const float* __re
   }
 }
 
+// ------------------------------------------------------------------ prep + stream + drain pipeline
+// The matrix path for large problems (the 128 x 196 416 assignment shape).
+//   prep   : one small launch builds the row records and, ONCE per column, the 20 bytes the conservative test
+//            reads (the round-1 stream kernel rebuilt them -- a double-precision sincos each -- in every one of
+//            the n1/16 row tiles), laid out so that the stream kernel's per-lane loads are 64 + 16 contiguous
+//            bytes, and zeroes the queue counter (no memset node);
+//   stream : tile = SROWS rows x 1024 columns: conservative test -> zeros streamed out with 16-byte stores,
+//            survivors -> LDS queue -> one of 64 bounded regions of the global queue (one atomicAdd per
+//            workgroup on that region's counter); entries that no longer fit are clipped by the workgroup
+//            itself, so the workspace is 0.5 B per pair, not 4 B;
+//   drain  : grid-stride over the concatenation of the regions, one pair per lane, balanced over the chip.
+// Measured and NOT shipped: a single persistent kernel in which workgroups alternate between
+// streaming tiles and clipping chunks published by other workgroups (tickets in global memory).  On gfx950 an
+// agent-scope release / acquire is an L2 write-back / invalidate of the whole XCD (the eight L2s are not
+// coherent with each other), so every published tile flushed the freshly written zeros: 725 us instead of 75.
+constexpr int F_NREG = 64;             // the global queue is split into 64 regions, each with its own counter:
+constexpr int F_CSTRIDE = 32;          // 1536 workgroups adding to ONE address serialise (device-scope atomics are
+constexpr int F_CTL = F_NREG * F_CSTRIDE;  // performed memory-side); counters sit 128 B apart
+
+template <int GEOM>
+__global__ __launch_bounds__(256) void iou_prep_kernel(const float* __restrict__ b1, int n1,
+                                                       const float* __restrict__ b2, int n2,
+                                                       BoxRec* __restrict__ recsA, float4* __restrict__ rejB,
+                                                       float* __restrict__ radB, unsigned* __restrict__ ctl) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < F_CTL) ctl[i] = 0;
+  if (i < n1) {
+    BoxRec rec;
+    make_record<GEOM>(b1 + (size_t)i * 5, 0.f, rec);
+    recsA[i] = rec;
+  }
+  if (i < n2) {
+    // columns: only the 20 bytes the stream kernel tests with (coalesced 16-byte + 4-byte stores).  Their full
+    // 64-byte records would be 12.5 MB of lane-strided stores at 196 416 anchors (13.5 us measured for this
+    // launch); the drain kernel rebuilds the record of a surviving pair's column instead (~1.7 % of the pairs).
+    const float* b = b2 + (size_t)i * 5;
+    const float x = b[0], y = b[1], w = b[2], h = b[3];
+    float sn, cs;
+    r3_sincos(b[4], sn, cs);
+    const float ac = fabsf(cs), as = fabsf(sn), aw = 0.5f * fabsf(w), ah = 0.5f * fabsf(h);
+    const float slack = 2e-6f * (fabsf(x) + fabsf(y)) + 1e-6f;
+    rejB[i] = make_float4(x, y, (ac * aw + as * ah) * 1.001f + slack, (as * aw + ac * ah) * 1.001f + slack);
+    radB[i] = r3_radius(x, y, w, h);
+  }
+}
+
+template <int GEOM, bool VEC, int SROWS>
+__global__ __launch_bounds__(T_THREADS) void iou_stream2_kernel(const BoxRec* __restrict__ recsA, int n1,
+                                                                const float* __restrict__ b2,
+                                                                const float4* __restrict__ rejB,
+                                                                const float* __restrict__ radB, int n2, int iof,
+                                                                float* __restrict__ out, unsigned* __restrict__ counter,
+                                                                unsigned* __restrict__ gqueue, unsigned qcap) {
+  __shared__ __attribute__((aligned(16))) float rows[SROWS][8];  // cx, cy, rad, ex, ey
+  __shared__ unsigned short queue[SROWS * T_COLS];
+  __shared__ int qcount;
+  __shared__ unsigned qbase;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int colbase = blockIdx.x * T_COLS;
+  const int col0 = colbase + tid * T_CPT;
+  const int row0 = blockIdx.y * SROWS;
+  const int nrows = min(SROWS, n1 - row0);
+  if (tid < nrows) {
+    const float* a = recsA[row0 + tid].f;
+#pragma unroll
+    for (int k = 0; k < 5; k++) rows[tid][k] = a[9 + k];
+  }
+  if (tid == 0) qcount = 0;
+  float4 cq[T_CPT];
+  float cr[T_CPT];
+  bool cvalid[T_CPT];
+  if (col0 + T_CPT <= n2) {
+    const float4 r4 = *reinterpret_cast<const float4*>(radB + col0);
+    cr[0] = r4.x; cr[1] = r4.y; cr[2] = r4.z; cr[3] = r4.w;
+#pragma unroll
+    for (int c = 0; c < T_CPT; c++) {
+      cq[c] = rejB[col0 + c];
+      cvalid[c] = true;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < T_CPT; c++) {
+      cvalid[c] = (col0 + c) < n2;
+      cq[c] = cvalid[c] ? rejB[col0 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      cr[c] = cvalid[c] ? radB[col0 + c] : 0.f;
+    }
+  }
+  const bool all_valid = cvalid[T_CPT - 1];
+  // Bounding box of this WAVE's 256 columns (inflated extents included).  Anchors and refined boxes come in
+  // spatial order, so for most (row, wave) combinations the row's box lies outside it: one wave-uniform test
+  // then replaces the 4 per-column tests (~14 VALU operations each: the stream kernel was co-limited by them,
+  // 34 us against 15 us for a plain fill of the same 100 MB) and the row segment is stored as zeros.
+  // Waves with an invalid or non-finite column never take the shortcut.
+  float bx0 = cq[0].x - cq[0].z, bx1 = cq[0].x + cq[0].z, by0 = cq[0].y - cq[0].w, by1 = cq[0].y + cq[0].w;
+  bool fin = all_valid;
+#pragma unroll
+  for (int c = 0; c < T_CPT; c++) {
+    bx0 = fminf(bx0, cq[c].x - cq[c].z);
+    bx1 = fmaxf(bx1, cq[c].x + cq[c].z);
+    by0 = fminf(by0, cq[c].y - cq[c].w);
+    by1 = fmaxf(by1, cq[c].y + cq[c].w);
+    fin = fin && (fabsf(cq[c].x) < 3.0e38f) && (fabsf(cq[c].y) < 3.0e38f) && (cq[c].z < 3.0e38f) && (cq[c].w < 3.0e38f);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    bx0 = fminf(bx0, __shfl_xor(bx0, d));
+    bx1 = fmaxf(bx1, __shfl_xor(bx1, d));
+    by0 = fminf(by0, __shfl_xor(by0, d));
+    by1 = fmaxf(by1, __shfl_xor(by1, d));
+  }
+  const bool wave_ok = VEC && (__ballot(fin) == ~0ULL);
+  __syncthreads();
+  for (int r = 0; r < nrows; r++) {
+    const float* A = rows[r];
+    const float ax = A[0], ay = A[1], ar = A[2], aex = A[3], aey = A[4];
+    if (wave_ok && ((ax - aex > bx1) | (ax + aex < bx0) | (ay - aey > by1) | (ay + aey < by0))) {
+      *reinterpret_cast<float4*>(out + (size_t)(row0 + r) * n2 + col0) = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    bool pend[T_CPT];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < T_CPT; c++) {
+      float dx = ax - cq[c].x, dy = ay - cq[c].y;
+      float rr = ar + cr[c];
+      bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + cq[c].z) | (fabsf(dy) > aey + cq[c].w);
+      pend[c] = cvalid[c] && !apart;
+      any |= pend[c];
+    }
+    float* o = out + (size_t)(row0 + r) * n2 + col0;
+    if (VEC && all_valid && !any) {
+      *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int c = 0; c < T_CPT; c++)
+        if (cvalid[c] && !pend[c]) o[c] = 0.f;
+    }
+    if (__ballot(any)) {
+#pragma unroll
+      for (int c = 0; c < T_CPT; c++) {
+        unsigned long long m = __ballot(pend[c]);
+        if (m) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&qcount, __popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (pend[c]) {
+            int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
+            queue[slot] = (unsigned short)((r << 10) | (tid * T_CPT + c));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int total = qcount;
+  if (total == 0) return;
+  const unsigned reg = (blockIdx.x + blockIdx.y * 7u) % (unsigned)F_NREG;  // heavy column tiles spread over regions
+  if (tid == 0) qbase = atomicAdd(counter + reg * F_CSTRIDE, (unsigned)total);
+  __syncthreads();
+  const unsigned base = qbase;
+  // entries [0, fit) go to this region of the global queue; the rest (only when the bounded region is full:
+  // dense inputs) are clipped here, one pair per lane without LDS staging
+  const int fit = base >= qcap ? 0 : (int)min((unsigned)total, qcap - base);
+  unsigned* region = gqueue + (size_t)reg * qcap;
+  for (int q = tid; q < fit; q += T_THREADS) {
+    const unsigned e = queue[q];
+    region[base + q] = (unsigned)(row0 + (int)(e >> 10)) * (unsigned)n2 + (unsigned)(colbase + (int)(e & 1023u));
+  }
+  for (int q = fit + tid; q < total; q += T_THREADS) {
+    const unsigned e = queue[q];
+    const unsigned r = (unsigned)row0 + (e >> 10), c = (unsigned)colbase + (e & 1023u);
+    BoxRec A = recsA[r];
+    BoxRec B;
+    make_record<GEOM>(b2 + (size_t)c * 5, 0.f, B);
+    float v;
+    if (GEOM == 1) v = v1_pair_slow(A, B, iof != 0);
+    else if (GEOM == 2) v = hull_pair_slow<true>(A, B, iof == 0);
+    else v = hull_pair_slow<false>(A, B, iof == 0);
+    out[(size_t)r * n2 + c] = v;
+  }
+}
+
 template <int GEOM>
 __global__ __launch_bounds__(T_THREADS) void iou_drain_kernel(const BoxRec* __restrict__ recsA,
-                                                              const BoxRec* __restrict__ recsB, int n2,
+                                                              const float* __restrict__ b2, int n2,
                                                               int iof, const unsigned* __restrict__ gqueue,
-                                                              const unsigned* __restrict__ counter,
+                                                              const unsigned* __restrict__ counter, unsigned qcap,
                                                               float* __restrict__ out) {
   __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
+  __shared__ unsigned pre[F_NREG + 1];  // exclusive prefix of the regions' (clamped) counts
   const LanePts<T_THREADS> lp{pts + threadIdx.x};
-  const unsigned total = *counter;
+  if (threadIdx.x < 64) {
+    unsigned v = min(counter[threadIdx.x * F_CSTRIDE], qcap);
+    unsigned incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned t = __shfl_up(incl, d);
+      if ((int)threadIdx.x >= d) incl += t;
+    }
+    pre[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) pre[0] = 0;
+  }
+  __syncthreads();
+  const unsigned total = pre[F_NREG];
   for (unsigned q = blockIdx.x * T_THREADS + threadIdx.x; q < total; q += gridDim.x * T_THREADS) {
-    const unsigned e = gqueue[q];
+    int lo = 0;  // region of entry q: largest lo with pre[lo] <= q
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1)
+      if (pre[lo + step] <= q) lo += step;
+    const unsigned e = gqueue[(size_t)lo * qcap + (q - pre[lo])];
     const unsigned r = e / (unsigned)n2;
     const unsigned c = e - r * (unsigned)n2;
     const BoxRec A = recsA[r];
-    const BoxRec B = recsB[c];
+    BoxRec B;
+    make_record<GEOM>(b2 + (size_t)c * 5, 0.f, B);
     out[e] = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, iof != 0, lp);
   }
 }
@@ -453,6 +660,45 @@ __global__ __launch_bounds__(256) void iou_vec_kernel(const float* __restrict__ 
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+struct PipeLayout {
+  unsigned* ctl;
+  BoxRec* recsA;
+  float4* rejB;
+  float* radB;
+  unsigned* gqueue;
+  unsigned qcap;
+};
+
+// bounded global queue: 64 regions of pairs / 512 entries each = one eighth of the pairs in total (assignment
+// shapes have < 2 % survivors; a workgroup whose region is full clips in place), at least 1 K entries per region
+inline size_t pipe_layout(int n1, int n2, void* ws, PipeLayout* L) {
+  const unsigned long long pairs = (unsigned long long)n1 * (unsigned long long)n2;
+  unsigned long long qcap = pairs / (8 * F_NREG);
+  if (qcap < 1024) qcap = 1024;
+  size_t off = 0;
+  char* p = (char*)ws;
+  auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
+  char* ctl = take((size_t)F_CTL * 4);
+  char* ra = take((size_t)n1 * sizeof(BoxRec));
+  char* rj = take((size_t)n2 * 16);
+  char* rd = take((size_t)n2 * 4 + 16);
+  char* gq = take((size_t)qcap * F_NREG * 4);
+  if (L) {
+    L->ctl = (unsigned*)ctl; L->recsA = (BoxRec*)ra; L->rejB = (float4*)rj; L->radB = (float*)rd;
+    L->gqueue = (unsigned*)gq; L->qcap = (unsigned)qcap;
+  }
+  return off + 256;
+}
+
+template <int GEOM, int CPT, int ROWS>
+void launch_compact(bool vec, int iof, const float* b1, int n1, const float* b2, int n2, float* out, hipStream_t stream) {
+  dim3 grid((n2 + T_THREADS * CPT - 1) / (T_THREADS * CPT), (n1 + ROWS - 1) / ROWS);
+  if (vec)
+    hipLaunchKernelGGL((iou_mat_compact_kernel<GEOM, true, CPT, ROWS>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, out);
+  else
+    hipLaunchKernelGGL((iou_mat_compact_kernel<GEOM, false, CPT, ROWS>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, out);
+}
+
 template <int GEOM>
 int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float* out, void* ws,
                size_t ws_bytes, hipStream_t stream) {
@@ -462,35 +708,37 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
     hipLaunchKernelGGL(iou_mat_kernel<GEOM>, grid, dim3(IOU_BLOCK), 0, stream, b1, n1, b2, n2, iof, out);
     return 0;
   }
-  const bool fits32 = (unsigned long long)n1 * (unsigned long long)n2 < 0xffffffffULL;
-  const bool queued = ws && fits32 && ws_bytes >= r3k_iou_workspace_bytes(n1, n2) && g_r3_iou_impl != 2;
-  if (!queued) {
-    dim3 grid((n2 + T_COLS - 1) / T_COLS, (n1 + T_ROWS - 1) / T_ROWS);
-    if (vec)
-      hipLaunchKernelGGL((iou_mat_compact_kernel<GEOM, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, out);
-    else
-      hipLaunchKernelGGL((iou_mat_compact_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, out);
+  const unsigned long long pairs = (unsigned long long)n1 * (unsigned long long)n2;
+  const bool fits32 = pairs < 0xffffffffULL;
+  // small problems: ONE launch (no prep, no control words): narrow tiles so that the grid still fills CUs
+  const unsigned long long small_pairs = g_r3_iou_small > 0 ? (unsigned long long)g_r3_iou_small : 4000000ULL;
+  const bool piped = ws && fits32 && ws_bytes >= r3k_iou_workspace_bytes(n1, n2) && g_r3_iou_impl != 2 &&
+                     (pairs > small_pairs || g_r3_iou_impl == 4);
+  if (!piped) {
+    if (g_r3_iou_impl == 2 || pairs > small_pairs) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);
+    else if (n2 <= 512) launch_compact<GEOM, 1, 8>(vec, iof, b1, n1, b2, n2, out, stream);
+    else launch_compact<GEOM, 4, 8>(vec, iof, b1, n1, b2, n2, out, stream);
     return 0;
   }
-  char* p = (char*)ws;
-  unsigned* counter = (unsigned*)p;
-  p += 256;
-  BoxRec* recsA = (BoxRec*)p;
-  p += align256((size_t)n1 * sizeof(BoxRec));
-  BoxRec* recsB = (BoxRec*)p;
-  p += align256((size_t)n2 * sizeof(BoxRec));
-  unsigned* gqueue = (unsigned*)p;
-  if (hipMemsetAsync(counter, 0, sizeof(unsigned), stream) != hipSuccess) return -2;
-  dim3 grid((n2 + T_COLS - 1) / T_COLS, (n1 + S_ROWS - 1) / S_ROWS);
+  PipeLayout L;
+  pipe_layout(n1, n2, ws, &L);
+  const int nmax = (n1 > n2 ? n1 : n2) > F_CTL ? (n1 > n2 ? n1 : n2) : F_CTL;
+  hipLaunchKernelGGL(iou_prep_kernel<GEOM>, dim3((nmax + 255) / 256), dim3(256), 0, stream, b1, n1, b2, n2, L.recsA,
+                     L.rejB, L.radB, L.ctl);
+  const unsigned qcap = g_r3_iou_qcap > 0 && (unsigned)g_r3_iou_qcap < L.qcap ? (unsigned)g_r3_iou_qcap : L.qcap;
+  constexpr int SR = 16;
+  dim3 grid((n2 + T_COLS - 1) / T_COLS, (n1 + SR - 1) / SR);
   if (vec)
-    hipLaunchKernelGGL((iou_stream_kernel<GEOM, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, recsA, recsB, gqueue, counter);
+    hipLaunchKernelGGL((iou_stream2_kernel<GEOM, true, SR>), grid, dim3(T_THREADS), 0, stream, L.recsA, n1, b2, L.rejB,
+                       L.radB, n2, iof, out, L.ctl, L.gqueue, qcap);
   else
-    hipLaunchKernelGGL((iou_stream_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, recsA, recsB, gqueue, counter);
+    hipLaunchKernelGGL((iou_stream2_kernel<GEOM, false, SR>), grid, dim3(T_THREADS), 0, stream, L.recsA, n1, b2, L.rejB,
+                       L.radB, n2, iof, out, L.ctl, L.gqueue, qcap);
   // drain: enough workgroups to fill the chip at the kernel's occupancy; grid-stride inside
-  unsigned long long pairs = (unsigned long long)n1 * n2;
   int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(iou_drain_kernel<GEOM>, dim3(blocks), dim3(T_THREADS), 0, stream, recsA, recsB, n2, iof, gqueue, counter, out);
+  hipLaunchKernelGGL(iou_drain_kernel<GEOM>, dim3(blocks), dim3(T_THREADS), 0, stream, L.recsA, b2, n2, iof, L.gqueue,
+                     L.ctl, qcap, out);
   return 0;
 }
 
@@ -498,8 +746,7 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
 
 size_t r3k_iou_workspace_bytes(int n1, int n2) {
   if (n1 <= 0 || n2 <= 0) return 256;
-  return 256 + ((size_t)n1 * sizeof(BoxRec) + 255) / 256 * 256 + ((size_t)n2 * sizeof(BoxRec) + 255) / 256 * 256 +
-         (size_t)n1 * (size_t)n2 * sizeof(unsigned) + 256;
+  return pipe_layout(n1, n2, nullptr, nullptr);
 }
 
 int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,

@@ -35,14 +35,18 @@ def same(a, b):
     return np.array_equal(a, b, equal_nan=True)
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["queue", "simple", "compact"])
+@pytest.fixture(params=[0, 1, 2, 4, 5], ids=["auto", "simple", "compact", "pipeline", "pipeline-overflow"])
 def iou_impl(request):
-    """0 = stream + drain over a global queue (default), 1 = one thread per pair, 2 = single
-    kernel with an in-workgroup queue (the no-workspace path)."""
+    """0 = automatic (one-launch narrow-tile kernel for small matrices, prep + stream + drain pipeline for
+    large ones), 1 = one thread per pair, 2 = the wide one-launch kernel with an in-workgroup queue (the
+    no-workspace path), 4 = the pipeline whatever the size, 5 = the pipeline with its global queue capped at
+    100 entries (the stream kernel then clips what does not fit itself)."""
     from r3det import _C
-    _C.set_option("iou_impl", request.param)
+    _C.set_option("iou_impl", 4 if request.param == 5 else request.param)
+    _C.set_option("iou_qcap", 100 if request.param == 5 else 0)
     yield request.param
     _C.set_option("iou_impl", 0)
+    _C.set_option("iou_qcap", 0)
 
 
 @pytest.mark.parametrize("geom", [O.V1, O.V2, O.V3])

@@ -60,8 +60,8 @@ def bench_iou():
                 _C.set_option("iou_impl", impl)
                 fn(a, b)
             return run
-        var = {"v1 queue": mk(0, rbbox_iou), "v1 compact": mk(2, rbbox_iou), "v1 simple": mk(1, rbbox_iou),
-               "v3 queue": mk(0, box_iou_rotated_v3), "v2 queue": mk(0, box_iou_rotated)}
+        var = {"v1 auto": mk(0, rbbox_iou), "v1 fused": mk(4, rbbox_iou), "v1 compact": mk(2, rbbox_iou),
+               "v1 simple": mk(1, rbbox_iou), "v3 auto": mk(0, box_iou_rotated_v3), "v2 auto": mk(0, box_iou_rotated)}
         if m * n > 3e7:
             var.pop("v1 simple")
         for k, (med, mn) in time_variants(var).items():
