@@ -12,15 +12,17 @@
 //             test (labels, circles, axis-aligned bounds); surviving pairs go to an LDS
 //             queue and from there to one global queue;
 //   drain   : the global queue is clipped one pair per lane, chip-wide balanced; IoU > thr
-//             sets bit j of mask[i][j/64] (atomicOr), flags the word in a per-row "non-zero
-//             word" bitmap nz[i], records the in-block in-edge and appends the word index to
-//             the row's list (mark_pair);
-//   reduce  : ONE workgroup per problem walks the rows in score order.  Wave 0 resolves a
-//             64-row block by dependency rounds on the in-edge words; the other lanes OR the
-//             listed words of the surviving rows into the running `removed` words in LDS;
-//             lists, words and in-edges are requested 4-8 blocks ahead through register FIFOs
-//             (nms_reduce_pipe_kernel).  Emits the keep list and its length.  The reference
-//             copies the whole n x n/64 mask to the host (9.2 MB at n = 8576) and scans it there.
+//             appends i to the list of SUPPRESSORS of j (elist[j], up to 32 entries; beyond that
+//             bit i of row j of a transposed overflow mask) (mark_pair);
+//   reduce  : one workgroup per problem resolves the greedy scan by DEPENDENCY ROUNDS over all
+//             rows at once (nms_reduce_rounds_kernel): a row is removed as soon as one of its
+//             suppressors is known kept, kept as soon as all of them are known removed; kept /
+//             removed bit sets live in LDS, every thread gathers the few listed words of its rows.
+//             Suppression chains are short on detection pools (2-5 rounds); after 32 rounds a
+//             sequential in-order finish takes over (adversarial chains).  Emits the keep list and
+//             its length.  The reference copies the whole n x n/64 mask to the host (9.2 MB at
+//             n = 8576) and scans it there; round 1 of this build walked 64-row blocks in score
+//             order (two barriers per block: 36 us per 4 x 3.3 k boxes, 260 us at n = 8576).
 //   ascending (v1 only): rnms returns keep sorted by index (rnms_kernel.cu:331-334).
 // The batched detection pipeline at the end of the file (r3det_mcnms_*) runs select / sort /
 // offsets / these kernels with blockIdx.z = image / finish for all images of a step.
@@ -48,7 +50,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Batch {
   const int* counts;
   size_t recs, mask, nz, counter, queue, keep;
-  size_t rows;  // row capacity of one image's arrays (= n for a single problem): diagT = nz + rows * nzw
+  size_t rows;  // row capacity of one image's arrays (= n for a single problem); `nz` = stride of the side tables
 };
 
 inline Batch single_problem(int n) {
@@ -57,44 +59,34 @@ inline Batch single_problem(int n) {
   return b;
 }
 
-// Side tables of one image, in the same allocation as (and zeroed with) the nz bitmap rows:
-//   diagT[r] : in-edges of row r inside its 64-row block (bit i & 63: row i of the block suppresses r)
-//   wcnt[r]  : number of non-zero mask words of row r beyond its diagonal word
-//   wlist[r] : the first WL of those word indices, in arrival order
-// They let the reducer find a row's words without searching the bitmap (which stays authoritative:
-// rows with more than WL words fall back to it).
-constexpr int WL = 16;
+// In-edge lists of one image (in the same allocation as, and zeroed with, the overflow mask):
+//   ecnt[r]  : number of boxes i < r (score order) with IoU(i, r) > thr -- the suppressors of r
+//   elist[r] : the first EL of them (u16 sorted positions, arrival order; 64 bytes per row)
+// Suppressors beyond EL (very dense clusters) go to row r of the TRANSPOSED mask instead (bit i of
+// maskT[r][i / 64]), which the reducer scans only for rows with ecnt > EL.
+constexpr int EL = 32;
 
 struct Side {
-  u64* diagT;
-  int* wcnt;
-  unsigned short* wlist;
+  int* ecnt;
+  unsigned short* elist;
 };
 
-__host__ __device__ inline size_t nz_side_words(size_t rows, int nzw) {  // u64 words: bitmap + side tables
-  return rows * (size_t)(nzw + 1) + (rows + 1) / 2 + (rows * WL + 3) / 4;
+__host__ __device__ inline size_t side_words(size_t rows) {  // u64 words of the lists
+  return (rows * EL + 3) / 4 + (rows + 1) / 2;
 }
 
-__host__ __device__ inline Side side_tables(u64* nz, size_t rows, int nzw) {
+__host__ __device__ inline Side side_tables(u64* side, size_t rows) {
   Side s;
-  s.diagT = nz + rows * nzw;
-  s.wcnt = reinterpret_cast<int*>(s.diagT + rows);
-  s.wlist = reinterpret_cast<unsigned short*>(s.diagT + rows + (rows + 1) / 2);
+  s.elist = reinterpret_cast<unsigned short*>(side);  // first: rows * 64 B keeps every row 64-byte aligned
+  s.ecnt = reinterpret_cast<int*>(side + (rows * EL + 3) / 4);
   return s;
 }
 
-// pair (i, j), i < j in score order, suppresses: all the bookkeeping of one mask bit
-__device__ __forceinline__ void mark_pair(u64* mask, u64* nz, const Side& sd, unsigned i, unsigned j, int cb,
-                                          int nzw) {
-  const unsigned wj = j >> 6;
-  const u64 old = atomicOr(&mask[(size_t)i * cb + wj], 1ULL << (j & 63u));
-  atomicOr(&nz[(size_t)i * nzw + (wj >> 6)], 1ULL << (wj & 63u));
-  if ((i >> 6) == wj) {
-    atomicOr(&sd.diagT[j], 1ULL << (i & 63u));
-  } else if (old == 0ULL) {  // first bit of this word: register the word once
-    const int s = atomicAdd(&sd.wcnt[i], 1);
-    if (s < WL) sd.wlist[(size_t)i * WL + s] = (unsigned short)wj;
-  }
+// pair (i, j), i < j in score order, suppresses: i joins the suppressors of j
+__device__ __forceinline__ void mark_pair(u64* maskT, const Side& sd, unsigned i, unsigned j, int cb) {
+  const int s = atomicAdd(&sd.ecnt[j], 1);
+  if (s < EL) sd.elist[(size_t)j * EL + s] = (unsigned short)i;
+  else atomicOr(&maskT[(size_t)j * cb + (i >> 6)], 1ULL << (i & 63u));
 }
 
 template <int GEOM>
@@ -223,15 +215,29 @@ __global__ __launch_bounds__(1024) void nms_reduce_dense_kernel(const u64* __res
 }
 
 // ---------------------------------------------------------------------------- queue pipeline
-constexpr int SQ_CAP = MASK_WAVES * TILE * TILE;  // 16384 u16 entries: a workgroup cannot overflow
+constexpr int SQ_CAP = 2048;  // LDS queue entries per workgroup (4 KB; the worst case of 16384 made the queue
+                             // the occupancy limiter); survivors beyond it go to the global queue one by one
+
+// pair (i, j) clipped where it stands (scratch-array variant of the pair function): the safety net of the
+// stream kernel when a queue is full; exact, not a hot path
+template <int GEOM>
+__device__ __forceinline__ void clip_here(const BoxRec* __restrict__ recs, unsigned i, unsigned j, float thr,
+                                       u64* __restrict__ mask, const Side& sd, int cb) {
+  const BoxRec A = recs[i];
+  const BoxRec B = recs[j];
+  float v;
+  if (GEOM == 1) v = v1_pair_slow(A, B, false);
+  else if (GEOM == 2) v = hull_pair_slow<true>(A, B, true);
+  else v = hull_pair_slow<false>(A, B, true);
+  if (v > thr) mark_pair(mask, sd, i, j, cb);
+}
 
 // stream: reject tests only.  Entry in the global queue: (i << 16) | j, i < j sorted positions.
 template <int GEOM, bool LABEL>
 __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict__ recs, int n, int cb,
                                                         float thr, unsigned* __restrict__ gqueue,
                                                         unsigned qcap, unsigned* __restrict__ counter,
-                                                        u64* __restrict__ mask, u64* __restrict__ nz,
-                                                        int nzw, Batch bt) {
+                                                        u64* __restrict__ mask, u64* __restrict__ side, Batch bt) {
   __shared__ float cols[MASK_WAVES][TILE][8];  // cx, cy, rad, ex, ey, label
   __shared__ unsigned short queue[SQ_CAP];
   __shared__ int qcount;
@@ -246,10 +252,10 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
     gqueue += img * bt.queue;
     counter += img * bt.counter;
     mask += img * bt.mask;
-    nz += img * bt.nz;
+    side += img * bt.nz;
     if (rb * TILE >= n) return;
   }
-  const Side sd = side_tables(nz, bt.rows, nzw);
+  const Side sd = side_tables(side, bt.rows);
   const int cbn = (n + TILE - 1) / TILE;
   const int cblk = blockIdx.x * MASK_WAVES + wave;
   const bool active = (cblk < cbn) && (cblk >= rb);
@@ -258,18 +264,22 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
   if (active) {
     col_size = min(n - cblk * TILE, TILE);
     if (lane < col_size) {
-      const float* f = recs[cblk * TILE + lane].f;
-#pragma unroll
-      for (int k = 0; k < 5; k++) cols[wave][lane][k] = f[9 + k];
-      cols[wave][lane][5] = (GEOM != 1) ? f[7] : 0.f;
+      // the reject data sit in the record's last two 16-byte quads (f[9..13]), the label in f[7]: three
+      // 16-byte loads instead of six scalar loads at a 64-byte lane stride
+      const float4* f4 = reinterpret_cast<const float4*>(recs[cblk * TILE + lane].f);
+      const float4 q2 = f4[2], q3 = f4[3];
+      *reinterpret_cast<float4*>(&cols[wave][lane][0]) = make_float4(q2.y, q2.z, q2.w, q3.x);
+      cols[wave][lane][4] = q3.y;
+      cols[wave][lane][5] = (GEOM != 1) ? f4[1].w : 0.f;
     }
   }
   __syncthreads();
   const int row = rb * TILE + lane;
   if (active && row < n) {
-    const float* f = recs[row].f;
-    const float ax = f[9], ay = f[10], ar = f[11], aex = f[12], aey = f[13];
-    const float alab = (GEOM != 1) ? f[7] : 0.f;
+    const float4* f4 = reinterpret_cast<const float4*>(recs[row].f);
+    const float4 q2 = f4[2], q3 = f4[3];
+    const float ax = q2.y, ay = q2.z, ar = q2.w, aex = q3.x, aey = q3.y;
+    const float alab = (GEOM != 1) ? f4[1].w : 0.f;
     const int start = (rb == cblk) ? lane + 1 : 0;
     // 64 reject tests into one per-lane bit mask (no cross-lane traffic in the loop) ...
     u64 pm = 0;
@@ -286,12 +296,20 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
       while (pm) {
         const int i = __ffsll((long long)pm) - 1;
         pm &= pm - 1;
-        queue[slot++] = (unsigned short)((wave << 12) | (lane << 6) | i);
+        if (slot < SQ_CAP) {
+          queue[slot] = (unsigned short)((wave << 12) | (lane << 6) | i);
+        } else {  // LDS queue full (a very dense tile): straight to the global queue
+          const unsigned ii = rb * TILE + lane, jj = cblk * TILE + i;
+          const unsigned g = atomicAdd(counter, 1u);
+          if (g < qcap) gqueue[g] = (ii << 16) | jj;
+          else clip_here<GEOM>(recs, ii, jj, thr, mask, sd, cb);
+        }
+        slot++;
       }
     }
   }
   __syncthreads();
-  const int total = qcount;
+  const int total = min(qcount, SQ_CAP);
   if (total == 0) return;
   if (tid == 0) qbase = atomicAdd(counter, (unsigned)total);
   __syncthreads();
@@ -301,18 +319,8 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
     const unsigned w = e >> 12, lr = (e >> 6) & 63u, lc = e & 63u;
     const unsigned i = rb * TILE + lr;
     const unsigned j = (blockIdx.x * MASK_WAVES + w) * TILE + lc;
-    if (base + q < qcap) {
-      gqueue[base + q] = (i << 16) | j;
-    } else {
-      // global queue exhausted (pathologically dense input): clip here, still exact
-      const BoxRec A = recs[i];
-      const BoxRec B = recs[j];
-      float v;  // scratch-array variant: this path is a safety net, not a hot path
-      if (GEOM == 1) v = v1_pair_slow(A, B, false);
-      else if (GEOM == 2) v = hull_pair_slow<true>(A, B, true);
-      else v = hull_pair_slow<false>(A, B, true);
-      if (v > thr) mark_pair(mask, nz, sd, i, j, cb, nzw);
-    }
+    if (base + q < qcap) gqueue[base + q] = (i << 16) | j;
+    else clip_here<GEOM>(recs, i, j, thr, mask, sd, cb);  // global queue exhausted (pathologically dense input)
   }
 }
 
@@ -320,8 +328,7 @@ template <int GEOM>
 __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict__ recs, int cb, float thr,
                                                         const unsigned* __restrict__ gqueue, unsigned qcap,
                                                         const unsigned* __restrict__ counter,
-                                                        u64* __restrict__ mask, u64* __restrict__ nz,
-                                                        int nzw, Batch bt) {
+                                                        u64* __restrict__ mask, u64* __restrict__ side, Batch bt) {
   __shared__ float2 pts[pts_slots<GEOM>() * 256];
   const LanePts<256> lp{pts + threadIdx.x};
   if (bt.counts) {
@@ -330,9 +337,9 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
     gqueue += img * bt.queue;
     counter += img * bt.counter;
     mask += img * bt.mask;
-    nz += img * bt.nz;
+    side += img * bt.nz;
   }
-  const Side sd = side_tables(nz, bt.rows, nzw);
+  const Side sd = side_tables(side, bt.rows);
   unsigned total = *counter;
   if (total > qcap) total = qcap;
   for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
@@ -341,179 +348,220 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
     const BoxRec A = recs[i];
     const BoxRec B = recs[j];
     const float v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
-    if (v > thr) mark_pair(mask, nz, sd, i, j, cb, nzw);
+    if (v > thr) mark_pair(mask, sd, i, j, cb);
   }
 }
 
-// k-th (0-based) set bit position among the nz words of a row, restricted to word indices
-// > b.  Returns -1 when the row has fewer such words.
-__device__ __forceinline__ int kth_word(const u64* nzrow, int nzw, int b, int k) {
-  for (int q = b >> 6; q < nzw; q++) {
-    u64 m = nzrow[q];
-    if (q == (b >> 6)) {
-      const int sh = (b & 63) + 1;
-      m = (sh >= 64) ? 0ULL : (m >> sh) << sh;
-    }
-    const int c = __popcll(m);
-    if (k < c) {
-      for (int t = 0; t < k; t++) m &= m - 1;
-      return q * 64 + (__ffsll((long long)m) - 1);
-    }
-    k -= c;
+
+// ---------------------------------------------------------------------------- reduce by dependency rounds
+// Greedy NMS in score order: row r is kept  <=>  no kept row i < r has IoU(i, r) > thr.  elist[r] (+ the
+// overflow row of the transposed mask) lists exactly those i.  Kept (K) and removed (R) bit sets live in LDS
+// and only ever receive FINAL decisions: r -> R once some suppressor is in K, r -> K once all suppressors are
+// in R, so the order in which threads look is irrelevant and the fixed point is the sequential answer.  One
+// workgroup per problem, thread <-> rows tid, tid + 1024, ...; a row's count and its 64-byte list are five
+// independent loads at computable addresses; every thread keeps the counts and first 8 suppressors of its
+// (up to 9) rows in registers for all rounds, so a round is LDS bit lookups plus on-demand loads for the rows
+// with more than 8 suppressors.  Measured alternatives: gathering mask WORDS through a per-row word
+// list (three dependent round trips per row: 189 us at n = 8576); round 1's walk over 64-row blocks with two
+// barriers per block (36 us per 4 x 3.3 k boxes, 100 us at n = 8576).
+// On detection pools (clusters of near-duplicates) almost every row decides in rounds 1-3; a row can stay
+// undecided only as long as a suppression CHAIN runs through it, so R_MAX_ROUNDS bounds the parallel part
+// and wave 0 finishes adversarial inputs row by row in score order.
+constexpr int RTHREADS = 1024;
+constexpr int R_MAX_ROUNDS = 32;
+constexpr int R_CACHE = 9;  // rows per thread whose count and first 8 suppressors stay in registers (n <= 9216)
+
+// state of one suppressor list entry against the K / R bit sets
+#define R3_LOOK(i, on, anyK, allR)                         \
+  {                                                        \
+    anyK |= (on) && ((K32[(i) >> 5] >> ((i) & 31)) & 1u);  \
+    allR &= !(on) || ((R32[(i) >> 5] >> ((i) & 31)) & 1u); \
   }
-  return -1;
-}
 
-constexpr int RSLOTS = 16;  // speculative word slots per row: 64 rows x 16 = 1024 threads (4 slots measured 25-45 % slower: clusters of duplicates give ~10 non-zero words per row)
-constexpr int RTHREADS = TILE * RSLOTS;
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every
-// outstanding global load (s_waitcnt vmcnt(0)), which would serialise the prefetches below
-// behind a full memory round trip per 64-row block.
-#define R3_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-// Greedy scan of one 64-row block by DEPENDENCY ROUNDS instead of row by row.  Lane k holds its
-// in-edges (bit j: an earlier row j of the block suppresses k).  A row is removed as soon as one
-// of its suppressors is known to be kept, and kept as soon as all of them are known to be removed;
-// the lowest undecided row always decides, so this terminates with exactly the sequential greedy
-// answer -- after 2-4 rounds of ~15 instructions on real pools (suppression chains are short)
-// where the row-by-row form costs ~30 scalar instructions for each of up to 64 rows.
-__device__ __forceinline__ u64 scan_block_rounds(u64 in, u64 removed, u64 valid) {
-  u64 R = removed & valid, K = 0;
-  while ((K | R) != valid) {
-    R |= __ballot((in & K) != 0ULL) & valid;
-    K |= __ballot((in & ~R) == 0ULL) & ~R & valid;
-  }
-  return K;
-}
-
-// ---------------------------------------------------------------------------- reduce, pipelined
-// ONE workgroup per image walks the 64-row blocks in score order.  A first version kept its three
-// prefetch streams in shifting registers (d0 = d1) behind conditional loads and looked the word
-// addresses up in the row bitmap; measured per 64-row block ~1.6 us, of which the compiler's
-// s_waitcnt vmcnt(0) at the top of every iteration (shifting registers and conditional loads defeat
-// its counting) and the k-th-set-bit search were the two largest parts.  This form:
-//   * every stream is a FIFO of RP statically indexed registers (walk unrolled by RP), every load
-//     is unconditional (clamped address, validity applied at the use) and the keep list is written
-//     after the walk: the loop body is straight-line, the compiler waits vmcnt(4 RP - k);
-//   * a row's word indices come from the drain kernel's per-row list (Side::wlist), requested
-//     2 RP blocks ahead; the words themselves RP blocks ahead; rows with more than WL words
-//     re-apply all of their words through the bitmap (rare);
-//   * the 64-row block is resolved by dependency rounds on the in-edge words (scan_block_rounds).
-constexpr int RP = 4;  // request distance in 64-row blocks
-static_assert(RSLOTS == WL, "one thread per (row, listed word)");
-
-__global__ __launch_bounds__(RTHREADS) void nms_reduce_pipe_kernel(const u64* __restrict__ mask,
-                                                                   const u64* __restrict__ nz, int nzw, int n,
-                                                                   int cb, const int64_t* __restrict__ order,
-                                                                   int64_t* __restrict__ keep_out,
-                                                                   int32_t* __restrict__ count_out, Batch bt) {
+__global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* __restrict__ maskT,
+                                                                     const u64* __restrict__ side, int n, int cb,
+                                                                     const int64_t* __restrict__ order,
+                                                                     int64_t* __restrict__ keep_out,
+                                                                     int32_t* __restrict__ count_out, Batch bt) {
   extern __shared__ __attribute__((aligned(16))) u64 smem[];
+  __shared__ int s_und;
+  __shared__ int wsum[RTHREADS / 64];
   if (bt.counts) {
     const int img = blockIdx.z;
     n = bt.counts[img];
-    mask += img * bt.mask;
-    nz += img * bt.nz;
+    maskT += img * bt.mask;
+    side += img * bt.nz;
     keep_out += img * bt.keep;
     count_out += img;
   }
   const int cbn = (n + TILE - 1) / TILE;
-  u64* remv = smem;        // cb words: bits removed so far
-  u64* kbits = smem + cb;  // cb words: kept bits per block (the keep list is built after the walk)
-  int* pre = reinterpret_cast<int*>(smem + 2 * cb);  // 1024 partial sums of the epilogue
+  u64* Kb = smem;        // cb words: rows known kept
+  u64* Rb = smem + cb;   // cb words: rows known removed
+  const unsigned* K32 = reinterpret_cast<const unsigned*>(Kb);  // (bit lookups read 32-bit halves: one register each)
+  const unsigned* R32 = reinterpret_cast<const unsigned*>(Rb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int myrow = tid / RSLOTS, myk = tid % RSLOTS;
-  const Side sd = side_tables(const_cast<u64*>(nz), bt.rows, nzw);
+  const Side sd = side_tables(const_cast<u64*>(side), bt.rows);
 
-  auto diag_load = [&](int blk) -> u64 {  // in-edges of row (blk, lane) from earlier rows of its block
-    const int r = blk * TILE + lane;
-    return sd.diagT[r < n ? r : 0];
-  };
-  auto list_load = [&](int blk, int& cnt) -> unsigned {  // this thread's listed word index, and the row's count
-    const int gr = blk * TILE + myrow;
-    const size_t r = gr < n ? gr : 0;
-    cnt = sd.wcnt[r];
-    return sd.wlist[r * WL + myk];
-  };
-  // request of word (blk, myrow, myk-th listed); widx < 0: nothing to apply; over: the row needs the bitmap
-  auto word_load = [&](int blk, unsigned w, int cnt, int& widx, bool& over) -> u64 {
-    const int gr = blk * TILE + myrow;
-    const bool row_ok = gr < n;
-    over = row_ok && cnt > WL;
-    widx = (row_ok && myk < cnt) ? (int)w : -1;
-    return mask[widx >= 0 ? (size_t)gr * cb + widx : 0];
-  };
-
-  for (int j = tid; j < cb; j += RTHREADS) remv[j] = 0;
-  u64 Dq[RP], Wq[RP];
-  unsigned Lw[RP];
-  int Lc[RP], Wi[RP];
-  bool Wo[RP];
+  // prologue: every thread fetches the counts and first chunks of its rows (all loads in flight together)
+  int cnt[R_CACHE];
+  uint4 c0[R_CACHE];
 #pragma unroll
-  for (int s = 0; s < RP; s++) {
-    int cnt;
-    const unsigned w = list_load(s, cnt);
-    Wq[s] = word_load(s, w, cnt, Wi[s], Wo[s]);
-    Dq[s] = diag_load(s);
-    Lw[s] = list_load(RP + s, Lc[s]);
+  for (int u = 0; u < R_CACHE; u++) {
+    const int r = tid + u * RTHREADS;
+    const int rr = r < n ? r : 0;
+    cnt[u] = sd.ecnt[rr];
+    c0[u] = *reinterpret_cast<const uint4*>(sd.elist + (size_t)rr * EL);
+  }
+  unsigned big = 0;  // cached rows with more than 8 suppressors
+#pragma unroll
+  for (int u = 0; u < R_CACHE; u++) big |= (cnt[u] > 8 ? 1u : 0u) << u;
+  for (int j = tid; j < cb; j += RTHREADS) {
+    Kb[j] = 0;
+    Rb[j] = 0;
   }
   __syncthreads();
-
-  auto step = [&](int b, auto slot_c) {
-    constexpr int s = decltype(slot_c)::value;
-    // ---- stage 1: wave 0 resolves block b on its in-edge words
-    if (wave == 0) {
-      const int nvalid = min(TILE, n - b * TILE);
-      const u64 valid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1ULL);
-      const u64 in = (b * TILE + lane < n) ? Dq[s] : 0ULL;
-      const u64 kb = scan_block_rounds(in, readlane64(remv[b], 0), valid);
-      if (lane == 0) kbits[b] = kb;
-    }
-    Dq[s] = diag_load(b + RP);
-    R3_LDS_BARRIER();
-    // ---- stage 2: OR the words of the kept rows into remv
-    const u64 kb = kbits[b];
-    if ((kb >> myrow) & 1ULL) {
-      if (Wi[s] >= 0 && Wq[s]) atomicOr(&remv[Wi[s]], Wq[s]);
-      if (Wo[s]) {  // more than WL words: all of them through the bitmap (rare)
-        const size_t gr = (size_t)b * TILE + myrow;
-        for (int k = myk;; k += RSLOTS) {
-          const int w = kth_word(nz + gr * nzw, nzw, b, k);
-          if (w < 0) break;
-          const u64 v = mask[gr * cb + w];
-          if (v) atomicOr(&remv[w], v);
+  // rows without suppressors are kept: round 1 then already sees the cluster heads.  A wave's 64 rows of one
+  // pass are exactly one 64-bit word of the bit sets, and no other wave touches that word in this pass: the
+  // decisions are collected with a ballot and written by lane 0 (64 lanes doing an LDS atomicOr on the same
+  // word serialise: that was half of the reducer's time).
+#pragma unroll
+  for (int u = 0; u < R_CACHE; u++) {
+    const int r = tid + u * RTHREADS;
+    const u64 k0 = __ballot(r < n && cnt[u] == 0);
+    if (lane == 0 && k0) Kb[r >> 6] = k0;
+  }
+  for (int u = R_CACHE; wave * 64 + u * RTHREADS < n; u++) {
+    const int r = tid + u * RTHREADS;
+    const u64 k0 = __ballot(r < n && sd.ecnt[r < n ? r : 0] == 0);
+    if (lane == 0 && k0) Kb[r >> 6] = k0;
+  }
+  __syncthreads();
+  int round = 0;
+  for (; round < R_MAX_ROUNDS; round++) {
+    if (tid == 0) s_und = 0;
+    __syncthreads();
+    int und = 0;
+    // pass A: the cached rows with at most 8 suppressors, straight from registers
+#pragma unroll
+    for (int u = 0; u < R_CACHE; u++) {
+      const int r = tid + u * RTHREADS;
+      const int w = r >> 6;
+      const bool act = r < n && cnt[u] <= 8 && !((Kb[w] | Rb[w]) >> (r & 63) & 1ULL);
+      bool anyK = false, allR = true;
+      if (act) {
+        unsigned wv[4] = {c0[u].x, c0[u].y, c0[u].z, c0[u].w};
+        // opaque copies: without them the compiler hoists the 16 derived word indices / shifts of every cached
+        // row out of the round loop and spills (34 registers per row instead of 5)
+        asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+          R3_LOOK(i, q < cnt[u], anyK, allR);
         }
       }
+      const u64 mr = __ballot(act && anyK), mk = __ballot(act && !anyK && allR);
+      und += act && !anyK && !allR;
+      if (lane == 0) {
+        if (mr) Rb[w] |= mr;
+        if (mk) Kb[w] |= mk;
+      }
     }
-    Wq[s] = word_load(b + RP, Lw[s], Lc[s], Wi[s], Wo[s]);
-    Lw[s] = list_load(b + 2 * RP, Lc[s]);
-    R3_LDS_BARRIER();
-  };
-  for (int b = 0; b < cbn; b += RP) {
-    step(b, std::integral_constant<int, 0>{});
-    if (b + 1 >= cbn) break;
-    step(b + 1, std::integral_constant<int, 1>{});
-    if (b + 2 >= cbn) break;
-    step(b + 2, std::integral_constant<int, 2>{});
-    if (b + 3 >= cbn) break;
-    step(b + 3, std::integral_constant<int, 3>{});
+    // pass B (a loop, not unrolled): rows with longer lists and rows beyond the register cache reload their list
+    for (int u = 0; wave * 64 + u * RTHREADS < n; u++) {
+      const int r = tid + u * RTHREADS;
+      const int w = r >> 6;
+      const bool act = r < n && !(u < R_CACHE && !((big >> u) & 1u)) && !((Kb[w] | Rb[w]) >> (r & 63) & 1ULL);
+      bool anyK = false, allR = true;
+      if (act) {
+        const int c = sd.ecnt[r];
+        const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
+        const uint4 t[4] = {lp[0], lp[1], lp[2], lp[3]};
+        const int listed = min(c, EL);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) {  // 8 suppressors per chunk; a chunk no lane needs is skipped as a whole
+          if (listed > 8 * c4) {
+            const unsigned wv[4] = {t[c4].x, t[c4].y, t[c4].z, t[c4].w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+              R3_LOOK(i, 8 * c4 + q < listed, anyK, allR);
+            }
+          }
+        }
+        if (c > EL && !anyK) {  // suppressors beyond the list: scan the overflow row (dense clusters only)
+          const u64* row = maskT + (size_t)r * cb;
+          for (int q = 0; q <= w && !anyK; q++) {
+            const u64 mm = row[q];
+            anyK = (mm & Kb[q]) != 0ULL;
+            allR &= (mm & ~Rb[q]) == 0ULL;
+          }
+        }
+      }
+      const u64 mr = __ballot(act && anyK), mk = __ballot(act && !anyK && allR);
+      und += act && !anyK && !allR;
+      if (lane == 0) {
+        if (mr) Rb[w] |= mr;
+        if (mk) Kb[w] |= mk;
+      }
+    }
+    if (und) atomicAdd(&s_und, und);
+    __syncthreads();
+    const int left = s_und;
+    __syncthreads();
+    if (left == 0) break;
   }
-  static_assert(RP == 4, "the walk above is unrolled by hand");
+  if (round == R_MAX_ROUNDS && tid < 64) {
+    // a suppression chain longer than the round budget: wave 0 finishes in score order (every earlier row is
+    // decided when a row's turn comes, so "no kept suppressor" decides it); lanes split the row's suppressors
+    for (int b = 0; b < cbn; b++) {
+      const int nvalid = min(TILE, n - b * TILE);
+      const u64 valid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1ULL);
+      u64 todo = valid & ~(Kb[b] | Rb[b]);
+      while (todo) {
+        const int k = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int r = b * TILE + k;
+        const int cnt = sd.ecnt[r];
+        bool hit = false;
+        if (lane < min(cnt, EL)) {
+          const unsigned i = sd.elist[(size_t)r * EL + lane];
+          hit = (Kb[i >> 6] >> (i & 63)) & 1ULL;
+        }
+        if (cnt > EL) {
+          const u64* row = maskT + (size_t)r * cb;
+          for (int q = lane; q <= b; q += 64) hit |= (row[q] & Kb[q]) != 0ULL;
+        }
+        const bool removed = __ballot(hit) != 0ULL;
+        if (lane == 0) {
+          if (removed) Rb[b] |= 1ULL << k;
+          else Kb[b] |= 1ULL << k;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+      }
+    }
+  }
   __syncthreads();
-  // keep list: block counts -> exclusive scan -> sorted positions (or original indices)
-  int c = 0;
-  for (int b = tid; b < cbn; b += RTHREADS) c += __popcll(kbits[b]);  // cbn <= 1024: one block per thread
-  pre[tid] = c;
+  // keep list: block counts -> exclusive scan (wave shuffles + 16 partials) -> sorted positions / original indices
+  const int c = tid < cbn ? __popcll(Kb[tid]) : 0;  // cbn <= 1024: one block per thread
+  int incl = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  for (int off = 1; off < RTHREADS; off <<= 1) {
-    const int v = (tid >= off) ? pre[tid - off] : 0;
-    __syncthreads();
-    pre[tid] += v;
-    __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < RTHREADS / 64; w++) {
+    const int t = wsum[w];
+    if (w < wave) woff += t;
+    total += t;
   }
   if (tid < cbn) {
-    int pos = pre[tid] - c;
-    u64 kb = kbits[tid];
+    int pos = woff + incl - c;
+    u64 kb = Kb[tid];
     while (kb) {
       const int k = __ffsll((long long)kb) - 1;
       kb &= kb - 1;
@@ -521,8 +569,9 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_pipe_kernel(const u64* __
       keep_out[pos++] = order ? order[p] : (int64_t)p;
     }
   }
-  if (tid == RTHREADS - 1) *count_out = pre[tid];
+  if (tid == 0) *count_out = total;
 }
+#undef R3_LOOK
 
 // rnms returns keep sorted by original index (rnms_kernel.cu:331-334): mark kept originals,
 // then an ordered compaction by one workgroup.
@@ -561,7 +610,7 @@ struct Layout {
   unsigned* gqueue;
   unsigned qcap;
   uint8_t* flags;
-  int cb, nzw;
+  int cb;
 };
 
 inline size_t queue_entries(int n) {
@@ -574,13 +623,12 @@ inline size_t queue_entries(int n) {
 
 inline size_t layout(int n, void* ws, Layout* L) {
   const size_t cb = (n + TILE - 1) / TILE;
-  const size_t nzw = (cb + 63) / 64;
   size_t off = 0;
   char* p = (char*)ws;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
   char* recs = take((size_t)n * sizeof(BoxRec));
   char* mask = take((size_t)n * cb * sizeof(u64));  // mask and nz are zeroed together
-  char* nz = take(nz_side_words((size_t)n, (int)nzw) * sizeof(u64));  // bitmap rows + side tables
+  char* nz = take(side_words((size_t)n) * sizeof(u64));  // side tables (zeroed with the mask)
   char* counter = take(256);
   char* gq = take(queue_entries(n) * sizeof(unsigned));
   char* flags = take((size_t)n);
@@ -589,7 +637,7 @@ inline size_t layout(int n, void* ws, Layout* L) {
     L->gqueue = (unsigned*)gq; L->qcap = (unsigned)queue_entries(n); L->flags = (uint8_t*)flags;
     // test hook: a tiny capacity forces the in-kernel overflow path of nms_stream_kernel
     if (g_r3_nms_qcap > 0 && (unsigned)g_r3_nms_qcap < L->qcap) L->qcap = (unsigned)g_r3_nms_qcap;
-    L->cb = (int)cb; L->nzw = (int)nzw;
+    L->cb = (int)cb;
   }
   return off + 256;
 }
@@ -600,10 +648,10 @@ inline int drain_blocks(size_t qcap) {
 }
 
 // greedy reduction of `images` problems (blockIdx.z)
-inline void launch_reduce(int images, const u64* mask, const u64* nz, int nzw, int n, int cb, const int64_t* order,
+inline void launch_reduce(int images, const u64* mask, const u64* side, int n, int cb, const int64_t* order,
                           int64_t* keep_out, int32_t* count_out, const Batch& bt, hipStream_t stream) {
-  const size_t lds = (size_t)2 * cb * sizeof(u64) + RTHREADS * sizeof(int);
-  hipLaunchKernelGGL(nms_reduce_pipe_kernel, dim3(1, 1, images), dim3(RTHREADS), lds, stream, mask, nz, nzw, n, cb,
+  const size_t lds = (size_t)2 * cb * sizeof(u64);
+  hipLaunchKernelGGL(nms_reduce_rounds_kernel, dim3(1, 1, images), dim3(RTHREADS), lds, stream, mask, side, n, cb,
                      order, keep_out, count_out, bt);
 }
 
@@ -627,10 +675,10 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
   size_t zbytes = (size_t)((char*)L.counter - (char*)L.mask);
   if (hipMemsetAsync(L.mask, 0, zbytes, stream) != hipSuccess) return -2;
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, thr,
-                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw, single_problem(n));
+                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, single_problem(n));
   hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dim3(drain_blocks(L.qcap)), dim3(256), 0, stream, L.recs, cb, thr,
-                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, L.nzw, single_problem(n));
-  launch_reduce(1, L.mask, L.nz, L.nzw, n, cb, order, keep_out, count_out, single_problem(n), stream);
+                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, single_problem(n));
+  launch_reduce(1, L.mask, L.nz, n, cb, order, keep_out, count_out, single_problem(n), stream);
   return 0;
 }
 
@@ -669,6 +717,24 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* wsum, int& total
   return woff + incl - v;
 }
 
+// scores above the threshold in one row of K class scores (+ the background column).  Rows of K + 1 = 16 floats
+// (15 DOTA classes) are 64 aligned bytes: four 16-byte loads instead of 15 scalar ones at a 64-byte lane stride.
+__device__ __forceinline__ int count_above(const float* __restrict__ s, int K, float thr) {
+  int cnt = 0;
+  if (((K + 1) & 3) == 0 && (reinterpret_cast<uintptr_t>(s) & 15) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    const int nq = (K + 1) >> 2;
+    for (int q = 0; q < nq; q++) {
+      const float4 v = s4[q];
+      const int k = q * 4;
+      cnt += (v.x > thr) + (v.y > thr) + (v.z > thr) + ((k + 3 < K) & (v.w > thr));
+    }
+  } else {
+    for (int k = 0; k < K; k++) cnt += s[k] > thr;
+  }
+  return cnt;
+}
+
 // select, pass 1: candidates per 1024-row part of an image (+ max over their boxes' columns)
 __global__ __launch_bounds__(SEL_T) void mc_count_kernel(const float* __restrict__ boxes,
                                                          const float* __restrict__ scores, int n, int K,
@@ -682,7 +748,7 @@ __global__ __launch_bounds__(SEL_T) void mc_count_kernel(const float* __restrict
   float mx = -INFINITY;
   if (row < n) {
     const float* s = scores + ((size_t)img * n + row) * (K + 1);  // last column = background
-    for (int k = 0; k < K; k++) cnt += s[k] > thr;
+    cnt = count_above(s, K, thr);
     if (cnt) {
       const float* b = boxes + ((size_t)img * n + row) * 5;
       mx = fmaxf(fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])), b[4]);
@@ -732,8 +798,7 @@ __global__ __launch_bounds__(SEL_T) void mc_write_kernel(const float* __restrict
   }
   const float* s = scores + ((size_t)img * n + row) * (K + 1);
   int cnt = 0;
-  if (row < n)
-    for (int k = 0; k < K; k++) cnt += s[k] > thr;
+  if (row < n) cnt = count_above(s, K, thr);
   int total;
   int pos = base + block_exclusive_scan(cnt, wsum, total);
   if (cnt) {
@@ -1012,18 +1077,18 @@ struct McLayout {
   float* extent;
   int* ccounts;
   size_t qcap, zero_bytes;
-  int cb, nzw;
+  int cb;
 };
 
 inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
-  const size_t cb = (cap + TILE - 1) / TILE, nzw = (cb + 63) / 64, qcap = queue_entries(cap);
+  const size_t cb = (cap + TILE - 1) / TILE, qcap = queue_entries(cap);
   size_t off = 0;
   char* p = (char*)ws;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
   char* svals = take((size_t)B * cap * 4);
   char* recs = take((size_t)B * cap * sizeof(BoxRec));
   char* mask = take((size_t)B * cap * cb * 8);  // mask and nz: one fill
-  char* nz = take((size_t)B * nz_side_words((size_t)cap, (int)nzw) * 8);  // per image: bitmap rows, side tables
+  char* nz = take((size_t)B * side_words((size_t)cap) * 8);  // per image: side tables
   char* counter = take((size_t)B * 256);
   char* gq = take((size_t)B * qcap * 4);
   char* keep = take((size_t)B * cap * 8);
@@ -1036,7 +1101,7 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
     L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
     L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->keep = (int64_t*)keep;
     L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
-    L->qcap = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb; L->nzw = (int)nzw;
+    L->qcap = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb;
     if (g_r3_nms_qcap > 0 && (size_t)g_r3_nms_qcap < L->qcap) L->qcap = (size_t)g_r3_nms_qcap;
   }
   return off + 256;
@@ -1088,7 +1153,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   McLayout L;
   mc_layout(B, cap, ws, &L);
   const size_t cbq = (size_t)L.cb;
-  Batch bt{L.ccounts, (size_t)cap, (size_t)cap * cbq, nz_side_words((size_t)cap, L.nzw), 64, L.qcap, (size_t)cap,
+  Batch bt{L.ccounts, (size_t)cap, (size_t)cap * cbq, side_words((size_t)cap), 64, L.qcap, (size_t)cap,
            (size_t)cap};
   // the rank kernel accumulates into cand_rank: zeroed here so that a caller's stale scratch cannot send
   // records out of bounds; and the counts are clamped to cap for the same reason (an image with more
@@ -1110,14 +1175,14 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   hipLaunchKernelGGL(mc_prepare_kernel<GEOM>, pgrid, dim3(256), 0, stream, boxes, n, cand_row, cand_label,        \
                      cand_rank, S, counts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.counter, bt.counter);        \
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, iou_thr,       \
-                     L.gqueue, (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt);                              \
+                     L.gqueue, (unsigned)L.qcap, L.counter, L.mask, L.nz, bt);                              \
   hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dgrid, dim3(256), 0, stream, L.recs, L.cb, iou_thr, L.gqueue,        \
-                     (unsigned)L.qcap, L.counter, L.mask, L.nz, L.nzw, bt)
+                     (unsigned)L.qcap, L.counter, L.mask, L.nz, bt)
   if (geom == 1) { R3_MC(1, false, maxc); }
   else if (geom == 3) { R3_MC(3, false, L.extent); }
   else { R3_MC(2, true, (const float*)nullptr); }
 #undef R3_MC
-  launch_reduce(B, L.mask, L.nz, L.nzw, 0, L.cb, nullptr, L.keep, L.kept, bt, stream);
+  launch_reduce(B, L.mask, L.nz, 0, L.cb, nullptr, L.keep, L.kept, bt, stream);
   if (geom == 1)
     hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label, cand_score,
                        S, L.svals, counts, L.keep, bt.keep, L.kept, L.flags, out_cap, dets_out, labels_out,

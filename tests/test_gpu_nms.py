@@ -235,3 +235,47 @@ def test_multiclass_mmcv_branch():
     assert np.array_equal(dets.cpu().numpy(), wd[:100])
     assert np.array_equal(labels.cpu().numpy(), wl[:100])
     assert (np.diff(dets[:, 5].cpu().numpy()) <= 0).all()
+
+
+@pytest.mark.parametrize("n", [70, 500, 3000])
+def test_long_suppression_chain(n):
+    """A line of boxes in which box k overlaps only its neighbours and the scores decrease along the line:
+    the greedy answer alternates kept / removed and its dependency chain is n long -- beyond the reducer's
+    round budget (R_MAX_ROUNDS = 32), so the in-order finish of nms_reduce_rounds_kernel decides the rest."""
+    from r3det.ops import ml_nms_rotated, obb_nms, rnms
+    b = np.zeros((n, 5), np.float32)
+    b[:, 0] = 10.0 + 6.0 * np.arange(n)  # 10 wide, 6 apart: IoU(k, k+1) = 4/16 = 0.25, IoU(k, k+2) = 0
+    b[:, 1] = 50.0
+    b[:, 2] = 10.0
+    b[:, 3] = 20.0
+    s = np.linspace(0.9, 0.1, n).astype(np.float32)
+    perm = np.random.default_rng(n).permutation(n)  # original order shuffled: keep is reported in original indices
+    b, s = b[perm], s[perm]
+    d6 = np.hstack([b, s[:, None]])
+    with O.twin():
+        w1 = O.nms(O.V1, b, s, 0.1, strict=True, ascending=True)
+        w3 = O.nms(O.V3, b, s, 0.1, strict=True)
+    assert len(w1) == (n + 1) // 2
+    assert np.array_equal(rnms(dev(d6), 0.1)[1].cpu().numpy(), w1)
+    assert np.array_equal(obb_nms(dev(d6), 0.1)[1].cpu().numpy(), w3)
+    k2 = ml_nms_rotated(dev(b), dev(s), dev(np.zeros(n, np.int64)), 0.1)
+    assert np.array_equal(k2.cpu().numpy(), w3)
+
+
+def test_row_with_more_in_edge_words_than_the_list_holds():
+    """2 100 near-duplicates of one box: the last ones are suppressed from > 16 different 64-box words (the
+    per-row word list holds 16), so the reducer scans their mask rows; plus a second far cluster."""
+    from r3det.ops import rnms
+    r = np.random.default_rng(5)
+    n = 2100
+    b = np.tile(np.array([[200., 200., 60., 30., -0.4]], np.float32), (n, 1))
+    b[:, :2] += r.normal(0, 0.5, (n, 2)).astype(np.float32)
+    far = np.tile(np.array([[900., 700., 40., 40., -1.0]], np.float32), (300, 1))
+    far[:, :2] += r.normal(0, 0.3, (300, 2)).astype(np.float32)
+    b = np.vstack([b, far])
+    s = r.uniform(0.1, 1.0, len(b)).astype(np.float32)
+    d6 = np.hstack([b, s[:, None]])
+    with O.twin():
+        want = O.nms(O.V1, b, s, 0.1, strict=True, ascending=True)
+    assert len(want) == 2
+    assert np.array_equal(rnms(dev(d6), 0.1)[1].cpu().numpy(), want)
