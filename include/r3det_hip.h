@@ -236,6 +236,23 @@ int r3det_feature_refine_module_prepared(const float* mixed_a, const float* mixe
 int r3det_frm_mix_nchw(const float* a_nhwc, const float* b_nhwc, const float* bias_a, const float* bias_b, int N,
                        int C, int H, int W, float* out_nchw, void* stream);
 
+/* channels_last (NHWC) forms of the sampler: `features` / `output` are (N, H, W, C) contiguous -- the memory of a
+ * torch channels_last (N, C, H, W) tensor -- so that a channels_last pipeline needs no layout switch around
+ * the FR module.  Same results, element for element, as the NCHW entry points (feature_refine_cuda.forward,
+ * fr/src/feature_refine_cuda.cpp:24-42; kernel feature_refine_kernel.cu:112-163).  One wavefront per position,
+ * lane <-> 4 channels: C % 4 == 0 and 16-byte aligned pointers, else R3DET_EINVAL (nothing launched).
+ *   _forward_nhwc : output = features + sample(features)                      (1 read + 1 write per element)
+ *   _module_nhwc  : the FeatureRefineModule tail (fr/feature_refine_module.py:121-126) in one launch:
+ *                   P = (conv_a + bias_a) + (conv_b + bias_b), output = residual + (P + sample(P)), with conv_a /
+ *                   conv_b the RAW outputs of conv_5_1(conv_1_5(x)) and conv_1_1(x), residual = x
+ *                   (3 reads + 1 write per element; conv_b and the biases may be NULL). */
+int r3det_feature_refine_forward_nhwc(const float* features, const float* best_bboxes, int N, int C, int H, int W,
+                                      float spatial_scale, int points, float* output, void* stream);
+int r3det_feature_refine_module_nhwc(const float* conv_a, const float* conv_b, const float* bias_a,
+                                     const float* bias_b, const float* residual, const float* best_bboxes, int N,
+                                     int C, int H, int W, float spatial_scale, int points, float* output,
+                                     void* stream);
+
 /* The per-level loop of FeatureRefineModule.forward (fr/feature_refine_module.py:115-127) in one call:
  * `levels` sampler launches enqueued back to back (from Python each level costs ~10 us of host time, more
  * than the kernels of the three coarse levels).  features / best_bboxes / outputs: HOST arrays of `levels`

@@ -190,6 +190,21 @@ int r3det_feature_refine_module_prepared(const float* mixed_a, const float* mixe
   return rc(r3k_fr_forward_prepared(mixed_a, mixed_b, residual, table, N, C, H, W, output, S(stream)));
 }
 
+int r3det_feature_refine_forward_nhwc(const float* features, const float* best_bboxes, int N, int C, int H, int W,
+                                      float spatial_scale, int points, float* output, void* stream) {
+  return rc(r3k_fr_forward_nhwc(features, nullptr, nullptr, nullptr, nullptr, best_bboxes, N, C, H, W, spatial_scale,
+                                points, output, S(stream)));
+}
+
+int r3det_feature_refine_module_nhwc(const float* conv_a, const float* conv_b, const float* bias_a,
+                                     const float* bias_b, const float* residual, const float* best_bboxes, int N,
+                                     int C, int H, int W, float spatial_scale, int points, float* output,
+                                     void* stream) {
+  if (!conv_a || !residual) return R3DET_EINVAL;
+  return rc(r3k_fr_forward_nhwc(conv_a, conv_b, bias_a, bias_b, residual, best_bboxes, N, C, H, W, spatial_scale,
+                                points, output, S(stream)));
+}
+
 size_t r3det_fr_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points) {
   size_t total = 0;
   for (int l = 0; l < levels; l++) total += r3k_fr_workspace_bytes(N, H[l], W[l], points);

@@ -404,6 +404,93 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_backward_plane(const float* __re
 }
 
 // ----------------------------------------------------------------------------------------
+// channels_last (NHWC) forward kernel.  A position's C channels are contiguous (1 KB at C = 256): one
+// WAVEFRONT per output position, lane <-> 4 consecutive channels, so the identity read, each of the four
+// bilinear taps and the store are single coalesced 16-byte-per-lane accesses and the (wave-uniform) tap
+// geometry is computed once per position instead of once per (position, channel).  No LDS, no plane
+// staging: the transpose that the reference's x / y swap makes of the gather (row <- x_ctr,
+// feature_refine_kernel.cu:131-132) only changes WHICH 1 KB rows a wave reads.
+// Locality: a workgroup owns a 4 x 4 tile of output positions; its taps fall in a ~5 x 5 block of input
+// positions (transposed), so the 4 x re-read of every input row hits L1 / L2.  Tiles are dealt to the
+// eight XCDs in contiguous bands (blockIdx & 7 = XCD under round-robin dispatch): halo rows shared by
+// neighbouring tiles are then fetched into ONE L2 instead of up to eight.
+// FUSED (the FeatureRefineModule tail for channels_last pipelines, feature_refine_module.py:121-126): the
+// sampled map is P = (a + bias_a) + (b + bias_b) with a, b the raw outputs of conv_5_1 and conv_1_1, and
+// out = res + (P(id) + sample(P)) in the reference's operation order: 3 reads + 1 write per element and no
+// layout switch, where the NCHW sampler needed two transposing passes (r3det_frm_mix_nchw) around it.
+// ----------------------------------------------------------------------------------------
+constexpr int NH_TILE = 4;
+
+template <int POINTS, bool FUSED>
+__global__ __launch_bounds__(256) void fr_forward_nhwc(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ bias_a,
+                                                       const float* __restrict__ bias_b,
+                                                       const float* __restrict__ res,
+                                                       const float* __restrict__ boxes, int C, int H, int W,
+                                                       float scale, int tiles_x, int tiles_per_img, int T,
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned t = blockIdx.x;
+  if ((T & 7) == 0) t = (t & 7u) * (unsigned)(T >> 3) + (t >> 3);  // XCD-contiguous bands of tiles
+  const int n = (int)(t / (unsigned)tiles_per_img);
+  const int tt = (int)(t - (unsigned)n * (unsigned)tiles_per_img);
+  const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+  const int h = ty * NH_TILE + wave;
+  if (h >= H) return;
+  const int HW = H * W, C4 = C >> 2;
+  const size_t img = (size_t)n * HW;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  const float4* r4 = reinterpret_cast<const float4*>(res);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  for (int c4 = lane; c4 < C4; c4 += 64) {
+    float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+    if (FUSED) {
+      if (bias_a) ba = reinterpret_cast<const float4*>(bias_a)[c4];
+      if (bias_b) bb = reinterpret_cast<const float4*>(bias_b)[c4];
+    }
+    // value of the sampled map at position q (a plain load, or the module's (a + bias_a) + (b + bias_b))
+    auto P = [&](size_t q) -> float4 {
+      float4 v = a4[q * C4 + c4];
+      if (FUSED) {
+        v.x += ba.x; v.y += ba.y; v.z += ba.z; v.w += ba.w;
+        if (b) {
+          float4 u = b4[q * C4 + c4];
+          u.x += bb.x; u.y += bb.y; u.z += bb.z; u.w += bb.w;
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+      }
+      return v;
+    };
+#pragma unroll
+    for (int k = 0; k < NH_TILE; k++) {
+      const int w = tx * NH_TILE + k;
+      if (w >= W) break;
+      const int hw = h * W + w;
+      Tap taps[POINTS];
+      make_taps<POINTS>(boxes + (img + hw) * 5, scale, H, W, W, taps);
+      float4 v = P(img + hw);
+#pragma unroll
+      for (int p = 0; p < POINTS; p++) {
+        const Tap& tp = taps[p];
+        const float4 lt = P(img + tp.o00), rt = P(img + tp.o01), lb = P(img + tp.o10), rb = P(img + tp.o11);
+        float4 s;
+        s.x = tp.w1 * lt.x + tp.w2 * rt.x + tp.w3 * lb.x + tp.w4 * rb.x;
+        s.y = tp.w1 * lt.y + tp.w2 * rt.y + tp.w3 * lb.y + tp.w4 * rb.y;
+        s.z = tp.w1 * lt.z + tp.w2 * rt.z + tp.w3 * lb.z + tp.w4 * rb.z;
+        s.w = tp.w1 * lt.w + tp.w2 * rt.w + tp.w3 * lb.w + tp.w4 * rb.w;
+        if (tp.valid) { v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+      }
+      if (FUSED && res) {
+        const float4 r = r4[(img + hw) * C4 + c4];
+        v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
+      }
+      o4[(img + hw) * C4 + c4] = v;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // "cell" forward kernel (points = 1, W x H a compile-time power-of-two shape).
 // What the plane kernel pays per (n, c) plane besides the plane itself is the per-position sample
 // data (the 20-byte box, or any tap record derived from it) re-read through the CU's vector-memory
@@ -1231,6 +1318,34 @@ int r3k_fr_forward_prepared(const float* feat, const float* feat2, const float* 
   if (W == 128) { if (feat2) R3_PREP(7, 1); else if (res) R3_PREP(7, 2); else R3_PREP(7, 0); }
   else { if (feat2) R3_PREP(6, 1); else if (res) R3_PREP(6, 2); else R3_PREP(6, 0); }
 #undef R3_PREP
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// channels_last sampler: feat / out are (N, H, W, C) contiguous.  b, biases, res null: out = feat + sample(feat)
+// (r3det_feature_refine_forward on NHWC memory); otherwise the module tail
+// out = res + (P + sample(P)), P = (a + bias_a) + (b + bias_b).  C % 4 == 0 and 16-byte aligned pointers.
+int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, const float* bias_b, const float* res,
+                        const float* boxes, int N, int C, int H, int W, float scale, int points, float* out,
+                        hipStream_t stream) {
+  if (!a || !boxes || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5)) return -1;
+  if ((C & 3) || !aligned16(a) || !aligned16(out) || (b && !aligned16(b)) || (res && !aligned16(res)) ||
+      (bias_a && !aligned16(bias_a)) || (bias_b && !aligned16(bias_b)))
+    return -1;
+  const bool fused = b || bias_a || bias_b || res;
+  const int tiles_x = (W + NH_TILE - 1) / NH_TILE, tiles_y = (H + NH_TILE - 1) / NH_TILE;
+  const int tpi = tiles_x * tiles_y;
+  const long long T = (long long)tpi * N;
+  if (T > 0x7fffffffLL) return -1;
+  FrProfileSlot* ps = (g_r3_fr_profile && points == 1) ? fr_profile_next(N, H) : nullptr;
+  if (ps) ps->mode = 3;
+  hipEvent_t e0 = ps ? ps->ev[0] : nullptr, e1 = ps ? ps->ev[3] : nullptr;
+  const dim3 grid((unsigned)T), block(256);
+#define R3_NHWC(PTS, FU) \
+  hipExtLaunchKernelGGL((fr_forward_nhwc<PTS, FU>), grid, block, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, boxes, C, \
+                        H, W, scale, tiles_x, tpi, (int)T, out)
+  if (points == 1) { if (fused) R3_NHWC(1, true); else R3_NHWC(1, false); }
+  else { if (fused) R3_NHWC(5, true); else R3_NHWC(5, false); }
+#undef R3_NHWC
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

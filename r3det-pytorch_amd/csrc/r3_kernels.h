@@ -86,6 +86,12 @@ int r3k_fr_prepare(const float* boxes, int N, int H, int W, float scale, float* 
 int r3k_fr_forward_prepared(const float* feat, const float* feat2, const float* res, const float* table, int N, int C,
                             int H, int W, float* out, hipStream_t stream);
 
+// channels_last (N, H, W, C) sampler; b / biases / res non-null: the module tail out = res + (P + sample(P)),
+// P = (a + bias_a) + (b + bias_b)
+int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, const float* bias_b, const float* res,
+                        const float* boxes, int N, int C, int H, int W, float scale, int points, float* out,
+                        hipStream_t stream);
+
 // profiling ring of the FR cell path (see r3det_fr_profile_read)
 int r3k_fr_profile_read(float* records, int capacity);
 extern int g_r3_fr_profile;

@@ -39,6 +39,8 @@ SIGNATURES = {
     "r3det_feature_refine_prepare": [_vp, _i, _i, _i, _f, _vp, _vp],
     "r3det_feature_refine_forward_prepared": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "r3det_frm_mix_nchw": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "r3det_feature_refine_forward_nhwc": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp],
+    "r3det_feature_refine_module_nhwc": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp],
     "r3det_feature_refine_module_prepared": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "r3det_feature_refine_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "r3det_feature_refine_backward_ws": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _sz, _vp],

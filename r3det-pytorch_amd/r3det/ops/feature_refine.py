@@ -11,7 +11,6 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _C
-from .epilogue import mix_to_nchw
 
 
 # bench.py hook: when set to a list, (start, end) stream events are recorded around every
@@ -126,6 +125,51 @@ def fr_module_prepared(mixed_a, mixed_b, residual, table, output):
     return _taken(rc, "fr_module_prepared")
 
 
+def _need_cl(t, name):
+    """A 4-d fp32 HIP tensor whose memory is (N, H, W, C) contiguous (torch channels_last)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
+        raise RuntimeError(f"{name} must be a 4-d fp32 CUDA tensor")
+    if not t.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError(f"{name} must be channels_last contiguous")
+    return t
+
+
+def fr_forward_nhwc(features, best_rbboxes, spatial_scale, points, output):
+    """The sampler on channels_last memory (r3det_feature_refine_forward_nhwc): ``features`` / ``output`` are
+    (N, C, H, W) tensors in torch.channels_last.  Same values as ``fr_forward``.  False when the library does
+    not take the shape (C % 4 != 0): nothing was launched."""
+    f, o = _need_cl(features, "features"), _need_cl(output, "output")
+    b = _C.need_hip(best_rbboxes, "best_bboxes")
+    N, C, H, W = f.shape
+    if b.numel() != N * H * W * 5 or o.shape != f.shape:
+        raise RuntimeError("best_bboxes must hold N*H*W x 5 values and output must have the features' shape")
+    with torch.cuda.device(f.device):
+        rc = _C.lib().r3det_feature_refine_forward_nhwc(_C.ptr(f), _C.ptr(b), N, C, H, W, float(spatial_scale),
+                                                        int(points), _C.ptr(o), _C.stream())
+    return _taken(rc, "fr_forward_nhwc")
+
+
+def fr_module_nhwc(conv_a, conv_b, bias_a, bias_b, residual, best_rbboxes, spatial_scale, points, output):
+    """The FeatureRefineModule tail for channels_last pipelines in ONE launch
+    (r3det_feature_refine_module_nhwc): ``P = (conv_a + bias_a) + (conv_b + bias_b)``,
+    ``output = residual + (P + sample(P))`` with conv_a / conv_b the raw (bias-free) outputs of
+    conv_5_1(conv_1_5(x)) and conv_1_1(x).  All maps channels_last.  False when the shape is not taken."""
+    a, r, o = _need_cl(conv_a, "conv_a"), _need_cl(residual, "residual"), _need_cl(output, "output")
+    cb = _need_cl(conv_b, "conv_b") if conv_b is not None else None
+    b = _C.need_hip(best_rbboxes, "best_bboxes")
+    N, C, H, W = a.shape
+    if b.numel() != N * H * W * 5 or r.shape != a.shape or o.shape != a.shape or (cb is not None and cb.shape != a.shape):
+        raise RuntimeError("conv_a, conv_b, residual and output must have one shape; best_bboxes N*H*W x 5")
+    for t, nm in ((bias_a, "bias_a"), (bias_b, "bias_b")):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.numel() != C or not t.is_contiguous()):
+            raise RuntimeError(f"{nm} must be a contiguous fp32 CUDA tensor of C values")
+    with torch.cuda.device(a.device):
+        rc = _C.lib().r3det_feature_refine_module_nhwc(_C.ptr(a), _C.ptr(cb), _C.ptr(bias_a), _C.ptr(bias_b), _C.ptr(r),
+                                                       _C.ptr(b), N, C, H, W, float(spatial_scale), int(points),
+                                                       _C.ptr(o), _C.stream())
+    return _taken(rc, "fr_module_nhwc")
+
+
 def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, overwrite=False):
     """feature_refine_cuda.backward (feature_refine_cuda.cpp:44-66): accumulates into
     ``bottom_grad`` (``overwrite=True``: writes it, no zero-fill needed)."""
@@ -149,6 +193,7 @@ _pack_streams = {}
 # of GEMMs sit between the sampler's forward and backward (the pack kernels take 4 CUs from them) and
 # 35 us LONGER when nothing does (events + stream switches on the host).
 PACK_AT_FORWARD = False
+NHWC_ONLY = False  # tests: fail instead of falling back when a channels_last module input does not take the NHWC launch
 
 
 def fr_backward_prepare_async(best_rbboxes, N, H, W, spatial_scale):
@@ -279,33 +324,38 @@ class FeatureRefineModule(nn.Module):
         """x: list of per-level (N,C,H,W); best_rbboxes: list over images of lists over levels
         of (H*W, 5)."""
         per_level = [torch.cat(lvl) for lvl in zip(*best_rbboxes)]
-        # tap tables of all levels first: each sampler call below is then a single launch with no
-        # dependent launch in front of it
-        tables = [fr_prepare(b, f.size(0), f.size(2), f.size(3), fr.spatial_scale, fr.points)
-                  for f, b, fr in zip(x, per_level, self.fr)]
+        # the fused forward-only launches build no autograd graph: only when nothing here can need a gradient
+        no_grad = not (torch.is_grad_enabled() and (any(f.requires_grad for f in x)
+                                                    or any(p.requires_grad for p in self.parameters())))
+
+        def is_cl(t):
+            return (t.is_cuda and t.dtype == torch.float32 and t.size(1) % 4 == 0 and not t.is_contiguous()
+                    and t.is_contiguous(memory_format=torch.channels_last))
+        nhwc = [no_grad and is_cl(f) for f in x]
+        # tap tables of the NCHW levels first: each sampler call below is then a single launch with no
+        # dependent launch in front of it (the channels_last launch derives its taps from the boxes itself)
+        tables = [None if cl else fr_prepare(b, f.size(0), f.size(2), f.size(3), fr.spatial_scale, fr.points)
+                  for f, b, fr, cl in zip(x, per_level, self.fr, nhwc)]
         out = []
-        for feat, boxes, fr, table in zip(x, per_level, self.fr, tables):
-            # The sampler reads NCHW planes.  The three convolutions run in whatever layout the module's
-            # weights are in (a channels_last module on channels_last features: no layout switch inside
-            # MIOpen); their outputs and the residual are made NCHW here (no-ops for NCHW callers, like the
-            # reference).
-            # the fused forward-only launches build no autograd graph: only when nothing here can need a gradient
-            infer = table is not None and not (torch.is_grad_enabled() and (
-                feat.requires_grad or any(p.requires_grad for p in self.parameters())))
-            if infer and feat.is_cuda and feat.is_contiguous(memory_format=torch.channels_last) \
-                    and not feat.is_contiguous():
-                # channels_last inference: the two convolutions' bias adds, their sum and the layout switch in
-                # one pass (r3det_frm_mix_nchw), the residual add in the sampler launch
-                res = mix_to_nchw(feat)  # first: written back long before the sampler reads it
+        for feat, boxes, fr, table, cl in zip(x, per_level, self.fr, tables, nhwc):
+            if cl:
+                # channels_last inference: ONE launch for the module's tail, on channels_last memory -- the two
+                # convolutions' bias adds, their sum, the sampler and the residual add (3 reads + 1 write per
+                # element); the result feeds the refine head's channels_last convolutions directly.  (Round 1
+                # switched layouts around an NCHW sampler: two transposing passes per level.)
                 ra = F.conv2d(self.conv_1_5(feat), self.conv_5_1.weight, None, self.conv_5_1.stride,
                               self.conv_5_1.padding)
                 rb = F.conv2d(feat, self.conv_1_1.weight, None, self.conv_1_1.stride, self.conv_1_1.padding)
-                mixed = mix_to_nchw(ra, rb, self.conv_5_1.bias, self.conv_1_1.bias)
-                if mixed is not None and res is not None:
-                    fused = torch.empty_like(res)
-                    if fr_module_prepared(mixed, None, res, table, fused):
+                if is_cl(ra) and is_cl(rb):
+                    fused = torch.empty_like(feat)  # (preserves channels_last)
+                    if fr_module_nhwc(ra, rb, self.conv_5_1.bias, self.conv_1_1.bias, feat, boxes.contiguous(),
+                                      fr.spatial_scale, fr.points, fused):
                         out.append(fused)
                         continue
+                if NHWC_ONLY:
+                    raise RuntimeError("channels_last FR module path not taken")
+            # NCHW: the sampler reads NCHW planes (no-ops for NCHW callers, like the reference)
+            infer = table is not None and no_grad
             a, b = self.conv_5_1(self.conv_1_5(feat)).contiguous(), self.conv_1_1(feat).contiguous()
             feat = feat.contiguous()
             if infer:

@@ -338,9 +338,12 @@ def test_mix_to_nchw(shape, two):
 
 
 def test_module_channels_last_inference_path():
-    """FeatureRefineModule on channels_last features without grad: raw convolutions + r3det_frm_mix_nchw +
-    the sampler with the residual folded in.  Against the module's own three-step form on the same weights."""
+    """FeatureRefineModule on channels_last features without grad: raw convolutions + ONE channels_last launch
+    for the whole tail (r3det_feature_refine_module_nhwc), output channels_last.  Against the module's own
+    three-step NCHW form on the same weights (different convolution kernels per layout: not bitwise), and against
+    the NCHW sampler applied to the channels_last convolutions' outputs."""
     from r3det.ops import FeatureRefineModule
+    from r3det.ops import feature_refine as frmod
     from r3det import synthetic as syn
     torch.manual_seed(3)
     N, C = 2, 256
@@ -353,11 +356,85 @@ def test_module_channels_last_inference_path():
     with torch.no_grad():
         want = m(feats, rois)                         # NCHW module, NCHW features
         mcl = m.to(memory_format=torch.channels_last)
-        got = mcl([f.contiguous(memory_format=torch.channels_last) for f in feats], rois)
-    for g, w in zip(got, want):
-        assert g.shape == w.shape and g.is_contiguous()
-        # different convolution kernels per layout: not bitwise
-        assert torch.allclose(g, w, rtol=1e-4, atol=1e-4), float((g - w).abs().max())
+        cl_feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+        frmod.NHWC_ONLY = True
+        try:
+            got = mcl(cl_feats, rois)
+        finally:
+            frmod.NHWC_ONLY = False
+        for l, (g, w, f) in enumerate(zip(got, want, cl_feats)):
+            assert g.shape == w.shape
+            assert g.is_contiguous(memory_format=torch.channels_last)
+            assert torch.allclose(g, w, rtol=1e-4, atol=1e-4), float((g - w).abs().max())
+            # the same arithmetic through the NCHW sampler on the channels_last convolutions' outputs (recomputed here:
+            # MIOpen may pick another kernel for the repeated call, so rounding-level, not bitwise; the bitwise
+            # statement is test_module_nhwc_bit_identical_to_the_nchw_steps)
+            a = torch.nn.functional.conv2d(mcl.conv_1_5(f), mcl.conv_5_1.weight, None, 1, mcl.conv_5_1.padding)
+            b = torch.nn.functional.conv2d(f, mcl.conv_1_1.weight, None)
+            mixed = ((a + mcl.conv_5_1.bias.view(1, -1, 1, 1)) + (b + mcl.conv_1_1.bias.view(1, -1, 1, 1))).contiguous()
+            sampled = torch.empty_like(mixed)
+            frmod.fr_forward(mixed, boxes[l], 1.0 / syn.STRIDES[l], 1, sampled)
+            assert torch.allclose(g.contiguous(), f.contiguous() + sampled, rtol=1e-5, atol=1e-5), l
+
+
+NHWC_SHAPES = [(n, (c + 3) // 4 * 4, h, w, st) for n, c, h, w, st in SHAPES] + [(2, 256, 64, 64, 16), (1, 260, 9, 5, 32)]
+
+
+@pytest.mark.parametrize("shape", NHWC_SHAPES)
+@pytest.mark.parametrize("points", [1, 5])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_forward_nhwc_bit_exact(shape, points, adversarial):
+    """The channels_last sampler (one wavefront per position) against the twin oracle on the transposed
+    input: every spatial shape of SHAPES with C rounded up to a multiple of 4, bit-exact."""
+    from r3det.ops.feature_refine import fr_forward_nhwc
+    N, C, H, W, stride = shape
+    r = np.random.default_rng(5 + C)
+    cs = min(C, 24)  # the oracle is serial: check the first and the last channels of wide maps
+    feat = r.normal(size=(N, C, H, W)).astype(np.float32)
+    boxes = fr_boxes(N, H, W, stride, 6, adversarial=adversarial)
+    sel = np.r_[0:cs // 2, C - cs // 2:C]
+    with O.twin():
+        want = O.fr_forward(np.ascontiguousarray(feat[:, sel]), boxes, 1 / stride, points, threads=8)
+    x = dev(feat).contiguous(memory_format=torch.channels_last)
+    out = torch.full((N, C, H, W), float('nan'), device='cuda').contiguous(memory_format=torch.channels_last)
+    assert fr_forward_nhwc(x, dev(boxes), 1 / stride, points, out)
+    assert not bool(torch.isnan(out).any())
+    assert np.array_equal(out[:, torch.from_numpy(sel).cuda()].contiguous().cpu().numpy(), want)
+
+
+def test_forward_nhwc_refuses_odd_channel_counts():
+    from r3det.ops.feature_refine import fr_forward_nhwc
+    x = torch.randn(1, 6, 8, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+    out = torch.full_like(x, 3.0)
+    assert not fr_forward_nhwc(x, dev(fr_boxes(1, 8, 8, 8, 1)), 0.125, 1, out)
+    assert bool((out == 3.0).all())
+    with pytest.raises(RuntimeError):
+        fr_forward_nhwc(x.contiguous(), dev(fr_boxes(1, 8, 8, 8, 1)), 0.125, 1, out)  # NCHW memory
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 128, 128, 8), (4, 256, 64, 64, 16), (3, 64, 13, 7, 32), (1, 256, 1, 1, 128)])
+@pytest.mark.parametrize("points", [1, 5])
+@pytest.mark.parametrize("with_b", [True, False])
+def test_module_nhwc_bit_identical_to_the_nchw_steps(shape, points, with_b):
+    """r3det_feature_refine_module_nhwc = residual + fr((a + bias_a) + (b + bias_b)) in one launch on
+    channels_last memory: bit-identical to the elementwise steps + the NCHW sampler (itself pinned to the
+    oracle above)."""
+    from r3det.ops.feature_refine import fr_forward, fr_module_nhwc
+    N, C, H, W, stride = shape
+    g = torch.Generator(device='cuda').manual_seed(C + H + points)
+    cl = torch.channels_last
+    a, b, res = (torch.randn(N, C, H, W, device='cuda', generator=g).contiguous(memory_format=cl) for _ in range(3))
+    ba, bb = torch.randn(C, device='cuda', generator=g), torch.randn(C, device='cuda', generator=g)
+    boxes = dev(fr_boxes(N, H, W, stride, 17, adversarial=True))
+    out = torch.full_like(a, float('nan'))
+    assert fr_module_nhwc(a, b if with_b else None, ba, bb if with_b else None, res, boxes, 1 / stride, points, out)
+    mixed = a + ba.view(1, -1, 1, 1)
+    if with_b:
+        mixed = mixed + (b + bb.view(1, -1, 1, 1))
+    mixed = mixed.contiguous()
+    sampled = torch.empty_like(mixed)
+    fr_forward(mixed, boxes, 1 / stride, points, sampled)
+    assert torch.equal(out.contiguous(), res.contiguous() + sampled)
 
 
 @pytest.mark.parametrize("level", [0, 1, 2, 4])
