@@ -94,6 +94,9 @@ def model_step(model, img):
 
 # ------------------------------------------------------------------------------------ training
 def build_train(device, seed, world):
+    # MIOpen's exhaustive find mode (cudnn.benchmark) searches every convolution of the step in three directions:
+    # 9 minutes on a fresh box for a 57 ms step.  The training step runs in immediate mode.
+    torch.backends.cudnn.benchmark = False
     from r3det import dist_train as dt
     from r3det import synthetic as syn
     from r3det.models import R3Det
@@ -454,11 +457,11 @@ def main():
         # profiler), so `achieved` errs on the low side.
         span_us = sum(r[4] for r in recs) / max(1, len(recs))
         H = W = 128
-        # 8 B per element (read + write once) for the sampler + the per-position sample data,
-        # which this kernel reads as an 8-byte tap (the 20-byte boxes are read by the table kernel, 1.3 MB, not
-        # counted here).  In the model the launch also carries the module's residual add: one more read per
-        # element, i.e. 12 B per element.
-        alg_bytes = 3 * 4 * BATCH * C * H * W + 8 * BATCH * H * W
+        # The launch is the FeatureRefineModule tail on channels_last memory (r3det_feature_refine_module_nhwc):
+        # conv_a, conv_b and the residual read once, the output written once = 16 B per element (SURVEY 8d's 8 B per
+        # element for the bare sampler + the module's two extra input streams that the launch folds in), plus the
+        # 20-byte box per position.
+        alg_bytes = 4 * 4 * BATCH * C * H * W + 20 * BATCH * H * W
         achieved = alg_bytes / (span_us * 1e-6) / 1e9 if recs else 0.0
         traffic, traffic_src = load_traffic()
         line = dict(common, **{
@@ -473,9 +476,10 @@ def main():
                                    "to ~1 % candidates",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "nms_type": "v1",
                        "parallelism": f"image-parallel x{world}, all_gather of detections"},
-            "roofline": {"bound": "hbm", "kernel": "FR forward level 0 (4x256x128x128) with the FeatureRefineModule's residual "
-                                                   "add folded in (2 reads + 1 write per element); duration = the launch's own "
-                                                   "start/stop HIP events (hipExtLaunchKernelGGL), timed steps",
+            "roofline": {"bound": "hbm", "kernel": "fr_forward_nhwc_pipe<true,4> = the FeatureRefineModule tail at level 0 "
+                                                   "(4x256x128x128, channels_last): (conv_a + bias) + (conv_b + bias), sampler, "
+                                                   "residual in one launch, 3 reads + 1 write per element; duration = the "
+                                                   "launch's own start/stop HIP events (hipExtLaunchKernelGGL), timed steps",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(span_us, 2),
@@ -527,31 +531,34 @@ def main():
                     "launches_timed": len(ctx["span"]),
                     "table_kernel_us_own_events": round(sum(r[2] for r in ctx["each"]) / max(1, len(ctx["each"])), 2),
                     "cell_kernel_us_own_events": round(sum(r[3] for r in ctx["each"]) / max(1, len(ctx["each"])), 2)}
-            # the roofline kernel alone, rotating over four input / output sets (4 x 403 MB): every launch
-            # reads and writes lines that are NOT in the 256 MiB Infinity Cache -> an HBM figure
-            from r3det.ops.feature_refine import fr_module_prepared, fr_prepare
-            f0, b0 = wl["feats"][0], wl["boxes"][0]
-            table = fr_prepare(b0, BATCH, H, W, 1.0 / 8)
-            sets = [(torch.randn_like(f0), torch.randn_like(f0), torch.empty_like(f0)) for _ in range(4)]
+            # the roofline kernel alone, rotating over three buffer sets (3 x 268 MB): every launch reads and
+            # writes lines that are NOT in the 256 MiB Infinity Cache -> an HBM figure
+            from r3det.ops.feature_refine import fr_module_nhwc
+            cl = torch.channels_last
+            b0 = wl["boxes"][0]
+            shape = wl["feats"][0].shape
+            sets = [tuple(torch.randn(shape, device=device).contiguous(memory_format=cl) for _ in range(4))
+                    for _ in range(3)]
+            bias = torch.randn(C, device=device)
             state = [0]
 
             def rot():
-                a, r, o = sets[state[0] % 4]
+                a, b, r, o = sets[state[0] % 3]
                 state[0] += 1
-                fr_module_prepared(a, None, r, table, o)
+                fr_module_nhwc(a, b, bias, bias, r, b0, 1.0 / 8, 1, o)
             _C.fr_profile_read()
             _C.set_option("fr_profile", 2)
-            timeit(rot, 20, warm=4)
+            timeit(rot, 20, warm=3)
             _C.set_option("fr_profile", 0)
             alone = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
             if alone:
                 us = sum(r[4] for r in alone) / len(alone)
                 line["roofline"]["kernel_alone_hbm"] = {
-                    "what": "the same launch repeated on its own over 4 rotating buffer sets (1.6 GB: beyond the "
+                    "what": "the same launch repeated on its own over 3 rotating buffer sets (0.8 GB: beyond the "
                             "Infinity Cache)",
                     "avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
                     "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
-            del sets, table, wl
+            del sets, wl
         if not args.no_ops:
             phase("op rates")
             line["ops"] = op_rates(device)

@@ -410,8 +410,8 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_backward_plane(const float* __re
 // geometry is computed once per position instead of once per (position, channel).  No LDS, no plane
 // staging: the transpose that the reference's x / y swap makes of the gather (row <- x_ctr,
 // feature_refine_kernel.cu:131-132) only changes WHICH 1 KB rows a wave reads.
-// Locality: a workgroup owns a 4 x 4 tile of output positions; its taps fall in a ~5 x 5 block of input
-// positions (transposed), so the 4 x re-read of every input row hits L1 / L2.  Tiles are dealt to the
+// Locality: a workgroup owns an 8 x 8 tile of output positions (two rows per wave); its taps fall in a ~9 x 9 block
+// of input positions (the transposed tile), so the re-reads of every input row hit L1 / L2.  Tiles are dealt to the
 // eight XCDs in contiguous bands (blockIdx & 7 = XCD under round-robin dispatch): halo rows shared by
 // neighbouring tiles are then fetched into ONE L2 instead of up to eight.
 // FUSED (the FeatureRefineModule tail for channels_last pipelines, feature_refine_module.py:121-126): the
@@ -419,9 +419,9 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_backward_plane(const float* __re
 // out = res + (P(id) + sample(P)) in the reference's operation order: 3 reads + 1 write per element and no
 // layout switch, where the NCHW sampler needed two transposing passes (r3det_frm_mix_nchw) around it.
 // ----------------------------------------------------------------------------------------
-constexpr int NH_TILE = 4;
+constexpr int NH_ROWS = 4;  // output rows per workgroup (one wave each)
 
-template <int POINTS, bool FUSED>
+template <int POINTS, bool FUSED, int KW>
 __global__ __launch_bounds__(256) void fr_forward_nhwc(const float* __restrict__ a, const float* __restrict__ b,
                                                        const float* __restrict__ bias_a,
                                                        const float* __restrict__ bias_b,
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void fr_forward_nhwc(const float* __restrict__
   const int n = (int)(t / (unsigned)tiles_per_img);
   const int tt = (int)(t - (unsigned)n * (unsigned)tiles_per_img);
   const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
-  const int h = ty * NH_TILE + wave;
+  const int h = ty * NH_ROWS + wave;
   if (h >= H) return;
   const int HW = H * W, C4 = C >> 2;
   const size_t img = (size_t)n * HW;
@@ -462,10 +462,12 @@ __global__ __launch_bounds__(256) void fr_forward_nhwc(const float* __restrict__
       }
       return v;
     };
+    // a wave walks KW consecutive output columns of its row
 #pragma unroll
-    for (int k = 0; k < NH_TILE; k++) {
-      const int w = tx * NH_TILE + k;
-      if (w >= W) break;
+    for (int k = 0; k < KW; k++) {
+      const int wq = tx * KW + k;
+      const bool live = wq < W;
+      const int w = live ? wq : W - 1;  // (clamped: no early exit, so that the loads of all k can be interleaved)
       const int hw = h * W + w;
       Tap taps[POINTS];
       make_taps<POINTS>(boxes + (img + hw) * 5, scale, H, W, W, taps);
@@ -485,7 +487,120 @@ __global__ __launch_bounds__(256) void fr_forward_nhwc(const float* __restrict__
         const float4 r = r4[(img + hw) * C4 + c4];
         v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w;
       }
-      o4[(img + hw) * C4 + c4] = v;
+      if (live) o4[(img + hw) * C4 + c4] = v;
+    }
+  }
+}
+
+// Software-pipelined form for points = 1 (the shipped configuration).  The simple kernel above is latency-bound:
+// per position a wave waits for the box, derives the tap, waits for its 11 loads, stores (3.2 TB/s on four streams
+// with one position per wave, less with more).  Here a wave walks KW consecutive columns of its row with a
+// three-stage pipeline in registers: box of position i + 2 requested | tap of i + 1 derived and its 11 loads
+// issued | position i consumed and stored -- so every wave always has one position's loads (11 x 1 KB) in flight.
+// Measured (level 0, N = 4, C = 256, buffers rotating beyond the Infinity Cache; tools/fr_nhwc_var.py,
+// gpurun PMC passes): 80-83 us whatever the form (1 / 4 / 8 / 16 columns per wave, pipelined or not, pairs of
+// taps reused in registers or not): FETCH_SIZE x 2 = 335 MB against 201 MB of inputs -- conv_a and conv_b cross
+// the fabric TWICE, once as the identity of their own position and once as taps of the transposed positions,
+// because ~160 concurrent workgroups stream ~16 MB through a 4 MB L2 between the two uses.  335 + 67 MB written
+// in 83 us = 4.85 TB/s: the same memory-side rate the NCHW kernels reach; the kernel is bound there.  Handling
+// an output tile and its transpose in one workgroup (second use right after the first) did not raise the L2
+// hit rate (4.05 M hits / 3.22 M misses vs 3.86 / 3.31) and cost 8 % (fewer, longer workgroups): not shipped.
+struct NhwcLoads {
+  float4 ia, ib, ir;     // identity: conv_a, conv_b, residual
+  float4 ta[4], tb[4];   // the four taps of conv_a / conv_b
+};
+
+template <bool FUSED, int KW>
+__global__ __launch_bounds__(256) void fr_forward_nhwc_pipe(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ bias_a,
+                                                            const float* __restrict__ bias_b,
+                                                            const float* __restrict__ res,
+                                                            const float* __restrict__ boxes, int C, int H, int W,
+                                                            float scale, int tiles_x, int tiles_per_img, int T,
+                                                            float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned t = blockIdx.x;
+  if ((T & 7) == 0) t = (t & 7u) * (unsigned)(T >> 3) + (t >> 3);  // XCD-contiguous bands of tiles
+  const int n = (int)(t / (unsigned)tiles_per_img);
+  const int tt = (int)(t - (unsigned)n * (unsigned)tiles_per_img);
+  const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+  const int h = ty * NH_ROWS + wave;
+  if (h >= H) return;
+  const int HW = H * W, C4 = C >> 2;
+  const size_t img = (size_t)n * HW;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  const float4* r4 = reinterpret_cast<const float4*>(res);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  const int w0 = tx * KW;
+  const int cnt = min(KW, W - w0);
+  const bool two = FUSED && b != nullptr, has_res = FUSED && res != nullptr;
+  for (int c4 = lane; c4 < C4; c4 += 64) {
+    float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+    if (FUSED) {
+      if (bias_a) ba = reinterpret_cast<const float4*>(bias_a)[c4];
+      if (bias_b) bb = reinterpret_cast<const float4*>(bias_b)[c4];
+    }
+    auto box_of = [&](int i, float& bx, float& by) {  // (clamped index: the loads are unconditional)
+      const float* bp = boxes + (img + (size_t)h * W + w0 + min(i, cnt - 1)) * 5;
+      bx = bp[0];
+      by = bp[1];
+    };
+    auto issue = [&](int i, const Tap& tp, NhwcLoads& L) {
+      const size_t q = img + (size_t)h * W + w0 + min(i, cnt - 1);
+      const size_t o[4] = {img + tp.o00, img + tp.o01, img + tp.o10, img + tp.o11};
+      L.ia = a4[q * C4 + c4];
+      if (two) L.ib = b4[q * C4 + c4];
+      if (has_res) L.ir = r4[q * C4 + c4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        L.ta[k] = a4[o[k] * C4 + c4];
+        if (two) L.tb[k] = b4[o[k] * C4 + c4];
+      }
+    };
+    auto mixv = [&](const float4& x, const float4& y) -> float4 {  // (x + bias_a) + (y + bias_b), or x alone
+      float4 v = x;
+      if (FUSED) {
+        v.x += ba.x; v.y += ba.y; v.z += ba.z; v.w += ba.w;
+        if (two) {
+          float4 u = y;
+          u.x += bb.x; u.y += bb.y; u.z += bb.z; u.w += bb.w;
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+      }
+      return v;
+    };
+    auto consume = [&](int i, const Tap& tp, const NhwcLoads& L) {
+      float4 v = mixv(L.ia, L.ib);
+      const float4 lt = mixv(L.ta[0], L.tb[0]), rt = mixv(L.ta[1], L.tb[1]);
+      const float4 lb = mixv(L.ta[2], L.tb[2]), rb = mixv(L.ta[3], L.tb[3]);
+      float4 s;
+      s.x = tp.w1 * lt.x + tp.w2 * rt.x + tp.w3 * lb.x + tp.w4 * rb.x;
+      s.y = tp.w1 * lt.y + tp.w2 * rt.y + tp.w3 * lb.y + tp.w4 * rb.y;
+      s.z = tp.w1 * lt.z + tp.w2 * rt.z + tp.w3 * lb.z + tp.w4 * rb.z;
+      s.w = tp.w1 * lt.w + tp.w2 * rt.w + tp.w3 * lb.w + tp.w4 * rb.w;
+      if (tp.valid) { v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w; }
+      if (has_res) { v.x = L.ir.x + v.x; v.y = L.ir.y + v.y; v.z = L.ir.z + v.z; v.w = L.ir.w + v.w; }
+      if (i < cnt) o4[(img + (size_t)h * W + w0 + i) * C4 + c4] = v;
+    };
+    float bx0, by0, bx1, by1;
+    box_of(0, bx0, by0);
+    box_of(1, bx1, by1);
+    Tap tA = make_tap(H, W, W, bx0 * scale, by0 * scale), tB;  // sic: row <- x_ctr, column <- y_ctr
+    NhwcLoads LA, LB;
+    issue(0, tA, LA);
+#pragma unroll 1  // (a rolled loop: fully unrolled, the scheduler hoists every iteration's loads and needs 256 VGPRs)
+    for (int i = 0; i < KW; i += 2) {
+      // stage: box i + 2 | tap + loads of i + 1 | consume i        (buffers A / B alternate)
+      float bx2, by2;
+      box_of(i + 2, bx2, by2);
+      tB = make_tap(H, W, W, bx1 * scale, by1 * scale);
+      issue(i + 1, tB, LB);
+      consume(i, tA, LA);
+      box_of(i + 3, bx1, by1);
+      tA = make_tap(H, W, W, bx2 * scale, by2 * scale);
+      issue(i + 2, tA, LA);  // (beyond the last column: a clamped reload, never consumed)
+      consume(i + 1, tB, LB);
     }
   }
 }
@@ -1332,7 +1447,9 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
       (bias_a && !aligned16(bias_a)) || (bias_b && !aligned16(bias_b)))
     return -1;
   const bool fused = b || bias_a || bias_b || res;
-  const int tiles_x = (W + NH_TILE - 1) / NH_TILE, tiles_y = (H + NH_TILE - 1) / NH_TILE;
+  // points = 1: the pipelined kernel on 4 x 4 tiles; points = 5: the simple kernel
+  const int kw = 4;
+  const int tiles_x = (W + kw - 1) / kw, tiles_y = (H + NH_ROWS - 1) / NH_ROWS;
   const int tpi = tiles_x * tiles_y;
   const long long T = (long long)tpi * N;
   if (T > 0x7fffffffLL) return -1;
@@ -1340,12 +1457,15 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   if (ps) ps->mode = 3;
   hipEvent_t e0 = ps ? ps->ev[0] : nullptr, e1 = ps ? ps->ev[3] : nullptr;
   const dim3 grid((unsigned)T), block(256);
-#define R3_NHWC(PTS, FU) \
-  hipExtLaunchKernelGGL((fr_forward_nhwc<PTS, FU>), grid, block, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, boxes, C, \
-                        H, W, scale, tiles_x, tpi, (int)T, out)
-  if (points == 1) { if (fused) R3_NHWC(1, true); else R3_NHWC(1, false); }
-  else { if (fused) R3_NHWC(5, true); else R3_NHWC(5, false); }
-#undef R3_NHWC
+#define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x, tpi, (int)T, out
+  if (points == 1) {
+    if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<true, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+    else hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<false, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+  } else {
+    if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc<5, true, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+    else hipExtLaunchKernelGGL((fr_forward_nhwc<5, false, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+  }
+#undef R3_ARGS
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

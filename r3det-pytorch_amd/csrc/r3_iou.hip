@@ -710,12 +710,15 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   }
   const unsigned long long pairs = (unsigned long long)n1 * (unsigned long long)n2;
   const bool fits32 = pairs < 0xffffffffULL;
-  // small problems: ONE launch (no prep, no control words): narrow tiles so that the grid still fills CUs
-  const unsigned long long small_pairs = g_r3_iou_small > 0 ? (unsigned long long)g_r3_iou_small : 4000000ULL;
+  // Wide matrices (assignment shapes: few gt rows x tens of thousands of anchors, < 2 % overlapping pairs) take
+  // the prep + stream + drain pipeline.  Everything else is ONE launch (no prep, no queue): tiles narrow enough
+  // that the grid still fills the CUs; dense square problems (2000 x 2000: 129 us here, 329 us through the
+  // pipeline, whose drain then carries most pairs) and small ones (1000 x 128: 17 us) both prefer it.
+  const int wide = g_r3_iou_small > 0 ? g_r3_iou_small : 16384;
   const bool piped = ws && fits32 && ws_bytes >= r3k_iou_workspace_bytes(n1, n2) && g_r3_iou_impl != 2 &&
-                     (pairs > small_pairs || g_r3_iou_impl == 4);
+                     (n2 >= wide || g_r3_iou_impl == 4);
   if (!piped) {
-    if (g_r3_iou_impl == 2 || pairs > small_pairs) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);
+    if (g_r3_iou_impl == 2 || pairs > 2000000ULL) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);
     else if (n2 <= 512) launch_compact<GEOM, 1, 8>(vec, iof, b1, n1, b2, n2, out, stream);
     else launch_compact<GEOM, 4, 8>(vec, iof, b1, n1, b2, n2, out, stream);
     return 0;
