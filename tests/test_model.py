@@ -272,3 +272,32 @@ def test_dense_part_captures_into_a_hip_graph():
         assert torch.allclose(gs, scores, atol=1e-4) and torch.allclose(gb, boxes, rtol=1e-3, atol=1e-2)
     res = g.simple_test(img)
     assert len(res) == 2 and all(d.size(1) == 6 and d.size(0) > 0 for d, _ in res)
+
+
+@pytest.mark.gpu
+def test_rretinanet_full_size_config1():
+    """BASELINE configs[1]: rretinanet_obb_r50_fpn v1, batch 2 x 1024^2.  The head's nms_pre top-2000 per level
+    gives 8576-box pools (2000 + 2000 + 2000 + 2000 + 576); the batched multiclass NMS must return, image by
+    image, exactly what the per-image operator path returns (counts, order, labels), and simple_test the same."""
+    from r3det.core.post_processing import multiclass_nms_rotated, multiclass_nms_rotated_batch
+    from r3det.models import RRetinaNet
+    from r3det.models.detectors import calibrate_score_bias
+    torch.manual_seed(13)
+    dev = torch.device('cuda')
+    m = RRetinaNet().eval().to(dev)
+    img = torch.randn(2, 3, 1024, 1024, device=dev)
+    calibrate_score_bias(m, img, frac=0.01)
+    with torch.no_grad():
+        cls, reg = m.bbox_head(m.extract_feat(img))
+        assert [tuple(c.shape[-2:]) for c in cls] == [(128, 128), (64, 64), (32, 32), (16, 16), (8, 8)]
+        boxes, scores = m.bbox_head.decode_bboxes(cls, reg, img.shape[-2:], m.test_cfg)
+        assert boxes.shape == (2, 8576, 5) and scores.shape == (2, 8576, 16)
+        cfg = m.test_cfg
+        got = multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+        for i, (d, l) in enumerate(got):
+            wd, wl = multiclass_nms_rotated(boxes[i], scores[i], cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+            assert d.size(0) > 50 and torch.equal(d, wd) and torch.equal(l, wl), i
+        res = m.simple_test(img)
+    assert len(res) == 2 and all(r[0].size(1) == 6 and 0 < r[0].size(0) <= 2000 for r in res)
+    # (MIOpen may pick another kernel for the repeated forward: counts agree to the rounding of a few scores)
+    assert all(abs(r[0].size(0) - g[0].size(0)) <= max(5, g[0].size(0) // 50) for r, g in zip(res, got))
