@@ -236,6 +236,24 @@ int r3det_feature_refine_module_prepared(const float* mixed_a, const float* mixe
 int r3det_frm_mix_nchw(const float* a_nhwc, const float* b_nhwc, const float* bias_a, const float* bias_b, int N,
                        int C, int H, int W, float* out_nchw, void* stream);
 
+/* The pre-NMS pool of ONE pyramid level for a whole batch -- what RAnchorHead._get_bboxes_single does per image
+ * and level in front of multiclass_nms_rotated (models/dense_heads/rotate_anchor_head.py:626-673; with the previous
+ * stage's boxes as anchors: rotate_retina_refine_head.py:147-196):
+ *   scores = cls_score.permute(1, 2, 0).reshape(-1, C).sigmoid();  top nms_pre rows by scores.max(dim=1) when the
+ *   level has more (in score order, ties by ascending row);  bboxes = delta2bbox_v1(anchors, deltas, max_shape).
+ * cls_score (N, A*C, H, W) and bbox_pred (N, A*5, H, W) are read through their strides (4 element strides each:
+ * NCHW or channels_last, no copy); anchors (H*W*A, 5), or (N, H*W*A, 5) when anchors_per_image != 0 (the refine
+ * head: A = 1, the previous boxes).  Rows [row_offset, row_offset + min(nms_pre, H*W*A)) of pool_boxes (N, pool_rows,
+ * 5) and pool_scores (N, pool_rows, C + 1) are written (last score column = 0, the background column
+ * multiclass_nms_rotated drops): exactly the arrays r3det_mcnms_select reads.  max_x / max_y = W_img - 1 / H_img - 1
+ * (centre clamp), or negative for none.  nms_pre <= 4096.  ws: r3det_level_pool_workspace_bytes() bytes (0 when
+ * the level keeps all rows). */
+size_t r3det_level_pool_workspace_bytes(int N, int A, int H, int W, int nms_pre);
+int r3det_level_pool(const float* cls_score, const long long* cls_strides, const float* bbox_pred,
+                     const long long* reg_strides, const float* anchors, int anchors_per_image, int N, int A, int C,
+                     int H, int W, int nms_pre, float max_ratio, float max_x, float max_y, float* pool_boxes,
+                     float* pool_scores, int pool_rows, int row_offset, void* ws, size_t ws_bytes, void* stream);
+
 /* channels_last (NHWC) forms of the sampler: `features` / `output` are (N, H, W, C) contiguous -- the memory of a
  * torch channels_last (N, C, H, W) tensor -- so that a channels_last pipeline needs no layout switch around
  * the FR module.  Same results, element for element, as the NCHW entry points (feature_refine_cuda.forward,

@@ -190,6 +190,19 @@ int r3det_feature_refine_module_prepared(const float* mixed_a, const float* mixe
   return rc(r3k_fr_forward_prepared(mixed_a, mixed_b, residual, table, N, C, H, W, output, S(stream)));
 }
 
+size_t r3det_level_pool_workspace_bytes(int N, int A, int H, int W, int nms_pre) {
+  return r3k_level_pool_workspace_bytes(N, A, H, W, nms_pre);
+}
+
+int r3det_level_pool(const float* cls_score, const long long* cls_strides, const float* bbox_pred,
+                     const long long* reg_strides, const float* anchors, int anchors_per_image, int N, int A, int C,
+                     int H, int W, int nms_pre, float max_ratio, float max_x, float max_y, float* pool_boxes,
+                     float* pool_scores, int pool_rows, int row_offset, void* ws, size_t ws_bytes, void* stream) {
+  return rc(r3k_level_pool(cls_score, cls_strides, bbox_pred, reg_strides, anchors, anchors_per_image, N, A, C, H, W,
+                           nms_pre, max_ratio, max_x, max_y, pool_boxes, pool_scores, pool_rows, row_offset, ws, ws_bytes,
+                           S(stream)));
+}
+
 int r3det_feature_refine_forward_nhwc(const float* features, const float* best_bboxes, int N, int C, int H, int W,
                                       float spatial_scale, int points, float* output, void* stream) {
   return rc(r3k_fr_forward_nhwc(features, nullptr, nullptr, nullptr, nullptr, best_bboxes, N, C, H, W, spatial_scale,

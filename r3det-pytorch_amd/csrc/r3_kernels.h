@@ -72,6 +72,14 @@ int r3k_filter_bboxes(const float* cls, const long long* cls_strides, const floa
                       const long long* reg_strides, const float* anchors, int per_image, int N, int A, int C,
                       int H, int W, float max_ratio, float* out, hipStream_t stream);
 
+// pre-NMS pool of one level for a batch: sigmoid, per-image top-nms_pre by the best class score (score order),
+// decode with the centre clamp, written at row_offset of the (N, pool_rows, 5) / (N, pool_rows, C + 1) arrays
+size_t r3k_level_pool_workspace_bytes(int N, int A, int H, int W, int nms_pre);
+int r3k_level_pool(const float* cls, const long long* cls_strides, const float* reg, const long long* reg_strides,
+                   const float* anchors, int per_image, int N, int A, int C, int H, int W, int nms_pre, float max_ratio,
+                   float clamp_x, float clamp_y, float* boxes, float* scores, int pool_rows, int row_offset, void* ws,
+                   size_t ws_bytes, hipStream_t stream);
+
 // convolution epilogue of the inference model: y = act(y + bias[c] (+ residual)), in place
 // channels_last -> NCHW: out = (a + bias_a[c]) (+ (b + bias_b[c])); b and the biases may be null
 int r3k_mix_to_nchw(const float* a, const float* b, const float* bias_a, const float* bias_b, int N, int C, int H, int W,

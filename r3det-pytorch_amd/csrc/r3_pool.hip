@@ -1,0 +1,276 @@
+// r3_pool.hip -- the pre-NMS pool of one pyramid level for a whole batch (second half):
+// what RAnchorHead._get_bboxes_single does per image and level before multiclass_nms_rotated
+// (models/dense_heads/rotate_anchor_head.py:626-673; rois-as-anchors variant
+// rotate_retina_refine_head.py:147-196):
+//     scores = cls_score.permute(1, 2, 0).reshape(-1, C).sigmoid()
+//     if nms_pre < scores.shape[0]:  topk over scores.max(dim=1) -> gather anchors / deltas / scores
+//     bboxes = bbox_coder.decode(anchors, bbox_pred, max_shape=img_shape)
+// In torch that is a sigmoid + max + topk (a radix sort, ~75 us per level on MI355X) + three gathers + ~10
+// elementwise launches per level.  Here, per level:
+//   keys   : one thread per (position, anchor): key = sigmoid(max_c logit) (= max_c sigmoid, monotone), order
+//            preserving u32, read through the head output's strides (NCHW or channels_last, no copy);
+//   select : ONE workgroup per image: exact k-th largest key by an 8-pass 4-bit radix select whose per-thread
+//            digit counts live in two byte-packed 64-bit registers (no LDS / global atomics: a detector's scores
+//            cluster in a few exponent bins, histograms of them serialise), ordered collection of the k winners
+//            (ties at the threshold: lowest index first), bitonic sort in LDS by (score desc, index asc),
+//            then decode + sigmoid of the winners' C logits straight into the pool arrays
+//            boxes (N, n, 5) / scores (N, n, C + 1) that r3det_mcnms_select reads;
+//   levels with at most nms_pre rows keep their order: one thread per row, no selection.
+// Arithmetic as the torch ops it replaces: sigmoid = 1 / (1 + expf(-x)), delta2bbox_v1 with the centre clamp
+// to the image (delta_xywha_rbbox_coder.py:142-211), IEEE add / mul (-ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "r3_kernels.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+struct PStrides {
+  long long n, c, h, w;  // in elements
+};
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ unsigned pool_key(float f) {  // monotone: a < b  <=>  key(a) < key(b)
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// row i of a level <-> (position p = i / A, anchor a = i % A), as the reference's permute + reshape orders them
+__global__ __launch_bounds__(256) void pool_keys_kernel(const float* __restrict__ cls, PStrides sc, int A, int C,
+                                                        int H, int W, unsigned* __restrict__ keys) {
+  const int HW = H * W, L = HW * A;
+  const int n = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= L) return;
+  // NCHW heads: neighbouring threads take neighbouring positions of one anchor (coalesced planes);
+  // channels_last heads: neighbouring threads take neighbouring anchors of one position (contiguous logits)
+  int p, a;
+  if (sc.c == 1) { p = t / A; a = t - p * A; }
+  else { a = t / HW; p = t - a * HW; }
+  const int h = p / W, w = p - h * W;
+  const float* cb = cls + n * sc.n + h * sc.h + w * sc.w + (long long)(a * C) * sc.c;
+  float m = -INFINITY;
+  for (int c = 0; c < C; c++) m = fmaxf(m, cb[(long long)c * sc.c]);
+  keys[(size_t)n * L + (size_t)p * A + a] = pool_key(sigmoidf(m));
+}
+
+// one pool row: decode + the C class scores of level row i
+__device__ __forceinline__ void pool_emit(const float* __restrict__ cls, const PStrides& sc,
+                                          const float* __restrict__ reg, const PStrides& sr,
+                                          const float* __restrict__ anchors, int per_image, int n, int i, int A,
+                                          int C, int H, int W, float max_ratio, float clamp_x, float clamp_y,
+                                          float* __restrict__ box_out, float* __restrict__ score_out) {
+  const int p = i / A, a = i - p * A;
+  const int h = p / W, w = p - h * W;
+  const float* rb = reg + n * sr.n + h * sr.h + w * sr.w + (long long)(a * 5) * sr.c;
+  const float d0 = rb[0], d1 = rb[sr.c], d2 = rb[2 * sr.c], d3 = rb[3 * sr.c], d4 = rb[4 * sr.c];
+  const float* an = anchors + ((size_t)(per_image ? n : 0) * H * W * A + (size_t)i) * 5;
+  const float ax = an[0], ay = an[1], aw = an[2], ah = an[3], aa = an[4];
+  const float dw = fminf(fmaxf(d2, -max_ratio), max_ratio);
+  const float dh = fminf(fmaxf(d3, -max_ratio), max_ratio);
+  float gx = ax + aw * d0, gy = ay + ah * d1;
+  if (clamp_x >= 0.f) {  // max_shape given: centres clamped to [0, W_img - 1] x [0, H_img - 1]
+    gx = fminf(fmaxf(gx, 0.f), clamp_x);
+    gy = fminf(fmaxf(gy, 0.f), clamp_y);
+  }
+  box_out[0] = gx;
+  box_out[1] = gy;
+  box_out[2] = aw * expf(dw);
+  box_out[3] = ah * expf(dh);
+  box_out[4] = aa + d4;
+  const float* cb = cls + n * sc.n + h * sc.h + w * sc.w + (long long)(a * C) * sc.c;
+  for (int c = 0; c < C; c++) score_out[c] = sigmoidf(cb[(long long)c * sc.c]);
+  score_out[C] = 0.f;  // the background column multiclass_nms_rotated drops
+}
+
+__global__ __launch_bounds__(256) void pool_all_kernel(const float* __restrict__ cls, PStrides sc,
+                                                       const float* __restrict__ reg, PStrides sr,
+                                                       const float* __restrict__ anchors, int per_image, int A, int C,
+                                                       int H, int W, float max_ratio, float clamp_x, float clamp_y,
+                                                       float* __restrict__ boxes, float* __restrict__ scores,
+                                                       int pool_rows, int row_offset) {
+  const int L = H * W * A, n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L) return;
+  const size_t row = (size_t)n * pool_rows + row_offset + i;
+  pool_emit(cls, sc, reg, sr, anchors, per_image, n, i, A, C, H, W, max_ratio, clamp_x, clamp_y, boxes + row * 5,
+            scores + row * (C + 1));
+}
+
+constexpr int PS_T = 1024;      // threads of the select workgroup
+constexpr int PS_KMAX = 4096;   // largest nms_pre (LDS list of 8-byte entries: 32 KB)
+
+__global__ __launch_bounds__(PS_T) void pool_select_kernel(const float* __restrict__ cls, PStrides sc,
+                                                           const float* __restrict__ reg, PStrides sr,
+                                                           const float* __restrict__ anchors, int per_image, int A,
+                                                           int C, int H, int W, int k, float max_ratio, float clamp_x,
+                                                           float clamp_y, const unsigned* __restrict__ keys,
+                                                           float* __restrict__ boxes, float* __restrict__ scores,
+                                                           int pool_rows, int row_offset) {
+  __shared__ u64 list[PS_KMAX];          // (key << 32) | ~index  -- larger = earlier
+  __shared__ int wcnt[PS_T / 64][16];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_need;
+  __shared__ int s_gt;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x, L = H * W * A;
+  const unsigned* kn = keys + (size_t)n * L;
+
+  // ---- exact k-th largest key: 8 passes over 4-bit digits, most significant first
+  unsigned prefix = 0, mask = 0;
+  int need = k;
+  for (int shift = 28; shift >= 0; shift -= 4) {
+    u64 lo = 0, hi = 0;  // 16 byte-wide counters (a thread sees at most L / 1024 <= 255 keys per flush)
+    int seen = 0;
+    int tot[16];
+#pragma unroll
+    for (int d = 0; d < 16; d++) tot[d] = 0;
+    auto flush = [&]() {
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        tot[d] += (int)((lo >> (8 * d)) & 255ULL);
+        tot[8 + d] += (int)((hi >> (8 * d)) & 255ULL);
+      }
+      lo = hi = 0;
+      seen = 0;
+    };
+    for (int i = tid; i < L; i += PS_T) {
+      const unsigned key = kn[i];
+      if ((key & mask) == prefix) {
+        const unsigned d = (key >> shift) & 15u;
+        const u64 one = 1ULL << ((d & 7u) * 8u);
+        lo += (d < 8u) ? one : 0ULL;
+        hi += (d < 8u) ? 0ULL : one;
+        if (++seen == 255) flush();
+      }
+    }
+    flush();
+#pragma unroll
+    for (int d = 0; d < 16; d++) {
+      int v = tot[d];
+#pragma unroll
+      for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+      if (lane == 0) wcnt[wave][d] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0, dstar = 0;
+      for (int d = 15; d >= 0; d--) {
+        int c = 0;
+        for (int w = 0; w < PS_T / 64; w++) c += wcnt[w][d];
+        if (acc + c >= need) { dstar = d; break; }
+        acc += c;
+      }
+      s_prefix = prefix | ((unsigned)dstar << shift);
+      s_need = need - acc;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    need = s_need;
+    mask |= 15u << shift;
+    __syncthreads();
+  }
+  const unsigned T = prefix;  // the k-th largest key; `need` of the keys equal to it are taken (lowest indices)
+
+  // ---- collection: keys > T all (any order: sorted below), keys == T the first `need` by index.  Every thread
+  // owns a contiguous index range, so "first by index" is an exclusive scan of the per-thread counts.
+  const int n_gt = k - need;
+  if (tid == 0) s_gt = 0;
+  __syncthreads();
+  const int per = (L + PS_T - 1) / PS_T;
+  const int lo_i = min(tid * per, L), hi_i = min(lo_i + per, L);
+  int ceq = 0;
+  for (int i = lo_i; i < hi_i; i++) {
+    const unsigned key = kn[i];
+    if (key > T) {
+      const int slot = atomicAdd(&s_gt, 1);
+      list[slot] = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned)i);
+    } else if (key == T) {
+      ceq++;
+    }
+  }
+  int incl = ceq;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wcnt[wave][0] = incl;
+  __syncthreads();
+  int base_eq = incl - ceq;
+#pragma unroll
+  for (int w = 0; w < PS_T / 64; w++)
+    if (w < wave) base_eq += wcnt[w][0];
+  if (ceq && base_eq < need) {
+    for (int i = lo_i; i < hi_i && base_eq < need; i++) {
+      if (kn[i] == T) {
+        list[n_gt + base_eq] = ((u64)T << 32) | (u64)(0xffffffffu - (unsigned)i);
+        base_eq++;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- bitonic sort, descending on (key, ~index): score descending, ties by ascending index
+  int P = 1;
+  while (P < k) P <<= 1;
+  for (int j = k + tid; j < P; j += PS_T) list[j] = 0ULL;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += PS_T) {
+        const int lo_i = ((t / stride) * stride * 2) + (t % stride);
+        const int hi_i = lo_i + stride;
+        const bool desc = ((lo_i & size) == 0);
+        const u64 x = list[lo_i], y = list[hi_i];
+        if ((x < y) == desc) { list[lo_i] = y; list[hi_i] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- emit the k rows in that order
+  for (int j = tid; j < k; j += PS_T) {
+    const int i = (int)(0xffffffffu - (unsigned)(list[j] & 0xffffffffULL));
+    const size_t row = (size_t)n * pool_rows + row_offset + j;
+    pool_emit(cls, sc, reg, sr, anchors, per_image, n, i, A, C, H, W, max_ratio, clamp_x, clamp_y, boxes + row * 5,
+              scores + row * (C + 1));
+  }
+}
+
+}  // namespace
+
+size_t r3k_level_pool_workspace_bytes(int N, int A, int H, int W, int nms_pre) {
+  if (N <= 0 || A <= 0 || H <= 0 || W <= 0) return 0;
+  const long long L = (long long)H * W * A;
+  return (nms_pre > 0 && nms_pre < L) ? (size_t)N * L * sizeof(unsigned) + 256 : 0;
+}
+
+int r3k_level_pool(const float* cls, const long long* cls_strides, const float* reg, const long long* reg_strides,
+                   const float* anchors, int per_image, int N, int A, int C, int H, int W, int nms_pre, float max_ratio,
+                   float clamp_x, float clamp_y, float* boxes, float* scores, int pool_rows, int row_offset, void* ws,
+                   size_t ws_bytes, hipStream_t stream) {
+  if (N <= 0 || A <= 0 || C <= 0 || H <= 0 || W <= 0 || !cls || !cls_strides || !reg || !reg_strides || !anchors ||
+      !boxes || !scores || pool_rows <= 0 || row_offset < 0)
+    return -1;
+  const long long L = (long long)H * W * A;
+  if (L > 0x7fffffffLL / 8) return -1;
+  const PStrides sc{cls_strides[0], cls_strides[1], cls_strides[2], cls_strides[3]};
+  const PStrides sr{reg_strides[0], reg_strides[1], reg_strides[2], reg_strides[3]};
+  const bool select = nms_pre > 0 && nms_pre < L;
+  const int rows = select ? nms_pre : (int)L;
+  if (row_offset + rows > pool_rows) return -1;
+  if (!select) {
+    hipLaunchKernelGGL(pool_all_kernel, dim3((unsigned)((L + 255) / 256), N), dim3(256), 0, stream, cls, sc, reg, sr, anchors,
+                       per_image, A, C, H, W, max_ratio, clamp_x, clamp_y, boxes, scores, pool_rows, row_offset);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
+  if (nms_pre > PS_KMAX) return -1;
+  if (!ws || ws_bytes < r3k_level_pool_workspace_bytes(N, A, H, W, nms_pre)) return -3;
+  unsigned* keys = (unsigned*)ws;
+  hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)((L + 255) / 256), N), dim3(256), 0, stream, cls, sc, A, C, H, W, keys);
+  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, cls, sc, reg, sr, anchors, per_image, A, C, H, W,
+                     nms_pre, max_ratio, clamp_x, clamp_y, keys, boxes, scores, pool_rows, row_offset);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -243,7 +243,32 @@ class RRetinaHead(nn.Module):
     def decode_bboxes(self, cls_scores, bbox_preds, img_shape, cfg=None, rois=None):
         """The shape-static part of get_bboxes (everything before the NMS, whose sizes depend on the
         scores): (N, n, 5) boxes and (N, n, C + 1) scores.  No host synchronisation: capturable in a
-        HIP graph together with the network."""
+        HIP graph together with the network.  On the device one library call per level (r3det_level_pool:
+        sigmoid, per-image top-nms_pre in score order, decoding, straight into the pool arrays); the op-by-op
+        torch form is ``decode_bboxes_torch``."""
+        cfg = cfg or self.test_cfg
+        nms_pre = cfg.get('nms_pre', -1)
+        if not cls_scores[0].is_cuda or cls_scores[0].dtype != torch.float32 or nms_pre > 4096:
+            return self.decode_bboxes_torch(cls_scores, bbox_preds, img_shape, cfg, rois)
+        N = cls_scores[0].size(0)
+        A, C = self.num_anchors, self.cls_out_channels
+        dev = cls_scores[0].device
+        if rois is None:
+            lvl_anchors = self.anchors([c.shape[-2:] for c in cls_scores], dev)
+        else:
+            lvl_anchors = [torch.stack([rois[i][l] for i in range(N)]) for l in range(len(cls_scores))]
+        rows = [c.shape[-2] * c.shape[-1] * A for c in cls_scores]
+        rows = [min(nms_pre, r) if nms_pre > 0 else r for r in rows]
+        n = sum(rows)
+        boxes = torch.empty((N, n, 5), dtype=torch.float32, device=dev)
+        scores = torch.empty((N, n, C + 1), dtype=torch.float32, device=dev)
+        off = 0
+        for cls, reg, anc, r in zip(cls_scores, bbox_preds, lvl_anchors, rows):
+            fr_boxes.level_pool(cls, reg, anc, A, C, nms_pre, img_shape, boxes, scores, off)
+            off += r
+        return boxes, scores
+
+    def decode_bboxes_torch(self, cls_scores, bbox_preds, img_shape, cfg=None, rois=None):
         cfg = cfg or self.test_cfg
         N = cls_scores[0].size(0)
         A, C = self.num_anchors, self.cls_out_channels

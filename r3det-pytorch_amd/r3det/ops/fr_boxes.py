@@ -51,3 +51,35 @@ def refine_bboxes(bbox_pred, rois):
         _C.check(_C.lib().r3det_filter_bboxes(None, None, _C.ptr(bbox_pred), _strides(bbox_pred), _C.ptr(rois), 1, N,
                                               1, 1, H, W, MAX_RATIO, _C.ptr(out), _C.stream()), "r3det_filter_bboxes")
     return out
+
+
+def level_pool(cls_score, bbox_pred, anchors, num_anchors, num_classes, nms_pre, max_shape, pool_boxes, pool_scores,
+               row_offset):
+    """One pyramid level of the pre-NMS pool for a whole batch (r3det_level_pool): sigmoid, per-image top
+    ``nms_pre`` rows by the best class score (score order), delta2bbox_v1 with the centre clamp to ``max_shape``
+    -- written into rows [row_offset, row_offset + min(nms_pre, H*W*A)) of ``pool_boxes`` (N, n, 5) and
+    ``pool_scores`` (N, n, C + 1).  ``anchors``: (H*W*A, 5), or (N, H*W*A, 5) per image (refine head).
+    Returns the number of rows written per image."""
+    cls_score, bbox_pred = _check(cls_score, "cls_score"), _check(bbox_pred, "bbox_pred")
+    N, _, H, W = cls_score.shape
+    A, C = num_anchors, num_classes
+    assert cls_score.size(1) == A * C and bbox_pred.size(1) == A * 5
+    per_image = anchors.dim() == 3
+    anchors = _C.need_hip(anchors.contiguous(), "anchors")
+    L = H * W * A
+    assert anchors.shape == ((N, L, 5) if per_image else (L, 5))
+    _C.need_hip(pool_boxes, "pool_boxes")
+    _C.need_hip(pool_scores, "pool_scores")
+    n = pool_boxes.size(1)
+    assert pool_boxes.shape == (N, n, 5) and pool_scores.shape == (N, n, C + 1)
+    lib = _C.lib()
+    k = int(nms_pre) if nms_pre is not None else -1
+    with torch.cuda.device(cls_score.device):
+        wsb = int(lib.r3det_level_pool_workspace_bytes(N, A, H, W, k))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=cls_score.device)
+        mx, my = (float(max_shape[1] - 1), float(max_shape[0] - 1)) if max_shape is not None else (-1.0, -1.0)
+        _C.check(lib.r3det_level_pool(_C.ptr(cls_score), _strides(cls_score), _C.ptr(bbox_pred), _strides(bbox_pred),
+                                      _C.ptr(anchors), int(per_image), N, A, C, H, W, k, MAX_RATIO, mx, my,
+                                      _C.ptr(pool_boxes), _C.ptr(pool_scores), n, int(row_offset), _C.ptr(ws), wsb,
+                                      _C.stream()), "r3det_level_pool")
+    return k if 0 < k < L else L

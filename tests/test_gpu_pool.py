@@ -1,0 +1,98 @@
+"""GPU: the fused per-level pre-NMS pool (r3det_level_pool: sigmoid + top-nms_pre + decode) against the op-by-op
+torch form of RAnchorHead._get_bboxes_single (rotate_anchor_head.py:626-673), for NCHW and channels_last head
+outputs, shared anchors (base head) and per-image rois (refine head), levels with and without a top-k."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_head(refine, strides):
+    from r3det.models.heads import RRetinaHead, RRetinaRefineHead
+    torch.manual_seed(1)
+    h = (RRetinaRefineHead if refine else RRetinaHead)(num_classes=15, in_channels=8, feat_channels=8, strides=strides)
+    return h.cuda().eval()
+
+
+def spread_logits(N, A, C, H, W, seed):
+    """cls maps whose best-class logit per (position, anchor) is a distinct, well separated value (a shuffled
+    linspace): the top-k set and its order are then the same for any correctly rounded sigmoid."""
+    g = torch.Generator().manual_seed(seed)
+    L = H * W * A
+    cls = torch.empty(N, L, C)
+    for n in range(N):
+        best = torch.linspace(-6, 4, L)[torch.randperm(L, generator=g)]
+        rest = best[:, None] - 0.5 - 3 * torch.rand(L, C, generator=g)
+        which = torch.randint(0, C, (L,), generator=g)
+        rest[torch.arange(L), which] = best
+        cls[n] = rest
+    # (N, L = (p, a), C) -> (N, A*C, H, W)
+    return cls.view(N, H, W, A * C).permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("refine", [False, True])
+def test_pool_matches_torch_path(refine, channels_last):
+    strides = (8, 16, 32)
+    head = make_head(refine, strides)
+    A, C, N = head.num_anchors, 15, 3
+    sizes = [(64, 48), (20, 20), (5, 7)]
+    cfg = dict(nms_pre=700, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=2000)
+    g = torch.Generator().manual_seed(3)
+    cls = [spread_logits(N, A, C, h, w, 10 + i).cuda() for i, (h, w) in enumerate(sizes)]
+    reg = [(torch.randn(N, A * 5, h, w, generator=g) * torch.tensor([0.3, 0.3, 2.5, 2.5, 0.4]).repeat(A)[None, :, None, None]).cuda()
+           for h, w in sizes]
+    rois = None
+    if refine:
+        rois = [[(torch.rand(h * w, 5, generator=g) * torch.tensor([400., 300., 60., 40., 1.]) + torch.tensor([0., 0., 4., 4., -1.5])).cuda()
+                 for h, w in sizes] for _ in range(N)]
+    if channels_last:
+        cls = [c.contiguous(memory_format=torch.channels_last) for c in cls]
+        reg = [r.contiguous(memory_format=torch.channels_last) for r in reg]
+    img_shape = (300, 420)
+    with torch.no_grad():
+        gb, gs = head.decode_bboxes(cls, reg, img_shape, cfg, rois=rois)
+        wb, ws = head.decode_bboxes_torch(cls, reg, img_shape, cfg, rois=rois)
+    assert gb.shape == wb.shape and gs.shape == ws.shape
+    assert gs.shape[1] == 700 + (700 if 400 * A > 700 else 400 * A) + 35 * A
+    assert torch.allclose(gs, ws, rtol=0, atol=1e-6), float((gs - ws).abs().max())
+    assert torch.allclose(gb, wb, rtol=1e-6, atol=1e-4), float((gb - wb).abs().max())
+    # inside a level with a top-k the rows come in descending order of the best class score
+    top = gs[:, :700, :-1].max(2)[0]
+    assert bool((top[:, 1:] <= top[:, :-1]).all())
+    assert float(gs[..., -1].abs().max()) == 0
+
+
+def test_pool_ties_take_lowest_rows_and_large_level():
+    """Every score equal: the k winners are the k lowest rows (this build's rule; torch.topk leaves ties open).
+    And a level of 147 456 rows (RRetinaNet level 0) against torch on well separated scores."""
+    from r3det.ops import fr_boxes
+    N, A, C, H, W, k = 2, 9, 15, 16, 16, 500
+    cls = torch.zeros(N, A * C, H, W, device='cuda')
+    reg = torch.zeros(N, A * 5, H, W, device='cuda')
+    anchors = torch.rand(H * W * A, 5, device='cuda') * 50 + 5
+    boxes = torch.full((N, k, 5), float('nan'), device='cuda')
+    scores = torch.full((N, k, C + 1), float('nan'), device='cuda')
+    assert fr_boxes.level_pool(cls, reg, anchors, A, C, k, None, boxes, scores, 0) == k
+    assert torch.equal(boxes[0], anchors[:k]) and torch.equal(boxes[1], anchors[:k])
+    assert torch.equal(scores[..., :-1], torch.full((N, k, C), 0.5, device='cuda'))
+    head = make_head(False, (8,))
+    A = head.num_anchors
+    cls = [spread_logits(1, A, C, 128, 128, 5).cuda()]
+    reg = [torch.randn(1, A * 5, 128, 128, device='cuda') * 0.2]
+    cfg = dict(nms_pre=2000)
+    with torch.no_grad():
+        gb, gs = head.decode_bboxes(cls, reg, (1024, 1024), cfg)
+        wb, ws = head.decode_bboxes_torch(cls, reg, (1024, 1024), cfg)
+    assert gb.shape == (1, 2000, 5)
+    assert torch.allclose(gs, ws, rtol=0, atol=1e-6) and torch.allclose(gb, wb, rtol=1e-6, atol=1e-4)
+
+
+def test_pool_argument_errors():
+    from r3det import _C
+    L = _C.lib()
+    assert L.r3det_level_pool(None, None, None, None, None, 0, 1, 1, 1, 1, 1, 1, 1.0, -1.0, -1.0, None, None, 1, 0, None, 0,
+                              None) == -1
+    assert L.r3det_level_pool_workspace_bytes(2, 9, 128, 128, 2000) == 2 * 147456 * 4 + 256
+    assert L.r3det_level_pool_workspace_bytes(2, 1, 8, 8, 2000) == 0
