@@ -66,24 +66,31 @@ inline Batch single_problem(int n) {
 // maskT[r][i / 64]), which the reducer scans only for rows with ecnt > EL.
 constexpr int EL = 32;
 
+//   msup[r]  : 65535 - (smallest suppressor index of r), 0 = none.  The highest-scored suppressor of a box is
+//              very often the kept head of its cluster: the reducer looks at it first and thereby decides most
+//              removed boxes without their lists (the lists hold the first EL ARRIVALS, in no order: in a
+//              cluster of a few hundred near-duplicates the head is rarely among them).
 struct Side {
   int* ecnt;
+  int* msup;
   unsigned short* elist;
 };
 
 __host__ __device__ inline size_t side_words(size_t rows) {  // u64 words of the lists
-  return (rows * EL + 3) / 4 + (rows + 1) / 2;
+  return (rows * EL + 3) / 4 + 2 * ((rows + 1) / 2);
 }
 
 __host__ __device__ inline Side side_tables(u64* side, size_t rows) {
   Side s;
   s.elist = reinterpret_cast<unsigned short*>(side);  // first: rows * 64 B keeps every row 64-byte aligned
   s.ecnt = reinterpret_cast<int*>(side + (rows * EL + 3) / 4);
+  s.msup = reinterpret_cast<int*>(side + (rows * EL + 3) / 4 + (rows + 1) / 2);
   return s;
 }
 
 // pair (i, j), i < j in score order, suppresses: i joins the suppressors of j
 __device__ __forceinline__ void mark_pair(u64* maskT, const Side& sd, unsigned i, unsigned j, int cb) {
+  atomicMax(&sd.msup[j], 65535 - (int)i);
   const int s = atomicAdd(&sd.ecnt[j], 1);
   if (s < EL) sd.elist[(size_t)j * EL + s] = (unsigned short)i;
   else atomicOr(&maskT[(size_t)j * cb + (i >> 6)], 1ULL << (i & 63u));
@@ -473,6 +480,10 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* 
       const bool act = r < n && !(u < R_CACHE && !((big >> u) & 1u)) && !((Kb[w] | Rb[w]) >> (r & 63) & 1ULL);
       bool anyK = false, allR = true;
       if (act) {
+        const unsigned m = 65535u - (unsigned)sd.msup[r];  // its highest-scored suppressor first
+        anyK = m < 65535u && ((K32[m >> 5] >> (m & 31)) & 1u);
+      }
+      if (act && !anyK) {
         const int c = sd.ecnt[r];
         const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
         const uint4 t[4] = {lp[0], lp[1], lp[2], lp[3]};
@@ -488,12 +499,21 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* 
             }
           }
         }
-        if (c > EL && !anyK) {  // suppressors beyond the list: scan the overflow row (dense clusters only)
+        if (c > EL && !anyK) {
+          // suppressors beyond the list: scan the overflow row, 8 independent word loads per step (a kept box of a
+          // dense cluster rescans its row every round until all of its suppressors are decided: one dependent
+          // load per word made this the reducer's largest cost on the model's pools)
           const u64* row = maskT + (size_t)r * cb;
-          for (int q = 0; q <= w && !anyK; q++) {
-            const u64 mm = row[q];
-            anyK = (mm & Kb[q]) != 0ULL;
-            allR &= (mm & ~Rb[q]) == 0ULL;
+          for (int q0 = 0; q0 <= w && !anyK; q0 += 8) {
+            u64 mm[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) mm[e] = row[min(q0 + e, w)];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const int q = min(q0 + e, w);
+              anyK |= (mm[e] & Kb[q]) != 0ULL;
+              allR &= (mm[e] & ~Rb[q]) == 0ULL;
+            }
           }
         }
       }

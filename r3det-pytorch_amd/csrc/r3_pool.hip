@@ -40,11 +40,14 @@ __device__ __forceinline__ unsigned pool_key(float f) {  // monotone: a < b  <=>
 
 // row i of a level <-> (position p = i / A, anchor a = i % A), as the reference's permute + reshape orders them
 __global__ __launch_bounds__(256) void pool_keys_kernel(const float* __restrict__ cls, PStrides sc, int A, int C,
-                                                        int H, int W, unsigned* __restrict__ keys) {
+                                                        int H, int W, int Lpad, unsigned* __restrict__ keys) {
   const int HW = H * W, L = HW * A;
   const int n = blockIdx.y;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= L) return;
+  if (t >= L) {
+    if (t < Lpad) keys[(size_t)n * Lpad + t] = 0u;  // padding: below every real key (a sigmoid is positive)
+    return;
+  }
   // NCHW heads: neighbouring threads take neighbouring positions of one anchor (coalesced planes);
   // channels_last heads: neighbouring threads take neighbouring anchors of one position (contiguous logits)
   int p, a;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void pool_keys_kernel(const float* __restrict_
   const float* cb = cls + n * sc.n + h * sc.h + w * sc.w + (long long)(a * C) * sc.c;
   float m = -INFINITY;
   for (int c = 0; c < C; c++) m = fmaxf(m, cb[(long long)c * sc.c]);
-  keys[(size_t)n * L + (size_t)p * A + a] = pool_key(sigmoidf(m));
+  keys[(size_t)n * Lpad + (size_t)p * A + a] = pool_key(sigmoidf(m));
 }
 
 // one pool row: decode + the C class scores of level row i
@@ -102,52 +105,61 @@ __global__ __launch_bounds__(256) void pool_all_kernel(const float* __restrict__
 
 constexpr int PS_T = 1024;      // threads of the select workgroup
 constexpr int PS_KMAX = 4096;   // largest nms_pre (LDS list of 8-byte entries: 32 KB)
+constexpr int PS_U = 4;         // 16-byte key loads in flight per thread and step
 
-__global__ __launch_bounds__(PS_T) void pool_select_kernel(const float* __restrict__ cls, PStrides sc,
-                                                           const float* __restrict__ reg, PStrides sr,
-                                                           const float* __restrict__ anchors, int per_image, int A,
-                                                           int C, int H, int W, int k, float max_ratio, float clamp_x,
-                                                           float clamp_y, const unsigned* __restrict__ keys,
-                                                           float* __restrict__ boxes, float* __restrict__ scores,
-                                                           int pool_rows, int row_offset) {
+// The select workgroup is alone on its CU (grid = images): what it can afford is bandwidth, not latency.  Keys are
+// read as uint4, PS_U independent loads per thread and step (a first version read one key per iteration, each
+// waiting for the previous: 127 us at 16 384 keys, 500 us at 147 456).
+__global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, const unsigned* __restrict__ keys,
+                                                           int* __restrict__ sel) {
   __shared__ u64 list[PS_KMAX];          // (key << 32) | ~index  -- larger = earlier
   __shared__ int wcnt[PS_T / 64][16];
   __shared__ unsigned s_prefix;
-  __shared__ int s_need;
-  __shared__ int s_gt;
+  __shared__ int s_need, s_eq_total;
+  __shared__ int s_gt, s_eq;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.x, L = H * W * A;
-  const unsigned* kn = keys + (size_t)n * L;
+  const int n = blockIdx.x;
+  const uint4* kn4 = reinterpret_cast<const uint4*>(keys + (size_t)n * Lpad);
+  const int L4 = Lpad >> 2;
+  const int steps = (L4 + PS_T * PS_U - 1) / (PS_T * PS_U);
 
   // ---- exact k-th largest key: 8 passes over 4-bit digits, most significant first
   unsigned prefix = 0, mask = 0;
   int need = k;
   for (int shift = 28; shift >= 0; shift -= 4) {
-    u64 lo = 0, hi = 0;  // 16 byte-wide counters (a thread sees at most L / 1024 <= 255 keys per flush)
-    int seen = 0;
     int tot[16];
 #pragma unroll
     for (int d = 0; d < 16; d++) tot[d] = 0;
-    auto flush = [&]() {
+    u64 lo = 0, hi = 0;  // 16 byte-wide digit counters, flushed every 15 steps (15 x 16 keys < 256)
+    for (int st = 0; st < steps; st++) {
+      uint4 v[PS_U];
 #pragma unroll
-      for (int d = 0; d < 8; d++) {
-        tot[d] += (int)((lo >> (8 * d)) & 255ULL);
-        tot[8 + d] += (int)((hi >> (8 * d)) & 255ULL);
+      for (int u = 0; u < PS_U; u++) {
+        const int q = (st * PS_U + u) * PS_T + tid;
+        v[u] = q < L4 ? kn4[q] : make_uint4(0u, 0u, 0u, 0u);
       }
-      lo = hi = 0;
-      seen = 0;
-    };
-    for (int i = tid; i < L; i += PS_T) {
-      const unsigned key = kn[i];
-      if ((key & mask) == prefix) {
-        const unsigned d = (key >> shift) & 15u;
-        const u64 one = 1ULL << ((d & 7u) * 8u);
-        lo += (d < 8u) ? one : 0ULL;
-        hi += (d < 8u) ? 0ULL : one;
-        if (++seen == 255) flush();
+#pragma unroll
+      for (int u = 0; u < PS_U; u++) {
+        const unsigned kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const unsigned key = kk[e];
+          const bool in = key != 0u && (key & mask) == prefix;
+          const unsigned d = (key >> shift) & 15u;
+          const u64 one = in ? (1ULL << ((d & 7u) * 8u)) : 0ULL;
+          lo += (d < 8u) ? one : 0ULL;
+          hi += (d < 8u) ? 0ULL : one;
+        }
+      }
+      if ((st % 15) == 14 || st == steps - 1) {
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          tot[d] += (int)((lo >> (8 * d)) & 255ULL);
+          tot[8 + d] += (int)((hi >> (8 * d)) & 255ULL);
+        }
+        lo = hi = 0;
       }
     }
-    flush();
 #pragma unroll
     for (int d = 0; d < 16; d++) {
       int v = tot[d];
@@ -156,16 +168,22 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(const float* __restri
       if (lane == 0) wcnt[wave][d] = v;
     }
     __syncthreads();
-    if (tid == 0) {
-      int acc = 0, dstar = 0;
-      for (int d = 15; d >= 0; d--) {
-        int c = 0;
-        for (int w = 0; w < PS_T / 64; w++) c += wcnt[w][d];
-        if (acc + c >= need) { dstar = d; break; }
-        acc += c;
+    if (tid < 16) {  // digit totals in parallel (a serial walk over 16 x 16 LDS words cost 7 us per pass)
+      int c = 0;
+#pragma unroll
+      for (int w = 0; w < PS_T / 64; w++) c += wcnt[w][tid];
+      // suffix sums over the digits above this one: the digit whose range contains the `need`-th largest wins
+      int above = 0;
+#pragma unroll
+      for (int d = 1; d < 16; d++) {
+        const int o = __shfl_down(c, d, 16);
+        if (tid + d < 16) above += o;
       }
-      s_prefix = prefix | ((unsigned)dstar << shift);
-      s_need = need - acc;
+      if (above < need && above + c >= need) {
+        s_prefix = prefix | ((unsigned)tid << shift);
+        s_need = need - above;
+        s_eq_total = c;  // (after the last pass: how many keys equal the threshold)
+      }
     }
     __syncthreads();
     prefix = s_prefix;
@@ -174,37 +192,53 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(const float* __restri
     __syncthreads();
   }
   const unsigned T = prefix;  // the k-th largest key; `need` of the keys equal to it are taken (lowest indices)
-
-  // ---- collection: keys > T all (any order: sorted below), keys == T the first `need` by index.  Every thread
-  // owns a contiguous index range, so "first by index" is an exclusive scan of the per-thread counts.
   const int n_gt = k - need;
-  if (tid == 0) s_gt = 0;
+  const bool all_eq = s_eq_total == need;  // every key equal to T is a winner: no index order needed among them
+
+  // ---- collection: keys > T all (any order: sorted below); keys == T all of them, or the first `need` by index
+  if (tid == 0) { s_gt = 0; s_eq = 0; }
   __syncthreads();
-  const int per = (L + PS_T - 1) / PS_T;
-  const int lo_i = min(tid * per, L), hi_i = min(lo_i + per, L);
-  int ceq = 0;
-  for (int i = lo_i; i < hi_i; i++) {
-    const unsigned key = kn[i];
-    if (key > T) {
-      const int slot = atomicAdd(&s_gt, 1);
-      list[slot] = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned)i);
-    } else if (key == T) {
-      ceq++;
+  for (int st = 0; st < steps; st++) {
+    uint4 v[PS_U];
+#pragma unroll
+    for (int u = 0; u < PS_U; u++) {
+      const int q = (st * PS_U + u) * PS_T + tid;
+      v[u] = q < L4 ? kn4[q] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < PS_U; u++) {
+      const unsigned kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      const int q = (st * PS_U + u) * PS_T + tid;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const unsigned key = kk[e];
+        const unsigned i = (unsigned)(q * 4 + e);
+        if (key > T) list[atomicAdd(&s_gt, 1)] = ((u64)key << 32) | (u64)(0xffffffffu - i);
+        else if (all_eq && key == T) list[n_gt + atomicAdd(&s_eq, 1)] = ((u64)key << 32) | (u64)(0xffffffffu - i);
+      }
     }
   }
-  int incl = ceq;
+  if (!all_eq) {
+    // ties straddle the threshold: the first `need` keys equal to T in index order.  Every thread counts the
+    // equal keys of a contiguous index range, an exclusive scan turns the counts into ranks.
+    const unsigned* kn = keys + (size_t)n * Lpad;
+    const int per = (Lpad + PS_T - 1) / PS_T;
+    const int lo_i = min(tid * per, Lpad), hi_i = min(lo_i + per, Lpad);
+    int ceq = 0;
+    for (int i = lo_i; i < hi_i; i++) ceq += kn[i] == T;
+    int incl = ceq;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d);
-    if (lane >= d) incl += t;
-  }
-  if (lane == 63) wcnt[wave][0] = incl;
-  __syncthreads();
-  int base_eq = incl - ceq;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wcnt[wave][0] = incl;
+    __syncthreads();
+    int base_eq = incl - ceq;
 #pragma unroll
-  for (int w = 0; w < PS_T / 64; w++)
-    if (w < wave) base_eq += wcnt[w][0];
-  if (ceq && base_eq < need) {
+    for (int w = 0; w < PS_T / 64; w++)
+      if (w < wave) base_eq += wcnt[w][0];
     for (int i = lo_i; i < hi_i && base_eq < need; i++) {
       if (kn[i] == T) {
         list[n_gt + base_eq] = ((u64)T << 32) | (u64)(0xffffffffu - (unsigned)i);
@@ -230,21 +264,31 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(const float* __restri
       __syncthreads();
     }
   }
-  // ---- emit the k rows in that order
-  for (int j = tid; j < k; j += PS_T) {
-    const int i = (int)(0xffffffffu - (unsigned)(list[j] & 0xffffffffULL));
-    const size_t row = (size_t)n * pool_rows + row_offset + j;
-    pool_emit(cls, sc, reg, sr, anchors, per_image, n, i, A, C, H, W, max_ratio, clamp_x, clamp_y, boxes + row * 5,
-              scores + row * (C + 1));
-  }
+  // ---- the winners' level rows, in pool order; a second launch spread over the chip decodes them (done here by
+  // the one workgroup per image it took 27 us of a 110 us kernel)
+  for (int j = tid; j < k; j += PS_T) sel[(size_t)n * k + j] = (int)(0xffffffffu - (unsigned)(list[j] & 0xffffffffULL));
+}
+
+__global__ __launch_bounds__(256) void pool_emit_kernel(const float* __restrict__ cls, PStrides sc,
+                                                        const float* __restrict__ reg, PStrides sr,
+                                                        const float* __restrict__ anchors, int per_image, int A, int C,
+                                                        int H, int W, int k, float max_ratio, float clamp_x,
+                                                        float clamp_y, const int* __restrict__ sel,
+                                                        float* __restrict__ boxes, float* __restrict__ scores,
+                                                        int pool_rows, int row_offset) {
+  const int n = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= k) return;
+  const size_t row = (size_t)n * pool_rows + row_offset + j;
+  pool_emit(cls, sc, reg, sr, anchors, per_image, n, sel[(size_t)n * k + j], A, C, H, W, max_ratio, clamp_x, clamp_y,
+            boxes + row * 5, scores + row * (C + 1));
 }
 
 }  // namespace
 
 size_t r3k_level_pool_workspace_bytes(int N, int A, int H, int W, int nms_pre) {
   if (N <= 0 || A <= 0 || H <= 0 || W <= 0) return 0;
-  const long long L = (long long)H * W * A;
-  return (nms_pre > 0 && nms_pre < L) ? (size_t)N * L * sizeof(unsigned) + 256 : 0;
+  const long long L = (long long)H * W * A, Lpad = (L + 3) / 4 * 4;
+  return (nms_pre > 0 && nms_pre < L) ? (size_t)N * Lpad * sizeof(unsigned) + (size_t)N * nms_pre * sizeof(int) + 512 : 0;
 }
 
 int r3k_level_pool(const float* cls, const long long* cls_strides, const float* reg, const long long* reg_strides,
@@ -268,9 +312,14 @@ int r3k_level_pool(const float* cls, const long long* cls_strides, const float* 
   }
   if (nms_pre > PS_KMAX) return -1;
   if (!ws || ws_bytes < r3k_level_pool_workspace_bytes(N, A, H, W, nms_pre)) return -3;
+  if (reinterpret_cast<uintptr_t>(ws) & 15) return -1;
   unsigned* keys = (unsigned*)ws;
-  hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)((L + 255) / 256), N), dim3(256), 0, stream, cls, sc, A, C, H, W, keys);
-  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, cls, sc, reg, sr, anchors, per_image, A, C, H, W,
-                     nms_pre, max_ratio, clamp_x, clamp_y, keys, boxes, scores, pool_rows, row_offset);
+  const int Lpad = (int)((L + 3) / 4 * 4);
+  hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)((Lpad + 255) / 256), N), dim3(256), 0, stream, cls, sc, A, C, H, W,
+                     Lpad, keys);
+  int* sel = (int*)((char*)ws + (((size_t)N * Lpad * sizeof(unsigned) + 255) & ~(size_t)255));
+  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, nms_pre, Lpad, keys, sel);
+  hipLaunchKernelGGL(pool_emit_kernel, dim3((nms_pre + 255) / 256, N), dim3(256), 0, stream, cls, sc, reg, sr, anchors,
+                     per_image, A, C, H, W, nms_pre, max_ratio, clamp_x, clamp_y, sel, boxes, scores, pool_rows, row_offset);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
