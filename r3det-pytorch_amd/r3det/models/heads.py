@@ -137,7 +137,8 @@ class RRetinaHead(nn.Module):
         gt_assign = gt_bboxes
         if self.assign_by_circumhbbox is not None and gt_bboxes.size(0) > 0:
             gt_assign = obb2hbb(gt_bboxes, self.assign_by_circumhbbox)
-        res = self.assigner.assign(anchors, gt_assign, None, gt_labels)
+        # (labels are derived below with masks: passing gt_labels would make the assigner run nonzero(), a host sync)
+        res = self.assigner.assign(anchors, gt_assign, None, None)
         gt_inds = res.gt_inds
         pos = gt_inds > 0
         n = anchors.size(0)

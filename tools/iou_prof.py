@@ -1,4 +1,5 @@
-"""rbbox_iou on the assignment shape (128 x 196416) and friends, for rocprofv3 --kernel-trace."""
+"""rbbox_iou (v1) on the bench shapes, for rocprofv3 --kernel-trace: IOU_PROF_SHAPE = 128x196416 (assignment of
+the base head), 128x21824 (refine stage), 1000x128 (BASELINE configs[0]) or all (default)."""
 import os
 import sys
 
@@ -8,32 +9,28 @@ for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
 
 import torch  # noqa: E402
 
-from r3det import _C, synthetic as syn  # noqa: E402
+from r3det import synthetic as syn  # noqa: E402
 from r3det.ops import rbbox_iou  # noqa: E402
 
 dev = torch.device("cuda")
+which = os.environ.get("IOU_PROF_SHAPE", "all")
 anchors = syn.anchor_grid(device=dev)
-for k in ((128,) if os.environ.get('IOU_PROF_128') else (128, 512)):
-    gt = syn.dota_like_rboxes(k, 5, device=dev)
+gt = syn.dota_like_rboxes(128, 5, device=dev)
+refined = torch.cat([syn.fr_level_boxes(1, 1024 // s, 1024 // s, s, 50 + i, device=dev) for i, s in enumerate(syn.STRIDES)])
+a, g = syn.rand_rboxes(1000, 0, device=dev), syn.rand_rboxes(128, 1, device=dev)
+for name, b1, b2 in (("128x196416", gt, anchors), ("128x21824", gt, refined), ("1000x128", a, g)):
+    if which not in ("all", name):
+        continue
     for _ in range(3):
-        rbbox_iou(gt, anchors)
+        rbbox_iou(b1, b2)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(20):
-        out = rbbox_iou(gt, anchors)
+        out = rbbox_iou(b1, b2)
     e.record()
     torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / 20
-    print(f"rbbox_iou {k}x{anchors.size(0)}: {us:8.1f} us  {out.numel() * 4 / us / 1e3:8.1f} GB/s  nnz {int((out > 0).sum())}", flush=True)
-z = torch.empty(128 * anchors.size(0), device=dev)
-for _ in range(3):
-    z.zero_()
-torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-for _ in range(20):
-    z.zero_()
-e.record()
-torch.cuda.synchronize()
-print(f"memset of the 128-row matrix: {s.elapsed_time(e) * 1e3 / 20:8.1f} us", flush=True)
+    alg = 4 * out.numel() + 20 * (b1.size(0) + b2.size(0))
+    print(f"rbbox_iou {name}: {us:8.1f} us per call  {alg / us / 1e3:8.1f} GB/s on {alg} algorithmic bytes  "
+          f"nnz {int((out > 0).sum())}", flush=True)

@@ -1,0 +1,58 @@
+#!/bin/bash
+# Round profiles (run on the GPU box from the repo root through gpurun): rocprofv3 --kernel-trace --stats summaries
+# of the bench step, the training step, configs[1], the IoU and NMS ops, and the PMC passes (separate runs,
+# --kernel-trace only) of the roofline kernel and of the IoU / NMS kernels.  Output: gpurun_out/profiles_<tag>/,
+# copied into profiles/ by hand (tracked).
+#   bash tools/make_profiles.sh r02
+set -u
+TAG=${1:-r02}
+R=$(pwd)
+O=$R/gpurun_out/profiles_$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+cd /tmp
+kt() {  # kt <outfile> <header> <program args...>: kernel trace + stats of one command
+  local out=$1 hdr=$2; shift 2
+  rm -rf /tmp/kt_run
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_run -o t -- "$@" > /tmp/kt_run.log 2>&1
+  { echo "# rocprofv3 --kernel-trace --stats -- $hdr"; grep -v "^W2\|^E2\|^I2" /tmp/kt_run.log | tail -6 | sed 's/^/# /'; } > $out
+}
+# 1. bench step (R3Det inference, configs[2])
+kt $O/${TAG}_bench_kernel_stats.txt "python3 bench.py --steps 10 --warmup 4 --model-only" python3 $R/bench.py --steps 10 --warmup 4 --model-only
+grep '^{' /tmp/kt_run.log | tail -1 > $O/${TAG}_bench_under_rocprof.json
+MS=$(python3 -c "import json;print(json.load(open('$O/${TAG}_bench_under_rocprof.json'))['ms_per_step'])")
+python3 $R/tools/step_kernels.py /tmp/kt_run $MS 60 >> $O/${TAG}_bench_kernel_stats.txt
+# 2. training step (configs[4])
+kt $O/${TAG}_train_kernel_stats.txt "python3 tools/train_prof.py (last step)" python3 $R/tools/train_prof.py
+MS=$(grep "train step" /tmp/kt_run.log | tail -1 | sed 's/.*: \([0-9.]*\) ms/\1/')
+python3 $R/tools/step_kernels.py /tmp/kt_run $MS 45 >> $O/${TAG}_train_kernel_stats.txt
+# 3. RRetinaNet step (configs[1])
+kt $O/${TAG}_rretinanet_kernel_stats.txt "python3 tools/rretina_prof.py (last step)" python3 $R/tools/rretina_prof.py
+python3 $R/tools/step_kernels.py /tmp/kt_run 10.7 40 >> $O/${TAG}_rretinanet_kernel_stats.txt
+# 4. IoU op, per shape
+: > $O/${TAG}_iou_kernel_stats.txt
+for shp in 128x196416 128x21824 1000x128; do
+  export IOU_PROF_SHAPE=$shp
+  kt /tmp/kt_one.txt "python3 tools/iou_prof.py  (IOU_PROF_SHAPE=$shp)" python3 $R/tools/iou_prof.py
+  cat /tmp/kt_one.txt >> $O/${TAG}_iou_kernel_stats.txt
+  python3 $R/tools/kstats.py /tmp/kt_run iou_ fill >> $O/${TAG}_iou_kernel_stats.txt
+done
+unset IOU_PROF_SHAPE
+# 5. NMS op, per size, and the batched pipeline
+: > $O/${TAG}_nms_kernel_stats.txt
+for n in 2000 5344 8576; do
+  export NMS_PROF_N=$n
+  kt /tmp/kt_one.txt "python3 tools/nms_prof.py  (NMS_PROF_N=$n)" python3 $R/tools/nms_prof.py
+  cat /tmp/kt_one.txt >> $O/${TAG}_nms_kernel_stats.txt
+  python3 $R/tools/kstats.py /tmp/kt_run nms_ mc_ fill >> $O/${TAG}_nms_kernel_stats.txt
+done
+unset NMS_PROF_N
+# 6. the roofline kernel alone (rotating buffers) + its PMC traffic passes
+kt $O/${TAG}_fr_nhwc_kernel_stats.txt "python3 tools/fr_nhwc_prof.py" python3 $R/tools/fr_nhwc_prof.py
+python3 $R/tools/kstats.py /tmp/kt_run fr_forward >> $O/${TAG}_fr_nhwc_kernel_stats.txt
+cd $R
+bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_fr_nhwc_pmc.txt fr_forward_nhwc "FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" tools/fr_nhwc_prof.py > /dev/null
+# 7. PMC of the IoU and NMS kernels
+IOU_PROF_SHAPE=128x196416 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_iou_pmc.txt iou_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/iou_prof.py > /dev/null
+NMS_PROF_N=8576 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_nms_pmc.txt nms_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/nms_prof.py > /dev/null
+ls -la $O
