@@ -510,20 +510,33 @@ struct NhwcLoads {
   float4 ta[4], tb[4];   // the four taps of conv_a / conv_b
 };
 
-template <bool FUSED, int KW>
-__global__ __launch_bounds__(256) void fr_forward_nhwc_pipe(const float* __restrict__ a, const float* __restrict__ b,
-                                                            const float* __restrict__ bias_a,
-                                                            const float* __restrict__ bias_b,
-                                                            const float* __restrict__ res,
-                                                            const float* __restrict__ boxes, int C, int H, int W,
-                                                            float scale, int tiles_x, int tiles_per_img, int T,
-                                                            float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// PAIRED (square maps): a workgroup of 8 waves owns the 4 x 4 output tile (i, j) AND its transpose (j, i), four
+// waves each, AT THE SAME TIME.  With the reference's x / y swap and a regular box field the taps of output tile
+// (i, j) lie in input tile (j, i), whose lines output tile (j, i) reads as its identity -- and vice versa: the two
+// uses of every conv_a / conv_b line then meet in the CU's L1 / the XCD's L2 instead of crossing the fabric twice.
+template <bool FUSED, int KW, bool PAIRED>
+__global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_pipe(
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
+    const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
+    float scale, int tiles_x, int tiles_per_img, int T, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, half = threadIdx.x >> 8;
   unsigned t = blockIdx.x;
   if ((T & 7) == 0) t = (t & 7u) * (unsigned)(T >> 3) + (t >> 3);  // XCD-contiguous bands of tiles
   const int n = (int)(t / (unsigned)tiles_per_img);
   const int tt = (int)(t - (unsigned)n * (unsigned)tiles_per_img);
-  const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+  int ty, tx;
+  if (PAIRED) {  // tt indexes the unordered pairs i <= j of the tiles_x x tiles_x grid
+    int pj = (int)((sqrtf(8.f * (float)tt + 1.f) - 1.f) * 0.5f);
+    while (pj * (pj + 1) / 2 > tt) pj--;
+    while ((pj + 1) * (pj + 2) / 2 <= tt) pj++;
+    const int pi = tt - pj * (pj + 1) / 2;
+    if (half == 1 && pi == pj) return;  // a diagonal tile is its own transpose
+    ty = half ? pj : pi;
+    tx = half ? pi : pj;
+  } else {
+    ty = tt / tiles_x;
+    tx = tt - ty * tiles_x;
+  }
   const int h = ty * NH_ROWS + wave;
   if (h >= H) return;
   const int HW = H * W, C4 = C >> 2;
@@ -1447,20 +1460,27 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
       (bias_a && !aligned16(bias_a)) || (bias_b && !aligned16(bias_b)))
     return -1;
   const bool fused = b || bias_a || bias_b || res;
-  // points = 1: the pipelined kernel on 4 x 4 tiles; points = 5: the simple kernel
+  // points = 1: the pipelined kernel on 4 x 4 tiles (square maps: transposed tile pairs per workgroup; fr_dbg 1
+  // switches the pairing off for A/B runs); points = 5: the simple kernel
   const int kw = 4;
   const int tiles_x = (W + kw - 1) / kw, tiles_y = (H + NH_ROWS - 1) / NH_ROWS;
-  const int tpi = tiles_x * tiles_y;
+  const bool paired = points == 1 && tiles_x == tiles_y && g_r3_fr_dbg != 1;
+  const int tpi = paired ? tiles_x * (tiles_x + 1) / 2 : tiles_x * tiles_y;
   const long long T = (long long)tpi * N;
   if (T > 0x7fffffffLL) return -1;
   FrProfileSlot* ps = (g_r3_fr_profile && points == 1) ? fr_profile_next(N, H) : nullptr;
   if (ps) ps->mode = 3;
   hipEvent_t e0 = ps ? ps->ev[0] : nullptr, e1 = ps ? ps->ev[3] : nullptr;
-  const dim3 grid((unsigned)T), block(256);
+  const dim3 grid((unsigned)T), block(paired ? 512 : 256);
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x, tpi, (int)T, out
   if (points == 1) {
-    if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<true, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
-    else hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<false, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+    if (paired) {
+      if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<true, 4, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+      else hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<false, 4, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+    } else {
+      if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<true, 4, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+      else hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<false, 4, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+    }
   } else {
     if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc<5, true, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
     else hipExtLaunchKernelGGL((fr_forward_nhwc<5, false, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
