@@ -71,23 +71,22 @@ constexpr int T_CPT = 4;                       // columns per thread (wide form)
 constexpr int T_COLS = T_THREADS * T_CPT;      // 1024
 constexpr int T_SUB = 8;                       // rows per phase-A/phase-B round
 
-template <int GEOM, bool VEC, int CPT, int ROWS>
-__global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float* __restrict__ b1, int n1,
-                                                                    const float* __restrict__ b2, int n2,
-                                                                    int iof, float* __restrict__ out) {
+// LDS of one tile routine call: rows[ROWS][R3_REC] floats, queue[SUB * 256 * CPT] u16 (a round can never overflow),
+// qcount[2], pts[pts_slots * 256]
+template <int GEOM, bool VEC, int CPT, int ROWS, int SUB>
+__device__ __forceinline__ void compact_tile(const int bx, const int by, const float* __restrict__ b1, int n1,
+                                             const float* __restrict__ b2, int n2, int iof,
+                                             float* __restrict__ out, float (*rows)[R3_REC], unsigned short* queue,
+                                             int* qcount, float2* pts) {
   constexpr int COLS = T_THREADS * CPT;
   constexpr int CSH = CPT == 4 ? 10 : (CPT == 2 ? 9 : 8);  // log2(COLS)
-  constexpr int QCAP = T_SUB * COLS;                        // a round can never overflow
-  __shared__ __attribute__((aligned(16))) float rows[ROWS][R3_REC];
-  __shared__ unsigned short queue[QCAP];
-  __shared__ int qcount[2];
-  __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
+  constexpr int T_SUB = SUB;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int colbase = blockIdx.x * COLS;
+  const int colbase = bx * COLS;
   const int col0 = colbase + tid * CPT;
-  const int row0 = blockIdx.y * ROWS;
+  const int row0 = by * ROWS;
   const int nrows = min(ROWS, n1 - row0);
 
   if (tid < nrows) {
@@ -182,6 +181,17 @@ __global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float*
     }
     __syncthreads();
   }
+}
+
+template <int GEOM, bool VEC, int CPT, int ROWS>
+__global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float* __restrict__ b1, int n1,
+                                                                    const float* __restrict__ b2, int n2,
+                                                                    int iof, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float rows[ROWS][R3_REC];
+  __shared__ unsigned short queue[T_SUB * T_THREADS * CPT];
+  __shared__ int qcount[2];
+  __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
+  compact_tile<GEOM, VEC, CPT, ROWS, T_SUB>(blockIdx.x, blockIdx.y, b1, n1, b2, n2, iof, out, rows, queue, qcount, pts);
 }
 
 // ------------------------------------------------------------------ global-queue pipeline
@@ -295,109 +305,121 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream_kernel(const float* __re
   }
 }
 
-// ------------------------------------------------------------------ prep + stream + drain pipeline
-// The matrix path for large problems (the 128 x 196 416 assignment shape).
-//   prep   : one small launch builds the row records and, ONCE per column, the 20 bytes the conservative test
-//            reads (the round-1 stream kernel rebuilt them -- a double-precision sincos each -- in every one of
-//            the n1/16 row tiles), laid out so that the stream kernel's per-lane loads are 64 + 16 contiguous
-//            bytes, and zeroes the queue counter (no memset node);
-//   stream : tile = SROWS rows x 1024 columns: conservative test -> zeros streamed out with 16-byte stores,
-//            survivors -> LDS queue -> one of 64 bounded regions of the global queue (one atomicAdd per
-//            workgroup on that region's counter); entries that no longer fit are clipped by the workgroup
-//            itself, so the workspace is 0.5 B per pair, not 4 B;
-//   drain  : grid-stride over the concatenation of the regions, one pair per lane, balanced over the chip.
+// ------------------------------------------------------------------ stream + drain pipeline
+// The matrix path for wide problems (the 128 x 196 416 assignment shape).  TWO launches and nothing in front of
+// them: on this part a launch that does nothing still occupies ~4.5 us of the stream (measured: an empty
+// 512-workgroup kernel), so the prep kernel (records + counter zeroing, 5 us), and the overflow kernel (4.4 us,
+// normally empty) of the earlier forms were a sixth of the op.
+//   stream : tile = 16 rows x 1024 columns.  The conservative-test data (centre, circumscribed radius, AABB half
+//            extents) is derived in the kernel from the raw boxes with hardware sine / cosine -- the test only
+//            has to be conservative, so the extents are inflated by the approximation's error bound instead of
+//            evaluating the exact double-precision sincos; zeros are streamed out with 16-byte stores;
+//            survivors -> per-wave LDS segments (no atomics) -> the tile's OWN slot of the workspace (u16
+//            tile-local entries, 1 B per pair of workspace) + the tile's count.  No global atomics, so nothing
+//            has to be zeroed first.  A tile with a wave more than half full is marked dense (count -1).
+//   drain  : every workgroup rebuilds the prefix over the tile counts (grouped, <= 1024 groups in LDS), then
+//            grid-strides over the concatenated entries, one pair per lane, balanced over the chip; dense
+//            tiles are redone whole by the one-launch form's tile routine at the end.
 // Measured and NOT shipped: a single persistent kernel in which workgroups alternate between
 // streaming tiles and clipping chunks published by other workgroups (tickets in global memory).  On gfx950 an
 // agent-scope release / acquire is an L2 write-back / invalidate of the whole XCD (the eight L2s are not
 // coherent with each other), so every published tile flushed the freshly written zeros: 725 us instead of 75.
-constexpr int F_NREG = 64;             // the global queue is split into 64 regions, each with its own counter:
-constexpr int F_CSTRIDE = 32;          // 1536 workgroups adding to ONE address serialise (device-scope atomics are
-constexpr int F_CTL = F_NREG * F_CSTRIDE;  // performed memory-side); counters sit 128 B apart
+constexpr int P_ROWS = 16;
+constexpr int P_WSEG = P_ROWS * 128;   // entries of a wave's LDS segment: half of its 16 x 256 pairs
+constexpr int P_SLOT = 4 * P_WSEG;     // u16 entries of a tile's slot in the workspace (16 KB)
+constexpr int P_GROUPS = 1024;         // tile groups whose prefix a drain workgroup keeps in LDS
+constexpr int P_MAX_TILES = 16384;     // beyond: the one-launch form (a group would span > 16 tiles)
 
-template <int GEOM>
-__global__ __launch_bounds__(256) void iou_prep_kernel(const float* __restrict__ b1, int n1,
-                                                       const float* __restrict__ b2, int n2,
-                                                       BoxRec* __restrict__ recsA, float4* __restrict__ rejB,
-                                                       float* __restrict__ radB, unsigned* __restrict__ ctl) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < F_CTL) ctl[i] = 0;
-  if (i < n1) {
-    BoxRec rec;
-    make_record<GEOM>(b1 + (size_t)i * 5, 0.f, rec);
-    recsA[i] = rec;
-  }
-  if (i < n2) {
-    // columns: only the 20 bytes the stream kernel tests with (coalesced 16-byte + 4-byte stores).  Their full
-    // 64-byte records would be 12.5 MB of lane-strided stores at 196 416 anchors (13.5 us measured for this
-    // launch); the drain kernel rebuilds the record of a surviving pair's column instead (~1.7 % of the pairs).
-    const float* b = b2 + (size_t)i * 5;
-    const float x = b[0], y = b[1], w = b[2], h = b[3];
-    float sn, cs;
-    r3_sincos(b[4], sn, cs);
-    const float ac = fabsf(cs), as = fabsf(sn), aw = 0.5f * fabsf(w), ah = 0.5f * fabsf(h);
-    const float slack = 2e-6f * (fabsf(x) + fabsf(y)) + 1e-6f;
-    rejB[i] = make_float4(x, y, (ac * aw + as * ah) * 1.001f + slack, (as * aw + ac * ah) * 1.001f + slack);
-    radB[i] = r3_radius(x, y, w, h);
+// centre / radius / AABB half extents for the conservative test, from hardware sine / cosine (|error| < 1e-3 on
+// |angle| < 64; larger finite angles use the circle's AABB; non-finite angles give NaN = "never apart")
+__device__ __forceinline__ void reject_data(const float x, const float y, const float w, const float h, const float a,
+                                            float& rad, float& ex, float& ey) {
+  rad = r3_radius(x, y, w, h);
+  const float aw = 0.5f * fabsf(w), ah = 0.5f * fabsf(h);
+  const float slack = 2e-6f * (fabsf(x) + fabsf(y)) + 1e-6f;
+  if (fabsf(a) < 64.f) {
+    const float ac = fabsf(__cosf(a)) + 1e-3f, as = fabsf(__sinf(a)) + 1e-3f;
+    ex = (ac * aw + as * ah) * 1.001f + slack;
+    ey = (as * aw + ac * ah) * 1.001f + slack;
+  } else {
+    ex = ey = (fabsf(a) < 3.0e38f) ? rad : __builtin_nanf("");
   }
 }
 
-template <int GEOM, bool VEC, int SROWS>
-__global__ __launch_bounds__(T_THREADS) void iou_stream2_kernel(const BoxRec* __restrict__ recsA, int n1,
-                                                                const float* __restrict__ b2,
-                                                                const float4* __restrict__ rejB,
-                                                                const float* __restrict__ radB, int n2, int iof,
-                                                                float* __restrict__ out, unsigned* __restrict__ counter,
-                                                                unsigned* __restrict__ gqueue, unsigned qcap) {
-  __shared__ __attribute__((aligned(16))) float rows[SROWS][8];  // cx, cy, rad, ex, ey
-  __shared__ unsigned short queue[SROWS * T_COLS];
-  __shared__ int qcount;
-  __shared__ unsigned qbase;
+template <int GEOM, bool VEC>
+__global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __restrict__ b1, int n1,
+                                                                const float* __restrict__ b2, int n2,
+                                                                float* __restrict__ out, BoxRec* __restrict__ recsA,
+                                                                int* __restrict__ tcount,
+                                                                unsigned short* __restrict__ slots, int wcap) {
+  __shared__ __attribute__((aligned(16))) float rows[P_ROWS][8];  // cx, cy, rad, ex, ey
+  __shared__ unsigned short queue[4 * P_WSEG];
+  __shared__ int wcount[4];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int colbase = blockIdx.x * T_COLS;
+  const int wave = tid >> 6;
+  // column tiles are walked from the END of the box list: anchor lists run from the fine to the coarse level
+  // and the coarse anchors (the last few tiles) carry most survivors -- started last they would be the tail
+  const int bx = (int)(gridDim.x - 1 - blockIdx.x);
+  const int colbase = bx * T_COLS;
   const int col0 = colbase + tid * T_CPT;
-  const int row0 = blockIdx.y * SROWS;
-  const int nrows = min(SROWS, n1 - row0);
+  const int row0 = blockIdx.y * P_ROWS;
+  const int nrows = min(P_ROWS, n1 - row0);
   if (tid < nrows) {
-    const float* a = recsA[row0 + tid].f;
-#pragma unroll
-    for (int k = 0; k < 5; k++) rows[tid][k] = a[9 + k];
+    const float* b = b1 + (size_t)(row0 + tid) * 5;
+    const float x = b[0], y = b[1];
+    float rad, ex, ey;
+    reject_data(x, y, b[2], b[3], b[4], rad, ex, ey);
+    rows[tid][0] = x; rows[tid][1] = y; rows[tid][2] = rad; rows[tid][3] = ex; rows[tid][4] = ey;
   }
-  if (tid == 0) qcount = 0;
-  float4 cq[T_CPT];
-  float cr[T_CPT];
+  // the exact row records for the drain kernel: written once, by the middle column tile's workgroups
+  if (blockIdx.x == gridDim.x / 2 && tid >= 64 && tid < 64 + nrows) {
+    BoxRec rec;
+    make_record<GEOM>(b1 + (size_t)(row0 + tid - 64) * 5, 0.f, rec);
+    recsA[row0 + tid - 64] = rec;
+  }
+  float cx[T_CPT], cy[T_CPT], cr[T_CPT], cex[T_CPT], cey[T_CPT];
   bool cvalid[T_CPT];
-  if (col0 + T_CPT <= n2) {
-    const float4 r4 = *reinterpret_cast<const float4*>(radB + col0);
-    cr[0] = r4.x; cr[1] = r4.y; cr[2] = r4.z; cr[3] = r4.w;
+  {
+    float raw[T_CPT * 5];
+    if (col0 + T_CPT <= n2 && (reinterpret_cast<uintptr_t>(b2) & 15) == 0) {
+      const float4* src = reinterpret_cast<const float4*>(b2 + (size_t)col0 * 5);  // 80 contiguous bytes per lane
 #pragma unroll
-    for (int c = 0; c < T_CPT; c++) {
-      cq[c] = rejB[col0 + c];
-      cvalid[c] = true;
+      for (int k = 0; k < 5; k++) {
+        const float4 v = src[k];
+        raw[4 * k] = v.x; raw[4 * k + 1] = v.y; raw[4 * k + 2] = v.z; raw[4 * k + 3] = v.w;
+      }
+#pragma unroll
+      for (int c = 0; c < T_CPT; c++) cvalid[c] = true;
+    } else {
+#pragma unroll
+      for (int c = 0; c < T_CPT; c++) {
+        cvalid[c] = (col0 + c) < n2;
+#pragma unroll
+        for (int k = 0; k < 5; k++) raw[c * 5 + k] = cvalid[c] ? b2[(size_t)(col0 + c) * 5 + k] : 0.f;
+      }
     }
-  } else {
 #pragma unroll
     for (int c = 0; c < T_CPT; c++) {
-      cvalid[c] = (col0 + c) < n2;
-      cq[c] = cvalid[c] ? rejB[col0 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      cr[c] = cvalid[c] ? radB[col0 + c] : 0.f;
+      cx[c] = raw[c * 5];
+      cy[c] = raw[c * 5 + 1];
+      reject_data(cx[c], cy[c], raw[c * 5 + 2], raw[c * 5 + 3], raw[c * 5 + 4], cr[c], cex[c], cey[c]);
     }
   }
   const bool all_valid = cvalid[T_CPT - 1];
   // Bounding box of this WAVE's 256 columns (inflated extents included).  Anchors and refined boxes come in
   // spatial order, so for most (row, wave) combinations the row's box lies outside it: one wave-uniform test
-  // then replaces the 4 per-column tests (~14 VALU operations each: the stream kernel was co-limited by them,
-  // 34 us against 15 us for a plain fill of the same 100 MB) and the row segment is stored as zeros.
-  // Waves with an invalid or non-finite column never take the shortcut.
-  float bx0 = cq[0].x - cq[0].z, bx1 = cq[0].x + cq[0].z, by0 = cq[0].y - cq[0].w, by1 = cq[0].y + cq[0].w;
+  // then replaces the 4 per-column tests and the row segment is stored as zeros.  Waves with an invalid or
+  // non-finite column never take the shortcut.
+  float bx0 = cx[0] - cex[0], bx1 = cx[0] + cex[0], by0 = cy[0] - cey[0], by1 = cy[0] + cey[0];
   bool fin = all_valid;
 #pragma unroll
   for (int c = 0; c < T_CPT; c++) {
-    bx0 = fminf(bx0, cq[c].x - cq[c].z);
-    bx1 = fmaxf(bx1, cq[c].x + cq[c].z);
-    by0 = fminf(by0, cq[c].y - cq[c].w);
-    by1 = fmaxf(by1, cq[c].y + cq[c].w);
-    fin = fin && (fabsf(cq[c].x) < 3.0e38f) && (fabsf(cq[c].y) < 3.0e38f) && (cq[c].z < 3.0e38f) && (cq[c].w < 3.0e38f);
+    bx0 = fminf(bx0, cx[c] - cex[c]);
+    bx1 = fmaxf(bx1, cx[c] + cex[c]);
+    by0 = fminf(by0, cy[c] - cey[c]);
+    by1 = fmaxf(by1, cy[c] + cey[c]);
+    fin = fin && (fabsf(cx[c]) < 3.0e38f) && (fabsf(cy[c]) < 3.0e38f) && (cex[c] < 3.0e38f) && (cey[c] < 3.0e38f);
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -407,6 +429,11 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream2_kernel(const BoxRec* __
     by1 = fmaxf(by1, __shfl_xor(by1, d));
   }
   const bool wave_ok = VEC && (__ballot(fin) == ~0ULL);
+  // survivors: one PRIVATE LDS segment per wave, its fill count in a wave-uniform register -- no LDS atomics,
+  // nothing to wait for (a shared queue with one atomicAdd per ballot cost 12 of the kernel's 32 us)
+  unsigned short* wq = queue + wave * P_WSEG;
+  int cnt = 0;
+  bool full = false;
   __syncthreads();
   for (int r = 0; r < nrows; r++) {
     const float* A = rows[r];
@@ -419,9 +446,9 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream2_kernel(const BoxRec* __
     bool any = false;
 #pragma unroll
     for (int c = 0; c < T_CPT; c++) {
-      float dx = ax - cq[c].x, dy = ay - cq[c].y;
+      float dx = ax - cx[c], dy = ay - cy[c];
       float rr = ar + cr[c];
-      bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + cq[c].z) | (fabsf(dy) > aey + cq[c].w);
+      bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + cex[c]) | (fabsf(dy) > aey + cey[c]);
       pend[c] = cvalid[c] && !apart;
       any |= pend[c];
     }
@@ -434,84 +461,107 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream2_kernel(const BoxRec* __
         if (cvalid[c] && !pend[c]) o[c] = 0.f;
     }
     if (__ballot(any)) {
+      if (cnt + 256 > wcap) {
+        full = true;
+      } else {
 #pragma unroll
-      for (int c = 0; c < T_CPT; c++) {
-        unsigned long long m = __ballot(pend[c]);
-        if (m) {
-          int base = 0;
-          if (lane == 0) base = atomicAdd(&qcount, __popcll(m));
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (pend[c]) {
-            int slot = base + __popcll(m & ((1ULL << lane) - 1ULL));
-            queue[slot] = (unsigned short)((r << 10) | (tid * T_CPT + c));
-          }
+        for (int c = 0; c < T_CPT; c++) {
+          const unsigned long long m = __ballot(pend[c]);
+          if (pend[c]) wq[cnt + __popcll(m & ((1ULL << lane) - 1ULL))] = (unsigned short)((r << 10) | (tid * T_CPT + c));
+          cnt += __popcll(m);
         }
       }
     }
   }
+  if (lane == 0) wcount[wave] = full ? -1 : cnt;
   __syncthreads();
-  const int total = qcount;
-  if (total == 0) return;
-  const unsigned reg = (blockIdx.x + blockIdx.y * 7u) % (unsigned)F_NREG;  // heavy column tiles spread over regions
-  if (tid == 0) qbase = atomicAdd(counter + reg * F_CSTRIDE, (unsigned)total);
-  __syncthreads();
-  const unsigned base = qbase;
-  // entries [0, fit) go to this region of the global queue; the rest (only when the bounded region is full:
-  // dense inputs) are clipped here, one pair per lane without LDS staging
-  const int fit = base >= qcap ? 0 : (int)min((unsigned)total, qcap - base);
-  unsigned* region = gqueue + (size_t)reg * qcap;
-  for (int q = tid; q < fit; q += T_THREADS) {
-    const unsigned e = queue[q];
-    region[base + q] = (unsigned)(row0 + (int)(e >> 10)) * (unsigned)n2 + (unsigned)(colbase + (int)(e & 1023u));
-  }
-  for (int q = fit + tid; q < total; q += T_THREADS) {
-    const unsigned e = queue[q];
-    const unsigned r = (unsigned)row0 + (e >> 10), c = (unsigned)colbase + (e & 1023u);
-    BoxRec A = recsA[r];
-    BoxRec B;
-    make_record<GEOM>(b2 + (size_t)c * 5, 0.f, B);
-    float v;
-    if (GEOM == 1) v = v1_pair_slow(A, B, iof != 0);
-    else if (GEOM == 2) v = hull_pair_slow<true>(A, B, iof == 0);
-    else v = hull_pair_slow<false>(A, B, iof == 0);
-    out[(size_t)r * n2 + c] = v;
-  }
+  const int c0 = wcount[0], c1 = wcount[1], c2 = wcount[2], c3 = wcount[3];
+  const bool dense = (c0 | c1 | c2 | c3) < 0;
+  const int tile = (int)(blockIdx.y * gridDim.x) + bx;
+  if (tid == 0) tcount[tile] = dense ? -1 : c0 + c1 + c2 + c3;
+  if (dense) return;
+  unsigned short* slot = slots + (size_t)tile * P_SLOT + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+  for (int q = lane; q < cnt; q += 64) slot[q] = wq[q];
 }
 
-template <int GEOM>
-__global__ __launch_bounds__(T_THREADS) void iou_drain_kernel(const BoxRec* __restrict__ recsA,
-                                                              const float* __restrict__ b2, int n2,
-                                                              int iof, const unsigned* __restrict__ gqueue,
-                                                              const unsigned* __restrict__ counter, unsigned qcap,
-                                                              float* __restrict__ out) {
+template <int GEOM, bool VEC>
+__global__ __launch_bounds__(T_THREADS) void iou_drain2_kernel(const float* __restrict__ b1, int n1,
+                                                               const float* __restrict__ b2, int n2, int iof,
+                                                               const BoxRec* __restrict__ recsA,
+                                                               const int* __restrict__ tcount,
+                                                               const unsigned short* __restrict__ slots, int tiles_x,
+                                                               int tiles, float* __restrict__ out) {
+  constexpr int D_SUB = 2;  // rows per round of the dense-tile routine
+  constexpr int AUX_WORDS = (P_ROWS * R3_REC * 4 + D_SUB * T_COLS * 2 + 16) / 4;  // >= P_GROUPS + 1
+  static_assert(AUX_WORDS >= P_GROUPS + 1, "aux holds the group prefix first, the dense-tile LDS afterwards");
   __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
-  __shared__ unsigned pre[F_NREG + 1];  // exclusive prefix of the regions' (clamped) counts
-  const LanePts<T_THREADS> lp{pts + threadIdx.x};
-  if (threadIdx.x < 64) {
-    unsigned v = min(counter[threadIdx.x * F_CSTRIDE], qcap);
-    unsigned incl = v;
+  __shared__ __attribute__((aligned(16))) unsigned aux[AUX_WORDS];
+  __shared__ unsigned wsum[4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const LanePts<T_THREADS> lp{pts + tid};
+  // prefix over the tile counts in groups of G consecutive tiles; thread t owns groups 4t .. 4t+3
+  const int G = (tiles + P_GROUPS - 1) / P_GROUPS;
+  unsigned gs[4];
+  unsigned mine = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned t = __shfl_up(incl, d);
-      if ((int)threadIdx.x >= d) incl += t;
-    }
-    pre[threadIdx.x + 1] = incl;
-    if (threadIdx.x == 0) pre[0] = 0;
+  for (int k = 0; k < 4; k++) {
+    unsigned sum = 0;
+    const int t0 = (tid * 4 + k) * G;
+    for (int t = t0; t < t0 + G && t < tiles; t++) sum += (unsigned)max(tcount[t], 0);
+    gs[k] = sum;
+    mine += sum;
   }
-  __syncthreads();
-  const unsigned total = pre[F_NREG];
-  for (unsigned q = blockIdx.x * T_THREADS + threadIdx.x; q < total; q += gridDim.x * T_THREADS) {
-    int lo = 0;  // region of entry q: largest lo with pre[lo] <= q
+  unsigned incl = mine;
 #pragma unroll
-    for (int step = 32; step >= 1; step >>= 1)
-      if (pre[lo + step] <= q) lo += step;
-    const unsigned e = gqueue[(size_t)lo * qcap + (q - pre[lo])];
-    const unsigned r = e / (unsigned)n2;
-    const unsigned c = e - r * (unsigned)n2;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  unsigned base = incl - mine;
+  for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    aux[tid * 4 + k] = base;
+    base += gs[k];
+  }
+  if (tid == T_THREADS - 1) aux[P_GROUPS] = base;
+  __syncthreads();
+  const unsigned total = aux[P_GROUPS];
+  for (unsigned q = blockIdx.x * T_THREADS + tid; q < total; q += gridDim.x * T_THREADS) {
+    int g = 0;  // group of entry q: largest g with aux[g] <= q
+#pragma unroll
+    for (int step = P_GROUPS / 2; step >= 1; step >>= 1)
+      if (aux[g + step] <= q) g += step;
+    unsigned off = q - aux[g];
+    int t = g * G;
+    for (;;) {  // tile inside the group (G is 1 or 2 for the assignment shapes)
+      const unsigned c = (unsigned)max(tcount[t], 0);
+      if (off < c) break;
+      off -= c;
+      t++;
+    }
+    const unsigned e = slots[(size_t)t * P_SLOT + off];
+    const int by = t / tiles_x, bx = t - by * tiles_x;
+    const unsigned r = (unsigned)(by * P_ROWS) + (e >> 10);
+    const unsigned c = (unsigned)(bx * T_COLS) + (e & 1023u);
     const BoxRec A = recsA[r];
     BoxRec B;
     make_record<GEOM>(b2 + (size_t)c * 5, 0.f, B);
-    out[e] = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, iof != 0, lp);
+    out[(size_t)r * n2 + c] = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, iof != 0, lp);
+  }
+  // dense tiles (a wave's survivors did not fit its segment): redone whole -- tests, zeros and clipping -- by the
+  // one-launch form's tile routine, in the LDS the prefix no longer needs
+  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+    if (tcount[t] >= 0) continue;
+    __syncthreads();
+    float (*rows)[R3_REC] = reinterpret_cast<float (*)[R3_REC]>(aux);
+    unsigned short* queue = reinterpret_cast<unsigned short*>(aux + P_ROWS * R3_REC);
+    int* qcount = reinterpret_cast<int*>(aux + P_ROWS * R3_REC + D_SUB * T_COLS / 2);
+    compact_tile<GEOM, VEC, T_CPT, P_ROWS, D_SUB>(t % tiles_x, t / tiles_x, b1, n1, b2, n2, iof, out, rows, queue,
+                                                   qcount, pts);
   }
 }
 
@@ -661,31 +711,24 @@ __global__ __launch_bounds__(256) void iou_vec_kernel(const float* __restrict__ 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct PipeLayout {
-  unsigned* ctl;
+  int* tcount;
   BoxRec* recsA;
-  float4* rejB;
-  float* radB;
-  unsigned* gqueue;
-  unsigned qcap;
+  unsigned short* slots;
+  int tiles_x, tiles_y;
 };
 
-// bounded global queue: 64 regions of pairs / 512 entries each = one eighth of the pairs in total (assignment
-// shapes have < 2 % survivors; a workgroup whose region is full clips in place), at least 1 K entries per region
+// workspace: the tile counts, the row records and one 16 KB slot per tile (1 B per pair)
 inline size_t pipe_layout(int n1, int n2, void* ws, PipeLayout* L) {
-  const unsigned long long pairs = (unsigned long long)n1 * (unsigned long long)n2;
-  unsigned long long qcap = pairs / (8 * F_NREG);
-  if (qcap < 1024) qcap = 1024;
+  const int tx = (n2 + T_COLS - 1) / T_COLS, ty = (n1 + P_ROWS - 1) / P_ROWS;
   size_t off = 0;
   char* p = (char*)ws;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
-  char* ctl = take((size_t)F_CTL * 4);
+  char* tc = take((size_t)tx * ty * 4);
   char* ra = take((size_t)n1 * sizeof(BoxRec));
-  char* rj = take((size_t)n2 * 16);
-  char* rd = take((size_t)n2 * 4 + 16);
-  char* gq = take((size_t)qcap * F_NREG * 4);
+  char* sl = take((size_t)tx * ty * P_SLOT * 2);
   if (L) {
-    L->ctl = (unsigned*)ctl; L->recsA = (BoxRec*)ra; L->rejB = (float4*)rj; L->radB = (float*)rd;
-    L->gqueue = (unsigned*)gq; L->qcap = (unsigned)qcap;
+    L->tcount = (int*)tc; L->recsA = (BoxRec*)ra; L->slots = (unsigned short*)sl;
+    L->tiles_x = tx; L->tiles_y = ty;
   }
   return off + 256;
 }
@@ -709,13 +752,15 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
     return 0;
   }
   const unsigned long long pairs = (unsigned long long)n1 * (unsigned long long)n2;
-  const bool fits32 = pairs < 0xffffffffULL;
   // Wide matrices (assignment shapes: few gt rows x tens of thousands of anchors, < 2 % overlapping pairs) take
-  // the prep + stream + drain pipeline.  Everything else is ONE launch (no prep, no queue): tiles narrow enough
+  // the stream + drain pipeline.  Everything else is ONE launch (no queue in memory): tiles narrow enough
   // that the grid still fills the CUs; dense square problems (2000 x 2000: 129 us here, 329 us through the
   // pipeline, whose drain then carries most pairs) and small ones (1000 x 128: 17 us) both prefer it.
   const int wide = g_r3_iou_small > 0 ? g_r3_iou_small : 16384;
-  const bool piped = ws && fits32 && ws_bytes >= r3k_iou_workspace_bytes(n1, n2) && g_r3_iou_impl != 2 &&
+  PipeLayout L;
+  const size_t need = pipe_layout(n1, n2, ws, &L);
+  const long long tiles = (long long)L.tiles_x * L.tiles_y;
+  const bool piped = ws && ws_bytes >= need && tiles <= P_MAX_TILES && g_r3_iou_impl != 2 &&
                      (n2 >= wide || g_r3_iou_impl == 4);
   if (!piped) {
     if (g_r3_iou_impl == 2 || pairs > 2000000ULL) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);
@@ -723,25 +768,22 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
     else launch_compact<GEOM, 4, 8>(vec, iof, b1, n1, b2, n2, out, stream);
     return 0;
   }
-  PipeLayout L;
-  pipe_layout(n1, n2, ws, &L);
-  const int nmax = (n1 > n2 ? n1 : n2) > F_CTL ? (n1 > n2 ? n1 : n2) : F_CTL;
-  hipLaunchKernelGGL(iou_prep_kernel<GEOM>, dim3((nmax + 255) / 256), dim3(256), 0, stream, b1, n1, b2, n2, L.recsA,
-                     L.rejB, L.radB, L.ctl);
-  const unsigned qcap = g_r3_iou_qcap > 0 && (unsigned)g_r3_iou_qcap < L.qcap ? (unsigned)g_r3_iou_qcap : L.qcap;
-  constexpr int SR = 16;
-  dim3 grid((n2 + T_COLS - 1) / T_COLS, (n1 + SR - 1) / SR);
-  if (vec)
-    hipLaunchKernelGGL((iou_stream2_kernel<GEOM, true, SR>), grid, dim3(T_THREADS), 0, stream, L.recsA, n1, b2, L.rejB,
-                       L.radB, n2, iof, out, L.ctl, L.gqueue, qcap);
-  else
-    hipLaunchKernelGGL((iou_stream2_kernel<GEOM, false, SR>), grid, dim3(T_THREADS), 0, stream, L.recsA, n1, b2, L.rejB,
-                       L.radB, n2, iof, out, L.ctl, L.gqueue, qcap);
+  const int wcap = g_r3_iou_qcap > 0 && g_r3_iou_qcap < P_WSEG ? g_r3_iou_qcap : P_WSEG;
+  const dim3 grid(L.tiles_x, L.tiles_y);
   // drain: enough workgroups to fill the chip at the kernel's occupancy; grid-stride inside
   int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(iou_drain_kernel<GEOM>, dim3(blocks), dim3(T_THREADS), 0, stream, L.recsA, b2, n2, iof, L.gqueue,
-                     L.ctl, qcap, out);
+  if (vec) {
+    hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
+                       L.tcount, L.slots, wcap);
+    hipLaunchKernelGGL((iou_drain2_kernel<GEOM, true>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof,
+                       L.recsA, L.tcount, L.slots, L.tiles_x, (int)tiles, out);
+  } else {
+    hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
+                       L.tcount, L.slots, wcap);
+    hipLaunchKernelGGL((iou_drain2_kernel<GEOM, false>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof,
+                       L.recsA, L.tcount, L.slots, L.tiles_x, (int)tiles, out);
+  }
   return 0;
 }
 
