@@ -51,17 +51,23 @@ struct LanePts {
 // ----------------------------------------------------------------------------------------
 // v1
 // ----------------------------------------------------------------------------------------
-template <int STRIDE>
-__device__ __forceinline__ void v1l_push(const LanePts<STRIDE>& u, int& cnt, Pt p) {
-  if (cnt < R3_V1_CAP) {
+// CAP = R3_V1_CAP: the reference's 16-point scratch (further candidates are dropped, r3_geom.h).  CAP = 8: the
+// short form -- 8 slots per lane, half the LDS, twice the resident waves; a 9th candidate (only possible with
+// coincident candidates: two convex quadrilaterals in general position give at most 8) raises `over` and the
+// caller redoes the pair with CAP = 16.
+template <int STRIDE, int CAP>
+__device__ __forceinline__ void v1l_push(const LanePts<STRIDE>& u, int& cnt, bool& over, Pt p) {
+  if (cnt < CAP) {
     u.set(cnt, p);
     cnt++;
+  } else {
+    over = true;
   }
 }
 
-template <int STRIDE>
+template <int STRIDE, int CAP>
 __device__ __forceinline__ void v1l_vertex_in(const Pt* v, const Pt* box, const LanePts<STRIDE>& u,
-                                              int& cnt) {
+                                              int& cnt, bool& over) {
   Pt s02 = addp(box[0], box[2]);
   Pt center = Pt{0.5f * s02.x, 0.5f * s02.y};
   Pt d10 = subp(box[1], box[0]);
@@ -73,13 +79,13 @@ __device__ __forceinline__ void v1l_vertex_in(const Pt* v, const Pt* box, const 
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     Pt pr = subp(v[i], center);
-    if (fabsf(dotp(pr, h_vec)) < h2 && fabsf(dotp(pr, w_vec)) < w2) v1l_push(u, cnt, v[i]);
+    if (fabsf(dotp(pr, h_vec)) < h2 && fabsf(dotp(pr, w_vec)) < w2) v1l_push<STRIDE, CAP>(u, cnt, over, v[i]);
   }
 }
 
-template <int STRIDE>
+template <int STRIDE, int CAP = R3_V1_CAP>
 __device__ __forceinline__ float v1_pair_lds(const float* __restrict__ A, const float* __restrict__ B,
-                                             bool iof, const LanePts<STRIDE>& u) {
+                                             bool iof, const LanePts<STRIDE>& u, bool* overflow = nullptr) {
   Pt v1[4], v2[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -87,8 +93,9 @@ __device__ __forceinline__ float v1_pair_lds(const float* __restrict__ A, const 
     v2[i] = Pt{B[2 * i], B[2 * i + 1]};
   }
   int cnt = 0;
-  v1l_vertex_in(v1, v2, u, cnt);
-  v1l_vertex_in(v2, v1, u, cnt);
+  bool over = false;
+  v1l_vertex_in<STRIDE, CAP>(v1, v2, u, cnt, over);
+  v1l_vertex_in<STRIDE, CAP>(v2, v1, u, cnt, over);
   Pt e1[4], e2[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -103,7 +110,7 @@ __device__ __forceinline__ float v1_pair_lds(const float* __restrict__ A, const 
       const Pt a1 = v1[i], b1 = v2[j], Av = e1[i], Bv = e2[j];
       const Pt Cv = subp(a1, b1);
       if (Cv.x == 0 && Cv.y == 0) {
-        v1l_push(u, cnt, a1);
+        v1l_push<STRIDE, CAP>(u, cnt, over, a1);
         continue;
       }
       const float D = -crossp(Av, Bv);
@@ -112,7 +119,7 @@ __device__ __forceinline__ float v1_pair_lds(const float* __restrict__ A, const 
         const float nt = -crossp(Av, Cv);
         if (unit_halfopen(ns, D) && unit_halfopen(nt, D)) {
           const float s = ns / D;
-          v1l_push(u, cnt, Pt{a1.x + s * Av.x, a1.y + s * Av.y});
+          v1l_push<STRIDE, CAP>(u, cnt, over, Pt{a1.x + s * Av.x, a1.y + s * Av.y});
         }
         continue;
       }
@@ -121,22 +128,38 @@ __device__ __forceinline__ float v1_pair_lds(const float* __restrict__ A, const 
       const float BdtB = dotp(Bv, Bv);
       const float AdtnC = -dotp(Av, Cv);
       const float AdtA = dotp(Av, Av);
-      if (BdtC >= 0 && BdtC < BdtB) v1l_push(u, cnt, a1);
-      if (AdtnC >= 0 && AdtnC < AdtA) v1l_push(u, cnt, b1);
+      if (BdtC >= 0 && BdtC < BdtB) v1l_push<STRIDE, CAP>(u, cnt, over, a1);
+      if (AdtnC >= 0 && AdtnC < AdtA) v1l_push<STRIDE, CAP>(u, cnt, over, b1);
     }
+  }
+  if (CAP < R3_V1_CAP) {
+    if (overflow) *overflow = over;
+    if (over) return 0.f;
   }
   if (cnt < 3) return 0.f;
 
-  // area (:193-228), in place: slot 0 stands for the origin / sentinel, p0 stays in registers
+  // area (:193-228), in place: slot 0 stands for the origin / sentinel, p0 stays in registers.
+  // Every loop below is a chain of dependent LDS reads (the drain kernel spent half of its wave cycles in
+  // s_waitcnt on them), so each one keeps several reads in flight: the next candidate is requested before the
+  // current one is examined, the cleaned list is compared four entries at a time, the insertion sort requests
+  // the entry below the one it is comparing.  Results and operation order are unchanged.
   const float numthres = (float)1e-2;
   const Pt p0 = u.get(0);
   int n = 1;
+  Pt cand = u.get(cnt > 1 ? 1 : 0);
   for (int i = 1; i < cnt; i++) {
-    const Pt d = subp(u.get(i), p0);
+    const Pt d = subp(cand, p0);
+    cand = u.get(i + 1 < cnt ? i + 1 : i);  // slot i + 1 > n: not touched by the set below
     bool clean = !(fabsf(d.x) < numthres && fabsf(d.y) < numthres);  // against vs[0] = origin
-    for (int j = 1; clean && j < n; j++) {
-      const Pt df = subp(d, u.get(j));
-      if (fabsf(df.x) < numthres && fabsf(df.y) < numthres) clean = false;
+    for (int j = 1; clean && j < n; j += 4) {
+      const Pt q0 = u.get(j), q1 = u.get(min(j + 1, CAP - 1)), q2 = u.get(min(j + 2, CAP - 1)),
+               q3 = u.get(min(j + 3, CAP - 1));
+      const Pt f0 = subp(d, q0), f1 = subp(d, q1), f2 = subp(d, q2), f3 = subp(d, q3);
+      const bool hit = (fabsf(f0.x) < numthres && fabsf(f0.y) < numthres) |
+                       ((j + 1 < n) & (fabsf(f1.x) < numthres && fabsf(f1.y) < numthres)) |
+                       ((j + 2 < n) & (fabsf(f2.x) < numthres && fabsf(f2.y) < numthres)) |
+                       ((j + 3 < n) & (fabsf(f3.x) < numthres && fabsf(f3.y) < numthres));
+      if (hit) clean = false;
     }
     if (clean) {
       u.set(n, d);
@@ -146,20 +169,44 @@ __device__ __forceinline__ float v1_pair_lds(const float* __restrict__ A, const 
   for (int i = 2; i < n; i++) {  // i = 1 is a no-op (vs[0] < vs[0] is false)
     const Pt key = u.get(i);
     int j = i - 1;
-    while (j >= 1) {
-      const Pt o = u.get(j);
+    Pt o = u.get(j);
+    for (;;) {
+      const Pt below = u.get(j > 1 ? j - 1 : 1);
       if (!v1_less(key, o)) break;
       u.set(j + 1, o);
       j--;
+      if (j < 1) break;
+      o = below;
     }
     u.set(j + 1, key);
   }
   float a = 0;
-  Pt cur = (n > 1) ? u.get(1) : Pt{0.f, 0.f};
-  for (int i = 1; i < n; i++) {
-    const Pt nx = (i + 1 == n) ? Pt{0.f, 0.f} : u.get(i + 1);
-    a += crossp(cur, nx);
-    cur = nx;
+  Pt cur = u.get(n > 1 ? 1 : 0);
+  if (n <= 1) cur = Pt{0.f, 0.f};
+  for (int i = 1; i < n; i += 4) {
+    const Pt q1 = u.get(min(i + 1, CAP - 1)), q2 = u.get(min(i + 2, CAP - 1)),
+             q3 = u.get(min(i + 3, CAP - 1)), q4 = u.get(min(i + 4, CAP - 1));
+    const Pt z = Pt{0.f, 0.f};
+    {
+      const Pt nx = (i + 1 == n) ? z : q1;
+      a += crossp(cur, nx);
+      cur = nx;
+    }
+    if (i + 1 < n) {
+      const Pt nx = (i + 2 == n) ? z : q2;
+      a += crossp(cur, nx);
+      cur = nx;
+    }
+    if (i + 2 < n) {
+      const Pt nx = (i + 3 == n) ? z : q3;
+      a += crossp(cur, nx);
+      cur = nx;
+    }
+    if (i + 3 < n) {
+      const Pt nx = (i + 4 == n) ? z : q4;
+      a += crossp(cur, nx);
+      cur = nx;
+    }
   }
   float su = a / 2;
   const float s1 = A[8], s2 = B[8];

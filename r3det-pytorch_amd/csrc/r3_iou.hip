@@ -310,22 +310,22 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream_kernel(const float* __re
 // them: on this part a launch that does nothing still occupies ~4.5 us of the stream (measured: an empty
 // 512-workgroup kernel), so the prep kernel (records + counter zeroing, 5 us), and the overflow kernel (4.4 us,
 // normally empty) of the earlier forms were a sixth of the op.
-//   stream : tile = 16 rows x 1024 columns.  The conservative-test data (centre, circumscribed radius, AABB half
-//            extents) is derived in the kernel from the raw boxes with hardware sine / cosine -- the test only
+//   stream : tile = 8 rows x 1024 columns (measured: 4 rows 24.5 us, 8 rows 21.5, 16 rows 24, 32 rows 29).  The
+//            conservative-test data (centre, circumscribed radius, AABB half extents) is derived in the kernel from the raw boxes with hardware sine / cosine -- the test only
 //            has to be conservative, so the extents are inflated by the approximation's error bound instead of
 //            evaluating the exact double-precision sincos; zeros are streamed out with 16-byte stores;
 //            survivors -> per-wave LDS segments (no atomics) -> the tile's OWN slot of the workspace (u16
 //            tile-local entries, 1 B per pair of workspace) + the tile's count.  No global atomics, so nothing
 //            has to be zeroed first.  A tile with a wave more than half full is marked dense (count -1).
 //   drain  : every workgroup rebuilds the prefix over the tile counts (grouped, <= 1024 groups in LDS), then
-//            grid-strides over the concatenated entries, one pair per lane, balanced over the chip; dense
-//            tiles are redone whole by the one-launch form's tile routine at the end.
+//            grid-strides over the concatenated entries, one pair per lane, balanced over the chip; a dense
+//            tile counts as its 8 x 1024 pairs, each tested with the exact records and clipped or zeroed.
 // Measured and NOT shipped: a single persistent kernel in which workgroups alternate between
 // streaming tiles and clipping chunks published by other workgroups (tickets in global memory).  On gfx950 an
 // agent-scope release / acquire is an L2 write-back / invalidate of the whole XCD (the eight L2s are not
 // coherent with each other), so every published tile flushed the freshly written zeros: 725 us instead of 75.
-constexpr int P_ROWS = 16;
-constexpr int P_WSEG = P_ROWS * 128;   // entries of a wave's LDS segment: half of its 16 x 256 pairs
+constexpr int P_ROWS = 8;
+constexpr int P_WSEG = P_ROWS * 128;   // entries of a wave's LDS segment: half of its 8 x 256 pairs
 constexpr int P_SLOT = 4 * P_WSEG;     // u16 entries of a tile's slot in the workspace (16 KB)
 constexpr int P_GROUPS = 1024;         // tile groups whose prefix a drain workgroup keeps in LDS
 constexpr int P_MAX_TILES = 16384;     // beyond: the one-launch form (a group would span > 16 tiles)
@@ -484,22 +484,25 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   for (int q = lane; q < cnt; q += 64) slot[q] = wq[q];
 }
 
-template <int GEOM, bool VEC>
-__global__ __launch_bounds__(T_THREADS) void iou_drain2_kernel(const float* __restrict__ b1, int n1,
+template <int GEOM>
+__global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __restrict__ b1, int n1,
                                                                const float* __restrict__ b2, int n2, int iof,
                                                                const BoxRec* __restrict__ recsA,
                                                                const int* __restrict__ tcount,
                                                                const unsigned short* __restrict__ slots, int tiles_x,
                                                                int tiles, float* __restrict__ out) {
-  constexpr int D_SUB = 2;  // rows per round of the dense-tile routine
-  constexpr int AUX_WORDS = (P_ROWS * R3_REC * 4 + D_SUB * T_COLS * 2 + 16) / 4;  // >= P_GROUPS + 1
-  static_assert(AUX_WORDS >= P_GROUPS + 1, "aux holds the group prefix first, the dense-tile LDS afterwards");
-  __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
-  __shared__ __attribute__((aligned(16))) unsigned aux[AUX_WORDS];
+  // One clip takes a wave ~15 us from first load to store (long dependent chains through LDS), the ALUs are idle
+  // most of that time, so what counts is how many waves a CU holds.  v1: 8 candidate slots per lane instead of
+  // the reference's 16 (wave-private [slot][lane] regions of 4 KB) => 18 KB of LDS per workgroup, 8 workgroups
+  // per CU; the rare pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region.
+  constexpr bool SHORT = GEOM == 1;
+  constexpr int D_PAIRS = P_ROWS * T_COLS;  // a dense tile is enumerated pair by pair
+  __shared__ float2 pts[SHORT ? 8 * T_THREADS : pts_slots<GEOM>() * T_THREADS];
+  __shared__ unsigned pre[P_GROUPS + 1];
   __shared__ unsigned wsum[4];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const LanePts<T_THREADS> lp{pts + tid};
+  const int wave = tid >> 6;
   // prefix over the tile counts in groups of G consecutive tiles; thread t owns groups 4t .. 4t+3
   const int G = (tiles + P_GROUPS - 1) / P_GROUPS;
   unsigned gs[4];
@@ -508,7 +511,10 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain2_kernel(const float* __re
   for (int k = 0; k < 4; k++) {
     unsigned sum = 0;
     const int t0 = (tid * 4 + k) * G;
-    for (int t = t0; t < t0 + G && t < tiles; t++) sum += (unsigned)max(tcount[t], 0);
+    for (int t = t0; t < t0 + G && t < tiles; t++) {
+      const int c = tcount[t];
+      sum += c < 0 ? (unsigned)D_PAIRS : (unsigned)c;
+    }
     gs[k] = sum;
     mine += sum;
   }
@@ -518,50 +524,83 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain2_kernel(const float* __re
     const unsigned t = __shfl_up(incl, d);
     if (lane >= d) incl += t;
   }
-  if (lane == 63) wsum[tid >> 6] = incl;
+  if (lane == 63) wsum[wave] = incl;
   __syncthreads();
   unsigned base = incl - mine;
-  for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+  for (int w = 0; w < wave; w++) base += wsum[w];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    aux[tid * 4 + k] = base;
+    pre[tid * 4 + k] = base;
     base += gs[k];
   }
-  if (tid == T_THREADS - 1) aux[P_GROUPS] = base;
+  if (tid == T_THREADS - 1) pre[P_GROUPS] = base;
   __syncthreads();
-  const unsigned total = aux[P_GROUPS];
-  for (unsigned q = blockIdx.x * T_THREADS + tid; q < total; q += gridDim.x * T_THREADS) {
-    int g = 0;  // group of entry q: largest g with aux[g] <= q
+  const unsigned total = pre[P_GROUPS];
+  for (unsigned qb = blockIdx.x * T_THREADS + wave * 64; qb < total; qb += gridDim.x * T_THREADS) {  // wave-uniform
+    const unsigned q = qb + lane;
+    bool valid = q < total;
+    bool dense = false;
+    unsigned r = 0, c = 0;
+    if (valid) {
+      int g = 0;  // group of entry q: largest g with pre[g] <= q
 #pragma unroll
-    for (int step = P_GROUPS / 2; step >= 1; step >>= 1)
-      if (aux[g + step] <= q) g += step;
-    unsigned off = q - aux[g];
-    int t = g * G;
-    for (;;) {  // tile inside the group (G is 1 or 2 for the assignment shapes)
-      const unsigned c = (unsigned)max(tcount[t], 0);
-      if (off < c) break;
-      off -= c;
-      t++;
+      for (int step = P_GROUPS / 2; step >= 1; step >>= 1)
+        if (pre[g + step] <= q) g += step;
+      unsigned off = q - pre[g];
+      int t = g * G;
+      for (;;) {  // tile inside the group (G = 3 at 1536 tiles)
+        const int tc = tcount[t];
+        const unsigned cn = tc < 0 ? (unsigned)D_PAIRS : (unsigned)tc;
+        if (off < cn) {
+          dense = tc < 0;
+          break;
+        }
+        off -= cn;
+        t++;
+      }
+      const unsigned e = dense ? off : slots[(size_t)t * P_SLOT + off];
+      const int by = t / tiles_x, bx = t - by * tiles_x;
+      r = (unsigned)(by * P_ROWS) + (e >> 10);
+      c = (unsigned)(bx * T_COLS) + (e & 1023u);
+      valid = r < (unsigned)n1 && c < (unsigned)n2;  // dense edge tiles enumerate beyond the matrix
     }
-    const unsigned e = slots[(size_t)t * P_SLOT + off];
-    const int by = t / tiles_x, bx = t - by * tiles_x;
-    const unsigned r = (unsigned)(by * P_ROWS) + (e >> 10);
-    const unsigned c = (unsigned)(bx * T_COLS) + (e & 1023u);
-    const BoxRec A = recsA[r];
-    BoxRec B;
-    make_record<GEOM>(b2 + (size_t)c * 5, 0.f, B);
-    out[(size_t)r * n2 + c] = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, iof != 0, lp);
-  }
-  // dense tiles (a wave's survivors did not fit its segment): redone whole -- tests, zeros and clipping -- by the
-  // one-launch form's tile routine, in the LDS the prefix no longer needs
-  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
-    if (tcount[t] >= 0) continue;
-    __syncthreads();
-    float (*rows)[R3_REC] = reinterpret_cast<float (*)[R3_REC]>(aux);
-    unsigned short* queue = reinterpret_cast<unsigned short*>(aux + P_ROWS * R3_REC);
-    int* qcount = reinterpret_cast<int*>(aux + P_ROWS * R3_REC + D_SUB * T_COLS / 2);
-    compact_tile<GEOM, VEC, T_CPT, P_ROWS, D_SUB>(t % tiles_x, t / tiles_x, b1, n1, b2, n2, iof, out, rows, queue,
-                                                   qcount, pts);
+    bool over = false;
+    if (valid) {
+      const BoxRec A = recsA[r];
+      BoxRec B;
+      make_record<GEOM>(b2 + (size_t)c * 5, 0.f, B);
+      float v = 0.f;
+      // a dense tile's pairs were never tested with exact records: do it here (apart => 0, as in every form)
+      if (!(dense && boxes_apart(A.f, B.f))) {
+        if (SHORT) {
+          const LanePts<64> lp{pts + wave * 512 + lane};
+          v = v1_pair_lds<64, 8>(A.f, B.f, iof != 0, lp, &over);
+        } else {
+          const LanePts<T_THREADS> lp{pts + tid};
+          v = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, iof != 0, lp);
+        }
+      }
+      if (!over) out[(size_t)r * n2 + c] = v;
+    }
+    if (SHORT) {
+      unsigned long long m = __ballot(over);
+      while (m) {  // rare: lane k < 32 redoes the k-th flagged pair with the full 16 slots
+        int src = -1, seen = 0;
+        for (unsigned long long t2 = m; t2; t2 &= t2 - 1) {
+          if (seen == lane) src = __builtin_ctzll(t2);
+          seen++;
+        }
+        const unsigned rr = __shfl(r, src < 0 ? 0 : src), cc = __shfl(c, src < 0 ? 0 : src);
+        if (lane < 32 && src >= 0) {
+          const BoxRec A = recsA[rr];
+          BoxRec B;
+          make_record<GEOM>(b2 + (size_t)cc * 5, 0.f, B);
+          const LanePts<32> lp{pts + wave * 512 + lane};
+          out[(size_t)rr * n2 + cc] = v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, iof != 0, lp);
+        }
+        for (int k = 0; k < 32 && m; k++) m &= m - 1;
+      }
+    }
   }
 }
 
@@ -717,7 +756,7 @@ struct PipeLayout {
   int tiles_x, tiles_y;
 };
 
-// workspace: the tile counts, the row records and one 16 KB slot per tile (1 B per pair)
+// workspace: the tile counts, the row records and one 8 KB slot per tile (1 B per pair)
 inline size_t pipe_layout(int n1, int n2, void* ws, PipeLayout* L) {
   const int tx = (n2 + T_COLS - 1) / T_COLS, ty = (n1 + P_ROWS - 1) / P_ROWS;
   size_t off = 0;
@@ -770,20 +809,18 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   }
   const int wcap = g_r3_iou_qcap > 0 && g_r3_iou_qcap < P_WSEG ? g_r3_iou_qcap : P_WSEG;
   const dim3 grid(L.tiles_x, L.tiles_y);
-  // drain: enough workgroups to fill the chip at the kernel's occupancy; grid-stride inside
+  // drain: enough workgroups to fill the chip at the kernel's occupancy (6 per CU measured best: 1024 -> 33 us, 1536 -> 28, 1792 and more -> 32); grid-stride inside
   int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
-  if (blocks > 1024) blocks = 1024;
-  if (vec) {
+  const int maxb = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : 1536;
+  if (blocks > maxb) blocks = maxb;
+  if (vec)
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
                        L.tcount, L.slots, wcap);
-    hipLaunchKernelGGL((iou_drain2_kernel<GEOM, true>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof,
-                       L.recsA, L.tcount, L.slots, L.tiles_x, (int)tiles, out);
-  } else {
+  else
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
                        L.tcount, L.slots, wcap);
-    hipLaunchKernelGGL((iou_drain2_kernel<GEOM, false>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof,
-                       L.recsA, L.tcount, L.slots, L.tiles_x, (int)tiles, out);
-  }
+  hipLaunchKernelGGL(iou_drain3_kernel<GEOM>, dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
+                     L.tcount, L.slots, L.tiles_x, (int)tiles, out);
   return 0;
 }
 
