@@ -41,6 +41,14 @@ typedef unsigned long long u64;
 constexpr int TILE = 64;        // one wavefront = one 64-wide bitmask word
 constexpr int MASK_WAVES = 4;   // tiles per workgroup of the tile kernels
 constexpr int NT = TILE * MASK_WAVES;
+// The global pair queue is split into Q_NREG regions, each with its own fill counter 128 B from the next: device-
+// scope atomics execute memory-side, one address takes ~12 ns per operation, and the stream kernel issues one per
+// tile (9 045 tiles at n = 8576 were 108 us on ONE counter).  Control block of one problem: the region counters,
+// then the redo-list counter.
+constexpr int Q_NREG = 64;
+constexpr int Q_CSTRIDE = 32;
+constexpr int Q_REDO = Q_NREG * Q_CSTRIDE;   // word index of the redo-list counter
+constexpr int Q_CTL_WORDS = Q_REDO + Q_CSTRIDE;
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -50,6 +58,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Batch {
   const int* counts;
   size_t recs, mask, nz, counter, queue, keep;
+  size_t redo;  // stride of the redo-tile lists
   size_t rows;  // row capacity of one image's arrays (= n for a single problem); `nz` = stride of the side tables
 };
 
@@ -104,7 +113,8 @@ __global__ __launch_bounds__(256) void nms_prepare_kernel(const float* __restric
                                                           BoxRec* __restrict__ recs,
                                                           unsigned* __restrict__ counter) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && counter) *counter = 0;
+  if (counter)
+    for (int k = i; k < Q_CTL_WORDS; k += gridDim.x * blockDim.x) counter[k] = 0;  // region fills, redo-list fill
   if (i >= n) return;
   int64_t src = order[i];
   float lab = labels ? (float)labels[src] : 0.f;  // at::cat({dets, labels}) promotes to float
@@ -222,35 +232,30 @@ __global__ __launch_bounds__(1024) void nms_reduce_dense_kernel(const u64* __res
 }
 
 // ---------------------------------------------------------------------------- queue pipeline
-constexpr int SQ_CAP = 2048;  // LDS queue entries per workgroup (4 KB; the worst case of 16384 made the queue
-                             // the occupancy limiter); survivors beyond it go to the global queue one by one
+// stream: reject tests only.  One wave = one 64 x 64 tile (rows rb, columns cblk >= rb, sorted positions).
+//   * The test loop is what the kernel costs (n = 8576: 18 M pairs), so it is as short as it gets: per column
+//     one 16-byte LDS broadcast and the AABB test (two packed adds, two comparisons) into a per-lane bit, all 64
+//     columns unrolled; the circle test, the label guard and the queue push only run for a lane's candidates.
+//     (Measured and dropped: one scalar branch per column on the 64-row ballot -- with 1-2 % near pairs most
+//     columns have SOME near row, and the dependent LDS-read -> compare -> branch chain cost 200 ns per column.)
+//   * survivors -> the wave's private LDS segment (count in a scalar register, no atomics), flushed per wave
+//     with ONE global atomic, all or nothing.
+//   * a tile that does not fit (segment full: > 1/4 of its pairs survive; or the global queue is full) goes to
+//     the REDO list and is enumerated pair by pair by the drain kernel.  Nothing is clipped here, so the kernel
+//     needs no scratch and no point arrays.
+// Entry in the global queue: (i << 16) | j, i < j sorted positions; 0xffffffff = hole (skipped by the drain).
+constexpr int SQ_WSEG = 1024;  // u16 entries per wave segment (2 KB)
 
-// pair (i, j) clipped where it stands (scratch-array variant of the pair function): the safety net of the
-// stream kernel when a queue is full; exact, not a hot path
-template <int GEOM>
-__device__ __forceinline__ void clip_here(const BoxRec* __restrict__ recs, unsigned i, unsigned j, float thr,
-                                       u64* __restrict__ mask, const Side& sd, int cb) {
-  const BoxRec A = recs[i];
-  const BoxRec B = recs[j];
-  float v;
-  if (GEOM == 1) v = v1_pair_slow(A, B, false);
-  else if (GEOM == 2) v = hull_pair_slow<true>(A, B, true);
-  else v = hull_pair_slow<false>(A, B, true);
-  if (v > thr) mark_pair(mask, sd, i, j, cb);
-}
-
-// stream: reject tests only.  Entry in the global queue: (i << 16) | j, i < j sorted positions.
 template <int GEOM, bool LABEL>
 __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict__ recs, int n, int cb,
-                                                        float thr, unsigned* __restrict__ gqueue,
-                                                        unsigned qcap, unsigned* __restrict__ counter,
-                                                        u64* __restrict__ mask, u64* __restrict__ side, Batch bt) {
-  __shared__ float cols[MASK_WAVES][TILE][8];  // cx, cy, rad, ex, ey, label
-  __shared__ unsigned short queue[SQ_CAP];
-  __shared__ int qcount;
-  __shared__ unsigned qbase;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                        unsigned* __restrict__ gqueue, unsigned qcap,
+                                                        unsigned* __restrict__ counter, unsigned* __restrict__ redo,
+                                                        Batch bt) {
+  __shared__ __attribute__((aligned(16))) float4 colsA[MASK_WAVES][TILE];  // cx, cy, ex, ey
+  __shared__ float2 colsB[MASK_WAVES][TILE];                               // radius, label
+  __shared__ unsigned short queue[MASK_WAVES][SQ_WSEG];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tells the compiler it is wave-uniform: scalar control flow
   const int rb = blockIdx.y;
   if (bt.counts) {  // cb stays the row pitch of mask; the image's own block count bounds the tiles
     const int img = blockIdx.z;
@@ -258,102 +263,148 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
     recs += img * bt.recs;
     gqueue += img * bt.queue;
     counter += img * bt.counter;
-    mask += img * bt.mask;
-    side += img * bt.nz;
+    redo += img * bt.redo;
     if (rb * TILE >= n) return;
   }
-  const Side sd = side_tables(side, bt.rows);
   const int cbn = (n + TILE - 1) / TILE;
   const int cblk = blockIdx.x * MASK_WAVES + wave;
-  const bool active = (cblk < cbn) && (cblk >= rb);
-  if (tid == 0) qcount = 0;
-  int col_size = 0;
-  if (active) {
-    col_size = min(n - cblk * TILE, TILE);
-    if (lane < col_size) {
-      // the reject data sit in the record's last two 16-byte quads (f[9..13]), the label in f[7]: three
-      // 16-byte loads instead of six scalar loads at a 64-byte lane stride
-      const float4* f4 = reinterpret_cast<const float4*>(recs[cblk * TILE + lane].f);
-      const float4 q2 = f4[2], q3 = f4[3];
-      *reinterpret_cast<float4*>(&cols[wave][lane][0]) = make_float4(q2.y, q2.z, q2.w, q3.x);
-      cols[wave][lane][4] = q3.y;
-      cols[wave][lane][5] = (GEOM != 1) ? f4[1].w : 0.f;
-    }
-  }
-  __syncthreads();
-  const int row = rb * TILE + lane;
-  if (active && row < n) {
-    const float4* f4 = reinterpret_cast<const float4*>(recs[row].f);
+  if (cblk >= cbn || cblk < rb) return;  // (no workgroup barrier below: waves are independent)
+  const int col_size = min(n - cblk * TILE, TILE);
+  if (lane < col_size) {
+    // the reject data sit in the record's last two 16-byte quads (f[9..13]), the label in f[7]
+    const float4* f4 = reinterpret_cast<const float4*>(recs[cblk * TILE + lane].f);
     const float4 q2 = f4[2], q3 = f4[3];
-    const float ax = q2.y, ay = q2.z, ar = q2.w, aex = q3.x, aey = q3.y;
-    const float alab = (GEOM != 1) ? f4[1].w : 0.f;
-    const int start = (rb == cblk) ? lane + 1 : 0;
-    // 64 reject tests into one per-lane bit mask (no cross-lane traffic in the loop) ...
-    u64 pm = 0;
-    for (int i = 0; i < col_size; i++) {
-      const float* B = cols[wave][i];
-      float dx = ax - B[0], dy = ay - B[1], rr = ar + B[2];
-      bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + B[3]) | (fabsf(dy) > aey + B[4]);
-      if (GEOM != 1 && LABEL) apart |= (alab != B[5]);
-      if ((i >= start) && !apart) pm |= 1ULL << i;
+    colsA[wave][lane] = make_float4(q2.y, q2.z, q3.x, q3.y);
+    colsB[wave][lane] = make_float2(q2.w, (GEOM != 1) ? f4[1].w : 0.f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave reads what its own lanes wrote: no workgroup barrier
+  __builtin_amdgcn_wave_barrier();
+  const int row = rb * TILE + lane;
+  const int rr_ = row < n ? row : n - 1;
+  const float4* f4 = reinterpret_cast<const float4*>(recs[rr_].f);
+  const float4 q2 = f4[2], q3 = f4[3];
+  const float ax = q2.y, ay = q2.z, ar = q2.w, aex = q3.x, aey = q3.y;
+  const float alab = (GEOM != 1) ? f4[1].w : 0.f;
+  const bool diag = rb == cblk;
+  unsigned short* wq = queue[wave];
+  int cnt = 0;        // wave-uniform
+  bool full = false;  // wave-uniform
+  // 64 AABB tests into one per-lane bit mask: straight-line code, the LDS broadcasts run ahead of the tests
+  // (8 columns per step: unrolling all 64 lets the compiler hoist every LDS read -- 256 VGPRs, 2 waves per SIMD)
+  unsigned long long pm = 0;
+#pragma unroll 1
+  for (int g = 0; g < TILE / 8; g++) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float4 B = colsA[wave][g * 8 + k];
+      const bool near = !(fabsf(ax - B.x) > aex + B.z) && !(fabsf(ay - B.y) > aey + B.w);
+      bits |= near ? (1u << k) : 0u;
     }
-    // ... then ONE LDS atomic per lane that has survivors (rare) reserves its queue slots
-    if (pm) {
-      int slot = atomicAdd(&qcount, __popcll(pm));
-      while (pm) {
-        const int i = __ffsll((long long)pm) - 1;
-        pm &= pm - 1;
-        if (slot < SQ_CAP) {
-          queue[slot] = (unsigned short)((wave << 12) | (lane << 6) | i);
-        } else {  // LDS queue full (a very dense tile): straight to the global queue
-          const unsigned ii = rb * TILE + lane, jj = cblk * TILE + i;
-          const unsigned g = atomicAdd(counter, 1u);
-          if (g < qcap) gqueue[g] = (ii << 16) | jj;
-          else clip_here<GEOM>(recs, ii, jj, thr, mask, sd, cb);
-        }
-        slot++;
-      }
+    pm |= (unsigned long long)bits << (8 * g);
+  }
+  if (col_size < TILE) pm &= (1ULL << col_size) - 1ULL;   // columns beyond the pool hold stale LDS
+  if (diag) pm &= ~((2ULL << lane) - 1ULL);              // pairs above the diagonal only: column > row
+  if (row >= n) pm = 0;
+  // the candidates (a few per lane): circle test, label guard, push.  Wave-uniform loop, one candidate per lane
+  // and turn, so that the fill count stays in a scalar register.
+  while (__builtin_amdgcn_ballot_w64(pm != 0)) {
+    const bool has = pm != 0;
+    const int c = has ? __builtin_ctzll(pm) : 0;
+    pm &= pm - 1;
+    const float4 B = colsA[wave][c];
+    const float2 B2 = colsB[wave][c];
+    const float dx = ax - B.x, dy = ay - B.y, rr = ar + B2.x;
+    bool p = has && !(dx * dx + dy * dy > rr * rr);
+    if (GEOM != 1 && LABEL) p = p && (alab == B2.y);
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(p);
+    if (m2 == 0) continue;
+    if (cnt + 64 > SQ_WSEG) {
+      full = true;
+      break;
+    }
+    if (p) wq[cnt + __popcll(m2 & ((1ULL << lane) - 1ULL))] = (unsigned short)((lane << 6) | c);
+    cnt += __popcll(m2);
+  }
+  if (!full && cnt == 0) return;
+  const unsigned reg = ((unsigned)rb * 5u + (unsigned)cblk) % (unsigned)Q_NREG;
+  unsigned* region = gqueue + (size_t)reg * qcap;  // qcap: entries per region
+  unsigned base = 0;
+  if (!full) {
+    if (lane == 0) base = atomicAdd(counter + reg * Q_CSTRIDE, (unsigned)cnt);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base + (unsigned)cnt > qcap) {  // region exhausted: plug what was reserved, redo the tile
+      for (unsigned q = base + lane; q < base + (unsigned)cnt && q < qcap; q += 64) region[q] = 0xffffffffu;
+      full = true;
     }
   }
-  __syncthreads();
-  const int total = min(qcount, SQ_CAP);
-  if (total == 0) return;
-  if (tid == 0) qbase = atomicAdd(counter, (unsigned)total);
-  __syncthreads();
-  const unsigned base = qbase;
-  for (int q = tid; q < total; q += NT) {
-    const unsigned e = queue[q];
-    const unsigned w = e >> 12, lr = (e >> 6) & 63u, lc = e & 63u;
-    const unsigned i = rb * TILE + lr;
-    const unsigned j = (blockIdx.x * MASK_WAVES + w) * TILE + lc;
-    if (base + q < qcap) gqueue[base + q] = (i << 16) | j;
-    else clip_here<GEOM>(recs, i, j, thr, mask, sd, cb);  // global queue exhausted (pathologically dense input)
+  if (full) {
+    if (lane == 0) redo[atomicAdd(counter + Q_REDO, 1u)] = ((unsigned)rb << 16) | (unsigned)cblk;
+    return;
+  }
+  for (int q = lane; q < cnt; q += 64) {
+    const unsigned e = wq[q];
+    region[base + q] = ((unsigned)(rb * TILE) + (e >> 6)) << 16 | ((unsigned)(cblk * TILE) + (e & 63u));
   }
 }
 
-template <int GEOM>
-__global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict__ recs, int cb, float thr,
+template <int GEOM, bool LABEL>
+__global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict__ recs, int n, int cb, float thr,
                                                         const unsigned* __restrict__ gqueue, unsigned qcap,
                                                         const unsigned* __restrict__ counter,
+                                                        const unsigned* __restrict__ redo,
                                                         u64* __restrict__ mask, u64* __restrict__ side, Batch bt) {
   __shared__ float2 pts[pts_slots<GEOM>() * 256];
   const LanePts<256> lp{pts + threadIdx.x};
   if (bt.counts) {
     const int img = blockIdx.z;
+    n = bt.counts[img];
     recs += img * bt.recs;
     gqueue += img * bt.queue;
     counter += img * bt.counter;
+    redo += img * bt.redo;
     mask += img * bt.mask;
     side += img * bt.nz;
   }
   const Side sd = side_tables(side, bt.rows);
-  unsigned total = *counter;
-  if (total > qcap) total = qcap;
+  __shared__ unsigned pre[Q_NREG + 1];  // exclusive prefix of the regions' (clamped) fills
+  if (threadIdx.x < 64) {
+    const unsigned v = min(counter[threadIdx.x * Q_CSTRIDE], qcap);
+    unsigned incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned t = __shfl_up(incl, d);
+      if ((int)threadIdx.x >= d) incl += t;
+    }
+    pre[threadIdx.x + 1] = incl;
+    if (threadIdx.x == 0) pre[0] = 0;
+  }
+  __syncthreads();
+  const unsigned total = pre[Q_NREG];
   for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
-    const unsigned e = gqueue[q];
+    int lo = 0;  // region of entry q: largest lo with pre[lo] <= q
+#pragma unroll
+    for (int step = Q_NREG / 2; step >= 1; step >>= 1)
+      if (pre[lo + step] <= q) lo += step;
+    const unsigned e = gqueue[(size_t)lo * qcap + (q - pre[lo])];
+    if (e == 0xffffffffu) continue;
     const unsigned i = e >> 16, j = e & 0xffffu;
     const BoxRec A = recs[i];
     const BoxRec B = recs[j];
+    const float v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
+    if (v > thr) mark_pair(mask, sd, i, j, cb);
+  }
+  // redo tiles (dense clusters, exhausted queue): all 64 x 64 pairs, 256 per step, tested with the records
+  const unsigned units = counter[Q_REDO] * 16u;
+  for (unsigned u = blockIdx.x; u < units; u += gridDim.x) {
+    const unsigned t = redo[u >> 4];
+    const unsigned p = (u & 15u) * 256u + threadIdx.x;
+    const unsigned i = (t >> 16) * TILE + (p >> 6), j = (t & 0xffffu) * TILE + (p & 63u);
+    if (i >= (unsigned)n || j >= (unsigned)n || i >= j) continue;
+    const BoxRec A = recs[i];
+    const BoxRec B = recs[j];
+    if (boxes_apart(A.f, B.f)) continue;
+    if (GEOM != 1 && LABEL && A.f[7] != B.f[7]) continue;
     const float v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
     if (v > thr) mark_pair(mask, sd, i, j, cb);
   }
@@ -628,17 +679,19 @@ struct Layout {
   u64* nz;
   unsigned* counter;
   unsigned* gqueue;
+  unsigned* redo;
   unsigned qcap;
   uint8_t* flags;
   int cb;
 };
 
 inline size_t queue_entries(int n) {
-  // generous for real pools (tens of candidate pairs per box); denser inputs spill to the
-  // in-kernel path of nms_stream_kernel
+  // all regions together: generous for real pools (tens of candidate pairs per box); denser inputs go through
+  // the redo list.  A region holds queue_entries / Q_NREG entries.
   size_t tri = (size_t)n * (size_t)(n - 1) / 2;
   size_t cap = (size_t)n * 64 + 65536;
-  return tri < cap ? tri : cap;
+  if (tri < cap) cap = tri < (size_t)Q_NREG * 64 ? (size_t)Q_NREG * 64 : tri;
+  return cap / Q_NREG * Q_NREG;
 }
 
 inline size_t layout(int n, void* ws, Layout* L) {
@@ -649,13 +702,14 @@ inline size_t layout(int n, void* ws, Layout* L) {
   char* recs = take((size_t)n * sizeof(BoxRec));
   char* mask = take((size_t)n * cb * sizeof(u64));  // mask and nz are zeroed together
   char* nz = take(side_words((size_t)n) * sizeof(u64));  // side tables (zeroed with the mask)
-  char* counter = take(256);
+  char* counter = take((size_t)Q_CTL_WORDS * 4);
   char* gq = take(queue_entries(n) * sizeof(unsigned));
+  char* rd = take(cb * cb * sizeof(unsigned));  // redo-tile list
   char* flags = take((size_t)n);
   if (L) {
     L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz; L->counter = (unsigned*)counter;
-    L->gqueue = (unsigned*)gq; L->qcap = (unsigned)queue_entries(n); L->flags = (uint8_t*)flags;
-    // test hook: a tiny capacity forces the in-kernel overflow path of nms_stream_kernel
+    L->gqueue = (unsigned*)gq; L->redo = (unsigned*)rd; L->qcap = (unsigned)(queue_entries(n) / Q_NREG); L->flags = (uint8_t*)flags;
+    // test hook: a tiny capacity forces the redo path of the stream / drain kernels
     if (g_r3_nms_qcap > 0 && (unsigned)g_r3_nms_qcap < L->qcap) L->qcap = (unsigned)g_r3_nms_qcap;
     L->cb = (int)cb;
   }
@@ -694,10 +748,10 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
   // mask + nz are adjacent: one fill
   size_t zbytes = (size_t)((char*)L.counter - (char*)L.mask);
   if (hipMemsetAsync(L.mask, 0, zbytes, stream) != hipSuccess) return -2;
-  hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, thr,
-                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, single_problem(n));
-  hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dim3(drain_blocks(L.qcap)), dim3(256), 0, stream, L.recs, cb, thr,
-                     L.gqueue, L.qcap, L.counter, L.mask, L.nz, single_problem(n));
+  hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, L.gqueue, L.qcap,
+                     L.counter, L.redo, single_problem(n));
+  hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL>), dim3(drain_blocks((size_t)L.qcap * Q_NREG)), dim3(256), 0, stream, L.recs, n, cb,
+                     thr, L.gqueue, L.qcap, L.counter, L.redo, L.mask, L.nz, single_problem(n));
   launch_reduce(1, L.mask, L.nz, n, cb, order, keep_out, count_out, single_problem(n), stream);
   return 0;
 }
@@ -955,7 +1009,7 @@ __global__ __launch_bounds__(256) void mc_prepare_kernel(const float* __restrict
                                                          size_t counter_stride) {
   const int img = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0) counter[img * counter_stride] = 0;
+  for (int k = c; k < Q_CTL_WORDS; k += gridDim.x * 256) counter[img * counter_stride + k] = 0;
   if (c >= counts[img]) return;
   const size_t cbase = (size_t)img * cand_stride;
   const int pos = cand_rank[cbase + c];
@@ -1089,6 +1143,7 @@ struct McLayout {
   u64* mask;
   u64* nz;
   unsigned* counter;
+  unsigned* redo;
   unsigned* gqueue;
   int64_t* keep;
   int32_t* kept;
@@ -1096,7 +1151,7 @@ struct McLayout {
   uint8_t* dead;
   float* extent;
   int* ccounts;
-  size_t qcap, zero_bytes;
+  size_t qcap, qstride, zero_bytes;  // entries per region; entries per image
   int cb;
 };
 
@@ -1109,8 +1164,9 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* recs = take((size_t)B * cap * sizeof(BoxRec));
   char* mask = take((size_t)B * cap * cb * 8);  // mask and nz: one fill
   char* nz = take((size_t)B * side_words((size_t)cap) * 8);  // per image: side tables
-  char* counter = take((size_t)B * 256);
+  char* counter = take((size_t)B * Q_CTL_WORDS * 4);
   char* gq = take((size_t)B * qcap * 4);
+  char* rd = take((size_t)B * cb * cb * 4);  // redo-tile lists
   char* keep = take((size_t)B * cap * 8);
   char* kept = take((size_t)B * 4);
   char* flags = take((size_t)B * cap);
@@ -1119,9 +1175,9 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* ccounts = take((size_t)B * 4);
   if (L) {
     L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
-    L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->keep = (int64_t*)keep;
+    L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->redo = (unsigned*)rd; L->keep = (int64_t*)keep;
     L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
-    L->qcap = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb;
+    L->qcap = qcap / Q_NREG; L->qstride = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb;
     if (g_r3_nms_qcap > 0 && (size_t)g_r3_nms_qcap < L->qcap) L->qcap = (size_t)g_r3_nms_qcap;
   }
   return off + 256;
@@ -1173,8 +1229,8 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   McLayout L;
   mc_layout(B, cap, ws, &L);
   const size_t cbq = (size_t)L.cb;
-  Batch bt{L.ccounts, (size_t)cap, (size_t)cap * cbq, side_words((size_t)cap), 64, L.qcap, (size_t)cap,
-           (size_t)cap};
+  Batch bt{L.ccounts, (size_t)cap, (size_t)cap * cbq, side_words((size_t)cap), (size_t)Q_CTL_WORDS, L.qstride,
+           (size_t)cap, cbq * cbq, (size_t)cap};
   // the rank kernel accumulates into cand_rank: zeroed here so that a caller's stale scratch cannot send
   // records out of bounds; and the counts are clamped to cap for the same reason (an image with more
   // candidates than cap is processed as its first cap candidates: the caller sizes cap from the counts,
@@ -1185,7 +1241,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   hipLaunchKernelGGL(mc_rank_kernel, dim3((cap + RK_T - 1) / RK_T, (cap + RK_J - 1) / RK_J, B), dim3(RK_T), 0, stream,
                      cand_score, S, counts, cand_rank);
   const dim3 pgrid((cap + 255) / 256, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
-  int dblocks = drain_blocks(L.qcap);
+  int dblocks = drain_blocks(L.qstride);
   if (dblocks > 256) dblocks = 256;  // B images share the chip
   const dim3 dgrid(dblocks, 1, B);
   if (geom == 3)
@@ -1194,10 +1250,10 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
 #define R3_MC(GEOM, LABEL, SCALE)                                                                                  \
   hipLaunchKernelGGL(mc_prepare_kernel<GEOM>, pgrid, dim3(256), 0, stream, boxes, n, cand_row, cand_label,        \
                      cand_rank, S, counts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.counter, bt.counter);        \
-  hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, iou_thr,       \
-                     L.gqueue, (unsigned)L.qcap, L.counter, L.mask, L.nz, bt);                              \
-  hipLaunchKernelGGL(nms_drain_kernel<GEOM>, dgrid, dim3(256), 0, stream, L.recs, L.cb, iou_thr, L.gqueue,        \
-                     (unsigned)L.qcap, L.counter, L.mask, L.nz, bt)
+  hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, L.gqueue,      \
+                     (unsigned)L.qcap, L.counter, L.redo, bt);                                                    \
+  hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb, iou_thr,      \
+                     L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt)
   if (geom == 1) { R3_MC(1, false, maxc); }
   else if (geom == 3) { R3_MC(3, false, L.extent); }
   else { R3_MC(2, true, (const float*)nullptr); }
