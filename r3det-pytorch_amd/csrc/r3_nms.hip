@@ -427,22 +427,29 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
 // and wave 0 finishes adversarial inputs row by row in score order.
 constexpr int RTHREADS = 1024;
 constexpr int R_MAX_ROUNDS = 32;
-constexpr int R_CACHE = 9;  // rows per thread whose count and first 8 suppressors stay in registers (n <= 9216)
+constexpr int R_CACHE = 9;     // rows per thread whose count and first 8 suppressors stay in registers (n <= 9216)
+constexpr int R_BLIST = 8192;  // rows on the long-list worklist (u16 each)
 
-// state of one suppressor list entry against the K / R bit sets
-#define R3_LOOK(i, on, anyK, allR)                         \
-  {                                                        \
-    anyK |= (on) && ((K32[(i) >> 5] >> ((i) & 31)) & 1u);  \
-    allR &= !(on) || ((R32[(i) >> 5] >> ((i) & 31)) & 1u); \
-  }
+// LDS of the reducer (dynamic): state bytes | K words | R words | block prefix | long-list worklist
+__host__ __device__ inline size_t reduce_lds_bytes(int n, int cb) {
+  return (size_t)((n + 15) & ~15) + (size_t)cb * 8 * 2 + (size_t)cb * 4 + (size_t)R_BLIST * 2 + 16;
+}
 
+// Measured inside the kernel (wall clock, n = 8576, 70 us before): round 1's pass over the register-cached rows
+// 9.5 us -- 144 bit lookups per thread, two LDS reads each, serialised by bank conflicts; the rows with more than
+// 8 suppressors 11.5 us per round -- nine serial iterations at ~10 % lane use, two dependent global loads each;
+// the keep list 8 us -- one thread per 64-row block writing its kept rows one by one.  Hence:
+//   * one STATE BYTE per row in LDS (0 undecided, 1 kept, 2 removed): one read per lookup, written by the row's
+//     owner only (no atomics); the K / R bit words are kept as well (ballots) for the overflow-mask scans;
+//   * the long-list rows are compacted ONCE into a worklist and visited one per thread and round;
+//   * the keep list is written one row per thread from the block prefix.
 __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* __restrict__ maskT,
                                                                      const u64* __restrict__ side, int n, int cb,
                                                                      const int64_t* __restrict__ order,
                                                                      int64_t* __restrict__ keep_out,
                                                                      int32_t* __restrict__ count_out, Batch bt) {
-  extern __shared__ __attribute__((aligned(16))) u64 smem[];
-  __shared__ int s_und;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+  __shared__ int s_und, s_nbig;
   __shared__ int wsum[RTHREADS / 64];
   if (bt.counts) {
     const int img = blockIdx.z;
@@ -453,10 +460,12 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* 
     count_out += img;
   }
   const int cbn = (n + TILE - 1) / TILE;
-  u64* Kb = smem;        // cb words: rows known kept
-  u64* Rb = smem + cb;   // cb words: rows known removed
-  const unsigned* K32 = reinterpret_cast<const unsigned*>(Kb);  // (bit lookups read 32-bit halves: one register each)
-  const unsigned* R32 = reinterpret_cast<const unsigned*>(Rb);
+  const int nb = (n + 15) & ~15;
+  unsigned char* st = smem8;                               // row state
+  u64* Kb = reinterpret_cast<u64*>(smem8 + nb);            // cb words: rows known kept
+  u64* Rb = Kb + cb;                                       // cb words: rows known removed
+  int* bpre = reinterpret_cast<int*>(Rb + cb);             // exclusive prefix of the kept counts per block
+  unsigned short* blist = reinterpret_cast<unsigned short*>(bpre + cb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Side sd = side_tables(const_cast<u64*>(side), bt.rows);
 
@@ -470,30 +479,85 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* 
     cnt[u] = sd.ecnt[rr];
     c0[u] = *reinterpret_cast<const uint4*>(sd.elist + (size_t)rr * EL);
   }
-  unsigned big = 0;  // cached rows with more than 8 suppressors
-#pragma unroll
-  for (int u = 0; u < R_CACHE; u++) big |= (cnt[u] > 8 ? 1u : 0u) << u;
+  if (tid == 0) s_nbig = 0;
   for (int j = tid; j < cb; j += RTHREADS) {
     Kb[j] = 0;
     Rb[j] = 0;
   }
   __syncthreads();
-  // rows without suppressors are kept: round 1 then already sees the cluster heads.  A wave's 64 rows of one
-  // pass are exactly one 64-bit word of the bit sets, and no other wave touches that word in this pass: the
-  // decisions are collected with a ballot and written by lane 0 (64 lanes doing an LDS atomicOr on the same
-  // word serialise: that was half of the reducer's time).
+  // rows without suppressors are kept: round 1 then already sees the cluster heads.  Rows with more than 8
+  // suppressors (or beyond the register cache) go to the worklist; what does not fit stays with its owner.
+  unsigned own = 0;  // cached rows with a long list that did not fit the worklist
 #pragma unroll
   for (int u = 0; u < R_CACHE; u++) {
     const int r = tid + u * RTHREADS;
-    const u64 k0 = __ballot(r < n && cnt[u] == 0);
+    const bool kept0 = r < n && cnt[u] == 0;
+    if (r < n) st[r] = kept0 ? 1 : 0;
+    const u64 k0 = __ballot(kept0);
     if (lane == 0 && k0) Kb[r >> 6] = k0;
+    const bool isbig = r < n && cnt[u] > 8;
+    const u64 mb = __ballot(isbig);
+    if (mb) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_nbig, __popcll(mb));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const int slot = base + __popcll(mb & ((1ULL << lane) - 1ULL));
+      if (isbig) {
+        if (slot < R_BLIST) blist[slot] = (unsigned short)r;
+        else own |= 1u << u;
+      }
+    }
   }
   for (int u = R_CACHE; wave * 64 + u * RTHREADS < n; u++) {
     const int r = tid + u * RTHREADS;
-    const u64 k0 = __ballot(r < n && sd.ecnt[r < n ? r : 0] == 0);
+    const bool kept0 = r < n && sd.ecnt[r < n ? r : 0] == 0;
+    if (r < n) st[r] = kept0 ? 1 : 0;
+    const u64 k0 = __ballot(kept0);
     if (lane == 0 && k0) Kb[r >> 6] = k0;
   }
   __syncthreads();
+  const int nbig = min(s_nbig, R_BLIST);
+
+  // one row against the K / R sets; returns 0 undecided, 1 kept, 2 removed
+  auto long_row = [&](const int r) -> int {
+    const unsigned m = 65535u - (unsigned)sd.msup[r];  // its highest-scored suppressor first
+    if (m < 65535u && st[m] == 1) return 2;
+    const int c = sd.ecnt[r];
+    const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
+    const uint4 t[4] = {lp[0], lp[1], lp[2], lp[3]};
+    const int listed = min(c, EL);
+    bool anyK = false, allR = true;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; c4++) {
+      const unsigned wv[4] = {t[c4].x, t[c4].y, t[c4].z, t[c4].w};
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+        const bool on = 8 * c4 + q < listed;
+        const unsigned char v = st[on ? i : 0];
+        anyK |= on && v == 1;
+        allR &= !on || v == 2;
+      }
+    }
+    if (c > EL && !anyK) {
+      // suppressors beyond the list: scan the overflow row, 8 independent word loads per step
+      const u64* row = maskT + (size_t)r * cb;
+      const int w = r >> 6;
+      for (int q0 = 0; q0 <= w && !anyK; q0 += 8) {
+        u64 mm[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) mm[e] = row[min(q0 + e, w)];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int q = min(q0 + e, w);
+          anyK |= (mm[e] & Kb[q]) != 0ULL;
+          allR &= (mm[e] & ~Rb[q]) == 0ULL;
+        }
+      }
+    }
+    return anyK ? 2 : (allR ? 1 : 0);
+  };
+
   int round = 0;
   for (; round < R_MAX_ROUNDS; round++) {
     if (tid == 0) s_und = 0;
@@ -503,76 +567,63 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* 
 #pragma unroll
     for (int u = 0; u < R_CACHE; u++) {
       const int r = tid + u * RTHREADS;
-      const int w = r >> 6;
-      const bool act = r < n && cnt[u] <= 8 && !((Kb[w] | Rb[w]) >> (r & 63) & 1ULL);
+      const bool act = r < n && cnt[u] <= 8 && cnt[u] > 0 && st[r] == 0;
+      if (__ballot(act) == 0ULL) continue;
       bool anyK = false, allR = true;
       if (act) {
         unsigned wv[4] = {c0[u].x, c0[u].y, c0[u].z, c0[u].w};
-        // opaque copies: without them the compiler hoists the 16 derived word indices / shifts of every cached
+        // opaque copies: without them the compiler hoists the 16 derived indices / shifts of every cached
         // row out of the round loop and spills (34 registers per row instead of 5)
         asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));
+        unsigned char v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {  // eight independent byte reads, then the logic
+          const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+          v[q] = st[q < cnt[u] ? i : 0];
+        }
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-          const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
-          R3_LOOK(i, q < cnt[u], anyK, allR);
+          const bool on = q < cnt[u];
+          anyK |= on && v[q] == 1;
+          allR &= !on || v[q] == 2;
         }
       }
-      const u64 mr = __ballot(act && anyK), mk = __ballot(act && !anyK && allR);
+      const bool toR = act && anyK, toK = act && !anyK && allR;
+      if (toR | toK) st[r] = toR ? 2 : 1;
+      const u64 mr = __ballot(toR), mk = __ballot(toK);
       und += act && !anyK && !allR;
       if (lane == 0) {
-        if (mr) Rb[w] |= mr;
-        if (mk) Kb[w] |= mk;
+        if (mr) Rb[r >> 6] |= mr;
+        if (mk) Kb[r >> 6] |= mk;
       }
     }
-    // pass B (a loop, not unrolled): rows with longer lists and rows beyond the register cache reload their list
-    for (int u = 0; wave * 64 + u * RTHREADS < n; u++) {
-      const int r = tid + u * RTHREADS;
-      const int w = r >> 6;
-      const bool act = r < n && !(u < R_CACHE && !((big >> u) & 1u)) && !((Kb[w] | Rb[w]) >> (r & 63) & 1ULL);
-      bool anyK = false, allR = true;
-      if (act) {
-        const unsigned m = 65535u - (unsigned)sd.msup[r];  // its highest-scored suppressor first
-        anyK = m < 65535u && ((K32[m >> 5] >> (m & 31)) & 1u);
+    // pass B: the worklist of long rows, one per thread.  (A wave's rows are not one 64-row block here: the bit
+    // words take LDS atomics -- few rows, spread over the words.)
+    for (int k = tid; k < nbig; k += RTHREADS) {
+      const int r = blist[k];
+      if (st[r] != 0) continue;
+      const int d = long_row(r);
+      if (d) {
+        st[r] = (unsigned char)d;
+        atomicOr(d == 1 ? &Kb[r >> 6] : &Rb[r >> 6], 1ULL << (r & 63));
+      } else {
+        und++;
       }
-      if (act && !anyK) {
-        const int c = sd.ecnt[r];
-        const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
-        const uint4 t[4] = {lp[0], lp[1], lp[2], lp[3]};
-        const int listed = min(c, EL);
-#pragma unroll
-        for (int c4 = 0; c4 < 4; c4++) {  // 8 suppressors per chunk; a chunk no lane needs is skipped as a whole
-          if (listed > 8 * c4) {
-            const unsigned wv[4] = {t[c4].x, t[c4].y, t[c4].z, t[c4].w};
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-              const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
-              R3_LOOK(i, 8 * c4 + q < listed, anyK, allR);
-            }
-          }
+    }
+    // pass C: cached long rows that did not fit the worklist, and rows beyond the register cache (n > 9216)
+    if (own || n > R_CACHE * RTHREADS) {
+      for (int u = 0; wave * 64 + u * RTHREADS < n; u++) {
+        const int r = tid + u * RTHREADS;
+        const bool mine = u < R_CACHE ? ((own >> u) & 1u) : true;
+        if (!(r < n && mine && st[r] == 0)) continue;
+        if (u >= R_CACHE && sd.ecnt[r] == 0) continue;
+        const int d = long_row(r);
+        if (d) {
+          st[r] = (unsigned char)d;
+          atomicOr(d == 1 ? &Kb[r >> 6] : &Rb[r >> 6], 1ULL << (r & 63));
+        } else {
+          und++;
         }
-        if (c > EL && !anyK) {
-          // suppressors beyond the list: scan the overflow row, 8 independent word loads per step (a kept box of a
-          // dense cluster rescans its row every round until all of its suppressors are decided: one dependent
-          // load per word made this the reducer's largest cost on the model's pools)
-          const u64* row = maskT + (size_t)r * cb;
-          for (int q0 = 0; q0 <= w && !anyK; q0 += 8) {
-            u64 mm[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) mm[e] = row[min(q0 + e, w)];
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-              const int q = min(q0 + e, w);
-              anyK |= (mm[e] & Kb[q]) != 0ULL;
-              allR &= (mm[e] & ~Rb[q]) == 0ULL;
-            }
-          }
-        }
-      }
-      const u64 mr = __ballot(act && anyK), mk = __ballot(act && !anyK && allR);
-      und += act && !anyK && !allR;
-      if (lane == 0) {
-        if (mr) Rb[w] |= mr;
-        if (mk) Kb[w] |= mk;
       }
     }
     if (und) atomicAdd(&s_und, und);
@@ -606,6 +657,7 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* 
         if (lane == 0) {
           if (removed) Rb[b] |= 1ULL << k;
           else Kb[b] |= 1ULL << k;
+          st[r] = removed ? 2 : 1;
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
@@ -613,36 +665,37 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* 
     }
   }
   __syncthreads();
-  // keep list: block counts -> exclusive scan (wave shuffles + 16 partials) -> sorted positions / original indices
-  const int c = tid < cbn ? __popcll(Kb[tid]) : 0;  // cbn <= 1024: one block per thread
-  int incl = c;
+  // keep list: block counts -> exclusive scan (wave shuffles + 16 partials) -> one kept row per thread
+  int total = 0;
+  for (int b0 = 0; b0 < cbn; b0 += RTHREADS) {  // (cbn <= 1024: one trip)
+    const int b = b0 + tid;
+    const int c = b < cbn ? __popcll(Kb[b]) : 0;
+    int incl = c;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d);
-    if (lane >= d) incl += t;
-  }
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  int woff = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < RTHREADS / 64; w++) {
-    const int t = wsum[w];
-    if (w < wave) woff += t;
-    total += t;
-  }
-  if (tid < cbn) {
-    int pos = woff + incl - c;
-    u64 kb = Kb[tid];
-    while (kb) {
-      const int k = __ffsll((long long)kb) - 1;
-      kb &= kb - 1;
-      const int p = tid * TILE + k;
-      keep_out[pos++] = order ? order[p] : (int64_t)p;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
     }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < RTHREADS / 64; w++) {
+      const int t = wsum[w];
+      if (w < wave) woff += t;
+      tot += t;
+    }
+    if (b < cbn) bpre[b] = total + woff + incl - c;
+    total += tot;
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += RTHREADS) {
+    const u64 kb = Kb[r >> 6];
+    if ((kb >> (r & 63)) & 1ULL)
+      keep_out[bpre[r >> 6] + __popcll(kb & ((1ULL << (r & 63)) - 1ULL))] = order ? order[r] : (int64_t)r;
   }
   if (tid == 0) *count_out = total;
 }
-#undef R3_LOOK
 
 // rnms returns keep sorted by original index (rnms_kernel.cu:331-334): mark kept originals,
 // then an ordered compaction by one workgroup.
@@ -724,7 +777,13 @@ inline int drain_blocks(size_t qcap) {
 // greedy reduction of `images` problems (blockIdx.z)
 inline void launch_reduce(int images, const u64* mask, const u64* side, int n, int cb, const int64_t* order,
                           int64_t* keep_out, int32_t* count_out, const Batch& bt, hipStream_t stream) {
-  const size_t lds = (size_t)2 * cb * sizeof(u64);
+  const size_t lds = reduce_lds_bytes(n > 0 ? n : (int)bt.rows, cb);  // (batched: n = 0, row capacity in bt)
+  static bool raised = false;  // the default cap on dynamic LDS is 64 KB
+  if (lds > 64 * 1024 && !raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_rounds_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    raised = true;
+  }
   hipLaunchKernelGGL(nms_reduce_rounds_kernel, dim3(1, 1, images), dim3(RTHREADS), lds, stream, mask, side, n, cb,
                      order, keep_out, count_out, bt);
 }
