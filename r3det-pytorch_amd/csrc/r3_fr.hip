@@ -618,6 +618,142 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_pipe(
   }
 }
 
+// High-occupancy form (the shipped one).  What the measurements say (tools/probes/stream_probe.hip,
+// tools/fr_nhwc_fields.py, tools/fr_nhwc_ab.py; level 0, N = 4, buffers rotating beyond the Infinity Cache):
+//   * out = a + b + r alone, in this kernel's 4 x 4 tile order, streams at 5.6 TB/s (48 us) with 8 light
+//     workgroups per CU; eight more cache-hitting row loads per position (the taps) make it 60 us -- the L1
+//     serves 64 B per clock and CU;
+//   * the software-pipelined kernels above need 156 / 240 VGPRs: 8 waves per CU, 83 / 112 us, and 72 us even when
+//     every sample is out of range -- they are bound by how few loads a CU has in flight, not by the gather.
+// So: no register pipeline: a wave requests the identity rows of its four positions at once and there are 16
+// waves per CU; and most tap rows never pass through the L1 at all (see the kernel's first comment).
+template <bool FUSED, bool PAIRED>
+__global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
+    const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
+    float scale, int tiles_x, int tiles_per_img, int T, float* __restrict__ out) {
+  // The sampled map P = (a + bias_a) + (b + bias_b) of the workgroup's own positions is shared through LDS: each
+  // wave computes P for its 4 positions once (their identity term), the barrier publishes the two 4 x 4 tiles, and
+  // a tap that falls inside either tile -- with transposed pairing that is 3 of 4 taps of a regular box field --
+  // is one LDS read instead of two row loads through the L1 (which serves 64 B per clock: the 8 tap rows per
+  // position were a third of the kernel).  Taps outside the two tiles are loaded as before.
+  __shared__ float4 Ps[PAIRED ? 2 : 1][NH_ROWS * 4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
+  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  unsigned t = blockIdx.x;
+  if ((T & 7) == 0) t = (t & 7u) * (unsigned)(T >> 3) + (t >> 3);  // XCD-contiguous bands of tiles
+  const int n = (int)(t / (unsigned)tiles_per_img);
+  const int tt = (int)(t - (unsigned)n * (unsigned)tiles_per_img);
+  int ty, tx, oy, ox;  // own tile, the other half's tile
+  bool idle = false;   // (an idle half still takes part in the barrier)
+  if (PAIRED) {
+    // tt < tiles_x (tiles_x - 1) / 2: the strict pairs i < j, one half each for (i, j) and (j, i); then the
+    // diagonal tiles two by two, so that every workgroup has two full halves (at N = 4, 128 x 128 that makes
+    // 2048 workgroups = exactly four residency rounds of 2 per CU: no tail)
+    const int off = tiles_x * (tiles_x - 1) / 2;
+    if (tt < off) {
+      int pj = (int)((sqrtf(8.f * (float)tt + 1.f) + 1.f) * 0.5f);
+      while (pj * (pj - 1) / 2 > tt) pj--;
+      while ((pj + 1) * pj / 2 <= tt) pj++;
+      const int pi = tt - pj * (pj - 1) / 2;
+      ty = half ? pj : pi;
+      tx = half ? pi : pj;
+      oy = tx;
+      ox = ty;
+    } else {
+      ty = tx = 2 * (tt - off) + half;
+      oy = ox = 2 * (tt - off) + (half ^ 1);
+      idle = ty >= tiles_x;
+    }
+  } else {
+    ty = tt / tiles_x;
+    tx = tt - ty * tiles_x;
+    oy = ty;
+    ox = tx;
+  }
+  const int h = ty * NH_ROWS + wave;
+  idle = idle || h >= H;
+  const int HW = H * W, C4 = C >> 2;
+  const size_t img = (size_t)n * HW;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  const float4* r4 = reinterpret_cast<const float4*>(res);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  const bool two = FUSED && b != nullptr, has_res = FUSED && res != nullptr;
+  const int w0 = tx * 4, cnt = idle ? 0 : min(4, W - w0);
+  for (int c0 = 0; c0 < C4; c0 += 64) {  // (wave-uniform trip count: the barriers are inside)
+    const int c4 = c0 + lane;
+    const bool cl = c4 < C4;
+    float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+    if (FUSED && cl) {
+      if (bias_a) ba = reinterpret_cast<const float4*>(bias_a)[c4];
+      if (bias_b) bb = reinterpret_cast<const float4*>(bias_b)[c4];
+    }
+    auto mixv = [&](const float4& x, const float4& y) -> float4 {  // (x + bias_a) + (y + bias_b), or x alone
+      float4 v = x;
+      if (FUSED) {
+        v.x += ba.x; v.y += ba.y; v.z += ba.z; v.w += ba.w;
+        if (two) {
+          float4 u = y;
+          u.x += bb.x; u.y += bb.y; u.z += bb.z; u.w += bb.w;
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+      }
+      return v;
+    };
+    // phase 1: the identity streams of the wave's 4 positions, all in flight together; P to LDS
+    {
+      float4 ia[4], ib[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const size_t q = img + (size_t)(idle ? 0 : h) * W + w0 + min(i, max(cnt - 1, 0));
+        const bool on = i < cnt && cl;
+        ia[i] = on ? a4[q * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ib[i] = (on && two) ? b4[q * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) Ps[half][wave * 4 + i][lane] = mixv(ia[i], ib[i]);
+    }
+    __syncthreads();
+    // phase 2, one position per step (a rolled loop: 45 VGPRs, four workgroups per CU): residual row and box
+    // requested first, the identity term back from LDS, then the taps
+    auto P = [&](const int y, const int x) -> float4 {  // y, x wave-uniform, inside the map
+      const int ly = y - ty * NH_ROWS, lx = x - tx * 4;
+      if ((unsigned)ly < (unsigned)NH_ROWS && (unsigned)lx < 4u) return Ps[half][ly * 4 + lx][lane];
+      if (PAIRED) {
+        const int my = y - oy * NH_ROWS, mx = x - ox * 4;
+        if ((unsigned)my < (unsigned)NH_ROWS && (unsigned)mx < 4u) return Ps[half ^ 1][my * 4 + mx][lane];
+      }
+      const size_t q = img + (size_t)y * W + x;
+      return mixv(a4[q * C4 + c4], two ? b4[q * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f));
+    };
+#pragma unroll 1
+    for (int i = 0; i < cnt; i++) {
+      const size_t q = img + (size_t)h * W + w0 + i;
+      const float* bp = boxes + q * 5;
+      const float bx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bp[0])));
+      const float by = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bp[1])));
+      if (!cl) continue;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_res) r = r4[q * C4 + c4];
+      const Tap tp = make_tap(H, W, W, bx * scale, by * scale);  // sic: row <- x_ctr, column <- y_ctr
+      float4 v = Ps[half][wave * 4 + i][lane];
+      const int y0 = tp.o00 / W, x0 = tp.o00 - y0 * W, y1 = tp.o11 / W, x1 = tp.o11 - y1 * W;
+      const float4 lt = P(y0, x0), rt = P(y0, x1), lb = P(y1, x0), rb = P(y1, x1);
+      float4 sm;
+      sm.x = tp.w1 * lt.x + tp.w2 * rt.x + tp.w3 * lb.x + tp.w4 * rb.x;
+      sm.y = tp.w1 * lt.y + tp.w2 * rt.y + tp.w3 * lb.y + tp.w4 * rb.y;
+      sm.z = tp.w1 * lt.z + tp.w2 * rt.z + tp.w3 * lb.z + tp.w4 * rb.z;
+      sm.w = tp.w1 * lt.w + tp.w2 * rt.w + tp.w3 * lb.w + tp.w4 * rb.w;
+      if (tp.valid) { v.x += sm.x; v.y += sm.y; v.z += sm.z; v.w += sm.w; }
+      if (has_res) { v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w; }
+      o4[q * C4 + c4] = v;
+    }
+    if (c0 + 64 < C4) __syncthreads();  // the next channel block overwrites Ps
+  }
+}
+
 // ----------------------------------------------------------------------------------------
 // "cell" forward kernel (points = 1, W x H a compile-time power-of-two shape).
 // What the plane kernel pays per (n, c) plane besides the plane itself is the per-position sample
@@ -1462,10 +1598,12 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   const bool fused = b || bias_a || bias_b || res;
   // points = 1: the pipelined kernel on 4 x 4 tiles (square maps: transposed tile pairs per workgroup; fr_dbg 1
   // switches the pairing off for A/B runs); points = 5: the simple kernel
-  const int kw = 4;
-  const int tiles_x = (W + kw - 1) / kw, tiles_y = (H + NH_ROWS - 1) / NH_ROWS;
+  const bool occ = points == 1 && g_r3_fr_dbg != 2;  // fr_dbg 2: the register-pipelined kernel (A/B runs)
+  const int kw = 4, kh = NH_ROWS;
+  const int tiles_x = (W + kw - 1) / kw, tiles_y = (H + kh - 1) / kh;
   const bool paired = points == 1 && tiles_x == tiles_y && g_r3_fr_dbg != 1;
-  const int tpi = paired ? tiles_x * (tiles_x + 1) / 2 : tiles_x * tiles_y;
+  const int tpi = !paired ? tiles_x * tiles_y
+                  : occ ? tiles_x * (tiles_x - 1) / 2 + (tiles_x + 1) / 2 : tiles_x * (tiles_x + 1) / 2;
   const long long T = (long long)tpi * N;
   if (T > 0x7fffffffLL) return -1;
   FrProfileSlot* ps = (g_r3_fr_profile && points == 1) ? fr_profile_next(N, H) : nullptr;
@@ -1473,7 +1611,15 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   hipEvent_t e0 = ps ? ps->ev[0] : nullptr, e1 = ps ? ps->ev[3] : nullptr;
   const dim3 grid((unsigned)T), block(paired ? 512 : 256);
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x, tpi, (int)T, out
-  if (points == 1) {
+  if (occ) {
+    if (paired) {
+      if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<true, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+      else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<false, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+    } else {
+      if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<true, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+      else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<false, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+    }
+  } else if (points == 1) {
     if (paired) {
       if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<true, 4, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
       else hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<false, 4, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);

@@ -1,0 +1,33 @@
+import os, sys
+ROOT = "/root/repo"
+for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")): sys.path.insert(0, p)
+import torch
+from r3det import synthetic as syn
+from r3det.ops.feature_refine import fr_module_nhwc, fr_forward_nhwc
+dev = torch.device("cuda")
+N, C, H = 4, 256, 128
+cl = torch.channels_last
+sets = [tuple(torch.randn(N, C, H, H, device=dev).contiguous(memory_format=cl) for _ in range(4)) for _ in range(3)]
+ba, bb = torch.randn(C, device=dev), torch.randn(C, device=dev)
+def run(name, boxes, scale=0.125):
+    for i in range(6):
+        a, b, r, o = sets[i % 3]; fr_module_nhwc(a, b, ba, bb, r, boxes, scale, 1, o)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(30):
+        a, b, r, o = sets[i % 3]; fr_module_nhwc(a, b, ba, bb, r, boxes, scale, 1, o)
+    e.record(); torch.cuda.synchronize()
+    print(f"{name:34s} {s.elapsed_time(e) * 1000 / 30:7.1f} us", flush=True)
+boxes = syn.fr_level_boxes(N, H, H, 8, 3, device=dev)
+run("jittered field (bench)", boxes)
+ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(H, device=dev), indexing="ij")
+reg = torch.zeros(N, H, H, 5, device=dev)
+reg[..., 0] = (xs + 0.5) * 8; reg[..., 1] = (ys + 0.5) * 8; reg[..., 2] = 30; reg[..., 3] = 10
+run("regular field (transposed taps)", reg.view(-1, 5).contiguous())
+sw = reg.clone(); sw[..., 0] = (ys + 0.5) * 8; sw[..., 1] = (xs + 0.5) * 8
+run("swapped centres (taps = own cell)", sw.view(-1, 5).contiguous())
+far = reg.clone(); far[..., 0] = -1000; far[..., 1] = -1000
+run("all samples out of range", far.view(-1, 5).contiguous())
+z = reg.clone(); z[..., 0] = 4; z[..., 1] = 4
+run("all sample the same cell", z.view(-1, 5).contiguous())
