@@ -157,6 +157,24 @@ def batched_rnms(bboxes, scores, inds, nms_thr, class_agnostic=False):
     return torch.cat([bboxes[keep], dets[:, -1:]], -1), keep
 
 
+_RNMS_CONST = {}
+
+
+def _rnms_constants(n, dev):
+    """Candidate rows 0..n-1, all-zero labels, the candidate count and the workspace size for a pool of n boxes:
+    the same for every call of that size, so they are built once (each was a small launch per call)."""
+    key = (n, dev.type, dev.index)
+    hit = _RNMS_CONST.get(key)
+    if hit is None:
+        if len(_RNMS_CONST) > 64:
+            _RNMS_CONST.clear()
+        cap = (n + 63) // 64 * 64
+        hit = (torch.arange(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
+               torch.full((1,), n, dtype=torch.int32, device=dev), int(_C.lib().r3det_mcnms_workspace_bytes(1, cap)))
+        _RNMS_CONST[key] = hit
+    return hit
+
+
 def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic):
     """The same result from ONE library call (r3det_mcnms_v1 with caller-made candidates: stable
     score sort by counting, class offsets, suppression, ascending keep and the gather on the
@@ -172,14 +190,12 @@ def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic):
     L = _C.lib()
     with torch.cuda.device(dev):
         b = bboxes.contiguous()
-        row = torch.arange(n, dtype=torch.int32, device=dev)
-        lab = torch.zeros(n, dtype=torch.int32, device=dev) if class_agnostic else inds.to(torch.int32).contiguous()
+        row, zero_lab, cnt, ws_bytes = _rnms_constants(n, dev)  # read-only inputs of the library: made once per size
+        lab = zero_lab if class_agnostic else inds.to(torch.int32).contiguous()
         sc = scores.contiguous()
-        rank = torch.zeros(n, dtype=torch.int32, device=dev)
-        cnt = torch.full((1,), n, dtype=torch.int32, device=dev)
+        rank = torch.empty(n, dtype=torch.int32, device=dev)    # (zeroed by the library)
         mx = b.max().reshape(1)
         cap = (n + 63) // 64 * 64
-        ws_bytes = int(L.r3det_mcnms_workspace_bytes(1, cap))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         dets = torch.empty((n, 6), dtype=torch.float32, device=dev)
         labels = torch.empty(n, dtype=torch.int64, device=dev)

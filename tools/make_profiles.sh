@@ -56,3 +56,7 @@ bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_fr_nhwc_pmc.txt fr_forw
 IOU_PROF_SHAPE=128x196416 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_iou_pmc.txt iou_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/iou_prof.py > /dev/null
 NMS_PROF_N=8576 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_nms_pmc.txt nms_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/nms_prof.py > /dev/null
 ls -la $O
+# 8. the bench lines themselves (no profiler attached)
+python3 $R/bench.py --steps 30 --warmup 5 > $O/${TAG}_bench.json 2> /dev/null
+python3 $R/bench.py --mode train --steps 10 --warmup 3 > $O/${TAG}_train.json 2> /dev/null
+python3 $R/bench.py --mode rretinanet --steps 20 --warmup 5 > $O/${TAG}_rretinanet.json 2> /dev/null
