@@ -18,9 +18,16 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", 1)))
 
 
+def force_group():
+    """R3DET_FORCE_DIST=1: build the process group (and the DDP wrapper) even for ONE rank, so that the RCCL code
+    path -- init with device_id, all_gather_into_tensor, bucketed gradient all-reduce -- can be run on a single-GPU
+    box (tests/test_gpu_dist_single.py)."""
+    return os.environ.get("R3DET_FORCE_DIST", "0") == "1"
+
+
 def init(backend=None, device=None):
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (force_group() and "MASTER_ADDR" in os.environ)) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
@@ -52,7 +59,7 @@ def pack_detections(dets_list, labels_list, max_per_img=MAX_PER_IMG):
 def gather_detections(packed, counts, dst=0):
     """Gather every rank's padded detections on ``dst``.  Returns (list_of_packed,
     list_of_counts) on dst and (None, None) elsewhere; single-process: passthrough."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_group()):
         return [packed], [counts]
     world, rank = dist.get_world_size(), dist.get_rank()
     if dist.get_backend() == "nccl":
@@ -83,7 +90,7 @@ def unpack_detections(packed, counts):
 
 def max_over_ranks(seconds, device):
     """Timing convention of bench.py: the slowest rank defines the step time."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_group()):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -91,7 +98,7 @@ def max_over_ranks(seconds, device):
 
 
 def barrier(device=None):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force_group()):
         if dist.get_backend() == "nccl" and device is not None:
             dist.barrier(device_ids=[device.index])
         else:

@@ -27,7 +27,8 @@ def wrap_ddp(model, device=None, bucket_cap_mb=BUCKET_CAP_MB):
     loss dict.  Frozen parameters (stem + layer1) take no part; every trainable parameter receives a
     gradient each step (both heads and the FR module are always used), so unused-parameter detection stays
     off.  Single-process (no process group): the model itself."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    from .dist_infer import force_group
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_group()):
         return model
     ids = [device.index] if device is not None and device.type == 'cuda' else None
     return DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
