@@ -47,11 +47,11 @@ const char* r3det_error_string(int code);
 int r3det_rbbox_geo_mat_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
                                 float* out, void* ws, size_t ws_bytes, void* stream);
 
-/* Optional scratch for the three (n1,n2) matrix entry points.  With ws == NULL the matrix is
- * produced by one kernel; with a workspace of at least this many bytes the library runs a
- * streaming kernel + a load-balanced drain kernel over a global queue of the overlapping
- * pairs (several times faster on assignment-shaped inputs).  The size is a worst case
- * (4 bytes per pair); only the part actually used is touched. */
+/* Optional scratch for the three (n1,n2) matrix entry points.  With ws == NULL (or a matrix narrower than
+ * 16384 columns) the matrix is produced by one kernel; with a workspace of at least this many bytes wide
+ * matrices take a streaming kernel + a load-balanced drain kernel over per-tile lists of the pairs that
+ * may overlap (several times faster on assignment-shaped inputs).  About 1 byte per pair; it need not be
+ * initialised. */
 size_t r3det_iou_workspace_bytes(int n1, int n2);
 
 /* rbbox_geo_cuda.vec_iou_iof(rb1, rb2, iof)            rbbox_geo/src/rbbox_geo_cuda.cpp:19-24
@@ -366,10 +366,14 @@ int r3det_convex_sort(const float* pts, const unsigned char* masks, int B, int P
 int r3det_bias_act(float* y, const float* bias, const float* residual, long long outer, int C, long long inner,
                    int relu, void* stream);
 
-/* Kernel-selection knobs for A/B measurements (not part of the reference surface).
- * r3det_set_option("fr_impl", 0 auto | 1 generic | 2 lds-plane | 10 cell), ("iou_impl", ...),
- * ("nms_impl", 0 | 1 tiles), ("nms_qcap", n), ("fr_profile", 0 | 1 every kernel | 2 first start and
- * last stop only), ("fr_dbg", 0 | 1 taps from the table kernel | 2 taps derived in the sampler). */
+/* Kernel-selection knobs for A/B measurements and for the tests of rarely taken paths (not part of the
+ * reference surface).  r3det_set_option("fr_impl", 0 auto | 1 generic | 2 lds-plane | 10 cell),
+ * ("iou_impl", 0 auto | 1 one thread per pair | 2 one-launch tile kernel | 4 stream + drain always),
+ * ("iou_small", columns from which the pipeline runs), ("iou_qcap", n: per-wave survivor capacity, small values
+ * force the dense-tile path), ("iou_dwgs", drain workgroups), ("nms_impl", 0 | 1 tiles), ("nms_qcap", n: entries
+ * per queue region, small values force the redo-tile path), ("fr_profile", 0 | 1 every kernel | 2 first start
+ * and last stop only), ("fr_dbg", NCHW: 0 | 1 taps from the table kernel | 2 taps derived in the sampler;
+ * NHWC: 1 no tile pairing | 2 the register-pipelined kernel). */
 int r3det_set_option(const char* name, int value);
 
 /* Measurement aid for bench.py (not part of the reference surface).  With option "fr_profile" = 1
