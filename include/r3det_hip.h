@@ -174,6 +174,15 @@ int r3det_mcnms_v1(const float* boxes, int B, int n, int K, const int32_t* cand_
                    size_t ws_bytes, float* dets_out, int64_t* labels_out, int64_t* keep_idx_out,
                    int32_t* counts_out, void* stream);
 
+/* batched_rnms(bboxes, scores, inds, nms_thr) (ops/rnms/rnms_wrapper.py:34-69) in one call on its raw inputs:
+ * offset = label * (max over all five box columns + 1) on cx, cy, NMS v1 (IoU > nms_thr), keep ASCENDING.
+ * bboxes (n,5), scores (n), inds (n) int64 or NULL (class-agnostic); dets_out (n,6) = [box, score] of the kept
+ * rows, keep_out (n) int64, kept_out (1) int32; rows beyond kept_out are not written.  n < 65536.
+ * ws: r3det_batched_rnms_workspace_bytes(n), uninitialised. */
+size_t r3det_batched_rnms_workspace_bytes(int n);
+int r3det_batched_rnms(const float* bboxes, const float* scores, const int64_t* inds, int n, float nms_thr, void* ws,
+                       size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, void* stream);
+
 /* The same pipeline for the other nms types of multiclass_nms_rotated (bbox_nms_rotated.py:42-58):
  *   nms_type 1 : batched_rnms, identical to r3det_mcnms_v1.
  *   nms_type 3 : obb_batched_nms (nms_rotated_wrapper.py:23-59): x, y += label * extent with

@@ -1329,6 +1329,87 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// batched_rnms (ops/rnms/rnms_wrapper.py:34-69) as ONE call on raw inputs: the candidate arrays of the batched
+// pipeline (row = 0..n-1, label, count = n) and the wrapper's `bboxes.max()` are produced by one small kernel
+// instead of five framework launches (arange, zeros, full, to(int32), max), then the B = 1 pipeline runs.
+namespace {
+__global__ __launch_bounds__(1024) void rnms_begin_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ inds,
+                                                          int n, int* __restrict__ row, int* __restrict__ lab,
+                                                          int* __restrict__ cnt, float* __restrict__ maxc) {
+  __shared__ float part[16];
+  __shared__ int anynan[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n; i += 1024) {
+    row[i] = i;
+    lab[i] = inds ? (int)inds[i] : 0;
+  }
+  float m = -3.4028235e38f;
+  int bad = 0;
+  for (int i0 = tid; i0 < 5 * n; i0 += 8 * 1024) {  // torch.max over all five columns; NaN propagates as in torch
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = boxes[min(i0 + u * 1024, 5 * n - 1)];  // eight loads in flight
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      bad |= v[u] != v[u];
+      m = fmaxf(m, v[u]);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, d));
+    bad |= __shfl_xor(bad, d);
+  }
+  if (lane == 0) { part[wave] = m; anynan[wave] = bad; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; w++) { m = fmaxf(m, part[w]); bad |= anynan[w]; }
+    maxc[0] = bad ? __builtin_nanf("") : m;
+    cnt[0] = n;
+  }
+}
+
+struct RnmsLayout {
+  int *row, *lab, *rank, *cnt;
+  float* maxc;
+  int64_t* labels_out;
+  void* mc;
+};
+inline size_t rnms_layout(int n, void* ws, RnmsLayout* L) {
+  const int cap = (n + 63) / 64 * 64;
+  size_t off = 0;
+  char* p = (char*)ws;
+  auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
+  char* row = take((size_t)n * 4);
+  char* lab = take((size_t)n * 4);
+  char* rank = take((size_t)n * 4);
+  char* cnt = take(4);
+  char* mx = take(4);
+  char* lo = take((size_t)n * 8);
+  char* mc = take(r3k_mcnms_workspace_bytes(1, cap));
+  if (L) {
+    L->row = (int*)row; L->lab = (int*)lab; L->rank = (int*)rank; L->cnt = (int*)cnt; L->maxc = (float*)mx;
+    L->labels_out = (int64_t*)lo; L->mc = mc;
+  }
+  return off + 256;
+}
+}  // namespace
+
+size_t r3k_batched_rnms_workspace_bytes(int n) { return n <= 0 ? 256 : rnms_layout(n, nullptr, nullptr); }
+
+int r3k_batched_rnms(const float* boxes, const float* scores, const int64_t* inds, int n, float thr, void* ws,
+                     size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, hipStream_t stream) {
+  if (n <= 0 || n >= 65536 || !boxes || !scores || !ws || !dets_out || !keep_out || !kept_out || !(thr >= 0.f)) return -1;
+  if (ws_bytes < r3k_batched_rnms_workspace_bytes(n)) return -3;
+  RnmsLayout L;
+  rnms_layout(n, ws, &L);
+  const int cap = (n + 63) / 64 * 64;
+  hipLaunchKernelGGL(rnms_begin_kernel, dim3(1), dim3(1024), 0, stream, boxes, inds, n, L.row, L.lab, L.cnt, L.maxc);
+  return r3k_mcnms_run(1, boxes, 1, n, 1, L.row, L.lab, scores, L.rank, L.cnt, L.maxc, cap, thr, n, L.mc,
+                       r3k_mcnms_workspace_bytes(1, cap), dets_out, L.labels_out, keep_out, kept_out, stream);
+}
+
+
 int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
                  const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
                  float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,

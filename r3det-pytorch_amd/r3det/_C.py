@@ -28,6 +28,7 @@ SIGNATURES = {
     "r3det_mmcv_nms_rotated": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
     "r3det_mcnms_select": [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "r3det_mcnms_v1": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
+    "r3det_batched_rnms": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp],
     "r3det_mcnms": [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "r3det_polygon_iou": [_vp, _i, _vp, _i, _vp, _vp],
     "r3det_poly_iou_mat": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
@@ -75,6 +76,8 @@ def lib():
         L.r3det_poly_nms_workspace_bytes.restype = _sz
         L.r3det_rbbox_assign_workspace_bytes.argtypes = [_i, _i]
         L.r3det_rbbox_assign_workspace_bytes.restype = _sz
+        L.r3det_batched_rnms_workspace_bytes.argtypes = [_i]
+        L.r3det_batched_rnms_workspace_bytes.restype = _sz
         L.r3det_mcnms_workspace_bytes.argtypes = [_i, _i]
         L.r3det_mcnms_workspace_bytes.restype = _sz
         L.r3det_mcnms_select_workspace_bytes.argtypes = [_i, _i]

@@ -157,29 +157,14 @@ def batched_rnms(bboxes, scores, inds, nms_thr, class_agnostic=False):
     return torch.cat([bboxes[keep], dets[:, -1:]], -1), keep
 
 
-_RNMS_CONST = {}
-
-
-def _rnms_constants(n, dev):
-    """Candidate rows 0..n-1, all-zero labels, the candidate count and the workspace size for a pool of n boxes:
-    the same for every call of that size, so they are built once (each was a small launch per call)."""
-    key = (n, dev.type, dev.index)
-    hit = _RNMS_CONST.get(key)
-    if hit is None:
-        if len(_RNMS_CONST) > 64:
-            _RNMS_CONST.clear()
-        cap = (n + 63) // 64 * 64
-        hit = (torch.arange(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
-               torch.full((1,), n, dtype=torch.int32, device=dev), int(_C.lib().r3det_mcnms_workspace_bytes(1, cap)))
-        _RNMS_CONST[key] = hit
-    return hit
+_RNMS_WS = {}
 
 
 def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic):
-    """The same result from ONE library call (r3det_mcnms_v1 with caller-made candidates: stable
-    score sort by counting, class offsets, suppression, ascending keep and the gather on the
-    device) instead of max / mul / clone / add / cat / sort / rnms / index launches.  None when the
-    input does not qualify (then the op-by-op form above runs)."""
+    """The same result from ONE library call (r3det_batched_rnms: candidate arrays and the wrapper's bboxes.max()
+    from one small kernel, stable score sort by counting, class offsets, suppression, ascending keep and the gather
+    on the device) instead of arange / zeros / max / mul / clone / add / cat / sort / rnms / index launches.  None
+    when the input does not qualify (then the op-by-op form above runs)."""
     if not (isinstance(bboxes, torch.Tensor) and bboxes.is_cuda and bboxes.dtype == torch.float32
             and bboxes.dim() == 2 and bboxes.size(1) == 5 and scores.dtype == torch.float32):
         return None
@@ -190,20 +175,18 @@ def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic):
     L = _C.lib()
     with torch.cuda.device(dev):
         b = bboxes.contiguous()
-        row, zero_lab, cnt, ws_bytes = _rnms_constants(n, dev)  # read-only inputs of the library: made once per size
-        lab = zero_lab if class_agnostic else inds.to(torch.int32).contiguous()
         sc = scores.contiguous()
-        rank = torch.empty(n, dtype=torch.int32, device=dev)    # (zeroed by the library)
-        mx = b.max().reshape(1)
-        cap = (n + 63) // 64 * 64
+        lab = None if class_agnostic else inds.to(torch.int64).contiguous()
+        ws_bytes = _RNMS_WS.get(n)
+        if ws_bytes is None:
+            ws_bytes = _RNMS_WS[n] = int(L.r3det_batched_rnms_workspace_bytes(n))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         dets = torch.empty((n, 6), dtype=torch.float32, device=dev)
-        labels = torch.empty(n, dtype=torch.int64, device=dev)
         keep = torch.empty(n, dtype=torch.int64, device=dev)
         kept = torch.empty(1, dtype=torch.int32, device=dev)
-        _C.check(L.r3det_mcnms_v1(_C.ptr(b), 1, n, 1, _C.ptr(row), _C.ptr(lab), _C.ptr(sc), _C.ptr(rank), _C.ptr(cnt),
-                                  _C.ptr(mx), cap, float(nms_thr), n, _C.ptr(ws), ws_bytes, _C.ptr(dets), _C.ptr(labels),
-                                  _C.ptr(keep), _C.ptr(kept), _C.stream()), "r3det_mcnms_v1")
+        _C.check(L.r3det_batched_rnms(_C.ptr(b), _C.ptr(sc), _C.ptr(lab) if lab is not None else None, n,
+                                      float(nms_thr), _C.ptr(ws), ws_bytes, _C.ptr(dets), _C.ptr(keep), _C.ptr(kept),
+                                      _C.stream()), "r3det_batched_rnms")
         k = int(kept.item())
     return dets[:k], keep[:k]
 
