@@ -10,7 +10,7 @@ top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 rows = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size", "")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size") or "x".join(str(r.get(c, "")) for c in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))))
 rows.sort()
 tend = rows[-1][1]
 sel = [r for r in rows if r[0] >= tend - int(step_ms * 1e6)]
