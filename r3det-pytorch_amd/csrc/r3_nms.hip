@@ -1105,44 +1105,64 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
                                                          const int* __restrict__ counts,
                                                          const int64_t* __restrict__ keep, size_t keep_stride,
                                                          const int32_t* __restrict__ kept_count,
-                                                         uint8_t* __restrict__ flags, int out_cap,
+                                                         int fwords, int out_cap,
                                                          float* __restrict__ dets_out,
                                                          int64_t* __restrict__ labels_out,
                                                          int64_t* __restrict__ keep_idx_out,
                                                          int32_t* __restrict__ counts_out) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
+  // Ascending keep = a bit per candidate, in LDS: set from the reducer's keep list (sorted positions -> candidate
+  // indices), block counts by popcount, wave-shuffle scan, then ONE kept candidate per thread and trip (the earlier
+  // form kept byte flags in global memory, scanned with 20 barriers and gathered up to 9 rows per thread serially).
+  extern __shared__ unsigned long long fbits[];  // ceil(M / 64) words, then as many ints of prefix
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int img = blockIdx.x;
   const int M = counts[img], cnt = kept_count[img];
   const size_t cbase = (size_t)img * cand_stride;
-  flags += img * keep_stride;
   keep += img * keep_stride;
-  for (int i = tid; i < M; i += 1024) flags[i] = 0;
+  const int words = (M + 63) >> 6;
+  int* wpre = reinterpret_cast<int*>(fbits + fwords);
+  for (int w = tid; w < words; w += 1024) fbits[w] = 0ULL;
   __syncthreads();
-  for (int i = tid; i < cnt; i += 1024) flags[sorted_vals[img * keep_stride + keep[i]]] = 1;
+  for (int i = tid; i < cnt; i += 1024) {
+    const int c = sorted_vals[img * keep_stride + keep[i]];
+    atomicOr(&fbits[c >> 6], 1ULL << (c & 63));
+  }
   __syncthreads();
-  const int per = (M + 1023) / 1024;
-  const int lo = min(tid * per, M), hi = min(lo + per, M);
-  int c = 0;
-  for (int i = lo; i < hi; i++) c += flags[i];
-  part[tid] = c;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    const int v = (tid >= off) ? part[tid - off] : 0;
+  int run = 0;
+  for (int w0 = 0; w0 < words; w0 += 1024) {  // (M <= 65472: one trip)
+    const int w = w0 + tid;
+    const int c = w < words ? __popcll(fbits[w]) : 0;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    part[tid] += v;
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int t = wsum[k];
+      if (k < wave) woff += t;
+      tot += t;
+    }
+    if (w < words) wpre[w] = run + woff + incl - c;
+    run += tot;
     __syncthreads();
   }
-  int pos = part[tid] - c;
-  for (int i = lo; i < hi && pos < out_cap; i++) {
-    if (!flags[i]) continue;
+  for (int i = tid; i < M; i += 1024) {
+    const unsigned long long wbits = fbits[i >> 6];
+    if (!((wbits >> (i & 63)) & 1ULL)) continue;
+    const int pos = wpre[i >> 6] + __popcll(wbits & ((1ULL << (i & 63)) - 1ULL));
+    if (pos >= out_cap) continue;
     const float* b = boxes + ((size_t)img * n + cand_row[cbase + i]) * 5;
     float* d = dets_out + ((size_t)img * out_cap + pos) * 6;
     d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
     d[5] = cand_score[cbase + i];
     labels_out[(size_t)img * out_cap + pos] = cand_label[cbase + i];
     if (keep_idx_out) keep_idx_out[(size_t)img * out_cap + pos] = i;  // candidate index, ascending
-    pos++;
   }
   if (tid == 0) counts_out[img] = min(cnt, out_cap);
 }
@@ -1319,8 +1339,8 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
 #undef R3_MC
   launch_reduce(B, L.mask, L.nz, 0, L.cb, nullptr, L.keep, L.kept, bt, stream);
   if (geom == 1)
-    hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label, cand_score,
-                       S, L.svals, counts, L.keep, bt.keep, L.kept, L.flags, out_cap, dets_out, labels_out,
+    hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), (size_t)L.cb * 12, stream, boxes, n, cand_row, cand_label,
+                       cand_score, S, L.svals, counts, L.keep, bt.keep, L.kept, L.cb, out_cap, dets_out, labels_out,
                        keep_idx_out, counts_out);
   else
     hipLaunchKernelGGL(mc_finish_score_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label,
