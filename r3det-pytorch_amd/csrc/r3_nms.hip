@@ -949,11 +949,17 @@ __global__ __launch_bounds__(SEL_T) void mc_write_kernel(const float* __restrict
   }
 }
 
+// also zeroes the overflow masks + side tables of all images (`zero16` 16-byte words from `zero`): one launch less
+// than a memset node in front of the pipeline (a launch that does next to nothing still takes ~4.5 us of the stream)
 __global__ __launch_bounds__(256) void mc_begin_kernel(const int* __restrict__ counts, int cap, int cand_stride,
-                                                       int* __restrict__ cand_rank, int* __restrict__ ccounts) {
+                                                       int* __restrict__ cand_rank, int* __restrict__ ccounts,
+                                                       uint4* __restrict__ zero, size_t zero16) {
   const int img = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
   if (c == 0) ccounts[img] = min(counts[img], cap);
   if (c < cap && c < cand_stride) cand_rank[(size_t)img * cand_stride + c] = 0;
+  const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
+  for (size_t k = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; k < zero16; k += nthreads)
+    zero[k] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // Stable descending sort of an image's candidates by COUNTING: rank(i) = #{j : s_j > s_i or
@@ -1314,8 +1320,12 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   // records out of bounds; and the counts are clamped to cap for the same reason (an image with more
   // candidates than cap is processed as its first cap candidates: the caller sizes cap from the counts,
   // or checks them afterwards and calls again)
-  hipLaunchKernelGGL(mc_begin_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, stream, counts, cap, S, cand_rank,
-                     L.ccounts);
+  // (mask + side tables are adjacent and 256-byte aligned: zeroed by the begin kernel, whose grid is widened so that
+  // the fill runs at memory speed)
+  const int bx = (cap + 255) / 256;
+  const int zx = (int)((L.zero_bytes / 16 / 256 / 8 + B - 1) / B);  // ~8 stores per thread
+  hipLaunchKernelGGL(mc_begin_kernel, dim3(zx > bx ? (zx > 2048 ? 2048 : zx) : bx, B), dim3(256), 0, stream, counts, cap,
+                     S, cand_rank, L.ccounts, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16);
   counts = L.ccounts;
   hipLaunchKernelGGL(mc_rank_kernel, dim3((cap + RK_T - 1) / RK_T, (cap + RK_J - 1) / RK_J, B), dim3(RK_T), 0, stream,
                      cand_score, S, counts, cand_rank);
@@ -1325,7 +1335,6 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   const dim3 dgrid(dblocks, 1, B);
   if (geom == 3)
     hipLaunchKernelGGL(mc_hbb_extent_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, S, counts, L.extent);
-  if (hipMemsetAsync(L.mask, 0, L.zero_bytes, stream) != hipSuccess) return -2;
 #define R3_MC(GEOM, LABEL, SCALE)                                                                                  \
   hipLaunchKernelGGL(mc_prepare_kernel<GEOM>, pgrid, dim3(256), 0, stream, boxes, n, cand_row, cand_label,        \
                      cand_rank, S, counts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.counter, bt.counter);        \
