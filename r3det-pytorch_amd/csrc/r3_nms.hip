@@ -354,8 +354,13 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
                                                         const unsigned* __restrict__ counter,
                                                         const unsigned* __restrict__ redo,
                                                         u64* __restrict__ mask, u64* __restrict__ side, Batch bt) {
-  __shared__ float2 pts[pts_slots<GEOM>() * 256];
-  const LanePts<256> lp{pts + threadIdx.x};
+  // v1: 8 candidate slots per lane in wave-private [slot][lane] regions (half the LDS of the reference's 16 slots:
+  // twice the resident waves; one clip is ~15 us of latency, so an image's pairs should take ONE trip); the rare
+  // pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region (as in the IoU drain)
+  constexpr bool SHORT = GEOM == 1;
+  __shared__ float2 pts[SHORT ? 8 * 256 : pts_slots<GEOM>() * 256];
+  __shared__ unsigned pre[Q_NREG + 1];  // exclusive prefix of the regions' (clamped) fills
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (bt.counts) {
     const int img = blockIdx.z;
     n = bt.counts[img];
@@ -367,7 +372,6 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
     side += img * bt.nz;
   }
   const Side sd = side_tables(side, bt.rows);
-  __shared__ unsigned pre[Q_NREG + 1];  // exclusive prefix of the regions' (clamped) fills
   if (threadIdx.x < 64) {
     const unsigned v = min(counter[threadIdx.x * Q_CSTRIDE], qcap);
     unsigned incl = v;
@@ -380,19 +384,59 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
     if (threadIdx.x == 0) pre[0] = 0;
   }
   __syncthreads();
+  // one pair (i, j), valid or not, per lane: clip, mark, and redo what did not fit 8 slots (wave-level: every lane
+  // of the wave comes through here together)
+  auto clip_pair = [&](const bool valid, const unsigned i, const unsigned j) {
+    bool over = false;
+    if (valid) {
+      const BoxRec A = recs[i];
+      const BoxRec B = recs[j];
+      float v;
+      if (SHORT) {
+        const LanePts<64> lp8{pts + wave * 512 + lane};
+        v = v1_pair_lds<64, 8>(A.f, B.f, false, lp8, &over);
+      } else {
+        const LanePts<256> lp{pts + threadIdx.x};
+        v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
+      }
+      if (!over && v > thr) mark_pair(mask, sd, i, j, cb);
+    }
+    if (SHORT) {
+      unsigned long long m = __ballot(over);
+      while (m) {
+        int src = -1, seen = 0;
+        for (unsigned long long t2 = m; t2; t2 &= t2 - 1) {
+          if (seen == lane) src = __builtin_ctzll(t2);
+          seen++;
+        }
+        const unsigned ii = __shfl(i, src < 0 ? 0 : src), jj = __shfl(j, src < 0 ? 0 : src);
+        if (lane < 32 && src >= 0) {
+          const BoxRec A = recs[ii];
+          const BoxRec B = recs[jj];
+          const LanePts<32> lp16{pts + wave * 512 + lane};
+          const float v = v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, false, lp16);
+          if (v > thr) mark_pair(mask, sd, ii, jj, cb);
+        }
+        for (int k = 0; k < 32 && m; k++) m &= m - 1;
+      }
+    }
+  };
   const unsigned total = pre[Q_NREG];
-  for (unsigned q = blockIdx.x * 256 + threadIdx.x; q < total; q += gridDim.x * 256) {
-    int lo = 0;  // region of entry q: largest lo with pre[lo] <= q
+  for (unsigned qb = blockIdx.x * 256 + wave * 64; qb < total; qb += gridDim.x * 256) {  // wave-uniform trips
+    const unsigned q = qb + lane;
+    bool valid = q < total;
+    unsigned i = 0, j = 0;
+    if (valid) {
+      int lo = 0;  // region of entry q: largest lo with pre[lo] <= q
 #pragma unroll
-    for (int step = Q_NREG / 2; step >= 1; step >>= 1)
-      if (pre[lo + step] <= q) lo += step;
-    const unsigned e = gqueue[(size_t)lo * qcap + (q - pre[lo])];
-    if (e == 0xffffffffu) continue;
-    const unsigned i = e >> 16, j = e & 0xffffu;
-    const BoxRec A = recs[i];
-    const BoxRec B = recs[j];
-    const float v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
-    if (v > thr) mark_pair(mask, sd, i, j, cb);
+      for (int step = Q_NREG / 2; step >= 1; step >>= 1)
+        if (pre[lo + step] <= q) lo += step;
+      const unsigned e = gqueue[(size_t)lo * qcap + (q - pre[lo])];
+      valid = e != 0xffffffffu;
+      i = e >> 16;
+      j = e & 0xffffu;
+    }
+    clip_pair(valid, i, j);
   }
   // redo tiles (dense clusters, exhausted queue): all 64 x 64 pairs, 256 per step, tested with the records
   const unsigned units = counter[Q_REDO] * 16u;
@@ -400,13 +444,13 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
     const unsigned t = redo[u >> 4];
     const unsigned p = (u & 15u) * 256u + threadIdx.x;
     const unsigned i = (t >> 16) * TILE + (p >> 6), j = (t & 0xffffu) * TILE + (p & 63u);
-    if (i >= (unsigned)n || j >= (unsigned)n || i >= j) continue;
-    const BoxRec A = recs[i];
-    const BoxRec B = recs[j];
-    if (boxes_apart(A.f, B.f)) continue;
-    if (GEOM != 1 && LABEL && A.f[7] != B.f[7]) continue;
-    const float v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
-    if (v > thr) mark_pair(mask, sd, i, j, cb);
+    bool valid = i < (unsigned)n && j < (unsigned)n && i < j;
+    if (valid) {
+      const BoxRec A = recs[i];
+      const BoxRec B = recs[j];
+      valid = !boxes_apart(A.f, B.f) && !(GEOM != 1 && LABEL && A.f[7] != B.f[7]);
+    }
+    clip_pair(valid, i, j);
   }
 }
 
@@ -771,7 +815,7 @@ inline size_t layout(int n, void* ws, Layout* L) {
 
 inline int drain_blocks(size_t qcap) {
   size_t blocks = (qcap + 255) / 256;
-  return blocks > 1024 ? 1024 : blocks < 1 ? 1 : (int)blocks;
+  return blocks > 2048 ? 2048 : blocks < 1 ? 1 : (int)blocks;  // (v1: 16 KB of LDS per workgroup, 8 per CU)
 }
 
 // greedy reduction of `images` problems (blockIdx.z)
@@ -1331,7 +1375,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
                      cand_score, S, counts, cand_rank);
   const dim3 pgrid((cap + 255) / 256, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
   int dblocks = drain_blocks(L.qstride);
-  if (dblocks > 256) dblocks = 256;  // B images share the chip
+  if (dblocks > 2048 / B) dblocks = 2048 / B > 0 ? 2048 / B : 1;  // B images share the chip
   const dim3 dgrid(dblocks, 1, B);
   if (geom == 3)
     hipLaunchKernelGGL(mc_hbb_extent_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, S, counts, L.extent);
