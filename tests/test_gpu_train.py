@@ -77,7 +77,11 @@ def test_forward_train_full_size_finite_and_frm_grads_match_generic_backward(mod
     for n in grads[0]:
         scale = float(grads[1][n].abs().max())
         assert scale > 0
-        assert float((grads[0][n] - grads[1][n]).abs().max()) <= 1e-5 * scale, n
+        # two full backward passes: the convolutions' own atomics reorder sums from run to run, so single elements
+        # may differ by a few 1e-5 of the largest gradient (seen once in ~10 runs); the norm-wise bound stays tight
+        d = grads[0][n] - grads[1][n]
+        assert float(d.abs().max()) <= 1e-4 * scale, n
+        assert float(d.norm()) <= 1e-5 * float(grads[1][n].norm()), n
 
 
 def test_targets_on_device_equal_cpu_path():
