@@ -47,8 +47,8 @@ const char* r3det_error_string(int code);
 int r3det_rbbox_geo_mat_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
                                 float* out, void* ws, size_t ws_bytes, void* stream);
 
-/* Optional scratch for the three (n1,n2) matrix entry points.  With ws == NULL (or a matrix narrower than
- * 16384 columns) the matrix is produced by one kernel; with a workspace of at least this many bytes wide
+/* Optional scratch for the three (n1,n2) matrix entry points.  With ws == NULL (or a matrix of at most
+ * 512 columns) the matrix is produced by one kernel; with a workspace of at least this many bytes wider
  * matrices take a streaming kernel + a load-balanced drain kernel over per-tile lists of the pairs that
  * may overlap (several times faster on assignment-shaped inputs).  About 1 byte per pair; it need not be
  * initialised. */

@@ -791,19 +791,20 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
     return 0;
   }
   const unsigned long long pairs = (unsigned long long)n1 * (unsigned long long)n2;
-  // Wide matrices (assignment shapes: few gt rows x tens of thousands of anchors, < 2 % overlapping pairs) take
-  // the stream + drain pipeline.  Everything else is ONE launch (no queue in memory): tiles narrow enough
-  // that the grid still fills the CUs; dense square problems (2000 x 2000: 129 us here, 329 us through the
-  // pipeline, whose drain then carries most pairs) and small ones (1000 x 128: 17 us) both prefer it.
-  const int wide = g_r3_iou_small > 0 ? g_r3_iou_small : 16384;
+  // More than 512 columns: the stream + drain pipeline (needs the workspace).  Narrower matrices: ONE launch of the
+  // tile kernel with one column per lane (no queue in memory).  Measured (tools/iou_crossover.py, random boxes,
+  // 1.8 % overlapping; us: tile kernel / pipeline): 500 x 500: 16 / 26, 2000 x 512: 17 / 26, 128 x 1000: 31 / 25,
+  // 1000 x 1000: 31 / 26, 2000 x 2000: 87 / 30, 4000 x 4000: 96 / 55; dense 2000 x 2000 (40 % overlapping): 364 / 71.
+  const int wide = g_r3_iou_small > 0 ? g_r3_iou_small : 513;
   PipeLayout L;
   const size_t need = pipe_layout(n1, n2, ws, &L);
   const long long tiles = (long long)L.tiles_x * L.tiles_y;
   const bool piped = ws && ws_bytes >= need && tiles <= P_MAX_TILES && g_r3_iou_impl != 2 &&
                      (n2 >= wide || g_r3_iou_impl == 4);
   if (!piped) {
-    if (g_r3_iou_impl == 2 || pairs > 2000000ULL) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);
+    if (g_r3_iou_impl == 2) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);
     else if (n2 <= 512) launch_compact<GEOM, 1, 8>(vec, iof, b1, n1, b2, n2, out, stream);
+    else if (pairs > 2000000ULL) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);  // (no workspace)
     else launch_compact<GEOM, 4, 8>(vec, iof, b1, n1, b2, n2, out, stream);
     return 0;
   }

@@ -113,6 +113,6 @@ extern int g_r3_fr_dbg;    // ablation bits for the persistent forward kernel
 extern int g_r3_iou_impl;  // 0 auto, 1 one thread per pair, 2 one-launch compact kernel, 4 prep + stream + drain pipeline always
 extern int g_r3_iou_dwgs;  // 0 default (2048); > 0: workgroups of the IoU drain kernel (tuning)
 extern int g_r3_iou_qcap;  // 0 default; > 0 caps the IoU pipeline's global pair queue (tests the overflow path)
-extern int g_r3_iou_small; // 0 default (16384); > 0: column count from which the pipeline runs
+extern int g_r3_iou_small; // 0 default (513); > 0: column count from which the pipeline runs
 extern int g_r3_nms_impl;  // 0 auto (queue pipeline), 1 tile kernels
 extern int g_r3_nms_qcap;  // 0 default; > 0 caps the global pair queue (tests the overflow path)
