@@ -183,6 +183,13 @@ size_t r3det_batched_rnms_workspace_bytes(int n);
 int r3det_batched_rnms(const float* bboxes, const float* scores, const int64_t* inds, int n, float nms_thr, void* ws,
                        size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, void* stream);
 
+/* obb_batched_nms(bboxes, scores, inds, nms_thr) (ops/nms_rotated/nms_rotated_wrapper.py:78-98, five-column boxes)
+ * the same way: offset = label * (max - min of the circumscribed horizontal boxes + 1) on cx, cy, boxes with
+ * min(w, h) < 0.001 never kept and never suppress, NMS v3, keep in SCORE order.  Arguments and workspace as
+ * r3det_batched_rnms. */
+int r3det_obb_batched_nms(const float* bboxes, const float* scores, const int64_t* inds, int n, float nms_thr, void* ws,
+                          size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, void* stream);
+
 /* The same pipeline for the other nms types of multiclass_nms_rotated (bbox_nms_rotated.py:42-58):
  *   nms_type 1 : batched_rnms, identical to r3det_mcnms_v1.
  *   nms_type 3 : obb_batched_nms (nms_rotated_wrapper.py:23-59): x, y += label * extent with

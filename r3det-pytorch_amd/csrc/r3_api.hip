@@ -159,7 +159,13 @@ size_t r3det_batched_rnms_workspace_bytes(int n) { return r3k_batched_rnms_works
 int r3det_batched_rnms(const float* bboxes, const float* scores, const int64_t* inds, int n, float nms_thr, void* ws,
                        size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, void* stream) {
   if (n == 0) return R3DET_OK;
-  return rc(r3k_batched_rnms(bboxes, scores, inds, n, nms_thr, ws, ws_bytes, dets_out, keep_out, kept_out, S(stream)));
+  return rc(r3k_batched_nms(1, bboxes, scores, inds, n, nms_thr, ws, ws_bytes, dets_out, keep_out, kept_out, S(stream)));
+}
+
+int r3det_obb_batched_nms(const float* bboxes, const float* scores, const int64_t* inds, int n, float nms_thr, void* ws,
+                          size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, void* stream) {
+  if (n == 0) return R3DET_OK;
+  return rc(r3k_batched_nms(3, bboxes, scores, inds, n, nms_thr, ws, ws_bytes, dets_out, keep_out, kept_out, S(stream)));
 }
 
 size_t r3det_fr_workspace_bytes(int N, int H, int W, int points) {

@@ -33,8 +33,8 @@ int r3k_mcnms_select(const float* boxes, const float* scores, int B, int n, int 
                      float* maxc, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t r3k_mcnms_workspace_bytes(int B, int cap);
 size_t r3k_batched_rnms_workspace_bytes(int n);
-int r3k_batched_rnms(const float* boxes, const float* scores, const int64_t* inds, int n, float thr, void* ws,
-                     size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, hipStream_t stream);
+int r3k_batched_nms(int geom, const float* boxes, const float* scores, const int64_t* inds, int n, float thr, void* ws,
+                    size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, hipStream_t stream);
 int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
                  const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
                  float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,

@@ -1470,15 +1470,18 @@ inline size_t rnms_layout(int n, void* ws, RnmsLayout* L) {
 
 size_t r3k_batched_rnms_workspace_bytes(int n) { return n <= 0 ? 256 : rnms_layout(n, nullptr, nullptr); }
 
-int r3k_batched_rnms(const float* boxes, const float* scores, const int64_t* inds, int n, float thr, void* ws,
-                     size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, hipStream_t stream) {
+// geom 1: batched_rnms (keep ascending); geom 3: obb_batched_nms (nms_rotated_wrapper.py:78-98: offsets from the
+// circumscribed horizontal boxes' extent, thin boxes never kept, keep in score order)
+int r3k_batched_nms(int geom, const float* boxes, const float* scores, const int64_t* inds, int n, float thr, void* ws,
+                    size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, hipStream_t stream) {
+  if (geom != 1 && geom != 3) return -1;
   if (n <= 0 || n >= 65536 || !boxes || !scores || !ws || !dets_out || !keep_out || !kept_out || !(thr >= 0.f)) return -1;
   if (ws_bytes < r3k_batched_rnms_workspace_bytes(n)) return -3;
   RnmsLayout L;
   rnms_layout(n, ws, &L);
   const int cap = (n + 63) / 64 * 64;
   hipLaunchKernelGGL(rnms_begin_kernel, dim3(1), dim3(1024), 0, stream, boxes, inds, n, L.row, L.lab, L.cnt, L.maxc);
-  return r3k_mcnms_run(1, boxes, 1, n, 1, L.row, L.lab, scores, L.rank, L.cnt, L.maxc, cap, thr, n, L.mc,
+  return r3k_mcnms_run(geom, boxes, 1, n, 1, L.row, L.lab, scores, L.rank, L.cnt, L.maxc, cap, thr, n, L.mc,
                        r3k_mcnms_workspace_bytes(1, cap), dets_out, L.labels_out, keep_out, kept_out, stream);
 }
 

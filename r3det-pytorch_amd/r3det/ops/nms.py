@@ -160,7 +160,7 @@ def batched_rnms(bboxes, scores, inds, nms_thr, class_agnostic=False):
 _RNMS_WS = {}
 
 
-def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic):
+def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry="r3det_batched_rnms"):
     """The same result from ONE library call (r3det_batched_rnms: candidate arrays and the wrapper's bboxes.max()
     from one small kernel, stable score sort by counting, class offsets, suppression, ascending keep and the gather
     on the device) instead of arange / zeros / max / mul / clone / add / cat / sort / rnms / index launches.  None
@@ -184,9 +184,9 @@ def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic):
         dets = torch.empty((n, 6), dtype=torch.float32, device=dev)
         keep = torch.empty(n, dtype=torch.int64, device=dev)
         kept = torch.empty(1, dtype=torch.int32, device=dev)
-        _C.check(L.r3det_batched_rnms(_C.ptr(b), _C.ptr(sc), _C.ptr(lab) if lab is not None else None, n,
-                                      float(nms_thr), _C.ptr(ws), ws_bytes, _C.ptr(dets), _C.ptr(keep), _C.ptr(kept),
-                                      _C.stream()), "r3det_batched_rnms")
+        _C.check(getattr(L, entry)(_C.ptr(b), _C.ptr(sc), _C.ptr(lab) if lab is not None else None, n,
+                                   float(nms_thr), _C.ptr(ws), ws_bytes, _C.ptr(dets), _C.ptr(keep), _C.ptr(kept),
+                                   _C.stream()), entry)
         k = int(kept.item())
     return dets[:k], keep[:k]
 
@@ -221,6 +221,10 @@ def obb_nms(dets, iou_thr, device_id=None):
 
 def obb_batched_nms(bboxes, scores, inds, nms_thr, class_agnostic=False):
     """Per-class NMS v3 (nms_rotated_wrapper.py:78-98); offset = label * (hbb extent + 1)."""
+    if isinstance(bboxes, torch.Tensor) and bboxes.dim() == 2 and bboxes.size(-1) == 5:
+        fast = _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, "r3det_obb_batched_nms")
+        if fast is not None:  # (one library call; the op-by-op form below is ~10 launches and a nonzero() sync)
+            return fast
     if class_agnostic:
         shifted = bboxes
     else:

@@ -279,3 +279,29 @@ def test_row_with_more_in_edge_words_than_the_list_holds():
         want = O.nms(O.V1, b, s, 0.1, strict=True, ascending=True)
     assert len(want) == 2
     assert np.array_equal(rnms(dev(d6), 0.1)[1].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("fn_name", ["batched_rnms", "obb_batched_nms"])
+@pytest.mark.parametrize("class_agnostic", [False, True])
+def test_batched_wrappers_one_call_equals_op_by_op(fn_name, class_agnostic, monkeypatch):
+    """r3det_batched_rnms / r3det_obb_batched_nms (the wrapper's whole body in one library call) against the
+    op-by-op form of the same wrapper (max / offsets / cat / sort / nms / index), incl. boxes thinner than 1e-3
+    (dropped by v3) and score ties."""
+    import r3det.ops.nms as M
+    from r3det import synthetic as syn
+    for n, seed in ((1, 3), (65, 4), (700, 5), (3000, 6)):
+        b = syn.rand_rboxes(n, seed, device='cuda')
+        g = torch.Generator().manual_seed(seed)
+        s = torch.rand(n, generator=g).cuda()
+        s[::7] = float(s[0])  # ties
+        lab = torch.randint(0, 15, (n,), generator=g).cuda()
+        if n > 10:
+            b[3, 2] = 5e-4   # thin boxes
+            b[9, 3] = 0.0
+        fn = getattr(M, fn_name)
+        fast_d, fast_k = fn(b, s, lab, 0.1, class_agnostic=class_agnostic)
+        with monkeypatch.context() as mp:
+            mp.setattr(M, "_batched_rnms_device", lambda *a, **k: None)
+            slow_d, slow_k = fn(b, s, lab, 0.1, class_agnostic=class_agnostic)
+        assert torch.equal(fast_k, slow_k), (fn_name, n)
+        assert torch.equal(fast_d, slow_d), (fn_name, n)
