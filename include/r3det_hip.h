@@ -177,7 +177,7 @@ int r3det_mcnms_v1(const float* boxes, int B, int n, int K, const int32_t* cand_
 /* batched_rnms(bboxes, scores, inds, nms_thr) (ops/rnms/rnms_wrapper.py:34-69) in one call on its raw inputs:
  * offset = label * (max over all five box columns + 1) on cx, cy, NMS v1 (IoU > nms_thr), keep ASCENDING.
  * bboxes (n,5), scores (n), inds (n) int64 or NULL (class-agnostic); dets_out (n,6) = [box, score] of the kept
- * rows, keep_out (n) int64, kept_out (1) int32; rows beyond kept_out are not written.  n < 65536.
+ * rows, keep_out (n) int64, kept_out (1) int32; rows beyond kept_out are not written.  n <= 65472.
  * ws: r3det_batched_rnms_workspace_bytes(n), uninitialised. */
 size_t r3det_batched_rnms_workspace_bytes(int n);
 int r3det_batched_rnms(const float* bboxes, const float* scores, const int64_t* inds, int n, float nms_thr, void* ws,

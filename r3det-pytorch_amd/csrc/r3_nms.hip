@@ -1475,7 +1475,7 @@ size_t r3k_batched_rnms_workspace_bytes(int n) { return n <= 0 ? 256 : rnms_layo
 int r3k_batched_nms(int geom, const float* boxes, const float* scores, const int64_t* inds, int n, float thr, void* ws,
                     size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, hipStream_t stream) {
   if (geom != 1 && geom != 3) return -1;
-  if (n <= 0 || n >= 65536 || !boxes || !scores || !ws || !dets_out || !keep_out || !kept_out || !(thr >= 0.f)) return -1;
+  if (n <= 0 || n > 65472 || !boxes || !scores || !ws || !dets_out || !keep_out || !kept_out || !(thr >= 0.f)) return -1;
   if (ws_bytes < r3k_batched_rnms_workspace_bytes(n)) return -3;
   RnmsLayout L;
   rnms_layout(n, ws, &L);

@@ -169,7 +169,7 @@ def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry="r
             and bboxes.dim() == 2 and bboxes.size(1) == 5 and scores.dtype == torch.float32):
         return None
     n = bboxes.size(0)
-    if n == 0 or n >= 16384 or not (nms_thr >= 0):  # (32 768 boxes: 1.53 ms here vs 1.45 ms op by op)
+    if n == 0 or n > 65472 or not (nms_thr >= 0):  # (the library's row capacity, a multiple of 64, stays below 65536)
         return None
     dev = bboxes.device
     L = _C.lib()
