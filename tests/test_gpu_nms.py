@@ -305,3 +305,24 @@ def test_batched_wrappers_one_call_equals_op_by_op(fn_name, class_agnostic, monk
             slow_d, slow_k = fn(b, s, lab, 0.1, class_agnostic=class_agnostic)
         assert torch.equal(fast_k, slow_k), (fn_name, n)
         assert torch.equal(fast_d, slow_d), (fn_name, n)
+
+
+def test_one_call_wrapper_large_pool():
+    """50 000 boxes: the reducer's row-state / bit-set / worklist LDS exceeds the default 64 KB dynamic limit (raised
+    with hipFuncSetAttribute); result against the op-by-op wrapper."""
+    import r3det.ops.nms as M
+    from r3det import synthetic as syn
+    n = 50000
+    b = syn.rand_rboxes(n, 3, device='cuda')
+    b[:, :2] *= 6
+    g = torch.Generator().manual_seed(1)
+    s = torch.rand(n, generator=g).cuda()
+    lab = torch.randint(0, 15, (n,), generator=g).cuda()
+    fd, fk = M.batched_rnms(b, s, lab, 0.1)
+    orig = M._batched_rnms_device
+    M._batched_rnms_device = lambda *a, **k: None
+    try:
+        sd, sk = M.batched_rnms(b, s, lab, 0.1)
+    finally:
+        M._batched_rnms_device = orig
+    assert fk.numel() > 1000 and torch.equal(fk, sk) and torch.equal(fd, sd)
