@@ -262,7 +262,7 @@ int r3det_frm_mix_nchw(const float* a_nhwc, const float* b_nhwc, const float* bi
  * head: A = 1, the previous boxes).  Rows [row_offset, row_offset + min(nms_pre, H*W*A)) of pool_boxes (N, pool_rows,
  * 5) and pool_scores (N, pool_rows, C + 1) are written (last score column = 0, the background column
  * multiclass_nms_rotated drops): exactly the arrays r3det_mcnms_select reads.  max_x / max_y = W_img - 1 / H_img - 1
- * (centre clamp), or negative for none.  nms_pre <= 4096.  ws: r3det_level_pool_workspace_bytes() bytes (0 when
+ * (centre clamp), or negative for none.  nms_pre <= 4096 and, when the level is cut, A*H*W <= 1 000 000.  ws: r3det_level_pool_workspace_bytes() bytes (0 when
  * the level keeps all rows). */
 size_t r3det_level_pool_workspace_bytes(int N, int A, int H, int W, int nms_pre);
 int r3det_level_pool(const float* cls_score, const long long* cls_strides, const float* bbox_pred,

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void pool_all_kernel(const float* __restrict__
 constexpr int PS_T = 1024;      // threads of the select workgroup
 constexpr int PS_KMAX = 4096;   // largest nms_pre (LDS list of 8-byte entries: 32 KB)
 constexpr int PS_U = 4;         // 16-byte key loads in flight per thread and step
+constexpr int PS_CAND = 16384;  // keys kept in LDS after three digits (64 KB)
 
 // The select workgroup is alone on its CU (grid = images): what it can afford is bandwidth, not latency.  Keys are
 // read as uint4, PS_U independent loads per thread and step (a first version read one key per iteration, each
@@ -113,6 +114,8 @@ constexpr int PS_U = 4;         // 16-byte key loads in flight per thread and st
 __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, const unsigned* __restrict__ keys,
                                                            int* __restrict__ sel) {
   __shared__ u64 list[PS_KMAX];          // (key << 32) | ~index  -- larger = earlier
+  __shared__ unsigned cand[PS_CAND];     // keys still in the race after three digits (see below)
+  __shared__ int s_ncand;
   __shared__ int wcnt[PS_T / 64][16];
   __shared__ unsigned s_prefix;
   __shared__ int s_need, s_eq_total;
@@ -126,7 +129,54 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
   // ---- exact k-th largest key: 8 passes over 4-bit digits, most significant first
   unsigned prefix = 0, mask = 0;
   int need = k;
-  for (int shift = 28; shift >= 0; shift -= 4) {
+  // one radix step: the per-thread digit counts `tot` -> the digit that holds the `need`-th largest key
+  auto choose = [&](int (&tot)[16], const int shift) {
+    // wave totals of the 16 digit counts: packed four to a 64-bit word (16-bit fields: a wave's total of one digit
+    // is at most 64 x 144 keys), 24 shuffles instead of 96
+    u64 pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      pk[q] = (u64)(unsigned)tot[4 * q] | ((u64)(unsigned)tot[4 * q + 1] << 16) | ((u64)(unsigned)tot[4 * q + 2] << 32) |
+              ((u64)(unsigned)tot[4 * q + 3] << 48);
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1)
+#pragma unroll
+      for (int q = 0; q < 4; q++) pk[q] += __shfl_xor(pk[q], sft);
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < 16; d++) wcnt[wave][d] = (int)((pk[d >> 2] >> (16 * (d & 3))) & 0xffffULL);
+    }
+    __syncthreads();
+    if (tid < 16) {  // digit totals in parallel (a serial walk over 16 x 16 LDS words cost 7 us per pass)
+      int c = 0;
+#pragma unroll
+      for (int w = 0; w < PS_T / 64; w++) c += wcnt[w][tid];
+      // suffix sums over the digits above this one: the digit whose range contains the `need`-th largest wins
+      int above = 0;
+#pragma unroll
+      for (int d = 1; d < 16; d++) {
+        const int o = __shfl_down(c, d, 16);
+        if (tid + d < 16) above += o;
+      }
+      if (above < need && above + c >= need) {
+        s_prefix = prefix | ((unsigned)tid << shift);
+        s_need = need - above;
+        s_eq_total = c;  // (after the last pass: how many keys equal the threshold)
+      }
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    need = s_need;
+    mask |= 15u << shift;
+    __syncthreads();
+    };
+  // Three digits over all keys (global memory: a pass is bound by what ONE compute unit can load, ~4 us for 147 k
+  // keys), then the keys that still match the prefix -- about 1 % -- are copied to LDS and the remaining five digits
+  // run there (0.3 us each instead of 4).  More than PS_CAND survivors (a flat score distribution): all eight
+  // digits from global memory as before.
+  int shift = 28;
+  for (; shift >= 0; shift -= 4) {
+    if (shift == 16 && s_eq_total <= PS_CAND) break;
     int tot[16];
 #pragma unroll
     for (int d = 0; d < 16; d++) tot[d] = 0;
@@ -160,36 +210,41 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
         lo = hi = 0;
       }
     }
-#pragma unroll
-    for (int d = 0; d < 16; d++) {
-      int v = tot[d];
-#pragma unroll
-      for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
-      if (lane == 0) wcnt[wave][d] = v;
-    }
+    choose(tot, shift);
+  }
+  if (shift >= 0) {
+    if (tid == 0) s_ncand = 0;
     __syncthreads();
-    if (tid < 16) {  // digit totals in parallel (a serial walk over 16 x 16 LDS words cost 7 us per pass)
-      int c = 0;
+    for (int st = 0; st < steps; st++) {
+      uint4 v[PS_U];
 #pragma unroll
-      for (int w = 0; w < PS_T / 64; w++) c += wcnt[w][tid];
-      // suffix sums over the digits above this one: the digit whose range contains the `need`-th largest wins
-      int above = 0;
-#pragma unroll
-      for (int d = 1; d < 16; d++) {
-        const int o = __shfl_down(c, d, 16);
-        if (tid + d < 16) above += o;
+      for (int u = 0; u < PS_U; u++) {
+        const int q = (st * PS_U + u) * PS_T + tid;
+        v[u] = q < L4 ? kn4[q] : make_uint4(0u, 0u, 0u, 0u);
       }
-      if (above < need && above + c >= need) {
-        s_prefix = prefix | ((unsigned)tid << shift);
-        s_need = need - above;
-        s_eq_total = c;  // (after the last pass: how many keys equal the threshold)
+#pragma unroll
+      for (int u = 0; u < PS_U; u++) {
+        const unsigned kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (kk[e] != 0u && (kk[e] & mask) == prefix) cand[atomicAdd(&s_ncand, 1)] = kk[e];
       }
     }
     __syncthreads();
-    prefix = s_prefix;
-    need = s_need;
-    mask |= 15u << shift;
-    __syncthreads();
+    const int ncand = s_ncand;
+    for (; shift >= 0; shift -= 4) {
+      int tot[16];
+#pragma unroll
+      for (int d = 0; d < 16; d++) tot[d] = 0;
+      for (int i = tid; i < ncand; i += PS_T) {  // (<= 16 keys per thread)
+        const unsigned key = cand[i];
+        const bool in = (key & mask) == prefix;
+        const unsigned d = (key >> shift) & 15u;
+#pragma unroll
+        for (int q = 0; q < 16; q++) tot[q] += (in && d == (unsigned)q) ? 1 : 0;
+      }
+      choose(tot, shift);
+    }
   }
   const unsigned T = prefix;  // the k-th largest key; `need` of the keys equal to it are taken (lowest indices)
   const int n_gt = k - need;
@@ -252,8 +307,12 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
   while (P < k) P <<= 1;
   for (int j = k + tid; j < P; j += PS_T) list[j] = 0ULL;
   __syncthreads();
+  // (a stage with stride <= 32 only exchanges inside the 128 elements a wave owns: wave-level ordering is enough
+  // there, so 10 of the 66 stages at P = 2048 take workgroup barriers)
   for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const bool wide = stride > 32;
+      if (wide) __syncthreads();
       for (int t = tid; t < (P >> 1); t += PS_T) {
         const int lo_i = ((t / stride) * stride * 2) + (t % stride);
         const int hi_i = lo_i + stride;
@@ -261,9 +320,15 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
         const u64 x = list[lo_i], y = list[hi_i];
         if ((x < y) == desc) { list[lo_i] = y; list[hi_i] = x; }
       }
-      __syncthreads();
+      if (wide) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
+  __syncthreads();
   // ---- the winners' level rows, in pool order; a second launch spread over the chip decodes them (done here by
   // the one workgroup per image it took 27 us of a 110 us kernel)
   for (int j = tid; j < k; j += PS_T) sel[(size_t)n * k + j] = (int)(0xffffffffu - (unsigned)(list[j] & 0xffffffffULL));
@@ -310,7 +375,7 @@ int r3k_level_pool(const float* cls, const long long* cls_strides, const float* 
                        per_image, A, C, H, W, max_ratio, clamp_x, clamp_y, boxes, scores, pool_rows, row_offset);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
-  if (nms_pre > PS_KMAX) return -1;
+  if (nms_pre > PS_KMAX || L > 1000000) return -1;  // (the select workgroup packs per-wave digit counts in 16 bits)
   if (!ws || ws_bytes < r3k_level_pool_workspace_bytes(N, A, H, W, nms_pre)) return -3;
   if (reinterpret_cast<uintptr_t>(ws) & 15) return -1;
   unsigned* keys = (unsigned*)ws;
