@@ -97,3 +97,32 @@ def test_pool_argument_errors():
     assert L.r3det_level_pool_workspace_bytes(2, 9, 128, 128, 2000) == 2 * 147456 * 4 + 2 * 2000 * 4 + 512
     assert L.r3det_level_pool_workspace_bytes(1, 9, 5, 7, 100) == 316 * 4 + 100 * 4 + 512  # keys padded to a multiple of 4
     assert L.r3det_level_pool_workspace_bytes(2, 1, 8, 8, 2000) == 0
+
+
+def test_pool_flat_scores_large_level_and_largest_k():
+    """147 456 equal scores: every key survives the first three digits, more than the LDS copy holds, so all eight
+    digits run on global memory (the fallback of the select kernel); and nms_pre = 4096, the largest the library
+    takes (two compare-exchange pairs per thread in the sort), on separated scores against torch.topk."""
+    from r3det.ops import fr_boxes
+    N, A, C, H, W, k = 1, 9, 15, 128, 128, 2000
+    cls = torch.zeros(N, A * C, H, W, device='cuda')
+    reg = torch.zeros(N, A * 5, H, W, device='cuda')
+    anchors = torch.rand(H * W * A, 5, device='cuda') * 50 + 5
+    boxes = torch.full((N, k, 5), float('nan'), device='cuda')
+    scores = torch.full((N, k, C + 1), float('nan'), device='cuda')
+    assert fr_boxes.level_pool(cls, reg, anchors, A, C, k, None, boxes, scores, 0) == k
+    assert torch.equal(boxes[0], anchors[:k])
+    k = 4096
+    g = torch.Generator().manual_seed(3)
+    perm = torch.randperm(H * W * A, generator=g)
+    logit = (perm.float() / (H * W * A) * 8 - 4)        # distinct scores
+    cls = torch.full((N, A * C, H, W), -20.0)
+    # class 0 of anchor a at (h, w) carries the logit of row (h * W + w) * A + a
+    cls.view(N, A, C, H, W)[0, :, 0] = logit.view(H, W, A).permute(2, 0, 1)
+    cls = cls.cuda()
+    boxes = torch.full((N, k, 5), float('nan'), device='cuda')
+    scores = torch.full((N, k, C + 1), float('nan'), device='cuda')
+    assert fr_boxes.level_pool(cls, reg, anchors, A, C, k, None, boxes, scores, 0) == k
+    want = torch.topk(logit, k)[1].cuda()
+    assert torch.equal(boxes[0], anchors[want])
+    assert torch.allclose(scores[0, :, 0], torch.sigmoid(logit.cuda()[want]), rtol=0, atol=1e-6)
