@@ -39,25 +39,41 @@ __device__ __forceinline__ unsigned pool_key(float f) {  // monotone: a < b  <=>
 }
 
 // row i of a level <-> (position p = i / A, anchor a = i % A), as the reference's permute + reshape orders them
+constexpr int PH_BINS = 4096;  // histogram of the keys' top 12 bits (= the first three 4-bit digits of the select)
+
+// keys + per-image histogram of their top 12 bits (LDS histogram per workgroup, its non-empty bins added to the
+// global one: scores crowd into a few dozen bins, one global atomic per key would serialise on them).  `hist`
+// zeroed by the caller.
 __global__ __launch_bounds__(256) void pool_keys_kernel(const float* __restrict__ cls, PStrides sc, int A, int C,
-                                                        int H, int W, int Lpad, unsigned* __restrict__ keys) {
+                                                        int H, int W, int Lpad, unsigned* __restrict__ keys,
+                                                        unsigned* __restrict__ hist) {
+  __shared__ unsigned lh[PH_BINS];
   const int HW = H * W, L = HW * A;
   const int n = blockIdx.y;
   const int t = blockIdx.x * 256 + threadIdx.x;
+  for (int b = threadIdx.x; b < PH_BINS; b += 256) lh[b] = 0u;
+  __syncthreads();
   if (t >= L) {
     if (t < Lpad) keys[(size_t)n * Lpad + t] = 0u;  // padding: below every real key (a sigmoid is positive)
-    return;
+  } else {
+    // NCHW heads: neighbouring threads take neighbouring positions of one anchor (coalesced planes);
+    // channels_last heads: neighbouring threads take neighbouring anchors of one position (contiguous logits)
+    int p, a;
+    if (sc.c == 1) { p = t / A; a = t - p * A; }
+    else { a = t / HW; p = t - a * HW; }
+    const int h = p / W, w = p - h * W;
+    const float* cb = cls + n * sc.n + h * sc.h + w * sc.w + (long long)(a * C) * sc.c;
+    float m = -INFINITY;
+    for (int c = 0; c < C; c++) m = fmaxf(m, cb[(long long)c * sc.c]);
+    const unsigned key = pool_key(sigmoidf(m));
+    keys[(size_t)n * Lpad + (size_t)p * A + a] = key;
+    if (key != 0u) atomicAdd(&lh[key >> 20], 1u);
   }
-  // NCHW heads: neighbouring threads take neighbouring positions of one anchor (coalesced planes);
-  // channels_last heads: neighbouring threads take neighbouring anchors of one position (contiguous logits)
-  int p, a;
-  if (sc.c == 1) { p = t / A; a = t - p * A; }
-  else { a = t / HW; p = t - a * HW; }
-  const int h = p / W, w = p - h * W;
-  const float* cb = cls + n * sc.n + h * sc.h + w * sc.w + (long long)(a * C) * sc.c;
-  float m = -INFINITY;
-  for (int c = 0; c < C; c++) m = fmaxf(m, cb[(long long)c * sc.c]);
-  keys[(size_t)n * Lpad + (size_t)p * A + a] = pool_key(sigmoidf(m));
+  __syncthreads();
+  for (int b = threadIdx.x; b < PH_BINS; b += 256) {
+    const unsigned c = lh[b];
+    if (c) atomicAdd(&hist[(size_t)n * PH_BINS + b], c);
+  }
 }
 
 // one pool row: decode + the C class scores of level row i
@@ -112,7 +128,7 @@ constexpr int PS_CAND = 16384;  // keys kept in LDS after three digits (64 KB)
 // read as uint4, PS_U independent loads per thread and step (a first version read one key per iteration, each
 // waiting for the previous: 127 us at 16 384 keys, 500 us at 147 456).
 __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, const unsigned* __restrict__ keys,
-                                                           int* __restrict__ sel) {
+                                                           const unsigned* __restrict__ hist, int* __restrict__ sel) {
   __shared__ u64 list[PS_KMAX];          // (key << 32) | ~index  -- larger = earlier
   __shared__ unsigned cand[PS_CAND];     // keys still in the race after three digits (see below)
   __shared__ int s_ncand;
@@ -170,11 +186,49 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
     mask |= 15u << shift;
     __syncthreads();
     };
-  // Three digits over all keys (global memory: a pass is bound by what ONE compute unit can load, ~4 us for 147 k
-  // keys), then the keys that still match the prefix -- about 1 % -- are copied to LDS and the remaining five digits
-  // run there (0.3 us each instead of 4).  More than PS_CAND survivors (a flat score distribution): all eight
-  // digits from global memory as before.
+  // A pass over all keys costs this ONE compute unit ~20 us at 147 k keys, so: three digits from the histogram,
+  // one pass that copies the keys still matching the prefix -- about 1 % -- to LDS, the remaining five digits there
+  // (0.3 us each), one pass that collects the winners.  More than PS_CAND survivors (a flat score distribution): the
+  // remaining digits from global memory.
   int shift = 28;
+  {
+    // the first three digits come from the histogram the key kernel made (spread over the chip): bins from the top
+    // down until `need` keys are covered.  Thread t owns bins 4t .. 4t+3.
+    const uint4 hb = reinterpret_cast<const uint4*>(hist + (size_t)n * PH_BINS)[tid];
+    const int c4[4] = {(int)hb.x, (int)hb.y, (int)hb.z, (int)hb.w};
+    const int mine = c4[0] + c4[1] + c4[2] + c4[3];
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wcnt[wave][0] = incl;
+    __syncthreads();
+    int before = incl, total = 0;
+#pragma unroll
+    for (int w = 0; w < PS_T / 64; w++) {
+      const int o = wcnt[w][0];
+      if (w < wave) before += o;
+      total += o;
+    }
+    int above = total - before;  // keys in the bins above this thread's
+#pragma unroll
+    for (int b = 3; b >= 0; b--) {
+      if (above < need && above + c4[b] >= need) {
+        s_prefix = (unsigned)(tid * 4 + b) << 20;
+        s_need = need - above;
+        s_eq_total = c4[b];
+      }
+      above += c4[b];
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    need = s_need;
+    mask = 0xfff00000u;
+    shift = 16;
+    __syncthreads();
+  }
   for (; shift >= 0; shift -= 4) {
     if (shift == 16 && s_eq_total <= PS_CAND) break;
     int tot[16];
@@ -353,7 +407,8 @@ __global__ __launch_bounds__(256) void pool_emit_kernel(const float* __restrict_
 size_t r3k_level_pool_workspace_bytes(int N, int A, int H, int W, int nms_pre) {
   if (N <= 0 || A <= 0 || H <= 0 || W <= 0) return 0;
   const long long L = (long long)H * W * A, Lpad = (L + 3) / 4 * 4;
-  return (nms_pre > 0 && nms_pre < L) ? (size_t)N * Lpad * sizeof(unsigned) + (size_t)N * nms_pre * sizeof(int) + 512 : 0;
+  return (nms_pre > 0 && nms_pre < L)
+             ? (size_t)N * Lpad * sizeof(unsigned) + (size_t)N * nms_pre * sizeof(int) + 512 + (size_t)N * PH_BINS * 4 : 0;
 }
 
 int r3k_level_pool(const float* cls, const long long* cls_strides, const float* reg, const long long* reg_strides,
@@ -380,10 +435,12 @@ int r3k_level_pool(const float* cls, const long long* cls_strides, const float* 
   if (reinterpret_cast<uintptr_t>(ws) & 15) return -1;
   unsigned* keys = (unsigned*)ws;
   const int Lpad = (int)((L + 3) / 4 * 4);
-  hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)((Lpad + 255) / 256), N), dim3(256), 0, stream, cls, sc, A, C, H, W,
-                     Lpad, keys);
   int* sel = (int*)((char*)ws + (((size_t)N * Lpad * sizeof(unsigned) + 255) & ~(size_t)255));
-  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, nms_pre, Lpad, keys, sel);
+  unsigned* hist = (unsigned*)((char*)sel + (((size_t)N * nms_pre * sizeof(int) + 255) & ~(size_t)255));
+  if (hipMemsetAsync(hist, 0, (size_t)N * PH_BINS * 4, stream) != hipSuccess) return -2;
+  hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)((Lpad + 255) / 256), N), dim3(256), 0, stream, cls, sc, A, C, H, W,
+                     Lpad, keys, hist);
+  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, nms_pre, Lpad, keys, hist, sel);
   hipLaunchKernelGGL(pool_emit_kernel, dim3((nms_pre + 255) / 256, N), dim3(256), 0, stream, cls, sc, reg, sr, anchors,
                      per_image, A, C, H, W, nms_pre, max_ratio, clamp_x, clamp_y, sel, boxes, scores, pool_rows, row_offset);
   return hipGetLastError() == hipSuccess ? 0 : -2;
