@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void pool_all_kernel(const float* __restrict__
 constexpr int PS_T = 1024;      // threads of the select workgroup
 constexpr int PS_KMAX = 4096;   // largest nms_pre (LDS list of 8-byte entries: 32 KB)
 constexpr int PS_U = 4;         // 16-byte key loads in flight per thread and step
-constexpr int PS_CAND = 16384;  // keys kept in LDS after three digits (64 KB)
+constexpr int PS_CAND = 8192;   // (key, index) entries kept in LDS after three digits (64 KB)
 
 // The select workgroup is alone on its CU (grid = images): what it can afford is bandwidth, not latency.  Keys are
 // read as uint4, PS_U independent loads per thread and step (a first version read one key per iteration, each
@@ -130,7 +130,7 @@ constexpr int PS_CAND = 16384;  // keys kept in LDS after three digits (64 KB)
 __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, const unsigned* __restrict__ keys,
                                                            const unsigned* __restrict__ hist, int* __restrict__ sel) {
   __shared__ u64 list[PS_KMAX];          // (key << 32) | ~index  -- larger = earlier
-  __shared__ unsigned cand[PS_CAND];     // keys still in the race after three digits (see below)
+  __shared__ u64 cand[PS_CAND];          // (key << 32) | ~index of the keys still in the race after three digits
   __shared__ int s_ncand;
   __shared__ int wcnt[PS_T / 64][16];
   __shared__ unsigned s_prefix;
@@ -266,8 +266,12 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
     }
     choose(tot, shift);
   }
-  if (shift >= 0) {
-    if (tid == 0) s_ncand = 0;
+  const bool in_lds = shift >= 0;  // the survivors fit the LDS copy (wave-uniform)
+  const int n_above = k - need;    // keys above the 12-bit prefix: winners whatever the remaining digits say
+  if (in_lds) {
+    // ONE pass over the keys: the winners above the prefix go straight to the output list, the keys matching it
+    // (with their indices) to the LDS copy
+    if (tid == 0) { s_ncand = 0; s_gt = 0; }
     __syncthreads();
     for (int st = 0; st < steps; st++) {
       uint4 v[PS_U];
@@ -279,9 +283,14 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
 #pragma unroll
       for (int u = 0; u < PS_U; u++) {
         const unsigned kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const int q = (st * PS_U + u) * PS_T + tid;
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-          if (kk[e] != 0u && (kk[e] & mask) == prefix) cand[atomicAdd(&s_ncand, 1)] = kk[e];
+        for (int e = 0; e < 4; e++) {
+          const unsigned key = kk[e];
+          const u64 ent = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned)(q * 4 + e));
+          if (key != 0u && (key & mask) == prefix) cand[atomicAdd(&s_ncand, 1)] = ent;
+          else if ((key & mask) > prefix) list[atomicAdd(&s_gt, 1)] = ent;
+        }
       }
     }
     __syncthreads();
@@ -290,8 +299,8 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
       int tot[16];
 #pragma unroll
       for (int d = 0; d < 16; d++) tot[d] = 0;
-      for (int i = tid; i < ncand; i += PS_T) {  // (<= 16 keys per thread)
-        const unsigned key = cand[i];
+      for (int i = tid; i < ncand; i += PS_T) {  // (<= 8 keys per thread)
+        const unsigned key = (unsigned)(cand[i] >> 32);
         const bool in = (key & mask) == prefix;
         const unsigned d = (key >> shift) & 15u;
 #pragma unroll
@@ -305,6 +314,18 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
   const bool all_eq = s_eq_total == need;  // every key equal to T is a winner: no index order needed among them
 
   // ---- collection: keys > T all (any order: sorted below); keys == T all of them, or the first `need` by index
+  if (in_lds) {
+    // the keys above the 12-bit prefix are in the list already (s_gt == n_above); the others come from the LDS copy
+    if (tid == 0) s_eq = 0;
+    __syncthreads();
+    const int ncand = s_ncand;
+    for (int i = tid; i < ncand; i += PS_T) {
+      const u64 ent = cand[i];
+      const unsigned key = (unsigned)(ent >> 32);
+      if (key > T) list[atomicAdd(&s_gt, 1)] = ent;
+      else if (all_eq && key == T) list[n_gt + atomicAdd(&s_eq, 1)] = ent;
+    }
+  } else {
   if (tid == 0) { s_gt = 0; s_eq = 0; }
   __syncthreads();
   for (int st = 0; st < steps; st++) {
@@ -327,6 +348,7 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
       }
     }
   }
+  }  // (collection from global memory)
   if (!all_eq) {
     // ties straddle the threshold: the first `need` keys equal to T in index order.  Every thread counts the
     // equal keys of a contiguous index range, an exclusive scan turns the counts into ranks.
