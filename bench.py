@@ -476,7 +476,7 @@ def main():
                                    "to ~1 % candidates",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "nms_type": "v1",
                        "parallelism": f"image-parallel x{world}, all_gather of detections"},
-            "roofline": {"bound": "hbm", "kernel": "fr_forward_nhwc_pipe<true,4> = the FeatureRefineModule tail at level 0 "
+            "roofline": {"bound": "hbm", "kernel": "fr_forward_nhwc_occ<true,true> = the FeatureRefineModule tail at level 0 "
                                                    "(4x256x128x128, channels_last): (conv_a + bias) + (conv_b + bias), sampler, "
                                                    "residual in one launch, 3 reads + 1 write per element; duration = the "
                                                    "launch's own start/stop HIP events (hipExtLaunchKernelGGL), timed steps",
