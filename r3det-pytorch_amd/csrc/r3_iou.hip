@@ -639,28 +639,66 @@ __global__ __launch_bounds__(T_THREADS) void assign_drain_kernel(const BoxRec* _
                                                                  const unsigned* __restrict__ counter,
                                                                  float* __restrict__ qiou, u64k* __restrict__ rowkey,
                                                                  u64k* __restrict__ colkey, int n1_lds) {
-  __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
+  // v1: the 8-slot clip of the IoU drain (wave-private [slot][lane] regions, 16 KB per workgroup instead of 32: twice
+  // the resident waves; a pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region)
+  constexpr bool SHORT = GEOM == 1;
+  __shared__ float2 pts[SHORT ? 8 * T_THREADS : pts_slots<GEOM>() * T_THREADS];
   extern __shared__ __attribute__((aligned(16))) u64k rowbest[];  // n1_lds entries (0 = none): per-workgroup row maxima
-  const LanePts<T_THREADS> lp{pts + threadIdx.x};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned total = *counter;
   for (int i = threadIdx.x; i < n1_lds; i += T_THREADS) rowbest[i] = 0;
   __syncthreads();
-  for (unsigned q = blockIdx.x * T_THREADS + threadIdx.x; q < total; q += gridDim.x * T_THREADS) {
-    const unsigned e = gqueue[q];
-    const unsigned r = e / (unsigned)n2;
-    const unsigned c = e - r * (unsigned)n2;
-    const BoxRec A = recsA[r];
-    const BoxRec B = recsB[c];
-    const float v = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, false, lp);
+  // The few hundred gt rows take ~5 k updates each: global atomics on 128 addresses serialise (0.6 ms).  Rows are
+  // reduced in LDS first and flushed once per workgroup; columns (anchors) are many and rarely contended: look (the
+  // keys only grow), then atomicMax.
+  auto record = [&](const unsigned q, const unsigned r, const unsigned c, const float v) {
     qiou[q] = v;
     if (v > 0.f) {
-      // The few hundred gt rows take ~5 k updates each: global atomics on 128 addresses serialise
-      // (0.6 ms).  Rows are reduced in LDS first and flushed once per workgroup; columns (anchors)
-      // are many and rarely contended: look (the keys only grow), then atomicMax.
       const u64k kc = pack_key(v, r), kr = pack_key(v, c);
       if (kc > __builtin_nontemporal_load(&colkey[c])) atomicMax(&colkey[c], kc);
       if ((int)r < n1_lds) atomicMax(&rowbest[r], kr);
       else if (kr > __builtin_nontemporal_load(&rowkey[r])) atomicMax(&rowkey[r], kr);
+    }
+  };
+  for (unsigned qb = blockIdx.x * T_THREADS + wave * 64; qb < total; qb += gridDim.x * T_THREADS) {  // wave-uniform
+    const unsigned q = qb + lane;
+    const bool valid = q < total;
+    unsigned r = 0, c = 0;
+    bool over = false;
+    if (valid) {
+      const unsigned e = gqueue[q];
+      r = e / (unsigned)n2;
+      c = e - r * (unsigned)n2;
+      const BoxRec A = recsA[r];
+      const BoxRec B = recsB[c];
+      float v;
+      if (SHORT) {
+        const LanePts<64> lp8{pts + wave * 512 + lane};
+        v = v1_pair_lds<64, 8>(A.f, B.f, false, lp8, &over);
+      } else {
+        const LanePts<T_THREADS> lp{pts + threadIdx.x};
+        v = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, false, lp);
+      }
+      if (!over) record(q, r, c, v);
+    }
+    if (SHORT) {
+      unsigned long long m = __ballot(over);
+      while (m) {  // rare: lane k < 32 redoes the k-th flagged pair with the full 16 slots
+        int src = -1, seen = 0;
+        for (unsigned long long t2 = m; t2; t2 &= t2 - 1) {
+          if (seen == lane) src = __builtin_ctzll(t2);
+          seen++;
+        }
+        const int sl = src < 0 ? 0 : src;
+        const unsigned qq = __shfl(q, sl), rr = __shfl(r, sl), cc = __shfl(c, sl);
+        if (lane < 32 && src >= 0) {
+          const BoxRec A = recsA[rr];
+          const BoxRec B = recsB[cc];
+          const LanePts<32> lp16{pts + wave * 512 + lane};
+          record(qq, rr, cc, v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, false, lp16));
+        }
+        for (int k = 0; k < 32 && m; k++) m &= m - 1;
+      }
     }
   }
   __syncthreads();
@@ -887,9 +925,12 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
                      (float*)nullptr, L.recsA, L.recsB, L.gqueue, L.counter);
   unsigned long long pairs = (unsigned long long)n1 * n2;
   int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
-  if (blocks > 1024) blocks = 1024;
-  const int n1_lds = n1 < 2048 ? n1 : 2048;  // rows reduced in LDS (16 KB); the rest goes straight to global
-  hipLaunchKernelGGL(assign_drain_kernel<GEOM>, dim3(blocks < 512 ? blocks : 512), dim3(T_THREADS),
+  if (blocks > 2048) blocks = 2048;
+  // rows reduced in LDS (16 KB); the rest goes straight to global.  (Look + global atomicMax for the rows as for the
+  // columns: 243 us instead of 55 -- a few hundred addresses take every pair's update.)
+  const int n1_lds = n1 < 2048 ? n1 : 2048;
+  const int dmax = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : 2048;  // (measured: 512 -> 62 us, 1024 -> 58, 1536 -> 55, 2048 -> 53)
+  hipLaunchKernelGGL(assign_drain_kernel<GEOM>, dim3(blocks < dmax ? blocks : dmax), dim3(T_THREADS),
                      (size_t)n1_lds * sizeof(u64k), stream, L.recsA, L.recsB, n2, L.gqueue, L.counter, L.qiou, L.rowkey,
                      L.colkey, n1_lds);
   if (match_low)
