@@ -648,6 +648,8 @@ __global__ __launch_bounds__(T_THREADS) void assign_drain_kernel(const BoxRec* _
   const unsigned total = *counter;
   for (int i = threadIdx.x; i < n1_lds; i += T_THREADS) rowbest[i] = 0;
   __syncthreads();
+  // (Measured: without the key updates below this kernel takes 27 us instead of 52 -- the ~0.37 M device-scope
+  // atomicMax on the column keys execute memory-side, ~12 ns each per channel.)
   // The few hundred gt rows take ~5 k updates each: global atomics on 128 addresses serialise (0.6 ms).  Rows are
   // reduced in LDS first and flushed once per workgroup; columns (anchors) are many and rarely contended: look (the
   // keys only grow), then atomicMax.
