@@ -166,7 +166,9 @@ def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry="r
     on the device) instead of arange / zeros / max / mul / clone / add / cat / sort / rnms / index launches.  None
     when the input does not qualify (then the op-by-op form above runs)."""
     if not (isinstance(bboxes, torch.Tensor) and bboxes.is_cuda and bboxes.dtype == torch.float32
-            and bboxes.dim() == 2 and bboxes.size(1) == 5 and scores.dtype == torch.float32):
+            and bboxes.dim() == 2 and bboxes.size(1) == 5 and isinstance(scores, torch.Tensor)
+            and scores.dtype == torch.float32 and scores.device == bboxes.device
+            and (class_agnostic or (isinstance(inds, torch.Tensor) and inds.device == bboxes.device))):
         return None
     n = bboxes.size(0)
     if n == 0 or n > 65472 or not (nms_thr >= 0):  # (the library's row capacity, a multiple of 64, stays below 65536)
