@@ -1429,13 +1429,6 @@ inline int plane_cpb(int C, int H, int W) {
   return cpb < 1 ? 0 : cpb;
 }
 
-inline int ilog2_exact(int v) {
-  if (v <= 0 || (v & (v - 1))) return -1;
-  int l = 0;
-  while ((1 << l) < v) l++;
-  return l;
-}
-
 inline int cu_count() {
   static int n_cu = 0;
   if (n_cu == 0) {

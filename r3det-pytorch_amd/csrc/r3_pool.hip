@@ -267,7 +267,7 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
     choose(tot, shift);
   }
   const bool in_lds = shift >= 0;  // the survivors fit the LDS copy (wave-uniform)
-  const int n_above = k - need;    // keys above the 12-bit prefix: winners whatever the remaining digits say
+  // (k - need keys lie above the 12-bit prefix: winners whatever the remaining digits say)
   if (in_lds) {
     // ONE pass over the keys: the winners above the prefix go straight to the output list, the keys matching it
     // (with their indices) to the LDS copy
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
 
   // ---- collection: keys > T all (any order: sorted below); keys == T all of them, or the first `need` by index
   if (in_lds) {
-    // the keys above the 12-bit prefix are in the list already (s_gt == n_above); the others come from the LDS copy
+    // the keys above the 12-bit prefix are in the list already; the others come from the LDS copy
     if (tid == 0) s_eq = 0;
     __syncthreads();
     const int ncand = s_ncand;
