@@ -66,7 +66,14 @@ class MaxIoUAssigner:
         geom = self._fusable(bboxes, gt_bboxes, gt_bboxes_ignore)
         if geom is None:
             overlaps = self.iou_calculator(gt_bboxes, bboxes)
-            # (gt_bboxes_ignore / ignore_iof_thr: disabled in the rotated configs, ignore_iof_thr = -1)
+            # ignore regions (mmdet 2.19 max_iou_assigner.py, restated; off in the rotated configs: ignore_iof_thr = -1)
+            if (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0
+                    and bboxes.numel() > 0):
+                if self.ignore_wrt_candidates:
+                    ign = self.iou_calculator(bboxes, gt_bboxes_ignore, mode='iof').max(dim=1)[0]
+                else:
+                    ign = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)[0]
+                overlaps[:, ign > self.ignore_iof_thr] = -1
             return self.assign_wrt_overlaps(overlaps, gt_labels)
         b = _C.need_hip(bboxes[:, :5].contiguous().float(), "bboxes")
         g = _C.need_hip(gt_bboxes[:, :5].contiguous().float(), "gt_bboxes")

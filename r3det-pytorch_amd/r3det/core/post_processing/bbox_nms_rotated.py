@@ -33,6 +33,17 @@ class CapacityHint:
         with self._lock:
             self._last[key] = value
 
+    # A hint is a cache, not state: a copy (copy.deepcopy of the owning module for an EMA / SWA twin, torch.save of
+    # the whole module, pickling into a worker process) starts empty with a lock of its own.
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
+    def __deepcopy__(self, memo):
+        return CapacityHint()
+
 
 def _get(nms, key):
     return nms[key] if isinstance(nms, dict) else getattr(nms, key)

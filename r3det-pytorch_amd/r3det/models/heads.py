@@ -122,7 +122,7 @@ class RRetinaHead(nn.Module):
                 [tuple(fs) for fs in featmap_sizes], meta['pad_shape'], device=device)))
         return [lvl for _ in img_metas], flags
 
-    def _targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta):
+    def _targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta, gt_bboxes_ignore=None):
         """rotate_anchor_head.py:172-277 for one image, PseudoSampler configuration: every assigned
         anchor is a positive, every anchor with gt_inds == 0 a negative.  Returns labels (n,),
         label_weights (n,), bbox_targets (n, 5), bbox_weights (n, 5), number of positives (0-dim)."""
@@ -132,13 +132,15 @@ class RRetinaHead(nn.Module):
         if valid_flags is not None or border >= 0:
             vf = valid_flags if valid_flags is not None else flat_anchors.new_ones(n_all, dtype=torch.bool)
             inside = ranchor_inside_flags(flat_anchors, vf, img_meta['img_shape'][:2], border)
+            if not bool(inside.any()):
+                return None  # rotate_anchor_head.py:215-216 (only reached with partial valid flags / a border)
         anchors = flat_anchors if inside is None else flat_anchors[inside]
         gt_bboxes = gt_bboxes.to(flat_anchors.dtype)
         gt_assign = gt_bboxes
         if self.assign_by_circumhbbox is not None and gt_bboxes.size(0) > 0:
             gt_assign = obb2hbb(gt_bboxes, self.assign_by_circumhbbox)
         # (labels are derived below with masks: passing gt_labels would make the assigner run nonzero(), a host sync)
-        res = self.assigner.assign(anchors, gt_assign, None, None)
+        res = self.assigner.assign(anchors, gt_assign, gt_bboxes_ignore, None)
         gt_inds = res.gt_inds
         pos = gt_inds > 0
         n = anchors.size(0)
@@ -164,12 +166,19 @@ class RRetinaHead(nn.Module):
             bbox_targets, bbox_weights = unmap(bbox_targets), unmap(bbox_weights)
         return labels, label_weights, bbox_targets, bbox_weights, pos.sum()
 
-    def get_targets(self, anchor_list, valid_flag_list, gt_bboxes_list, img_metas, gt_labels_list):
+    def get_targets(self, anchor_list, valid_flag_list, gt_bboxes_list, img_metas, gt_labels_list,
+                    gt_bboxes_ignore_list=None):
         """rotate_anchor_head.py:279-377: per level (N, n_l[, 5]) targets and
-        ``num_total_pos = sum_i max(#pos_i, 1)`` (a device scalar)."""
+        ``num_total_pos = sum_i max(#pos_i, 1)`` (a device scalar); None when an image has no anchor inside
+        (:352-353)."""
         num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        if gt_bboxes_ignore_list is None:
+            gt_bboxes_ignore_list = [None] * len(img_metas)
         per_img = [self._targets_single(torch.cat(anchor_list[i]), valid_flag_list[i], gt_bboxes_list[i],
-                                        gt_labels_list[i], img_metas[i]) for i in range(len(img_metas))]
+                                        gt_labels_list[i], img_metas[i], gt_bboxes_ignore_list[i])
+                   for i in range(len(img_metas))]
+        if any(r is None for r in per_img):
+            return None
         labels, label_w, bbox_t, bbox_w = (torch.stack([r[k] for r in per_img]) for k in range(4))
         num_total_pos = torch.stack([r[4] for r in per_img]).clamp(min=1).sum()
         split = lambda t: list(t.split(num_level_anchors, dim=1))  # noqa: E731  (images_to_levels)
@@ -191,8 +200,10 @@ class RRetinaHead(nn.Module):
         featmap_sizes = [f.shape[-2:] for f in cls_scores]
         assert len(featmap_sizes) == len(self.strides)
         anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, cls_scores[0].device)
-        labels, label_w, bbox_t, bbox_w, num_total_pos = self.get_targets(anchor_list, valid_flag_list, gt_bboxes,
-                                                                        img_metas, gt_labels)
+        targets = self.get_targets(anchor_list, valid_flag_list, gt_bboxes, img_metas, gt_labels, gt_bboxes_ignore)
+        if targets is None:
+            return None  # rotate_anchor_head.py:469-470
+        labels, label_w, bbox_t, bbox_w, num_total_pos = targets
         avg = num_total_pos.to(torch.float32)
         out = [self.loss_single(c.float(), r.float(), la, lw, bt, bw, avg)
                for c, r, la, lw, bt, bw in zip(cls_scores, bbox_preds, labels, label_w, bbox_t, bbox_w)]
@@ -249,7 +260,8 @@ class RRetinaHead(nn.Module):
         torch form is ``decode_bboxes_torch``."""
         cfg = cfg or self.test_cfg
         nms_pre = cfg.get('nms_pre', -1)
-        if not cls_scores[0].is_cuda or cls_scores[0].dtype != torch.float32 or nms_pre > 4096:
+        nms_pre = -1 if nms_pre is None else int(nms_pre)
+        if not cls_scores[0].is_cuda or cls_scores[0].dtype != torch.float32:
             return self.decode_bboxes_torch(cls_scores, bbox_preds, img_shape, cfg, rois)
         N = cls_scores[0].size(0)
         A, C = self.num_anchors, self.cls_out_channels
@@ -265,33 +277,47 @@ class RRetinaHead(nn.Module):
         scores = torch.empty((N, n, C + 1), dtype=torch.float32, device=dev)
         off = 0
         for cls, reg, anc, r in zip(cls_scores, bbox_preds, lvl_anchors, rows):
-            fr_boxes.level_pool(cls, reg, anc, A, C, nms_pre, img_shape, boxes, scores, off)
+            L = cls.shape[-2] * cls.shape[-1] * A
+            # the library's top-k holds at most POOL_MAX_K winners and POOL_MAX_ROWS keys per image and level
+            # (r3_pool.hip); a level beyond that takes the op-by-op form, level by level (a 4096^2 test image at
+            # stride 8 has 2.36 M rows)
+            if 0 < nms_pre < L and (nms_pre > fr_boxes.POOL_MAX_K or L > fr_boxes.POOL_MAX_ROWS):
+                b, sc = self._level_torch(cls, reg, anc if anc.dim() == 3 else anc[None].expand(N, -1, -1), nms_pre,
+                                          img_shape)
+                boxes[:, off:off + r] = b
+                scores[:, off:off + r, :C] = sc
+                scores[:, off:off + r, C] = 0
+            else:
+                fr_boxes.level_pool(cls, reg, anc, A, C, nms_pre, img_shape, boxes, scores, off)
             off += r
         return boxes, scores
+
+    def _level_torch(self, cls, reg, anc, nms_pre, img_shape):
+        """One level of rotate_anchor_head.py:626-660 for the whole batch, op by op: (N, r, 5), (N, r, C)."""
+        N, C = cls.size(0), self.cls_out_channels
+        scores = cls.permute(0, 2, 3, 1).reshape(N, -1, C).sigmoid()
+        reg = reg.permute(0, 2, 3, 1).reshape(N, -1, 5)
+        if 0 < nms_pre < scores.shape[1]:
+            top = scores.max(dim=2)[0].topk(nms_pre, dim=1)[1]             # (N, nms_pre)
+            anc = anc.gather(1, top[..., None].expand(-1, -1, 5))
+            reg = reg.gather(1, top[..., None].expand(-1, -1, 5))
+            scores = scores.gather(1, top[..., None].expand(-1, -1, C))
+        return delta2bbox_v1(anc, reg, max_shape=img_shape), scores
 
     def decode_bboxes_torch(self, cls_scores, bbox_preds, img_shape, cfg=None, rois=None):
         cfg = cfg or self.test_cfg
         N = cls_scores[0].size(0)
-        A, C = self.num_anchors, self.cls_out_channels
         if rois is None:
             anchors = self.anchors([c.shape[-2:] for c in cls_scores], cls_scores[0].device)
             lvl_anchors = [a[None].expand(N, -1, -1) for a in anchors]
         else:
             lvl_anchors = [torch.stack([rois[i][l] for i in range(N)]) for l in range(len(cls_scores))]
         nms_pre = cfg.get('nms_pre', -1)
-        boxes_l, scores_l = [], []
-        for cls, reg, anc in zip(cls_scores, bbox_preds, lvl_anchors):
-            scores = cls.permute(0, 2, 3, 1).reshape(N, -1, C).sigmoid()
-            reg = reg.permute(0, 2, 3, 1).reshape(N, -1, 5)
-            if 0 < nms_pre < scores.shape[1]:
-                top = scores.max(dim=2)[0].topk(nms_pre, dim=1)[1]             # (N, nms_pre)
-                anc = anc.gather(1, top[..., None].expand(-1, -1, 5))
-                reg = reg.gather(1, top[..., None].expand(-1, -1, 5))
-                scores = scores.gather(1, top[..., None].expand(-1, -1, C))
-            boxes_l.append(delta2bbox_v1(anc, reg, max_shape=img_shape))
-            scores_l.append(scores)
-        boxes = torch.cat(boxes_l, 1)
-        scores = torch.cat(scores_l, 1)
+        nms_pre = -1 if nms_pre is None else int(nms_pre)
+        per = [self._level_torch(cls, reg, anc, nms_pre, img_shape)
+               for cls, reg, anc in zip(cls_scores, bbox_preds, lvl_anchors)]
+        boxes = torch.cat([p[0] for p in per], 1)
+        scores = torch.cat([p[1] for p in per], 1)
         scores = torch.cat([scores, scores.new_zeros(N, scores.shape[1], 1)], 2)  # dummy background
         return boxes, scores
 

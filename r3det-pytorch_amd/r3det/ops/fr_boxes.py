@@ -13,6 +13,8 @@ import torch
 from .. import _C
 
 MAX_RATIO = abs(math.log(16 / 1000))  # delta2bbox_v1: wh_ratio_clip = 16 / 1000
+POOL_MAX_K = 4096          # r3det_level_pool: largest top-k (the select kernel's LDS sort)
+POOL_MAX_ROWS = 1_000_000  # ... and most rows per image and level when a top-k is needed (csrc/r3_pool.hip)
 
 
 def _strides(t):

@@ -87,23 +87,26 @@ def ml_nms_rotated(dets, scores, labels, iou_threshold):
 # values only: with or without labels the suppression is CLASS-AGNOSTIC.  Restated from memory of the
 # mmcv sources (they are not under the reference tree; parity UNPINNED).  True = use the label
 # guard of the in-tree ml_nms_rotated instead (boxes of different labels never suppress each other).
+# This constant is only the DEFAULT of ``nms_rotated(..., label_guard=None)``; pass the keyword to choose per call.
 MMCV_LABEL_GUARD = False
 
 
-def nms_rotated(dets, scores, iou_threshold, labels=None):
+def nms_rotated(dets, scores, iou_threshold, labels=None, label_guard=None):
     """Stand-in for ``mmcv.ops.nms_rotated``: returns (cat(dets[keep], scores[keep]), keep), keep in
     score order.
 
     mmcv is outside the reference tree (pinned only as 1.3.15..1.5.0); semantics restated from
     its call site bbox_nms_rotated.py:86-95, the in-tree ml_nms_rotated sources (geometry) and the
-    note on ``MMCV_LABEL_GUARD`` above (labels are accepted and, by default, have no effect).
+    note on ``MMCV_LABEL_GUARD`` above: labels are accepted and, by default, have no effect -- UNVERIFIED
+    against a real mmcv build.  ``label_guard=True`` (not an mmcv keyword) makes boxes of different
+    labels never suppress each other, as the in-tree ml_nms_rotated does; ``None`` takes the module default.
     """
     if dets.shape[0] == 0:
         return dets, None
     dets_c = _C.need_hip(dets.contiguous(), "dets")
     scores_c = _C.need_hip(scores.contiguous(), "scores")
     lab = None
-    if labels is not None and MMCV_LABEL_GUARD:
+    if labels is not None and (MMCV_LABEL_GUARD if label_guard is None else label_guard):
         lab = labels.to(device=dets.device, dtype=torch.int64).contiguous()
     n = dets_c.size(0)
     order = _order(scores_c)
@@ -158,6 +161,10 @@ def batched_rnms(bboxes, scores, inds, nms_thr, class_agnostic=False):
 
 
 _RNMS_WS = {}
+# Largest pool the one-call forms take.  The library holds up to 65 472 rows, but its workspace carries a dense
+# n x n/64 suppressor mask (540 MB, zero-filled per call, at 65 k rows): beyond 16 384 rows (33 MB) the op-by-op
+# wrapper is the faster form (measured at 32 768 in round 2), so the crossover stays there.
+FAST_MAX_N = 16384
 
 
 def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry="r3det_batched_rnms"):
@@ -168,10 +175,11 @@ def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry="r
     if not (isinstance(bboxes, torch.Tensor) and bboxes.is_cuda and bboxes.dtype == torch.float32
             and bboxes.dim() == 2 and bboxes.size(1) == 5 and isinstance(scores, torch.Tensor)
             and scores.dtype == torch.float32 and scores.device == bboxes.device
-            and (class_agnostic or (isinstance(inds, torch.Tensor) and inds.device == bboxes.device))):
-        return None
+            and (class_agnostic or (isinstance(inds, torch.Tensor) and inds.device == bboxes.device
+                                    and not inds.dtype.is_floating_point and inds.dtype != torch.bool))):
+        return None  # (float ``inds`` multiply the offset as floats in the reference: op-by-op form)
     n = bboxes.size(0)
-    if n == 0 or n > 65472 or not (nms_thr >= 0):  # (the library's row capacity, a multiple of 64, stays below 65536)
+    if n == 0 or n > min(FAST_MAX_N, 65472) or not (nms_thr >= 0):  # (65 472 = the library's row capacity)
         return None
     dev = bboxes.device
     L = _C.lib()

@@ -61,3 +61,39 @@ def fr_boxes(N, H, W, stride, seed, jitter=0.1, adversarial=False):
     b[:, 3] = r.uniform(2 * stride, 8 * stride, n)
     b[:, 4] = r.uniform(-np.pi / 2, 0, n)
     return b.astype(np.float32)
+
+
+def assert_pool_matches_golden(got_boxes, got_scores, want_boxes, want_scores, level_rows, tag=""):
+    """Compare one image's pre-NMS pool (n, 5) / (n, C + 1) with the arrays recorded from the reference's
+    ``_get_bboxes_single(with_nms=False)`` (tests/golden/getbboxes.npz).  Bars: scores <= 1e-6 absolute, boxes
+    <= 1e-5 relative; inside every level slice (``level_rows`` rows each) row set AND order exact where the
+    recorded best scores are distinct -- rows of a run of exactly equal best scores (topk leaves their order
+    open) are compared as a multiset."""
+    gb, gs = np.asarray(got_boxes, np.float32), np.asarray(got_scores, np.float32)
+    wb, ws = np.asarray(want_boxes, np.float32), np.asarray(want_scores, np.float32)
+    assert gb.shape == wb.shape and gs.shape == ws.shape, (tag, gb.shape, wb.shape, gs.shape, ws.shape)
+    assert sum(level_rows) == wb.shape[0], (tag, level_rows, wb.shape)
+    assert np.all(gs[:, -1] == 0) and np.all(ws[:, -1] == 0), tag  # the background column
+    off = 0
+    for rows in level_rows:
+        sl = slice(off, off + rows)
+        off += rows
+        g = np.concatenate([gs[sl], gb[sl]], 1)
+        w = np.concatenate([ws[sl], wb[sl]], 1)
+        best = ws[sl, :-1].max(1)
+        # runs of equal best score (adjacent after the reference's topk; a level without a top-k is in row order
+        # and is compared row by row)
+        i = 0
+        while i < rows:
+            j = i + 1
+            while j < rows and best[j] == best[i]:
+                j += 1
+            if j - i > 1:
+                # canonical order inside a tie run: lexicographic on the recorded row contents
+                g[i:j] = g[i:j][np.lexsort(np.round(g[i:j, ::-1].T.astype(np.float64), 3))]
+                w[i:j] = w[i:j][np.lexsort(np.round(w[i:j, ::-1].T.astype(np.float64), 3))]
+            i = j
+        nc = gs.shape[1]
+        ds = np.abs(g[:, :nc] - w[:, :nc]).max()
+        assert ds <= 1e-6, (tag, "scores", float(ds))
+        assert np.allclose(g[:, nc:], w[:, nc:], rtol=1e-5, atol=1e-5), (tag, "boxes", float(np.abs(g[:, nc:] - w[:, nc:]).max()))

@@ -102,3 +102,26 @@ def test_degenerate_inputs_take_the_dense_path():
     assert (res.gt_inds == 0).all() and res.num_gts == 0
     res = asg.assign(boxes.new_zeros((0, 5)), boxes[:3])
     assert res.gt_inds.numel() == 0
+
+
+@pytest.mark.parametrize("wrt_candidates", [True, False])
+def test_ignore_regions_mark_anchors_ignored(wrt_candidates):
+    """ignore_iof_thr > 0 with a non-empty ignore set (mmdet 2.19 max_iou_assigner.py, restated): anchors whose IoF
+    with an ignore region exceeds the threshold become -1 unless matched low-quality; the configuration leaves the
+    fused path (it has no ignore input) and the result equals the rules applied to the masked dense matrix."""
+    asg = make('RBboxOverlaps2D_v1', ignore_iof_thr=0.5, ignore_wrt_candidates=wrt_candidates, match_low_quality=False)
+    boxes = dev(rand_boxes(3000, 4, span=400.))
+    gts = dev(rand_boxes(12, 5, span=400.))
+    ign = dev(rand_boxes(6, 6, span=400., lo=60., hi=200.))
+    res = asg.assign(boxes, gts, gt_bboxes_ignore=ign)
+    ov = asg.iou_calculator(gts, boxes)
+    iof = asg.iou_calculator(boxes, ign, mode='iof').max(1)[0] if wrt_candidates else \
+        asg.iou_calculator(ign, boxes, mode='iof').max(0)[0]
+    hit = iof > 0.5
+    assert 10 < int(hit.sum()) < 3000
+    assert bool((res.gt_inds[hit] == -1).all())
+    ov[:, hit] = -1
+    assert torch.equal(res.gt_inds, asg.assign_wrt_overlaps(ov).gt_inds)
+    # an empty ignore set, or the threshold off: unchanged, fused
+    plain = make('RBboxOverlaps2D_v1', match_low_quality=False).assign(boxes, gts)
+    assert torch.equal(asg.assign(boxes, gts, gt_bboxes_ignore=ign[:0]).gt_inds, plain.gt_inds)

@@ -412,7 +412,9 @@ def test_forward_nhwc_refuses_odd_channel_counts():
         fr_forward_nhwc(x.contiguous(), dev(fr_boxes(1, 8, 8, 8, 1)), 0.125, 1, out)  # NCHW memory
 
 
-@pytest.mark.parametrize("shape", [(2, 256, 128, 128, 8), (4, 256, 64, 64, 16), (3, 64, 13, 7, 32), (1, 256, 1, 1, 128)])
+@pytest.mark.parametrize("shape", [(2, 256, 128, 128, 8), (4, 256, 64, 64, 16), (3, 64, 13, 7, 32), (1, 256, 1, 1, 128),
+                                   (4, 256, 128, 128, 8),   # bench.py's roofline launch: 2048 workgroups, XCD band remap on
+                                   (8, 256, 128, 128, 8), (1, 256, 128, 128, 8), (3, 256, 32, 32, 32)])
 @pytest.mark.parametrize("points", [1, 5])
 @pytest.mark.parametrize("with_b", [True, False])
 def test_module_nhwc_bit_identical_to_the_nchw_steps(shape, points, with_b):

@@ -37,10 +37,11 @@ def same(a, b):
 
 @pytest.fixture(params=[0, 1, 2, 4, 5], ids=["auto", "simple", "compact", "pipeline", "pipeline-overflow"])
 def iou_impl(request):
-    """0 = automatic (one-launch narrow-tile kernel for small matrices, prep + stream + drain pipeline for
-    large ones), 1 = one thread per pair, 2 = the wide one-launch kernel with an in-workgroup queue (the
-    no-workspace path), 4 = the pipeline whatever the size, 5 = the pipeline with its global queue capped at
-    100 entries (the stream kernel then clips what does not fit itself)."""
+    """0 = automatic (one-launch narrow-tile kernel up to 512 columns, stream + drain pipeline beyond),
+    1 = one thread per pair, 2 = the wide one-launch kernel with an in-workgroup queue (the no-workspace path),
+    4 = the pipeline whatever the size, 5 = the pipeline with every wave's LDS segment capped at 100 entries: a
+    tile with a fuller wave is marked dense and the drain tests all of its 8192 pairs with the exact records
+    (nothing is clipped inside the stream kernel)."""
     from r3det import _C
     _C.set_option("iou_impl", 4 if request.param == 5 else request.param)
     _C.set_option("iou_qcap", 100 if request.param == 5 else 0)

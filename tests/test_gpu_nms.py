@@ -24,9 +24,9 @@ def case(n, seed, span):
 
 @pytest.fixture(params=["queue", "tiles", "overflow"])
 def nms_impl(request):
-    """queue = stream/drain/sparse-reduce pipeline (default); tiles = in-place tile mask +
-    dense reduce; overflow = queue pipeline with a 100-entry global queue, which forces the
-    in-kernel clipping path of the stream kernel."""
+    """queue = stream / drain / dependency-round reduce pipeline (default); tiles = in-place tile mask +
+    dense reduce; overflow = queue pipeline with 100-entry queue regions: a tile that does not fit goes to the
+    redo-tile list and is enumerated pair by pair by the drain (nothing is clipped inside the stream kernel)."""
     from r3det import _C
     _C.set_option("nms_impl", 1 if request.param == "tiles" else 0)
     _C.set_option("nms_qcap", 100 if request.param == "overflow" else 0)
@@ -318,7 +318,13 @@ def test_one_call_wrapper_large_pool():
     g = torch.Generator().manual_seed(1)
     s = torch.rand(n, generator=g).cuda()
     lab = torch.randint(0, 15, (n,), generator=g).cuda()
-    fd, fk = M.batched_rnms(b, s, lab, 0.1)
+    assert M._batched_rnms_device(b, s, lab, 0.1, False) is None  # beyond FAST_MAX_N the wrapper goes op by op ...
+    orig_max = M.FAST_MAX_N
+    M.FAST_MAX_N = 65472                                          # ... the library itself takes up to 65 472 rows
+    try:
+        fd, fk = M._batched_rnms_device(b, s, lab, 0.1, False)
+    finally:
+        M.FAST_MAX_N = orig_max
     orig = M._batched_rnms_device
     M._batched_rnms_device = lambda *a, **k: None
     try:
@@ -326,3 +332,8 @@ def test_one_call_wrapper_large_pool():
     finally:
         M._batched_rnms_device = orig
     assert fk.numel() > 1000 and torch.equal(fk, sk) and torch.equal(fd, sd)
+    # float ``inds`` (the reference multiplies them as floats) never take the one-call form
+    assert M._batched_rnms_device(b[:100], s[:100], lab[:100].float(), 0.1, False) is None
+    d1, k1 = M.batched_rnms(b[:100], s[:100], lab[:100].float(), 0.1)
+    d2, k2 = M.batched_rnms(b[:100], s[:100], lab[:100], 0.1)
+    assert torch.equal(k1, k2) and torch.equal(d1, d2)

@@ -126,3 +126,42 @@ def test_pool_flat_scores_large_level_and_largest_k():
     want = torch.topk(logit, k)[1].cuda()
     assert torch.equal(boxes[0], anchors[want])
     assert torch.allclose(scores[0, :, 0], torch.sigmoid(logit.cuda()[want]), rtol=0, atol=1e-6)
+
+
+def test_levels_beyond_the_library_limits_fall_back_per_level(monkeypatch):
+    """a level with more rows than the select kernel holds (1 000 000; a 4096^2 image at stride 8 has
+    2.36 M) or nms_pre > 4096 used to raise; such a level now takes the op-by-op form while the other levels still
+    go through the library.  The limits are lowered here instead of building a 2.36 M-row level; the library's own
+    refusal at the real limit is checked through the C ABI.  nms_pre = None means no cut."""
+    from r3det import _C
+    from r3det.ops import fr_boxes
+    head = make_head(False, (8, 16, 32))
+    A, C, N = head.num_anchors, 15, 2
+    sizes = [(32, 32), (12, 12), (4, 4)]
+    g = torch.Generator().manual_seed(9)
+    cls = [spread_logits(N, A, C, h, w, 30 + i).cuda() for i, (h, w) in enumerate(sizes)]
+    reg = [(torch.randn(N, A * 5, h, w, generator=g) * 0.3).cuda() for h, w in sizes]
+    cfg = dict(nms_pre=300)
+    calls = []
+    real = fr_boxes.level_pool
+    monkeypatch.setattr(fr_boxes, "level_pool", lambda *a, **k: (calls.append(a[0].shape[-1]), real(*a, **k))[1])
+    with torch.no_grad():
+        wb, ws = head.decode_bboxes_torch(cls, reg, (256, 256), cfg)
+        monkeypatch.setattr(fr_boxes, "POOL_MAX_ROWS", 5000)   # level 0 has 9216 rows
+        gb, gs = head.decode_bboxes(cls, reg, (256, 256), cfg)
+        assert calls == [12, 4]
+        monkeypatch.setattr(fr_boxes, "POOL_MAX_ROWS", 1_000_000)
+        monkeypatch.setattr(fr_boxes, "POOL_MAX_K", 200)       # every cut level
+        kb, ks = head.decode_bboxes(cls, reg, (256, 256), cfg)
+        assert calls == [12, 4, 4]
+        nb, ns = head.decode_bboxes(cls, reg, (256, 256), dict(nms_pre=None))
+    for b, s in ((gb, gs), (kb, ks)):
+        assert torch.allclose(s, ws, rtol=0, atol=1e-6) and torch.allclose(b, wb, rtol=1e-6, atol=1e-4)
+    assert nb.shape == (N, sum(h * w * A for h, w in sizes), 5) and float(ns[..., -1].abs().max()) == 0
+    L = _C.lib()
+    assert L.r3det_level_pool_workspace_bytes(1, 9, 512, 512, 2000) > 0  # 2.36 M rows: sized, but the call refuses:
+    t = torch.zeros(16, device='cuda')
+    import ctypes
+    st = (ctypes.c_longlong * 4)(0, 0, 0, 0)
+    assert L.r3det_level_pool(_C.ptr(t), st, _C.ptr(t), st, _C.ptr(t), 0, 1, 9, 15, 512, 512, 2000, 4.0, -1.0, -1.0,
+                              _C.ptr(t), _C.ptr(t), 2000, 0, _C.ptr(t), 1 << 30, None) == -1

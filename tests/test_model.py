@@ -91,6 +91,29 @@ def test_state_dict_names_and_param_count():
     assert m.bbox_head.retina_cls.bias[0].item() == pytest.approx(-math.log(99), rel=1e-6)
 
 
+def test_models_copy_and_pickle():
+    """the heads own a CapacityHint (a lock inside); deepcopy (EMA / SWA twins), torch.save of the whole
+    module and pickling must work, and the copy starts with an empty hint of its own."""
+    import copy
+    import io
+    import pickle
+    from r3det.models import R3Det
+    m = R3Det()
+    m.bbox_head.nms_hint.put(("k",), 7)
+    c = copy.deepcopy(m)
+    assert c.bbox_head.nms_hint is not m.bbox_head.nms_hint and c.bbox_head.nms_hint.get(("k",)) is None
+    assert m.bbox_head.nms_hint.get(("k",)) == 7
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+    head = pickle.loads(pickle.dumps(m.refine_head[0]))
+    assert head.nms_hint.get(("k",)) is None
+    head.nms_hint.put(("a",), 1)  # the recreated lock works
+    buf = io.BytesIO()
+    torch.save(m.bbox_head, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    assert again.retina_cls.weight.shape == m.bbox_head.retina_cls.weight.shape
+
+
 def _loop_get_bboxes(head, cls_scores, bbox_preds, img_shape, cfg, rois):
     """Per-image, per-level restatement (rotate_anchor_head.py:590-675)."""
     from r3det.core.post_processing import multiclass_nms_rotated
