@@ -66,10 +66,14 @@ def spread_cls(N, A, C, h, w, g, lo=-6.0, hi=4.0):
     return cls.view(N, h, w, A * C).permute(0, 3, 1, 2).contiguous()
 
 
-def tie_rows(cls, n, A, C, rows, value):
-    """Give the rows (p * A + a) of image n the same best logit ``value`` (an exact tie inside the top-k set)."""
+def tie_rows(cls, n, A, C, rows, value, out, key):
+    """Give the rows (p * A + a) of image n the same best logit ``value`` (an exact tie inside the top-k set).
+    The rows' original values are recorded under ``key`` so that a test can rebuild the tie-free map (the detections
+    are recorded on the tie-free maps: with tied scores the NMS order is open)."""
     N, _, h, w = cls.shape
     v = cls.permute(0, 2, 3, 1).reshape(N, h * w * A, C)  # a copy (permute of a contiguous NCHW tensor)
+    out[key + "_img"], out[key + "_rows"] = np.array(n), np.array(rows)
+    out[key + "_values"] = v[n, rows].numpy().copy()
     for r in rows:
         v[n, r] = value - 1.0
         v[n, r, r % C] = value
@@ -93,8 +97,9 @@ def main():
     head = R.RRetinaHead(num_classes=C, in_channels=8, stacked_convs=1, feat_channels=8, anchor_generator=ANCHOR_CFG,
                          bbox_coder=CODER_CFG, loss_cls=LOSS_CLS, loss_bbox=LOSS_BBOX, train_cfg=train_cfg(0.5, 0.4))
     cls = [spread_cls(N, A, C, h, w, g) for h, w in sizes]
-    cls[0] = tie_rows(cls[0], 0, A, C, [17, 4000, 4001, 6911], 5.0)      # four-way tie above everything else
-    cls[1] = tie_rows(cls[1], 1, A, C, [3, 1700], 3.9990234375)          # a two-way tie inside the set
+    cls_untied = list(cls)
+    cls[0] = tie_rows(cls[0], 0, A, C, [17, 4000, 4001, 6911], 5.0, out, "s0_untie_l0")  # four-way tie above everything
+    cls[1] = tie_rows(cls[1], 1, A, C, [3, 1700], 3.9990234375, out, "s0_untie_l1")      # a two-way tie inside the set
     # deltas: dx / dy up to several box sizes (centres leave the image -> max_shape clamp), dw / dh beyond
     # the clip |d| <= log(1000 / 16) = 4.135
     reg = [torch.randn(N, A * 5, h, w, generator=g) * torch.tensor([1.5, 1.5, 3.0, 3.0, 0.7]).repeat(A)[None, :, None, None]
@@ -108,7 +113,7 @@ def main():
             out[f"s0_k{nms_pre}_boxes_{i}"], out[f"s0_k{nms_pre}_scores_{i}"] = b.numpy(), s.numpy()
         print("stage 0 nms_pre", nms_pre, "pool", tuple(res[0][0].shape), tuple(res[0][1].shape))
     cfg = Cfg(nms_pre=500, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=2000)
-    for i, (d, lab) in enumerate(head.get_bboxes(cls, reg, metas, cfg)):
+    for i, (d, lab) in enumerate(head.get_bboxes(cls_untied, reg, metas, cfg)):
         out[f"s0_dets_{i}"], out[f"s0_labels_{i}"] = d.numpy(), lab.numpy()
         print("stage 0 detections", i, tuple(d.shape))
 
@@ -120,7 +125,8 @@ def main():
                                 assign_by_circumhbbox=None, bbox_coder=CODER_CFG, loss_cls=LOSS_CLS,
                                 loss_bbox=LOSS_BBOX, train_cfg=train_cfg(0.6, 0.5))
     rcls = [spread_cls(N, 1, C, h, w, g) for h, w in sizes]
-    rcls[0] = tie_rows(rcls[0], 1, 1, C, [5, 6, 700], 5.0)
+    rcls_untied = list(rcls)
+    rcls[0] = tie_rows(rcls[0], 1, 1, C, [5, 6, 700], 5.0, out, "sr_untie_l0")
     rreg = [torch.randn(N, 5, h, w, generator=g) * torch.tensor([1.0, 1.0, 2.5, 2.5, 0.5])[None, :, None, None]
             for h, w in sizes]
     for l in range(5):
@@ -136,7 +142,7 @@ def main():
             out[f"sr_k{nms_pre}_boxes_{i}"], out[f"sr_k{nms_pre}_scores_{i}"] = b.numpy(), s.numpy()
         print("refine nms_pre", nms_pre, "pool", tuple(b.shape), tuple(s.shape))
     cfg = Cfg(nms_pre=100, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=2000)
-    for i, (d, lab) in enumerate(rhead.get_bboxes(rcls, rreg, metas, cfg, rois=rois)):
+    for i, (d, lab) in enumerate(rhead.get_bboxes(rcls_untied, rreg, metas, cfg, rois=rois)):
         out[f"sr_dets_{i}"], out[f"sr_labels_{i}"] = d.numpy(), lab.numpy()
         print("refine detections", i, tuple(d.shape))
     np.savez_compressed(os.path.join(HERE, "getbboxes.npz"), **out)

@@ -23,10 +23,21 @@ def heads():
             RRetinaRefineHead(num_classes=15, in_channels=8, feat_channels=8, stacked_convs=1).eval())
 
 
-def maps(prefix, dev="cpu", channels_last=False):
+def maps(prefix, dev="cpu", channels_last=False, untied=False):
+    """The recorded head maps; ``untied``: with the rows that were overwritten to make exact score ties restored
+    (the detections were recorded on those: with tied scores the NMS order is open)."""
     out = []
     for kind in ("cls", "reg"):
-        ts = [torch.from_numpy(G[f"{prefix}_{kind}_l{l}"]).to(dev) for l in range(5)]
+        ts = [torch.from_numpy(G[f"{prefix}_{kind}_l{l}"]).clone() for l in range(5)]
+        for l in range(5):
+            if untied and kind == "cls" and f"{prefix}_untie_l{l}_rows" in G:
+                N, AC, h, w = ts[l].shape
+                C = G[f"{prefix}_untie_l{l}_values"].shape[1]
+                v = ts[l].permute(0, 2, 3, 1).reshape(N, -1, C)
+                v[int(G[f"{prefix}_untie_l{l}_img"]), torch.from_numpy(G[f"{prefix}_untie_l{l}_rows"])] = \
+                    torch.from_numpy(G[f"{prefix}_untie_l{l}_values"])
+                ts[l] = v.view(N, h, w, AC).permute(0, 3, 1, 2).contiguous()
+        ts = [t.to(dev) for t in ts]
         if channels_last:
             ts = [t.contiguous(memory_format=torch.channels_last) for t in ts]
         out.append(ts)

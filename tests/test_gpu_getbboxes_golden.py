@@ -48,7 +48,7 @@ def test_get_bboxes_matches_reference_detections(stage, channels_last):
     """Pool + multiclass_nms_rotated (v1) of both heads against the reference's get_bboxes(with_nms=True)."""
     h0, hr = heads()
     head = (h0 if stage == "s0" else hr).cuda()
-    cls, reg = maps(stage, "cuda", channels_last)
+    cls, reg = maps(stage, "cuda", channels_last, untied=True)
     cfg = dict(nms_pre=500 if stage == "s0" else 100, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1),
                max_per_img=2000)
     res = head.get_bboxes(cls, reg, IMG, cfg, rois=rois("cuda") if stage == "sr" else None)
