@@ -330,6 +330,27 @@ int r3det_feature_refine_backward_prepared(const float* top_grad, const float* b
                                            int W, float spatial_scale, float* bottom_grad, void* ws, size_t ws_bytes,
                                            void* stream);
 
+/* feature_refine_cuda.backward on channels_last memory: top_grad / bottom_grad are (N, H, W, C) contiguous
+ * (torch.channels_last of the (N, C, H, W) tensors), C % 4 == 0, 16-byte aligned.  Same values as
+ * r3det_feature_refine_backward up to the summation order (kernel feature_refine_kernel.cu:165-230, caller
+ * fr/feature_refine_module.py:28-40), points 1 or 5, any H x W with W <= 4096.  The scatter of the reference (five
+ * float atomics per element) is a gather here: _index turns the boxes of a level into the inverse tap index
+ * (per cell the list of {source position, weight}, sorted, so the sum has ONE order: results are reproducible
+ * run to run) in one launch; the gradient pass then reads the identity row + one row per entry and writes each
+ * row once -- no atomics, no zero-fill.  overwrite == 0 adds to bottom_grad like the reference.  ws: device
+ * workspace of r3det_fr_backward_nhwc_workspace_bytes() bytes (0 = shape not taken, R3DET_EINVAL from the calls).
+ * _nhwc = _index + _indexed in one call; the split form lets a training step build the index when the forward
+ * pass has the boxes. */
+size_t r3det_fr_backward_nhwc_workspace_bytes(int N, int H, int W, int points);
+int r3det_feature_refine_backward_nhwc(const float* top_grad, const float* best_bboxes, int N, int C, int H, int W,
+                                       float spatial_scale, int points, float* bottom_grad, int overwrite, void* ws,
+                                       size_t ws_bytes, void* stream);
+int r3det_feature_refine_backward_nhwc_index(const float* best_bboxes, int N, int H, int W, float spatial_scale,
+                                             int points, void* ws, size_t ws_bytes, void* stream);
+int r3det_feature_refine_backward_nhwc_indexed(const float* top_grad, int N, int C, int H, int W, int points,
+                                               float* bottom_grad, int overwrite, void* ws, size_t ws_bytes,
+                                               void* stream);
+
 /* Producer of the FR boxes: RRetinaHead.filter_bboxes
  * (models/dense_heads/rotate_retina_head.py:117-179) and, with num_anchors = 1 and
  * anchors_per_image = 1, RRetinaRefineHead.refine_bboxes (rotate_retina_refine_head.py:56-97),

@@ -294,6 +294,34 @@ int r3det_feature_refine_backward_prepared(const float* top_grad, const float* b
                             S(stream)));
 }
 
+size_t r3det_fr_backward_nhwc_workspace_bytes(int N, int H, int W, int points) {
+  return r3k_frb_workspace_bytes(N, H, W, points);
+}
+
+int r3det_feature_refine_backward_nhwc(const float* top_grad, const float* best_bboxes, int N, int C, int H, int W,
+                                       float spatial_scale, int points, float* bottom_grad, int overwrite, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  if (N < 0 || C < 0 || H < 0 || W < 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
+  if ((size_t)N * C * H * W == 0) return R3DET_OK;
+  if (!top_grad || !best_bboxes || !bottom_grad || !ws) return R3DET_EINVAL;
+  return rc(r3k_frb_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, points, bottom_grad, overwrite, ws,
+                             ws_bytes, 0, S(stream)));
+}
+
+int r3det_feature_refine_backward_nhwc_index(const float* best_bboxes, int N, int H, int W, float spatial_scale,
+                                             int points, void* ws, size_t ws_bytes, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0) return R3DET_EINVAL;
+  return rc(r3k_frb_index(best_bboxes, N, H, W, spatial_scale, points, ws, ws_bytes, S(stream)));
+}
+
+int r3det_feature_refine_backward_nhwc_indexed(const float* top_grad, int N, int C, int H, int W, int points,
+                                               float* bottom_grad, int overwrite, void* ws, size_t ws_bytes,
+                                               void* stream) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || !top_grad || !bottom_grad || !ws) return R3DET_EINVAL;
+  return rc(r3k_frb_backward(top_grad, nullptr, N, C, H, W, 0.f, points, bottom_grad, overwrite, ws, ws_bytes, 1,
+                             S(stream)));
+}
+
 int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, const float* bbox_pred,
                         const long long* pred_strides, const float* anchors, int anchors_per_image, int N,
                         int num_anchors, int num_classes, int H, int W, float max_ratio, float* boxes_out,
@@ -338,6 +366,7 @@ int r3det_set_option(const char* name, int value) {
   if (!strcmp(name, "fr_impl")) g_r3_fr_impl = value;
   else if (!strcmp(name, "fr_dbg")) g_r3_fr_dbg = value;
   else if (!strcmp(name, "fr_profile")) g_r3_fr_profile = value;
+  else if (!strcmp(name, "frb_impl")) g_r3_frb_impl = value;
   else if (!strcmp(name, "iou_impl")) g_r3_iou_impl = value;
   else if (!strcmp(name, "iou_small")) g_r3_iou_small = value;
   else if (!strcmp(name, "iou_qcap")) g_r3_iou_qcap = value;

@@ -26,6 +26,7 @@
 
 #include <type_traits>
 
+#include "r3_fr_tap.h"
 #include "r3_kernels.h"
 #include "r3_trig.h"
 
@@ -34,75 +35,6 @@ int g_r3_fr_dbg = 0;  // spare switch for kernel experiments (unused by the ship
 int g_r3_fr_profile = 0;  // 1: cell-path launches record their own start / stop events
 
 namespace {
-
-struct Tap {
-  int o00, o01, o10, o11;  // offsets inside a plane with row pitch `pitch`
-  float w1, w2, w3, w4;
-  bool valid;
-};
-
-// bilinear_interpolate / _gradient coordinate logic (feature_refine_kernel.cu:16-52,67-106)
-__device__ __forceinline__ Tap make_tap(int height, int width, int pitch, float y, float x) {
-  Tap t;
-  if (y < -1.0 || y > height || x < -1.0 || x > width) {
-    t.valid = false;
-    t.o00 = t.o01 = t.o10 = t.o11 = 0;
-    t.w1 = t.w2 = t.w3 = t.w4 = 0.f;
-    return t;
-  }
-  t.valid = true;
-  if (y <= 0) y = 0;
-  if (x <= 0) x = 0;
-  int y_low = (int)y, x_low = (int)x, y_high, x_high;
-  if (y_low >= height - 1) {
-    y_high = y_low = height - 1;
-    y = (float)y_low;
-  } else {
-    y_high = y_low + 1;
-  }
-  if (x_low >= width - 1) {
-    x_high = x_low = width - 1;
-    x = (float)x_low;
-  } else {
-    x_high = x_low + 1;
-  }
-  float ly = y - y_low;
-  float lx = x - x_low;
-  float hy = (float)(1. - (double)ly);
-  float hx = (float)(1. - (double)lx);
-  t.w1 = hy * hx;
-  t.w2 = hy * lx;
-  t.w3 = ly * hx;
-  t.w4 = ly * lx;
-  t.o00 = y_low * pitch + x_low;
-  t.o01 = y_low * pitch + x_high;
-  t.o10 = y_high * pitch + x_low;
-  t.o11 = y_high * pitch + x_high;
-  return t;
-}
-
-// sample points of one position (feature_refine_kernel.cu:125-151)
-template <int POINTS>
-__device__ __forceinline__ void make_taps(const float* __restrict__ box, float scale, int H, int W,
-                                          int pitch, Tap* taps) {
-  float roi_y = box[0] * scale;  // sic: row <- x_ctr
-  float roi_x = box[1] * scale;  //      col <- y_ctr
-  taps[0] = make_tap(H, W, pitch, roi_y, roi_x);
-  if (POINTS > 1) {
-    float roi_w = box[2] * scale;
-    float roi_h = box[3] * scale;
-    float roi_a = box[4];
-    float w_2 = roi_w / 2, h_2 = roi_h / 2;
-    float sina, cosa;
-    r3_sincos(roi_a, sina, cosa);
-    float wx = cosa * w_2, wy = sina * w_2;
-    float hx = -sina * h_2, hy = cosa * h_2;
-    taps[1] = make_tap(H, W, pitch, roi_y + wy + hy, roi_x + wx + hx);
-    taps[2] = make_tap(H, W, pitch, roi_y - wy + hy, roi_x - wx + hx);
-    taps[3] = make_tap(H, W, pitch, roi_y - wy - hy, roi_x - wx - hx);
-    taps[4] = make_tap(H, W, pitch, roi_y + wy - hy, roi_x + wx - hx);
-  }
-}
 
 // Branch-free: an invalid tap has offsets 0 (always readable) and its value is discarded by
 // a select, so the four reads of every tap can be issued back to back (an `if (valid)` around
@@ -627,7 +559,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_pipe(
 //     every sample is out of range -- they are bound by how few loads a CU has in flight, not by the gather.
 // So: no register pipeline: a wave requests the identity rows of its four positions at once and there are 16
 // waves per CU; and most tap rows never pass through the L1 at all (see the kernel's first comment).
-template <bool FUSED, bool PAIRED>
+template <bool FUSED, bool PAIRED, bool PRE = true>
 __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
     const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
@@ -702,22 +634,30 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
       }
       return v;
     };
-    // phase 1: the identity streams of the wave's 4 positions, all in flight together; P to LDS
+    // phase 1: the identity streams of the wave's 4 positions and their 4 boxes, all in flight together; P to LDS
+    float bxs[4], bys[4];  // (wave-uniform: scalar registers)
     {
       float4 ia[4], ib[4];
+      float bxv[4], byv[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const size_t q = img + (size_t)(idle ? 0 : h) * W + w0 + min(i, max(cnt - 1, 0));
         const bool on = i < cnt && cl;
         ia[i] = on ? a4[q * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         ib[i] = (on && two) ? b4[q * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bxv[i] = boxes[q * 5];
+        byv[i] = boxes[q * 5 + 1];
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) Ps[half][wave * 4 + i][lane] = mixv(ia[i], ib[i]);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        bxs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bxv[i])));
+        bys[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, byv[i])));
+      }
     }
     __syncthreads();
-    // phase 2, one position per step (a rolled loop: 45 VGPRs, four workgroups per CU): residual row and box
-    // requested first, the identity term back from LDS, then the taps
+    // phase 2, one position per step: residual row requested first, the identity term back from LDS, then the taps
     auto P = [&](const int y, const int x) -> float4 {  // y, x wave-uniform, inside the map
       const int ly = y - ty * NH_ROWS, lx = x - tx * 4;
       if ((unsigned)ly < (unsigned)NH_ROWS && (unsigned)lx < 4u) return Ps[half][ly * 4 + lx][lane];
@@ -728,13 +668,9 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
       const size_t q = img + (size_t)y * W + x;
       return mixv(a4[q * C4 + c4], two ? b4[q * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f));
     };
-#pragma unroll 1
-    for (int i = 0; i < cnt; i++) {
+    auto position = [&](const int i, const float bx, const float by) {
       const size_t q = img + (size_t)h * W + w0 + i;
-      const float* bp = boxes + q * 5;
-      const float bx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bp[0])));
-      const float by = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bp[1])));
-      if (!cl) continue;
+      if (!cl) return;
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
       if (has_res) r = r4[q * C4 + c4];
       const Tap tp = make_tap(H, W, W, bx * scale, by * scale);  // sic: row <- x_ctr, column <- y_ctr
@@ -749,6 +685,19 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
       if (tp.valid) { v.x += sm.x; v.y += sm.y; v.z += sm.z; v.w += sm.w; }
       if (has_res) { v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w; }
       o4[q * C4 + c4] = v;
+    };
+    if (PRE) {
+      if (cnt > 0) position(0, bxs[0], bys[0]);
+      if (cnt > 1) position(1, bxs[1], bys[1]);
+      if (cnt > 2) position(2, bxs[2], bys[2]);
+      if (cnt > 3) position(3, bxs[3], bys[3]);
+    } else {
+#pragma unroll 1
+      for (int i = 0; i < cnt; i++) {
+        const float* bp = boxes + (img + (size_t)h * W + w0 + i) * 5;
+        position(i, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bp[0]))),
+                 __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bp[1]))));
+      }
     }
     if (c0 + 64 < C4) __syncthreads();  // the next channel block overwrites Ps
   }
@@ -1605,7 +1554,9 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   const dim3 grid((unsigned)T), block(paired ? 512 : 256);
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x, tpi, (int)T, out
   if (occ) {
-    if (paired) {
+    if (paired && fused && g_r3_fr_dbg == 3) {  // A/B: boxes loaded inside the position loop (the round-2 form)
+      hipExtLaunchKernelGGL((fr_forward_nhwc_occ<true, true, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+    } else if (paired) {
       if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<true, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
       else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<false, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
     } else {

@@ -1,0 +1,650 @@
+// r3_frb.hip -- Feature Refinement sampler, BACKWARD on channels_last memory (N, H, W, C).
+//
+// Replaces feature_refine_backward_kernel (fr/src/feature_refine_kernel.cu:165-230; called from
+// feature_refine_module.py:28-40) for channels_last pipelines.  The reference scatters: one thread per
+// element, five global float atomics (the identity term + the four bilinear taps).  Here the scatter is
+// turned into a GATHER, which needs no atomics and no zero-fill and sums in a fixed order:
+//
+//   grad_in[q] = grad_out[q] + sum over the entries e of cell q:  w_e * grad_out[src_e]
+//
+// where the entries of a cell are the (source position, tap) pairs that touch it.  In channels_last a
+// position's gradient is one contiguous row of C floats (1 KB at C = 256): a wavefront owns a cell, a lane
+// owns 4 channels, every row access is one 16-byte load per lane.
+//
+//   index   (boxes only, once per level and step, independent of C): the inverse tap index in CSR form --
+//           per cell {start, len}, per entry {key, weight}, key = (source row * 8192 + source column) * 32 +
+//           point * 4 + tap -- built in ONE launch.  A workgroup owns a band of cell rows.  It scans the
+//           sample rows of all sources of its image (a level's boxes are 320 KB: L2-resident), keeps the few
+//           whose taps reach the band, and derives the band's base in the entry array from a private count of
+//           the entries that fall in earlier rows -- so no cross-workgroup prefix and no global atomics.
+//           points = 1 (frb_index_sort_kernel): the band's entries are collected in LDS in a
+//           fixed (wave, source, tap) order and stably sorted by cell: the sorted list IS the band's CSR slice,
+//           every cell's entries in one fixed order, no LDS atomics (they retire about one lane per 3 cycles and
+//           serialise on piles of sources sampling one cell -- what a trained detector produces around every
+//           object).  A band with more entries than the
+//           LDS list holds, and points = 5, take the general form (frb_index_general: LDS counters, fill, sort).
+//   gather  the sum above.  A 512-thread workgroup owns a 4 x 4 tile of cells and its TRANSPOSE (the reference
+//           samples row <- x_ctr, column <- y_ctr: the sources of tile (i, j) lie in tile (j, i)); the two
+//           tiles' gradient rows are shared through LDS, so most entries are one LDS read instead of a row
+//           load, and the second use of every row meets the first in the same compute unit.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "r3_fr_tap.h"
+#include "r3_kernels.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int IX_T = 1024;         // threads of an index workgroup
+constexpr int IX_WAVES = IX_T / 64;
+constexpr int IX_MAXCELLS = 4096;  // cells of one band (general form)
+constexpr int IX_SORT_MAX = 48;    // general form: lists up to this length are sorted (longer ones keep the fill order)
+constexpr int IXS_CELLS = 256;     // sort form: cells per band (an average of 1024 entries)
+constexpr int IXS_CAP = 8192;      // sort form: entries a band sorts in LDS
+constexpr int IXS_SEG = 256;       // sort form: sources per wave that reach the band
+
+// An entry's first word tells the gather where the source's gradient row is: bits 0..25 the source position
+// sy * W + sx; bit 31 set: the source lies in the 4 x 4 cell tile of the entry's own cell (bits 26..29 = its slot
+// (sy & 3) * 4 + (sx & 3), bit 30 clear) or in that tile's partner in the gather's paired launch (bit 30 set) --
+// the transposed tile (tx, ty), for a diagonal tile its neighbour ty ^ 1 -- whose rows the workgroup holds in LDS.
+__device__ __forceinline__ int frb_entry_code(int sy, int sx, int y, int x, int W) {
+  const int s = sy * W + sx, ty = y >> 2, tx = x >> 2, syt = sy >> 2, sxt = sx >> 2;
+  const int slot = (sy & 3) * 4 + (sx & 3);
+  if (syt == ty && sxt == tx) return (int)(0x80000000u | ((unsigned)slot << 26) | (unsigned)s);
+  const int oy = ty != tx ? tx : (ty ^ 1), ox = ty != tx ? ty : (ty ^ 1);
+  if (syt == oy && sxt == ox) return (int)(0xc0000000u | ((unsigned)slot << 26) | (unsigned)s);
+  return s;
+}
+
+struct FrbLayout {
+  int2* cellinfo;  // [N][HW] {start (in the image's entry array), len}
+  int2* entries;   // [N][4 * points * HW] {key, weight bits}
+  size_t bytes;
+};
+
+inline FrbLayout frb_layout(void* ws, int N, int H, int W, int points) {
+  FrbLayout L;
+  const size_t hw = (size_t)H * W;
+  const size_t ci = (N * hw * sizeof(int2) + 255) & ~(size_t)255;
+  L.cellinfo = reinterpret_cast<int2*>(ws);
+  L.entries = reinterpret_cast<int2*>(static_cast<char*>(ws) + ci);
+  L.bytes = ci + N * hw * 4 * points * sizeof(int2) + 256;
+  return L;
+}
+
+inline int general_band_rows(int H, int W) {
+  int r = IX_T / W;  // one cell per thread in the common shapes
+  if (r < 1) r = 1;
+  return r > H ? H : r;
+}
+
+inline int sort_band_rows(int H, int W) {
+  int r = IXS_CELLS / W;
+  if (r < 1) r = 1;
+  return r > H ? H : r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// general form: any band up to IX_MAXCELLS cells, points 1 or 5
+// ------------------------------------------------------------------------------------------------
+template <int POINTS>
+__device__ __forceinline__ void frb_index_general_body(const float* __restrict__ bx, float scale, int H, int W, int r0,
+                                                       int r1, int* ix, int2* __restrict__ ci, int2* __restrict__ en) {
+  const int CB = (r1 - r0) * W;
+  int* cnt = ix;           // [CB] entries per cell, later the fill cursor
+  int* start = cnt + CB;   // [CB] exclusive prefix inside the band
+  int* part = start + CB;  // [IX_WAVES] wave totals
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HW = H * W;
+  for (int i = tid; i < CB; i += IX_T) cnt[i] = 0;
+  __syncthreads();
+  // pass A: entries per cell of the band; entries in earlier rows (private count)
+  int before = 0;
+  for (int s = tid; s < HW; s += IX_T) {
+    TapYX taps[POINTS];
+    make_taps_yx<POINTS>(bx + (size_t)s * 5, scale, H, W, taps);
+#pragma unroll
+    for (int p = 0; p < POINTS; p++) {
+      const TapYX& t = taps[p];
+      if (!t.valid) continue;
+      before += (t.yl < r0 ? 2 : 0) + (t.yh < r0 ? 2 : 0);
+      if (t.yl >= r0 && t.yl < r1) {
+        atomicAdd(&cnt[(t.yl - r0) * W + t.xl], 1);
+        atomicAdd(&cnt[(t.yl - r0) * W + t.xh], 1);
+      }
+      if (t.yh >= r0 && t.yh < r1) {
+        atomicAdd(&cnt[(t.yh - r0) * W + t.xl], 1);
+        atomicAdd(&cnt[(t.yh - r0) * W + t.xh], 1);
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+  if (lane == 0) part[wave] = before;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < IX_WAVES; w++) base += part[w];
+  __syncthreads();
+  // exclusive prefix of cnt over the band's cells (CPT consecutive cells per thread)
+  const int CPT = (CB + IX_T - 1) / IX_T;
+  const int lo = min(tid * CPT, CB), hi = min(lo + CPT, CB);
+  int mine = 0;
+  for (int i = lo; i < hi; i++) mine += cnt[i];
+  int incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) part[wave] = incl;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < wave; w++) wbase += part[w];
+  int run = base + wbase + incl - mine;
+  for (int i = lo; i < hi; i++) {
+    const int c = cnt[i];
+    start[i] = run;
+    ci[r0 * W + i] = make_int2(run, c);
+    run += c;
+  }
+  __syncthreads();
+  for (int i = tid; i < CB; i += IX_T) cnt[i] = 0;  // fill cursors
+  __syncthreads();
+  // pass B: the entries at their places (order inside a list = arrival order; sorted below)
+  for (int s = tid; s < HW; s += IX_T) {
+    TapYX taps[POINTS];
+    make_taps_yx<POINTS>(bx + (size_t)s * 5, scale, H, W, taps);
+    const int sy = s / W, sx = s - sy * W;
+#pragma unroll
+    for (int p = 0; p < POINTS; p++) {
+      const TapYX& t = taps[p];
+      if (!t.valid) continue;
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const int y = (d >> 1) ? t.yh : t.yl, x = (d & 1) ? t.xh : t.xl;
+        if (y >= r0 && y < r1) {
+          const int c = (y - r0) * W + x;
+          const int rank = atomicAdd(&cnt[c], 1);
+          en[start[c] + rank] = make_int2(frb_entry_code(sy, sx, y, x, W), __float_as_int(t.w[d]));
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // every list in (code, weight bits) order: the gather then sums in one fixed order (entries equal in both commute)
+  for (int i = lo; i < hi; i++) {
+    const int len = cnt[i];
+    if (len < 2 || len > IX_SORT_MAX) continue;
+    int2* e = en + start[i];
+    for (int a = 1; a < len; a++) {
+      const int2 v = e[a];
+      int b = a - 1;
+      while (b >= 0) {
+        const int2 u = e[b];
+        if (u.x < v.x || (u.x == v.x && u.y <= v.y)) break;
+        e[b + 1] = u;
+        b--;
+      }
+      e[b + 1] = v;
+    }
+  }
+}
+
+template <int POINTS>
+__global__ __launch_bounds__(IX_T) void frb_index_general_kernel(const float* __restrict__ boxes, float scale, int H,
+                                                                 int W, int R, int2* __restrict__ cellinfo,
+                                                                 int2* __restrict__ entries) {
+  extern __shared__ __attribute__((aligned(16))) int ix[];
+  const int n = blockIdx.y, r0 = blockIdx.x * R, r1 = min(H, r0 + R);
+  const size_t HW = (size_t)H * W;
+  frb_index_general_body<POINTS>(boxes + n * HW * 5, scale, H, W, r0, r1, ix, cellinfo + n * HW,
+                                 entries + n * HW * 4 * POINTS);
+}
+
+__device__ __attribute__((noinline)) void frb_index_general_call(const float* __restrict__ bx, float scale, int H, int W,
+                                                                 int r0, int r1, int* ix, int2* __restrict__ ci,
+                                                                 int2* __restrict__ en) {
+  frb_index_general_body<1>(bx, scale, H, W, r0, r1, ix, ci, en);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sort form (points = 1)
+// ------------------------------------------------------------------------------------------------
+struct IxsLds {
+  u64 sk[IXS_CAP];              // (cell in the band << 56) | (source << 34) | (tap << 32) | weight bits
+  int seg[IX_WAVES * IXS_SEG];  // sources that reach the band, per wave
+  int cst[IXS_CELLS], cend[IXS_CELLS];
+  int hist[16 * 8 * IX_WAVES + IX_WAVES];  // the sort's block counts (E <= 8)
+  int wcnt[IX_WAVES];
+  int part[IX_WAVES];
+  int total, over;
+};
+
+// Stable sort of E * 1024 keys by their top byte (the cell), E per thread (element e * 1024 + tid): two passes of a
+// 4-bit counting sort.  A wavefront ranks its 64 keys with 16 ballots (no LDS atomics), the 16 x (16 E) block counts are
+// scanned digit-major in LDS, every key goes to its place.  Stable, so the order inside a cell is the list's own
+// (deterministic) order.  (A full bitonic sort of (cell, source, tap) was 18-34 us of this kernel: 55 stages for
+// 1024 keys, 0.3-0.6 us each.)
+template <int E>
+__device__ __forceinline__ void ixs_sort(u64* sk, int* hist, const int tid) {
+  constexpr int NB = E * IX_WAVES;  // 64-key blocks
+  const int lane = tid & 63, wave = tid >> 6;
+  u64 v[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) v[e] = sk[e * IX_T + tid];
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    int rank[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int dg = (int)(v[e] >> (56 + 4 * pass)) & 15;
+      int r = 0, c = 0;
+#pragma unroll
+      for (int d = 0; d < 16; d++) {
+        const u64 m = __ballot(dg == d);
+        if (dg == d) r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (lane == d) c = __popcll(m);
+      }
+      rank[e] = r;
+      if (lane < 16) hist[lane * NB + e * IX_WAVES + wave] = c;
+    }
+    __syncthreads();
+    // exclusive scan of the 16 NB counts (digit-major): CPT consecutive counts per thread
+    {
+      constexpr int CNT = 16 * NB, CPT = (CNT + IX_T - 1) / IX_T;
+      int c[CPT], mine = 0;
+#pragma unroll
+      for (int q = 0; q < CPT; q++) {
+        const int i = tid * CPT + q;
+        c[q] = i < CNT ? hist[i] : 0;
+        mine += c[q];
+      }
+      int incl = mine;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+      }
+      if (lane == 63) hist[CNT + wave] = incl;
+      __syncthreads();
+      int run = incl - mine;
+      for (int w = 0; w < wave; w++) run += hist[CNT + w];
+#pragma unroll
+      for (int q = 0; q < CPT; q++) {
+        const int i = tid * CPT + q;
+        if (i < CNT) hist[i] = run;
+        run += c[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int dg = (int)(v[e] >> (56 + 4 * pass)) & 15;
+      sk[hist[dg * NB + e * IX_WAVES + wave] + rank[e]] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; e++) v[e] = sk[e * IX_T + tid];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __restrict__ boxes, float scale, int H, int W,
+                                                              int R, int2* __restrict__ cellinfo,
+                                                              int2* __restrict__ entries,
+                                                              u64* __restrict__ stamps = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) int ix[];
+  IxsLds& S = *reinterpret_cast<IxsLds*>(ix);
+  // (tools/probes/frb_index_probe.hip: clock stamps of one workgroup at the phase boundaries)
+  auto stamp = [&](int k) {
+    if (stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.y, r0 = blockIdx.x * R, r1 = min(H, r0 + R);
+  const int HW = H * W, CB = (r1 - r0) * W;
+  const float* bx = boxes + (size_t)n * HW * 5;
+  int2* ci = cellinfo + (size_t)n * HW;
+  int2* en = entries + (size_t)n * HW * 4;
+  if (tid == 0) S.over = 0;
+  for (int i = tid; i < IXS_CELLS; i += IX_T) S.cst[i] = S.cend[i] = 0;
+  __syncthreads();
+  // A: the sample rows of every source: entries in earlier rows (the band's base), sources that reach the band
+  int before = 0, wc = 0;
+  bool over = false;
+  constexpr int UA = 8;  // sources per thread and round: their 2 x UA loads are in flight together (one workgroup per
+                         // compute unit: a round is one L2 latency; a pre-pass that stored the sample rows as one
+                         // int per source made this phase no shorter, it is bound by the 16 ballots, not the loads)
+  for (int s0 = 0; s0 < HW; s0 += IX_T * UA) {
+    float yv[UA], xv[UA];
+#pragma unroll
+    for (int u = 0; u < UA; u++) {
+      const int s = s0 + u * IX_T + tid;
+      yv[u] = -3.0e38f;  // (beyond the map: out of range below)
+      xv[u] = 0.f;
+      if (s < HW) {
+        yv[u] = bx[(size_t)s * 5];
+        xv[u] = bx[(size_t)s * 5 + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UA; u++) {
+      const int s = s0 + u * IX_T + tid;
+      bool pass = false;
+      float y = yv[u] * scale, x = xv[u] * scale;  // sic: row <- x_ctr, column <- y_ctr
+      if (!(y < -1.0 || y > H || x < -1.0 || x > W)) {  // (feature_refine_kernel.cu:72-79)
+        if (y <= 0) y = 0;
+        int yl = (int)y, yh;
+        if (yl >= H - 1) yh = yl = H - 1; else yh = yl + 1;
+        before += (yl < r0 ? 2 : 0) + (yh < r0 ? 2 : 0);
+        pass = yl < r1 && yh >= r0;
+      }
+      const u64 m = __ballot(pass);
+      if (pass) {
+        const int at = wc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (at < IXS_SEG) S.seg[wave * IXS_SEG + at] = s; else over = true;
+      }
+      wc += __popcll(m);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+  if (lane == 0) S.part[wave] = before;
+  if (over) S.over = 1;
+  __syncthreads();
+  stamp(1);
+  int base = 0;
+  for (int w = 0; w < IX_WAVES; w++) base += S.part[w];
+  // B: every wave its own reaching sources: the four taps; entries of this band to the LDS list, in (wave, source,
+  // tap) order: first the wave's count, then -- behind the waves before it -- the entries
+  const int wcc = min(wc, IXS_SEG);
+  int wtot = 0;
+  for (int i0 = 0; i0 < wcc; i0 += 64) {
+    const int i = i0 + lane;
+    TapYX t;
+    t.valid = false;
+    if (i < wcc) {
+      const int s = S.seg[wave * IXS_SEG + i];
+      t = make_tap_yx(H, W, bx[(size_t)s * 5] * scale, bx[(size_t)s * 5 + 1] * scale);
+    }
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const int y = (d >> 1) ? t.yh : t.yl;
+      wtot += __popcll(__ballot(t.valid && y >= r0 && y < r1));
+    }
+  }
+  if (lane == 0) S.wcnt[wave] = wtot;
+  __syncthreads();
+  int at0 = 0, total = 0;
+  for (int w = 0; w < IX_WAVES; w++) {
+    const int c = S.wcnt[w];
+    if (w < wave) at0 += c;
+    total += c;
+  }
+  if (!S.over && total <= IXS_CAP) {
+    for (int i0 = 0; i0 < wcc; i0 += 64) {
+      const int i = i0 + lane;
+      TapYX t;
+      t.valid = false;
+      int s = 0;
+      if (i < wcc) {
+        s = S.seg[wave * IXS_SEG + i];
+        t = make_tap_yx(H, W, bx[(size_t)s * 5] * scale, bx[(size_t)s * 5 + 1] * scale);
+      }
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const int y = (d >> 1) ? t.yh : t.yl, x = (d & 1) ? t.xh : t.xl;
+        const bool in = t.valid && y >= r0 && y < r1;
+        const u64 m = __ballot(in);
+        if (in) {
+          const int at = at0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          S.sk[at] = ((u64)(unsigned)((y - r0) * W + x) << 56) | ((u64)(unsigned)s << 34) | ((u64)d << 32) |
+                     (unsigned)__float_as_int(t.w[d]);
+        }
+        at0 += __popcll(m);
+      }
+    }
+  }
+  __syncthreads();
+  stamp(2);
+  if (S.over || total > IXS_CAP) {  // more than the LDS list holds: the general form on the same band
+    __syncthreads();
+    frb_index_general_call(bx, scale, H, W, r0, r1, ix, ci, en);
+    return;
+  }
+  // C: stable sort by cell
+  const int npad = total <= IX_T ? IX_T : total <= 2 * IX_T ? 2 * IX_T : total <= 4 * IX_T ? 4 * IX_T : 8 * IX_T;
+  for (int i = total + tid; i < npad; i += IX_T) S.sk[i] = ~0ull;
+  __syncthreads();
+  if (npad == IX_T) ixs_sort<1>(S.sk, S.hist, tid);
+  else if (npad == 2 * IX_T) ixs_sort<2>(S.sk, S.hist, tid);
+  else if (npad == 4 * IX_T) ixs_sort<4>(S.sk, S.hist, tid);
+  else ixs_sort<8>(S.sk, S.hist, tid);
+  stamp(3);
+  // D: the sorted list is the band's slice of the entry array; run boundaries give {start, len} per cell
+  for (int i = tid; i < total; i += IX_T) {
+    const u64 k = S.sk[i];
+    const int c = (int)(k >> 56);
+    if (i == 0 || (int)(S.sk[i - 1] >> 56) != c) S.cst[c] = i;
+    if (i == total - 1 || (int)(S.sk[i + 1] >> 56) != c) S.cend[c] = i + 1;
+    const int s = (int)((k >> 34) & 0x3fffff);
+    const int sy = s / W, sx = s - sy * W, y = r0 + c / W, x = c - (c / W) * W;
+    en[base + i] = make_int2(frb_entry_code(sy, sx, y, x, W), (int)(unsigned)k);
+  }
+  __syncthreads();
+  for (int c = tid; c < CB; c += IX_T) ci[r0 * W + c] = make_int2(base + S.cst[c], S.cend[c] - S.cst[c]);
+  stamp(4);
+  if (stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) {
+    stamps[5] = (u64)total;
+    stamps[6] = (u64)wc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather
+// ------------------------------------------------------------------------------------------------
+// PAIRED (square tile grids): 8 waves = the 4 x 4 cell tile (i, j) and its transpose (j, i), four waves each;
+// the diagonal tiles two by two (every workgroup has two full halves).  Tiles are dealt to the XCDs in
+// contiguous bands (blockIdx & 7 = XCD under round-robin dispatch).
+// All index arithmetic in 32 bits (the launcher refuses tensors of 4 GB and more), everything about a cell's list in
+// scalar registers: the first version of this kernel spent 640 scalar instructions per wavefront on 64-bit address
+// arithmetic and register spills and was bound by their issue (PMC: 10.5 M scalar of 15.5 M instructions).
+template <bool ACCUM, bool PAIRED>
+__global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const float* __restrict__ top,
+                                                                        const int2* __restrict__ cellinfo,
+                                                                        const int2* __restrict__ entries, int C, int H,
+                                                                        int W, int EPI, int tiles_x, int tiles_per_img,
+                                                                        int T, float* __restrict__ bottom) {
+  __shared__ float4 Gs[PAIRED ? 32 : 16][64];  // slot (half * 16 + row of the tile * 4 + column) x lane
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
+  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  unsigned t = blockIdx.x;
+  if ((T & 7) == 0) t = (t & 7u) * (unsigned)(T >> 3) + (t >> 3);  // XCD-contiguous bands of tiles
+  const int n = (int)(t / (unsigned)tiles_per_img);
+  const int tt = (int)(t - (unsigned)n * (unsigned)tiles_per_img);
+  int ty, tx;
+  bool idle = false;   // (an idle half still takes part in the barriers)
+  if (PAIRED) {
+    const int off = tiles_x * (tiles_x - 1) / 2;
+    if (tt < off) {
+      int pj = (int)((sqrtf(8.f * (float)tt + 1.f) + 1.f) * 0.5f);
+      while (pj * (pj - 1) / 2 > tt) pj--;
+      while ((pj + 1) * pj / 2 <= tt) pj++;
+      const int pi = tt - pj * (pj - 1) / 2;
+      ty = half ? pj : pi;
+      tx = half ? pi : pj;
+    } else {
+      ty = tx = 2 * (tt - off) + half;
+      idle = ty >= tiles_x;
+    }
+  } else {
+    ty = tt / tiles_x;
+    tx = tt - ty * tiles_x;
+  }
+  const int h = ty * 4 + wave;
+  idle = idle || h >= H;
+  const int HW = H * W, C4 = C >> 2;
+  const int w0 = tx * 4, cnt = idle ? 0 : min(4, W - w0);
+  // per-image bases (the only 64-bit arithmetic); below, byte offsets are unsigned 32-bit
+  const char* gI = reinterpret_cast<const char*>(top) + (size_t)n * HW * C * 4;
+  char* oI = reinterpret_cast<char*>(bottom) + (size_t)n * HW * C * 4;
+  const char* ciI = reinterpret_cast<const char*>(cellinfo + (size_t)n * HW);
+  const char* enI = reinterpret_cast<const char*>(entries + (size_t)n * EPI);
+  const unsigned rowB = (unsigned)C * 4u;       // bytes of a gradient row
+  const unsigned q0 = idle ? 0u : (unsigned)(h * W + w0);
+  const int own = half * 16 + wave * 4;         // this wave's first slot
+  const int halfX = PAIRED ? half << 4 : 0;     // an entry's slot is relative to its own cell's tile
+  auto entry = [&](unsigned k) -> int2 { return *reinterpret_cast<const int2*>(enI + k * 8u); };
+  for (int c0 = 0; c0 < C4; c0 += 64) {  // (wave-uniform trip count: the barriers are inside)
+    const bool cl = c0 + lane < C4;
+    const unsigned laneB = (unsigned)(c0 + lane) * 16u;  // this lane's 16 bytes inside a row
+    // phase 1: the gradient rows of the wave's own 4 cells and their {start, len}, all in flight together; rows to LDS
+    int st[4], len[4];
+    {
+      float4 gi[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned q = q0 + (unsigned)min(i, max(cnt - 1, 0));
+        const int2 ci = *reinterpret_cast<const int2*>(ciI + q * 8u);
+        st[i] = i < cnt ? ci.x : 0;
+        len[i] = i < cnt ? ci.y : 0;
+        gi[i] = (i < cnt && cl) ? *reinterpret_cast<const float4*>(gI + (q * rowB + laneB)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) Gs[own + i][lane] = gi[i];
+    }
+    __syncthreads();
+    // an entry's gradient row: from either tile of the workgroup (LDS) or from memory
+    auto G = [&](const int code) -> float4 {  // wave-uniform
+      if (code < 0 && (PAIRED || !(code & 0x40000000))) return Gs[((code >> 26) & 31) ^ halfX][lane];
+      return cl ? *reinterpret_cast<const float4*>(gI + (((unsigned)code & 0x3ffffffu) * rowB + laneB))
+                : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    struct E4 { int2 e[4]; };
+    auto first4 = [&](const int st_i) -> E4 {  // (entries st .. st + 3 are inside the array, or the slack behind it)
+      E4 r;
+#pragma unroll
+      for (int u = 0; u < 4; u++) r.e[u] = entry((unsigned)(st_i + u));
+      return r;
+    };
+    auto cell = [&](const int i, const int st_i, const int len_i, const E4& ef) {
+      const unsigned q = q0 + (unsigned)i;
+      float4 acc = Gs[own + i][lane];
+      if (ACCUM && cl) {
+        const float4 o = *reinterpret_cast<const float4*>(oI + (q * rowB + laneB));
+        acc.x = o.x + acc.x; acc.y = o.y + acc.y; acc.z = o.z + acc.z; acc.w = o.w + acc.w;
+      }
+      int k = 0;
+      for (; k + 4 <= len_i; k += 4) {  // four rows requested, then four updates
+        int2 e[4];
+        float4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = k == 0 ? ef.e[u] : entry((unsigned)(st_i + k + u));
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = G(e[u].x);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float w = __int_as_float(e[u].y);
+          acc.x += w * r[u].x; acc.y += w * r[u].y; acc.z += w * r[u].z; acc.w += w * r[u].w;
+        }
+      }
+      for (; k < len_i; k++) {
+        const int2 e = k == 0 ? ef.e[0] : k == 1 ? ef.e[1] : k == 2 ? ef.e[2] : entry((unsigned)(st_i + k));
+        const float4 r = G(e.x);
+        const float w = __int_as_float(e.y);
+        acc.x += w * r.x; acc.y += w * r.y; acc.z += w * r.z; acc.w += w * r.w;
+      }
+      if (cl) *reinterpret_cast<float4*>(oI + (q * rowB + laneB)) = acc;
+    };
+    // (the first entries of cell i + 1 are requested before cell i is worked on)
+    E4 en_next = first4(st[0]);
+#pragma unroll 1
+    for (int i = 0; i < cnt; i++) {
+      const int st_i = i == 0 ? st[0] : i == 1 ? st[1] : i == 2 ? st[2] : st[3];
+      const int len_i = i == 0 ? len[0] : i == 1 ? len[1] : i == 2 ? len[2] : len[3];
+      const E4 en_cur = en_next;
+      en_next = first4(i == 0 ? st[1] : i == 1 ? st[2] : st[3]);
+      cell(i, st_i, len_i, en_cur);
+    }
+    if (c0 + 64 < C4) __syncthreads();  // the next channel block overwrites Gs
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename K>
+inline void allow_big_lds(K kernel, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace
+
+int g_r3_frb_impl = 0;  // 0 auto; 1: the general index form whatever the shape; 2: unpaired gather (A/B runs, tests)
+
+size_t r3k_frb_workspace_bytes(int N, int H, int W, int points) {
+  if (N <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5) || W > IX_MAXCELLS || (long long)H * W > (1LL << 26)) return 0;
+  return frb_layout(nullptr, N, H, W, points).bytes;
+}
+
+// the inverse tap index of a level (depends on the boxes only)
+int r3k_frb_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
+                  hipStream_t stream) {
+  const size_t need = r3k_frb_workspace_bytes(N, H, W, points);
+  if (need == 0 || !boxes || !ws || !aligned16(ws)) return -1;
+  if (ws_bytes < need) return -3;
+  const FrbLayout L = frb_layout(ws, N, H, W, points);
+  if (points == 1 && W <= IXS_CELLS && (long long)H * W <= (1LL << 22) && g_r3_frb_impl != 1) {
+    static bool once = (allow_big_lds(frb_index_sort_kernel, (int)sizeof(IxsLds)), true);
+    (void)once;
+    const int R = sort_band_rows(H, W);
+    hipLaunchKernelGGL(frb_index_sort_kernel, dim3((H + R - 1) / R, N), dim3(IX_T), sizeof(IxsLds), stream, boxes, scale,
+                       H, W, R, L.cellinfo, L.entries, (u64*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
+  const int R = general_band_rows(H, W);
+  const dim3 grid((H + R - 1) / R, N);
+  const size_t lds = ((size_t)2 * R * W + IX_WAVES + 8) * sizeof(int);
+  if (points == 1)
+    hipLaunchKernelGGL(frb_index_general_kernel<1>, grid, dim3(IX_T), lds, stream, boxes, scale, H, W, R, L.cellinfo,
+                       L.entries);
+  else
+    hipLaunchKernelGGL(frb_index_general_kernel<5>, grid, dim3(IX_T), lds, stream, boxes, scale, H, W, R, L.cellinfo,
+                       L.entries);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// bottom_grad (N, H, W, C) = [bottom_grad +] backward(top_grad); index_ready: ws holds r3k_frb_index of these boxes
+int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W, float scale, int points,
+                     float* bottom_grad, int overwrite, void* ws, size_t ws_bytes, int index_ready,
+                     hipStream_t stream) {
+  if (!top_grad || !bottom_grad || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (C & 3) || !aligned16(top_grad) ||
+      !aligned16(bottom_grad))
+    return -1;
+  if (!index_ready) {
+    const int rc = r3k_frb_index(boxes, N, H, W, scale, points, ws, ws_bytes, stream);
+    if (rc) return rc;
+  } else if (!ws || !aligned16(ws) || !r3k_frb_workspace_bytes(N, H, W, points) ||
+             ws_bytes < r3k_frb_workspace_bytes(N, H, W, points)) {
+    return -1;
+  }
+  if ((unsigned long long)N * H * W * C * 4ull >= (1ull << 32)) return -1;  // (32-bit byte offsets inside an image)
+  const FrbLayout L = frb_layout(ws, N, H, W, points);
+  const int tiles_x = (W + 3) / 4, tiles_y = (H + 3) / 4;
+  const bool paired = tiles_x == tiles_y && g_r3_frb_impl != 2;
+  const int tpi = paired ? tiles_x * (tiles_x - 1) / 2 + (tiles_x + 1) / 2 : tiles_x * tiles_y;
+  const long long T = (long long)tpi * N;
+  if (T > 0x7fffffffLL) return -1;
+  const int EPI = H * W * 4 * points;
+  const dim3 grid((unsigned)T), block(paired ? 512 : 256);
+#define R3_ARGS top_grad, L.cellinfo, L.entries, C, H, W, EPI, tiles_x, tpi, (int)T, bottom_grad
+  if (paired) {
+    if (overwrite) hipLaunchKernelGGL((frb_gather_kernel<false, true>), grid, block, 0, stream, R3_ARGS);
+    else hipLaunchKernelGGL((frb_gather_kernel<true, true>), grid, block, 0, stream, R3_ARGS);
+  } else {
+    if (overwrite) hipLaunchKernelGGL((frb_gather_kernel<false, false>), grid, block, 0, stream, R3_ARGS);
+    else hipLaunchKernelGGL((frb_gather_kernel<true, false>), grid, block, 0, stream, R3_ARGS);
+  }
+#undef R3_ARGS
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -103,6 +103,14 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
                         const float* boxes, int N, int C, int H, int W, float scale, int points, float* out,
                         hipStream_t stream);
 
+// channels_last backward (r3_frb.hip): inverse tap index of the boxes + gather; points 1 or 5, any H x W with W <= 4096
+size_t r3k_frb_workspace_bytes(int N, int H, int W, int points);
+int r3k_frb_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
+                  hipStream_t stream);
+int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W, float scale, int points,
+                     float* bottom_grad, int overwrite, void* ws, size_t ws_bytes, int index_ready,
+                     hipStream_t stream);
+
 // profiling ring of the FR cell path (see r3det_fr_profile_read)
 int r3k_fr_profile_read(float* records, int capacity);
 extern int g_r3_fr_profile;
@@ -110,6 +118,7 @@ extern int g_r3_fr_profile;
 // A/B knobs (r3det_set_option)
 extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane, 3/4 tap-table, 5/6 persistent
 extern int g_r3_fr_dbg;    // ablation bits for the persistent forward kernel
+extern int g_r3_frb_impl;  // 0 auto; 1 general index form always; 2 unpaired gather
 extern int g_r3_iou_impl;  // 0 auto, 1 one thread per pair, 2 one-launch compact kernel, 4 prep + stream + drain pipeline always
 extern int g_r3_iou_dwgs;  // 0 default (2048); > 0: workgroups of the IoU drain kernel (tuning)
 extern int g_r3_iou_qcap;  // 0 default; > 0 caps the IoU pipeline's global pair queue (tests the overflow path)

@@ -125,6 +125,12 @@ def fr_module_prepared(mixed_a, mixed_b, residual, table, output):
     return _taken(rc, "fr_module_prepared")
 
 
+def _is_cl(t):
+    """fp32 HIP tensor in channels_last memory that the NHWC kernels take (C % 4 == 0; not also NCHW-contiguous)."""
+    return (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4
+            and t.size(1) % 4 == 0 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last))
+
+
 def _need_cl(t, name):
     """A 4-d fp32 HIP tensor whose memory is (N, H, W, C) contiguous (torch channels_last)."""
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
@@ -185,6 +191,49 @@ def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, over
                                                     int(points), _C.ptr(o), int(bool(overwrite)), _C.ptr(ws), wsb,
                                                     _C.stream()), "fr_backward")
     return 1
+
+
+def fr_backward_nhwc(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, overwrite=False, index=None):
+    """feature_refine_cuda.backward on channels_last memory (r3det_feature_refine_backward_nhwc): ``top_grad`` /
+    ``bottom_grad`` are (N, C, H, W) tensors in torch.channels_last.  A gather over the inverse tap index of the
+    boxes: no atomics, one summation order.  ``index``: result of ``fr_backward_nhwc_index`` for these boxes (then
+    the boxes are not read).  False when the library does not take the shape: nothing was launched."""
+    g, o = _need_cl(top_grad, "top_grad"), _need_cl(bottom_grad, "bottom_grad")
+    N, C, H, W = g.shape
+    if o.shape != g.shape:
+        raise RuntimeError("bottom_grad must have top_grad's shape")
+    L = _C.lib()
+    with torch.cuda.device(g.device):
+        if index is not None:
+            rc = L.r3det_feature_refine_backward_nhwc_indexed(_C.ptr(g), N, C, H, W, int(points), _C.ptr(o),
+                                                              int(bool(overwrite)), _C.ptr(index), index.numel(),
+                                                              _C.stream())
+            return _taken(rc, "fr_backward_nhwc_indexed")
+        b = _C.need_hip(best_rbboxes, "best_bboxes")
+        if b.numel() != N * H * W * 5:
+            raise RuntimeError(f"best_bboxes must hold N*H*W x 5 values, got {tuple(b.shape)}")
+        wsb = int(L.r3det_fr_backward_nhwc_workspace_bytes(N, H, W, int(points)))
+        if wsb == 0:
+            return False
+        ws = torch.empty(wsb, dtype=torch.uint8, device=g.device)
+        rc = L.r3det_feature_refine_backward_nhwc(_C.ptr(g), _C.ptr(b), N, C, H, W, float(spatial_scale), int(points),
+                                                  _C.ptr(o), int(bool(overwrite)), _C.ptr(ws), wsb, _C.stream())
+    return _taken(rc, "fr_backward_nhwc")
+
+
+def fr_backward_nhwc_index(best_rbboxes, N, H, W, spatial_scale, points=1):
+    """The inverse tap index of one level's boxes (r3det_feature_refine_backward_nhwc_index): depends on the boxes
+    only, so it can be built when the forward pass has them.  None when the shape is not taken."""
+    b = _C.need_hip(best_rbboxes, "best_bboxes")
+    L = _C.lib()
+    wsb = int(L.r3det_fr_backward_nhwc_workspace_bytes(N, H, W, int(points)))
+    if wsb == 0 or b.numel() != N * H * W * 5:
+        return None
+    with torch.cuda.device(b.device):
+        ws = torch.empty(wsb, dtype=torch.uint8, device=b.device)
+        rc = L.r3det_feature_refine_backward_nhwc_index(_C.ptr(b), N, H, W, float(spatial_scale), int(points),
+                                                        _C.ptr(ws), wsb, _C.stream())
+    return ws if _taken(rc, "fr_backward_nhwc_index") else None
 
 
 _pack_streams = {}
@@ -249,11 +298,19 @@ class FeatureRefineFunction(Function):
         ctx.save_for_backward(best_rbboxes)
         assert points in [1, 5]
         assert features.is_cuda
+        ctx.pack = None
+        ctx.nhwc = False
+        if _is_cl(features):
+            # channels_last pipelines (training included): sampler and its backward on (N, H, W, C) memory, no
+            # layout switch around them
+            output = torch.empty_like(features)  # (preserves channels_last)
+            if fr_forward_nhwc(features, best_rbboxes.contiguous(), spatial_scale, points, output):
+                ctx.nhwc = True
+                return output
         features = features.contiguous()
         output = torch.empty_like(features)  # the kernel overwrites every element
         if table is None or not fr_forward_prepared(features, table, output):
             fr_forward(features, best_rbboxes.contiguous(), spatial_scale, points, output)
-        ctx.pack = None
         if PACK_AT_FORWARD and points == 1 and ctx.needs_input_grad[0]:
             N, _, H, W = features.shape
             ctx.boxes_c = best_rbboxes.contiguous()
@@ -267,6 +324,12 @@ class FeatureRefineFunction(Function):
         assert grad_output.is_cuda
         grad_input = None
         if ctx.needs_input_grad[0]:
+            if ctx.nhwc:
+                g = grad_output.contiguous(memory_format=torch.channels_last)
+                grad_input = torch.empty_like(g)
+                if fr_backward_nhwc(g, best_rbboxes.contiguous(), ctx.spatial_scale, ctx.points, grad_input,
+                                    overwrite=True):
+                    return grad_input, None, None, None, None
             grad_output = grad_output.contiguous()
             grad_input = torch.empty_like(grad_output)
             if ctx.pack is None or not fr_backward_prepared(grad_output, ctx.boxes_c, ctx.spatial_scale, grad_input,
@@ -328,9 +391,7 @@ class FeatureRefineModule(nn.Module):
         no_grad = not (torch.is_grad_enabled() and (any(f.requires_grad for f in x)
                                                     or any(p.requires_grad for p in self.parameters())))
 
-        def is_cl(t):
-            return (t.is_cuda and t.dtype == torch.float32 and t.size(1) % 4 == 0 and not t.is_contiguous()
-                    and t.is_contiguous(memory_format=torch.channels_last))
+        is_cl = _is_cl
         nhwc = [no_grad and is_cl(f) for f in x]
         # tap tables of the NCHW levels first: each sampler call below is then a single launch with no
         # dependent launch in front of it (the channels_last launch derives its taps from the boxes itself)
@@ -354,6 +415,13 @@ class FeatureRefineModule(nn.Module):
                         continue
                 if NHWC_ONLY:
                     raise RuntimeError("channels_last FR module path not taken")
+            if is_cl(feat) and not no_grad:
+                # channels_last training: convolutions, sampler and the sampler's backward all stay on
+                # (N, H, W, C) memory (FeatureRefineFunction takes the NHWC kernels for channels_last input)
+                mixed = self.conv_5_1(self.conv_1_5(feat)) + self.conv_1_1(feat)
+                if is_cl(mixed):
+                    out.append(feat + fr(mixed, boxes))
+                    continue
             # NCHW: the sampler reads NCHW planes (no-ops for NCHW callers, like the reference)
             infer = table is not None and no_grad
             a, b = self.conv_5_1(self.conv_1_5(feat)).contiguous(), self.conv_1_1(feat).contiguous()

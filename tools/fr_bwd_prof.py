@@ -1,0 +1,52 @@
+"""FR backward at the BASELINE training / inference shapes, both layouts, on rotating buffers (beyond the Infinity
+Cache) -- the driver for `rocprofv3 --kernel-trace` / PMC passes of the backward kernels:
+  NHWC: r3det_feature_refine_backward_nhwc (frb_index_kernel + frb_gather_kernel)
+  NCHW: r3det_feature_refine_backward_ws  (fr_bwd_pack + fr_bwd_place + fr_backward_packed)
+FR_BWD_LEVEL (0), FR_BWD_N (4), FR_BWD_FIELD=regular|adversarial|trained."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+from r3det import synthetic as syn  # noqa: E402
+from r3det.ops.feature_refine import fr_backward, fr_backward_nhwc  # noqa: E402
+
+dev = torch.device("cuda")
+level, N, C = int(os.environ.get("FR_BWD_LEVEL", 0)), int(os.environ.get("FR_BWD_N", 4)), 256
+field = os.environ.get("FR_BWD_FIELD", "regular")
+H = 128 >> level
+stride = 8 << level
+cl = torch.channels_last
+boxes = syn.fr_level_boxes(N, H, H, stride, 3, device=dev)
+if field == "adversarial":
+    boxes[:, :2] = torch.rand(boxes.shape[0], 2, device=dev) * (H * stride)
+elif field == "trained":  # every position regresses to the centre of the object it lies on: piles of ~9-25 per cell
+    g = (boxes[:, :2] / (4 * stride)).floor() * (4 * stride) + 2 * stride
+    boxes[:, :2] = g + torch.randn_like(g) * 0.3 * stride
+nset = max(3, int(0.9e9 // (2 * N * C * H * H * 4)))
+sets_cl = [tuple(torch.randn(N, C, H, H, device=dev).contiguous(memory_format=cl) for _ in range(2)) for _ in range(nset)]
+alg = 8 * N * C * H * H + 20 * N * H * H
+
+
+def timed(name, fn, sets):
+    for i in range(2 * len(sets)):
+        fn(*sets[i % len(sets)])
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 30
+    s.record()
+    for i in range(reps):
+        fn(*sets[i % len(sets)])
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1000 / reps
+    print(f"{name:34s} level {level} N={N} {field:11s}: {us:7.1f} us per call, {alg / us / 1e3:7.1f} GB/s on {alg} algorithmic bytes", flush=True)
+
+
+timed("fr_backward_nhwc (index + gather)", lambda g, o: fr_backward_nhwc(g, boxes, 1.0 / stride, 1, o, overwrite=True), sets_cl)
+del sets_cl
+sets = [tuple(torch.randn(N, C, H, H, device=dev) for _ in range(2)) for _ in range(nset)]
+timed("fr_backward NCHW (pack + accumulate)", lambda g, o: fr_backward(g, boxes, 1.0 / stride, 1, o, overwrite=True), sets)
