@@ -50,6 +50,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achie
 NMS_CFG = dict(iou_thr=0.1)  # type absent -> 'v1' (bbox_nms_rotated.py:43)
 SCORE_THR, MAX_PER_IMG = 0.05, 2000
 CHANNELS_LAST = os.environ.get("R3DET_BENCH_NCHW", "0") != "1"  # activation layout of the conv stack
+# R3DET_TRAIN_CHANNELS_LAST=1: the training step in channels_last -- the FR sampler and its backward then run on NHWC
+# memory (r3det_feature_refine_backward_nhwc).  Off by default: MIOpen's fp32 backward convolutions are slower on
+# NHWC activations (62.4 vs 53.5 ms per step measured, round 3), although the FR backward itself is faster there.
+TRAIN_CHANNELS_LAST = os.environ.get("R3DET_TRAIN_CHANNELS_LAST", "0") == "1"
 FUSE = os.environ.get("R3DET_BENCH_NOFUSE", "0") != "1"          # conv+BN folding and fused epilogues
 PROFILE_PMC = os.path.join(ROOT, "profiles", "roofline_kernel_pmc.json")
 FR_SOURCE = os.path.join(ROOT, "r3det-pytorch_amd", "csrc", "r3_fr.hip")
@@ -88,12 +92,12 @@ def model_step(model, img):
     from r3det import dist_infer as di
     res = model.simple_test(img)
     packed, counts = di.pack_detections([r[0] for r in res], [r[1] for r in res], MAX_PER_IMG)
-    di.gather_detections(packed, counts)
+    di.gather_detections(packed, counts)  # (pads a short batch to the ranks' maximum itself)
     return counts
 
 
 # ------------------------------------------------------------------------------------ training
-def build_train(device, seed, world):
+def build_train(device, seed, world, channels_last=None):
     # MIOpen's exhaustive find mode (cudnn.benchmark) searches every convolution of the step in three directions:
     # 9 minutes on a fresh box for a 57 ms step.  The training step runs in immediate mode.
     torch.backends.cudnn.benchmark = False
@@ -101,15 +105,20 @@ def build_train(device, seed, world):
     from r3det import synthetic as syn
     from r3det.models import R3Det
     torch.manual_seed(seed)
+    channels_last = TRAIN_CHANNELS_LAST if channels_last is None else channels_last
     model = R3Det().train().to(device)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
     ddp = dt.wrap_ddp(model, device) if world > 1 else model
     opt = dt.build_optimizer(model)
     g = torch.Generator(device="cpu")
     g.manual_seed(seed + 1)
     img = torch.randn(TRAIN_BATCH, 3, IMG, IMG, generator=g).to(device)
+    if channels_last:
+        img = img.contiguous(memory_format=torch.channels_last)
     gtb = [syn.dota_like_rboxes(TRAIN_GT, seed * 10 + i, device=device) for i in range(TRAIN_BATCH)]
     gtl = [torch.randint(0, 15, (TRAIN_GT,), generator=g).to(device) for _ in range(TRAIN_BATCH)]
-    return dict(model=model, ddp=ddp, opt=opt, img=img, gtb=gtb, gtl=gtl)
+    return dict(model=model, ddp=ddp, opt=opt, img=img, gtb=gtb, gtl=gtl, channels_last=channels_last)
 
 
 def train_step(tr):
@@ -127,7 +136,9 @@ def train_custom_op_ms(tr, device):
     anchors = torch.cat(m.bbox_head.anchors([(IMG // s, IMG // s) for s in syn.STRIDES], device))
     feats, boxes = syn.fr_pyramid(TRAIN_BATCH, C, 9, device=device)
     refined = [torch.cat([b.view(TRAIN_BATCH, -1, 5)[i] for b in boxes]) for i in range(TRAIN_BATCH)]
-    xs = [f.clone().requires_grad_(True) for f in feats]
+    if tr["channels_last"]:
+        feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+    xs = [f.clone().requires_grad_(True) for f in feats]  # (clone preserves the layout)
     gs = [torch.randn_like(f) for f in feats]
 
     def assign():
@@ -403,8 +414,10 @@ def main():
                         ms_per_step=round(ms, 3), per_rank_ms_per_step=ranks, **dist_info(),
                         config={"workload": "BASELINE configs[4]: r3det_r50_fpn_1x v1 training step, batch=2 x 1024x1024 per "
                                             "GPU, 128 synthetic GT per image: forward_train (fused MaxIoU assignment, focal + "
-                                            "smooth-L1, FR forward + packed backward), backward, SGD(momentum); random-init "
+                                            "smooth-L1, FR forward + backward), backward, SGD(momentum); random-init "
                                             "weights; norm_eval, frozen stem + layer1 as in the config",
+                                "layout": "channels_last (FR sampler + backward on NHWC memory)" if TRAIN_CHANNELS_LAST
+                                else "NCHW (packed FR backward)",
                                 "batch_per_gpu": TRAIN_BATCH, "global_batch": TRAIN_BATCH * world,
                                 "parallelism": f"DDP x{world} (RCCL all-reduce of 168 MB fp32 gradients in 48 MB buckets)"},
                         final_loss=round(float(loss), 4),
@@ -586,8 +599,19 @@ def main():
                                          "region, with DDP at N > 1)",
                              "img_s": round(TRAIN_BATCH * ex.steps / e3, 2), "ms_per_step": round(ms3, 3),
                              "final_loss": round(float(loss), 4),
+                             "layout": "channels_last" if TRAIN_CHANNELS_LAST else "NCHW",
                              "custom_ops_isolated": {"assign_ms": round(ta, 3), "fr_fwd_bwd_ms": round(tf, 3),
                                                      "share_of_step": round((ta + tf) / ms3, 4)}}
+            del tr
+            torch.cuda.empty_cache()
+            # the same step in the other layout (3 steps): channels_last runs the FR sampler + backward on NHWC memory
+            tr = build_train(device, 300, 1, channels_last=not TRAIN_CHANNELS_LAST)
+            ex3 = argparse.Namespace(steps=3, warmup=2)
+            e4, _, _ = timed_region(lambda: train_step(tr), ex3, device, di)
+            _, tf4 = train_custom_op_ms(tr, device)
+            line["train"]["other_layout"] = {"layout": "NCHW" if TRAIN_CHANNELS_LAST else "channels_last",
+                                             "ms_per_step": round(e4 / ex3.steps * 1e3, 3),
+                                             "fr_fwd_bwd_ms_isolated": round(tf4, 3)}
             del tr
         if world == 1 and not args.no_cpu_baseline:
             phase("cpu baseline")

@@ -56,35 +56,47 @@ def pack_detections(dets_list, labels_list, max_per_img=MAX_PER_IMG):
     return out, counts
 
 
-def gather_detections(packed, counts, dst=0):
-    """Gather every rank's padded detections on ``dst``.  Returns (list_of_packed,
-    list_of_counts) on dst and (None, None) elsewhere; single-process: passthrough."""
+def gather_detections(packed, counts, dst=0, batch_size=None):
+    """Gather every rank's padded detections on ``dst``.  Returns (list_of_packed, list_of_counts) on dst -- one
+    entry per rank, each ``batch_size`` images long with count -1 for the images a rank did not have
+    (``unpack_detections`` skips them) -- and (None, None) elsewhere; single-process: passthrough.
+
+    ONE code path for RCCL ('nccl') and gloo: ``all_gather_into_tensor`` needs identical shapes on every rank, so
+    every rank first pads its batch to a common size -- ``batch_size`` when the caller knows the configured batch
+    (no extra collective), otherwise the MAX of the ranks' batch sizes (one 8-byte all-reduce) -- with count -1
+    marking the padding; an uneven last batch therefore neither hangs nor mixes up ranks."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_group()):
         return [packed], [counts]
     world, rank = dist.get_world_size(), dist.get_rank()
-    if dist.get_backend() == "nccl":
-        # RCCL has no native gather-to-one that beats all_gather at 56 KB/img; one fused
-        # all_gather_into_tensor per tensor keeps it a single collective launch each.
-        allp = packed.new_empty((world,) + tuple(packed.shape))
-        allc = counts.new_empty((world,) + tuple(counts.shape))
-        dist.all_gather_into_tensor(allp, packed.contiguous())
-        dist.all_gather_into_tensor(allc, counts.contiguous())
-        if rank != dst:
-            return None, None
-        return list(allp.unbind(0)), list(allc.unbind(0))
-    gp = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
-    gc = [torch.empty_like(counts) for _ in range(world)] if rank == dst else None
-    dist.gather(packed, gp, dst=dst)
-    dist.gather(counts, gc, dst=dst)
-    return (gp, gc) if rank == dst else (None, None)
+    B = packed.size(0)
+    if batch_size is None:
+        m = torch.tensor([B], dtype=torch.int64, device=packed.device)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        batch_size = int(m.item())
+    if B > batch_size:
+        raise RuntimeError(f"rank {rank}: batch of {B} images exceeds the common batch size {batch_size}")
+    if B < batch_size:
+        packed = torch.cat([packed, packed.new_zeros((batch_size - B,) + tuple(packed.shape[1:]))])
+        counts = torch.cat([counts, counts.new_full((batch_size - B,), -1)])
+    # (concatenated along dim 0: the output form both RCCL and gloo take)
+    allp = packed.new_empty((world * batch_size,) + tuple(packed.shape[1:]))
+    allc = counts.new_empty((world * batch_size,))
+    # (RCCL has no native gather-to-one that beats all_gather at 56 KB / image: one collective launch per tensor)
+    dist.all_gather_into_tensor(allp, packed.contiguous())
+    dist.all_gather_into_tensor(allc, counts.contiguous())
+    if rank != dst:
+        return None, None
+    # (no host read here: the padding is marked in the counts)
+    return list(allp.split(batch_size)), list(allc.split(batch_size))
 
 
 def unpack_detections(packed, counts):
-    """Inverse of pack_detections for one rank's tensors -> [(dets (k,6), labels (k,))]."""
+    """Inverse of pack_detections for one rank's tensors -> [(dets (k,6), labels (k,))]; entries with count -1 (the
+    padding ``gather_detections`` adds behind a short batch) are skipped."""
     out = []
-    for i in range(packed.size(0)):
-        k = int(counts[i])
-        out.append((packed[i, :k, :6], packed[i, :k, 6].to(torch.long)))
+    for i, k in enumerate(counts.tolist()):  # (one host read for the whole batch)
+        if k >= 0:
+            out.append((packed[i, :k, :6], packed[i, :k, 6].to(torch.long)))
     return out
 
 

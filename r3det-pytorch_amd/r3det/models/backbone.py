@@ -31,10 +31,18 @@ class Bottleneck(nn.Module):
 
 
 class ResNet50(nn.Module):
-    """depth=50, num_stages=4, out_indices=(0,1,2,3), frozen_stages=1, norm_eval=True."""
+    """depth=50, num_stages=4, out_indices=(0,1,2,3), frozen_stages=1, norm_eval=True.  Registered as ``ResNet``
+    with mmdet's keywords (configs/r3det/r3det_r50_fpn_1x_dota_v1.py:8-18): what this restatement does not
+    implement (another depth / style, fewer stages) raises instead of being ignored; ``init_cfg`` / ``pretrained``
+    are accepted and not acted on (there are no checkpoints here: random init)."""
 
-    def __init__(self, frozen_stages=1, norm_eval=True):
+    def __init__(self, frozen_stages=1, norm_eval=True, depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                 zero_init_residual=False, norm_cfg=None, style='pytorch', init_cfg=None, pretrained=None):
         super().__init__()
+        norm_cfg = dict(norm_cfg or dict(type='BN', requires_grad=True))
+        if depth != 50 or num_stages != 4 or tuple(out_indices) != (0, 1, 2, 3) or style != 'pytorch' or \
+                norm_cfg.get('type', 'BN') != 'BN' or zero_init_residual:
+            raise NotImplementedError('ResNet: only the shipped configuration (depth 50, 4 stages, pytorch style, BN)')
         self.frozen_stages, self.norm_eval = frozen_stages, norm_eval
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -96,8 +104,13 @@ class FPN(nn.Module):
     """in_channels=[256,512,1024,2048], out 256, start_level=1, add_extra_convs='on_input',
     num_outs=5: P3-P5 from C3-C5, P6 = 3x3/s2 conv on C5, P7 = 3x3/s2 conv on P6."""
 
-    def __init__(self, in_channels=(256, 512, 1024, 2048), out_channels=256, start_level=1, num_outs=5):
+    def __init__(self, in_channels=(256, 512, 1024, 2048), out_channels=256, start_level=1, num_outs=5,
+                 add_extra_convs='on_input', end_level=-1, relu_before_extra_convs=False, no_norm_on_lateral=False,
+                 conv_cfg=None, norm_cfg=None, act_cfg=None, upsample_cfg=None, init_cfg=None):
         super().__init__()
+        if add_extra_convs != 'on_input' or end_level != -1 or relu_before_extra_convs or conv_cfg or norm_cfg or \
+                act_cfg or (upsample_cfg and dict(upsample_cfg).get('mode', 'nearest') != 'nearest'):
+            raise NotImplementedError("FPN: only the shipped configuration (add_extra_convs='on_input', no norm)")
         self.start_level = start_level
         self.lateral_convs = nn.ModuleList()
         self.fpn_convs = nn.ModuleList()

@@ -7,10 +7,23 @@ import torch.nn as nn
 
 from ..core.post_processing import multiclass_nms_rotated_batch
 from ..ops import FeatureRefineModule
+from ..registry import BACKBONES, DETECTORS, HEADS, NECKS, build_from
 from .backbone import FPN, ResNet50
-from .heads import RRetinaHead, RRetinaRefineHead
+from .heads import RRetinaHead, RRetinaRefineHead, _cfg_dict
 
 from .heads import S0_TRAIN_CFG, SR_TRAIN_CFG  # noqa: E402
+
+if 'ResNet' not in BACKBONES:
+    BACKBONES.register_module(name='ResNet', module=ResNet50)
+if 'FPN' not in NECKS:
+    NECKS.register_module(module=FPN)
+
+# configs/r3det/r3det_r50_fpn_1x_dota_v1.py:8-25: what the constructors build when given no backbone / neck dict
+BACKBONE_CFG = dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                    zero_init_residual=False, norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True,
+                    style='pytorch')
+NECK_CFG = dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
+                add_extra_convs='on_input', num_outs=5)
 
 TEST_CFG = dict(nms_pre=2000, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=2000)
 # configs/r3det/r3det_r50_fpn_1x_dota_v1.py:69-98
@@ -55,16 +68,22 @@ class _Detector(nn.Module):
 
 class RRetinaNet(_Detector):
     """configs/rretinanet/rretinanet_obb_r50_fpn_1x_dota_v1.py: one RRetinaHead, assignment on the
-    oriented GT (assign_by_circumhbbox=None)."""
+    oriented GT (assign_by_circumhbbox=None).  Keywords as mmdet's SingleStageDetector (models/detectors/
+    rretinanet.py:9-21): ``RRetinaNet(backbone, neck, bbox_head, train_cfg, test_cfg, pretrained, init_cfg)``; every
+    argument defaults to that config."""
 
-    def __init__(self, num_classes=15, test_cfg=None, train_cfg=None):
+    def __init__(self, backbone=None, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None,
+                 init_cfg=None, num_classes=15):
         super().__init__()
-        self.test_cfg = dict(test_cfg or TEST_CFG)
-        self.train_cfg = dict(train_cfg or S0_TRAIN_CFG)
-        self.backbone = ResNet50()
-        self.neck = FPN()
-        self.bbox_head = RRetinaHead(num_classes, test_cfg=self.test_cfg, train_cfg=self.train_cfg,
-                                     assign_by_circumhbbox=None)
+        self.test_cfg = _cfg_dict(test_cfg) if test_cfg is not None else dict(TEST_CFG)
+        self.train_cfg = _cfg_dict(train_cfg) if train_cfg is not None else dict(S0_TRAIN_CFG)
+        self.backbone = build_from(BACKBONES, _cfg_dict(backbone or BACKBONE_CFG), pretrained=pretrained)
+        self.neck = build_from(NECKS, _cfg_dict(neck or NECK_CFG))
+        head = _cfg_dict(bbox_head) if bbox_head is not None else dict(
+            type='RRetinaHead', num_classes=num_classes, in_channels=256, assign_by_circumhbbox=None,
+            loss_bbox=dict(type='L1Loss', loss_weight=1.0))  # (:49 of that config)
+        head.update(train_cfg=self.train_cfg, test_cfg=self.test_cfg)
+        self.bbox_head = build_from(HEADS, head)
 
     def extract_feat(self, img):
         return self.neck(self.backbone(img))
@@ -86,24 +105,38 @@ class R3Det(_Detector):
     state-dict names follow the reference (backbone / neck / bbox_head / feat_refine_module.i /
     refine_head.i)."""
 
-    def __init__(self, num_classes=15, num_refine_stages=1, frm_cfgs=None, test_cfg=None, train_cfg=None):
+    def __init__(self, num_refine_stages=1, backbone=None, neck=None, bbox_head=None, frm_cfgs=None, refine_heads=None,
+                 train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None, num_classes=15):
+        """Keywords as the reference's (models/detectors/r3det.py:16-52): the ``model = dict(...)`` of
+        configs/r3det/r3det_r50_fpn_1x_dota_v1.py:6-104 builds this class through ``build_detector`` unchanged;
+        every argument defaults to that config's value."""
         super().__init__()
-        self.test_cfg = dict(test_cfg or TEST_CFG)
-        self.train_cfg = dict(train_cfg or R3DET_TRAIN_CFG)
+        self.test_cfg = _cfg_dict(test_cfg) if test_cfg is not None else dict(TEST_CFG)
+        self.train_cfg = _cfg_dict(train_cfg) if train_cfg is not None else dict(R3DET_TRAIN_CFG)
         if len(self.train_cfg['sr']) < num_refine_stages:
             self.train_cfg['sr'] = list(self.train_cfg['sr']) * num_refine_stages
             self.train_cfg['stage_loss_weights'] = list(self.train_cfg['stage_loss_weights']) * num_refine_stages
         self.num_refine_stages = num_refine_stages
-        self.backbone = ResNet50()
-        self.neck = FPN()
+        self.backbone = build_from(BACKBONES, _cfg_dict(backbone or BACKBONE_CFG), pretrained=pretrained)
+        self.neck = build_from(NECKS, _cfg_dict(neck or NECK_CFG))
         # the base head assigns on the circumscribed horizontal box of the GT (its default 'v1',
         # rotate_anchor_head.py:47,220-224); the refine heads on the oriented GT (config :58)
-        self.bbox_head = RRetinaHead(num_classes, test_cfg=self.test_cfg, train_cfg=self.train_cfg['s0'])
+        head = _cfg_dict(bbox_head) if bbox_head is not None else dict(type='RRetinaHead', num_classes=num_classes,
+                                                                       in_channels=256)
+        head.update(train_cfg=self.train_cfg['s0'], test_cfg=self.test_cfg)
+        self.bbox_head = build_from(HEADS, head)
         frm_cfgs = frm_cfgs or [dict(in_channels=256, featmap_strides=[8, 16, 32, 64, 128])] * num_refine_stages
-        self.feat_refine_module = nn.ModuleList(FeatureRefineModule(**c) for c in frm_cfgs)
-        self.refine_head = nn.ModuleList(RRetinaRefineHead(num_classes, test_cfg=self.test_cfg,
-                                                           train_cfg=self.train_cfg['sr'][i])
-                                         for i in range(num_refine_stages))
+        if refine_heads is None:
+            refine_heads = [dict(type='RRetinaRefineHead', num_classes=num_classes, in_channels=256,
+                                 assign_by_circumhbbox=None)] * num_refine_stages
+        if len(frm_cfgs) != num_refine_stages or len(refine_heads) != num_refine_stages:
+            raise ValueError('frm_cfgs and refine_heads need one entry per refinement stage')
+        self.feat_refine_module = nn.ModuleList(FeatureRefineModule(**_cfg_dict(c)) for c in frm_cfgs)
+        self.refine_head = nn.ModuleList()
+        for i, rh in enumerate(refine_heads):
+            rh = _cfg_dict(rh)
+            rh.update(train_cfg=self.train_cfg['sr'][i], test_cfg=self.test_cfg)
+            self.refine_head.append(build_from(HEADS, rh))
         for m in self.feat_refine_module:
             m.init_weights()
 
@@ -192,11 +225,21 @@ class GraphedDense:
                                             hint=self.model.refine_head[-1].nms_hint)
 
 
-def build_detector(cfg):
-    """dict(type='R3Det' | 'RRetinaNet', ...) -> module (subset of mmdet's build_detector)."""
-    cfg = dict(cfg)
-    typ = cfg.pop('type')
-    return {'R3Det': R3Det, 'RRetinaNet': RRetinaNet}[typ](**cfg)
+for _c in (R3Det, RRetinaNet):
+    if _c.__name__ not in DETECTORS:
+        DETECTORS.register_module(module=_c)
+
+
+def build_detector(cfg, train_cfg=None, test_cfg=None):
+    """mmdet's build_detector on this package's registries: ``cfg`` is the ``model = dict(type='R3Det' |
+    'RRetinaNet', backbone=dict(...), neck=dict(...), bbox_head=dict(...), ...)`` of a reference config (a dict, an
+    mmcv Config node, anything with keys())."""
+    cfg = _cfg_dict(cfg)
+    if train_cfg is not None:
+        cfg['train_cfg'] = train_cfg
+    if test_cfg is not None:
+        cfg['test_cfg'] = test_cfg
+    return build_from(DETECTORS, cfg)
 
 
 @torch.no_grad()

@@ -22,6 +22,17 @@ from ..ops import fr_boxes
 from .backbone import ConvModule
 from .coder import delta2bbox_v1
 from .losses import build_loss
+from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, HEADS, PRIOR_GENERATORS, build_from
+
+for _n, _c in (('MaxIoUAssigner', MaxIoUAssigner),):
+    if _n not in BBOX_ASSIGNERS:
+        BBOX_ASSIGNERS.register_module(name=_n, module=_c)
+if 'DeltaXYWHAOBBoxCoder' not in BBOX_CODERS:
+    BBOX_CODERS.register_module(module=DeltaXYWHAOBBoxCoder)
+from ..core.anchor import PseudoAnchorGenerator  # noqa: E402
+for _c in (RAnchorGenerator, PseudoAnchorGenerator):
+    if _c.__name__ not in PRIOR_GENERATORS:
+        PRIOR_GENERATORS.register_module(module=_c)
 
 S0_TRAIN_CFG = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0,
                                   ignore_iof_thr=-1, iou_calculator=dict(type='RBboxOverlaps2D_v1')),
@@ -32,11 +43,16 @@ SR_TRAIN_CFG = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.6, neg_io
 
 
 def build_assigner(cfg):
-    cfg = dict(cfg)
-    typ = cfg.pop('type')
-    if typ != 'MaxIoUAssigner':
-        raise KeyError(f'assigner {typ!r}: only MaxIoUAssigner is used by the rotated configs')
-    return MaxIoUAssigner(**cfg)
+    return build_from(BBOX_ASSIGNERS, cfg)  # (only MaxIoUAssigner is registered: the rotated configs use no other)
+
+
+def _cfg_dict(cfg):
+    """A (possibly attribute-style) config mapping -> plain nested dicts."""
+    if hasattr(cfg, 'keys'):
+        return {k: _cfg_dict(cfg[k]) for k in cfg.keys()}
+    if isinstance(cfg, (list, tuple)):
+        return type(cfg)(_cfg_dict(v) for v in cfg)
+    return cfg
 
 
 def level_anchors(featmap_size, stride, device, octave_base_scale=4, scales_per_octave=3,
@@ -49,28 +65,48 @@ def level_anchors(featmap_size, stride, device, octave_base_scale=4, scales_per_
 
 
 class RRetinaHead(nn.Module):
-    """4 x (3x3 conv + ReLU) towers, 9 anchors / position (rotate_retina_head.py:51-115)."""
+    """4 x (3x3 conv + ReLU) towers, 9 anchors / position (rotate_retina_head.py:51-115).
 
-    def __init__(self, num_classes=15, in_channels=256, stacked_convs=4, feat_channels=256, num_anchors=9,
-                 strides=(8, 16, 32, 64, 128), test_cfg=None, train_cfg=None, assign_by_circumhbbox='v1',
-                 bbox_coder=None, loss_cls=None, loss_bbox=None):
+    Constructor keywords are the reference's (rotate_retina_head.py:29-49 + RAnchorHead, rotate_anchor_head.py:33-98):
+    ``RRetinaHead(num_classes, in_channels, stacked_convs=4, feat_channels=256, anchor_generator=dict(type=
+    'RAnchorGenerator', ...), bbox_coder=dict(...), loss_cls=dict(...), loss_bbox=dict(...), train_cfg=..., test_cfg=
+    ..., assign_by_circumhbbox='v1')`` -- so the ``bbox_head`` dict of configs/r3det/r3det_r50_fpn_1x_dota_v1.py
+    builds it unchanged (registry name ``RRetinaHead``).  Every argument defaults to that config's value;
+    ``strides`` / ``num_anchors`` are shorthands for the default anchor generator on other strides."""
+
+    def __init__(self, num_classes=15, in_channels=256, stacked_convs=4, feat_channels=256, num_anchors=None,
+                 strides=None, test_cfg=None, train_cfg=None, assign_by_circumhbbox='v1', bbox_coder=None,
+                 loss_cls=None, loss_bbox=None, conv_cfg=None, norm_cfg=None, anchor_generator=None,
+                 reg_decoded_bbox=False):
         super().__init__()
-        self.num_classes, self.num_anchors, self.strides = num_classes, num_anchors, strides
+        if conv_cfg is not None or norm_cfg is not None or reg_decoded_bbox:
+            raise NotImplementedError('RRetinaHead: conv_cfg / norm_cfg / reg_decoded_bbox are not used by the '
+                                      'rotated configs and not restated')
+        if anchor_generator is None:
+            anchor_generator = self._default_anchor_generator(strides or (8, 16, 32, 64, 128))
+        self.anchor_generator = build_from(PRIOR_GENERATORS, anchor_generator)
+        self.strides = tuple(s[0] for s in self.anchor_generator.strides)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        if num_anchors is not None and num_anchors != self.num_anchors:
+            raise ValueError(f'num_anchors={num_anchors} contradicts the anchor generator ({self.num_anchors})')
+        self.num_classes, self.in_channels, self.feat_channels = num_classes, in_channels, feat_channels
+        self.stacked_convs = stacked_convs
+        loss_cls = _cfg_dict(loss_cls or dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25,
+                                              loss_weight=1.0))
+        if not loss_cls.get('use_sigmoid', False):
+            raise NotImplementedError('softmax classification heads are not used by the rotated configs')
+        self.use_sigmoid_cls = True
         self.cls_out_channels = num_classes  # use_sigmoid_cls
-        self.test_cfg = test_cfg or dict(nms_pre=2000, min_bbox_size=0, score_thr=0.05,
-                                         nms=dict(iou_thr=0.1), max_per_img=2000)
+        self.test_cfg = _cfg_dict(test_cfg) if test_cfg is not None else dict(
+            nms_pre=2000, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=2000)
         # training side (rotate_anchor_head.py:33-98); defaults = configs/r3det/r3det_r50_fpn_1x_dota_v1.py
-        self.train_cfg = dict(train_cfg) if train_cfg is not None else dict(S0_TRAIN_CFG)
+        self.train_cfg = _cfg_dict(train_cfg) if train_cfg is not None else dict(self._default_train_cfg())
         self.assign_by_circumhbbox = assign_by_circumhbbox
         self.assigner = build_assigner(self.train_cfg['assigner'])
-        coder_cfg = dict(bbox_coder or dict(type='DeltaXYWHAOBBoxCoder'))
-        assert coder_cfg.pop('type') == 'DeltaXYWHAOBBoxCoder'
-        self.bbox_coder = DeltaXYWHAOBBoxCoder(**coder_cfg)
-        self.loss_cls = build_loss(loss_cls or dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25,
-                                                    loss_weight=1.0))
-        self.loss_bbox = build_loss(loss_bbox or dict(type='SmoothL1Loss', beta=0.11, loss_weight=1.0))
-        self.anchor_generator = RAnchorGenerator(list(strides), [1.0, 0.5, 2.0], octave_base_scale=4,
-                                                 scales_per_octave=3)
+        self.bbox_coder = build_from(BBOX_CODERS, _cfg_dict(bbox_coder or dict(type='DeltaXYWHAOBBoxCoder')))
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(_cfg_dict(loss_bbox or dict(type='SmoothL1Loss', beta=0.11, loss_weight=1.0)))
+        num_anchors = self.num_anchors
         self.cls_convs = nn.ModuleList()
         self.reg_convs = nn.ModuleList()
         for i in range(stacked_convs):
@@ -82,6 +118,15 @@ class RRetinaHead(nn.Module):
         self._anchor_cache = {}
         self.nms_hint = CapacityHint()  # this head's own workspace-size memory for the batched NMS
         self.init_weights()
+
+    @staticmethod
+    def _default_anchor_generator(strides):
+        return dict(type='RAnchorGenerator', octave_base_scale=4, scales_per_octave=3, ratios=[1.0, 0.5, 2.0],
+                    strides=list(strides))
+
+    @staticmethod
+    def _default_train_cfg():
+        return S0_TRAIN_CFG
 
     def init_weights(self):
         for m in list(self.cls_convs) + list(self.reg_convs):
@@ -324,12 +369,18 @@ class RRetinaHead(nn.Module):
 
 class RRetinaRefineHead(RRetinaHead):
     """Same towers, one (pseudo) anchor per position: the previous stage's boxes
-    (rotate_retina_refine_head.py:20-196)."""
+    (rotate_retina_refine_head.py:20-196).  Registry name ``RRetinaRefineHead``; keywords as the reference's."""
 
-    def __init__(self, num_classes=15, in_channels=256, stacked_convs=4, feat_channels=256,
-                 strides=(8, 16, 32, 64, 128), test_cfg=None, train_cfg=None, assign_by_circumhbbox=None, **kwargs):
-        super().__init__(num_classes, in_channels, stacked_convs, feat_channels, 1, strides, test_cfg,
-                         train_cfg if train_cfg is not None else SR_TRAIN_CFG, assign_by_circumhbbox, **kwargs)
+    @staticmethod
+    def _default_train_cfg():
+        return SR_TRAIN_CFG
+
+    def __init__(self, num_classes=15, in_channels=256, stacked_convs=4, feat_channels=256, strides=None, test_cfg=None,
+                 train_cfg=None, assign_by_circumhbbox=None, anchor_generator=None, **kwargs):
+        if anchor_generator is None:  # (rotate_retina_refine_head.py:36-38)
+            anchor_generator = dict(type='PseudoAnchorGenerator', strides=list(strides or (8, 16, 32, 64, 128)))
+        super().__init__(num_classes, in_channels, stacked_convs, feat_channels, test_cfg=test_cfg, train_cfg=train_cfg,
+                         assign_by_circumhbbox=assign_by_circumhbbox, anchor_generator=anchor_generator, **kwargs)
         self.bboxes_as_anchors = None
 
     def get_anchors(self, featmap_sizes, img_metas, device):
@@ -346,7 +397,7 @@ class RRetinaRefineHead(RRetinaHead):
             else:
                 per = self.anchor_generator.valid_flags([tuple(fs) for fs in featmap_sizes], meta['pad_shape'],
                                                         device=device)
-                flags.append(torch.cat([f[::9] for f in per]))
+                flags.append(torch.cat(per))  # (PseudoAnchorGenerator: one flag per position)
         return anchor_list, flags
 
     def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, rois=None, gt_bboxes_ignore=None):
@@ -378,3 +429,8 @@ class RRetinaRefineHead(RRetinaHead):
             for i in range(N):
                 out[i].append(ref[i])
         return out
+
+
+for _c in (RRetinaHead, RRetinaRefineHead):
+    if _c.__name__ not in HEADS:
+        HEADS.register_module(module=_c)

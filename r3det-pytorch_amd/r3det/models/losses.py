@@ -70,9 +70,24 @@ class SmoothL1Loss(nn.Module):
         return self.loss_weight * weight_reduce_loss(loss, weight, reduction, avg_factor)
 
 
-LOSSES = {'FocalLoss': FocalLoss, 'SmoothL1Loss': SmoothL1Loss}
+class L1Loss(nn.Module):
+    """mmdet L1Loss (configs/rretinanet/rretinanet_obb_r50_fpn_1x_dota_v1.py:49)."""
+
+    def __init__(self, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        reduction = reduction_override or self.reduction
+        return self.loss_weight * weight_reduce_loss((pred - target).abs(), weight, reduction, avg_factor)
+
+
+from ..registry import LOSSES, build_from  # noqa: E402
+
+for _c in (FocalLoss, SmoothL1Loss, L1Loss):
+    if _c.__name__ not in LOSSES:
+        LOSSES.register_module(module=_c)
 
 
 def build_loss(cfg):
-    cfg = dict(cfg)
-    return LOSSES[cfg.pop('type')](**cfg)
+    return build_from(LOSSES, cfg)

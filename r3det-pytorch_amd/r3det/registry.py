@@ -40,6 +40,28 @@ except Exception:  # noqa: BLE001
     IOU_CALCULATORS = Registry('IoU calculator')
 
 
+# The model-side registries of the reference stack (mmdet.models.builder / mmdet.core builders), local: the names
+# of configs/r3det/*.py and configs/rretinanet/*.py resolve to this package's classes (models/__init__.py registers
+# them), so ``build_detector(cfg.model)`` builds the same module tree from the reference's ``model = dict(...)``.
+DETECTORS = Registry('detector')
+BACKBONES = Registry('backbone')
+NECKS = Registry('neck')
+HEADS = Registry('head')
+LOSSES = Registry('loss')
+PRIOR_GENERATORS = Registry('prior generator')
+BBOX_CODERS = Registry('bbox coder')
+BBOX_ASSIGNERS = Registry('bbox assigner')
+
+
+def _plain(cfg):
+    """mmcv.Config / ConfigDict / dict -> a plain (shallow-copied) dict."""
+    return {k: cfg[k] for k in cfg.keys()}
+
+
+def build_from(registry, cfg, **default_args):
+    return registry.build(_plain(cfg), **default_args)
+
+
 def build_iou_calculator(cfg, default_args=None):
     if hasattr(IOU_CALCULATORS, 'build') and isinstance(IOU_CALCULATORS, Registry):
         return IOU_CALCULATORS.build(cfg, **(default_args or {}))

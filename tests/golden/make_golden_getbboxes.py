@@ -113,6 +113,11 @@ def main():
             out[f"s0_k{nms_pre}_boxes_{i}"], out[f"s0_k{nms_pre}_scores_{i}"] = b.numpy(), s.numpy()
         print("stage 0 nms_pre", nms_pre, "pool", tuple(res[0][0].shape), tuple(res[0][1].shape))
     cfg = Cfg(nms_pre=500, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=2000)
+    # detections on the tie-free maps, with the pool they were made from (the boxes of a pool are reproduced to
+    # 1e-5 only by another implementation of exp / sin; a dense pool's NMS is not stable under that, so the
+    # composition pool -> multiclass_nms_rotated is pinned on the reference's own pool bits)
+    for i, (b, s) in enumerate(head.get_bboxes(cls_untied, reg, metas, cfg, with_nms=False)):
+        out[f"s0_untied_boxes_{i}"], out[f"s0_untied_scores_{i}"] = b.numpy(), s.numpy()
     for i, (d, lab) in enumerate(head.get_bboxes(cls_untied, reg, metas, cfg)):
         out[f"s0_dets_{i}"], out[f"s0_labels_{i}"] = d.numpy(), lab.numpy()
         print("stage 0 detections", i, tuple(d.shape))
@@ -142,6 +147,10 @@ def main():
             out[f"sr_k{nms_pre}_boxes_{i}"], out[f"sr_k{nms_pre}_scores_{i}"] = b.numpy(), s.numpy()
         print("refine nms_pre", nms_pre, "pool", tuple(b.shape), tuple(s.shape))
     cfg = Cfg(nms_pre=100, min_bbox_size=0, score_thr=0.05, nms=dict(iou_thr=0.1), max_per_img=2000)
+    for i in range(N):
+        b, s = rhead._get_bboxes_single([c[i] for c in rcls_untied], [r[i] for r in rreg], rois[i], metas[i]['img_shape'],
+                                        1.0, cfg, False, with_nms=False)
+        out[f"sr_untied_boxes_{i}"], out[f"sr_untied_scores_{i}"] = b.numpy(), s.numpy()
     for i, (d, lab) in enumerate(rhead.get_bboxes(rcls_untied, rreg, metas, cfg, rois=rois)):
         out[f"sr_dets_{i}"], out[f"sr_labels_{i}"] = d.numpy(), lab.numpy()
         print("refine detections", i, tuple(d.shape))

@@ -46,16 +46,16 @@ def _worker(rank, world, port, num_tiles, batch, out_path):
         tiles = mine[b0:b0 + batch]
         dl = [_fake_detections(t) for t in tiles]
         packed, counts = di.pack_detections([d for d, _ in dl], [l for _, l in dl], max_per_img=64)
-        # ranks may hold a short last batch: pad to the batch size so collectives stay uniform
-        if packed.size(0) < batch:
-            pad = batch - packed.size(0)
-            packed = torch.cat([packed, packed.new_zeros(pad, 64, di.DET_COLS)])
-            counts = torch.cat([counts, counts.new_zeros(pad)])
-        gp, gc = di.gather_detections(packed, counts, dst=0)
+        # a rank's last batch may be short (13 tiles over 2 ranks, batch 4: 4 + 3 and 4 + 2): gather_detections
+        # pads it itself -- to the configured batch size in the even rounds, to the MAX over the ranks (one more
+        # tiny all-reduce) in the odd ones -- and all ranks go through the same all_gather_into_tensor
+        gp, gc = di.gather_detections(packed, counts, dst=0, batch_size=batch if (b0 // batch) % 2 == 0 else None)
         if rank == 0:
             for src in range(world):
                 src_tiles = di.shard_tiles(num_tiles, src, world)[b0:b0 + batch]
-                for j, (d, l) in enumerate(di.unpack_detections(gp[src], gc[src])[:len(src_tiles)]):
+                got = di.unpack_detections(gp[src], gc[src])
+                assert len(got) == len(src_tiles) and gp[src].size(0) >= len(src_tiles)
+                for j, (d, l) in enumerate(got):
                     collected[src_tiles[j]] = (d.clone(), l.clone())
         else:
             assert gp is None and gc is None
@@ -142,7 +142,8 @@ def _bench_worker(rank, world, port, out_path):
 def test_bench_step_gather_and_rank_metadata_world2(tmp_path):
     """bench.py's own model_step / timed_region / per-rank times / backend + rank count under gloo,
     world size 2, with ranks whose batches differ in size (the gather of detections is per rank: shapes
-    need not agree across ranks) and an image without detections."""
+    differ across ranks: the shorter one is padded inside gather_detections, both go through the same
+    all_gather_into_tensor the RCCL runs use) and an image without detections."""
     out = str(tmp_path / "bench.pt")
     mp.spawn(_bench_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out)
