@@ -36,6 +36,8 @@ int g_r3_fr_profile = 0;  // 1: cell-path launches record their own start / stop
 
 namespace {
 
+typedef float fr_v4 __attribute__((ext_vector_type(4)));
+
 // Branch-free: an invalid tap has offsets 0 (always readable) and its value is discarded by
 // a select, so the four reads of every tap can be issued back to back (an `if (valid)` around
 // them costs one exposed LDS round trip per tap: measured 2.9 -> 4.4 TB/s-equivalent).
@@ -559,7 +561,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_pipe(
 //     every sample is out of range -- they are bound by how few loads a CU has in flight, not by the gather.
 // So: no register pipeline: a wave requests the identity rows of its four positions at once and there are 16
 // waves per CU; and most tap rows never pass through the L1 at all (see the kernel's first comment).
-template <bool FUSED, bool PAIRED, bool PRE = true>
+// VAR bit 0: boxes prefetched in phase 1; bit 1: non-temporal res / out; bit 2: 32-bit index arithmetic
+template <bool FUSED, bool PAIRED, int VAR = 0>
 __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
     const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
@@ -569,6 +572,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
   // a tap that falls inside either tile -- with transposed pairing that is 3 of 4 taps of a regular box field --
   // is one LDS read instead of two row loads through the L1 (which serves 64 B per clock: the 8 tap rows per
   // position were a third of the kernel).  Taps outside the two tiles are loaded as before.
+  constexpr bool PRE = (VAR & 1) != 0, NT = (VAR & 2) != 0, LEAN = (VAR & 4) != 0;
   __shared__ float4 Ps[PAIRED ? 2 : 1][NH_ROWS * 4][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
@@ -603,6 +607,113 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
     tx = tt - ty * tiles_x;
     oy = ty;
     ox = tx;
+  }
+  if (LEAN) {
+    // The same kernel with 32-bit index arithmetic (per-image base pointers, unsigned byte offsets: the launcher
+    // sends tensors of 4 GB and more through the other form) and the taps as (row, column) pairs instead of plane
+    // offsets that have to be divided by W again: the first form issues ~2.3 instructions for every one here, and a
+    // compute unit issues one scalar instruction per cycle for all its waves (PMC, r3_frb.hip's gather: same finding).
+    const int h = ty * NH_ROWS + wave;
+    idle = idle || h >= H;
+    const int HW = H * W, C4 = C >> 2;
+    const bool two = FUSED && b != nullptr, has_res = FUSED && res != nullptr;
+    const int w0 = tx * 4, cnt = idle ? 0 : min(4, W - w0);
+    const size_t imgB = (size_t)n * HW * C * 4;
+    const char* aI = reinterpret_cast<const char*>(a) + imgB;
+    const char* bI = two ? reinterpret_cast<const char*>(b) + imgB : aI;
+    const char* rI = has_res ? reinterpret_cast<const char*>(res) + imgB : aI;
+    char* oI = reinterpret_cast<char*>(out) + imgB;
+    const float* bxI = boxes + (size_t)n * HW * 5;
+    const unsigned rowB = (unsigned)C * 4u;
+    const unsigned q0 = idle ? 0u : (unsigned)(h * W + w0);
+    const int own = half * 16 + wave * 4, halfX = PAIRED ? half << 4 : 0;
+    float4 (*Pf)[64] = &Ps[0][0];  // slot (half * 16 + row of the tile * 4 + column) x lane
+    const int ty4 = ty * NH_ROWS, tx4 = tx * 4, oy4 = oy * NH_ROWS, ox4 = ox * 4;
+    for (int c0 = 0; c0 < C4; c0 += 64) {  // (wave-uniform trip count: the barriers are inside)
+      const bool cl = c0 + lane < C4;
+      const unsigned laneB = (unsigned)(c0 + lane) * 16u;
+      float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+      if (FUSED && cl) {
+        if (bias_a) ba = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bias_a) + laneB);
+        if (bias_b) bb = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bias_b) + laneB);
+      }
+      auto mixv = [&](const float4& x, const float4& y) -> float4 {  // (x + bias_a) + (y + bias_b), or x alone
+        float4 v = x;
+        if (FUSED) {
+          v.x += ba.x; v.y += ba.y; v.z += ba.z; v.w += ba.w;
+          if (two) {
+            float4 u = y;
+            u.x += bb.x; u.y += bb.y; u.z += bb.z; u.w += bb.w;
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+          }
+        }
+        return v;
+      };
+      {
+        float4 ia[4], ib[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const unsigned off = (q0 + (unsigned)min(i, max(cnt - 1, 0))) * rowB + laneB;
+          const bool on = i < cnt && cl;
+          ia[i] = on ? *reinterpret_cast<const float4*>(aI + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          ib[i] = (on && two) ? *reinterpret_cast<const float4*>(bI + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) Pf[own + i][lane] = mixv(ia[i], ib[i]);
+      }
+      __syncthreads();
+      auto P = [&](const int y, const int x) -> float4 {  // y, x wave-uniform, inside the map
+        const int ly = y - ty4, lx = x - tx4;
+        if ((unsigned)ly < (unsigned)NH_ROWS && (unsigned)lx < 4u) return Pf[(half << 4) + ly * 4 + lx][lane];
+        if (PAIRED) {
+          const int my = y - oy4, mx = x - ox4;
+          if ((unsigned)my < (unsigned)NH_ROWS && (unsigned)mx < 4u) return Pf[(((half ^ 1) << 4)) + my * 4 + mx][lane];
+        }
+        const unsigned off = (unsigned)(y * W + x) * rowB + laneB;
+        return mixv(*reinterpret_cast<const float4*>(aI + off),
+                    two ? *reinterpret_cast<const float4*>(bI + off) : make_float4(0.f, 0.f, 0.f, 0.f));
+      };
+      (void)halfX;
+#pragma unroll 1
+      for (int i = 0; i < cnt; i++) {
+        const unsigned q = q0 + (unsigned)i;
+        const float bx = bxI[q * 5u], by = bxI[q * 5u + 1u];  // (uniform addresses: scalar loads)
+        if (!cl) continue;
+        const unsigned off = q * rowB + laneB;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_res) {
+          if (NT) {
+            const fr_v4 t4 = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(rI + off));
+            r = make_float4(t4.x, t4.y, t4.z, t4.w);
+          } else {
+            r = *reinterpret_cast<const float4*>(rI + off);
+          }
+        }
+        const TapYX tp = make_tap_yx(H, W, bx * scale, by * scale);  // sic: row <- x_ctr, column <- y_ctr
+        // (the box is wave-uniform but its float arithmetic runs in the vector unit: hand the four cell
+        // coordinates back to scalar registers, so that "which tile holds this tap" below is a scalar branch and not
+        // exec-mask bookkeeping in every lane)
+        const int yl = __builtin_amdgcn_readfirstlane(tp.yl), xl = __builtin_amdgcn_readfirstlane(tp.xl);
+        const int yh = __builtin_amdgcn_readfirstlane(tp.yh), xh = __builtin_amdgcn_readfirstlane(tp.xh);
+        float4 v = Pf[own + i][lane];
+        const float4 lt = P(yl, xl), rt = P(yl, xh), lb = P(yh, xl), rb = P(yh, xh);
+        float4 sm;
+        sm.x = tp.w[0] * lt.x + tp.w[1] * rt.x + tp.w[2] * lb.x + tp.w[3] * rb.x;
+        sm.y = tp.w[0] * lt.y + tp.w[1] * rt.y + tp.w[2] * lb.y + tp.w[3] * rb.y;
+        sm.z = tp.w[0] * lt.z + tp.w[1] * rt.z + tp.w[2] * lb.z + tp.w[3] * rb.z;
+        sm.w = tp.w[0] * lt.w + tp.w[1] * rt.w + tp.w[2] * lb.w + tp.w[3] * rb.w;
+        if (tp.valid) { v.x += sm.x; v.y += sm.y; v.z += sm.z; v.w += sm.w; }
+        if (has_res) { v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w; }
+        if (NT) {
+          const fr_v4 t4 = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(t4, reinterpret_cast<fr_v4*>(oI + off));
+        } else {
+          *reinterpret_cast<float4*>(oI + off) = v;
+        }
+      }
+      if (c0 + 64 < C4) __syncthreads();  // the next channel block overwrites Ps
+    }
+    return;
   }
   const int h = ty * NH_ROWS + wave;
   idle = idle || h >= H;
@@ -672,7 +783,14 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
       const size_t q = img + (size_t)h * W + w0 + i;
       if (!cl) return;
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_res) r = r4[q * C4 + c4];
+      if (has_res) {
+        if (NT) {
+          const fr_v4 t4 = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(&r4[q * C4 + c4]));
+          r = make_float4(t4.x, t4.y, t4.z, t4.w);
+        } else {
+          r = r4[q * C4 + c4];
+        }
+      }
       const Tap tp = make_tap(H, W, W, bx * scale, by * scale);  // sic: row <- x_ctr, column <- y_ctr
       float4 v = Ps[half][wave * 4 + i][lane];
       const int y0 = tp.o00 / W, x0 = tp.o00 - y0 * W, y1 = tp.o11 / W, x1 = tp.o11 - y1 * W;
@@ -684,7 +802,12 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
       sm.w = tp.w1 * lt.w + tp.w2 * rt.w + tp.w3 * lb.w + tp.w4 * rb.w;
       if (tp.valid) { v.x += sm.x; v.y += sm.y; v.z += sm.z; v.w += sm.w; }
       if (has_res) { v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w; }
-      o4[q * C4 + c4] = v;
+      if (NT) {
+        const fr_v4 t4 = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t4, reinterpret_cast<fr_v4*>(&o4[q * C4 + c4]));
+      } else {
+        o4[q * C4 + c4] = v;
+      }
     };
     if (PRE) {
       if (cnt > 0) position(0, bxs[0], bys[0]);
@@ -1554,15 +1677,25 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   const dim3 grid((unsigned)T), block(paired ? 512 : 256);
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x, tpi, (int)T, out
   if (occ) {
-    if (paired && fused && g_r3_fr_dbg == 3) {  // A/B: boxes loaded inside the position loop (the round-2 form)
-      hipExtLaunchKernelGGL((fr_forward_nhwc_occ<true, true, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
-    } else if (paired) {
-      if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<true, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
-      else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<false, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+    // shipped: VAR 6 = 32-bit index arithmetic + non-temporal residual loads / output stores (each touched exactly
+    // once: they no longer evict the a / b rows the neighbouring workgroups' halo taps are about to ask for).  Level 0,
+    // N = 4, rotating buffers: 66.1 us (round-2 form, fr_dbg 3) -> 60.6 us, FETCH x 2 + WRITE 337 -> 317 MB
+    // (tools/fr_nhwc_ab.py, gpurun_out/fr_fwd_pmc_*.txt); prefetching the boxes in phase 1 (VAR 1, fr_dbg 4): 67.6 us.
+    const bool big = (unsigned long long)N * H * W * C * 4ull >= (1ull << 32);  // (32-bit byte offsets inside an image)
+    const int var = (g_r3_fr_dbg == 3 || big) ? 0 : g_r3_fr_dbg == 4 ? 1 : g_r3_fr_dbg == 5 ? 2 : 6;
+#define R3_OCC(F, P) \
+  do { \
+    if (var == 0) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 0>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+    else if (var == 1) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 1>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+    else if (var == 2) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 2>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+    else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 6>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+  } while (0)
+    if (paired) {
+      if (fused) R3_OCC(true, true); else R3_OCC(false, true);
     } else {
-      if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<true, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
-      else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<false, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
+      if (fused) R3_OCC(true, false); else R3_OCC(false, false);
     }
+#undef R3_OCC
   } else if (points == 1) {
     if (paired) {
       if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<true, 4, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);

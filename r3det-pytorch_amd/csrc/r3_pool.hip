@@ -119,6 +119,20 @@ __global__ __launch_bounds__(256) void pool_all_kernel(const float* __restrict__
             scores + row * (C + 1));
 }
 
+// Append under a predicate with ONE LDS atomic per wavefront (ballot + popcount; lane ranks by mbcnt) instead of one
+// per lane: k winners appended lane by lane to one counter were k serialised same-address atomics -- most of this
+// kernel's time at k = 2000 (LDS atomics retire about one lane per 3+ cycles, far slower on one address).
+// Returns the slot, or -1 for lanes whose predicate is false.  Called by all active lanes of the wave together.
+__device__ __forceinline__ int wave_append(int* counter, const bool pred) {
+  const u64 m = __ballot(pred);
+  if (m == 0) return -1;
+  const int first = __ffsll((long long)m) - 1;
+  int base = 0;
+  if ((int)(threadIdx.x & 63) == first) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, first);
+  return pred ? base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) : -1;
+}
+
 constexpr int PS_T = 1024;      // threads of the select workgroup
 constexpr int PS_KMAX = 4096;   // largest nms_pre (LDS list of 8-byte entries: 32 KB)
 constexpr int PS_U = 4;         // 16-byte key loads in flight per thread and step
@@ -128,7 +142,13 @@ constexpr int PS_CAND = 8192;   // (key, index) entries kept in LDS after three 
 // read as uint4, PS_U independent loads per thread and step (a first version read one key per iteration, each
 // waiting for the previous: 127 us at 16 384 keys, 500 us at 147 456).
 __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, const unsigned* __restrict__ keys,
-                                                           const unsigned* __restrict__ hist, int* __restrict__ sel) {
+                                                           const unsigned* __restrict__ hist, int* __restrict__ sel,
+                                                           u64* __restrict__ stamps = nullptr) {
+  // (tools/probes/pool_select_probe.hip: clock stamps of workgroup 0 at the phase boundaries)
+  auto stamp = [&](int i) {
+    if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   __shared__ u64 list[PS_KMAX];          // (key << 32) | ~index  -- larger = earlier
   __shared__ u64 cand[PS_CAND];          // (key << 32) | ~index of the keys still in the race after three digits
   __shared__ int s_ncand;
@@ -229,6 +249,7 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
     shift = 16;
     __syncthreads();
   }
+  stamp(1);
   for (; shift >= 0; shift -= 4) {
     if (shift == 16 && s_eq_total <= PS_CAND) break;
     int tot[16];
@@ -288,12 +309,16 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
         for (int e = 0; e < 4; e++) {
           const unsigned key = kk[e];
           const u64 ent = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned)(q * 4 + e));
-          if (key != 0u && (key & mask) == prefix) cand[atomicAdd(&s_ncand, 1)] = ent;
-          else if ((key & mask) > prefix) list[atomicAdd(&s_gt, 1)] = ent;
+          const bool is_c = key != 0u && (key & mask) == prefix, is_g = !is_c && (key & mask) > prefix;
+          const int pc = wave_append(&s_ncand, is_c);
+          if (pc >= 0) cand[pc] = ent;
+          const int pg = wave_append(&s_gt, is_g);
+          if (pg >= 0) list[pg] = ent;
         }
       }
     }
     __syncthreads();
+    stamp(2);
     const int ncand = s_ncand;
     for (; shift >= 0; shift -= 4) {
       int tot[16];
@@ -309,6 +334,7 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
       choose(tot, shift);
     }
   }
+  stamp(3);
   const unsigned T = prefix;  // the k-th largest key; `need` of the keys equal to it are taken (lowest indices)
   const int n_gt = k - need;
   const bool all_eq = s_eq_total == need;  // every key equal to T is a winner: no index order needed among them
@@ -322,8 +348,10 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
     for (int i = tid; i < ncand; i += PS_T) {
       const u64 ent = cand[i];
       const unsigned key = (unsigned)(ent >> 32);
-      if (key > T) list[atomicAdd(&s_gt, 1)] = ent;
-      else if (all_eq && key == T) list[n_gt + atomicAdd(&s_eq, 1)] = ent;
+      const int pg = wave_append(&s_gt, key > T);
+      if (pg >= 0) list[pg] = ent;
+      const int pe = wave_append(&s_eq, all_eq && key == T);
+      if (pe >= 0) list[n_gt + pe] = ent;
     }
   } else {
   if (tid == 0) { s_gt = 0; s_eq = 0; }
@@ -343,8 +371,10 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
       for (int e = 0; e < 4; e++) {
         const unsigned key = kk[e];
         const unsigned i = (unsigned)(q * 4 + e);
-        if (key > T) list[atomicAdd(&s_gt, 1)] = ((u64)key << 32) | (u64)(0xffffffffu - i);
-        else if (all_eq && key == T) list[n_gt + atomicAdd(&s_eq, 1)] = ((u64)key << 32) | (u64)(0xffffffffu - i);
+        const int pg = wave_append(&s_gt, key > T);
+        if (pg >= 0) list[pg] = ((u64)key << 32) | (u64)(0xffffffffu - i);
+        const int pe = wave_append(&s_eq, all_eq && key == T);
+        if (pe >= 0) list[n_gt + pe] = ((u64)key << 32) | (u64)(0xffffffffu - i);
       }
     }
   }
@@ -378,6 +408,7 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
     }
   }
   __syncthreads();
+  stamp(4);
   // ---- bitonic sort, descending on (key, ~index): score descending, ties by ascending index
   int P = 1;
   while (P < k) P <<= 1;
@@ -407,7 +438,9 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
   __syncthreads();
   // ---- the winners' level rows, in pool order; a second launch spread over the chip decodes them (done here by
   // the one workgroup per image it took 27 us of a 110 us kernel)
+  stamp(5);
   for (int j = tid; j < k; j += PS_T) sel[(size_t)n * k + j] = (int)(0xffffffffu - (unsigned)(list[j] & 0xffffffffULL));
+  stamp(6);
 }
 
 __global__ __launch_bounds__(256) void pool_emit_kernel(const float* __restrict__ cls, PStrides sc,
@@ -462,7 +495,7 @@ int r3k_level_pool(const float* cls, const long long* cls_strides, const float* 
   if (hipMemsetAsync(hist, 0, (size_t)N * PH_BINS * 4, stream) != hipSuccess) return -2;
   hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)((Lpad + 255) / 256), N), dim3(256), 0, stream, cls, sc, A, C, H, W,
                      Lpad, keys, hist);
-  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, nms_pre, Lpad, keys, hist, sel);
+  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, nms_pre, Lpad, keys, hist, sel, (u64*)nullptr);
   hipLaunchKernelGGL(pool_emit_kernel, dim3((nms_pre + 255) / 256, N), dim3(256), 0, stream, cls, sc, reg, sr, anchors,
                      per_image, A, C, H, W, nms_pre, max_ratio, clamp_x, clamp_y, sel, boxes, scores, pool_rows, row_offset);
   return hipGetLastError() == hipSuccess ? 0 : -2;
