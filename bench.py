@@ -155,20 +155,42 @@ def train_custom_op_ms(tr, device):
 
 # ------------------------------------------------------------------------------------ custom ops alone
 def build_hot_workload(device, seed):
+    """What the custom-op layer of R3Det.simple_test runs per step at BATCH x 1024^2 in the channels_last model:
+    per pyramid level the FeatureRefineModule tail (one fr_module_nhwc launch), the refine head's pre-NMS pool per
+    level (r3det_level_pool: levels 0 / 1 cut at nms_pre = 2000 -> 5344 rows per image), the batched multiclass
+    NMS (v1).  Synthetic head maps: ~4 % of the (row, class) scores pass score_thr, as in the calibrated model."""
     from r3det import synthetic as syn
     from r3det.core.post_processing import CapacityHint
+    cl = torch.channels_last
+    g = torch.Generator(device=device).manual_seed(seed)
     feats, boxes = syn.fr_pyramid(BATCH, C, seed, device=device)
-    outs = [torch.empty_like(f) for f in feats]
-    pools = [syn.nms_pool(syn.R3DET_POOL, seed * 1000 + i, device=device) for i in range(BATCH)]
-    return dict(feats=feats, boxes=boxes, outs=outs, pool_boxes=torch.stack([p[0] for p in pools]),
-                pool_scores=torch.stack([p[1] for p in pools]), nms_hint=CapacityHint())
+    levels = []
+    for f, bx, st in zip(feats, boxes, syn.STRIDES):
+        H, W = f.shape[-2:]
+
+        def mk(*shape, scale=1.0, shift=0.0):
+            return (torch.randn(*shape, device=device, generator=g) * scale + shift).contiguous(memory_format=cl)
+        levels.append(dict(a=mk(*f.shape), b=mk(*f.shape), res=f.contiguous(memory_format=cl),
+                           out=torch.empty_like(f, memory_format=cl), boxes=bx, scale=1.0 / st,
+                           cls=mk(BATCH, 15, H, W, scale=1.5, shift=-5.5), reg=mk(BATCH, 5, H, W, scale=0.1),
+                           rois=bx.view(BATCH, H * W, 5).contiguous(), rows=min(2000, H * W)))
+    n = sum(lv["rows"] for lv in levels)
+    return dict(levels=levels, bias=torch.randn(C, device=device, generator=g),
+                pool_boxes=torch.empty(BATCH, n, 5, device=device), pool_scores=torch.empty(BATCH, n, 16, device=device),
+                nms_hint=CapacityHint())
 
 
 def hot_path_step(wl):
     from r3det.core.post_processing import multiclass_nms_rotated_batch
-    from r3det.ops.feature_refine import fr_forward_levels
-    from r3det.synthetic import STRIDES
-    fr_forward_levels(wl["feats"], wl["boxes"], [1.0 / s for s in STRIDES], 1, wl["outs"])
+    from r3det.ops import fr_boxes
+    from r3det.ops.feature_refine import fr_module_nhwc
+    for lv in wl["levels"]:
+        fr_module_nhwc(lv["a"], lv["b"], wl["bias"], wl["bias"], lv["res"], lv["boxes"], lv["scale"], 1, lv["out"])
+    off = 0
+    for lv in wl["levels"]:
+        fr_boxes.level_pool(lv["cls"], lv["reg"], lv["rois"], 1, 15, 2000, (IMG, IMG), wl["pool_boxes"],
+                            wl["pool_scores"], off)
+        off += lv["rows"]
     res = multiclass_nms_rotated_batch(wl["pool_boxes"], wl["pool_scores"], SCORE_THR, NMS_CFG, MAX_PER_IMG,
                                        hint=wl["nms_hint"])
     return sum(d.size(0) for d, _ in res)
@@ -197,38 +219,104 @@ def b_nms(n):
     return 24 * n + 8 * n * w + 8 * n        # boxes + upper-triangle mask written and read + keep
 
 
+def _roof(nbytes, dt, bound="hbm"):
+    gbs = nbytes / dt / 1e9
+    return {"bound": bound, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 5)}
+
+
+def b_fr(N, hw, points=1):
+    return 2 * 4 * N * C * hw + 20 * N * hw     # one read + one write per element, one box per position
+
+
 def op_rates(device):
-    """Op-level rates quoted by BASELINE.json's metric (Mpairs/s, Mboxes/s) with one roofline entry per
-    op: algorithmic bytes (SURVEY 8d) / time per call (wall clock around back-to-back calls, synchronised;
-    the per-kernel durations of the same calls are in profiles/*_iou_* and *_nms_*)."""
+    """Op-level rates quoted by BASELINE.json's metric (Mpairs/s, Mboxes/s) and SURVEY 8d's micro-benchmark list,
+    one roofline entry per row: algorithmic bytes / time per call (wall clock around back-to-back
+    calls, synchronised, so host launch gaps are inside; the per-kernel durations of the same calls are in
+    profiles/r03_*).  FR rows rotate over buffer sets of >= 0.6 GB where the level is large enough, so their inputs
+    come from HBM, not from the 256 MiB Infinity Cache."""
     from r3det import synthetic as syn
-    from r3det.ops import batched_rnms, rbbox_iou
+    from r3det.ops import batched_rnms, obb_batched_nms, obb_overlaps, rbbox_iou
     out = {}
     anchors = syn.anchor_grid(device=device)
     gt = syn.dota_like_rboxes(128, 5, device=device)
+    gt512 = syn.dota_like_rboxes(512, 6, device=device)
     refined = torch.cat([syn.fr_level_boxes(1, IMG // s, IMG // s, s, 50 + i, device=device)
                          for i, s in enumerate(syn.STRIDES)])
     a, g = syn.rand_rboxes(1000, 0, device=device), syn.rand_rboxes(128, 1, device=device)
-    for name, b1, b2, reps in (("128x196416", gt, anchors, 20), ("128x21824", gt, refined, 50), ("1000x128", a, g, 50)):
-        dt = timeit(lambda: rbbox_iou(b1, b2), reps)
+    for name, fn, b1, b2, reps in (("iou_v1_128x196416", rbbox_iou, gt, anchors, 20),
+                                   ("iou_v1_512x196416", rbbox_iou, gt512, anchors, 10),
+                                   ("iou_v1_128x21824", rbbox_iou, gt, refined, 50),
+                                   ("iou_v1_1000x128", rbbox_iou, a, g, 50),
+                                   ("iou_v3_128x196416", obb_overlaps, gt, anchors, 10)):
+        dt = timeit(lambda: fn(b1, b2), reps)
         m, n = b1.size(0), b2.size(0)
-        gbs = b_iou(m, n) / dt / 1e9
-        out[f"iou_v1_{name}"] = {"Mpairs_s": round(m * n / dt / 1e6, 1), "us_per_call": round(dt * 1e6, 2),
-                                 "alg_bytes": b_iou(m, n),
-                                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                              "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}}
-    for n in (2000, 5344, 8576):
+        out[name] = {"Mpairs_s": round(m * n / dt / 1e6, 1), "us_per_call": round(dt * 1e6, 2),
+                     "alg_bytes": b_iou(m, n), "roofline": _roof(b_iou(m, n), dt)}
+    for n, fn, tag in ((2000, batched_rnms, "v1"), (5344, batched_rnms, "v1"), (8576, batched_rnms, "v1"),
+                       (32768, batched_rnms, "v1"), (8576, obb_batched_nms, "v3")):
         mb, ms = syn.nms_pool(n * 10 // 6 + 64, 77 + n, device=device)
         sc, lab = ms[:, :-1].max(1)
         idx = torch.nonzero(sc > SCORE_THR).squeeze(1)[:n]
         b, s, l = mb[idx].contiguous(), sc[idx].contiguous(), lab[idx].contiguous()
-        dt = timeit(lambda: batched_rnms(b, s, l, 0.1), 10)
+        dt = timeit(lambda: fn(b, s, l, 0.1), 10)
         k = b.size(0)
-        gbs = b_nms(k) / dt / 1e9
-        out[f"nms_v1_{k}"] = {"Mboxes_s": round(k / dt / 1e6, 3), "us_per_call": round(dt * 1e6, 1),
-                              "alg_bytes": b_nms(k), "what": "batched_rnms (15 classes) incl. its host read of the count",
-                              "roofline": {"bound": "hbm (latency-bound in practice)", "achieved": round(gbs, 2),
-                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5)}}
+        out[f"nms_{tag}_{k}"] = {"Mboxes_s": round(k / dt / 1e6, 3), "us_per_call": round(dt * 1e6, 1),
+                                 "alg_bytes": b_nms(k),
+                                 "what": f"{fn.__name__} (15 classes) incl. its host read of the count",
+                                 "roofline": _roof(b_nms(k), dt, "hbm (latency-bound in practice)")}
+    out.update(fr_rates(device))
+    return out
+
+
+def fr_rates(device):
+    """FR forward per level and fused-5-level, N in {1, 2, 4, 8}, points in {1, 5}; FR backward with the
+    same B_fr.  NCHW = the reference's layout (r3det_feature_refine_forward / _backward_ws), NHWC = channels_last
+    (r3det_feature_refine_forward_nhwc / _backward_nhwc)."""
+    from r3det import synthetic as syn
+    from r3det.ops.feature_refine import fr_backward, fr_backward_nhwc, fr_forward, fr_forward_nhwc
+    cl = torch.channels_last
+    out = {}
+
+    def run(name, N, lvls, points, fn, nhwc, reps=10):
+        feats, boxes = syn.fr_pyramid(N, C, 31, device=device)
+        feats, boxes = [feats[i] for i in lvls], [boxes[i] for i in lvls]
+        scales = [1.0 / syn.STRIDES[i] for i in lvls]
+        per_set = 2 * 4 * sum(f.numel() for f in feats)
+        nset = max(2, min(16, int(6e8 // per_set) + 1))
+        sets = []
+        for _ in range(nset):
+            xs = [torch.randn_like(f) for f in feats]
+            if nhwc:
+                xs = [x.contiguous(memory_format=cl) for x in xs]
+            sets.append((xs, [torch.empty_like(x) for x in xs]))
+        state = [0]
+
+        def call():
+            xs, os_ = sets[state[0] % nset]
+            state[0] += 1
+            for x, o, b, sc in zip(xs, os_, boxes, scales):
+                fn(x, b, sc, points, o)
+        dt = timeit(call, reps)
+        hw = sum(f.shape[-1] * f.shape[-2] for f in feats)
+        nb = b_fr(N, hw, points)
+        out[name] = {"us_per_call": round(dt * 1e6, 1), "alg_bytes": nb, "launch_groups": len(lvls),
+                     "rotating_MB": round(per_set * nset / 1e6), "roofline": _roof(nb, dt)}
+        del sets
+
+    fwd = {False: lambda x, b, sc, p, o: fr_forward(x, b, sc, p, o),
+           True: lambda x, b, sc, p, o: fr_forward_nhwc(x, b, sc, p, o)}
+    bwd = {False: lambda x, b, sc, p, o: fr_backward(x, b, sc, p, o, overwrite=True),
+           True: lambda x, b, sc, p, o: fr_backward_nhwc(x, b, sc, p, o, overwrite=True)}
+    for nhwc, lay in ((False, "nchw"), (True, "nhwc")):
+        for points in (1, 5):
+            for lvl in range(5):
+                run(f"fr_fwd_{lay}_p{points}_N4_L{lvl}", 4, [lvl], points, fwd[nhwc], nhwc)
+            for N in (1, 2, 4, 8):
+                run(f"fr_fwd_{lay}_p{points}_N{N}_5lvl", N, list(range(5)), points, fwd[nhwc], nhwc)
+        for N in (2, 4):
+            for lvls, tag in (([0], "L0"), ([1], "L1"), (list(range(5)), "5lvl")):
+                run(f"fr_bwd_{lay}_p1_N{N}_{tag}", N, lvls, 1, bwd[nhwc], nhwc)
     return out
 
 
@@ -282,10 +370,14 @@ def cpu_baseline():
         t = clock(lambda: O.ref_v1_iou_mat(gt, sample))
         per_op["iou_v1_128x196416"] = {"Mpairs_s_1thread": round(128 * len(sample) / t / 1e6, 3), "kind": "reference",
                                        "sample": f"128 x {len(sample)} (every 12th anchor)"}
-    t = clock(lambda: O.iou_mat(O.V1, a, g, threads=cores))
-    per_op.setdefault("iou_v1_1000x128", {})[f"Mpairs_s_openmp_{cores}"] = round(128000 / t / 1e6, 3)
-    t = clock(lambda: O.iou_mat(O.V1, gt, anchors, threads=cores))
-    per_op.setdefault("iou_v1_128x196416", {})[f"Mpairs_s_openmp_{cores}"] = round(128 * len(anchors) / t / 1e6, 3)
+    # OpenMP over rows: no more threads than rows, and at most 64 for the 128 000-pair case (256 threads on it
+    # measured thread start-up, not the op: 1.03 Mpairs/s against 11.4 on one thread)
+    th = min(cores, 64)
+    t = clock(lambda: O.iou_mat(O.V1, a, g, threads=th))
+    per_op.setdefault("iou_v1_1000x128", {})[f"Mpairs_s_openmp_{th}"] = round(128000 / t / 1e6, 3)
+    th = min(cores, 128)
+    t = clock(lambda: O.iou_mat(O.V1, gt, anchors, threads=th))
+    per_op.setdefault("iou_v1_128x196416", {})[f"Mpairs_s_openmp_{th}"] = round(128 * len(anchors) / t / 1e6, 3)
     for n in (2000, 5344, 8576):
         pb, ps = syn.nms_pool(n * 10 // 6 + 64, 77 + n)
         sc, lab = ps[:, :-1].max(1)
@@ -299,7 +391,9 @@ def cpu_baseline():
                                       "kind": "reference" if use_ref else "port"}
     return {"value": round(1.0 / dt, 3), "unit": "img/s", "cores": cores,
             "kind": "port",
-            "compare_with": "hot_path.img_s (the custom ops alone on the GPU), not with `value` (full model)",
+            "compare_with": "hot_path.img_s (the custom ops alone on the GPU; its launches also carry the module's "
+                            "elementwise adds and the per-level top-k pool, which this CPU sample does not run), not "
+                            "with `value` (full model)",
             "sample": f"{reps} x custom-op hot path of ONE image (no convs): FR forward 5 levels N=1 C=256 on "
                       f"{cores} threads [oracle port; the reference has no CPU FR] + NMS v1 on a 5344-box "
                       f"pool, 1 thread [{'reference rnms_cpu via oracle/_ref' if use_ref else 'oracle port'}]",
@@ -448,6 +542,69 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
+    H = W = 128
+    # The roofline launch is the FeatureRefineModule tail on channels_last memory (r3det_feature_refine_module_nhwc):
+    # conv_a, conv_b and the residual read once, the output written once = 16 B per element (SURVEY 8d's 8 B per
+    # element for the bare sampler + the module's two extra input streams that the launch folds in), plus the
+    # 20-byte box per position.
+    alg_bytes = 4 * 4 * BATCH * C * H * W + 20 * BATCH * H * W
+
+    # ---- the custom ops on their own, BEFORE the model exists (round 1 / 2 measured them after `del model;
+    # empty_cache()` and twice met one ~85 ms host-side launch stall right there: tools/hip_trace_slow.py)
+    hot, alone_rec, ops = None, None, None
+    if rank == 0 and not args.model_only:
+        phase("hot path (custom ops alone)")
+        wl = build_hot_workload(device, seed=7)
+        per, allocs = [], []
+        for i in range(3 + 30):
+            s0 = torch.cuda.memory_stats(device)["num_device_alloc"]
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            hot_path_step(wl)
+            torch.cuda.synchronize()
+            if i >= 3:
+                per.append(time.perf_counter() - t)
+                allocs.append(torch.cuda.memory_stats(device)["num_device_alloc"] - s0)
+        worst = max(range(len(per)), key=lambda i: per[i])
+        srt = sorted(per)
+        dt = srt[len(srt) // 2]
+        hot = {"what": "the custom ops of one R3Det.simple_test step, alone, same shapes (N=4, C=256, channels_last): "
+                       "FeatureRefineModule tail x5 levels (fr_module_nhwc) + refine-head pool x5 levels "
+                       "(r3det_level_pool, 5344 rows / image) + batched multiclass_nms_rotated (v1)",
+               "ms_per_step": round(dt * 1e3, 3), "img_s": round(BATCH / dt, 1),
+               "ms_per_step_mean": round(sum(per) / len(per) * 1e3, 3), "steps": len(per),
+               "slowest_step": {"index": worst, "ms": round(per[worst] * 1e3, 3), "device_allocs_in_it": allocs[worst]},
+               "measured": "before the model is built"}
+        # the roofline kernel alone, rotating over three buffer sets (3 x 268 MB): every launch reads and
+        # writes lines that are NOT in the 256 MiB Infinity Cache -> an HBM figure
+        from r3det.ops.feature_refine import fr_module_nhwc
+        cl = torch.channels_last
+        lv0 = wl["levels"][0]
+        sets = [tuple(torch.randn(lv0["a"].shape, device=device).contiguous(memory_format=cl) for _ in range(4))
+                for _ in range(3)]
+        state = [0]
+
+        def rot():
+            a, b, r, o = sets[state[0] % 3]
+            state[0] += 1
+            fr_module_nhwc(a, b, wl["bias"], wl["bias"], r, lv0["boxes"], 1.0 / 8, 1, o)
+        _C.fr_profile_read()
+        _C.set_option("fr_profile", 2)
+        timeit(rot, 20, warm=3)
+        _C.set_option("fr_profile", 0)
+        alone = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
+        if alone:
+            us = sum(r[4] for r in alone) / len(alone)
+            alone_rec = {"avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
+                         "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
+        del sets, wl
+        if not args.no_ops:
+            phase("op rates")
+            ops = op_rates(device)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
     phase("infer: build + calibrate")
     model, img = build_model(device, seed=100 + rank)
     phase("infer: warm-up + timed steps")
@@ -469,14 +626,14 @@ def main():
         # ~4 us longer than rocprofv3's duration of the same kernel (profiles/: same command under the
         # profiler), so `achieved` errs on the low side.
         span_us = sum(r[4] for r in recs) / max(1, len(recs))
-        H = W = 128
-        # The launch is the FeatureRefineModule tail on channels_last memory (r3det_feature_refine_module_nhwc):
-        # conv_a, conv_b and the residual read once, the output written once = 16 B per element (SURVEY 8d's 8 B per
-        # element for the bare sampler + the module's two extra input streams that the launch folds in), plus the
-        # 20-byte box per position.
-        alg_bytes = 4 * 4 * BATCH * C * H * W + 20 * BATCH * H * W
-        achieved = alg_bytes / (span_us * 1e-6) / 1e9 if recs else 0.0
+        in_model = alg_bytes / (span_us * 1e-6) / 1e9 if recs else 0.0
         traffic, traffic_src = load_traffic()
+        # roofline.achieved / frac: the launch on rotating buffers beyond the Infinity Cache (an HBM figure, the same
+        # measurement profiles/r03_fr_nhwc_kernel_stats.txt holds under rocprofv3); the launch inside the timed model
+        # steps reads what the convolutions just wrote -- partly from the 256 MiB Infinity Cache -- and is reported
+        # next to it as in_model_l3_assisted.  With --model-only only the in-model figure exists.
+        head = alone_rec or {"avg_launch_us": round(span_us, 2), "achieved": round(in_model, 1),
+                             "frac": round(in_model / HBM_PEAK_GBS, 4), "launches_timed": len(recs)}
         line = dict(common, **{
             "metric": "img/s, R3Det R50-FPN 1024x1024 inference (r3det_r50_fpn_1x v1)",
             "value": round(world * BATCH * args.steps / elapsed, 2),
@@ -489,92 +646,35 @@ def main():
                                    "to ~1 % candidates",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "nms_type": "v1",
                        "parallelism": f"image-parallel x{world}, all_gather of detections"},
-            "roofline": {"bound": "hbm", "kernel": "fr_forward_nhwc_occ<true,true> = the FeatureRefineModule tail at level 0 "
-                                                   "(4x256x128x128, channels_last): (conv_a + bias) + (conv_b + bias), sampler, "
-                                                   "residual in one launch, 3 reads + 1 write per element; duration = the "
-                                                   "launch's own start/stop HIP events (hipExtLaunchKernelGGL), timed steps",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_us": round(span_us, 2),
-                         "launches_timed": len(recs)},
+            "roofline": {"bound": "hbm",
+                         "kernel": "fr_forward_nhwc_occ<true,true,6> = the FeatureRefineModule tail at level 0 "
+                                   "(4x256x128x128, channels_last): (conv_a + bias) + (conv_b + bias), sampler, residual in "
+                                   "one launch, 3 reads + 1 write per element; duration = the launch's own start/stop HIP "
+                                   "events (hipExtLaunchKernelGGL)",
+                         "measured_on": ("the launch alone over 3 rotating buffer sets (0.8 GB: beyond the 256 MiB "
+                                         "Infinity Cache)") if alone_rec else "inside the timed model steps (--model-only)",
+                         "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
+                         "avg_launch_us": head["avg_launch_us"], "launches_timed": head["launches_timed"],
+                         "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes,
+                         "sampler_only_frac": round(head["frac"] * (2 * 4 * BATCH * C * H * W + 20 * BATCH * H * W)
+                                                    / alg_bytes, 4),
+                         "sampler_only_note": "the same launch priced at SURVEY 8d's B_fr (1 read + 1 write per element: "
+                                              "135.5 MB) instead of the 16 B / element the fused launch has to move",
+                         "in_model_l3_assisted": {"avg_launch_us": round(span_us, 2), "achieved": round(in_model, 1),
+                                                  "frac": round(in_model / HBM_PEAK_GBS, 4), "launches_timed": len(recs),
+                                                  "what": "the same launch inside the timed model steps: its three "
+                                                          "inputs were just written by the convolutions (Infinity "
+                                                          "Cache-assisted, not an HBM fraction)"}},
             "kept_per_image": [int(c) for c in counts.tolist()],
         })
+        if hot is not None:
+            line["hot_path"] = hot
+        if ops is not None:
+            line["ops"] = ops
         del model, img
-        if not args.model_only:
-            import gc
-            gc.collect()              # the module graph has reference cycles: free it now, not in the timed loop
-            torch.cuda.empty_cache()  # drop the model's cached blocks: the op-level runs start clean
-            phase("hot path (custom ops alone)")
-            wl = build_hot_workload(device, seed=7)
-            per, allocs = [], []
-            for i in range(3 + 30):
-                s0 = torch.cuda.memory_stats(device)["num_device_alloc"]
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                hot_path_step(wl)
-                torch.cuda.synchronize()
-                if i >= 3:
-                    per.append(time.perf_counter() - t)
-                    allocs.append(torch.cuda.memory_stats(device)["num_device_alloc"] - s0)
-            worst = max(range(len(per)), key=lambda i: per[i])
-            srt = sorted(per)
-            dt = srt[len(srt) // 2]
-            line["hot_path"] = {"what": "custom ops only, same shapes: FR sampler x5 levels (N=4, C=256) + batched "
-                                        "multiclass_nms_rotated(v1) on 4 x 5344-box pools",
-                                "ms_per_step": round(dt * 1e3, 3), "img_s": round(BATCH / dt, 1),
-                                "ms_per_step_mean": round(sum(per) / len(per) * 1e3, 3), "steps": len(per),
-                                "slowest_step": {"index": worst, "ms": round(per[worst] * 1e3, 3),
-                                                 "device_allocs_in_it": allocs[worst]}}
-            ctx = {}
-            for mode, key in ((2, "span"), (1, "each")):
-                _C.fr_profile_read()
-                _C.set_option("fr_profile", mode)
-                timeit(lambda: hot_path_step(wl), 20, warm=0)
-                _C.set_option("fr_profile", 0)
-                ctx[key] = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
-            if ctx["span"]:
-                us = sum(r[4] for r in ctx["span"]) / len(ctx["span"])
-                alg_plain = 2 * 4 * BATCH * C * H * W + 8 * BATCH * H * W  # the sampler alone: 1 read + 1 write
-                line["roofline"]["hot_path_context"] = {
-                    "kernel": "the plain sampler (r3det_feature_refine_forward), 1 read + 1 write per element, in the "
-                              "custom-op loop; its 135 MB working set stays in the 256 MiB Infinity Cache between steps: "
-                              "an L3-assisted figure, not an HBM fraction",
-                    "alg_bytes_per_launch": alg_plain,
-                    "avg_launch_us": round(us, 2), "achieved": round(alg_plain / us / 1e3, 1),
-                    "launches_timed": len(ctx["span"]),
-                    "table_kernel_us_own_events": round(sum(r[2] for r in ctx["each"]) / max(1, len(ctx["each"])), 2),
-                    "cell_kernel_us_own_events": round(sum(r[3] for r in ctx["each"]) / max(1, len(ctx["each"])), 2)}
-            # the roofline kernel alone, rotating over three buffer sets (3 x 268 MB): every launch reads and
-            # writes lines that are NOT in the 256 MiB Infinity Cache -> an HBM figure
-            from r3det.ops.feature_refine import fr_module_nhwc
-            cl = torch.channels_last
-            b0 = wl["boxes"][0]
-            shape = wl["feats"][0].shape
-            sets = [tuple(torch.randn(shape, device=device).contiguous(memory_format=cl) for _ in range(4))
-                    for _ in range(3)]
-            bias = torch.randn(C, device=device)
-            state = [0]
-
-            def rot():
-                a, b, r, o = sets[state[0] % 3]
-                state[0] += 1
-                fr_module_nhwc(a, b, bias, bias, r, b0, 1.0 / 8, 1, o)
-            _C.fr_profile_read()
-            _C.set_option("fr_profile", 2)
-            timeit(rot, 20, warm=3)
-            _C.set_option("fr_profile", 0)
-            alone = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
-            if alone:
-                us = sum(r[4] for r in alone) / len(alone)
-                line["roofline"]["kernel_alone_hbm"] = {
-                    "what": "the same launch repeated on its own over 3 rotating buffer sets (0.8 GB: beyond the "
-                            "Infinity Cache)",
-                    "avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
-                    "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
-            del sets, wl
-        if not args.no_ops:
-            phase("op rates")
-            line["ops"] = op_rates(device)
+        import gc
+        gc.collect()              # the module graph has reference cycles: free it now
+        torch.cuda.empty_cache()
         if world == 1 and not args.no_extras:
             torch.cuda.empty_cache()
             ex = argparse.Namespace(steps=5, warmup=3)
