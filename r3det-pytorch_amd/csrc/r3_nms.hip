@@ -993,74 +993,14 @@ __global__ __launch_bounds__(SEL_T) void mc_write_kernel(const float* __restrict
   }
 }
 
-// also zeroes the overflow masks + side tables of all images (`zero16` 16-byte words from `zero`): one launch less
-// than a memset node in front of the pipeline (a launch that does next to nothing still takes ~4.5 us of the stream)
-__global__ __launch_bounds__(256) void mc_begin_kernel(const int* __restrict__ counts, int cap, int cand_stride,
-                                                       int* __restrict__ cand_rank, int* __restrict__ ccounts,
-                                                       uint4* __restrict__ zero, size_t zero16) {
-  const int img = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0) ccounts[img] = min(counts[img], cap);
-  if (c < cap && c < cand_stride) cand_rank[(size_t)img * cand_stride + c] = 0;
-  const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
-  for (size_t k = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; k < zero16; k += nthreads)
-    zero[k] = make_uint4(0u, 0u, 0u, 0u);
-}
-
 // Stable descending sort of an image's candidates by COUNTING: rank(i) = #{j : s_j > s_i or
 // (s_j == s_i and j < i)} = position of i under torch.sort(descending=True, stable=True).
 // O(M^2) compares, but spread over the chip in one launch with device-side M (M = 3 k: ~5 us,
 // where a segmented radix sort of 4 segments takes 97 us on one workgroup each).
-constexpr int RK_T = 256, RK_J = 256;
 
 __device__ __forceinline__ unsigned order_key(float f) {  // monotone: a < b  <=>  key(a) < key(b)
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__global__ __launch_bounds__(RK_T) void mc_rank_kernel(const float* __restrict__ cand_score, int cand_stride,
-                                                       const int* __restrict__ counts, int* __restrict__ cand_rank) {
-  __shared__ __attribute__((aligned(16))) unsigned keys[RK_J];
-  const int img = blockIdx.z, M = counts[img];
-  const int i0 = blockIdx.x * RK_T, j0 = blockIdx.y * RK_J;
-  if (i0 >= M || j0 >= M) return;
-  const float* sc = cand_score + (size_t)img * cand_stride;
-  const int jn = min(RK_J, M - j0);
-  // key 0 (the bit pattern of a NaN, never a candidate) pads the tile: it is below every real key
-  for (int j = threadIdx.x; j < RK_J; j += RK_T) keys[j] = j < jn ? order_key(sc[j0 + j]) : 0u;
-  __syncthreads();
-  const int i = i0 + threadIdx.x;
-  if (i >= M) return;
-  const unsigned ui = order_key(sc[i]);
-  const int before = i - j0;  // j < before  <=>  candidate j0 + j precedes i
-  int cnt = 0;
-  const uint4* k4 = reinterpret_cast<const uint4*>(keys);
-  const int jn4 = (jn + 3) >> 2;
-  // A tile entirely before / after this workgroup's candidates needs one compare per key (ties
-  // count / do not count); only the tile on the diagonal needs the per-lane tie rule.
-  if (j0 + RK_J <= i0) {
-#pragma unroll 8
-    for (int q = 0; q < jn4; q++) {  // broadcast b128 reads: 4 keys per LDS instruction
-      const uint4 u = k4[q];
-      cnt += (u.x >= ui) + (u.y >= ui) + (u.z >= ui) + (u.w >= ui);
-    }
-  } else if (j0 >= i0 + RK_T) {
-#pragma unroll 8
-    for (int q = 0; q < jn4; q++) {
-      const uint4 u = k4[q];
-      cnt += (u.x > ui) + (u.y > ui) + (u.z > ui) + (u.w > ui);
-    }
-  } else {
-#pragma unroll 4
-    for (int q = 0; q < jn4; q++) {
-      const uint4 u = k4[q];
-      const int j = q * 4;
-      cnt += (u.x > ui) | ((u.x == ui) & (j < before));
-      cnt += (u.y > ui) | ((u.y == ui) & (j + 1 < before));
-      cnt += (u.z > ui) | ((u.z == ui) & (j + 2 < before));
-      cnt += (u.w > ui) | ((u.w == ui) & (j + 3 < before));
-    }
-  }
-  if (cnt) atomicAdd(&cand_rank[(size_t)img * cand_stride + i], cnt);
 }
 
 // v3 class offsets (obb_batched_nms, nms_rotated_wrapper.py:78-98): label * (hbb.max() - hbb.min() + 1)
@@ -1068,11 +1008,11 @@ __global__ __launch_bounds__(RK_T) void mc_rank_kernel(const float* __restrict__
 // the torch ops it mirrors).  One workgroup per image; extent[img] = (max - min) + 1.
 __global__ __launch_bounds__(1024) void mc_hbb_extent_kernel(const float* __restrict__ boxes, int n,
                                                              const int* __restrict__ cand_row, int cand_stride,
-                                                             const int* __restrict__ counts,
+                                                             const int* __restrict__ counts, int cap,
                                                              float* __restrict__ extent) {
   __shared__ float smin[16], smax[16];
   const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int M = counts[img];
+  const int M = min(counts[img], cap);
   float lo = INFINITY, hi = -INFINITY;
   for (int c = tid; c < M; c += 1024) {
     const float* b = boxes + ((size_t)img * n + cand_row[(size_t)img * cand_stride + c]) * 5;
@@ -1106,22 +1046,97 @@ __global__ __launch_bounds__(1024) void mc_hbb_extent_kernel(const float* __rest
 //   GEOM 3: x, y += label * extent; boxes thinner than 1e-3 never take part (obb_nms removes them
 //           before its kernel, nms_rotated_wrapper.py:40-46): flagged dead and moved out of reach
 //   GEOM 2: no offsets, the label rides in the record (ml_nms_rotated: IoU = 0 across labels)
+// begin + rank + prepare in ONE launch (round 2: three launches of <= 12 us of work that each took their ~4.5 us
+// of the stream, and 0.3 M atomics into the rank array).  A workgroup owns RP_C = 32 candidates of one image and
+// ranks them itself against ALL M candidates, tile by tile through LDS (rank by counting, as the rank kernel it
+// replaces): RP_P threads per candidate, each a slice of every tile -- M = 8576 is 1072 workgroups of 268 compares
+// per thread (measured at 8576: 256 candidates per workgroup, one thread each = 34 workgroups: 84 us; 32 candidates
+// x 8 threads = 268 workgroups: 22 us).  Then the records go to their
+// ranks; on the way the grid zeroes the overflow masks + side tables and the queue counters the next kernels expect.
+constexpr int RP_TJ = 1024;  // keys per LDS tile
+constexpr int RP_C = 8;      // candidates per workgroup
+constexpr int RP_P = 32;     // threads per candidate
+
 template <int GEOM>
-__global__ __launch_bounds__(256) void mc_prepare_kernel(const float* __restrict__ boxes, int n,
-                                                         const int* __restrict__ cand_row,
-                                                         const int* __restrict__ cand_label,
-                                                         const int* __restrict__ cand_rank, int cand_stride,
-                                                         const int* __restrict__ counts,
-                                                         const float* __restrict__ scale, BoxRec* __restrict__ recs,
-                                                         size_t recs_stride, int* __restrict__ sorted_vals,
-                                                         uint8_t* __restrict__ dead, unsigned* __restrict__ counter,
-                                                         size_t counter_stride) {
-  const int img = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  for (int k = c; k < Q_CTL_WORDS; k += gridDim.x * 256) counter[img * counter_stride + k] = 0;
-  if (c >= counts[img]) return;
+__global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
+    const float* __restrict__ boxes, int n, const int* __restrict__ cand_row, const int* __restrict__ cand_label,
+    const float* __restrict__ cand_score, int cand_stride, const int* __restrict__ counts_raw, int cap,
+    int* __restrict__ ccounts, const float* __restrict__ scale, BoxRec* __restrict__ recs, size_t recs_stride,
+    int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, unsigned* __restrict__ counter, size_t counter_stride,
+    uint4* __restrict__ zero, size_t zero16) {
+  __shared__ __attribute__((aligned(16))) unsigned keys[RP_TJ];
+  __shared__ int partial[RP_P][RP_C];
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const int M = min(counts_raw[img], cap);  // (an image with more candidates than cap is its first cap candidates)
+  if (blockIdx.x == 0 && tid == 0) ccounts[img] = M;
+  {
+    const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
+    for (size_t k = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; k < zero16; k += nthreads)
+      zero[k] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  for (int k = blockIdx.x * 256 + tid; k < Q_CTL_WORDS; k += gridDim.x * 256) counter[img * counter_stride + k] = 0;
+  const int i0 = blockIdx.x * RP_C;
+  if (i0 >= M) return;
   const size_t cbase = (size_t)img * cand_stride;
-  const int pos = cand_rank[cbase + c];
+  const float* sc = cand_score + cbase;
+  const int ci = tid & (RP_C - 1), part = tid / RP_C;
+  const int c = i0 + ci;
+  const bool live = c < M;
+  const unsigned ui = live ? order_key(sc[c]) : 0xffffffffu;
+  int cnt = 0;
+  constexpr int SL4 = RP_TJ / RP_P / 4;  // uint4 reads of a thread per tile
+  const uint4* k4 = reinterpret_cast<const uint4*>(keys) + part * SL4;
+  // (the next tile's scores are requested before the current tile is counted: a tile is 4 keys per thread)
+  float nxt[RP_TJ / 256];
+#pragma unroll
+  for (int u = 0; u < RP_TJ / 256; u++) nxt[u] = (u * 256 + tid) < M ? sc[u * 256 + tid] : 0.f;
+  for (int j0 = 0; j0 < M; j0 += RP_TJ) {
+    const int jn = min(RP_TJ, M - j0);
+    __syncthreads();
+    // key 0 (the bit pattern of a NaN, never a candidate) pads the tile: it is below every real key
+#pragma unroll
+    for (int u = 0; u < RP_TJ / 256; u++) keys[u * 256 + tid] = (u * 256 + tid) < jn ? order_key(nxt[u]) : 0u;
+#pragma unroll
+    for (int u = 0; u < RP_TJ / 256; u++) {
+      const int j = j0 + RP_TJ + u * 256 + tid;
+      nxt[u] = j < M ? sc[j] : 0.f;
+    }
+    __syncthreads();
+    // a tile entirely before / after this workgroup's candidates needs one compare per key (ties count / do not
+    // count); only a tile that overlaps them needs the per-lane tie rule
+    if (j0 + RP_TJ <= i0) {
+#pragma unroll 8
+      for (int q = 0; q < SL4; q++) {  // (half-wave broadcast b128 reads: 4 keys per LDS instruction)
+        const uint4 u = k4[q];
+        cnt += (u.x >= ui) + (u.y >= ui) + (u.z >= ui) + (u.w >= ui);
+      }
+    } else if (j0 >= i0 + RP_C) {
+#pragma unroll 8
+      for (int q = 0; q < SL4; q++) {
+        const uint4 u = k4[q];
+        cnt += (u.x > ui) + (u.y > ui) + (u.z > ui) + (u.w > ui);
+      }
+    } else {
+      const int before = c - j0 - part * (RP_TJ / RP_P);  // j < before  <=>  this slice's key j precedes c
+#pragma unroll 4
+      for (int q = 0; q < SL4; q++) {
+        const uint4 u = k4[q];
+        const int j = q * 4;
+        cnt += (u.x > ui) | ((u.x == ui) & (j < before));
+        cnt += (u.y > ui) | ((u.y == ui) & (j + 1 < before));
+        cnt += (u.z > ui) | ((u.z == ui) & (j + 2 < before));
+        cnt += (u.w > ui) | ((u.w == ui) & (j + 3 < before));
+      }
+    }
+  }
+  partial[part][ci] = cnt;
+  __syncthreads();
+  if (part != 0) return;
+  cnt = 0;
+#pragma unroll
+  for (int q = 0; q < RP_P; q++) cnt += partial[q][ci];
+  if (!live) return;
+  const int pos = cnt;
   const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
   const float lab = (float)cand_label[cbase + c];
   float d[5] = {b[0], b[1], b[2], b[3], b[4]};
@@ -1366,22 +1381,17 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   // or checks them afterwards and calls again)
   // (mask + side tables are adjacent and 256-byte aligned: zeroed by the begin kernel, whose grid is widened so that
   // the fill runs at memory speed)
-  const int bx = (cap + 255) / 256;
-  const int zx = (int)((L.zero_bytes / 16 / 256 / 8 + B - 1) / B);  // ~8 stores per thread
-  hipLaunchKernelGGL(mc_begin_kernel, dim3(zx > bx ? (zx > 2048 ? 2048 : zx) : bx, B), dim3(256), 0, stream, counts, cap,
-                     S, cand_rank, L.ccounts, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16);
-  counts = L.ccounts;
-  hipLaunchKernelGGL(mc_rank_kernel, dim3((cap + RK_T - 1) / RK_T, (cap + RK_J - 1) / RK_J, B), dim3(RK_T), 0, stream,
-                     cand_score, S, counts, cand_rank);
-  const dim3 pgrid((cap + 255) / 256, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
+  const dim3 pgrid((cap + RP_C - 1) / RP_C, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
   int dblocks = drain_blocks(L.qstride);
   if (dblocks > 2048 / B) dblocks = 2048 / B > 0 ? 2048 / B : 1;  // B images share the chip
   const dim3 dgrid(dblocks, 1, B);
-  if (geom == 3)
-    hipLaunchKernelGGL(mc_hbb_extent_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, S, counts, L.extent);
+  if (geom == 3)  // (reads the raw counts and clamps them itself: the clamped copy is written by the next kernel)
+    hipLaunchKernelGGL(mc_hbb_extent_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, S, counts, cap, L.extent);
+  (void)cand_rank;  // (scratch of the three-launch form of round 2; kept in the signature)
 #define R3_MC(GEOM, LABEL, SCALE)                                                                                  \
-  hipLaunchKernelGGL(mc_prepare_kernel<GEOM>, pgrid, dim3(256), 0, stream, boxes, n, cand_row, cand_label,        \
-                     cand_rank, S, counts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.counter, bt.counter);        \
+  hipLaunchKernelGGL(mc_sort_prepare_kernel<GEOM>, pgrid, dim3(256), 0, stream, boxes, n, cand_row, cand_label,   \
+                     cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.counter,    \
+                     bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16);                             \
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, L.gqueue,      \
                      (unsigned)L.qcap, L.counter, L.redo, bt);                                                    \
   hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb, iou_thr,      \
@@ -1390,6 +1400,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   else if (geom == 3) { R3_MC(3, false, L.extent); }
   else { R3_MC(2, true, (const float*)nullptr); }
 #undef R3_MC
+  counts = L.ccounts;
   launch_reduce(B, L.mask, L.nz, 0, L.cb, nullptr, L.keep, L.kept, bt, stream);
   if (geom == 1)
     hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), (size_t)L.cb * 12, stream, boxes, n, cand_row, cand_label,
