@@ -23,9 +23,15 @@ anchors = syn.anchor_grid(device=dev)
 gt = syn.dota_like_rboxes(128, 5, device=dev)
 refined = torch.cat([syn.fr_level_boxes(1, 1024 // s, 1024 // s, s, 50 + i, device=dev) for i, s in enumerate(syn.STRIDES)])
 a, g = syn.rand_rboxes(1000, 0, device=dev), syn.rand_rboxes(128, 1, device=dev)
-for name, b1, b2 in (("128x196416", gt, anchors), ("128x21824", gt, refined), ("1000x128", a, g)):
+from r3det.ops import obb_overlaps  # noqa: E402
+
+gt512 = syn.dota_like_rboxes(512, 6, device=dev)
+for name, b1, b2 in (("128x196416", gt, anchors), ("512x196416", gt512, anchors), ("128x21824", gt, refined),
+                     ("1000x128", a, g), ("v3_128x196416", gt, anchors)):
     if which not in ("all", name):
         continue
+    if name.startswith("v3"):
+        rbbox_iou = obb_overlaps  # noqa: F811  (the v3 family: box_iou_rotated_ext.overlaps)
     for _ in range(3):
         rbbox_iou(b1, b2)
     torch.cuda.synchronize()

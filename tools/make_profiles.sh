@@ -3,9 +3,9 @@
 # of the bench step, the training step, configs[1], the IoU and NMS ops, and the PMC passes (separate runs,
 # --kernel-trace only) of the roofline kernel and of the IoU / NMS kernels.  Output: gpurun_out/profiles_<tag>/,
 # copied into profiles/ by hand (tracked).
-#   bash tools/make_profiles.sh r02
+#   bash tools/make_profiles.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
@@ -31,7 +31,7 @@ kt $O/${TAG}_rretinanet_kernel_stats.txt "python3 tools/rretina_prof.py (last st
 python3 $R/tools/step_kernels.py /tmp/kt_run 10.7 40 >> $O/${TAG}_rretinanet_kernel_stats.txt
 # 4. IoU op, per shape
 : > $O/${TAG}_iou_kernel_stats.txt
-for shp in 128x196416 128x21824 1000x128; do
+for shp in 128x196416 512x196416 128x21824 1000x128 v3_128x196416; do
   export IOU_PROF_SHAPE=$shp
   kt /tmp/kt_one.txt "python3 tools/iou_prof.py  (IOU_PROF_SHAPE=$shp)" python3 $R/tools/iou_prof.py
   cat /tmp/kt_one.txt >> $O/${TAG}_iou_kernel_stats.txt
@@ -40,7 +40,7 @@ done
 unset IOU_PROF_SHAPE
 # 5. NMS op, per size, and the batched pipeline
 : > $O/${TAG}_nms_kernel_stats.txt
-for n in 2000 5344 8576; do
+for n in 2000 5344 8576 32768 v3_8576; do
   export NMS_PROF_N=$n
   kt /tmp/kt_one.txt "python3 tools/nms_prof.py  (NMS_PROF_N=$n)" python3 $R/tools/nms_prof.py
   cat /tmp/kt_one.txt >> $O/${TAG}_nms_kernel_stats.txt
@@ -51,7 +51,27 @@ unset NMS_PROF_N
 kt $O/${TAG}_fr_nhwc_kernel_stats.txt "python3 tools/fr_nhwc_prof.py" python3 $R/tools/fr_nhwc_prof.py
 python3 $R/tools/kstats.py /tmp/kt_run fr_forward >> $O/${TAG}_fr_nhwc_kernel_stats.txt
 cd $R
-bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_fr_nhwc_pmc.txt fr_forward_nhwc "FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" tools/fr_nhwc_prof.py > /dev/null
+bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_fr_nhwc_pmc.txt fr_forward_nhwc "FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" tools/fr_nhwc_prof.py > /dev/null
+python3 tools/make_roofline_pmc.py gpurun_out/profiles_$TAG/${TAG}_fr_nhwc_pmc.txt gpurun_out/profiles_$TAG/roofline_kernel_pmc.json
+# 6b. FR backward, both layouts (rotating buffers): level 0 / 1 at N = 4, level 0 at N = 2, and the "trained" field
+: > $O/${TAG}_fr_backward_kernel_stats.txt
+for cfg in "0 4 regular" "1 4 regular" "0 2 regular" "0 4 trained" "0 4 adversarial"; do
+  set -- $cfg
+  export FR_BWD_LEVEL=$1 FR_BWD_N=$2 FR_BWD_FIELD=$3
+  kt /tmp/kt_one.txt "python3 tools/fr_bwd_prof.py  (FR_BWD_LEVEL=$1 FR_BWD_N=$2 FR_BWD_FIELD=$3)" python3 $R/tools/fr_bwd_prof.py
+  cat /tmp/kt_one.txt >> $O/${TAG}_fr_backward_kernel_stats.txt
+  python3 $R/tools/kstats.py /tmp/kt_run frb_ fr_b >> $O/${TAG}_fr_backward_kernel_stats.txt
+done
+unset FR_BWD_LEVEL FR_BWD_N FR_BWD_FIELD
+cd $R
+bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_fr_backward_pmc.txt fr "FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/fr_bwd_prof.py > /dev/null
+cd /tmp
+# 6c. the plain samplers (the reference's API: r3det_feature_refine_forward NCHW, _forward_nhwc) per level, N = 4
+kt $O/${TAG}_fr_forward_kernel_stats.txt "python3 tools/fr_fwd_prof.py" python3 $R/tools/fr_fwd_prof.py
+python3 $R/tools/kstats.py /tmp/kt_run fr_ >> $O/${TAG}_fr_forward_kernel_stats.txt
+# 6d. the per-level pre-NMS pool (r3det_level_pool) at the two models' shapes
+kt $O/${TAG}_pool_kernel_stats.txt "python3 tools/pool_prof.py" python3 $R/tools/pool_prof.py
+python3 $R/tools/kt_by_grid.py $(find /tmp/kt_run -name "*kernel_trace.csv" | head -1) pool_ fill >> $O/${TAG}_pool_kernel_stats.txt
 # 7. PMC of the IoU and NMS kernels
 IOU_PROF_SHAPE=128x196416 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_iou_pmc.txt iou_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/iou_prof.py > /dev/null
 NMS_PROF_N=8576 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_nms_pmc.txt nms_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/nms_prof.py > /dev/null

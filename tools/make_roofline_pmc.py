@@ -1,7 +1,7 @@
 """profiles/roofline_kernel_pmc.json from the PMC passes of the roofline kernel (tools/make_profiles.sh step 6):
 HBM bytes per launch = FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE, tagged with the sha256
 of the kernel source so that bench.py reports `traffic` only for the code it was measured on.
-    python tools/make_roofline_pmc.py profiles/r02_fr_nhwc_pmc.txt"""
+    python tools/make_roofline_pmc.py profiles/r03_fr_nhwc_pmc.txt [out.json]"""
 import hashlib
 import json
 import os
@@ -10,7 +10,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_fr_nhwc_pmc.txt")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_fr_nhwc_pmc.txt")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "roofline_kernel_pmc.json")
 txt = open(src).read()
 
 
@@ -23,7 +24,10 @@ hit, miss = counter("TCC_HIT_sum"), counter("TCC_MISS_sum")
 sym = re.search(r"(fr_forward_nhwc\w*<[^>]*>)", txt).group(1)
 launches = int(re.search(r"n= (\d+)", txt).group(1))
 sha = hashlib.sha256(open(os.path.join(ROOT, "r3det-pytorch_amd", "csrc", "r3_fr.hip"), "rb").read()).hexdigest()[:16]
-commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
+try:
+    commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:  # noqa: BLE001  (the GPU box has no .git: the sha of the source is the tag that matters)
+    commit = "gpu-box snapshot"
 N, C, H = 4, 256, 128
 alg = 16 * N * C * H * H + 20 * N * H * H
 hbm = fetch * 1024 * 2 + write * 1024
@@ -39,5 +43,5 @@ rec = {
               "only; FETCH_SIZE x 2 on gfx950 per MI355X_MICROARCH.md; buffers rotate over 0.8 GB so the launches run "
               "from HBM); %d launches averaged" % (os.path.relpath(src, ROOT), launches),
 }
-json.dump(rec, open(os.path.join(ROOT, "profiles", "roofline_kernel_pmc.json"), "w"), indent=1)
+json.dump(rec, open(dst, "w"), indent=1)
 print(rec["hbm_bytes_per_launch"], rec["traffic_over_algorithmic"], sym, sha, commit)

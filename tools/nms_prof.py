@@ -13,8 +13,13 @@ from r3det.core.post_processing import CapacityHint, multiclass_nms_rotated_batc
 from r3det.ops import batched_rnms  # noqa: E402
 
 dev = torch.device("cuda")
-sizes = [int(os.environ["NMS_PROF_N"])] if os.environ.get("NMS_PROF_N") else [2000, 5344, 8576]
+from r3det.ops import obb_batched_nms  # noqa: E402
+
+sizes = [os.environ["NMS_PROF_N"]] if os.environ.get("NMS_PROF_N") else [2000, 5344, 8576]
 for n in sizes:
+    if str(n).startswith("v3_"):  # the v3 family (nms_rotated_ext.nms_rotated behind obb_batched_nms)
+        n, batched_rnms = int(str(n)[3:]), obb_batched_nms
+    n = int(n)
     mb, ms = syn.nms_pool(n * 10 // 6 + 64, 77 + n, device=dev)
     sc, lab = ms[:, :-1].max(1)
     idx = torch.nonzero(sc > 0.05).squeeze(1)[:n]
