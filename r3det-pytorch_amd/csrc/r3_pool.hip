@@ -142,15 +142,19 @@ constexpr int PS_CAND = 8192;   // (key, index) entries kept in LDS after three 
 // read as uint4, PS_U independent loads per thread and step (a first version read one key per iteration, each
 // waiting for the previous: 127 us at 16 384 keys, 500 us at 147 456).
 __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, const unsigned* __restrict__ keys,
-                                                           const unsigned* __restrict__ hist, int* __restrict__ sel,
+                                                           const unsigned* __restrict__ hist, u64* __restrict__ glist,
+                                                           u64* __restrict__ clist, int* __restrict__ meta,
                                                            u64* __restrict__ stamps = nullptr) {
   // (tools/probes/pool_select_probe.hip: clock stamps of workgroup 0 at the phase boundaries)
   auto stamp = [&](int i) {
     if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
-  __shared__ u64 list[PS_KMAX];          // (key << 32) | ~index  -- larger = earlier
-  __shared__ u64 cand[PS_CAND];          // (key << 32) | ~index of the keys still in the race after three digits
+  // entries (key << 32) | ~index -- larger = earlier in the pool -- go to two per-image lists in the workspace:
+  // `list` the keys above the threshold's 12-bit bin (all winners), `cand` the keys inside it (the first `need` of
+  // them in descending order are the remaining winners).  Nothing is sorted here: the emit launch ranks by counting.
+  u64* list = glist + (size_t)blockIdx.x * PS_KMAX;
+  u64* cand = clist + (size_t)blockIdx.x * PS_CAND;
   __shared__ int s_ncand;
   __shared__ int wcnt[PS_T / 64][16];
   __shared__ unsigned s_prefix;
@@ -206,10 +210,9 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
     mask |= 15u << shift;
     __syncthreads();
     };
-  // A pass over all keys costs this ONE compute unit ~20 us at 147 k keys, so: three digits from the histogram,
-  // one pass that copies the keys still matching the prefix -- about 1 % -- to LDS, the remaining five digits there
-  // (0.3 us each), one pass that collects the winners.  More than PS_CAND survivors (a flat score distribution): the
-  // remaining digits from global memory.
+  // A pass over all keys costs this ONE compute unit ~20 us at 147 k keys, so: three digits from the histogram, then
+  // ONE pass that sorts the keys into "above the threshold bin" / "inside it" (about 1 %) / "below".  More than
+  // PS_CAND keys inside the bin (a flat score distribution): the remaining digits from global memory.
   int shift = 28;
   {
     // the first three digits come from the histogram the key kernel made (spread over the chip): bins from the top
@@ -288,10 +291,12 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
     choose(tot, shift);
   }
   const bool in_lds = shift >= 0;  // the survivors fit the LDS copy (wave-uniform)
-  // (k - need keys lie above the 12-bit prefix: winners whatever the remaining digits say)
   if (in_lds) {
-    // ONE pass over the keys: the winners above the prefix go straight to the output list, the keys matching it
-    // (with their indices) to the LDS copy
+    // ONE pass over the keys: the keys above the 12-bit prefix go to `list` (k - need of them: winners whatever the
+    // remaining digits say), the keys matching it to `cand`.  No more digits and no sort here: the emit launch ranks
+    // every entry by counting, spread over the chip -- in this one workgroup the five LDS digit passes took 18 us
+    // and the bitonic sort of the k winners 27 us of a 56 us kernel (tools/probes/pool_select_probe.hip), whether
+    // the sort ran through LDS or in registers with shuffles.
     if (tid == 0) { s_ncand = 0; s_gt = 0; }
     __syncthreads();
     for (int st = 0; st < steps; st++) {
@@ -319,142 +324,148 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
     }
     __syncthreads();
     stamp(2);
-    const int ncand = s_ncand;
-    for (; shift >= 0; shift -= 4) {
-      int tot[16];
-#pragma unroll
-      for (int d = 0; d < 16; d++) tot[d] = 0;
-      for (int i = tid; i < ncand; i += PS_T) {  // (<= 8 keys per thread)
-        const unsigned key = (unsigned)(cand[i] >> 32);
-        const bool in = (key & mask) == prefix;
-        const unsigned d = (key >> shift) & 15u;
-#pragma unroll
-        for (int q = 0; q < 16; q++) tot[q] += (in && d == (unsigned)q) ? 1 : 0;
-      }
-      choose(tot, shift);
+    if (tid == 0) {
+      meta[blockIdx.x * 4 + 0] = k - need;   // entries of `list`
+      meta[blockIdx.x * 4 + 1] = s_ncand;    // entries of `cand`
+      meta[blockIdx.x * 4 + 2] = need;       // winners among them
     }
-  }
-  stamp(3);
-  const unsigned T = prefix;  // the k-th largest key; `need` of the keys equal to it are taken (lowest indices)
-  const int n_gt = k - need;
-  const bool all_eq = s_eq_total == need;  // every key equal to T is a winner: no index order needed among them
-
-  // ---- collection: keys > T all (any order: sorted below); keys == T all of them, or the first `need` by index
-  if (in_lds) {
-    // the keys above the 12-bit prefix are in the list already; the others come from the LDS copy
-    if (tid == 0) s_eq = 0;
-    __syncthreads();
-    const int ncand = s_ncand;
-    for (int i = tid; i < ncand; i += PS_T) {
-      const u64 ent = cand[i];
-      const unsigned key = (unsigned)(ent >> 32);
-      const int pg = wave_append(&s_gt, key > T);
-      if (pg >= 0) list[pg] = ent;
-      const int pe = wave_append(&s_eq, all_eq && key == T);
-      if (pe >= 0) list[n_gt + pe] = ent;
-    }
+    stamp(3);
+    stamp(4);
   } else {
-  if (tid == 0) { s_gt = 0; s_eq = 0; }
-  __syncthreads();
-  for (int st = 0; st < steps; st++) {
-    uint4 v[PS_U];
+    // more survivors than the LDS copy holds (a flat score distribution): the remaining digits were taken from
+    // global memory above; collection from global memory, then the sort
+    const unsigned T = prefix;  // the k-th largest key; `need` of the keys equal to it are taken (lowest indices)
+    const int n_gt = k - need;
+    const bool all_eq = s_eq_total == need;  // every key equal to T is a winner: no index order needed among them
+    if (tid == 0) { s_gt = 0; s_eq = 0; }
+    __syncthreads();
+    for (int st = 0; st < steps; st++) {
+      uint4 v[PS_U];
 #pragma unroll
-    for (int u = 0; u < PS_U; u++) {
-      const int q = (st * PS_U + u) * PS_T + tid;
-      v[u] = q < L4 ? kn4[q] : make_uint4(0u, 0u, 0u, 0u);
-    }
+      for (int u = 0; u < PS_U; u++) {
+        const int q = (st * PS_U + u) * PS_T + tid;
+        v[u] = q < L4 ? kn4[q] : make_uint4(0u, 0u, 0u, 0u);
+      }
 #pragma unroll
-    for (int u = 0; u < PS_U; u++) {
-      const unsigned kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-      const int q = (st * PS_U + u) * PS_T + tid;
+      for (int u = 0; u < PS_U; u++) {
+        const unsigned kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        const int q = (st * PS_U + u) * PS_T + tid;
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const unsigned key = kk[e];
-        const unsigned i = (unsigned)(q * 4 + e);
-        const int pg = wave_append(&s_gt, key > T);
-        if (pg >= 0) list[pg] = ((u64)key << 32) | (u64)(0xffffffffu - i);
-        const int pe = wave_append(&s_eq, all_eq && key == T);
-        if (pe >= 0) list[n_gt + pe] = ((u64)key << 32) | (u64)(0xffffffffu - i);
+        for (int e = 0; e < 4; e++) {
+          const unsigned key = kk[e];
+          const unsigned i = (unsigned)(q * 4 + e);
+          const int pg = wave_append(&s_gt, key > T);
+          if (pg >= 0) list[pg] = ((u64)key << 32) | (u64)(0xffffffffu - i);
+          const int pe = wave_append(&s_eq, all_eq && key == T);
+          if (pe >= 0) list[n_gt + pe] = ((u64)key << 32) | (u64)(0xffffffffu - i);
+        }
       }
     }
-  }
-  }  // (collection from global memory)
-  if (!all_eq) {
-    // ties straddle the threshold: the first `need` keys equal to T in index order.  Every thread counts the
-    // equal keys of a contiguous index range, an exclusive scan turns the counts into ranks.
-    const unsigned* kn = keys + (size_t)n * Lpad;
-    const int per = (Lpad + PS_T - 1) / PS_T;
-    const int lo_i = min(tid * per, Lpad), hi_i = min(lo_i + per, Lpad);
-    int ceq = 0;
-    for (int i = lo_i; i < hi_i; i++) ceq += kn[i] == T;
-    int incl = ceq;
+    if (!all_eq) {
+      // ties straddle the threshold: the first `need` keys equal to T in index order.  Every thread counts the
+      // equal keys of a contiguous index range, an exclusive scan turns the counts into ranks.
+      const unsigned* kn = keys + (size_t)n * Lpad;
+      const int per = (Lpad + PS_T - 1) / PS_T;
+      const int lo_i = min(tid * per, Lpad), hi_i = min(lo_i + per, Lpad);
+      int ceq = 0;
+      for (int i = lo_i; i < hi_i; i++) ceq += kn[i] == T;
+      int incl = ceq;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      __syncthreads();
+      if (lane == 63) wcnt[wave][0] = incl;
+      __syncthreads();
+      int base_eq = incl - ceq;
+#pragma unroll
+      for (int w = 0; w < PS_T / 64; w++)
+        if (w < wave) base_eq += wcnt[w][0];
+      for (int i = lo_i; i < hi_i && base_eq < need; i++) {
+        if (kn[i] == T) {
+          list[n_gt + base_eq] = ((u64)T << 32) | (u64)(0xffffffffu - (unsigned)i);
+          base_eq++;
+        }
+      }
     }
     __syncthreads();
-    if (lane == 63) wcnt[wave][0] = incl;
-    __syncthreads();
-    int base_eq = incl - ceq;
-#pragma unroll
-    for (int w = 0; w < PS_T / 64; w++)
-      if (w < wave) base_eq += wcnt[w][0];
-    for (int i = lo_i; i < hi_i && base_eq < need; i++) {
-      if (kn[i] == T) {
-        list[n_gt + base_eq] = ((u64)T << 32) | (u64)(0xffffffffu - (unsigned)i);
-        base_eq++;
-      }
+    stamp(4);
+    if (tid == 0) {  // all k winners are in `list`
+      meta[blockIdx.x * 4 + 0] = k;
+      meta[blockIdx.x * 4 + 1] = 0;
+      meta[blockIdx.x * 4 + 2] = 0;
     }
   }
-  __syncthreads();
-  stamp(4);
-  // ---- bitonic sort, descending on (key, ~index): score descending, ties by ascending index
-  int P = 1;
-  while (P < k) P <<= 1;
-  for (int j = k + tid; j < P; j += PS_T) list[j] = 0ULL;
-  __syncthreads();
-  // (a stage with stride <= 32 only exchanges inside the 128 elements a wave owns: wave-level ordering is enough
-  // there, so 10 of the 66 stages at P = 2048 take workgroup barriers)
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const bool wide = stride > 32;
-      if (wide) __syncthreads();
-      for (int t = tid; t < (P >> 1); t += PS_T) {
-        const int lo_i = ((t / stride) * stride * 2) + (t % stride);
-        const int hi_i = lo_i + stride;
-        const bool desc = ((lo_i & size) == 0);
-        const u64 x = list[lo_i], y = list[hi_i];
-        if ((x < y) == desc) { list[lo_i] = y; list[hi_i] = x; }
-      }
-      if (wide) {
-        __syncthreads();
-      } else {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
-  __syncthreads();
-  // ---- the winners' level rows, in pool order; a second launch spread over the chip decodes them (done here by
-  // the one workgroup per image it took 27 us of a 110 us kernel)
   stamp(5);
-  for (int j = tid; j < k; j += PS_T) sel[(size_t)n * k + j] = (int)(0xffffffffu - (unsigned)(list[j] & 0xffffffffULL));
   stamp(6);
 }
 
-__global__ __launch_bounds__(256) void pool_emit_kernel(const float* __restrict__ cls, PStrides sc,
-                                                        const float* __restrict__ reg, PStrides sr,
-                                                        const float* __restrict__ anchors, int per_image, int A, int C,
-                                                        int H, int W, int k, float max_ratio, float clamp_x,
-                                                        float clamp_y, const int* __restrict__ sel,
-                                                        float* __restrict__ boxes, float* __restrict__ scores,
-                                                        int pool_rows, int row_offset) {
-  const int n = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= k) return;
-  const size_t row = (size_t)n * pool_rows + row_offset + j;
-  pool_emit(cls, sc, reg, sr, anchors, per_image, n, sel[(size_t)n * k + j], A, C, H, W, max_ratio, clamp_x, clamp_y,
-            boxes + row * 5, scores + row * (C + 1));
+// Rank by counting + decode, over the chip.  A workgroup owns PE_C = 32 entries of one list: workgroups
+// 0 .. kb-1 of an image entries of `list`, the others entries of `cand`.  An entry's pool row is the number of larger
+// entries of its own list (every `list` entry is above every `cand` entry; entries are distinct: they carry their
+// index) -- for `cand` behind the n_gt rows of `list`, and only if that rank is below `need`.  PE_P = 8 threads share
+// an entry's compares, each an eighth of every 1024-entry LDS tile (two u64 per half-wave broadcast read); k = 2000:
+// 250 compares per thread.  (One thread per entry, 256 entries per workgroup: 8 workgroups per image, +20 us.)
+constexpr int PE_TILE = 1024;
+constexpr int PE_C = 32, PE_P = 8;
+
+__global__ __launch_bounds__(256) void pool_rank_emit_kernel(const float* __restrict__ cls, PStrides sc,
+                                                             const float* __restrict__ reg, PStrides sr,
+                                                             const float* __restrict__ anchors, int per_image, int A,
+                                                             int C, int H, int W, int k, int kb, float max_ratio,
+                                                             float clamp_x, float clamp_y, const u64* __restrict__ glist,
+                                                             const u64* __restrict__ clist, const int* __restrict__ meta,
+                                                             float* __restrict__ boxes, float* __restrict__ scores,
+                                                             int pool_rows, int row_offset) {
+  __shared__ __attribute__((aligned(16))) u64 tile[PE_TILE];
+  __shared__ int partial[PE_P][PE_C];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int n_gt = meta[n * 4 + 0], ncand = meta[n * 4 + 1], need = meta[n * 4 + 2];
+  const bool in_list = (int)blockIdx.x < kb;
+  const u64* src = in_list ? glist + (size_t)n * PS_KMAX : clist + (size_t)n * PS_CAND;
+  const int cnt = in_list ? n_gt : ncand;
+  const int i0 = (in_list ? (int)blockIdx.x : (int)blockIdx.x - kb) * PE_C;
+  if (i0 >= cnt) return;
+  const int ci = tid & (PE_C - 1), part = tid / PE_C;
+  const int i = i0 + ci;
+  const u64 mine = i < cnt ? src[i] : ~0ULL;
+  int rank = 0;
+  u64 nxt[PE_TILE / 256];
+#pragma unroll
+  for (int u = 0; u < PE_TILE / 256; u++) nxt[u] = (u * 256 + tid) < cnt ? src[u * 256 + tid] : 0ULL;
+  constexpr int SL2 = PE_TILE / PE_P / 2;  // ulonglong2 reads of a thread per tile
+  const ulonglong2* t2 = reinterpret_cast<const ulonglong2*>(tile) + part * SL2;
+  for (int j0 = 0; j0 < cnt; j0 += PE_TILE) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PE_TILE / 256; u++) tile[u * 256 + tid] = nxt[u];   // (0 pads: below every entry)
+#pragma unroll
+    for (int u = 0; u < PE_TILE / 256; u++) {
+      const int j = j0 + PE_TILE + u * 256 + tid;
+      nxt[u] = j < cnt ? src[j] : 0ULL;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int q = 0; q < SL2; q++) {
+      const ulonglong2 e = t2[q];
+      rank += (e.x > mine) + (e.y > mine);
+    }
+  }
+  partial[part][ci] = rank;
+  __syncthreads();
+  if (part != 0 || i >= cnt) return;
+  rank = 0;
+#pragma unroll
+  for (int q = 0; q < PE_P; q++) rank += partial[q][ci];
+  if (!in_list) {
+    if (rank >= need) return;
+    rank += n_gt;
+  }
+  if (rank >= k) return;  // (cannot happen for consistent lists; keeps a corrupted workspace inside the pool)
+  const size_t row = (size_t)n * pool_rows + row_offset + rank;
+  pool_emit(cls, sc, reg, sr, anchors, per_image, n, (int)(0xffffffffu - (unsigned)(mine & 0xffffffffULL)), A, C, H, W,
+            max_ratio, clamp_x, clamp_y, boxes + row * 5, scores + row * (C + 1));
 }
 
 }  // namespace
@@ -462,8 +473,11 @@ __global__ __launch_bounds__(256) void pool_emit_kernel(const float* __restrict_
 size_t r3k_level_pool_workspace_bytes(int N, int A, int H, int W, int nms_pre) {
   if (N <= 0 || A <= 0 || H <= 0 || W <= 0) return 0;
   const long long L = (long long)H * W * A, Lpad = (L + 3) / 4 * 4;
+  // keys | the two entry lists + 4 ints per image | histogram
   return (nms_pre > 0 && nms_pre < L)
-             ? (size_t)N * Lpad * sizeof(unsigned) + (size_t)N * nms_pre * sizeof(int) + 512 + (size_t)N * PH_BINS * 4 : 0;
+             ? (size_t)N * Lpad * sizeof(unsigned) + (size_t)N * ((PS_KMAX + PS_CAND) * sizeof(u64) + 16) + 768 +
+                   (size_t)N * PH_BINS * 4
+             : 0;
 }
 
 int r3k_level_pool(const float* cls, const long long* cls_strides, const float* reg, const long long* reg_strides,
@@ -490,13 +504,19 @@ int r3k_level_pool(const float* cls, const long long* cls_strides, const float* 
   if (reinterpret_cast<uintptr_t>(ws) & 15) return -1;
   unsigned* keys = (unsigned*)ws;
   const int Lpad = (int)((L + 3) / 4 * 4);
-  int* sel = (int*)((char*)ws + (((size_t)N * Lpad * sizeof(unsigned) + 255) & ~(size_t)255));
-  unsigned* hist = (unsigned*)((char*)sel + (((size_t)N * nms_pre * sizeof(int) + 255) & ~(size_t)255));
+  char* p = (char*)ws + (((size_t)N * Lpad * sizeof(unsigned) + 255) & ~(size_t)255);
+  u64* glist = (u64*)p;
+  u64* clist = glist + (size_t)N * PS_KMAX;
+  int* meta = (int*)(clist + (size_t)N * PS_CAND);
+  unsigned* hist = (unsigned*)((char*)meta + (((size_t)N * 16 + 255) & ~(size_t)255));
   if (hipMemsetAsync(hist, 0, (size_t)N * PH_BINS * 4, stream) != hipSuccess) return -2;
   hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)((Lpad + 255) / 256), N), dim3(256), 0, stream, cls, sc, A, C, H, W,
                      Lpad, keys, hist);
-  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, nms_pre, Lpad, keys, hist, sel, (u64*)nullptr);
-  hipLaunchKernelGGL(pool_emit_kernel, dim3((nms_pre + 255) / 256, N), dim3(256), 0, stream, cls, sc, reg, sr, anchors,
-                     per_image, A, C, H, W, nms_pre, max_ratio, clamp_x, clamp_y, sel, boxes, scores, pool_rows, row_offset);
+  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, nms_pre, Lpad, keys, hist, glist, clist, meta,
+                     (u64*)nullptr);
+  const int kb = (nms_pre + PE_C - 1) / PE_C;
+  hipLaunchKernelGGL(pool_rank_emit_kernel, dim3(kb + PS_CAND / PE_C, N), dim3(256), 0, stream, cls, sc, reg, sr, anchors,
+                     per_image, A, C, H, W, nms_pre, kb, max_ratio, clamp_x, clamp_y, glist, clist, meta, boxes, scores,
+                     pool_rows, row_offset);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

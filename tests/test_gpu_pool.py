@@ -94,8 +94,9 @@ def test_pool_argument_errors():
     L = _C.lib()
     assert L.r3det_level_pool(None, None, None, None, None, 0, 1, 1, 1, 1, 1, 1, 1.0, -1.0, -1.0, None, None, 1, 0, None, 0,
                               None) == -1
-    assert L.r3det_level_pool_workspace_bytes(2, 9, 128, 128, 2000) == 2 * 147456 * 4 + 2 * 2000 * 4 + 512 + 2 * 4096 * 4
-    assert L.r3det_level_pool_workspace_bytes(1, 9, 5, 7, 100) == 316 * 4 + 100 * 4 + 512 + 4096 * 4  # keys padded to a multiple of 4; + histogram
+    lists = (4096 + 8192) * 8 + 16  # per image: the entries above / inside the threshold bin, 4 ints
+    assert L.r3det_level_pool_workspace_bytes(2, 9, 128, 128, 2000) == 2 * 147456 * 4 + 2 * lists + 768 + 2 * 4096 * 4
+    assert L.r3det_level_pool_workspace_bytes(1, 9, 5, 7, 100) == 316 * 4 + lists + 768 + 4096 * 4  # keys padded to a multiple of 4; + histogram
     assert L.r3det_level_pool_workspace_bytes(2, 1, 8, 8, 2000) == 0
 
 

@@ -1,6 +1,5 @@
 // Probe: where the time of pool_select_kernel (csrc/r3_pool.hip) goes -- s_memtime stamps of workgroup 0 at the phase
-// boundaries: 0-1 histogram digits | 1-2 candidate pass over the keys | 2-3 LDS digits | 3-4 collection | 4-5 bitonic
-// sort | 5-6 output.  N = 4 images of L keys (argv[1], default 16384), k = 2000, detector-like score distribution.
+// boundaries: 0-1 histogram digits | 1-2 the pass over the keys (entries to the two lists) | the rest: meta write.  N = 4 images of L keys (argv[1], default 16384), k = 2000, detector-like score distribution.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I r3det-pytorch_amd/csrc -I include -o tools/probes/pool_select_probe tools/probes/pool_select_probe.hip
 #include "../../r3det-pytorch_amd/csrc/r3_pool.hip"
 #include <cmath>
@@ -24,15 +23,15 @@ int main(int argc, char** argv) {
       unsigned u; memcpy(&u, &s, 4);
       h[(size_t)n * Lpad + i] = u | 0x80000000u;
     }
-  unsigned *dk, *dh; int* sel; u64* st;
-  CK(hipMalloc(&dk, h.size() * 4)); CK(hipMalloc(&dh, (size_t)N * PH_BINS * 4)); CK(hipMalloc(&sel, (size_t)N * k * 4)); CK(hipMalloc(&st, 64));
+  unsigned *dk, *dh; int* sel; u64* st; u64 *gl, *cl_;
+  CK(hipMalloc(&dk, h.size() * 4)); CK(hipMalloc(&dh, (size_t)N * PH_BINS * 4)); CK(hipMalloc(&sel, (size_t)N * k * 4)); CK(hipMalloc(&st, 64)); CK(hipMalloc(&gl, (size_t)N * PS_KMAX * 8)); CK(hipMalloc(&cl_, (size_t)N * PS_CAND * 8));
   CK(hipMemcpy(dk, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemset(dh, 0, (size_t)N * PH_BINS * 4));
   hipLaunchKernelGGL(hist_kernel, dim3((Lpad + 255) / 256, N), dim3(256), 0, 0, dk, Lpad, dh);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int it = 0; it < 3; it++) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, 0, k, Lpad, dk, dh, sel, st);
+    hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, 0, k, Lpad, dk, dh, gl, cl_, sel, st);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     u64 s[8]; CK(hipMemcpy(s, st, 64, hipMemcpyDeviceToHost));
