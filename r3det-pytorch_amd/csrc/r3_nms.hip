@@ -48,6 +48,8 @@ constexpr int NT = TILE * MASK_WAVES;
 constexpr int Q_NREG = 64;
 constexpr int Q_CSTRIDE = 32;
 constexpr int Q_REDO = Q_NREG * Q_CSTRIDE;   // word index of the redo-list counter
+constexpr int Q_XFLAG = Q_REDO + 1;            // set by the drain when a suppressor edge joins two label groups (batched runs)
+constexpr int RG_GROUPS = 16;                  // label groups of the batched reducer: group = label mod 16
 constexpr int Q_CTL_WORDS = Q_REDO + Q_CSTRIDE;
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -60,6 +62,7 @@ struct Batch {
   size_t recs, mask, nz, counter, queue, keep;
   size_t redo;  // stride of the redo-tile lists
   size_t rows;  // row capacity of one image's arrays (= n for a single problem); `nz` = stride of the side tables
+  const uint8_t* rlab;  // batched runs: label of every sorted row (stride `rows`), or nullptr
 };
 
 inline Batch single_problem(int n) {
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
 template <int GEOM, bool LABEL>
 __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict__ recs, int n, int cb, float thr,
                                                         const unsigned* __restrict__ gqueue, unsigned qcap,
-                                                        const unsigned* __restrict__ counter,
+                                                        unsigned* __restrict__ counter,
                                                         const unsigned* __restrict__ redo,
                                                         u64* __restrict__ mask, u64* __restrict__ side, Batch bt) {
   // v1: 8 candidate slots per lane in wave-private [slot][lane] regions (half the LDS of the reference's 16 slots:
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
     mask += img * bt.mask;
     side += img * bt.nz;
   }
+  const uint8_t* rlab = (bt.counts && bt.rlab) ? bt.rlab + (size_t)blockIdx.z * bt.rows : nullptr;
   const Side sd = side_tables(side, bt.rows);
   if (threadIdx.x < 64) {
     const unsigned v = min(counter[threadIdx.x * Q_CSTRIDE], qcap);
@@ -399,7 +403,10 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
         const LanePts<256> lp{pts + threadIdx.x};
         v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
       }
-      if (!over && v > thr) mark_pair(mask, sd, i, j, cb);
+      if (!over && v > thr) {
+        mark_pair(mask, sd, i, j, cb);
+        if (rlab && ((rlab[i] ^ rlab[j]) & (RG_GROUPS - 1))) counter[Q_XFLAG] = 1u;
+      }
     }
     if (SHORT) {
       unsigned long long m = __ballot(over);
@@ -415,7 +422,10 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
           const BoxRec B = recs[jj];
           const LanePts<32> lp16{pts + wave * 512 + lane};
           const float v = v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, false, lp16);
-          if (v > thr) mark_pair(mask, sd, ii, jj, cb);
+          if (v > thr) {
+            mark_pair(mask, sd, ii, jj, cb);
+            if (rlab && ((rlab[ii] ^ rlab[jj]) & (RG_GROUPS - 1))) counter[Q_XFLAG] = 1u;
+          }
         }
         for (int k = 0; k < 32 && m; k++) m &= m - 1;
       }
@@ -741,6 +751,299 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* 
   if (tid == 0) *count_out = total;
 }
 
+// ---------------------------------------------------------------------------- batched runs: one reducer per label
+// The batched pipeline (r3det_mcnms*: per-class NMS through class offsets or the label guard) has no suppressor edge
+// between boxes of different labels -- by construction for the label guard (v2), and for the offsets (v1 / v3)
+// whenever no box reaches across an offset, which the drain checks edge by edge (counter[Q_XFLAG]).  Then the greedy
+// reduction of an image falls apart into one independent problem per label: grid = (labels, 1, images), every
+// workgroup compacts the rows of its label (score order kept) and runs the dependency rounds over those ~n / 15 rows
+// only -- one workgroup per image walked all 8576 rows for 38 us.  (Groups = labels mod 16: any number of classes, a
+// fixed grid.)  Flag set: workgroup 0 of the image runs the rounds over all rows, the others leave.  Output: the kept rows as bits in `kbits` (zeroed with the side tables), which the
+// finish kernels turn into the detections; no keep list.
+constexpr int RG_MAXN = 16384;  // largest row capacity with grouping (LDS: state bytes + row list + worklist)
+
+__host__ __device__ inline size_t reduce_groups_lds_bytes(int n, int cb, bool with_row_list) {
+  return (size_t)((n + 15) & ~15) + (size_t)cb * 8 * 3 + (with_row_list ? (size_t)n * 2 : 0) + (size_t)R_BLIST * 2 + 64;
+}
+
+template <bool GROUPED>
+__device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT, const Side& sd, const int n,
+                                                   const int bt_rows, const int cb, const uint8_t* __restrict__ rlab,
+                                                   const int group,
+                                                   u64* __restrict__ kbits, unsigned char* smem8, int* s_und,
+                                                   int* s_nbig, int* s_m, int* wsum) {
+  const int cbn = (n + TILE - 1) / TILE;
+  const int nb = (n + 15) & ~15;
+  unsigned char* st = smem8;                               // row state: 0 undecided, 1 kept, 2 removed
+  u64* Kb = reinterpret_cast<u64*>(smem8 + nb);            // cb words: rows known kept
+  u64* Rb = Kb + cb;                                       // cb words: rows known removed
+  u64* Own = Rb + cb;                                      // cb words: rows of this workgroup
+  unsigned short* rows_l = reinterpret_cast<unsigned short*>(Own + cb);  // this workgroup's rows, ascending
+  unsigned short* blist = rows_l + (gridDim.x > 1 ? bt_rows : 0);         // (the list exists in multi-group launches)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < cb; j += RTHREADS) {
+    Kb[j] = 0;
+    Rb[j] = 0;
+    Own[j] = 0;
+  }
+  if (tid == 0) {
+    *s_nbig = 0;
+    *s_m = 0;
+  }
+  __syncthreads();
+  int m = n;
+  if (GROUPED) {
+    // ordered compaction of the label's rows: block counts -> exclusive scan -> ranks
+    int base = 0;
+    for (int r0 = 0; r0 < n; r0 += RTHREADS) {
+      const int r = r0 + tid;
+      const bool mine = r < n && (rlab[r] & (RG_GROUPS - 1)) == group;
+      const u64 mb = __ballot(mine);
+      if (lane == 0) {
+        wsum[wave] = __popcll(mb);
+        if (mb) Own[r >> 6] = mb;  // (a wave's 64 rows are one mask word)
+      }
+      __syncthreads();
+      int woff = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < RTHREADS / 64; w++) {
+        const int t = wsum[w];
+        if (w < wave) woff += t;
+        tot += t;
+      }
+      if (mine) rows_l[base + woff + __popcll(mb & ((1ULL << lane) - 1ULL))] = (unsigned short)r;
+      base += tot;
+      __syncthreads();
+    }
+    m = base;
+  }
+  auto row_of = [&](const int k) -> int { return GROUPED ? (int)rows_l[k] : k; };
+  auto set_bit = [&](u64* words, const int r) { atomicOr(&words[r >> 6], 1ULL << (r & 63)); };
+
+  // prologue: counts and first chunks of this workgroup's rows (all loads in flight together)
+  int cnt[R_CACHE];
+  uint4 c0[R_CACHE];
+#pragma unroll
+  for (int u = 0; u < R_CACHE; u++) {
+    const int k = tid + u * RTHREADS;
+    const int rr = k < m ? row_of(k) : 0;
+    cnt[u] = sd.ecnt[rr];
+    c0[u] = *reinterpret_cast<const uint4*>(sd.elist + (size_t)rr * EL);
+  }
+  unsigned own = 0;  // cached rows with a long list that did not fit the worklist
+#pragma unroll
+  for (int u = 0; u < R_CACHE; u++) {
+    const int k = tid + u * RTHREADS;
+    const int r = k < m ? row_of(k) : 0;
+    const bool kept0 = k < m && cnt[u] == 0;
+    if (k < m) st[r] = kept0 ? 1 : 0;
+    if (GROUPED) {
+      if (kept0) set_bit(Kb, r);
+    } else {
+      const u64 k0 = __ballot(kept0);
+      if (lane == 0 && k0) Kb[r >> 6] = k0;
+    }
+    const bool isbig = k < m && cnt[u] > 8;
+    const u64 mb = __ballot(isbig);
+    if (mb) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(s_nbig, __popcll(mb));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const int slot = base + __popcll(mb & ((1ULL << lane) - 1ULL));
+      if (isbig) {
+        if (slot < R_BLIST) blist[slot] = (unsigned short)r;
+        else own |= 1u << u;
+      }
+    }
+  }
+  for (int u = R_CACHE; wave * 64 + u * RTHREADS < m; u++) {  // rows beyond the register cache
+    const int k = tid + u * RTHREADS;
+    const int r = k < m ? row_of(k) : 0;
+    const bool kept0 = k < m && sd.ecnt[r] == 0;
+    if (k < m) st[r] = kept0 ? 1 : 0;
+    if (kept0) set_bit(Kb, r);
+  }
+  __syncthreads();
+  const int nbig = min(*s_nbig, R_BLIST);
+
+  // one row against the K / R sets; returns 0 undecided, 1 kept, 2 removed
+  auto long_row = [&](const int r) -> int {
+    const unsigned ms = 65535u - (unsigned)sd.msup[r];  // its highest-scored suppressor first
+    if (ms < 65535u && st[ms] == 1) return 2;
+    const int c = sd.ecnt[r];
+    const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
+    const uint4 t[4] = {lp[0], lp[1], lp[2], lp[3]};
+    const int listed = min(c, EL);
+    bool anyK = false, allR = true;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; c4++) {
+      const unsigned wv[4] = {t[c4].x, t[c4].y, t[c4].z, t[c4].w};
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+        const bool on = 8 * c4 + q < listed;
+        const unsigned char v = st[on ? i : (unsigned)r];
+        anyK |= on && v == 1;
+        allR &= !on || v == 2;
+      }
+    }
+    if (c > EL && !anyK) {
+      // suppressors beyond the list: scan the overflow row, 8 independent word loads per step
+      const u64* row = maskT + (size_t)r * cb;
+      const int w = r >> 6;
+      for (int q0 = 0; q0 <= w && !anyK; q0 += 8) {
+        u64 mm[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) mm[e] = row[min(q0 + e, w)];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int q = min(q0 + e, w);
+          anyK |= (mm[e] & Kb[q]) != 0ULL;
+          allR &= (mm[e] & ~Rb[q]) == 0ULL;
+        }
+      }
+    }
+    return anyK ? 2 : (allR ? 1 : 0);
+  };
+  auto decide = [&](const int r, const int d) {
+    st[r] = (unsigned char)d;
+    set_bit(d == 1 ? Kb : Rb, r);
+  };
+
+  int round = 0;
+  for (; round < R_MAX_ROUNDS; round++) {
+    if (tid == 0) *s_und = 0;
+    __syncthreads();
+    int und = 0;
+    // pass A: the cached rows with at most 8 suppressors, straight from registers
+#pragma unroll
+    for (int u = 0; u < R_CACHE; u++) {
+      const int k = tid + u * RTHREADS;
+      const int r = k < m ? row_of(k) : 0;
+      const bool act = k < m && cnt[u] <= 8 && cnt[u] > 0 && st[r] == 0;
+      if (__ballot(act) == 0ULL) continue;
+      bool anyK = false, allR = true;
+      if (act) {
+        unsigned wv[4] = {c0[u].x, c0[u].y, c0[u].z, c0[u].w};
+        asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));  // (see nms_reduce_rounds_kernel)
+        unsigned char v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+          v[q] = st[q < cnt[u] ? i : (unsigned)r];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const bool on = q < cnt[u];
+          anyK |= on && v[q] == 1;
+          allR &= !on || v[q] == 2;
+        }
+      }
+      const bool toR = act && anyK, toK = act && !anyK && allR;
+      und += act && !anyK && !allR;
+      if (GROUPED) {
+        if (toR | toK) decide(r, toR ? 2 : 1);
+      } else {
+        if (toR | toK) st[r] = toR ? 2 : 1;
+        const u64 mr = __ballot(toR), mk = __ballot(toK);
+        if (lane == 0) {
+          if (mr) Rb[r >> 6] |= mr;
+          if (mk) Kb[r >> 6] |= mk;
+        }
+      }
+    }
+    // pass B: the worklist of long rows, one per thread
+    for (int k = tid; k < nbig; k += RTHREADS) {
+      const int r = blist[k];
+      if (st[r] != 0) continue;
+      const int d = long_row(r);
+      if (d) decide(r, d);
+      else und++;
+    }
+    // pass C: cached long rows that did not fit the worklist, and rows beyond the register cache
+    if (own || m > R_CACHE * RTHREADS) {
+      for (int u = 0; wave * 64 + u * RTHREADS < m; u++) {
+        const int k = tid + u * RTHREADS;
+        const bool mine = u < R_CACHE ? ((own >> u) & 1u) : true;
+        if (!(k < m && mine)) continue;
+        const int r = row_of(k);
+        if (st[r] != 0) continue;
+        if (u >= R_CACHE && sd.ecnt[r] == 0) continue;
+        const int d = long_row(r);
+        if (d) decide(r, d);
+        else und++;
+      }
+    }
+    if (und) atomicAdd(s_und, und);
+    __syncthreads();
+    const int left = *s_und;
+    __syncthreads();
+    if (left == 0) break;
+  }
+  if (round == R_MAX_ROUNDS && tid < 64) {
+    // a suppression chain longer than the round budget: wave 0 finishes this workgroup's rows in score order
+    for (int b = 0; b < cbn; b++) {
+      const int nvalid = min(TILE, n - b * TILE);
+      const u64 valid = nvalid >= 64 ? ~0ULL : ((1ULL << nvalid) - 1ULL);
+      u64 todo = (GROUPED ? Own[b] : valid) & ~(Kb[b] | Rb[b]);
+      while (todo) {
+        const int k = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int r = b * TILE + k;
+        const int c = sd.ecnt[r];
+        bool hit = false;
+        if (lane < min(c, EL)) {
+          const unsigned i = sd.elist[(size_t)r * EL + lane];
+          hit = (Kb[i >> 6] >> (i & 63)) & 1ULL;
+        }
+        if (c > EL) {
+          const u64* row = maskT + (size_t)r * cb;
+          for (int q = lane; q <= b; q += 64) hit |= (row[q] & Kb[q]) != 0ULL;
+        }
+        const bool removed = __ballot(hit) != 0ULL;
+        if (lane == 0) {
+          if (removed) Rb[b] |= 1ULL << k;
+          else Kb[b] |= 1ULL << k;
+          st[r] = removed ? 2 : 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+      }
+    }
+  }
+  __syncthreads();
+  // the kept rows of this workgroup, as bits
+  for (int b = tid; b < cbn; b += RTHREADS) {
+    const u64 kb = Kb[b];
+    if (GROUPED) {
+      if (kb) atomicOr(&kbits[b], kb);  // (a word holds rows of several labels)
+    } else {
+      kbits[b] = kb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* __restrict__ maskT,
+                                                                     u64* __restrict__ side, int cb,
+                                                                     const unsigned* __restrict__ counter,
+                                                                     u64* __restrict__ kbits, size_t kbits_stride,
+                                                                     Batch bt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+  __shared__ int s_und, s_nbig, s_m;
+  __shared__ int wsum[RTHREADS / 64];
+  const int img = blockIdx.z;
+  const int n = bt.counts[img];
+  const bool grouped = gridDim.x > 1 && bt.rlab && counter[img * bt.counter + Q_XFLAG] == 0u;
+  if (!grouped && blockIdx.x != 0) return;
+  const Side sd = side_tables(side + img * bt.nz, bt.rows);
+  if (grouped)
+    reduce_groups_body<true>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, bt.rlab + (size_t)img * bt.rows, (int)blockIdx.x,
+                             kbits + img * kbits_stride, smem8, &s_und, &s_nbig, &s_m, wsum);
+  else
+    reduce_groups_body<false>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, nullptr, 0, kbits + img * kbits_stride, smem8, &s_und,
+                              &s_nbig, &s_m, wsum);
+}
+
 // rnms returns keep sorted by original index (rnms_kernel.cu:331-334): mark kept originals,
 // then an ordered compaction by one workgroup.
 __global__ __launch_bounds__(1024) void nms_ascending_kernel(int n, uint8_t* __restrict__ flags,
@@ -1062,8 +1365,8 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
     const float* __restrict__ boxes, int n, const int* __restrict__ cand_row, const int* __restrict__ cand_label,
     const float* __restrict__ cand_score, int cand_stride, const int* __restrict__ counts_raw, int cap,
     int* __restrict__ ccounts, const float* __restrict__ scale, BoxRec* __restrict__ recs, size_t recs_stride,
-    int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, unsigned* __restrict__ counter, size_t counter_stride,
-    uint4* __restrict__ zero, size_t zero16) {
+    int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab,
+    unsigned* __restrict__ counter, size_t counter_stride, uint4* __restrict__ zero, size_t zero16) {
   __shared__ __attribute__((aligned(16))) unsigned keys[RP_TJ];
   __shared__ int partial[RP_P][RP_C];
   const int img = blockIdx.y, tid = threadIdx.x;
@@ -1159,6 +1462,7 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
   make_record<GEOM>(d, GEOM == 2 ? lab : 0.f, r);
   recs[img * recs_stride + pos] = r;
   sorted_vals[img * recs_stride + pos] = c;
+  rlab[img * recs_stride + pos] = (uint8_t)cand_label[cbase + c];  // (the reducer groups by label mod 16: the low bits)
   if (GEOM == 3) dead[img * recs_stride + c] = is_dead;
 }
 
@@ -1168,29 +1472,30 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
                                                          const float* __restrict__ cand_score, int cand_stride,
                                                          const int* __restrict__ sorted_vals,
                                                          const int* __restrict__ counts,
-                                                         const int64_t* __restrict__ keep, size_t keep_stride,
-                                                         const int32_t* __restrict__ kept_count,
-                                                         int fwords, int out_cap,
+                                                         const u64* __restrict__ kbits, size_t kbits_stride,
+                                                         size_t rows_stride, int fwords, int out_cap,
                                                          float* __restrict__ dets_out,
                                                          int64_t* __restrict__ labels_out,
                                                          int64_t* __restrict__ keep_idx_out,
                                                          int32_t* __restrict__ counts_out) {
-  // Ascending keep = a bit per candidate, in LDS: set from the reducer's keep list (sorted positions -> candidate
-  // indices), block counts by popcount, wave-shuffle scan, then ONE kept candidate per thread and trip (the earlier
-  // form kept byte flags in global memory, scanned with 20 barriers and gathered up to 9 rows per thread serially).
+  // Ascending keep = a bit per candidate, in LDS: set from the reducer's kept rows (bits over the sorted positions ->
+  // candidate indices), block counts by popcount, wave-shuffle scan, then ONE kept candidate per thread and trip (the
+  // earlier form kept byte flags in global memory, scanned with 20 barriers and gathered up to 9 rows per thread
+  // serially).
   extern __shared__ unsigned long long fbits[];  // ceil(M / 64) words, then as many ints of prefix
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int img = blockIdx.x;
-  const int M = counts[img], cnt = kept_count[img];
+  const int M = counts[img];
   const size_t cbase = (size_t)img * cand_stride;
-  keep += img * keep_stride;
+  kbits += img * kbits_stride;
   const int words = (M + 63) >> 6;
   int* wpre = reinterpret_cast<int*>(fbits + fwords);
   for (int w = tid; w < words; w += 1024) fbits[w] = 0ULL;
   __syncthreads();
-  for (int i = tid; i < cnt; i += 1024) {
-    const int c = sorted_vals[img * keep_stride + keep[i]];
+  for (int r = tid; r < M; r += 1024) {
+    if (!((kbits[r >> 6] >> (r & 63)) & 1ULL)) continue;
+    const int c = sorted_vals[img * rows_stride + r];
     atomicOr(&fbits[c >> 6], 1ULL << (c & 63));
   }
   __syncthreads();
@@ -1229,7 +1534,7 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
     labels_out[(size_t)img * out_cap + pos] = cand_label[cbase + i];
     if (keep_idx_out) keep_idx_out[(size_t)img * out_cap + pos] = i;  // candidate index, ascending
   }
-  if (tid == 0) counts_out[img] = min(cnt, out_cap);
+  if (tid == 0) counts_out[img] = min(run, out_cap);
 }
 
 // finish for the score-ordered families (v3 obb_nms, v2 ml_nms_rotated): the keep list already is in
@@ -1239,8 +1544,9 @@ __global__ __launch_bounds__(1024) void mc_finish_score_kernel(const float* __re
                                                                const int* __restrict__ cand_label,
                                                                const float* __restrict__ cand_score, int cand_stride,
                                                                const int* __restrict__ sorted_vals,
-                                                               const int64_t* __restrict__ keep, size_t keep_stride,
-                                                               const int32_t* __restrict__ kept_count,
+                                                               const int* __restrict__ counts,
+                                                               const u64* __restrict__ kbits, size_t kbits_stride,
+                                                               size_t rows_stride,
                                                                const uint8_t* __restrict__ dead, int out_cap,
                                                                float* __restrict__ dets_out,
                                                                int64_t* __restrict__ labels_out,
@@ -1249,15 +1555,19 @@ __global__ __launch_bounds__(1024) void mc_finish_score_kernel(const float* __re
   __shared__ int part[1024];
   const int tid = threadIdx.x;
   const int img = blockIdx.x;
-  const int cnt = kept_count[img];
+  const int M = counts[img];
   const size_t cbase = (size_t)img * cand_stride;
-  keep += img * keep_stride;
-  sorted_vals += img * keep_stride;
-  if (dead) dead += img * keep_stride;
-  const int per = (cnt + 1023) / 1024;
-  const int lo = min(tid * per, cnt), hi = min(lo + per, cnt);
+  kbits += img * kbits_stride;
+  sorted_vals += img * rows_stride;
+  if (dead) dead += img * rows_stride;
+  // every thread a contiguous range of sorted positions (= score order); kept and not dead rows are emitted
+  const int per = (M + 1023) / 1024;
+  const int lo = min(tid * per, M), hi = min(lo + per, M);
+  auto live = [&](const int r) -> bool {
+    return ((kbits[r >> 6] >> (r & 63)) & 1ULL) && !(dead && dead[sorted_vals[r]]);
+  };
   int c = 0;
-  for (int i = lo; i < hi; i++) c += !(dead && dead[sorted_vals[keep[i]]]);
+  for (int r = lo; r < hi; r++) c += live(r);
   part[tid] = c;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -1267,9 +1577,9 @@ __global__ __launch_bounds__(1024) void mc_finish_score_kernel(const float* __re
     __syncthreads();
   }
   int pos = part[tid] - c;
-  for (int i = lo; i < hi && pos < out_cap; i++) {
-    const int cand = sorted_vals[keep[i]];
-    if (dead && dead[cand]) continue;
+  for (int r = lo; r < hi && pos < out_cap; r++) {
+    if (!live(r)) continue;
+    const int cand = sorted_vals[r];
     const float* b = boxes + ((size_t)img * n + cand_row[cbase + cand]) * 5;
     float* d = dets_out + ((size_t)img * out_cap + pos) * 6;
     d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
@@ -1293,6 +1603,8 @@ struct McLayout {
   int32_t* kept;
   uint8_t* flags;
   uint8_t* dead;
+  uint8_t* rlab;   // label of every sorted row
+  u64* kbits;      // kept rows as bits (cb words per image; zeroed with the masks)
   float* extent;
   int* ccounts;
   size_t qcap, qstride, zero_bytes;  // entries per region; entries per image
@@ -1308,6 +1620,7 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* recs = take((size_t)B * cap * sizeof(BoxRec));
   char* mask = take((size_t)B * cap * cb * 8);  // mask and nz: one fill
   char* nz = take((size_t)B * side_words((size_t)cap) * 8);  // per image: side tables
+  char* kbits = take((size_t)B * cb * 8);                    // (still inside the zeroed region)
   char* counter = take((size_t)B * Q_CTL_WORDS * 4);
   char* gq = take((size_t)B * qcap * 4);
   char* rd = take((size_t)B * cb * cb * 4);  // redo-tile lists
@@ -1315,12 +1628,13 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* kept = take((size_t)B * 4);
   char* flags = take((size_t)B * cap);
   char* dead = take((size_t)B * cap);
+  char* rlab = take((size_t)B * cap);
   char* extent = take((size_t)B * 4);
   char* ccounts = take((size_t)B * 4);
   if (L) {
     L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
     L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->redo = (unsigned*)rd; L->keep = (int64_t*)keep;
-    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
+    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->rlab = (uint8_t*)rlab; L->kbits = (u64*)kbits; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
     L->qcap = qcap / Q_NREG; L->qstride = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb;
     if (g_r3_nms_qcap > 0 && (size_t)g_r3_nms_qcap < L->qcap) L->qcap = (size_t)g_r3_nms_qcap;
   }
@@ -1374,7 +1688,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   mc_layout(B, cap, ws, &L);
   const size_t cbq = (size_t)L.cb;
   Batch bt{L.ccounts, (size_t)cap, (size_t)cap * cbq, side_words((size_t)cap), (size_t)Q_CTL_WORDS, L.qstride,
-           (size_t)cap, cbq * cbq, (size_t)cap};
+           (size_t)cap, cbq * cbq, (size_t)cap, L.rlab};
   // the rank kernel accumulates into cand_rank: zeroed here so that a caller's stale scratch cannot send
   // records out of bounds; and the counts are clamped to cap for the same reason (an image with more
   // candidates than cap is processed as its first cap candidates: the caller sizes cap from the counts,
@@ -1390,8 +1704,8 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   (void)cand_rank;  // (scratch of the three-launch form of round 2; kept in the signature)
 #define R3_MC(GEOM, LABEL, SCALE)                                                                                  \
   hipLaunchKernelGGL(mc_sort_prepare_kernel<GEOM>, pgrid, dim3(256), 0, stream, boxes, n, cand_row, cand_label,   \
-                     cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.counter,    \
-                     bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16);                             \
+                     cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.rlab,       \
+                     L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16);                  \
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, L.gqueue,      \
                      (unsigned)L.qcap, L.counter, L.redo, bt);                                                    \
   hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb, iou_thr,      \
@@ -1401,15 +1715,30 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   else { R3_MC(2, true, (const float*)nullptr); }
 #undef R3_MC
   counts = L.ccounts;
-  launch_reduce(B, L.mask, L.nz, 0, L.cb, nullptr, L.keep, L.kept, bt, stream);
+  {
+    // one reducer workgroup per (image, label group = label mod 16) when the pool is small enough for its LDS; the
+    // kernel itself falls back to one workgroup per image when the drain saw an edge between two groups
+    const int groups = (cap <= RG_MAXN && g_r3_nms_impl != 2) ? RG_GROUPS : 1;
+    const size_t lds = reduce_groups_lds_bytes(cap, L.cb, groups > 1);
+    static bool raised = false;  // the default cap on dynamic LDS is 64 KB
+    if (lds > 64 * 1024 && !raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+      raised = true;
+    }
+    if (lds > 160 * 1024 - 256) return -1;  // (cap < 65536: never)
+    hipLaunchKernelGGL(nms_reduce_groups_kernel, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
+                       L.counter, L.kbits, cbq, bt);
+  }
   if (geom == 1)
     hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), (size_t)L.cb * 12, stream, boxes, n, cand_row, cand_label,
-                       cand_score, S, L.svals, counts, L.keep, bt.keep, L.kept, L.cb, out_cap, dets_out, labels_out,
+                       cand_score, S, L.svals, counts, L.kbits, cbq, (size_t)cap, L.cb, out_cap, dets_out, labels_out,
                        keep_idx_out, counts_out);
   else
     hipLaunchKernelGGL(mc_finish_score_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label,
-                       cand_score, S, L.svals, L.keep, bt.keep, L.kept, geom == 3 ? L.dead : (const uint8_t*)nullptr,
-                       out_cap, dets_out, labels_out, keep_idx_out, counts_out);
+                       cand_score, S, L.svals, counts, L.kbits, cbq, (size_t)cap,
+                       geom == 3 ? L.dead : (const uint8_t*)nullptr, out_cap, dets_out, labels_out, keep_idx_out,
+                       counts_out);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

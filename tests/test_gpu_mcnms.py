@@ -203,3 +203,53 @@ def test_pool_at_the_capacity_edge(m_target):
         out = multiclass_nms_rotated_batch(boxes, scores, 0.05, CFG, 2000, hint=h)
         assert out[0][0].shape == (2000, 6) and out[1][0].shape == (50, 6)
     same(out, boxes, scores, 0.05, CFG, 2000)
+
+
+def test_label_group_reducer_equals_single_workgroup(nms_type):
+    """The batched pipeline reduces every (image, label mod 16) group in its own workgroup when no suppressor edge
+    joins two groups; option nms_impl = 2 forces the one-workgroup-per-image reducer: identical results, also with 40
+    classes (groups hold several labels) and with one class."""
+    from r3det import _C
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    cfg = dict(type=nms_type, iou_thr=0.1)
+    for B, n, classes in ((4, 5344, 15), (2, 3000, 40), (1, 700, 1)):
+        boxes, scores = pools(B, n, 91 + classes, classes=classes)
+        got = multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000)
+        _C.set_option("nms_impl", 2)
+        try:
+            want = multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000)
+        finally:
+            _C.set_option("nms_impl", 0)
+        for (d, lab), (wd, wl) in zip(got, want):
+            assert torch.equal(d, wd) and torch.equal(lab, wl), (nms_type, B, n, classes)
+
+
+@pytest.mark.parametrize("ver", ["v1", "v3"])
+def test_box_across_the_class_offset_takes_the_whole_image_reducer(ver):
+    """v1 / v3 separate the classes by coordinate offsets (rnms_wrapper.py:58-63, nms_rotated_wrapper.py:84-90); a box
+    wide enough to reach across an offset suppresses boxes of ANOTHER class in the reference.  The drain flags such an
+    edge and the reducer then runs the whole image in one workgroup: same detections as the per-image wrapper path."""
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    g = torch.Generator().manual_seed(5)
+    n, C = 600, 15
+    b = torch.rand(n, 5, generator=g) * torch.tensor([100., 100., 12., 12., 1.]) + torch.tensor([0., 0., 2., 2., -1.5])
+    # class 0: a 100-wide box centred at x = 100; class 1: boxes at x ~ 0, which the offset (max + 1 = 101 for v1)
+    # moves to x ~ 101 -- inside the wide box
+    b[0] = torch.tensor([100., 50., 100., 100., 0.])
+    b[1:40, 0] = torch.rand(39, generator=g) * 3
+    b[1:40, 1] = 50 + torch.rand(39, generator=g) * 20
+    s = torch.rand(n, C + 1, generator=g) * 0.04
+    s[0, 0] = 0.99
+    s[1:40, 1] = 0.5 + 0.4 * torch.rand(39, generator=g)
+    idx = torch.arange(40, n)
+    s[idx, torch.randint(0, C, (n - 40,), generator=g)] = 0.06 + 0.9 * torch.rand(n - 40, generator=g)
+    s[:, -1] = 0
+    boxes, scores = torch.stack([b, b.flip(0)]).cuda(), torch.stack([s, s.flip(0)]).cuda()
+    cfg = dict(type=ver, iou_thr=0.1)
+    out = multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000)
+    same(out, boxes, scores, 0.05, cfg, 2000)
+    if ver == "v1":
+        # the cross-class suppression really happens: some class-1 box near x = 0 is missing from the detections
+        d, lab = out[0]
+        kept1 = int((lab == 1).sum())
+        assert kept1 < int((s[1:40, 1] > 0.05).sum())
