@@ -15,7 +15,7 @@ kt() {  # kt <outfile> <header> <program args...>: kernel trace + stats of one c
   local out=$1 hdr=$2; shift 2
   rm -rf /tmp/kt_run
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_run -o t -- "$@" > /tmp/kt_run.log 2>&1
-  { echo "# rocprofv3 --kernel-trace --stats -- $hdr"; grep -v "^W2\|^E2\|^I2" /tmp/kt_run.log | tail -6 | sed 's/^/# /'; } > $out
+  { echo "# rocprofv3 --kernel-trace --stats -- $hdr"; grep -v "^W2\|^E2\|^I2" /tmp/kt_run.log | tail -14 | sed 's/^/# /'; } > $out
 }
 # 1. bench step (R3Det inference, configs[2])
 kt $O/${TAG}_bench_kernel_stats.txt "python3 bench.py --steps 10 --warmup 4 --model-only" python3 $R/bench.py --steps 10 --warmup 4 --model-only
@@ -73,6 +73,7 @@ python3 $R/tools/kstats.py /tmp/kt_run fr_ >> $O/${TAG}_fr_forward_kernel_stats.
 kt $O/${TAG}_pool_kernel_stats.txt "python3 tools/pool_prof.py" python3 $R/tools/pool_prof.py
 python3 $R/tools/kt_by_grid.py $(find /tmp/kt_run -name "*kernel_trace.csv" | head -1) pool_ fill >> $O/${TAG}_pool_kernel_stats.txt
 # 7. PMC of the IoU and NMS kernels
+cd $R
 IOU_PROF_SHAPE=128x196416 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_iou_pmc.txt iou_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/iou_prof.py > /dev/null
 NMS_PROF_N=8576 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_nms_pmc.txt nms_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/nms_prof.py > /dev/null
 ls -la $O
