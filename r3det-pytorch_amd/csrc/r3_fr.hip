@@ -32,6 +32,7 @@
 
 int g_r3_fr_impl = 0;
 int g_r3_fr_dbg = 0;  // spare switch for kernel experiments (unused by the shipped kernels)
+int g_r3_fr_walk = 8; // strip height of the tile-pair walk (r3_fr_tap.h pair_walk; 0: row-major)
 int g_r3_fr_profile = 0;  // 1: cell-path launches record their own start / stop events
 
 namespace {
@@ -566,7 +567,8 @@ template <bool FUSED, bool PAIRED, int VAR = 0>
 __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
     const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
-    float scale, int tiles_x, int tiles_per_img, int T, float* __restrict__ out) {
+    float scale, int tiles_xs, int tiles_per_img, int T, float* __restrict__ out) {
+  const int tiles_x = tiles_xs & 0xfffff, strip = tiles_xs >> 20;  // (the pair walk's strip height rides in the top bits)
   // The sampled map P = (a + bias_a) + (b + bias_b) of the workgroup's own positions is shared through LDS: each
   // wave computes P for its 4 positions once (their identity term), the barrier publishes the two 4 x 4 tiles, and
   // a tap that falls inside either tile -- with transposed pairing that is 3 of 4 taps of a regular box field --
@@ -589,10 +591,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
     // 2048 workgroups = exactly four residency rounds of 2 per CU: no tail)
     const int off = tiles_x * (tiles_x - 1) / 2;
     if (tt < off) {
-      int pj = (int)((sqrtf(8.f * (float)tt + 1.f) + 1.f) * 0.5f);
-      while (pj * (pj - 1) / 2 > tt) pj--;
-      while ((pj + 1) * pj / 2 <= tt) pj++;
-      const int pi = tt - pj * (pj - 1) / 2;
+      int pi, pj;
+      pair_walk(tt, tiles_x, strip, pi, pj);
       ty = half ? pj : pi;
       tx = half ? pi : pj;
       oy = tx;
@@ -1681,8 +1681,15 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     // once: they no longer evict the a / b rows the neighbouring workgroups' halo taps are about to ask for).  Level 0,
     // N = 4, rotating buffers: 66.1 us (round-2 form, fr_dbg 3) -> 60.6 us, FETCH x 2 + WRITE 337 -> 317 MB
     // (tools/fr_nhwc_ab.py, gpurun_out/fr_fwd_pmc_*.txt); prefetching the boxes in phase 1 (VAR 1, fr_dbg 4): 67.6 us.
+    // Measured and not kept (round 3, same buffers): touching the out-of-tile tap rows in phase 1 (one lane per
+    // 128-byte line) 59.6 -> 63.4 us with FETCH 123.2 -> 129.4 K: the rows are fetched again anyway; requesting the
+    // residual rows in phase 1 (16 more VGPRs) 60.6 us.  The pair walk in strips (r3_fr_tap.h) 60.9 -> 59.4 us at
+    // unchanged FETCH.  What is left above the algorithmic bytes (+45 MB of 207 MB read) is exactly the out-of-tile
+    // tap rows of about half the tile edges (fields without such taps: FETCH = 204 MB), whatever the launch order.
     const bool big = (unsigned long long)N * H * W * C * 4ull >= (1ull << 32);  // (32-bit byte offsets inside an image)
     const int var = (g_r3_fr_dbg == 3 || big) ? 0 : g_r3_fr_dbg == 4 ? 1 : g_r3_fr_dbg == 5 ? 2 : 6;
+#undef R3_ARGS
+#define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x | (g_r3_fr_walk << 20), tpi, (int)T, out
 #define R3_OCC(F, P) \
   do { \
     if (var == 0) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 0>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
@@ -1696,6 +1703,8 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
       if (fused) R3_OCC(true, false); else R3_OCC(false, false);
     }
 #undef R3_OCC
+#undef R3_ARGS
+#define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x, tpi, (int)T, out
   } else if (points == 1) {
     if (paired) {
       if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<true, 4, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);

@@ -145,4 +145,35 @@ __device__ __forceinline__ void make_taps_yx(const float* __restrict__ box, floa
   }
 }
 
+// Walk of the strict tile pairs (pi < pj) of a tiles x tiles grid for the kernels that give one workgroup a 4 x 4
+// tile and its transpose.  A pair's out-of-tile taps fall in the tiles of the pairs (pi +- 1, pj) and (pi, pj +- 1);
+// a row fetched for one of them is still in the XCD's L2 for the other only when the two workgroups start within
+// a few microseconds of each other, i.e. a few dozen places apart in launch order.  Row-major over the triangle,
+// (pi, pj +- 1) are up to `tiles` places apart and the earlier one's rows are gone.  Here: strips of `strip` rows
+// of pj, column-major inside a strip, so that (pi, pj +- 1) are neighbours and (pi +- 1, pj) are `strip` apart;
+// only a strip's first / last row has a far neighbour.  strip <= 0: the row-major walk.  All scalar arithmetic.
+__device__ __forceinline__ void pair_walk(int tt, int tiles, int strip, int& pi, int& pj) {
+  if (strip <= 0) strip = tiles;  // one strip: plain row-major over the triangle
+  int s0 = 0, base = 0, hs, body;
+  for (;;) {  // strip of rows [s0, s0 + hs): hs * s0 full columns' worth, then the hs x hs triangle at the diagonal
+    hs = min(strip, tiles - s0);
+    body = hs * s0;
+    const int cnt = body + hs * (hs - 1) / 2;
+    if (tt < base + cnt || s0 + hs >= tiles) break;
+    base += cnt;
+    s0 += hs;
+  }
+  const int u = tt - base;
+  if (u < body) {
+    pi = u / hs;
+    pj = s0 + (u - pi * hs);
+  } else {
+    const int v = u - body;
+    int b = 1;
+    while ((b + 1) * b / 2 <= v) b++;
+    pi = s0 + v - b * (b - 1) / 2;
+    pj = s0 + b;
+  }
+}
+
 }  // namespace

@@ -453,8 +453,9 @@ template <bool ACCUM, bool PAIRED>
 __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const float* __restrict__ top,
                                                                         const int2* __restrict__ cellinfo,
                                                                         const int2* __restrict__ entries, int C, int H,
-                                                                        int W, int EPI, int tiles_x, int tiles_per_img,
+                                                                        int W, int EPI, int tiles_xs, int tiles_per_img,
                                                                         int T, float* __restrict__ bottom) {
+  const int tiles_x = tiles_xs & 0xfffff, strip = tiles_xs >> 20;  // (the pair walk's strip height rides in the top bits)
   __shared__ float4 Gs[PAIRED ? 32 : 16][64];  // slot (half * 16 + row of the tile * 4 + column) x lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
@@ -468,10 +469,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
   if (PAIRED) {
     const int off = tiles_x * (tiles_x - 1) / 2;
     if (tt < off) {
-      int pj = (int)((sqrtf(8.f * (float)tt + 1.f) + 1.f) * 0.5f);
-      while (pj * (pj - 1) / 2 > tt) pj--;
-      while ((pj + 1) * pj / 2 <= tt) pj++;
-      const int pi = tt - pj * (pj - 1) / 2;
+      int pi, pj;
+      pair_walk(tt, tiles_x, strip, pi, pj);
       ty = half ? pj : pi;
       tx = half ? pi : pj;
     } else {
@@ -637,7 +636,7 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
   if (T > 0x7fffffffLL) return -1;
   const int EPI = H * W * 4 * points;
   const dim3 grid((unsigned)T), block(paired ? 512 : 256);
-#define R3_ARGS top_grad, L.cellinfo, L.entries, C, H, W, EPI, tiles_x, tpi, (int)T, bottom_grad
+#define R3_ARGS top_grad, L.cellinfo, L.entries, C, H, W, EPI, tiles_x | (g_r3_fr_walk << 20), tpi, (int)T, bottom_grad
   if (paired) {
     if (overwrite) hipLaunchKernelGGL((frb_gather_kernel<false, true>), grid, block, 0, stream, R3_ARGS);
     else hipLaunchKernelGGL((frb_gather_kernel<true, true>), grid, block, 0, stream, R3_ARGS);

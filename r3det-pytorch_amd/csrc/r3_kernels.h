@@ -118,6 +118,7 @@ extern int g_r3_fr_profile;
 // A/B knobs (r3det_set_option)
 extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane, 3/4 tap-table, 5/6 persistent
 extern int g_r3_fr_dbg;    // ablation bits for the persistent forward kernel
+extern int g_r3_fr_walk;   // strip height of the tile-pair walk (0: row-major)
 extern int g_r3_frb_impl;  // 0 auto; 1 general index form always; 2 unpaired gather
 extern int g_r3_iou_impl;  // 0 auto, 1 one thread per pair, 2 one-launch compact kernel, 4 prep + stream + drain pipeline always
 extern int g_r3_iou_dwgs;  // 0 default (2048); > 0: workgroups of the IoU drain kernel (tuning)

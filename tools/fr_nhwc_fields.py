@@ -1,5 +1,5 @@
 import os, sys
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")): sys.path.insert(0, p)
 import torch
 from r3det import synthetic as syn
@@ -9,7 +9,10 @@ N, C, H = 4, 256, 128
 cl = torch.channels_last
 sets = [tuple(torch.randn(N, C, H, H, device=dev).contiguous(memory_format=cl) for _ in range(4)) for _ in range(3)]
 ba, bb = torch.randn(C, device=dev), torch.randn(C, device=dev)
+ONLY = os.environ.get("FR_FIELD", "")  # run one field only (PMC passes average over a kernel's launches)
 def run(name, boxes, scale=0.125):
+    if ONLY and ONLY not in name:
+        return
     for i in range(6):
         a, b, r, o = sets[i % 3]; fr_module_nhwc(a, b, ba, bb, r, boxes, scale, 1, o)
     torch.cuda.synchronize()

@@ -16,6 +16,8 @@ from r3det.ops.feature_refine import fr_module_nhwc  # noqa: E402
 from r3det import _C  # noqa: E402
 
 _C.set_option("fr_dbg", int(os.environ.get("FR_DBG", "0")))  # A/B variants of the launch (csrc/r3_fr.hip)
+if "FR_WALK" in os.environ:
+    _C.set_option("fr_walk", int(os.environ["FR_WALK"]))  # strip height of the tile-pair walk (0: row-major)
 dev = torch.device("cuda")
 N, C, H = 4, 256, 128
 cl = torch.channels_last
