@@ -156,8 +156,8 @@ def train_custom_op_ms(tr, device):
 # ------------------------------------------------------------------------------------ custom ops alone
 def build_hot_workload(device, seed):
     """What the custom-op layer of R3Det.simple_test runs per step at BATCH x 1024^2 in the channels_last model:
-    per pyramid level the FeatureRefineModule tail (one fr_module_nhwc launch), the refine head's pre-NMS pool per
-    level (r3det_level_pool: levels 0 / 1 cut at nms_pre = 2000 -> 5344 rows per image), the batched multiclass
+    per pyramid level the FeatureRefineModule tail (one fr_module_nhwc launch), the refine head's pre-NMS pool of
+    all levels (r3det_levels_pool: levels 0 / 1 cut at nms_pre = 2000 -> 5344 rows per image), the batched multiclass
     NMS (v1).  Synthetic head maps: ~4 % of the (row, class) scores pass score_thr, as in the calibrated model."""
     from r3det import synthetic as syn
     from r3det.core.post_processing import CapacityHint
@@ -186,11 +186,9 @@ def hot_path_step(wl):
     from r3det.ops.feature_refine import fr_module_nhwc
     for lv in wl["levels"]:
         fr_module_nhwc(lv["a"], lv["b"], wl["bias"], wl["bias"], lv["res"], lv["boxes"], lv["scale"], 1, lv["out"])
-    off = 0
-    for lv in wl["levels"]:
-        fr_boxes.level_pool(lv["cls"], lv["reg"], lv["rois"], 1, 15, 2000, (IMG, IMG), wl["pool_boxes"],
-                            wl["pool_scores"], off)
-        off += lv["rows"]
+    L = wl["levels"]
+    fr_boxes.levels_pool([lv["cls"] for lv in L], [lv["reg"] for lv in L], [lv["rois"] for lv in L], 1, 15, 2000,
+                         (IMG, IMG), wl["pool_boxes"], wl["pool_scores"])
     res = multiclass_nms_rotated_batch(wl["pool_boxes"], wl["pool_scores"], SCORE_THR, NMS_CFG, MAX_PER_IMG,
                                        hint=wl["nms_hint"])
     return sum(d.size(0) for d, _ in res)
@@ -570,7 +568,7 @@ def main():
         dt = srt[len(srt) // 2]
         hot = {"what": "the custom ops of one R3Det.simple_test step, alone, same shapes (N=4, C=256, channels_last): "
                        "FeatureRefineModule tail x5 levels (fr_module_nhwc) + refine-head pool x5 levels "
-                       "(r3det_level_pool, 5344 rows / image) + batched multiclass_nms_rotated (v1)",
+                       "(r3det_levels_pool, 5344 rows / image) + batched multiclass_nms_rotated (v1)",
                "ms_per_step": round(dt * 1e3, 3), "img_s": round(BATCH / dt, 1),
                "ms_per_step_mean": round(sum(per) / len(per) * 1e3, 3), "steps": len(per),
                "slowest_step": {"index": worst, "ms": round(per[worst] * 1e3, 3), "device_allocs_in_it": allocs[worst]},

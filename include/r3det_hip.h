@@ -270,6 +270,19 @@ int r3det_level_pool(const float* cls_score, const long long* cls_strides, const
                      int H, int W, int nms_pre, float max_ratio, float max_x, float max_y, float* pool_boxes,
                      float* pool_scores, int pool_rows, int row_offset, void* ws, size_t ws_bytes, void* stream);
 
+/* The same for ALL pyramid levels of a head in one call (the `for` over mlvl_* of _get_bboxes_single,
+ * rotate_anchor_head.py:626-673): level l's rows follow level l - 1's in the pool, exactly as the reference
+ * concatenates them; row for row the result of num_levels r3det_level_pool calls, in three launches instead of
+ * up to three per level.  cls_scores / bbox_preds / anchors: HOST arrays of num_levels device pointers; cls_strides /
+ * reg_strides: 4 element strides per level; A / H / W: per level.  num_levels <= 8.  ws:
+ * r3det_levels_pool_workspace_bytes() bytes. */
+size_t r3det_levels_pool_workspace_bytes(int num_levels, int N, const int* A, const int* H, const int* W, int nms_pre);
+int r3det_levels_pool(int num_levels, const float* const* cls_scores, const long long* cls_strides,
+                      const float* const* bbox_preds, const long long* reg_strides, const float* const* anchors,
+                      int anchors_per_image, int N, const int* A, int C, const int* H, const int* W, int nms_pre,
+                      float max_ratio, float max_x, float max_y, float* pool_boxes, float* pool_scores, int pool_rows,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* channels_last (NHWC) forms of the sampler: `features` / `output` are (N, H, W, C) contiguous -- the memory of a
  * torch channels_last (N, C, H, W) tensor -- so that a channels_last pipeline needs no layout switch around
  * the FR module.  Same results, element for element, as the NCHW entry points (feature_refine_cuda.forward,

@@ -218,6 +218,20 @@ int r3det_level_pool(const float* cls_score, const long long* cls_strides, const
                            S(stream)));
 }
 
+size_t r3det_levels_pool_workspace_bytes(int num_levels, int N, const int* A, const int* H, const int* W, int nms_pre) {
+  return r3k_levels_pool_workspace_bytes(num_levels, N, A, H, W, nms_pre);
+}
+
+int r3det_levels_pool(int num_levels, const float* const* cls_scores, const long long* cls_strides,
+                      const float* const* bbox_preds, const long long* reg_strides, const float* const* anchors,
+                      int anchors_per_image, int N, const int* A, int C, const int* H, const int* W, int nms_pre,
+                      float max_ratio, float max_x, float max_y, float* pool_boxes, float* pool_scores, int pool_rows,
+                      void* ws, size_t ws_bytes, void* stream) {
+  return rc(r3k_levels_pool(num_levels, cls_scores, cls_strides, bbox_preds, reg_strides, anchors, anchors_per_image, N, A,
+                            C, H, W, nms_pre, max_ratio, max_x, max_y, pool_boxes, pool_scores, pool_rows, 0, ws, ws_bytes,
+                            S(stream)));
+}
+
 int r3det_feature_refine_forward_nhwc(const float* features, const float* best_bboxes, int N, int C, int H, int W,
                                       float spatial_scale, int points, float* output, void* stream) {
   return rc(r3k_fr_forward_nhwc(features, nullptr, nullptr, nullptr, nullptr, best_bboxes, N, C, H, W, spatial_scale,

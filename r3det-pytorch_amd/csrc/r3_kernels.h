@@ -82,6 +82,13 @@ int r3k_level_pool(const float* cls, const long long* cls_strides, const float* 
                    const float* anchors, int per_image, int N, int A, int C, int H, int W, int nms_pre, float max_ratio,
                    float clamp_x, float clamp_y, float* boxes, float* scores, int pool_rows, int row_offset, void* ws,
                    size_t ws_bytes, hipStream_t stream);
+// ... all levels of a head in one set of launches (levels in pool order; row offsets follow from the level sizes)
+#define R3K_POOL_MAX_LEVELS 8
+size_t r3k_levels_pool_workspace_bytes(int nlevels, int N, const int* A, const int* H, const int* W, int nms_pre);
+int r3k_levels_pool(int nlevels, const float* const* cls, const long long* cls_strides, const float* const* reg,
+                    const long long* reg_strides, const float* const* anchors, int per_image, int N, const int* A, int C,
+                    const int* H, const int* W, int nms_pre, float max_ratio, float clamp_x, float clamp_y, float* boxes,
+                    float* scores, int pool_rows, int row_offset, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // convolution epilogue of the inference model: y = act(y + bias[c] (+ residual)), in place
 // channels_last -> NCHW: out = (a + bias_a[c]) (+ (b + bias_b[c])); b and the biases may be null

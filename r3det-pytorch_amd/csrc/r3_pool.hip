@@ -41,16 +41,54 @@ __device__ __forceinline__ unsigned pool_key(float f) {  // monotone: a < b  <=>
 // row i of a level <-> (position p = i / A, anchor a = i % A), as the reference's permute + reshape orders them
 constexpr int PH_BINS = 4096;  // histogram of the keys' top 12 bits (= the first three 4-bit digits of the select)
 
+// All levels of a head in ONE set of launches (r3k_levels_pool): a launch's workgroups find their level from the
+// block ranges below.  Per level and launch the kernels are short (5 - 11 us) and mostly ramp: five levels one after
+// the other were 11 launches and 71 us per R3Det step, the same work in 3 launches + one memset is bounded by the
+// largest level.
+constexpr int PL_MAX = R3K_POOL_MAX_LEVELS;
+struct PLevel {
+  const float* cls;
+  const float* reg;
+  const float* anchors;
+  PStrides sc, sr;
+  int A, H, W, Lpad;
+  int select;      // 1: the level is cut to its k best rows; 0: all rows in their order
+  int row_offset;  // first pool row of the level
+  int kblk0;       // first workgroup of the level in the key launch (select levels)
+  int eblk0;       // first workgroup of the level in the emit launch
+  int sel_index;   // index among the select levels (blockIdx.y of the select launch)
+  unsigned* keys;
+  unsigned* hist;
+  unsigned long long* glist;
+  unsigned long long* clist;
+  int* meta;
+};
+struct PLevels {
+  int count, C, per_image, k, kb;
+  float max_ratio, clamp_x, clamp_y;
+  float* boxes;
+  float* scores;
+  int pool_rows;
+  PLevel lv[PL_MAX];
+};
+
 // keys + per-image histogram of their top 12 bits (LDS histogram per workgroup, its non-empty bins added to the
 // global one: scores crowd into a few dozen bins, one global atomic per key would serialise on them).  `hist`
 // zeroed by the caller.
-__global__ __launch_bounds__(256) void pool_keys_kernel(const float* __restrict__ cls, PStrides sc, int A, int C,
-                                                        int H, int W, int Lpad, unsigned* __restrict__ keys,
-                                                        unsigned* __restrict__ hist) {
+__global__ __launch_bounds__(256) void pool_keys_kernel(const PLevels P) {
   __shared__ unsigned lh[PH_BINS];
+  int li = 0;
+  for (int l = 0; l < P.count; l++)
+    if (P.lv[l].select && (int)blockIdx.x >= P.lv[l].kblk0) li = l;
+  const PLevel& V = P.lv[li];
+  const float* __restrict__ cls = V.cls;
+  const PStrides sc = V.sc;
+  const int A = V.A, C = P.C, H = V.H, W = V.W, Lpad = V.Lpad;
+  unsigned* __restrict__ keys = V.keys;
+  unsigned* __restrict__ hist = V.hist;
   const int HW = H * W, L = HW * A;
   const int n = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int t = ((int)blockIdx.x - V.kblk0) * 256 + threadIdx.x;
   for (int b = threadIdx.x; b < PH_BINS; b += 256) lh[b] = 0u;
   __syncthreads();
   if (t >= L) {
@@ -105,18 +143,14 @@ __device__ __forceinline__ void pool_emit(const float* __restrict__ cls, const P
   score_out[C] = 0.f;  // the background column multiclass_nms_rotated drops
 }
 
-__global__ __launch_bounds__(256) void pool_all_kernel(const float* __restrict__ cls, PStrides sc,
-                                                       const float* __restrict__ reg, PStrides sr,
-                                                       const float* __restrict__ anchors, int per_image, int A, int C,
-                                                       int H, int W, float max_ratio, float clamp_x, float clamp_y,
-                                                       float* __restrict__ boxes, float* __restrict__ scores,
-                                                       int pool_rows, int row_offset) {
-  const int L = H * W * A, n = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// a level that is not cut: one thread per row, rows in their order
+__device__ __forceinline__ void pool_all_body(const PLevels& P, const PLevel& V, const int blk) {
+  const int L = V.H * V.W * V.A, n = blockIdx.y;
+  const int i = blk * 256 + threadIdx.x;
   if (i >= L) return;
-  const size_t row = (size_t)n * pool_rows + row_offset + i;
-  pool_emit(cls, sc, reg, sr, anchors, per_image, n, i, A, C, H, W, max_ratio, clamp_x, clamp_y, boxes + row * 5,
-            scores + row * (C + 1));
+  const size_t row = (size_t)n * P.pool_rows + V.row_offset + i;
+  pool_emit(V.cls, V.sc, V.reg, V.sr, V.anchors, P.per_image, n, i, V.A, P.C, V.H, V.W, P.max_ratio, P.clamp_x, P.clamp_y,
+            P.boxes + row * 5, P.scores + row * (P.C + 1));
 }
 
 // Append under a predicate with ONE LDS atomic per wavefront (ballot + popcount; lane ranks by mbcnt) instead of one
@@ -141,13 +175,20 @@ constexpr int PS_CAND = 8192;   // (key, index) entries kept in LDS after three 
 // The select workgroup is alone on its CU (grid = images): what it can afford is bandwidth, not latency.  Keys are
 // read as uint4, PS_U independent loads per thread and step (a first version read one key per iteration, each
 // waiting for the previous: 127 us at 16 384 keys, 500 us at 147 456).
-__global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, const unsigned* __restrict__ keys,
-                                                           const unsigned* __restrict__ hist, u64* __restrict__ glist,
-                                                           u64* __restrict__ clist, int* __restrict__ meta,
-                                                           u64* __restrict__ stamps = nullptr) {
+__global__ __launch_bounds__(PS_T) void pool_select_kernel(const PLevels P, u64* __restrict__ stamps = nullptr) {
+  int li = 0;
+  for (int l = 0; l < P.count; l++)
+    if (P.lv[l].select && P.lv[l].sel_index == (int)blockIdx.y) li = l;
+  const PLevel& V = P.lv[li];
+  const int k = P.k, Lpad = V.Lpad;
+  const unsigned* __restrict__ keys = V.keys;
+  const unsigned* __restrict__ hist = V.hist;
+  u64* __restrict__ glist = V.glist;
+  u64* __restrict__ clist = V.clist;
+  int* __restrict__ meta = V.meta;
   // (tools/probes/pool_select_probe.hip: clock stamps of workgroup 0 at the phase boundaries)
   auto stamp = [&](int i) {
-    if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime();
+    if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
   // entries (key << 32) | ~index -- larger = earlier in the pool -- go to two per-image lists in the workspace:
@@ -410,22 +451,26 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(int k, int Lpad, cons
 constexpr int PE_TILE = 1024;
 constexpr int PE_C = 32, PE_P = 8;
 
-__global__ __launch_bounds__(256) void pool_rank_emit_kernel(const float* __restrict__ cls, PStrides sc,
-                                                             const float* __restrict__ reg, PStrides sr,
-                                                             const float* __restrict__ anchors, int per_image, int A,
-                                                             int C, int H, int W, int k, int kb, float max_ratio,
-                                                             float clamp_x, float clamp_y, const u64* __restrict__ glist,
-                                                             const u64* __restrict__ clist, const int* __restrict__ meta,
-                                                             float* __restrict__ boxes, float* __restrict__ scores,
-                                                             int pool_rows, int row_offset) {
+__global__ __launch_bounds__(256) void pool_emit_kernel(const PLevels P) {
   __shared__ __attribute__((aligned(16))) u64 tile[PE_TILE];
   __shared__ int partial[PE_P][PE_C];
+  int li = 0;
+  for (int l = 0; l < P.count; l++)
+    if ((int)blockIdx.x >= P.lv[l].eblk0) li = l;
+  const PLevel& V = P.lv[li];
+  const int blk = (int)blockIdx.x - V.eblk0;
+  if (!V.select) {
+    pool_all_body(P, V, blk);
+    return;
+  }
+  const int k = P.k, kb = P.kb;
   const int n = blockIdx.y, tid = threadIdx.x;
+  const int* __restrict__ meta = V.meta;
   const int n_gt = meta[n * 4 + 0], ncand = meta[n * 4 + 1], need = meta[n * 4 + 2];
-  const bool in_list = (int)blockIdx.x < kb;
-  const u64* src = in_list ? glist + (size_t)n * PS_KMAX : clist + (size_t)n * PS_CAND;
+  const bool in_list = blk < kb;
+  const u64* src = in_list ? V.glist + (size_t)n * PS_KMAX : V.clist + (size_t)n * PS_CAND;
   const int cnt = in_list ? n_gt : ncand;
-  const int i0 = (in_list ? (int)blockIdx.x : (int)blockIdx.x - kb) * PE_C;
+  const int i0 = (in_list ? blk : blk - kb) * PE_C;
   if (i0 >= cnt) return;
   const int ci = tid & (PE_C - 1), part = tid / PE_C;
   const int i = i0 + ci;
@@ -463,60 +508,122 @@ __global__ __launch_bounds__(256) void pool_rank_emit_kernel(const float* __rest
     rank += n_gt;
   }
   if (rank >= k) return;  // (cannot happen for consistent lists; keeps a corrupted workspace inside the pool)
-  const size_t row = (size_t)n * pool_rows + row_offset + rank;
-  pool_emit(cls, sc, reg, sr, anchors, per_image, n, (int)(0xffffffffu - (unsigned)(mine & 0xffffffffULL)), A, C, H, W,
-            max_ratio, clamp_x, clamp_y, boxes + row * 5, scores + row * (C + 1));
+  const size_t row = (size_t)n * P.pool_rows + V.row_offset + rank;
+  pool_emit(V.cls, V.sc, V.reg, V.sr, V.anchors, P.per_image, n, (int)(0xffffffffu - (unsigned)(mine & 0xffffffffULL)), V.A,
+            P.C, V.H, V.W, P.max_ratio, P.clamp_x, P.clamp_y, P.boxes + row * 5, P.scores + row * (P.C + 1));
 }
 
 }  // namespace
 
+static size_t level_ws_bytes(int N, long long L) {
+  const long long Lpad = (L + 3) / 4 * 4;
+  // keys | the two entry lists + 4 ints per image | histogram  (768: alignment slack of the three parts)
+  return (size_t)N * Lpad * sizeof(unsigned) + (size_t)N * ((PS_KMAX + PS_CAND) * sizeof(u64) + 16) + 768 +
+         (size_t)N * PH_BINS * 4;
+}
+
+size_t r3k_levels_pool_workspace_bytes(int nlevels, int N, const int* A, const int* H, const int* W, int nms_pre) {
+  if (nlevels <= 0 || nlevels > PL_MAX || N <= 0 || !A || !H || !W) return 0;
+  size_t total = 0;
+  for (int l = 0; l < nlevels; l++) {
+    if (A[l] <= 0 || H[l] <= 0 || W[l] <= 0) return 0;
+    const long long L = (long long)H[l] * W[l] * A[l];
+    if (nms_pre > 0 && nms_pre < L) total += level_ws_bytes(N, L);
+  }
+  return total;
+}
+
 size_t r3k_level_pool_workspace_bytes(int N, int A, int H, int W, int nms_pre) {
-  if (N <= 0 || A <= 0 || H <= 0 || W <= 0) return 0;
-  const long long L = (long long)H * W * A, Lpad = (L + 3) / 4 * 4;
-  // keys | the two entry lists + 4 ints per image | histogram
-  return (nms_pre > 0 && nms_pre < L)
-             ? (size_t)N * Lpad * sizeof(unsigned) + (size_t)N * ((PS_KMAX + PS_CAND) * sizeof(u64) + 16) + 768 +
-                   (size_t)N * PH_BINS * 4
-             : 0;
+  return r3k_levels_pool_workspace_bytes(1, N, &A, &H, &W, nms_pre);
+}
+
+int r3k_levels_pool(int nlevels, const float* const* cls, const long long* cls_strides, const float* const* reg,
+                    const long long* reg_strides, const float* const* anchors, int per_image, int N, const int* A, int C,
+                    const int* H, const int* W, int nms_pre, float max_ratio, float clamp_x, float clamp_y, float* boxes,
+                    float* scores, int pool_rows, int row_offset, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (nlevels <= 0 || nlevels > PL_MAX || N <= 0 || C <= 0 || !cls || !cls_strides || !reg || !reg_strides || !anchors ||
+      !A || !H || !W || !boxes || !scores || pool_rows <= 0 || row_offset < 0)
+    return -1;
+  PLevels P;
+  P.count = nlevels;
+  P.C = C;
+  P.per_image = per_image;
+  P.k = nms_pre;
+  P.kb = nms_pre > 0 ? (nms_pre + PE_C - 1) / PE_C : 0;
+  P.max_ratio = max_ratio;
+  P.clamp_x = clamp_x;
+  P.clamp_y = clamp_y;
+  P.boxes = boxes;
+  P.scores = scores;
+  P.pool_rows = pool_rows;
+  int nsel = 0;
+  long long kblocks = 0, eblocks = 0, off = row_offset;
+  for (int l = 0; l < nlevels; l++) {
+    PLevel& V = P.lv[l];
+    if (A[l] <= 0 || H[l] <= 0 || W[l] <= 0 || !cls[l] || !reg[l] || !anchors[l]) return -1;
+    const long long L = (long long)H[l] * W[l] * A[l];
+    if (L > 0x7fffffffLL / 8) return -1;
+    V.cls = cls[l];
+    V.reg = reg[l];
+    V.anchors = anchors[l];
+    V.sc = PStrides{cls_strides[4 * l], cls_strides[4 * l + 1], cls_strides[4 * l + 2], cls_strides[4 * l + 3]};
+    V.sr = PStrides{reg_strides[4 * l], reg_strides[4 * l + 1], reg_strides[4 * l + 2], reg_strides[4 * l + 3]};
+    V.A = A[l];
+    V.H = H[l];
+    V.W = W[l];
+    V.Lpad = (int)((L + 3) / 4 * 4);
+    V.select = nms_pre > 0 && nms_pre < L;
+    V.row_offset = (int)off;
+    V.kblk0 = (int)kblocks;
+    V.eblk0 = (int)eblocks;
+    V.sel_index = nsel;
+    V.keys = nullptr;
+    V.hist = nullptr;
+    V.glist = V.clist = nullptr;
+    V.meta = nullptr;
+    if (V.select) {
+      if (nms_pre > PS_KMAX || L > 1000000) return -1;  // (the select workgroup packs per-wave digit counts in 16 bits)
+      nsel++;
+      kblocks += (V.Lpad + 255) / 256;
+      eblocks += P.kb + PS_CAND / PE_C;
+      off += nms_pre;
+    } else {
+      eblocks += (L + 255) / 256;
+      off += L;
+    }
+    if (off > pool_rows || eblocks > 0x7fffffffLL) return -1;
+  }
+  if (nsel) {
+    if (!ws || ws_bytes < r3k_levels_pool_workspace_bytes(nlevels, N, A, H, W, nms_pre)) return -3;
+    if (reinterpret_cast<uintptr_t>(ws) & 15) return -1;
+    // all histograms first (one memset), then per select level: keys | list | cand | meta
+    char* p = (char*)ws;
+    const size_t hist_bytes = (size_t)N * PH_BINS * 4;
+    char* q = p + (size_t)nsel * hist_bytes;
+    for (int l = 0; l < nlevels; l++) {
+      PLevel& V = P.lv[l];
+      if (!V.select) continue;
+      V.hist = (unsigned*)(p + (size_t)V.sel_index * hist_bytes);
+      V.keys = (unsigned*)q;
+      q += ((size_t)N * V.Lpad * sizeof(unsigned) + 255) & ~(size_t)255;
+      V.glist = (u64*)q;
+      V.clist = V.glist + (size_t)N * PS_KMAX;
+      V.meta = (int*)(V.clist + (size_t)N * PS_CAND);
+      q = (char*)V.meta + (((size_t)N * 16 + 255) & ~(size_t)255);
+    }
+    if (hipMemsetAsync(p, 0, (size_t)nsel * hist_bytes, stream) != hipSuccess) return -2;
+    hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)kblocks, N), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(pool_select_kernel, dim3(N, nsel), dim3(PS_T), 0, stream, P, (u64*)nullptr);
+  }
+  hipLaunchKernelGGL(pool_emit_kernel, dim3((unsigned)eblocks, N), dim3(256), 0, stream, P);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int r3k_level_pool(const float* cls, const long long* cls_strides, const float* reg, const long long* reg_strides,
                    const float* anchors, int per_image, int N, int A, int C, int H, int W, int nms_pre, float max_ratio,
                    float clamp_x, float clamp_y, float* boxes, float* scores, int pool_rows, int row_offset, void* ws,
                    size_t ws_bytes, hipStream_t stream) {
-  if (N <= 0 || A <= 0 || C <= 0 || H <= 0 || W <= 0 || !cls || !cls_strides || !reg || !reg_strides || !anchors ||
-      !boxes || !scores || pool_rows <= 0 || row_offset < 0)
-    return -1;
-  const long long L = (long long)H * W * A;
-  if (L > 0x7fffffffLL / 8) return -1;
-  const PStrides sc{cls_strides[0], cls_strides[1], cls_strides[2], cls_strides[3]};
-  const PStrides sr{reg_strides[0], reg_strides[1], reg_strides[2], reg_strides[3]};
-  const bool select = nms_pre > 0 && nms_pre < L;
-  const int rows = select ? nms_pre : (int)L;
-  if (row_offset + rows > pool_rows) return -1;
-  if (!select) {
-    hipLaunchKernelGGL(pool_all_kernel, dim3((unsigned)((L + 255) / 256), N), dim3(256), 0, stream, cls, sc, reg, sr, anchors,
-                       per_image, A, C, H, W, max_ratio, clamp_x, clamp_y, boxes, scores, pool_rows, row_offset);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-  }
-  if (nms_pre > PS_KMAX || L > 1000000) return -1;  // (the select workgroup packs per-wave digit counts in 16 bits)
-  if (!ws || ws_bytes < r3k_level_pool_workspace_bytes(N, A, H, W, nms_pre)) return -3;
-  if (reinterpret_cast<uintptr_t>(ws) & 15) return -1;
-  unsigned* keys = (unsigned*)ws;
-  const int Lpad = (int)((L + 3) / 4 * 4);
-  char* p = (char*)ws + (((size_t)N * Lpad * sizeof(unsigned) + 255) & ~(size_t)255);
-  u64* glist = (u64*)p;
-  u64* clist = glist + (size_t)N * PS_KMAX;
-  int* meta = (int*)(clist + (size_t)N * PS_CAND);
-  unsigned* hist = (unsigned*)((char*)meta + (((size_t)N * 16 + 255) & ~(size_t)255));
-  if (hipMemsetAsync(hist, 0, (size_t)N * PH_BINS * 4, stream) != hipSuccess) return -2;
-  hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)((Lpad + 255) / 256), N), dim3(256), 0, stream, cls, sc, A, C, H, W,
-                     Lpad, keys, hist);
-  hipLaunchKernelGGL(pool_select_kernel, dim3(N), dim3(PS_T), 0, stream, nms_pre, Lpad, keys, hist, glist, clist, meta,
-                     (u64*)nullptr);
-  const int kb = (nms_pre + PE_C - 1) / PE_C;
-  hipLaunchKernelGGL(pool_rank_emit_kernel, dim3(kb + PS_CAND / PE_C, N), dim3(256), 0, stream, cls, sc, reg, sr, anchors,
-                     per_image, A, C, H, W, nms_pre, kb, max_ratio, clamp_x, clamp_y, glist, clist, meta, boxes, scores,
-                     pool_rows, row_offset);
-  return hipGetLastError() == hipSuccess ? 0 : -2;
+  if (!cls || !reg || !anchors) return -1;
+  return r3k_levels_pool(1, &cls, cls_strides, &reg, reg_strides, &anchors, per_image, N, &A, C, &H, &W, nms_pre, max_ratio,
+                         clamp_x, clamp_y, boxes, scores, pool_rows, row_offset, ws, ws_bytes, stream);
 }

@@ -39,6 +39,8 @@ SIGNATURES = {
     "r3det_filter_bboxes": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "r3det_level_pool": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _i, _i, _vp, _sz,
                          _vp],
+    "r3det_levels_pool": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _i, _vp, _sz,
+                          _vp],
     "r3det_feature_refine_forward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp],
     "r3det_feature_refine_prepare": [_vp, _i, _i, _i, _f, _vp, _vp],
     "r3det_feature_refine_forward_prepared": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
@@ -88,6 +90,8 @@ def lib():
         L.r3det_mcnms_select_workspace_bytes.restype = _sz
         L.r3det_level_pool_workspace_bytes.argtypes = [_i, _i, _i, _i, _i]
         L.r3det_level_pool_workspace_bytes.restype = _sz
+        L.r3det_levels_pool_workspace_bytes.argtypes = [_i, _i, _vp, _vp, _vp, _i]
+        L.r3det_levels_pool_workspace_bytes.restype = _sz
         L.r3det_fr_table_bytes.argtypes = [_i, _i, _i]
         L.r3det_fr_table_bytes.restype = _sz
         L.r3det_fr_workspace_bytes.argtypes = [_i, _i, _i, _i]

@@ -300,9 +300,10 @@ class RRetinaHead(nn.Module):
     def decode_bboxes(self, cls_scores, bbox_preds, img_shape, cfg=None, rois=None):
         """The shape-static part of get_bboxes (everything before the NMS, whose sizes depend on the
         scores): (N, n, 5) boxes and (N, n, C + 1) scores.  No host synchronisation: capturable in a
-        HIP graph together with the network.  On the device one library call per level (r3det_level_pool:
-        sigmoid, per-image top-nms_pre in score order, decoding, straight into the pool arrays); the op-by-op
-        torch form is ``decode_bboxes_torch``."""
+        HIP graph together with the network.  On the device one library call for all levels (r3det_levels_pool:
+        sigmoid, per-image top-nms_pre in score order, decoding, straight into the pool arrays; level by level
+        through r3det_level_pool / torch when a level is beyond the library's top-k); the op-by-op torch form is
+        ``decode_bboxes_torch``."""
         cfg = cfg or self.test_cfg
         nms_pre = cfg.get('nms_pre', -1)
         nms_pre = -1 if nms_pre is None else int(nms_pre)
@@ -320,6 +321,13 @@ class RRetinaHead(nn.Module):
         n = sum(rows)
         boxes = torch.empty((N, n, 5), dtype=torch.float32, device=dev)
         scores = torch.empty((N, n, C + 1), dtype=torch.float32, device=dev)
+        too_big = [0 < nms_pre < c.shape[-2] * c.shape[-1] * A and
+                   (nms_pre > fr_boxes.POOL_MAX_K or c.shape[-2] * c.shape[-1] * A > fr_boxes.POOL_MAX_ROWS)
+                   for c in cls_scores]
+        if not any(too_big) and len(cls_scores) <= fr_boxes.POOL_MAX_LEVELS:
+            # all levels in one library call (three launches for the whole pool)
+            fr_boxes.levels_pool(list(cls_scores), list(bbox_preds), lvl_anchors, A, C, nms_pre, img_shape, boxes, scores)
+            return boxes, scores
         off = 0
         for cls, reg, anc, r in zip(cls_scores, bbox_preds, lvl_anchors, rows):
             L = cls.shape[-2] * cls.shape[-1] * A

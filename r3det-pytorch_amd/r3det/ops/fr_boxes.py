@@ -85,3 +85,48 @@ def level_pool(cls_score, bbox_pred, anchors, num_anchors, num_classes, nms_pre,
                                       _C.ptr(pool_boxes), _C.ptr(pool_scores), n, int(row_offset), _C.ptr(ws), wsb,
                                       _C.stream()), "r3det_level_pool")
     return k if 0 < k < L else L
+
+
+POOL_MAX_LEVELS = 8  # r3det_levels_pool: levels per call
+
+
+def levels_pool(cls_scores, bbox_preds, anchors, num_anchors, num_classes, nms_pre, max_shape, pool_boxes, pool_scores):
+    """All pyramid levels of the pre-NMS pool in one library call (r3det_levels_pool): ``cls_scores`` /
+    ``bbox_preds`` / ``anchors`` are per-level lists as for ``level_pool``; level l's rows follow level l - 1's,
+    starting at row 0 of the pool arrays.  Row for row what one ``level_pool`` call per level writes.  Returns the
+    number of rows written per image."""
+    nl = len(cls_scores)
+    assert 0 < nl <= POOL_MAX_LEVELS and len(bbox_preds) == nl and len(anchors) == nl
+    A, C = num_anchors, num_classes
+    N = cls_scores[0].size(0)
+    per_image = anchors[0].dim() == 3
+    anchors = [_C.need_hip(a.contiguous(), "anchors") for a in anchors]
+    Hs, Ws, rows = [], [], 0
+    k = int(nms_pre) if nms_pre is not None else -1
+    for cls, reg, anc in zip(cls_scores, bbox_preds, anchors):
+        _check(cls, "cls_score"), _check(reg, "bbox_pred")
+        n_, _, H, W = cls.shape
+        L = H * W * A
+        assert n_ == N and cls.size(1) == A * C and reg.shape == (N, A * 5, H, W)
+        assert (anc.dim() == 3) == per_image and anc.shape == ((N, L, 5) if per_image else (L, 5))
+        Hs.append(H), Ws.append(W)
+        rows += k if 0 < k < L else L
+    _C.need_hip(pool_boxes, "pool_boxes")
+    _C.need_hip(pool_scores, "pool_scores")
+    n = pool_boxes.size(1)
+    assert pool_boxes.shape == (N, n, 5) and pool_scores.shape == (N, n, C + 1) and rows <= n
+    ptrs = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])  # noqa: E731
+    strides = lambda ts: (ctypes.c_longlong * (4 * nl))(*[v for t in ts for v in t.stride()])  # noqa: E731
+    ints = lambda vs: (ctypes.c_int * nl)(*vs)  # noqa: E731
+    lib = _C.lib()
+    dev = cls_scores[0].device
+    with torch.cuda.device(dev):
+        cA, cH, cW = ints([A] * nl), ints(Hs), ints(Ws)
+        wsb = int(lib.r3det_levels_pool_workspace_bytes(nl, N, cA, cH, cW, k))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        mx, my = (float(max_shape[1] - 1), float(max_shape[0] - 1)) if max_shape is not None else (-1.0, -1.0)
+        _C.check(lib.r3det_levels_pool(nl, ptrs(cls_scores), strides(cls_scores), ptrs(bbox_preds), strides(bbox_preds),
+                                       ptrs(anchors), int(per_image), N, cA, C, cH, cW, k, MAX_RATIO, mx, my,
+                                       _C.ptr(pool_boxes), _C.ptr(pool_scores), n, _C.ptr(ws), wsb, _C.stream()),
+                 "r3det_levels_pool")
+    return rows

@@ -30,16 +30,18 @@ def test_level_pool_matches_reference_pool(stage, nms_pre, channels_last):
 
 
 def test_decode_bboxes_goes_through_the_library(monkeypatch):
-    """The arrays above come from r3det_level_pool, not from the torch form: count the library calls."""
+    """The arrays above come from r3det_levels_pool (one call for the five levels), not from the torch form: count
+    the library calls."""
     from r3det.ops import fr_boxes
     h0, _ = heads()
     cls, reg = maps("s0", "cuda")
     n = []
-    real = fr_boxes.level_pool
-    monkeypatch.setattr(fr_boxes, "level_pool", lambda *a, **k: (n.append(1), real(*a, **k))[1])
+    real = fr_boxes.levels_pool
+    monkeypatch.setattr(fr_boxes, "levels_pool", lambda *a, **k: (n.append(len(a[0])), real(*a, **k))[1])
+    monkeypatch.setattr(h0, "decode_bboxes_torch", None)
     with torch.no_grad():
         h0.cuda().decode_bboxes(cls, reg, IMG, dict(nms_pre=500))
-    assert len(n) == 5
+    assert n == [5]
 
 
 @pytest.mark.parametrize("stage", ["s0", "sr"])

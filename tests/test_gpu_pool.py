@@ -166,3 +166,46 @@ def test_levels_beyond_the_library_limits_fall_back_per_level(monkeypatch):
     st = (ctypes.c_longlong * 4)(0, 0, 0, 0)
     assert L.r3det_level_pool(_C.ptr(t), st, _C.ptr(t), st, _C.ptr(t), 0, 1, 9, 15, 512, 512, 2000, 4.0, -1.0, -1.0,
                               _C.ptr(t), _C.ptr(t), 2000, 0, _C.ptr(t), 1 << 30, None) == -1
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("per_image", [False, True])
+@pytest.mark.parametrize("nms_pre", [300, -1, 5000])
+def test_levels_pool_equals_level_by_level(per_image, channels_last, nms_pre):
+    """r3det_levels_pool (all levels, three launches) writes bit for bit what one r3det_level_pool call per level
+    writes: levels that are cut and levels that are not, in any mix, one pool."""
+    from r3det.ops import fr_boxes
+    A, C, N = (1 if per_image else 3), 15, 3
+    sizes = [(40, 36), (3, 5), (20, 18), (10, 9), (5, 5), (1, 1)]
+    g = torch.Generator().manual_seed(7)
+    cls = [spread_logits(N, A, C, h, w, 30 + i).cuda() for i, (h, w) in enumerate(sizes)]
+    reg = [(torch.randn(N, A * 5, h, w, generator=g) * 0.5).cuda() for h, w in sizes]
+    if channels_last:
+        cls = [c.contiguous(memory_format=torch.channels_last) for c in cls]
+        reg = [r.contiguous(memory_format=torch.channels_last) for r in reg]
+    anchors = [(torch.rand(*((N,) if per_image else ()), h * w * A, 5, generator=g) * torch.tensor([400., 300., 60., 40., 1.])
+                + torch.tensor([0., 0., 4., 4., -1.5])).cuda() for h, w in sizes]
+    rows = [min(nms_pre, h * w * A) if nms_pre > 0 else h * w * A for h, w in sizes]
+    n = sum(rows)
+    wb, ws = torch.full((N, n, 5), -7.0).cuda(), torch.full((N, n, C + 1), -7.0).cuda()
+    off = 0
+    for c, r, a, k in zip(cls, reg, anchors, rows):
+        assert fr_boxes.level_pool(c, r, a, A, C, nms_pre, (300, 420), wb, ws, off) == k
+        off += k
+    gb, gs = torch.full((N, n + 3, 5), -7.0).cuda(), torch.full((N, n + 3, C + 1), -7.0).cuda()
+    assert fr_boxes.levels_pool(cls, reg, anchors, A, C, nms_pre, (300, 420), gb, gs) == n
+    assert torch.equal(gb[:, :n], wb) and torch.equal(gs[:, :n], ws)
+    assert bool((gb[:, n:] == -7).all()) and bool((gs[:, n:] == -7).all())  # nothing behind the pool's rows
+
+
+def test_levels_pool_argument_checks():
+    import ctypes
+    from r3det import _C
+    L = _C.lib()
+    i3 = (ctypes.c_int * 3)
+    assert L.r3det_levels_pool_workspace_bytes(3, 2, i3(9, 9, 9), i3(128, 64, 8), i3(128, 64, 8), 2000) == \
+        L.r3det_level_pool_workspace_bytes(2, 9, 128, 128, 2000) + L.r3det_level_pool_workspace_bytes(2, 9, 64, 64, 2000)
+    assert L.r3det_levels_pool_workspace_bytes(0, 2, i3(9, 9, 9), i3(8, 8, 8), i3(8, 8, 8), 2000) == 0
+    assert L.r3det_levels_pool_workspace_bytes(9, 2, None, None, None, 2000) == 0  # more than 8 levels
+    assert L.r3det_levels_pool(0, None, None, None, None, None, 0, 1, None, 15, None, None, -1, 1.0, -1.0, -1.0, None, None,
+                               0, None, 0, None) != 0
