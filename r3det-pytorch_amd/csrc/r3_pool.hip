@@ -9,12 +9,13 @@
 // elementwise launches per level.  Here, per level:
 //   keys   : one thread per (position, anchor): key = sigmoid(max_c logit) (= max_c sigmoid, monotone), order
 //            preserving u32, read through the head output's strides (NCHW or channels_last, no copy);
-//   select : ONE workgroup per image: exact k-th largest key by an 8-pass 4-bit radix select whose per-thread
-//            digit counts live in two byte-packed 64-bit registers (no LDS / global atomics: a detector's scores
-//            cluster in a few exponent bins, histograms of them serialise), ordered collection of the k winners
-//            (ties at the threshold: lowest index first), bitonic sort in LDS by (score desc, index asc),
-//            then decode + sigmoid of the winners' C logits straight into the pool arrays
-//            boxes (N, n, 5) / scores (N, n, C + 1) that r3det_mcnms_select reads;
+//   select : the threshold's 12-bit bin from the key launch's histogram; the keys above it and the keys inside it
+//            go to two per-image lists, 16 384 keys per workgroup (a flat score distribution with more than 8192
+//            keys in that bin: ONE workgroup per image finds the exact k-th largest key by 4-bit radix passes whose
+//            per-thread digit counts live in two byte-packed 64-bit registers);
+//   emit   : rank by counting over the chip (score desc, ties by ascending row), then decode + sigmoid of the
+//            winners' C logits straight into the pool arrays boxes (N, n, 5) / scores (N, n, C + 1) that
+//            r3det_mcnms_select reads;
 //   levels with at most nms_pre rows keep their order: one thread per row, no selection.
 // Arithmetic as the torch ops it replaces: sigmoid = 1 / (1 + expf(-x)), delta2bbox_v1 with the centre clamp
 // to the image (delta_xywha_rbbox_coder.py:142-211), IEEE add / mul (-ffp-contract=off).
@@ -206,6 +207,8 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(const PLevels P, u64*
   const uint4* kn4 = reinterpret_cast<const uint4*>(keys + (size_t)n * Lpad);
   const int L4 = Lpad >> 2;
   const int steps = (L4 + PS_T * PS_U - 1) / (PS_T * PS_U);
+  const int chunk = blockIdx.z;  // the split below: one step (16 384 keys) per workgroup
+  if (chunk >= steps) return;
 
   // ---- exact k-th largest key: 8 passes over 4-bit digits, most significant first
   unsigned prefix = 0, mask = 0;
@@ -294,8 +297,9 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(const PLevels P, u64*
     __syncthreads();
   }
   stamp(1);
-  for (; shift >= 0; shift -= 4) {
-    if (shift == 16 && s_eq_total <= PS_CAND) break;
+  const bool flat = s_eq_total > PS_CAND;  // (known from the histogram alone: every workgroup of the image agrees)
+  if (flat && chunk != 0) return;
+  for (; flat && shift >= 0; shift -= 4) {
     int tot[16];
 #pragma unroll
     for (int d = 0; d < 16; d++) tot[d] = 0;
@@ -331,45 +335,74 @@ __global__ __launch_bounds__(PS_T) void pool_select_kernel(const PLevels P, u64*
     }
     choose(tot, shift);
   }
-  const bool in_lds = shift >= 0;  // the survivors fit the LDS copy (wave-uniform)
-  if (in_lds) {
-    // ONE pass over the keys: the keys above the 12-bit prefix go to `list` (k - need of them: winners whatever the
-    // remaining digits say), the keys matching it to `cand`.  No more digits and no sort here: the emit launch ranks
-    // every entry by counting, spread over the chip -- in this one workgroup the five LDS digit passes took 18 us
-    // and the bitonic sort of the k winners 27 us of a 56 us kernel (tools/probes/pool_select_probe.hip), whether
-    // the sort ran through LDS or in registers with shuffles.
-    if (tid == 0) { s_ncand = 0; s_gt = 0; }
-    __syncthreads();
-    for (int st = 0; st < steps; st++) {
-      uint4 v[PS_U];
+  if (!flat) {
+    // The keys above the 12-bit prefix go to `list` (k - need of them: winners whatever the remaining digits say),
+    // the keys matching it to `cand`.  No more digits and no sort: the emit launch ranks every entry by counting,
+    // spread over the chip -- in one workgroup the five LDS digit passes took 18 us and the bitonic sort of the k
+    // winners 27 us of a 56 us kernel (tools/probes/pool_select_probe.hip).  And the pass itself is spread over the
+    // chip too: a workgroup takes ONE step of 16 384 keys, counts its entries (ballots), reserves its places in the
+    // two lists with one global atomic each and writes them -- any order will do, the entries carry their index.
+    // (One workgroup per image walked all keys: 52 us at RRetinaNet's 147 456 rows.)
+    uint4 v[PS_U];
 #pragma unroll
-      for (int u = 0; u < PS_U; u++) {
-        const int q = (st * PS_U + u) * PS_T + tid;
-        v[u] = q < L4 ? kn4[q] : make_uint4(0u, 0u, 0u, 0u);
-      }
+    for (int u = 0; u < PS_U; u++) {
+      const int q = (chunk * PS_U + u) * PS_T + tid;
+      v[u] = q < L4 ? kn4[q] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    int wc = 0, wg = 0;  // this wave's entries (wave-uniform)
 #pragma unroll
-      for (int u = 0; u < PS_U; u++) {
-        const unsigned kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-        const int q = (st * PS_U + u) * PS_T + tid;
+    for (int u = 0; u < PS_U; u++) {
+      const unsigned kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const unsigned key = kk[e];
-          const u64 ent = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned)(q * 4 + e));
-          const bool is_c = key != 0u && (key & mask) == prefix, is_g = !is_c && (key & mask) > prefix;
-          const int pc = wave_append(&s_ncand, is_c);
-          if (pc >= 0) cand[pc] = ent;
-          const int pg = wave_append(&s_gt, is_g);
-          if (pg >= 0) list[pg] = ent;
-        }
+      for (int e = 0; e < 4; e++) {
+        const unsigned key = kk[e];
+        const bool is_c = key != 0u && (key & mask) == prefix, is_g = !is_c && (key & mask) > prefix;
+        wc += __popcll(__ballot(is_c));
+        wg += __popcll(__ballot(is_g));
       }
     }
+    if (lane == 0) {
+      wcnt[wave][0] = wc;
+      wcnt[wave][1] = wg;
+    }
     __syncthreads();
-    stamp(2);
+    int bc = 0, bg = 0, tc = 0, tg = 0;
+#pragma unroll
+    for (int w = 0; w < PS_T / 64; w++) {
+      const int c = wcnt[w][0], g = wcnt[w][1];
+      if (w < wave) { bc += c; bg += g; }
+      tc += c;
+      tg += g;
+    }
     if (tid == 0) {
-      meta[blockIdx.x * 4 + 0] = k - need;   // entries of `list`
-      meta[blockIdx.x * 4 + 1] = s_ncand;    // entries of `cand`
-      meta[blockIdx.x * 4 + 2] = need;       // winners among them
+      s_ncand = tc ? atomicAdd(&meta[n * 4 + 1], tc) : 0;
+      s_gt = tg ? atomicAdd(&meta[n * 4 + 3], tg) : 0;
+      if (chunk == 0) {
+        meta[n * 4 + 0] = k - need;  // entries of `list` (meta[3]: the cursor that fills it)
+        meta[n * 4 + 2] = need;      // winners among the entries of `cand` (meta[1]: their number)
+      }
     }
+    __syncthreads();
+    int pc = s_ncand + bc, pg = s_gt + bg;
+#pragma unroll
+    for (int u = 0; u < PS_U; u++) {
+      const unsigned kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      const int q = (chunk * PS_U + u) * PS_T + tid;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const unsigned key = kk[e];
+        const u64 ent = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned)(q * 4 + e));
+        const bool is_c = key != 0u && (key & mask) == prefix, is_g = !is_c && (key & mask) > prefix;
+        const u64 mc = __ballot(is_c), mg = __ballot(is_g);
+        const int rc_ = pc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mc, 0u));
+        const int rg_ = pg + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, 0u));
+        if (is_c && rc_ < PS_CAND) cand[rc_] = ent;
+        if (is_g && rg_ < PS_KMAX) list[rg_] = ent;
+        pc += __popcll(mc);
+        pg += __popcll(mg);
+      }
+    }
+    stamp(2);
     stamp(3);
     stamp(4);
   } else {
@@ -596,24 +629,27 @@ int r3k_levels_pool(int nlevels, const float* const* cls, const long long* cls_s
   if (nsel) {
     if (!ws || ws_bytes < r3k_levels_pool_workspace_bytes(nlevels, N, A, H, W, nms_pre)) return -3;
     if (reinterpret_cast<uintptr_t>(ws) & 15) return -1;
-    // all histograms first (one memset), then per select level: keys | list | cand | meta
+    // all histograms and list cursors first (one memset), then per select level: keys | list | cand
     char* p = (char*)ws;
-    const size_t hist_bytes = (size_t)N * PH_BINS * 4;
-    char* q = p + (size_t)nsel * hist_bytes;
+    const size_t hist_bytes = (size_t)N * PH_BINS * 4, meta_bytes = ((size_t)N * 16 + 255) & ~(size_t)255;
+    char* q = p + (size_t)nsel * (hist_bytes + meta_bytes);
+    int max_steps = 1;
     for (int l = 0; l < nlevels; l++) {
       PLevel& V = P.lv[l];
       if (!V.select) continue;
       V.hist = (unsigned*)(p + (size_t)V.sel_index * hist_bytes);
+      V.meta = (int*)(p + (size_t)nsel * hist_bytes + (size_t)V.sel_index * meta_bytes);
       V.keys = (unsigned*)q;
       q += ((size_t)N * V.Lpad * sizeof(unsigned) + 255) & ~(size_t)255;
       V.glist = (u64*)q;
       V.clist = V.glist + (size_t)N * PS_KMAX;
-      V.meta = (int*)(V.clist + (size_t)N * PS_CAND);
-      q = (char*)V.meta + (((size_t)N * 16 + 255) & ~(size_t)255);
+      q = (char*)(V.clist + (size_t)N * PS_CAND);
+      const int steps = ((V.Lpad >> 2) + PS_T * PS_U - 1) / (PS_T * PS_U);
+      if (steps > max_steps) max_steps = steps;
     }
-    if (hipMemsetAsync(p, 0, (size_t)nsel * hist_bytes, stream) != hipSuccess) return -2;
+    if (hipMemsetAsync(p, 0, (size_t)nsel * (hist_bytes + meta_bytes), stream) != hipSuccess) return -2;
     hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)kblocks, N), dim3(256), 0, stream, P);
-    hipLaunchKernelGGL(pool_select_kernel, dim3(N, nsel), dim3(PS_T), 0, stream, P, (u64*)nullptr);
+    hipLaunchKernelGGL(pool_select_kernel, dim3(N, nsel, max_steps), dim3(PS_T), 0, stream, P, (u64*)nullptr);
   }
   hipLaunchKernelGGL(pool_emit_kernel, dim3((unsigned)eblocks, N), dim3(256), 0, stream, P);
   return hipGetLastError() == hipSuccess ? 0 : -2;

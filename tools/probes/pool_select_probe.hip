@@ -35,7 +35,8 @@ int main(int argc, char** argv) {
     P.count = 1; P.k = k; P.kb = (k + PE_C - 1) / PE_C;
     P.lv[0].select = 1; P.lv[0].Lpad = Lpad; P.lv[0].keys = dk; P.lv[0].hist = dh; P.lv[0].glist = gl; P.lv[0].clist = cl_;
     P.lv[0].meta = sel;
-    hipLaunchKernelGGL(pool_select_kernel, dim3(N, 1), dim3(PS_T), 0, 0, P, st);
+    CK(hipMemset(sel, 0, (size_t)N * 16));
+    hipLaunchKernelGGL(pool_select_kernel, dim3(N, 1, ((Lpad >> 2) + PS_T * PS_U - 1) / (PS_T * PS_U)), dim3(PS_T), 0, 0, P, st);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     u64 s[8]; CK(hipMemcpy(s, st, 64, hipMemcpyDeviceToHost));
