@@ -66,6 +66,13 @@ int r3det_box_iou_rotated_overlaps(const float* b1, int n1, const float* b2, int
                                    int iou_or_iof, float* out, void* ws, size_t ws_bytes,
                                    void* stream);
 
+/* obb_overlaps(bboxes1, bboxes2, mode, is_aligned=False)   ops/box_iou_rotated/box_iou_rotated_wrapper.py:8-64:
+ * the call above followed by the wrapper's epilogue -- rows of b1-boxes and columns of b2-boxes with
+ * min(w, h) < 1e-3 are zeroed (:53-60) -- in one more small launch instead of six framework ones (the
+ * masked_fill alone rewrites the whole matrix). */
+int r3det_obb_overlaps(const float* b1, int n1, const float* b2, int n2, int iou_or_iof, float* out, void* ws,
+                       size_t ws_bytes, void* stream);
+
 /* Pairwise companion of the call above: out[i] = overlap(b1[i], b2[i]), i < n.  Serves
  * obb_overlaps(is_aligned=True) (box_iou_rotated_wrapper.py:48-49), whose reference
  * implementation is a differentiable torch composition + convex_sort. */

@@ -66,6 +66,14 @@ int r3det_box_iou_rotated_overlaps(const float* b1, int n1, const float* b2, int
   return rc(r3k_iou_mat(R3DET_GEOM_V3, iou_or_iof == 0, b1, n1, b2, n2, out, ws, ws_bytes, S(stream)));
 }
 
+int r3det_obb_overlaps(const float* b1, int n1, const float* b2, int n2, int iou_or_iof, float* out, void* ws,
+                       size_t ws_bytes, void* stream) {
+  if (bad_iou_args(b1, n1, b2, n2, out)) return R3DET_EINVAL;
+  const int r = r3k_iou_mat(R3DET_GEOM_V3, iou_or_iof == 0, b1, n1, b2, n2, out, ws, ws_bytes, S(stream));
+  if (r) return rc(r);
+  return rc(r3k_iou_zero_thin(b1, n1, b2, n2, out, S(stream)));
+}
+
 int r3det_box_iou_rotated_overlaps_aligned(const float* b1, const float* b2, int n,
                                            int iou_or_iof, float* out, void* stream) {
   if (bad_iou_args(b1, n, b2, n, out)) return R3DET_EINVAL;

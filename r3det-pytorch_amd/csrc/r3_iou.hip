@@ -867,6 +867,42 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
 
 }  // namespace
 
+namespace {
+// obb_overlaps' epilogue (box_iou_rotated_wrapper.py:53-60): rows of b1-boxes and columns of b2-boxes with
+// min(w, h) < 1e-3 are zeroed.  One thread looks at one line (row or column); a wave zeroes its (rare) thin lines
+// together.  torch.min propagates NaN, and NaN < 1e-3 is false: a box with a NaN side is not thin.
+__global__ __launch_bounds__(256) void iou_zero_thin_kernel(const float* __restrict__ b1, int n1,
+                                                            const float* __restrict__ b2, int n2,
+                                                            float* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  bool thin = false;
+  if (t < n1 + n2) {
+    const float* b = t < n1 ? b1 + (size_t)t * 5 : b2 + (size_t)(t - n1) * 5;
+    const float w = b[2], h = b[3];
+    thin = !(w != w || h != h) && fminf(w, h) < 0.001f;
+  }
+  unsigned long long m = __ballot(thin);
+  while (m) {
+    const int line = t - lane + __builtin_ctzll(m);  // wave-uniform
+    m &= m - 1;
+    if (line < n1) {
+      float* o = out + (size_t)line * n2;
+      for (int c = lane; c < n2; c += 64) o[c] = 0.f;
+    } else {
+      float* o = out + (line - n1);
+      for (int r = lane; r < n1; r += 64) o[(size_t)r * n2] = 0.f;
+    }
+  }
+}
+}  // namespace
+
+int r3k_iou_zero_thin(const float* b1, int n1, const float* b2, int n2, float* out, hipStream_t stream) {
+  if (n1 <= 0 || n2 <= 0) return 0;
+  hipLaunchKernelGGL(iou_zero_thin_kernel, dim3((unsigned)(((long long)n1 + n2 + 255) / 256)), dim3(256), 0, stream, b1, n1,
+                     b2, n2, out);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 size_t r3k_iou_workspace_bytes(int n1, int n2) {
   if (n1 <= 0 || n2 <= 0) return 256;
   return pipe_layout(n1, n2, nullptr, nullptr);

@@ -9,6 +9,8 @@ size_t r3k_iou_workspace_bytes(int n1, int n2);
 // ws may be null (single-kernel path); with a workspace the stream + drain pipeline runs
 int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
                 void* ws, size_t ws_bytes, hipStream_t stream);
+// obb_overlaps' epilogue: zero the rows / columns of boxes with min(w, h) < 1e-3
+int r3k_iou_zero_thin(const float* b1, int n1, const float* b2, int n2, float* out, hipStream_t stream);
 int r3k_iou_vec(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
                 hipStream_t stream);
 

@@ -19,6 +19,7 @@ SIGNATURES = {
     "r3det_rbbox_geo_mat_iou_iof": [_vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp],
     "r3det_rbbox_geo_vec_iou_iof": [_vp, _i, _vp, _i, _i, _vp, _vp],
     "r3det_box_iou_rotated_overlaps": [_vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp],
+    "r3det_obb_overlaps": [_vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp],
     "r3det_box_iou_rotated_overlaps_aligned": [_vp, _vp, _i, _i, _vp, _vp],
     "r3det_mmcv_box_iou_rotated": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp],
     "r3det_rbbox_assign": [_i, _vp, _i, _vp, _i, _f, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],

@@ -115,11 +115,16 @@ def obb_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, device_id=None)
     elif is_aligned:
         out = aligned_obb_overlaps(b1, b2, mode)
     else:
-        out = box_iou_rotated_v3(b1, b2, mode == 'iou')
-        small1 = b1[:, 2:4].min(1)[0] < 0.001
-        small2 = b2[:, 2:4].min(1)[0] < 0.001
-        # branch-free form of the reference's `if any(): outputs[inds] = 0` (no host sync)
-        out = out.masked_fill(small1[:, None] | small2[None, :], 0.)
+        # the kernel + the reference's `if too_small.any(): outputs[inds] = 0` epilogue in one library call
+        # (r3det_obb_overlaps: no host sync, no second pass over the matrix)
+        b1 = _as_boxes(b1.contiguous(), "bboxes1")
+        b2 = _as_boxes(b2.contiguous(), "bboxes2")
+        n1, n2 = b1.size(0), b2.size(0)
+        out = b1.new_empty((n1, n2))
+        with torch.cuda.device(b1.device):
+            ws, wsb = _C.iou_workspace(n1, n2, b1.device)
+            _C.check(_C.lib().r3det_obb_overlaps(_C.ptr(b1), n1, _C.ptr(b2), n2, int(mode == 'iou'), _C.ptr(out),
+                                                 _C.ptr(ws), wsb, _C.stream()), "obb_overlaps")
     return out.cpu().numpy() if is_numpy else out
 
 

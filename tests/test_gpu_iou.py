@@ -188,6 +188,33 @@ def test_calculators_and_wrapper_quirks():
     assert obb_overlaps(dev(a)[:0], dev(b)).shape == (0, 77)
 
 
+@pytest.mark.parametrize("shape", [(300, 77), (40, 5000), (3, 1), (130, 2100)])
+@pytest.mark.parametrize("mode", ["iou", "iof"])
+def test_obb_overlaps_epilogue_in_the_library(shape, mode):
+    """r3det_obb_overlaps = the v3 matrix + `outputs[too_small] = 0` (box_iou_rotated_wrapper.py:53-60) in the same
+    call: equal to the matrix entry followed by the reference's torch epilogue -- several thin lines per wave,
+    the first and last line, a NaN side (torch.min propagates it: not thin), zero and negative sides, every matrix
+    form (small, one-launch tiles, stream + drain)."""
+    from r3det.ops import obb_overlaps
+    from r3det.ops.iou import box_iou_rotated_v3
+    n1, n2 = shape
+    a, b = rand_boxes(n1, 51, span=120.0), rand_boxes(n2, 52, span=120.0)
+    for arr, idx in ((a, [0, n1 - 1, n1 // 2, n1 // 2 + 1]), (b, [0, n2 - 1, n2 // 3, n2 // 3 + 1, n2 // 3 + 2])):
+        for k, i in enumerate(idx):
+            arr[i % len(arr), 2 + (k & 1)] = [5e-4, 0.0, -3.0, 9.9e-4, 1e-5][k % 5]
+    if n1 > 10:
+        a[7, 2], a[7, 3] = np.nan, 1e-5   # not thin: min() is NaN
+        a[9, 2] = 1e-3                    # not thin: strictly below 1e-3 only
+    ta, tb = dev(a), dev(b)
+    want = box_iou_rotated_v3(ta, tb, mode == 'iou')
+    s1 = ta[:, 2:4].min(1)[0] < 0.001
+    s2 = tb[:, 2:4].min(1)[0] < 0.001
+    assert int(s1.sum()) >= 1 and int(s2.sum()) >= 1 and (n1 <= 10 or (not bool(s1[7]) and not bool(s1[9])))
+    want = want.masked_fill(s1[:, None] | s2[None, :], 0.)
+    got = obb_overlaps(ta, tb, mode=mode)
+    assert same(got.cpu().numpy(), want.cpu().numpy())
+
+
 def test_errors():
     from r3det.ops import rbbox_iou
     a = dev(rand_boxes(10, 1))
