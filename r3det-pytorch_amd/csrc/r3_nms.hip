@@ -770,7 +770,8 @@ template <bool GROUPED>
 __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT, const Side& sd, const int n,
                                                    const int bt_rows, const int cb, const uint8_t* __restrict__ rlab,
                                                    const int group,
-                                                   u64* __restrict__ kbits, unsigned char* smem8, int* s_und,
+                                                   u64* __restrict__ kbits, const int* __restrict__ svals,
+                                                   u64* __restrict__ fbits, unsigned char* smem8, int* s_und,
                                                    int* s_nbig, int* s_m, int* wsum) {
   const int cbn = (n + TILE - 1) / TILE;
   const int nb = (n + 15) & ~15;
@@ -793,29 +794,46 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   __syncthreads();
   int m = n;
   if (GROUPED) {
-    // ordered compaction of the label's rows: block counts -> exclusive scan -> ranks
-    int base = 0;
-    for (int r0 = 0; r0 < n; r0 += RTHREADS) {
-      const int r = r0 + tid;
-      const bool mine = r < n && (rlab[r] & (RG_GROUPS - 1)) == group;
-      const u64 mb = __ballot(mine);
-      if (lane == 0) {
-        wsum[wave] = __popcll(mb);
-        if (mb) Own[r >> 6] = mb;  // (a wave's 64 rows are one mask word)
+    // ordered compaction of the label's rows: every thread's labels requested together (a trip per 1024 rows with
+    // its own load and two barriers made this the longest phase of the kernel: nine dependent L2 round trips at
+    // n = 8576), the wave masks kept in registers, ONE table of wave counts, ranks from it
+    constexpr int TRIPS = RG_MAXN / RTHREADS;
+    unsigned char lb[TRIPS];
+#pragma unroll
+    for (int u = 0; u < TRIPS; u++) {
+      const int r = u * RTHREADS + tid;
+      lb[u] = r < n ? rlab[r] : (unsigned char)0;
+    }
+    u64 mbs[TRIPS];
+    unsigned short* wtab = blist;  // [TRIPS][16] wave counts (the worklist is not in use yet)
+#pragma unroll
+    for (int u = 0; u < TRIPS; u++) {
+      const int r = u * RTHREADS + tid;
+      const bool mine = r < n && (lb[u] & (RG_GROUPS - 1)) == group;
+      mbs[u] = __ballot(mine);
+      if (lane == 0 && u * RTHREADS < n) {
+        wtab[u * 16 + wave] = (unsigned short)__popcll(mbs[u]);
+        if (mbs[u]) Own[r >> 6] = mbs[u];  // (a wave's 64 rows are one mask word)
       }
-      __syncthreads();
+    }
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int u = 0; u < TRIPS; u++) {
+      if (u * RTHREADS >= n) break;
       int woff = 0, tot = 0;
 #pragma unroll
       for (int w = 0; w < RTHREADS / 64; w++) {
-        const int t = wsum[w];
+        const int t = wtab[u * 16 + w];
         if (w < wave) woff += t;
         tot += t;
       }
-      if (mine) rows_l[base + woff + __popcll(mb & ((1ULL << lane) - 1ULL))] = (unsigned short)r;
+      if ((mbs[u] >> lane) & 1ULL)
+        rows_l[base + woff + __popcll(mbs[u] & ((1ULL << lane) - 1ULL))] = (unsigned short)(u * RTHREADS + tid);
       base += tot;
-      __syncthreads();
     }
     m = base;
+    __syncthreads();
   }
   auto row_of = [&](const int k) -> int { return GROUPED ? (int)rows_l[k] : k; };
   auto set_bit = [&](u64* words, const int r) { atomicOr(&words[r >> 6], 1ULL << (r & 63)); };
@@ -1021,13 +1039,24 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       kbits[b] = kb;
     }
   }
+  // ... and over the CANDIDATE indices (the index-ordered finish reads these: no translation pass there)
+  if (fbits) {
+    for (int k = tid; k < m; k += RTHREADS) {
+      const int r = row_of(k);
+      if (st[r] == 1) {
+        const int c = svals[r];
+        atomicOr(&fbits[c >> 6], 1ULL << (c & 63));
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* __restrict__ maskT,
                                                                      u64* __restrict__ side, int cb,
                                                                      const unsigned* __restrict__ counter,
                                                                      u64* __restrict__ kbits, size_t kbits_stride,
-                                                                     Batch bt) {
+                                                                     const int* __restrict__ svals,
+                                                                     u64* __restrict__ fbits, Batch bt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
   __shared__ int s_und, s_nbig, s_m;
   __shared__ int wsum[RTHREADS / 64];
@@ -1038,9 +1067,11 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* 
   const Side sd = side_tables(side + img * bt.nz, bt.rows);
   if (grouped)
     reduce_groups_body<true>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, bt.rlab + (size_t)img * bt.rows, (int)blockIdx.x,
-                             kbits + img * kbits_stride, smem8, &s_und, &s_nbig, &s_m, wsum);
+                             kbits + img * kbits_stride, svals + (size_t)img * bt.rows,
+                             fbits ? fbits + img * kbits_stride : nullptr, smem8, &s_und, &s_nbig, &s_m, wsum);
   else
-    reduce_groups_body<false>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, nullptr, 0, kbits + img * kbits_stride, smem8, &s_und,
+    reduce_groups_body<false>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, nullptr, 0, kbits + img * kbits_stride,
+                              svals + (size_t)img * bt.rows, fbits ? fbits + img * kbits_stride : nullptr, smem8, &s_und,
                               &s_nbig, &s_m, wsum);
 }
 
@@ -1470,71 +1501,63 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
                                                          const int* __restrict__ cand_row,
                                                          const int* __restrict__ cand_label,
                                                          const float* __restrict__ cand_score, int cand_stride,
-                                                         const int* __restrict__ sorted_vals,
                                                          const int* __restrict__ counts,
-                                                         const u64* __restrict__ kbits, size_t kbits_stride,
-                                                         size_t rows_stride, int fwords, int out_cap,
+                                                         const u64* __restrict__ fbits, size_t fbits_stride, int out_cap,
                                                          float* __restrict__ dets_out,
                                                          int64_t* __restrict__ labels_out,
                                                          int64_t* __restrict__ keep_idx_out,
                                                          int32_t* __restrict__ counts_out) {
-  // Ascending keep = a bit per candidate, in LDS: set from the reducer's kept rows (bits over the sorted positions ->
-  // candidate indices), block counts by popcount, wave-shuffle scan, then ONE kept candidate per thread and trip (the
-  // earlier form kept byte flags in global memory, scanned with 20 barriers and gathered up to 9 rows per thread
-  // serially).
-  extern __shared__ unsigned long long fbits[];  // ceil(M / 64) words, then as many ints of prefix
-  __shared__ int wsum[16];
+  // Ascending keep: the reducer left a bit per kept CANDIDATE (fbits).  grid = (chunks of 1024 candidates, images):
+  // a workgroup counts the kept candidates in front of its chunk (popcounts of at most 1023 words), then every
+  // thread emits its own candidate.  (One workgroup per image that first translated the sorted rows to candidates
+  // and then walked all of them: 14.5 us at 8576 candidates.)
+  __shared__ int wsum[2][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int img = blockIdx.x;
+  const int img = blockIdx.y;
   const int M = counts[img];
+  const int i0 = blockIdx.x * 1024;
+  if (i0 >= M && blockIdx.x != 0) return;
   const size_t cbase = (size_t)img * cand_stride;
-  kbits += img * kbits_stride;
+  fbits += img * fbits_stride;
   const int words = (M + 63) >> 6;
-  int* wpre = reinterpret_cast<int*>(fbits + fwords);
-  for (int w = tid; w < words; w += 1024) fbits[w] = 0ULL;
-  __syncthreads();
-  for (int r = tid; r < M; r += 1024) {
-    if (!((kbits[r >> 6] >> (r & 63)) & 1ULL)) continue;
-    const int c = sorted_vals[img * rows_stride + r];
-    atomicOr(&fbits[c >> 6], 1ULL << (c & 63));
+  const int first = blockIdx.x * 16, wmine = first + wave;  // the chunk's words; the wave's own word
+  int before = 0, all = 0;  // kept candidates in front of the chunk; all of them (workgroup 0: counts_out)
+  for (int w = tid; w < words; w += 1024) {  // (M < 65536: one trip)
+    const int c = __popcll(fbits[w]);
+    all += c;
+    if (w < first) before += c;
   }
-  __syncthreads();
-  int run = 0;
-  for (int w0 = 0; w0 < words; w0 += 1024) {  // (M <= 65472: one trip)
-    const int w = w0 + tid;
-    const int c = w < words ? __popcll(fbits[w]) : 0;
-    int incl = c;
+  int inside = (lane < wave && first + lane < words) ? __popcll(fbits[first + lane]) : 0;  // the chunk's words in front of the wave's
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int woff = 0, tot = 0;
+  for (int d = 32; d >= 1; d >>= 1) {
+    before += __shfl_xor(before, d);
+    all += __shfl_xor(all, d);
+    inside += __shfl_xor(inside, d);
+  }
+  if (lane == 0) {
+    wsum[0][wave] = before;
+    wsum[1][wave] = all;
+  }
+  __syncthreads();
+  int base = inside, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int t = wsum[k];
-      if (k < wave) woff += t;
-      tot += t;
-    }
-    if (w < words) wpre[w] = run + woff + incl - c;
-    run += tot;
-    __syncthreads();
+  for (int w = 0; w < 16; w++) {
+    base += wsum[0][w];
+    tot += wsum[1][w];
   }
-  for (int i = tid; i < M; i += 1024) {
-    const unsigned long long wbits = fbits[i >> 6];
-    if (!((wbits >> (i & 63)) & 1ULL)) continue;
-    const int pos = wpre[i >> 6] + __popcll(wbits & ((1ULL << (i & 63)) - 1ULL));
-    if (pos >= out_cap) continue;
-    const float* b = boxes + ((size_t)img * n + cand_row[cbase + i]) * 5;
-    float* d = dets_out + ((size_t)img * out_cap + pos) * 6;
-    d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
-    d[5] = cand_score[cbase + i];
-    labels_out[(size_t)img * out_cap + pos] = cand_label[cbase + i];
-    if (keep_idx_out) keep_idx_out[(size_t)img * out_cap + pos] = i;  // candidate index, ascending
-  }
-  if (tid == 0) counts_out[img] = min(run, out_cap);
+  if (blockIdx.x == 0 && tid == 0) counts_out[img] = min(tot, out_cap);
+  const int i = i0 + tid;
+  if (i >= M) return;
+  const u64 wbits = fbits[wmine];
+  if (!((wbits >> lane) & 1ULL)) return;
+  const int pos = base + __popcll(wbits & ((1ULL << lane) - 1ULL));
+  if (pos >= out_cap) return;
+  const float* b = boxes + ((size_t)img * n + cand_row[cbase + i]) * 5;
+  float* d = dets_out + ((size_t)img * out_cap + pos) * 6;
+  d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
+  d[5] = cand_score[cbase + i];
+  labels_out[(size_t)img * out_cap + pos] = cand_label[cbase + i];
+  if (keep_idx_out) keep_idx_out[(size_t)img * out_cap + pos] = i;  // candidate index, ascending
 }
 
 // finish for the score-ordered families (v3 obb_nms, v2 ml_nms_rotated): the keep list already is in
@@ -1605,6 +1628,7 @@ struct McLayout {
   uint8_t* dead;
   uint8_t* rlab;   // label of every sorted row
   u64* kbits;      // kept rows as bits (cb words per image; zeroed with the masks)
+  u64* fbits;      // kept CANDIDATES as bits (index order; the same)
   float* extent;
   int* ccounts;
   size_t qcap, qstride, zero_bytes;  // entries per region; entries per image
@@ -1621,6 +1645,7 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* mask = take((size_t)B * cap * cb * 8);  // mask and nz: one fill
   char* nz = take((size_t)B * side_words((size_t)cap) * 8);  // per image: side tables
   char* kbits = take((size_t)B * cb * 8);                    // (still inside the zeroed region)
+  char* fbits = take((size_t)B * cb * 8);                    // (the same)
   char* counter = take((size_t)B * Q_CTL_WORDS * 4);
   char* gq = take((size_t)B * qcap * 4);
   char* rd = take((size_t)B * cb * cb * 4);  // redo-tile lists
@@ -1634,7 +1659,7 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   if (L) {
     L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
     L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->redo = (unsigned*)rd; L->keep = (int64_t*)keep;
-    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->rlab = (uint8_t*)rlab; L->kbits = (u64*)kbits; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
+    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->rlab = (uint8_t*)rlab; L->kbits = (u64*)kbits; L->fbits = (u64*)fbits; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
     L->qcap = qcap / Q_NREG; L->qstride = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb;
     if (g_r3_nms_qcap > 0 && (size_t)g_r3_nms_qcap < L->qcap) L->qcap = (size_t)g_r3_nms_qcap;
   }
@@ -1728,12 +1753,12 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     }
     if (lds > 160 * 1024 - 256) return -1;  // (cap < 65536: never)
     hipLaunchKernelGGL(nms_reduce_groups_kernel, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
-                       L.counter, L.kbits, cbq, bt);
+                       L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt);
   }
   if (geom == 1)
-    hipLaunchKernelGGL(mc_finish_kernel, dim3(B), dim3(1024), (size_t)L.cb * 12, stream, boxes, n, cand_row, cand_label,
-                       cand_score, S, L.svals, counts, L.kbits, cbq, (size_t)cap, L.cb, out_cap, dets_out, labels_out,
-                       keep_idx_out, counts_out);
+    hipLaunchKernelGGL(mc_finish_kernel, dim3((cap + 1023) / 1024, B), dim3(1024), 0, stream, boxes, n, cand_row,
+                       cand_label, cand_score, S, counts, L.fbits, cbq, out_cap, dets_out, labels_out, keep_idx_out,
+                       counts_out);
   else
     hipLaunchKernelGGL(mc_finish_score_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label,
                        cand_score, S, L.svals, counts, L.kbits, cbq, (size_t)cap,
