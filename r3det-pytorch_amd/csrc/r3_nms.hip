@@ -766,13 +766,19 @@ __host__ __device__ inline size_t reduce_groups_lds_bytes(int n, int cb, bool wi
   return (size_t)((n + 15) & ~15) + (size_t)cb * 8 * 3 + (with_row_list ? (size_t)n * 2 : 0) + (size_t)R_BLIST * 2 + 64;
 }
 
+u64* g_nms_stamps = nullptr;  // tools/probes/nms_reduce_probe.hip: clock stamps of reducer workgroup (0, 0) at its phases
+
 template <bool GROUPED>
 __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT, const Side& sd, const int n,
                                                    const int bt_rows, const int cb, const uint8_t* __restrict__ rlab,
                                                    const int group,
                                                    u64* __restrict__ kbits, const int* __restrict__ svals,
                                                    u64* __restrict__ fbits, unsigned char* smem8, int* s_und,
-                                                   int* s_nbig, int* s_m, int* wsum) {
+                                                   int* s_nbig, int* s_m, int* wsum, u64* __restrict__ stamps) {
+  auto stamp = [&](int k) {
+    if (stamps && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   const int cbn = (n + TILE - 1) / TILE;
   const int nb = (n + 15) & ~15;
   unsigned char* st = smem8;                               // row state: 0 undecided, 1 kept, 2 removed
@@ -817,27 +823,108 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       }
     }
     __syncthreads();
-    int base = 0;
+    // exclusive scan over the (trip, wave) table, by every wave for itself: lane l takes entries 4l .. 4l+3 (one
+    // 8-byte LDS read), six shuffle steps, and the wave's 16 bases come back through readlane -- 16 LDS reads per
+    // thread and trip (the first form of this loop) were 10 us of the kernel (tools/probes/nms_reduce_probe.hip)
+    const int trips = (n + RTHREADS - 1) / RTHREADS;
+    const uint2 q4 = (4 * lane < trips * 16) ? reinterpret_cast<const uint2*>(wtab)[lane] : make_uint2(0u, 0u);
+    const int e0 = (int)(q4.x & 0xffffu), e1 = (int)(q4.x >> 16), e2 = (int)(q4.y & 0xffffu), e3 = (int)(q4.y >> 16);
+    const int mine4 = e0 + e1 + e2 + e3;
+    int incl = mine4;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    const int ex0 = incl - mine4;  // exclusive prefix of entry 4 * lane
+    const int wvu = __builtin_amdgcn_readfirstlane(wave);
+    const int wq = wvu & 3;        // the wave's entry in trip u is 16 u + wave: lane 4 u + wave / 4, component wave & 3
+    const int exw = ex0 + (wq > 0 ? e0 : 0) + (wq > 1 ? e1 : 0) + (wq > 2 ? e2 : 0);
 #pragma unroll
     for (int u = 0; u < TRIPS; u++) {
       if (u * RTHREADS >= n) break;
-      int woff = 0, tot = 0;
-#pragma unroll
-      for (int w = 0; w < RTHREADS / 64; w++) {
-        const int t = wtab[u * 16 + w];
-        if (w < wave) woff += t;
-        tot += t;
-      }
+      const int base = __builtin_amdgcn_readlane(exw, 4 * u + (wvu >> 2));
       if ((mbs[u] >> lane) & 1ULL)
-        rows_l[base + woff + __popcll(mbs[u] & ((1ULL << lane) - 1ULL))] = (unsigned short)(u * RTHREADS + tid);
-      base += tot;
+        rows_l[base + __popcll(mbs[u] & ((1ULL << lane) - 1ULL))] = (unsigned short)(u * RTHREADS + tid);
     }
-    m = base;
+    m = __builtin_amdgcn_readlane(incl, 63);
     __syncthreads();
   }
+  stamp(1);
   auto row_of = [&](const int k) -> int { return GROUPED ? (int)rows_l[k] : k; };
   auto set_bit = [&](u64* words, const int r) { atomicOr(&words[r >> 6], 1ULL << (r & 63)); };
 
+  int round = 0;
+  if (GROUPED && m <= RTHREADS) {
+    // A label's rows fit one per thread (n / 15 rows at 15 classes): count, best suppressor and the WHOLE 32-entry
+    // list stay in registers, a round is 32 LDS byte reads and one barrier.  (The general form below re-reads the
+    // lists of rows with more than 8 suppressors from global memory in every round -- most rows of a detector's
+    // clustered pool: 8.5 us for two rounds.)
+    const bool has = tid < m;
+    const int r = has ? (int)rows_l[tid] : 0;
+    int c = 0;
+    unsigned ms = 65535u;
+    uint4 t[4] = {};
+    if (has) {
+      c = sd.ecnt[r];
+      ms = 65535u - (unsigned)sd.msup[r];
+      const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
+      t[0] = lp[0]; t[1] = lp[1]; t[2] = lp[2]; t[3] = lp[3];
+    }
+    int state = has ? (c == 0 ? 1 : 0) : 3;
+    if (has) {
+      st[r] = (unsigned char)state;
+      if (state == 1) set_bit(Kb, r);
+    }
+    __syncthreads();
+    stamp(2);
+    const int listed = min(c, EL);
+    for (;; round++) {
+      bool und = false;
+      if (state == 0 && round < R_MAX_ROUNDS) {
+        bool anyK = ms < 65535u && st[ms] == 1, allR = true;  // its highest-scored suppressor first
+        if (!anyK) {
+#pragma unroll
+          for (int c4 = 0; c4 < 4; c4++) {
+            const unsigned wv[4] = {t[c4].x, t[c4].y, t[c4].z, t[c4].w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+              const bool on = 8 * c4 + q < listed;
+              const unsigned char v = st[on ? i : (unsigned)r];
+              anyK |= on && v == 1;
+              allR &= !on || v == 2;
+            }
+          }
+          if (c > EL && !anyK) {  // suppressors beyond the list: the overflow row, 8 independent word loads per step
+            const u64* row = maskT + (size_t)r * cb;
+            const int w = r >> 6;
+            for (int q0 = 0; q0 <= w && !anyK; q0 += 8) {
+              u64 mm[8];
+#pragma unroll
+              for (int e = 0; e < 8; e++) mm[e] = row[min(q0 + e, w)];
+#pragma unroll
+              for (int e = 0; e < 8; e++) {
+                const int q = min(q0 + e, w);
+                anyK |= (mm[e] & Kb[q]) != 0ULL;
+                allR &= (mm[e] & ~Rb[q]) == 0ULL;
+              }
+            }
+          }
+        }
+        if (anyK || allR) {
+          state = anyK ? 2 : 1;
+          st[r] = (unsigned char)state;
+          set_bit(anyK ? Rb : Kb, r);
+        } else {
+          und = true;
+        }
+      } else if (state == 0) {
+        und = true;
+      }
+      if (!__syncthreads_or(und ? 1 : 0) || round >= R_MAX_ROUNDS) break;  // (round budget spent: the tail below)
+    }
+  } else {
   // prologue: counts and first chunks of this workgroup's rows (all loads in flight together)
   int cnt[R_CACHE];
   uint4 c0[R_CACHE];
@@ -882,6 +969,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     if (kept0) set_bit(Kb, r);
   }
   __syncthreads();
+  stamp(2);
   const int nbig = min(*s_nbig, R_BLIST);
 
   // one row against the K / R sets; returns 0 undecided, 1 kept, 2 removed
@@ -928,7 +1016,6 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     set_bit(d == 1 ? Kb : Rb, r);
   };
 
-  int round = 0;
   for (; round < R_MAX_ROUNDS; round++) {
     if (tid == 0) *s_und = 0;
     __syncthreads();
@@ -998,6 +1085,9 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     __syncthreads();
     if (left == 0) break;
   }
+  }
+  stamp(3);
+  if (stamps && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) stamps[7] = (u64)round;
   if (round == R_MAX_ROUNDS && tid < 64) {
     // a suppression chain longer than the round budget: wave 0 finishes this workgroup's rows in score order
     for (int b = 0; b < cbn; b++) {
@@ -1030,6 +1120,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     }
   }
   __syncthreads();
+  stamp(4);
   // the kept rows of this workgroup, as bits
   for (int b = tid; b < cbn; b += RTHREADS) {
     const u64 kb = Kb[b];
@@ -1049,6 +1140,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       }
     }
   }
+  stamp(5);
 }
 
 __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* __restrict__ maskT,
@@ -1056,7 +1148,8 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* 
                                                                      const unsigned* __restrict__ counter,
                                                                      u64* __restrict__ kbits, size_t kbits_stride,
                                                                      const int* __restrict__ svals,
-                                                                     u64* __restrict__ fbits, Batch bt) {
+                                                                     u64* __restrict__ fbits, Batch bt,
+                                                                     u64* __restrict__ stamps = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
   __shared__ int s_und, s_nbig, s_m;
   __shared__ int wsum[RTHREADS / 64];
@@ -1068,11 +1161,11 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* 
   if (grouped)
     reduce_groups_body<true>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, bt.rlab + (size_t)img * bt.rows, (int)blockIdx.x,
                              kbits + img * kbits_stride, svals + (size_t)img * bt.rows,
-                             fbits ? fbits + img * kbits_stride : nullptr, smem8, &s_und, &s_nbig, &s_m, wsum);
+                             fbits ? fbits + img * kbits_stride : nullptr, smem8, &s_und, &s_nbig, &s_m, wsum, stamps);
   else
     reduce_groups_body<false>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, nullptr, 0, kbits + img * kbits_stride,
                               svals + (size_t)img * bt.rows, fbits ? fbits + img * kbits_stride : nullptr, smem8, &s_und,
-                              &s_nbig, &s_m, wsum);
+                              &s_nbig, &s_m, wsum, stamps);
 }
 
 // rnms returns keep sorted by original index (rnms_kernel.cu:331-334): mark kept originals,
@@ -1748,12 +1841,12 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     static bool raised = false;  // the default cap on dynamic LDS is 64 KB
     if (lds > 64 * 1024 && !raised) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);  // (+ ~300 B static)
       raised = true;
     }
-    if (lds > 160 * 1024 - 256) return -1;  // (cap < 65536: never)
+    if (lds > 160 * 1024 - 1024) return -1;  // (cap < 65536: 106 KB at most)
     hipLaunchKernelGGL(nms_reduce_groups_kernel, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
-                       L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt);
+                       L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);
   }
   if (geom == 1)
     hipLaunchKernelGGL(mc_finish_kernel, dim3((cap + 1023) / 1024, B), dim3(1024), 0, stream, boxes, n, cand_row,

@@ -1,0 +1,47 @@
+// Probe: where the time of nms_reduce_groups_kernel (csrc/r3_nms.hip) goes -- s_memtime stamps of reducer workgroup
+// (group 0, image 0) at the phase boundaries (label compaction | prologue loads | rounds | keep bits), on a
+// clustered pool like tools/nms_prof.py's (n boxes around n / 12 objects, 15 labels), through r3k_batched_nms.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I r3det-pytorch_amd/csrc -I include -o tools/probes/nms_reduce_probe tools/probes/nms_reduce_probe.hip
+#include "../../r3det-pytorch_amd/csrc/r3_nms.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+int g_r3_nms_impl = 0, g_r3_nms_qcap = 0;
+static float urand() { return (float)(rand() % 1000003) / 1000003.f; }
+static float nrand() { return sqrtf(-2.f * logf(urand() + 1e-7f)) * cosf(6.2831853f * urand()); }
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 8576;
+  const int nobj = n / 12 > 0 ? n / 12 : 1;
+  srand(3);
+  std::vector<float> obj(nobj * 5); std::vector<int> ocls(nobj);
+  for (int o = 0; o < nobj; o++) {
+    float w = 10.f + 140.f * urand(), asp = 1.f + 3.f * urand();
+    obj[o * 5] = 1024.f * urand(); obj[o * 5 + 1] = 1024.f * urand(); obj[o * 5 + 2] = w; obj[o * 5 + 3] = w / asp;
+    obj[o * 5 + 4] = -1.5708f * urand(); ocls[o] = rand() % 15;
+  }
+  std::vector<float> b(n * 5), sc(n); std::vector<long long> lab(n);
+  for (int i = 0; i < n; i++) {
+    const int o = rand() % nobj;
+    const float m = fminf(obj[o * 5 + 2], obj[o * 5 + 3]);
+    b[i * 5] = obj[o * 5] + nrand() * 0.15f * m; b[i * 5 + 1] = obj[o * 5 + 1] + nrand() * 0.15f * m;
+    b[i * 5 + 2] = obj[o * 5 + 2] * expf(nrand() * 0.1f); b[i * 5 + 3] = obj[o * 5 + 3] * expf(nrand() * 0.1f);
+    b[i * 5 + 4] = obj[o * 5 + 4] + nrand() * 0.05f; sc[i] = 0.05f + 0.95f * urand(); lab[i] = ocls[o];
+  }
+  float *db, *ds, *dd; long long *dl, *dk; int* dc; void* ws; u64* st;
+  const size_t wsb = r3k_batched_rnms_workspace_bytes(n);
+  CK(hipMalloc(&db, n * 20)); CK(hipMalloc(&ds, n * 4)); CK(hipMalloc(&dl, n * 8)); CK(hipMalloc(&dd, n * 24)); CK(hipMalloc(&dk, n * 8));
+  CK(hipMalloc(&dc, 4)); CK(hipMalloc(&ws, wsb)); CK(hipMalloc(&st, 64));
+  CK(hipMemcpy(db, b.data(), n * 20, hipMemcpyHostToDevice)); CK(hipMemcpy(ds, sc.data(), n * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dl, lab.data(), n * 8, hipMemcpyHostToDevice));
+  g_nms_stamps = st;
+  for (int it = 0; it < 3; it++) {
+    const int rc = r3k_batched_nms(1, db, ds, (const int64_t*)dl, n, 0.1f, ws, wsb, dd, (int64_t*)dk, dc, 0);
+    CK(hipDeviceSynchronize());
+    u64 s[8]; int kept; CK(hipMemcpy(s, st, 64, hipMemcpyDeviceToHost)); CK(hipMemcpy(&kept, dc, 4, hipMemcpyDeviceToHost));
+    printf("n %d rc %d kept %d | cycles: compaction %llu  prologue %llu  rounds %llu (%llu rounds)  tail %llu  bits %llu  total %llu\n", n, rc,
+           kept, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[7], s[4] - s[3], s[5] - s[4], s[5] - s[0]);
+  }
+  return 0;
+}
