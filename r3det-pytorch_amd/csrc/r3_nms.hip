@@ -30,6 +30,7 @@
 // The original tile kernel (mask computed in place, dense reduction) is kept as impl 1: it
 // serves thr < 0, n >= 65536 and the A/B measurements.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "r3_geom_lds.h"
 #include "r3_kernels.h"
@@ -855,75 +856,97 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   auto set_bit = [&](u64* words, const int r) { atomicOr(&words[r >> 6], 1ULL << (r & 63)); };
 
   int round = 0;
-  if (GROUPED && m <= RTHREADS) {
-    // A label's rows fit one per thread (n / 15 rows at 15 classes): count, best suppressor and the WHOLE 32-entry
-    // list stay in registers, a round is 32 LDS byte reads and one barrier.  (The general form below re-reads the
-    // lists of rows with more than 8 suppressors from global memory in every round -- most rows of a detector's
-    // clustered pool: 8.5 us for two rounds.)
-    const bool has = tid < m;
-    const int r = has ? (int)rows_l[tid] : 0;
-    int c = 0;
-    unsigned ms = 65535u;
-    uint4 t[4] = {};
-    if (has) {
-      c = sd.ecnt[r];
-      ms = 65535u - (unsigned)sd.msup[r];
-      const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
-      t[0] = lp[0]; t[1] = lp[1]; t[2] = lp[2]; t[3] = lp[3];
-    }
-    int state = has ? (c == 0 ? 1 : 0) : 3;
-    if (has) {
-      st[r] = (unsigned char)state;
-      if (state == 1) set_bit(Kb, r);
-    }
-    __syncthreads();
-    stamp(2);
-    const int listed = min(c, EL);
-    for (;; round++) {
-      bool und = false;
-      if (state == 0 && round < R_MAX_ROUNDS) {
-        bool anyK = ms < 65535u && st[ms] == 1, allR = true;  // its highest-scored suppressor first
-        if (!anyK) {
+  if (GROUPED && m <= 2 * RTHREADS) {
+    // A label's rows fit 1 or 2 per thread (n / 15 rows at 15 balanced classes; a pool dominated by one class --
+    // the random-init bench model: 89 % of its 2170 candidates in one label -- fits at 2; 4 rows per thread need
+    // more than the 128 registers a 1024-thread workgroup has): count, best suppressor
+    // and the WHOLE 32-entry list stay in registers, a round is 32 LDS byte reads per row and one barrier.  (The
+    // general form below re-reads the lists of rows with more than 8 suppressors from global memory in every round
+    // -- most rows of a detector's clustered pool: 8.5 us for two rounds.)
+    auto in_regs = [&](auto rpt_tag) -> int {
+      constexpr int RPT = decltype(rpt_tag)::value;
+      int rr[RPT], c[RPT], state[RPT];
+      unsigned ms[RPT];
+      uint4 t[RPT][4];
 #pragma unroll
-          for (int c4 = 0; c4 < 4; c4++) {
-            const unsigned wv[4] = {t[c4].x, t[c4].y, t[c4].z, t[c4].w};
+      for (int u = 0; u < RPT; u++) {
+        const int k = tid + u * RTHREADS;
+        const bool has = k < m;
+        rr[u] = has ? (int)rows_l[k] : 0;
+        c[u] = 0;
+        ms[u] = 65535u;
+        t[u][0] = t[u][1] = t[u][2] = t[u][3] = make_uint4(0u, 0u, 0u, 0u);
+        if (has) {
+          c[u] = sd.ecnt[rr[u]];
+          ms[u] = 65535u - (unsigned)sd.msup[rr[u]];
+          const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)rr[u] * EL);
+          t[u][0] = lp[0]; t[u][1] = lp[1]; t[u][2] = lp[2]; t[u][3] = lp[3];
+        }
+        state[u] = has ? 0 : 3;
+      }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-              const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
-              const bool on = 8 * c4 + q < listed;
-              const unsigned char v = st[on ? i : (unsigned)r];
-              anyK |= on && v == 1;
-              allR &= !on || v == 2;
+      for (int u = 0; u < RPT; u++) {
+        if (state[u] == 0 && c[u] == 0) state[u] = 1;
+        if (state[u] != 3) {
+          st[rr[u]] = (unsigned char)state[u];
+          if (state[u] == 1) set_bit(Kb, rr[u]);
+        }
+      }
+      __syncthreads();
+      stamp(2);
+      int rnd = 0;
+      for (;; rnd++) {
+        bool und = false;
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+          if (state[u] != 0) continue;
+          if (rnd >= R_MAX_ROUNDS) { und = true; continue; }
+          const int r = rr[u];
+          const int listed = min(c[u], EL);
+          bool anyK = ms[u] < 65535u && st[ms[u]] == 1, allR = true;  // its highest-scored suppressor first
+          if (!anyK) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {
+              const unsigned wv[4] = {t[u][c4].x, t[u][c4].y, t[u][c4].z, t[u][c4].w};
+#pragma unroll
+              for (int q = 0; q < 8; q++) {
+                const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+                const bool on = 8 * c4 + q < listed;
+                const unsigned char v = st[on ? i : (unsigned)r];
+                anyK |= on && v == 1;
+                allR &= !on || v == 2;
+              }
             }
-          }
-          if (c > EL && !anyK) {  // suppressors beyond the list: the overflow row, 8 independent word loads per step
-            const u64* row = maskT + (size_t)r * cb;
-            const int w = r >> 6;
-            for (int q0 = 0; q0 <= w && !anyK; q0 += 8) {
-              u64 mm[8];
+            if (c[u] > EL && !anyK) {  // suppressors beyond the list: the overflow row, 8 independent word loads per step
+              const u64* row = maskT + (size_t)r * cb;
+              const int w = r >> 6;
+              for (int q0 = 0; q0 <= w && !anyK; q0 += 8) {
+                u64 mm[8];
 #pragma unroll
-              for (int e = 0; e < 8; e++) mm[e] = row[min(q0 + e, w)];
+                for (int e = 0; e < 8; e++) mm[e] = row[min(q0 + e, w)];
 #pragma unroll
-              for (int e = 0; e < 8; e++) {
-                const int q = min(q0 + e, w);
-                anyK |= (mm[e] & Kb[q]) != 0ULL;
-                allR &= (mm[e] & ~Rb[q]) == 0ULL;
+                for (int e = 0; e < 8; e++) {
+                  const int q = min(q0 + e, w);
+                  anyK |= (mm[e] & Kb[q]) != 0ULL;
+                  allR &= (mm[e] & ~Rb[q]) == 0ULL;
+                }
               }
             }
           }
+          if (anyK || allR) {
+            state[u] = anyK ? 2 : 1;
+            st[r] = (unsigned char)state[u];
+            set_bit(anyK ? Rb : Kb, r);
+          } else {
+            und = true;
+          }
         }
-        if (anyK || allR) {
-          state = anyK ? 2 : 1;
-          st[r] = (unsigned char)state;
-          set_bit(anyK ? Rb : Kb, r);
-        } else {
-          und = true;
-        }
-      } else if (state == 0) {
-        und = true;
+        if (!__syncthreads_or(und ? 1 : 0) || rnd >= R_MAX_ROUNDS) break;  // (round budget spent: the tail below)
       }
-      if (!__syncthreads_or(und ? 1 : 0) || round >= R_MAX_ROUNDS) break;  // (round budget spent: the tail below)
-    }
+      return rnd;
+    };
+    if (m <= RTHREADS) round = in_regs(std::integral_constant<int, 1>{});
+    else round = in_regs(std::integral_constant<int, 2>{});
   } else {
   // prologue: counts and first chunks of this workgroup's rows (all loads in flight together)
   int cnt[R_CACHE];
