@@ -263,7 +263,31 @@ def op_rates(device):
                                  "alg_bytes": b_nms(k),
                                  "what": f"{fn.__name__} (15 classes) incl. its host read of the count",
                                  "roofline": _roof(b_nms(k), dt, "hbm (latency-bound in practice)")}
+    out.update(pool_rates(device))
     out.update(fr_rates(device))
+    return out
+
+
+def pool_rates(device):
+    """The pre-NMS pool of a whole head in one library call (r3det_levels_pool: sigmoid, per-image top-2000 per level,
+    decode) at the two BASELINE models' shapes; algorithmic bytes = the head's cls + reg maps read once + the pool
+    arrays written once."""
+    from r3det.ops import fr_boxes
+    g = torch.Generator(device=device).manual_seed(3)
+    out, Cc, k = {}, 15, 2000
+    for name, N, A in (("pool_r3det_refine_N4", 4, 1), ("pool_rretinanet_N2", 2, 9)):
+        sizes = [IMG // s for s in (8, 16, 32, 64, 128)]
+        cl = torch.channels_last
+        cls = [(torch.randn(N, A * Cc, H, H, device=device, generator=g) * 1.5 - 4.0).contiguous(memory_format=cl) for H in sizes]
+        reg = [(torch.randn(N, A * 5, H, H, device=device, generator=g) * 0.2).contiguous(memory_format=cl) for H in sizes]
+        anc = [torch.rand(H * H * A, 5, device=device, generator=g) * 50 + 5 for H in sizes]
+        n = sum(min(k, H * H * A) for H in sizes)
+        boxes, scores = torch.empty(N, n, 5, device=device), torch.empty(N, n, Cc + 1, device=device)
+        dt = timeit(lambda: fr_boxes.levels_pool(cls, reg, anc, A, Cc, k, (IMG, IMG), boxes, scores), 20)
+        nb = sum(c.numel() + r.numel() for c, r in zip(cls, reg)) * 4 + (boxes.numel() + scores.numel()) * 4
+        out[name] = {"us_per_call": round(dt * 1e6, 1), "alg_bytes": nb, "pool_rows_per_image": n,
+                     "what": f"r3det_levels_pool, five levels, A = {A}, nms_pre = {k}: memset + 3 launches",
+                     "roofline": _roof(nb, dt, "hbm (launch- and latency-bound in practice)")}
     return out
 
 

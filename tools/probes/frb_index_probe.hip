@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+int g_r3_fr_walk = 8;
 int main() {
   const int N = 4, H = 128, W = 128, HW = H * W;
   std::vector<float> b((size_t)N * HW * 5);
