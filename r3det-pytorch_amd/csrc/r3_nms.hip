@@ -776,8 +776,10 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
                                                    u64* __restrict__ kbits, const int* __restrict__ svals,
                                                    u64* __restrict__ fbits, unsigned char* smem8, int* s_und,
                                                    int* s_nbig, int* s_m, int* wsum, u64* __restrict__ stamps) {
+  // (probe: stamps[15] names the group whose workgroup, image 0, writes the stamps)
+  const bool stamp_on = stamps && blockIdx.z == 0 && threadIdx.x == 0 && blockIdx.x == (unsigned)stamps[15];
   auto stamp = [&](int k) {
-    if (stamps && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
+    if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
   const int cbn = (n + TILE - 1) / TILE;
@@ -856,6 +858,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   auto set_bit = [&](u64* words, const int r) { atomicOr(&words[r >> 6], 1ULL << (r & 63)); };
 
   int round = 0;
+  bool fbits_done = false;
   if (GROUPED && m <= 2 * RTHREADS) {
     // A label's rows fit 1 or 2 per thread (n / 15 rows at 15 balanced classes; a pool dominated by one class --
     // the random-init bench model: 89 % of its 2170 candidates in one label -- fits at 2; 4 rows per thread need
@@ -865,7 +868,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     // -- most rows of a detector's clustered pool: 8.5 us for two rounds.)
     auto in_regs = [&](auto rpt_tag) -> int {
       constexpr int RPT = decltype(rpt_tag)::value;
-      int rr[RPT], c[RPT], state[RPT];
+      int rr[RPT], c[RPT], state[RPT], sv[RPT];
       unsigned ms[RPT];
       uint4 t[RPT][4];
 #pragma unroll
@@ -874,9 +877,11 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         const bool has = k < m;
         rr[u] = has ? (int)rows_l[k] : 0;
         c[u] = 0;
+        sv[u] = 0;
         ms[u] = 65535u;
         t[u][0] = t[u][1] = t[u][2] = t[u][3] = make_uint4(0u, 0u, 0u, 0u);
         if (has) {
+          if (fbits) sv[u] = svals[rr[u]];  // (the row's candidate index: for the keep bits behind the rounds)
           c[u] = sd.ecnt[rr[u]];
           ms[u] = 65535u - (unsigned)sd.msup[rr[u]];
           const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)rr[u] * EL);
@@ -884,65 +889,178 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         }
         state[u] = has ? 0 : 3;
       }
+      // Rows with more suppressors than the 32-entry list (mark_pair keeps the rest as bits of the row's overflow
+      // mask): the bits are turned into u16 entries of an LDS list ONCE, a wave per row (lanes <-> words, one round
+      // trip), so that the rounds never leave the LDS.  (Re-scanning the mask row from global memory in every
+      // round -- up to 17 dependent batches of 8 words -- made a dozen such rows cost 30 us of a 48 us kernel on the
+      // bench model's pool.)  xs < 0: the list is full, that row keeps the per-round scan.
+      int xs[RPT], xl[RPT];
+      unsigned short* ext = blist;  // (the long-row worklist of the general form: unused here)
+#pragma unroll
+      for (int u = 0; u < RPT; u++) {
+        xs[u] = 0;
+        xl[u] = 0;
+        u64 need = __ballot(state[u] == 0 && c[u] > EL);
+        while (need) {
+          const int src = __builtin_ctzll(need);
+          need &= need - 1;
+          const int r = __builtin_amdgcn_readlane(rr[u], src);
+          const u64* row = maskT + (size_t)r * cb;
+          const int nw = (r >> 6) + 1;
+          int base = 0, total = 0;
+          for (int w0 = 0; w0 < nw; w0 += 64) {  // (first pass: the number of entries)
+            const u64 wd = (w0 + lane < nw) ? row[w0 + lane] : 0ULL;
+            int pc = __popcll(wd);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
+            total += pc;
+          }
+          if (lane == 0) base = atomicAdd(s_nbig, total);
+          base = __builtin_amdgcn_readfirstlane(base);
+          const bool fits = base + total <= R_BLIST;
+          if (fits) {
+            int at = base;
+            for (int w0 = 0; w0 < nw; w0 += 64) {
+              u64 wd = (w0 + lane < nw) ? row[w0 + lane] : 0ULL;
+              const int pc = __popcll(wd);
+              int incl = pc;
+#pragma unroll
+              for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+              }
+              int o = at + incl - pc;
+              while (wd) {
+                ext[o++] = (unsigned short)((w0 + lane) * 64 + __builtin_ctzll(wd));
+                wd &= wd - 1;
+              }
+              at += __builtin_amdgcn_readlane(incl, 63);
+            }
+          }
+          if (lane == src) {
+            xs[u] = fits ? base : -1;
+            xl[u] = total;
+          }
+        }
+      }
 #pragma unroll
       for (int u = 0; u < RPT; u++) {
         if (state[u] == 0 && c[u] == 0) state[u] = 1;
-        if (state[u] != 3) {
-          st[rr[u]] = (unsigned char)state[u];
-          if (state[u] == 1) set_bit(Kb, rr[u]);
-        }
+        if (state[u] != 3) st[rr[u]] = (unsigned char)state[u];
       }
       __syncthreads();
       stamp(2);
-      int rnd = 0;
+      // (no K / R bit sets in this loop: 64 lanes deciding rows of one or two mask words are 64 same-address LDS
+      // atomics; the sets are rebuilt from the state bytes once, behind the loop)
+      int rnd = 0, left_before = -1;
       for (;; rnd++) {
         bool und = false;
+        if (stamp_on && rnd < 8) stamps[16 + 4 * rnd] = __builtin_amdgcn_s_memtime();
+        // What a round costs is LDS reads of scattered state bytes (bank conflicts: ~12 cycles per wave read, 16 waves
+        // on one LDS) and the slowest wave in front of the barrier.  So: a wave whose rows are all decided reads
+        // nothing; the best suppressor and the first 8 entries are read together (most rows have fewer than 8);
+        // entries 8..31 in one batch, only in waves with an undecided row that long; the overflow entries 4 at a time.
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
-          if (state[u] != 0) continue;
-          if (rnd >= R_MAX_ROUNDS) { und = true; continue; }
-          const int r = rr[u];
-          const int listed = min(c[u], EL);
-          bool anyK = ms[u] < 65535u && st[ms[u]] == 1, allR = true;  // its highest-scored suppressor first
-          if (!anyK) {
+          const bool act = state[u] == 0;
+          if (__ballot(act) == 0ULL) continue;
+          if (rnd >= R_MAX_ROUNDS) { und |= act; continue; }
+          const unsigned r = (unsigned)rr[u];
+          const int listed = act ? min(c[u], EL) : 0;
+          unsigned char v0, v8[8];
+          v0 = st[(act && ms[u] < 65535u) ? ms[u] : r];
+          {
+            const unsigned wv[4] = {t[u][0].x, t[u][0].y, t[u][0].z, t[u][0].w};
 #pragma unroll
-            for (int c4 = 0; c4 < 4; c4++) {
+            for (int q = 0; q < 8; q++) v8[q] = st[q < listed ? ((wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu) : r];
+          }
+          bool aK = act && ms[u] < 65535u && v0 == 1, aR = true;  // its highest-scored suppressor first
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            aK |= q < listed && v8[q] == 1;
+            aR &= !(q < listed) || v8[q] == 2;
+          }
+          if (__ballot(act && !aK && listed > 8) != 0ULL) {
+            unsigned char w[24];
+#pragma unroll
+            for (int c4 = 1; c4 < 4; c4++) {
               const unsigned wv[4] = {t[u][c4].x, t[u][c4].y, t[u][c4].z, t[u][c4].w};
 #pragma unroll
-              for (int q = 0; q < 8; q++) {
-                const unsigned i = (wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
-                const bool on = 8 * c4 + q < listed;
-                const unsigned char v = st[on ? i : (unsigned)r];
-                anyK |= on && v == 1;
-                allR &= !on || v == 2;
-              }
+              for (int q = 0; q < 8; q++)
+                w[8 * (c4 - 1) + q] = st[8 * c4 + q < listed ? ((wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu) : r];
             }
-            if (c[u] > EL && !anyK) {  // suppressors beyond the list: the overflow row, 8 independent word loads per step
-              const u64* row = maskT + (size_t)r * cb;
-              const int w = r >> 6;
-              for (int q0 = 0; q0 <= w && !anyK; q0 += 8) {
-                u64 mm[8];
 #pragma unroll
-                for (int e = 0; e < 8; e++) mm[e] = row[min(q0 + e, w)];
+            for (int q = 0; q < 24; q++) {
+              aK |= 8 + q < listed && w[q] == 1;
+              aR &= !(8 + q < listed) || w[q] == 2;
+            }
+            const bool ovf = act && !aK && c[u] > EL;
+            if (__ballot(ovf) != 0ULL) {
+              if (ovf && xs[u] < 0) aR = false;  // (the LDS list was full: left to the tail below)
+              const int len = (ovf && xs[u] >= 0) ? xl[u] : 0;
+              for (int e0 = 0; __ballot(e0 < len) != 0ULL; e0 += 4) {  // suppressors beyond the list: their LDS entries
+                unsigned short xi[4];
+                unsigned char xv[4];
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                  const int q = min(q0 + e, w);
-                  anyK |= (mm[e] & Kb[q]) != 0ULL;
-                  allR &= (mm[e] & ~Rb[q]) == 0ULL;
+                for (int e = 0; e < 4; e++) xi[e] = e0 + e < len ? ext[xs[u] + e0 + e] : (unsigned short)r;
+#pragma unroll
+                for (int e = 0; e < 4; e++) xv[e] = st[xi[e]];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  aK |= e0 + e < len && xv[e] == 1;
+                  aR &= !(e0 + e < len) || xv[e] == 2;
                 }
               }
             }
           }
-          if (anyK || allR) {
-            state[u] = anyK ? 2 : 1;
-            st[r] = (unsigned char)state[u];
-            set_bit(anyK ? Rb : Kb, r);
-          } else {
-            und = true;
+          if (act) {
+            if (aK || aR) {
+              state[u] = aK ? 2 : 1;
+              st[r] = (unsigned char)state[u];
+            } else {
+              und = true;
+            }
           }
         }
-        if (!__syncthreads_or(und ? 1 : 0) || rnd >= R_MAX_ROUNDS) break;  // (round budget spent: the tail below)
+        if (stamp_on && rnd < 8) stamps[18 + 4 * rnd] = __builtin_amdgcn_s_memtime();
+        // undecided rows of the workgroup: wave popcounts through a double-buffered table, ONE barrier per round
+        // (__syncthreads_count costs ~1900 cycles however little the waves do)
+        int* wtab2 = wsum;  // (2 x 16 ints)
+        const int wund = __popcll(__ballot(und));
+        if (lane == 0) wtab2[(rnd & 1) * 16 + wave] = wund;
+        __syncthreads();
+        int left = 0;
+#pragma unroll
+        for (int w = 0; w < RTHREADS / 64; w++) left += wtab2[(rnd & 1) * 16 + w];
+        if (stamp_on && rnd < 8) stamps[19 + 4 * rnd] = __builtin_amdgcn_s_memtime();
+        if (left == 0) break;                                                     // every row decided
+        if (left == left_before || rnd >= R_MAX_ROUNDS) { rnd = R_MAX_ROUNDS; break; }  // stuck or out of budget: the tail below
+        left_before = left;
       }
+      // K / R as bits, from the state bytes of this workgroup's rows (8 bytes at a time: byte == 1 / == 2 -> one bit)
+      for (int b = tid; b < cbn; b += RTHREADS) {
+        const u64 own = Own[b];
+        u64 kb = 0, rb = 0;
+        if (own) {
+          const u64* sp = reinterpret_cast<const u64*>(st + (size_t)b * 64);
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const u64 x = sp[q];
+            const u64 k1 = x & ~(x >> 1) & 0x0101010101010101ULL, r1 = (x >> 1) & ~x & 0x0101010101010101ULL;
+            kb |= ((k1 * 0x0102040810204080ULL) >> 56) << (8 * q);
+            rb |= ((r1 * 0x0102040810204080ULL) >> 56) << (8 * q);
+          }
+        }
+        Kb[b] = kb & own;
+        Rb[b] = rb & own;
+      }
+      if (fbits && rnd < R_MAX_ROUNDS) {  // kept candidates as bits, from the registers (the tail's rows: below)
+#pragma unroll
+        for (int u = 0; u < RPT; u++)
+          if (state[u] == 1) atomicOr(&fbits[sv[u] >> 6], 1ULL << (sv[u] & 63));
+        fbits_done = true;
+      }
+      __syncthreads();
       return rnd;
     };
     if (m <= RTHREADS) round = in_regs(std::integral_constant<int, 1>{});
@@ -1110,7 +1228,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   }
   }
   stamp(3);
-  if (stamps && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) stamps[7] = (u64)round;
+  if (stamp_on) stamps[7] = (u64)round;
   if (round == R_MAX_ROUNDS && tid < 64) {
     // a suppression chain longer than the round budget: wave 0 finishes this workgroup's rows in score order
     for (int b = 0; b < cbn; b++) {
@@ -1154,7 +1272,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     }
   }
   // ... and over the CANDIDATE indices (the index-ordered finish reads these: no translation pass there)
-  if (fbits) {
+  if (fbits && !fbits_done) {
     for (int k = tid; k < m; k += RTHREADS) {
       const int r = row_of(k);
       if (st[r] == 1) {
@@ -1175,7 +1293,7 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* 
                                                                      u64* __restrict__ stamps = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
   __shared__ int s_und, s_nbig, s_m;
-  __shared__ int wsum[RTHREADS / 64];
+  __shared__ int wsum[2 * RTHREADS / 64];
   const int img = blockIdx.z;
   const int n = bt.counts[img];
   const bool grouped = gridDim.x > 1 && bt.rlab && counter[img * bt.counter + Q_XFLAG] == 0u;

@@ -25,3 +25,29 @@ for i in range(boxes.size(0)):
     rows_x = cross.any(0).sum().item()
     print(f"image {i}: {n} candidates, edges same-label {int(same.sum().item()) // 2}, cross-label {int(cross.sum().item()) // 2}, rows with a cross-label partner {rows_x}, w max {b[:,2].max().item():.0f} h max {b[:,3].max().item():.0f} coordinate max {boxes[i].max().item():.0f}")
     print("   candidates per label:", torch.bincount(labs, minlength=15).tolist())
+    # suppressor lists in score order (per label), rows beyond the 32-entry list, and the dependency rounds greedy needs
+    if i == 0:
+        import numpy as np
+        sco = sc[rows, labs]
+        order = torch.argsort(sco, descending=True)
+        M = (same[order][:, order]).cpu().numpy()          # M[a, b]: a and b overlap (same label), positions in score order
+        n_ = M.shape[0]
+        sup = np.triu(M, 1)                                 # sup[a, b] (a < b): a is a suppressor of b
+        cnt = sup.sum(0)
+        state = np.zeros(n_, np.int8)                       # 0 undecided, 1 kept, 2 removed
+        state[cnt == 0] = 1
+        rounds = 0
+        while (state == 0).any():
+            kept, rem = state == 1, state == 2
+            anyK = (sup & kept[:, None]).any(0)
+            allR = ((~sup) | rem[:, None]).all(0)
+            new = state.copy()
+            new[(state == 0) & anyK] = 2
+            new[(state == 0) & ~anyK & allR] = 1
+            state = new
+            rounds += 1
+        print(f"   image 0: suppressors per row mean {cnt.mean():.1f} max {cnt.max()}, rows with more than 32: {(cnt > 32).sum()}, more than 8: {(cnt > 8).sum()}; dependency rounds {rounds}; kept {(state == 1).sum()}")
+    if i == 0 and os.environ.get("DUMP_POOL"):
+        import numpy as np
+        arr = torch.cat([b.new_tensor([float(n)]), boxes[i][rows].reshape(-1), sc[rows, labs], labs.to(b)]).cpu().numpy().astype(np.float32)
+        arr.tofile(os.environ["DUMP_POOL"])  # n | boxes (n, 5) | scores | labels: input of tools/probes/nms_reduce_probe

@@ -69,7 +69,7 @@ cd /tmp
 # 6c. the plain samplers (the reference's API: r3det_feature_refine_forward NCHW, _forward_nhwc) per level, N = 4
 kt $O/${TAG}_fr_forward_kernel_stats.txt "python3 tools/fr_fwd_prof.py" python3 $R/tools/fr_fwd_prof.py
 python3 $R/tools/kstats.py /tmp/kt_run fr_ >> $O/${TAG}_fr_forward_kernel_stats.txt
-# 6d. the per-level pre-NMS pool (r3det_level_pool) at the two models' shapes
+# 6d. the pre-NMS pool at the two models' shapes: per level (r3det_level_pool) and the whole head in one call (r3det_levels_pool)
 kt $O/${TAG}_pool_kernel_stats.txt "python3 tools/pool_prof.py" python3 $R/tools/pool_prof.py
 python3 $R/tools/kt_by_grid.py $(find /tmp/kt_run -name "*kernel_trace.csv" | head -1) pool_ fill >> $O/${TAG}_pool_kernel_stats.txt
 # 7. PMC of the IoU and NMS kernels

@@ -29,17 +29,32 @@ int main(int argc, char** argv) {
     b[i * 5 + 2] = obj[o * 5 + 2] * expf(nrand() * 0.1f); b[i * 5 + 3] = obj[o * 5 + 3] * expf(nrand() * 0.1f);
     b[i * 5 + 4] = obj[o * 5 + 4] + nrand() * 0.05f; sc[i] = 0.05f + 0.95f * urand(); lab[i] = ocls[o];
   }
+  if (argc > 2) {  // a dumped pool (tools/cross_label_edges.py, DUMP_POOL=file): n | boxes | scores | labels, all f32
+    FILE* f = fopen(argv[2], "rb");
+    if (!f) { printf("cannot open %s\n", argv[2]); return 1; }
+    float fn; if (fread(&fn, 4, 1, f) != 1) return 1;
+    const int m = (int)fn;
+    if (m != n) { printf("file holds %d boxes: pass that number as the first argument\n", m); return 1; }
+    std::vector<float> lf(n);
+    if (fread(b.data(), 4, (size_t)n * 5, f) != (size_t)n * 5 || fread(sc.data(), 4, n, f) != (size_t)n || fread(lf.data(), 4, n, f) != (size_t)n) return 1;
+    for (int i = 0; i < n; i++) lab[i] = (long long)lf[i];
+    fclose(f);
+  }
   float *db, *ds, *dd; long long *dl, *dk; int* dc; void* ws; u64* st;
   const size_t wsb = r3k_batched_rnms_workspace_bytes(n);
   CK(hipMalloc(&db, n * 20)); CK(hipMalloc(&ds, n * 4)); CK(hipMalloc(&dl, n * 8)); CK(hipMalloc(&dd, n * 24)); CK(hipMalloc(&dk, n * 8));
-  CK(hipMalloc(&dc, 4)); CK(hipMalloc(&ws, wsb)); CK(hipMalloc(&st, 64));
+  CK(hipMalloc(&dc, 4)); CK(hipMalloc(&ws, wsb)); CK(hipMalloc(&st, 512)); CK(hipMemset(st, 0, 512));
   CK(hipMemcpy(db, b.data(), n * 20, hipMemcpyHostToDevice)); CK(hipMemcpy(ds, sc.data(), n * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dl, lab.data(), n * 8, hipMemcpyHostToDevice));
   g_nms_stamps = st;
+  { const u64 grp = argc > 3 ? (u64)atoi(argv[3]) : 0; CK(hipMemcpy(st + 15, &grp, 8, hipMemcpyHostToDevice)); }  // the stamped group
   for (int it = 0; it < 3; it++) {
     const int rc = r3k_batched_nms(1, db, ds, (const int64_t*)dl, n, 0.1f, ws, wsb, dd, (int64_t*)dk, dc, 0);
     CK(hipDeviceSynchronize());
-    u64 s[8]; int kept; CK(hipMemcpy(s, st, 64, hipMemcpyDeviceToHost)); CK(hipMemcpy(&kept, dc, 4, hipMemcpyDeviceToHost));
+    u64 s[64]; int kept; CK(hipMemcpy(s, st, 512, hipMemcpyDeviceToHost));
+    if (it == 2) for (int r = 0; r < 8 && s[16 + 4 * r]; r++)
+      printf("  round %d: rows %llu  barrier+count %llu  (this workgroup's thread 0)\n", r, s[18 + 4 * r] - s[16 + 4 * r],
+             s[19 + 4 * r] - s[18 + 4 * r]); CK(hipMemcpy(&kept, dc, 4, hipMemcpyDeviceToHost));
     printf("n %d rc %d kept %d | cycles: compaction %llu  prologue %llu  rounds %llu (%llu rounds)  tail %llu  bits %llu  total %llu\n", n, rc,
            kept, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[7], s[4] - s[3], s[5] - s[4], s[5] - s[0]);
   }
