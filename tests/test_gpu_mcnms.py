@@ -253,3 +253,40 @@ def test_box_across_the_class_offset_takes_the_whole_image_reducer(ver):
         d, lab = out[0]
         kept1 = int((lab == 1).sum())
         assert kept1 < int((s[1:40, 1] > 0.05).sum())
+
+
+@pytest.mark.parametrize("piles,per_pile,classes", [(40, 40, 5), (6, 300, 3), (1, 2000, 1), (3, 700, 15), (50, 34, 1)])
+def test_reducer_rows_with_long_suppressor_lists(piles, per_pile, classes, nms_type):
+    """Piles of near-identical boxes: the j-th box of a pile has j suppressors -- beyond the 32-entry list the drain
+    keeps them as overflow-mask bits, which the in-register reducer turns into LDS entries (40 x 40: 1120 entries),
+    or, when the LDS list is full (300- and 2000-box piles: 10^4 .. 10^6 entries), leaves to the sequential tail.  One
+    or two rows per thread (2000 rows in one label), deep chains.  Equal to the one-workgroup reducer and to the
+    per-image wrapper path."""
+    from r3det import _C
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    g = torch.Generator().manual_seed(piles * 1000 + per_pile)
+    n = piles * per_pile
+    centres = torch.stack([torch.arange(piles) % 9, torch.arange(piles) // 9], 1).float() * 100 + 60  # well apart
+    b = torch.zeros(n, 5)
+    pile = torch.arange(n) % piles
+    b[:, :2] = centres[pile] + torch.randn(n, 2, generator=g) * 0.3
+    b[:, 2] = 30 + torch.rand(n, generator=g)
+    b[:, 3] = 12 + torch.rand(n, generator=g)
+    b[:, 4] = -0.4 + 0.01 * torch.randn(n, generator=g)
+    s = torch.rand(n, classes + 1, generator=g) * 0.04
+    s[torch.arange(n), pile % classes] = 0.06 + 0.9 * torch.rand(n, generator=g)
+    s[:, -1] = 0
+    boxes, scores = torch.stack([b, b.flip(0)]).cuda(), torch.stack([s, s.flip(0)]).cuda()
+    cfg = dict(type=nms_type, iou_thr=0.1)
+    got = multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000)
+    for d, lab in got:
+        assert d.size(0) == piles  # the best box of every pile, nothing else
+    _C.set_option("nms_impl", 2)
+    try:
+        want = multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000)
+    finally:
+        _C.set_option("nms_impl", 0)
+    for (d, lab), (wd, wl) in zip(got, want):
+        assert torch.equal(d, wd) and torch.equal(lab, wl)
+    if n <= 2000:
+        same(got, boxes, scores, 0.05, cfg, 2000)
