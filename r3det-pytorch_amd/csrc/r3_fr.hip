@@ -575,6 +575,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
   // is one LDS read instead of two row loads through the L1 (which serves 64 B per clock: the 8 tap rows per
   // position were a third of the kernel).  Taps outside the two tiles are loaded as before.
   constexpr bool PRE = (VAR & 1) != 0, NT = (VAR & 2) != 0, LEAN = (VAR & 4) != 0;
+  constexpr bool NTI = (VAR & 8) != 0;  // (LEAN) the identity rows of a tile's 2 x 2 interior are loaded non-temporally
   __shared__ float4 Ps[PAIRED ? 2 : 1][NH_ROWS * 4][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
@@ -655,8 +656,27 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
         for (int i = 0; i < 4; i++) {
           const unsigned off = (q0 + (unsigned)min(i, max(cnt - 1, 0))) * rowB + laneB;
           const bool on = i < cnt && cl;
-          ia[i] = on ? *reinterpret_cast<const float4*>(aI + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-          ib[i] = (on && two) ? *reinterpret_cast<const float4*>(bI + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          // The 2 x 2 interior of a tile is asked for by no other workgroup as long as a box samples within one cell
+          // of its own transposed position: those rows need not stay in the L2, and a non-temporal load lands
+          // sooner.  Level 0, N = 4, rotating buffers, same run: 58.1 -> 53.9 us (FETCH 124.1 -> 122.2 K).  The same
+          // hint on ALL identity rows: 62.0 us (the neighbours' tap rows are gone from the L2: FETCH 133.2 K); on
+          // the out-of-tile tap rows: 58.9 us alone, 55.9 us with the interior hint (FETCH 118.6 K, but no faster).
+          const bool inner = NTI && (wave == 1 || wave == 2) && (i == 1 || i == 2);
+          if (inner) {
+            ia[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ib[i] = ia[i];
+            if (on) {
+              const fr_v4 ta = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(aI + off));
+              ia[i] = make_float4(ta.x, ta.y, ta.z, ta.w);
+              if (two) {
+                const fr_v4 tb = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(bI + off));
+                ib[i] = make_float4(tb.x, tb.y, tb.z, tb.w);
+              }
+            }
+          } else {
+            ia[i] = on ? *reinterpret_cast<const float4*>(aI + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ib[i] = (on && two) ? *reinterpret_cast<const float4*>(bI + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) Pf[own + i][lane] = mixv(ia[i], ib[i]);
@@ -696,13 +716,17 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
         const int yl = __builtin_amdgcn_readfirstlane(tp.yl), xl = __builtin_amdgcn_readfirstlane(tp.xl);
         const int yh = __builtin_amdgcn_readfirstlane(tp.yh), xh = __builtin_amdgcn_readfirstlane(tp.xh);
         float4 v = Pf[own + i][lane];
-        const float4 lt = P(yl, xl), rt = P(yl, xh), lb = P(yh, xl), rb = P(yh, xh);
-        float4 sm;
-        sm.x = tp.w[0] * lt.x + tp.w[1] * rt.x + tp.w[2] * lb.x + tp.w[3] * rb.x;
-        sm.y = tp.w[0] * lt.y + tp.w[1] * rt.y + tp.w[2] * lb.y + tp.w[3] * rb.y;
-        sm.z = tp.w[0] * lt.z + tp.w[1] * rt.z + tp.w[2] * lb.z + tp.w[3] * rb.z;
-        sm.w = tp.w[0] * lt.w + tp.w[1] * rt.w + tp.w[2] * lb.w + tp.w[3] * rb.w;
-        if (tp.valid) { v.x += sm.x; v.y += sm.y; v.z += sm.z; v.w += sm.w; }
+        // (a sample outside the map reads nothing, as in the reference: its taps would all be cell (0, 0), one row
+        // requested by every wave of the chip -- a field of such boxes ran 65 us instead of 54)
+        if (__builtin_amdgcn_readfirstlane((int)tp.valid)) {
+          const float4 lt = P(yl, xl), rt = P(yl, xh), lb = P(yh, xl), rb = P(yh, xh);
+          float4 sm;
+          sm.x = tp.w[0] * lt.x + tp.w[1] * rt.x + tp.w[2] * lb.x + tp.w[3] * rb.x;
+          sm.y = tp.w[0] * lt.y + tp.w[1] * rt.y + tp.w[2] * lb.y + tp.w[3] * rb.y;
+          sm.z = tp.w[0] * lt.z + tp.w[1] * rt.z + tp.w[2] * lb.z + tp.w[3] * rb.z;
+          sm.w = tp.w[0] * lt.w + tp.w[1] * rt.w + tp.w[2] * lb.w + tp.w[3] * rb.w;
+          v.x += sm.x; v.y += sm.y; v.z += sm.z; v.w += sm.w;
+        }
         if (has_res) { v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w; }
         if (NT) {
           const fr_v4 t4 = {v.x, v.y, v.z, v.w};
@@ -1677,7 +1701,8 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   const dim3 grid((unsigned)T), block(paired ? 512 : 256);
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x, tpi, (int)T, out
   if (occ) {
-    // shipped: VAR 6 = 32-bit index arithmetic + non-temporal residual loads / output stores (each touched exactly
+    // shipped: VAR 14 = VAR 6 + non-temporal loads of the tiles' interior identity rows (fr_dbg 6: VAR 6 alone);
+    // VAR 6 = 32-bit index arithmetic + non-temporal residual loads / output stores (each touched exactly
     // once: they no longer evict the a / b rows the neighbouring workgroups' halo taps are about to ask for).  Level 0,
     // N = 4, rotating buffers: 66.1 us (round-2 form, fr_dbg 3) -> 60.6 us, FETCH x 2 + WRITE 337 -> 317 MB
     // (tools/fr_nhwc_ab.py, gpurun_out/fr_fwd_pmc_*.txt); prefetching the boxes in phase 1 (VAR 1, fr_dbg 4): 67.6 us.
@@ -1687,7 +1712,8 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     // unchanged FETCH.  What is left above the algorithmic bytes (+45 MB of 207 MB read) is exactly the out-of-tile
     // tap rows of about half the tile edges (fields without such taps: FETCH = 204 MB), whatever the launch order.
     const bool big = (unsigned long long)N * H * W * C * 4ull >= (1ull << 32);  // (32-bit byte offsets inside an image)
-    const int var = (g_r3_fr_dbg == 3 || big) ? 0 : g_r3_fr_dbg == 4 ? 1 : g_r3_fr_dbg == 5 ? 2 : 6;
+    const int var = (g_r3_fr_dbg == 3 || big) ? 0 : g_r3_fr_dbg == 4 ? 1 : g_r3_fr_dbg == 5 ? 2
+                    : g_r3_fr_dbg == 6 ? 6 : 14;
 #undef R3_ARGS
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x | (g_r3_fr_walk << 20), tpi, (int)T, out
 #define R3_OCC(F, P) \
@@ -1695,7 +1721,8 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     if (var == 0) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 0>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
     else if (var == 1) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 1>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
     else if (var == 2) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 2>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
-    else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 6>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+    else if (var == 6) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 6>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+    else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 14>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
   } while (0)
     if (paired) {
       if (fused) R3_OCC(true, true); else R3_OCC(false, true);

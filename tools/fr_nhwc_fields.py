@@ -7,7 +7,16 @@ from r3det.ops.feature_refine import fr_module_nhwc, fr_forward_nhwc
 dev = torch.device("cuda")
 N, C, H = 4, 256, 128
 cl = torch.channels_last
-sets = [tuple(torch.randn(N, C, H, H, device=dev).contiguous(memory_format=cl) for _ in range(4)) for _ in range(3)]
+# FR_PAD=bytes: a pad allocation between the tensors, so that a / b / res / out do not start 2^26 bytes apart
+# (the same DRAM channel / bank bits for the four rows of a position)
+PAD = int(os.environ.get("FR_PAD", "0"))
+_pads = []
+def _mk():
+    if PAD:
+        _pads.append(torch.empty(PAD, dtype=torch.uint8, device=dev))
+    return torch.randn(N, C, H, H, device=dev).contiguous(memory_format=cl)
+sets = [tuple(_mk() for _ in range(4)) for _ in range(3)]
+print("pad", PAD, "address deltas of set 0 (bytes):", [sets[0][i + 1].data_ptr() - sets[0][i].data_ptr() for i in range(3)], flush=True)
 ba, bb = torch.randn(C, device=dev), torch.randn(C, device=dev)
 ONLY = os.environ.get("FR_FIELD", "")  # run one field only (PMC passes average over a kernel's launches)
 def run(name, boxes, scale=0.125):

@@ -19,19 +19,20 @@ _C.set_option("fr_dbg", int(os.environ.get("FR_DBG", "0")))  # A/B variants of t
 if "FR_WALK" in os.environ:
     _C.set_option("fr_walk", int(os.environ["FR_WALK"]))  # strip height of the tile-pair walk (0: row-major)
 dev = torch.device("cuda")
-N, C, H = 4, 256, 128
+N, C, H = int(os.environ.get("FR_N", "4")), 256, 128
 cl = torch.channels_last
 boxes = syn.fr_level_boxes(N, H, H, 8, 3, device=dev)
-sets = [tuple(torch.randn(N, C, H, H, device=dev).contiguous(memory_format=cl) for _ in range(4)) for _ in range(3)]
+NSET = max(3, 12 // N)
+sets = [tuple(torch.randn(N, C, H, H, device=dev).contiguous(memory_format=cl) for _ in range(4)) for _ in range(NSET)]
 ba, bb = torch.randn(C, device=dev), torch.randn(C, device=dev)
 for i in range(6):
-    a, b, r, o = sets[i % 3]
+    a, b, r, o = sets[i % NSET]
     fr_module_nhwc(a, b, ba, bb, r, boxes, 0.125, 1, o)
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for i in range(30):
-    a, b, r, o = sets[i % 3]
+    a, b, r, o = sets[i % NSET]
     fr_module_nhwc(a, b, ba, bb, r, boxes, 0.125, 1, o)
 e.record()
 torch.cuda.synchronize()
