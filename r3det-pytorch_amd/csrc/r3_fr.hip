@@ -660,7 +660,8 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
           // of its own transposed position: those rows need not stay in the L2, and a non-temporal load lands
           // sooner.  Level 0, N = 4, rotating buffers, same run: 58.1 -> 53.9 us (FETCH 124.1 -> 122.2 K).  The same
           // hint on ALL identity rows: 62.0 us (the neighbours' tap rows are gone from the L2: FETCH 133.2 K); on
-          // the out-of-tile tap rows: 58.9 us alone, 55.9 us with the interior hint (FETCH 118.6 K, but no faster).
+          // the out-of-tile tap rows: 58.9 us alone, 55.9 us with the interior hint (FETCH 118.6 K, but no faster);
+          // the residual row of position i + 1 requested before position i is worked on (63 VGPRs): +1.5 us.
           const bool inner = NTI && (wave == 1 || wave == 2) && (i == 1 || i == 2);
           if (inner) {
             ia[i] = make_float4(0.f, 0.f, 0.f, 0.f);
