@@ -914,7 +914,7 @@ typedef float fr_f2 __attribute__((ext_vector_type(2)));
 // 121-126): the sampled plane is feat + feat2 (= conv_5_1(conv_1_5(x)) + conv_1_1(x)), and the result
 // gets the module's residual, out = res + (plane + sample(plane)), in the reference's operation order.
 // 3 reads + 1 write per element instead of (2r + 1w) + (1r + 1w) + (2r + 1w) over three launches.
-template <int LOGW, int LOGH, int THREADS, bool FROM_BOXES, int FUSED = 0>
+template <int LOGW, int LOGH, int THREADS, bool FROM_BOXES, int FUSED = 0, bool NTP = (LOGW >= 7)>
 __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restrict__ feat,
                                                            const float* __restrict__ table, int C, int G,
                                                            float scale, float* __restrict__ out,
@@ -973,6 +973,13 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
   // requested while position k is sampled, and element k is written to the idle LDS buffer D
   // positions after its request: one load, one store and one LDS write per position, no bursts.
   constexpr int D = K > 1 ? K / 2 : 0;  // (3K/4 measured the same cold and 4 % slower warm)
+  // every plane element is read once and written once by the whole launch: non-temporal at 128 x 128 (NTP; level 0,
+  // N = 4, rotating buffers: 33.2 -> 32.3 us; at 64 x 64 no gain, tools/fr_nchw_nt_ab.py)
+  auto LD = [](const float* p) -> float { return NTP ? __builtin_nontemporal_load(p) : *p; };
+  auto ST = [](float* p, const float x) {
+    if (NTP) __builtin_nontemporal_store(x, p);
+    else *p = x;
+  };
   float v[K], vd = 0.f;
   constexpr bool TWO = FUSED == 1, RES = FUSED != 0;  // FUSED 2: the residual only (the plane is already summed)
   float v2[K], vd2 = 0.f, vr[K];  // second addend of the plane, the residual of the output plane
@@ -981,12 +988,12 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
     const float* src2 = TWO ? feat2 + (plane0 << (LOGW + LOGH)) : nullptr;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-      v[k] = src[tid + k * FRC_BLOCK];
-      if (TWO) v2[k] = src2[tid + k * FRC_BLOCK];
+      v[k] = LD(&src[tid + k * FRC_BLOCK]);
+      if (TWO) v2[k] = LD(&src2[tid + k * FRC_BLOCK]);
     }
     if (dup) {
-      vd = src[dsrc];
-      if (TWO) vd2 = src2[dsrc];
+      vd = LD(&src[dsrc]);
+      if (TWO) vd2 = LD(&src2[dsrc]);
     }
 #pragma unroll
     for (int k = 0; k < K; k++) lds[self0 + k * KSTEP] = TWO ? v[k] + v2[k] : v[k];
@@ -994,9 +1001,9 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
     src += HW;  // G >= 2 (launcher)
 #pragma unroll
     for (int k = 0; k < D; k++) {
-      v[k] = src[tid + k * FRC_BLOCK];
-      if (TWO) v2[k] = src2[HW + tid + k * FRC_BLOCK];
-      if (RES) vr[k] = res[(plane0 << (LOGW + LOGH)) + tid + k * FRC_BLOCK];
+      v[k] = LD(&src[tid + k * FRC_BLOCK]);
+      if (TWO) v2[k] = LD(&src2[HW + tid + k * FRC_BLOCK]);
+      if (RES) vr[k] = LD(&res[(plane0 << (LOGW + LOGH)) + tid + k * FRC_BLOCK]);
     }
   }
   __syncthreads();
@@ -1011,19 +1018,19 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
     const float* resc = RES ? res + ((plane0 + c) << (LOGW + LOGH)) : nullptr;
     float* dst = out + ((plane0 + c) << (LOGW + LOGH));
     if (L1 && dup) {
-      vd = src1[dsrc];
-      if (TWO) vd2 = src21[dsrc];
+      vd = LD(&src1[dsrc]);
+      if (TWO) vd2 = LD(&src21[dsrc]);
     }
 #pragma unroll
     for (int k = 0; k < K; k++) {
       if (k + D < K) {
-        if (L1) v[k + D] = src1[tid + (k + D) * FRC_BLOCK];
-        if (TWO && L1) v2[k + D] = src21[tid + (k + D) * FRC_BLOCK];
-        if (RES) vr[k + D] = resc[tid + (k + D) * FRC_BLOCK];
+        if (L1) v[k + D] = LD(&src1[tid + (k + D) * FRC_BLOCK]);
+        if (TWO && L1) v2[k + D] = LD(&src21[tid + (k + D) * FRC_BLOCK]);
+        if (RES) vr[k + D] = LD(&resc[tid + (k + D) * FRC_BLOCK]);
       } else {
-        if (L2) v[k + D - K] = src1[HW + tid + (k + D - K) * FRC_BLOCK];
-        if (TWO && L2) v2[k + D - K] = src21[HW + tid + (k + D - K) * FRC_BLOCK];
-        if (RES && L1) vr[k + D - K] = resc[HW + tid + (k + D - K) * FRC_BLOCK];
+        if (L2) v[k + D - K] = LD(&src1[HW + tid + (k + D - K) * FRC_BLOCK]);
+        if (TWO && L2) v2[k + D - K] = LD(&src21[HW + tid + (k + D - K) * FRC_BLOCK]);
+        if (RES && L1) vr[k + D - K] = LD(&resc[HW + tid + (k + D - K) * FRC_BLOCK]);
       }
       float y = ty[k], x = tx[k];
       // opaque copies: without them LICM hoists cell / fractions / address of all K positions
@@ -1042,7 +1049,7 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
       const fr_f2 pt = ((1.f - fy) * hf) * top;  // {w1 * v1, w2 * v2}
       const fr_f2 pb = (fy * hf) * bot;          // {w3 * v3, w4 * v4}
       const float val = (pt.x + pt.y + pb.x + pb.y);
-      dst[tid + k * FRC_BLOCK] = RES ? vr[k] + (id + val) : id + val;
+      ST(&dst[tid + k * FRC_BLOCK], RES ? vr[k] + (id + val) : id + val);
       if (L1) nbuf[self0 + k * KSTEP] = TWO ? v[k] + v2[k] : v[k];
     }
     if (L1 && dup) nbuf[ddst] = TWO ? vd + vd2 : vd;
@@ -1569,7 +1576,9 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
     float* table = reinterpret_cast<float*>(ws);
     const int total = N * H * W;
     static bool once = (allow_big_lds(fr_forward_cell<7, 7, 1024, false>, 160 * 1024),
-                        allow_big_lds(fr_forward_cell<7, 7, 1024, true>, 160 * 1024), true);
+                        allow_big_lds(fr_forward_cell<7, 7, 1024, true>, 160 * 1024),
+                        allow_big_lds(fr_forward_cell<7, 7, 1024, false, 0, false>, 160 * 1024),
+                        allow_big_lds(fr_forward_cell<7, 7, 1024, true, 0, false>, 160 * 1024), true);
     (void)once;
     const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
     // profiling mode (r3det_set_option("fr_profile", 1 | 2)): the launches carry their own start /
@@ -1585,7 +1594,10 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
                             H, W, scale, table);
     // (64 x 64 with 512- or 256-thread workgroups, several per CU, measured 1-5 % slower than 1024)
 #define R3_CELL(LW, LH, FB, SRC) \
-  hipExtLaunchKernelGGL((fr_forward_cell<LW, LH, 1024, FB>), grid, block, lds, stream, c0, c1, 0, feat, SRC, C, G, scale, out, (const float*)nullptr, (const float*)nullptr)
+  do { \
+    if (g_r3_fr_dbg == 21) hipExtLaunchKernelGGL((fr_forward_cell<LW, LH, 1024, FB, 0, false>), grid, block, lds, stream, c0, c1, 0, feat, SRC, C, G, scale, out, (const float*)nullptr, (const float*)nullptr); \
+    else hipExtLaunchKernelGGL((fr_forward_cell<LW, LH, 1024, FB>), grid, block, lds, stream, c0, c1, 0, feat, SRC, C, G, scale, out, (const float*)nullptr, (const float*)nullptr); \
+  } while (0)
     if (W == 128) { if (from_boxes) R3_CELL(7, 7, true, boxes); else R3_CELL(7, 7, false, table); }
     else { if (from_boxes) R3_CELL(6, 6, true, boxes); else R3_CELL(6, 6, false, table); }
 #undef R3_CELL
