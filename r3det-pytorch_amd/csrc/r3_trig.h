@@ -11,6 +11,11 @@
 #include <hip/hip_runtime.h>
 
 __device__ __forceinline__ void r3_sincos(float a, float& s_out, float& c_out) {
+  if (a == 0.f) {  // (anchor grids: the polynomial below gives exactly (a, 1) for +-0; a wave of such boxes skips it)
+    s_out = a;
+    c_out = 1.f;
+    return;
+  }
   double x = (double)a;
   if (!(fabs(x) < 1.0e9)) {
     float q = a - a;  // NaN for inf/nan input, mirrors "no finite answer"
