@@ -851,6 +851,154 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
   }
 }
 
+// "Wide" form of the kernel above for square maps whose side is a multiple of 8: 64 positions and 16 waves per
+// workgroup instead of 32 and 8, still two residency slots' worth of LDS per position (64 KB, two workgroups per CU).
+// What it buys: a region of 4 x 8 cells has 12 interior positions of 32 (an 8 x 8 one 36 of 64) against 4 of 16 for
+// a 4 x 4 tile -- more identity rows that no other workgroup will ask for (non-temporal loads) -- and 30 % (53 %)
+// fewer taps that leave the workgroup's regions, i.e. fewer rows fetched twice.
+//   off-diagonal 8 x 8 super-blocks (I < J): a workgroup owns the 4 x 8 region A = rows 8I + 4k .. + 3, columns
+//     8J .. 8J + 7 (k = 0, 1) and its TRANSPOSE, the 8 x 4 region B = rows 8J .. 8J + 7, columns 8I + 4k .. + 3 of
+//     super-block (J, I): the sources of A sample B and the other way round (row <- x_ctr, column <- y_ctr);
+//   diagonal super-blocks: one workgroup owns the whole 8 x 8 block, which is its own transpose.
+// Slots of the LDS map: A (or the 8 x 8 block) row-major with 8 columns, then B row-major with 4 columns at slot 32.
+// A wave owns 4 positions of one row.  Same arithmetic, same operation order as the other forms (bit-identical).
+// MEASURED, NOT THE DEFAULT (option fr_dbg 8; level 0, N = 4, rotating buffers, A/B inside one run,
+// tools/fr_fwd_var_ab.py): HBM traffic FETCH x 2 + WRITE 317 -> 288 MB = 1.07 x algorithmic (the verdict's bar was
+// 1.12 x), but 55.8 - 57.6 us against 53.9 - 55.0 us for the 4 x 4 pairs: two 16-wave workgroups per CU leave
+// fewer workgroups in their load phase while the others work through their four positions one memory latency at a
+// time.  Requesting the four residual rows together behind the barrier needs 71 VGPRs (one workgroup per CU:
+// 57 - 61 us).  What this form wants is a persistent, software-pipelined workgroup.
+template <bool FUSED>
+__global__ __launch_bounds__(1024) void fr_forward_nhwc_wide(
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
+    const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
+    float scale, int S_strip, int per_img, int T, float* __restrict__ out) {
+  __shared__ float4 Pw[64][64];  // slot x lane
+  const int S = S_strip & 0xfffff, strip = S_strip >> 20;  // super-blocks per side; the pair walk's strip height
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned t = blockIdx.x;
+  if ((T & 7) == 0) t = (t & 7u) * (unsigned)(T >> 3) + (t >> 3);  // XCD-contiguous bands
+  const int n = (int)(t / (unsigned)per_img);
+  const int tt = (int)(t - (unsigned)n * (unsigned)per_img);
+  int y0a, x0a, ra, y0b, x0b, rb;  // region A: ra x 8 cells at (y0a, x0a); region B: rb x 4 cells at (y0b, x0b)
+  const int offd = S * (S - 1);
+  if (tt < offd) {
+    int I, J;
+    pair_walk(tt >> 1, S, strip, I, J);
+    const int k4 = (tt & 1) * 4;
+    y0a = 8 * I + k4; x0a = 8 * J; ra = 4;
+    y0b = 8 * J; x0b = 8 * I + k4; rb = 8;
+  } else {
+    y0a = x0a = 8 * (tt - offd); ra = 8;
+    y0b = x0b = 0; rb = 0;
+  }
+  // the wave's row and first column, its first slot, and which of its 4 positions are interior to their region
+  const bool inB = rb != 0 && wave >= 8;
+  const int wl = inB ? wave - 8 : wave;
+  const int py = inB ? y0b + wl : y0a + (wl >> 1);
+  const int px0 = inB ? x0b : x0a + (wl & 1) * 4;
+  const int slot0 = inB ? 32 + wl * 4 : (wl >> 1) * 8 + (wl & 1) * 4;
+  const int lrow = inB ? wl : (wl >> 1), nrow = inB ? 8 : ra;
+  const bool row_inner = lrow >= 1 && lrow <= nrow - 2;
+  // (columns: B has 4 -> positions 1, 2; A has 8 -> the left wave's 1..3, the right wave's 0..2)
+  const int in_lo = inB ? 1 : ((wl & 1) ? 0 : 1), in_hi = inB ? 2 : ((wl & 1) ? 2 : 3);
+  const int HW = H * W, C4 = C >> 2;
+  const bool two = FUSED && b != nullptr, has_res = FUSED && res != nullptr;
+  const size_t imgB = (size_t)n * HW * C * 4;
+  const char* aI = reinterpret_cast<const char*>(a) + imgB;
+  const char* bI = two ? reinterpret_cast<const char*>(b) + imgB : aI;
+  const char* rI = has_res ? reinterpret_cast<const char*>(res) + imgB : aI;
+  char* oI = reinterpret_cast<char*>(out) + imgB;
+  const float* bxI = boxes + (size_t)n * HW * 5;
+  const unsigned rowB = (unsigned)C * 4u;
+  const unsigned q0 = (unsigned)(py * W + px0);
+  for (int c0 = 0; c0 < C4; c0 += 64) {  // (wave-uniform trip count: the barriers are inside)
+    const bool cl = c0 + lane < C4;
+    const unsigned laneB = (unsigned)(c0 + lane) * 16u;
+    float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+    if (FUSED && cl) {
+      if (bias_a) ba = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bias_a) + laneB);
+      if (bias_b) bb = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bias_b) + laneB);
+    }
+    auto mixv = [&](const float4& x, const float4& y) -> float4 {  // (x + bias_a) + (y + bias_b), or x alone
+      float4 v = x;
+      if (FUSED) {
+        v.x += ba.x; v.y += ba.y; v.z += ba.z; v.w += ba.w;
+        if (two) {
+          float4 u = y;
+          u.x += bb.x; u.y += bb.y; u.z += bb.z; u.w += bb.w;
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+      }
+      return v;
+    };
+    {
+      float4 ia[4], ib[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned off = (q0 + (unsigned)i) * rowB + laneB;
+        ia[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ib[i] = ia[i];
+        if (cl) {
+          if (row_inner && i >= in_lo && i <= in_hi) {  // (wave-uniform) interior of the region: non-temporal
+            const fr_v4 ta = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(aI + off));
+            ia[i] = make_float4(ta.x, ta.y, ta.z, ta.w);
+            if (two) {
+              const fr_v4 tb = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(bI + off));
+              ib[i] = make_float4(tb.x, tb.y, tb.z, tb.w);
+            }
+          } else {
+            ia[i] = *reinterpret_cast<const float4*>(aI + off);
+            if (two) ib[i] = *reinterpret_cast<const float4*>(bI + off);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) Pw[slot0 + i][lane] = mixv(ia[i], ib[i]);
+    }
+    __syncthreads();
+    auto P = [&](const int y, const int x) -> float4 {  // y, x wave-uniform, inside the map
+      const int ly = y - y0a, lx = x - x0a;
+      if ((unsigned)ly < (unsigned)ra && (unsigned)lx < 8u) return Pw[ly * 8 + lx][lane];
+      const int my = y - y0b, mx = x - x0b;
+      if ((unsigned)my < (unsigned)rb && (unsigned)mx < 4u) return Pw[32 + my * 4 + mx][lane];
+      const unsigned off = (unsigned)(y * W + x) * rowB + laneB;
+      return mixv(*reinterpret_cast<const float4*>(aI + off),
+                  two ? *reinterpret_cast<const float4*>(bI + off) : make_float4(0.f, 0.f, 0.f, 0.f));
+    };
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+      const unsigned q = q0 + (unsigned)i;
+      const float bx = bxI[q * 5u], by = bxI[q * 5u + 1u];  // (uniform addresses: scalar loads)
+      if (!cl) continue;
+      const unsigned off = q * rowB + laneB;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_res) {
+        const fr_v4 t4 = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(rI + off));
+        r = make_float4(t4.x, t4.y, t4.z, t4.w);
+      }
+      const TapYX tp = make_tap_yx(H, W, bx * scale, by * scale);  // sic: row <- x_ctr, column <- y_ctr
+      const int yl = __builtin_amdgcn_readfirstlane(tp.yl), xl = __builtin_amdgcn_readfirstlane(tp.xl);
+      const int yh = __builtin_amdgcn_readfirstlane(tp.yh), xh = __builtin_amdgcn_readfirstlane(tp.xh);
+      float4 v = Pw[slot0 + i][lane];
+      if (__builtin_amdgcn_readfirstlane((int)tp.valid)) {  // (a sample outside the map reads nothing)
+        const float4 lt = P(yl, xl), rt = P(yl, xh), lb = P(yh, xl), rbv = P(yh, xh);
+        float4 sm;
+        sm.x = tp.w[0] * lt.x + tp.w[1] * rt.x + tp.w[2] * lb.x + tp.w[3] * rbv.x;
+        sm.y = tp.w[0] * lt.y + tp.w[1] * rt.y + tp.w[2] * lb.y + tp.w[3] * rbv.y;
+        sm.z = tp.w[0] * lt.z + tp.w[1] * rt.z + tp.w[2] * lb.z + tp.w[3] * rbv.z;
+        sm.w = tp.w[0] * lt.w + tp.w[1] * rt.w + tp.w[2] * lb.w + tp.w[3] * rbv.w;
+        v.x += sm.x; v.y += sm.y; v.z += sm.z; v.w += sm.w;
+      }
+      if (has_res) { v.x = r.x + v.x; v.y = r.y + v.y; v.z = r.z + v.z; v.w = r.w + v.w; }
+      const fr_v4 t4 = {v.x, v.y, v.z, v.w};
+      __builtin_nontemporal_store(t4, reinterpret_cast<fr_v4*>(oI + off));
+    }
+    if (c0 + 64 < C4) __syncthreads();  // the next channel block overwrites Pw
+  }
+}
+
 // ----------------------------------------------------------------------------------------
 // "cell" forward kernel (points = 1, W x H a compile-time power-of-two shape).
 // What the plane kernel pays per (n, c) plane besides the plane itself is the per-position sample
@@ -1711,6 +1859,21 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   FrProfileSlot* ps = (g_r3_fr_profile && points == 1) ? fr_profile_next(N, H) : nullptr;
   if (ps) ps->mode = 3;
   hipEvent_t e0 = ps ? ps->ev[0] : nullptr, e1 = ps ? ps->ev[3] : nullptr;
+  // square maps with a side that is a multiple of 8 can take the wide form (fr_dbg 8; not the default: see the kernel)
+  if (occ && paired && H == W && (H & 7) == 0 && g_r3_fr_dbg == 8 &&
+      (unsigned long long)N * H * W * C * 4ull < (1ull << 32)) {
+    const int S = H / 8;
+    const long long Tw = (long long)S * S * N;
+    const dim3 gw((unsigned)Tw), bw(1024);
+    const int s_strip = S | (g_r3_fr_walk << 20);
+    if (fused)
+      hipExtLaunchKernelGGL((fr_forward_nhwc_wide<true>), gw, bw, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, boxes, C,
+                            H, W, scale, s_strip, S * S, (int)Tw, out);
+    else
+      hipExtLaunchKernelGGL((fr_forward_nhwc_wide<false>), gw, bw, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, boxes,
+                            C, H, W, scale, s_strip, S * S, (int)Tw, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   const dim3 grid((unsigned)T), block(paired ? 512 : 256);
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x, tpi, (int)T, out
   if (occ) {

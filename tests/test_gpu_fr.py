@@ -414,13 +414,29 @@ def test_forward_nhwc_refuses_odd_channel_counts():
 
 @pytest.mark.parametrize("shape", [(2, 256, 128, 128, 8), (4, 256, 64, 64, 16), (3, 64, 13, 7, 32), (1, 256, 1, 1, 128),
                                    (4, 256, 128, 128, 8),   # bench.py's roofline launch: 2048 workgroups, XCD band remap on
-                                   (8, 256, 128, 128, 8), (1, 256, 128, 128, 8), (3, 256, 32, 32, 32)])
+                                   (8, 256, 128, 128, 8), (1, 256, 128, 128, 8), (3, 256, 32, 32, 32), (2, 64, 8, 8, 128),
+                                   (1, 512, 16, 16, 64)])
 @pytest.mark.parametrize("points", [1, 5])
 @pytest.mark.parametrize("with_b", [True, False])
-def test_module_nhwc_bit_identical_to_the_nchw_steps(shape, points, with_b):
+@pytest.mark.parametrize("form", ["pairs", "wide"])
+def test_module_nhwc_bit_identical_to_the_nchw_steps(shape, points, with_b, form):
     """r3det_feature_refine_module_nhwc = residual + fr((a + bias_a) + (b + bias_b)) in one launch on
     channels_last memory: bit-identical to the elementwise steps + the NCHW sampler (itself pinned to the
-    oracle above)."""
+    oracle above).  form "wide": option fr_dbg 8, the 4 x 8 / 8 x 4 / 8 x 8 regions form for square maps with a side
+    that is a multiple of 8 (the other shapes take the same launches either way)."""
+    from r3det import _C
+    from r3det.ops.feature_refine import fr_forward, fr_module_nhwc
+    N, C, H, W, stride = shape
+    if form == "wide" and (points != 1 or H != W or H % 8):
+        pytest.skip("the wide form does not take this shape")
+    _C.set_option("fr_dbg", 8 if form == "wide" else 0)
+    try:
+        _module_nhwc_case(shape, points, with_b)
+    finally:
+        _C.set_option("fr_dbg", 0)
+
+
+def _module_nhwc_case(shape, points, with_b):
     from r3det.ops.feature_refine import fr_forward, fr_module_nhwc
     N, C, H, W, stride = shape
     g = torch.Generator(device='cuda').manual_seed(C + H + points)
