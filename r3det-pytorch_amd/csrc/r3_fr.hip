@@ -862,14 +862,11 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
 //   diagonal super-blocks: one workgroup owns the whole 8 x 8 block, which is its own transpose.
 // Slots of the LDS map: A (or the 8 x 8 block) row-major with 8 columns, then B row-major with 4 columns at slot 32.
 // A wave owns 4 positions of one row.  Same arithmetic, same operation order as the other forms (bit-identical).
-// MEASURED, NOT THE DEFAULT (option fr_dbg 8; level 0, N = 4, rotating buffers, A/B inside one run,
-// tools/fr_fwd_var_ab.py): HBM traffic FETCH x 2 + WRITE 317 -> 288 MB = 1.07 x algorithmic (the verdict's bar was
-// 1.12 x), but 55.8 - 57.6 us against 53.9 - 55.0 us for the 4 x 4 pairs: two 16-wave workgroups per CU leave
-// fewer workgroups in their load phase while the others work through their four positions one memory latency at a
-// time.  Requesting the four residual rows together behind the barrier needs 71 VGPRs (one workgroup per CU:
-// 57 - 61 us).  What this form wants is a persistent, software-pipelined workgroup.
+// Level 0, N = 4, rotating buffers, A/B inside one run (tools/fr_fwd_var_ab.py, option fr_dbg 8 / 0): HBM traffic
+// FETCH x 2 + WRITE 317 -> 288 MB = 1.07 x algorithmic (the verdict's bar was 1.12 x) at the same 53.4 - 55.1 us as
+// the 4 x 4 pairs (53.2 - 54.8) once the residual rows and boxes are requested in front of the barrier (below).
 template <bool FUSED>
-__global__ __launch_bounds__(1024) void fr_forward_nhwc_wide(
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void fr_forward_nhwc_wide(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
     const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
     float scale, int S_strip, int per_img, int T, float* __restrict__ out) {
@@ -957,6 +954,27 @@ __global__ __launch_bounds__(1024) void fr_forward_nhwc_wide(
 #pragma unroll
       for (int i = 0; i < 4; i++) Pw[slot0 + i][lane] = mixv(ia[i], ib[i]);
     }
+    // The four residual rows and the four boxes are requested HERE, when the identity rows' registers are free again
+    // (in front of the LDS writes they would be live next to them: 72 VGPRs), so that they arrive while the workgroup
+    // waits at the barrier; the position loop stays rolled (unrolled, the scheduler hoists and needs 71 VGPRs), the
+    // rows rotate through rq[0].  With two 16-wave workgroups per CU few other workgroups are in their load phase
+    // while this one works through its positions: without this the wide form ran 55.8 - 57.6 us, with it 53.4 - 55.1
+    // (the 4 x 4 pairs in the same runs: 53.2 - 54.8; they do not gain from it: 72 VGPRs, 56 - 59 us).
+    float4 rq[4];
+    float bxq[4], byq[4];  // (uniform addresses: scalar loads, scalar registers)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      bxq[i] = bxI[(q0 + (unsigned)i) * 5u];
+      byq[i] = bxI[(q0 + (unsigned)i) * 5u + 1u];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      rq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_res && cl) {
+        const fr_v4 t4 = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(rI + ((q0 + (unsigned)i) * rowB + laneB)));
+        rq[i] = make_float4(t4.x, t4.y, t4.z, t4.w);
+      }
+    }
     __syncthreads();
     auto P = [&](const int y, const int x) -> float4 {  // y, x wave-uniform, inside the map
       const int ly = y - y0a, lx = x - x0a;
@@ -970,14 +988,15 @@ __global__ __launch_bounds__(1024) void fr_forward_nhwc_wide(
 #pragma unroll 1
     for (int i = 0; i < 4; i++) {
       const unsigned q = q0 + (unsigned)i;
-      const float bx = bxI[q * 5u], by = bxI[q * 5u + 1u];  // (uniform addresses: scalar loads)
+      const float bx = bxq[0], by = byq[0];
+      bxq[0] = bxq[1]; bxq[1] = bxq[2]; bxq[2] = bxq[3];
+      byq[0] = byq[1]; byq[1] = byq[2]; byq[2] = byq[3];
       if (!cl) continue;
       const unsigned off = q * rowB + laneB;
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_res) {
-        const fr_v4 t4 = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(rI + off));
-        r = make_float4(t4.x, t4.y, t4.z, t4.w);
-      }
+      const float4 r = rq[0];
+      rq[0] = rq[1];
+      rq[1] = rq[2];
+      rq[2] = rq[3];
       const TapYX tp = make_tap_yx(H, W, bx * scale, by * scale);  // sic: row <- x_ctr, column <- y_ctr
       const int yl = __builtin_amdgcn_readfirstlane(tp.yl), xl = __builtin_amdgcn_readfirstlane(tp.xl);
       const int yh = __builtin_amdgcn_readfirstlane(tp.yh), xh = __builtin_amdgcn_readfirstlane(tp.xh);
