@@ -669,7 +669,7 @@ def main():
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "nms_type": "v1",
                        "parallelism": f"image-parallel x{world}, all_gather of detections"},
             "roofline": {"bound": "hbm",
-                         "kernel": "fr_forward_nhwc_occ<true,true,6> = the FeatureRefineModule tail at level 0 "
+                         "kernel": "fr_forward_nhwc_wide<true> = the FeatureRefineModule tail at level 0 "
                                    "(4x256x128x128, channels_last): (conv_a + bias) + (conv_b + bias), sampler, residual in "
                                    "one launch, 3 reads + 1 write per element; duration = the launch's own start/stop HIP "
                                    "events (hipExtLaunchKernelGGL)",

@@ -430,7 +430,7 @@ int r3det_bias_act(float* y, const float* bias, const float* residual, long long
  * force the dense-tile path), ("iou_dwgs", drain workgroups), ("nms_impl", 0 | 1 tiles), ("nms_qcap", n: entries
  * per queue region, small values force the redo-tile path), ("fr_profile", 0 | 1 every kernel | 2 first start
  * and last stop only), ("fr_dbg", NCHW: 0 | 1 taps from the table kernel | 2 taps derived in the sampler;
- * NHWC: 1 no tile pairing | 2 the register-pipelined kernel), ("fr_walk", strip height of the tile-pair launch
+ * NHWC: 1 no tile pairing | 2 the register-pipelined kernel | 9 the 4 x 4 tile pairs instead of the wide regions), ("fr_walk", strip height of the tile-pair launch
  * order of the channels_last sampler kernels, 0 row-major, default 8). */
 int r3det_set_option(const char* name, int value);
 

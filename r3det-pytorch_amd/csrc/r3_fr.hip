@@ -1878,8 +1878,9 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   FrProfileSlot* ps = (g_r3_fr_profile && points == 1) ? fr_profile_next(N, H) : nullptr;
   if (ps) ps->mode = 3;
   hipEvent_t e0 = ps ? ps->ev[0] : nullptr, e1 = ps ? ps->ev[3] : nullptr;
-  // square maps with a side that is a multiple of 8 can take the wide form (fr_dbg 8; not the default: see the kernel)
-  if (occ && paired && H == W && (H & 7) == 0 && g_r3_fr_dbg == 8 &&
+  // square maps with a side that is a multiple of 8 take the wide form (fr_dbg 9 and the other A/B switches keep the
+  // 4 x 4 tile pairs)
+  if (occ && paired && H == W && (H & 7) == 0 && (g_r3_fr_dbg == 0 || g_r3_fr_dbg == 8) &&
       (unsigned long long)N * H * W * C * 4ull < (1ull << 32)) {
     const int S = H / 8;
     const long long Tw = (long long)S * S * N;

@@ -422,14 +422,14 @@ def test_forward_nhwc_refuses_odd_channel_counts():
 def test_module_nhwc_bit_identical_to_the_nchw_steps(shape, points, with_b, form):
     """r3det_feature_refine_module_nhwc = residual + fr((a + bias_a) + (b + bias_b)) in one launch on
     channels_last memory: bit-identical to the elementwise steps + the NCHW sampler (itself pinned to the
-    oracle above).  form "wide": option fr_dbg 8, the 4 x 8 / 8 x 4 / 8 x 8 regions form for square maps with a side
-    that is a multiple of 8 (the other shapes take the same launches either way)."""
+    oracle above).  form "wide" (the default): the 4 x 8 / 8 x 4 / 8 x 8 regions form for square maps with a side
+    that is a multiple of 8; "pairs" (option fr_dbg 9): the 4 x 4 tile pairs for every shape."""
     from r3det import _C
     from r3det.ops.feature_refine import fr_forward, fr_module_nhwc
     N, C, H, W, stride = shape
-    if form == "wide" and (points != 1 or H != W or H % 8):
-        pytest.skip("the wide form does not take this shape")
-    _C.set_option("fr_dbg", 8 if form == "wide" else 0)
+    if form == "pairs" and (points != 1 or H != W or H % 8):
+        pytest.skip("this shape takes the same launch either way")
+    _C.set_option("fr_dbg", 9 if form == "pairs" else 0)
     try:
         _module_nhwc_case(shape, points, with_b)
     finally:

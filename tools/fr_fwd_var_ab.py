@@ -1,6 +1,6 @@
-"""A/B of the channels_last module-tail kernel's launch variants (option fr_dbg: 0 shipped | 3 round-2 form |
-6 without the non-temporal interior identity rows), level 0 / 1, rotating buffers;
-every variant must be bit-identical to the first."""
+"""A/B of the channels_last module-tail kernel's launch variants (option fr_dbg: 0 shipped = the wide regions form |
+9 the 4 x 4 tile pairs | 6 pairs without the non-temporal interior identity rows | 3 round-2 form), level 0 / 1,
+rotating buffers; every variant must be bit-identical to the first."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")): sys.path.insert(0, p)
@@ -11,7 +11,7 @@ dev = torch.device("cuda")
 C = 256
 cl = torch.channels_last
 N = int(os.environ.get("FR_AB_N", "4"))
-variants = tuple(int(x) for x in os.environ.get("FR_AB", "0,6,3").split(","))
+variants = tuple(int(x) for x in os.environ.get("FR_AB", "0,9,6,3").split(","))
 for H, stride in ((128, 8), (64, 16)):
     nset = 3 if H == 128 else 10
     sets = [tuple(torch.randn(N, C, H, H, device=dev).contiguous(memory_format=cl) for _ in range(4)) for _ in range(nset)]
