@@ -1880,7 +1880,10 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   hipEvent_t e0 = ps ? ps->ev[0] : nullptr, e1 = ps ? ps->ev[3] : nullptr;
   // square maps with a side that is a multiple of 8 take the wide form (fr_dbg 9 and the other A/B switches keep the
   // 4 x 4 tile pairs)
-  if (occ && paired && H == W && (H & 7) == 0 && (g_r3_fr_dbg == 0 || g_r3_fr_dbg == 8) &&
+  // ... when that makes at least 512 workgroups (two per CU): 32 x 32 maps at N = 4 are 64 wide workgroups against
+  // 144 pairs, 16.0 against 11.7 us inside the model; fr_dbg 8 forces the wide form (tests)
+  if (occ && paired && H == W && (H & 7) == 0 &&
+      ((g_r3_fr_dbg == 0 && (long long)(H / 8) * (H / 8) * N >= 512) || g_r3_fr_dbg == 8) &&
       (unsigned long long)N * H * W * C * 4ull < (1ull << 32)) {
     const int S = H / 8;
     const long long Tw = (long long)S * S * N;

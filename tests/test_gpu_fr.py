@@ -418,18 +418,19 @@ def test_forward_nhwc_refuses_odd_channel_counts():
                                    (1, 512, 16, 16, 64)])
 @pytest.mark.parametrize("points", [1, 5])
 @pytest.mark.parametrize("with_b", [True, False])
-@pytest.mark.parametrize("form", ["pairs", "wide"])
+@pytest.mark.parametrize("form", ["pairs", "wide", "auto"])
 def test_module_nhwc_bit_identical_to_the_nchw_steps(shape, points, with_b, form):
     """r3det_feature_refine_module_nhwc = residual + fr((a + bias_a) + (b + bias_b)) in one launch on
     channels_last memory: bit-identical to the elementwise steps + the NCHW sampler (itself pinned to the
-    oracle above).  form "wide" (the default): the 4 x 8 / 8 x 4 / 8 x 8 regions form for square maps with a side
-    that is a multiple of 8; "pairs" (option fr_dbg 9): the 4 x 4 tile pairs for every shape."""
+    oracle above).  form "wide" (option fr_dbg 8): the 4 x 8 / 8 x 4 / 8 x 8 regions form for square maps with a side
+    that is a multiple of 8; "pairs" (fr_dbg 9): the 4 x 4 tile pairs; "auto": the library's choice (wide from 512
+    workgroups)."""
     from r3det import _C
     from r3det.ops.feature_refine import fr_forward, fr_module_nhwc
     N, C, H, W, stride = shape
-    if form == "pairs" and (points != 1 or H != W or H % 8):
+    if form != "auto" and (points != 1 or H != W or H % 8):
         pytest.skip("this shape takes the same launch either way")
-    _C.set_option("fr_dbg", 9 if form == "pairs" else 0)
+    _C.set_option("fr_dbg", {"pairs": 9, "wide": 8, "auto": 0}[form])
     try:
         _module_nhwc_case(shape, points, with_b)
     finally:
