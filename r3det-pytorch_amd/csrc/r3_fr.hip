@@ -862,9 +862,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
 //   diagonal super-blocks: one workgroup owns the whole 8 x 8 block, which is its own transpose.
 // Slots of the LDS map: A (or the 8 x 8 block) row-major with 8 columns, then B row-major with 4 columns at slot 32.
 // A wave owns 4 positions of one row.  Same arithmetic, same operation order as the other forms (bit-identical).
-// Level 0, N = 4, rotating buffers, A/B inside one run (tools/fr_fwd_var_ab.py, option fr_dbg 8 / 0): HBM traffic
-// FETCH x 2 + WRITE 317 -> 288 MB = 1.07 x algorithmic (the verdict's bar was 1.12 x) at the same 53.4 - 55.1 us as
-// the 4 x 4 pairs (53.2 - 54.8) once the residual rows and boxes are requested in front of the barrier (below).
+// Level 0, N = 4, rotating buffers, A/B inside one run (tools/fr_fwd_var_ab.py, option fr_dbg 8 / 9): as first
+// written HBM traffic FETCH x 2 + WRITE 317 -> 288 MB = 1.07 x algorithmic, but 55.8 - 57.6 us against 53.9 - 55.0 for
+// the 4 x 4 pairs; with the residual rows and boxes requested in front of the barrier (below) 53.4 - 55.1 us, the same
+// as the pairs, at 311 MB = 1.15 x (more rows in flight turn the L2 over faster: some of the saved re-fetches return).
 template <bool FUSED>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void fr_forward_nhwc_wide(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
@@ -1002,6 +1003,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       const int yh = __builtin_amdgcn_readfirstlane(tp.yh), xh = __builtin_amdgcn_readfirstlane(tp.xh);
       float4 v = Pw[slot0 + i][lane];
       if (__builtin_amdgcn_readfirstlane((int)tp.valid)) {  // (a sample outside the map reads nothing)
+        // (measured, not kept: two taps requested raw before the first is mixed, so that out-of-region taps wait
+        // for two L2 round trips instead of four: 48 B of scratch at the 64-VGPR cap, 89 us)
         const float4 lt = P(yl, xl), rt = P(yl, xh), lb = P(yh, xl), rbv = P(yh, xh);
         float4 sm;
         sm.x = tp.w[0] * lt.x + tp.w[1] * rt.x + tp.w[2] * lb.x + tp.w[3] * rbv.x;
