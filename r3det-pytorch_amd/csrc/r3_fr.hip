@@ -683,17 +683,22 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
         for (int i = 0; i < 4; i++) Pf[own + i][lane] = mixv(ia[i], ib[i]);
       }
       __syncthreads();
-      auto P = [&](const int y, const int x) -> float4 {  // y, x wave-uniform, inside the map
+      // A tap's value: from the workgroup's tiles (LDS), else two row loads.  `fetch` only REQUESTS (raw rows, not yet
+      // mixed), `fin` mixes: two taps are fetched before the first is finished, so that a position whose taps lie
+      // outside the tiles waits for two L2 round trips instead of four (tools/fr_offset_sweep.py).
+      auto fetch = [&](const int y, const int x, float4& xa, float4& xb) -> bool {  // y, x wave-uniform, inside the map
         const int ly = y - ty4, lx = x - tx4;
-        if ((unsigned)ly < (unsigned)NH_ROWS && (unsigned)lx < 4u) return Pf[(half << 4) + ly * 4 + lx][lane];
+        if ((unsigned)ly < (unsigned)NH_ROWS && (unsigned)lx < 4u) { xa = Pf[(half << 4) + ly * 4 + lx][lane]; return false; }
         if (PAIRED) {
           const int my = y - oy4, mx = x - ox4;
-          if ((unsigned)my < (unsigned)NH_ROWS && (unsigned)mx < 4u) return Pf[(((half ^ 1) << 4)) + my * 4 + mx][lane];
+          if ((unsigned)my < (unsigned)NH_ROWS && (unsigned)mx < 4u) { xa = Pf[(((half ^ 1) << 4)) + my * 4 + mx][lane]; return false; }
         }
         const unsigned off = (unsigned)(y * W + x) * rowB + laneB;
-        return mixv(*reinterpret_cast<const float4*>(aI + off),
-                    two ? *reinterpret_cast<const float4*>(bI + off) : make_float4(0.f, 0.f, 0.f, 0.f));
+        xa = *reinterpret_cast<const float4*>(aI + off);
+        if (two) xb = *reinterpret_cast<const float4*>(bI + off);
+        return true;
       };
+      auto fin = [&](const bool raw, const float4& xa, const float4& xb) -> float4 { return raw ? mixv(xa, xb) : xa; };
       (void)halfX;
 #pragma unroll 1
       for (int i = 0; i < cnt; i++) {
@@ -720,7 +725,12 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
         // (a sample outside the map reads nothing, as in the reference: its taps would all be cell (0, 0), one row
         // requested by every wave of the chip -- a field of such boxes ran 65 us instead of 54)
         if (__builtin_amdgcn_readfirstlane((int)tp.valid)) {
-          const float4 lt = P(yl, xl), rt = P(yl, xh), lb = P(yh, xl), rb = P(yh, xh);
+          float4 xa0, xb0 = make_float4(0.f, 0.f, 0.f, 0.f), xa1, xb1 = xb0;
+          bool g0 = fetch(yl, xl, xa0, xb0), g1 = fetch(yl, xh, xa1, xb1);
+          const float4 lt = fin(g0, xa0, xb0), rt = fin(g1, xa1, xb1);
+          g0 = fetch(yh, xl, xa0, xb0);
+          g1 = fetch(yh, xh, xa1, xb1);
+          const float4 lb = fin(g0, xa0, xb0), rb = fin(g1, xa1, xb1);
           float4 sm;
           sm.x = tp.w[0] * lt.x + tp.w[1] * rt.x + tp.w[2] * lb.x + tp.w[3] * rb.x;
           sm.y = tp.w[0] * lt.y + tp.w[1] * rt.y + tp.w[2] * lb.y + tp.w[3] * rb.y;
