@@ -377,15 +377,31 @@ def test_module_channels_last_inference_path():
             assert torch.allclose(g.contiguous(), f.contiguous() + sampled, rtol=1e-5, atol=1e-5), l
 
 
-NHWC_SHAPES = [(n, (c + 3) // 4 * 4, h, w, st) for n, c, h, w, st in SHAPES] + [(2, 256, 64, 64, 16), (1, 260, 9, 5, 32)]
+# (the last: 1024 workgroups of the wide form = the library's own choice for that shape)
+NHWC_SHAPES = [(n, (c + 3) // 4 * 4, h, w, st) for n, c, h, w, st in SHAPES] + [(2, 256, 64, 64, 16), (1, 260, 9, 5, 32),
+                                                                                (4, 32, 128, 128, 8)]
 
 
 @pytest.mark.parametrize("shape", NHWC_SHAPES)
 @pytest.mark.parametrize("points", [1, 5])
 @pytest.mark.parametrize("adversarial", [False, True])
-def test_forward_nhwc_bit_exact(shape, points, adversarial):
-    """The channels_last sampler (one wavefront per position) against the twin oracle on the transposed
-    input: every spatial shape of SHAPES with C rounded up to a multiple of 4, bit-exact."""
+@pytest.mark.parametrize("form", ["auto", "wide"])
+def test_forward_nhwc_bit_exact(shape, points, adversarial, form):
+    """The channels_last sampler against the twin oracle on the transposed input: every spatial shape of SHAPES with C
+    rounded up to a multiple of 4, bit-exact.  form "wide": option fr_dbg 8 forces the wide regions form on the square
+    maps with a side that is a multiple of 8 (the library takes it by itself from 512 workgroups)."""
+    from r3det import _C
+    N, C, H, W, stride = shape
+    if form == "wide" and (points != 1 or H != W or H % 8):
+        pytest.skip("the wide form does not take this shape")
+    _C.set_option("fr_dbg", 8 if form == "wide" else 0)
+    try:
+        _forward_nhwc_case(shape, points, adversarial)
+    finally:
+        _C.set_option("fr_dbg", 0)
+
+
+def _forward_nhwc_case(shape, points, adversarial):
     from r3det.ops.feature_refine import fr_forward_nhwc
     N, C, H, W, stride = shape
     r = np.random.default_rng(5 + C)
