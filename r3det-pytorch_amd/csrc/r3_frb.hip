@@ -314,34 +314,37 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __res
   // A: the sample rows of every source: entries in earlier rows (the band's base), sources that reach the band
   int before = 0, wc = 0;
   bool over = false;
-  constexpr int UA = 8;  // sources per thread and round: their 2 x UA loads are in flight together (one workgroup per
-                         // compute unit: a round is one L2 latency; a pre-pass that stored the sample rows as one
-                         // int per source made this phase no shorter, it is bound by the 16 ballots, not the loads)
+  constexpr int UA = 8;  // sources per thread and round: their UA loads are in flight together (one workgroup per
+                         // compute unit: a round is one L2 latency).  The phase is bound by its ~28 instructions per
+                         // source at 4 waves per SIMD (16.0 k cycles with guarded loads and a validity branch ->
+                         // 13.3 k with clamped unconditional loads and a branch-free body; a pre-pass that stored the
+                         // sample rows as one int per source made it no shorter).
   for (int s0 = 0; s0 < HW; s0 += IX_T * UA) {
     float yv[UA], xv[UA];
 #pragma unroll
     for (int u = 0; u < UA; u++) {
+      // (unconditional loads at a clamped index: behind `if (s < HW)` every load waited for itself -- 16 L2 round
+      // trips in a row, the whole of this phase)
       const int s = s0 + u * IX_T + tid;
-      yv[u] = -3.0e38f;  // (beyond the map: out of range below)
-      xv[u] = 0.f;
-      if (s < HW) {
-        yv[u] = bx[(size_t)s * 5];
-        xv[u] = bx[(size_t)s * 5 + 1];
-      }
+      const float* bp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bx) + (unsigned)min(s, HW - 1) * 20u);
+      const float y = bp[0], x = bp[1];
+      yv[u] = s < HW ? y : -3.0e38f;  // (beyond the map: out of range below)
+      xv[u] = s < HW ? x : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < UA; u++) {
       const int s = s0 + u * IX_T + tid;
-      bool pass = false;
-      float y = yv[u] * scale, x = xv[u] * scale;  // sic: row <- x_ctr, column <- y_ctr
-      if (!(y < -1.0 || y > H || x < -1.0 || x > W)) {  // (feature_refine_kernel.cu:72-79)
-        if (y <= 0) y = 0;
-        int yl = (int)y, yh;
-        if (yl >= H - 1) yh = yl = H - 1; else yh = yl + 1;
-        before += (yl < r0 ? 2 : 0) + (yh < r0 ? 2 : 0);
-        pass = yl < r1 && yh >= r0;
-      }
+      // (branch-free: every workgroup of the image walks all sources, so this body is the kernel's instruction
+      // budget; with the validity test as a branch a third of it was exec-mask bookkeeping)
+      float y = yv[u] * scale;
+      const float x = xv[u] * scale;  // sic: row <- x_ctr, column <- y_ctr
+      const bool valid = !(y < -1.0 || y > H || x < -1.0 || x > W);  // (feature_refine_kernel.cu:72-79)
+      y = y <= 0 ? 0.f : y;
+      const int yl = min((int)y, H - 1), yh = min(yl + 1, H - 1);  // (= the reference's clamp: yl >= H - 1 -> both H - 1)
+      before += valid ? (yl < r0 ? 2 : 0) + (yh < r0 ? 2 : 0) : 0;
+      const bool pass = valid && yl < r1 && yh >= r0;
       const u64 m = __ballot(pass);
+      if (m == 0ULL) continue;
       if (pass) {
         const int at = wc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         if (at < IXS_SEG) S.seg[wave * IXS_SEG + at] = s; else over = true;
