@@ -876,7 +876,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
 // written HBM traffic FETCH x 2 + WRITE 317 -> 288 MB = 1.07 x algorithmic, but 55.8 - 57.6 us against 53.9 - 55.0 for
 // the 4 x 4 pairs; with the residual rows and boxes requested in front of the barrier (below) 53.4 - 55.1 us, the same
 // as the pairs, at 311 MB = 1.15 x (more rows in flight turn the L2 over faster: some of the saved re-fetches return).
-template <bool FUSED>
+template <bool FUSED, bool TWO = false, bool RES = false>  // TWO: a second addend b; RES: a residual (both FUSED only)
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void fr_forward_nhwc_wide(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
     const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
@@ -910,9 +910,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   const int lrow = inB ? wl : (wl >> 1), nrow = inB ? 8 : ra;
   const bool row_inner = lrow >= 1 && lrow <= nrow - 2;
   // (columns: B has 4 -> positions 1, 2; A has 8 -> the left wave's 1..3, the right wave's 0..2)
-  const int in_lo = inB ? 1 : ((wl & 1) ? 0 : 1), in_hi = inB ? 2 : ((wl & 1) ? 2 : 3);
   const int HW = H * W, C4 = C >> 2;
-  const bool two = FUSED && b != nullptr, has_res = FUSED && res != nullptr;
+  constexpr bool two = FUSED && TWO, has_res = FUSED && RES;  // (compile-time: straight-line load blocks)
   const size_t imgB = (size_t)n * HW * C * 4;
   const char* aI = reinterpret_cast<const char*>(a) + imgB;
   const char* bI = two ? reinterpret_cast<const char*>(b) + imgB : aI;
@@ -944,12 +943,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     {
       float4 ia[4], ib[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const unsigned off = (q0 + (unsigned)i) * rowB + laneB;
-        ia[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ib[i] = ia[i];
-        if (cl) {
-          if (row_inner && i >= in_lo && i <= in_hi) {  // (wave-uniform) interior of the region: non-temporal
+      for (int i = 0; i < 4; i++) ia[i] = ib[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // The eight identity rows in ONE straight-line block per kind of wave (which of its positions are interior to
+      // the region -- non-temporal -- is a compile-time mask): with a scalar branch per row ("interior?") the compiler
+      // put a wait in front of every second load and a wave had two or three rows in flight instead of eight.
+      auto load8 = [&](auto mask_tag) {
+        constexpr int M = decltype(mask_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const unsigned off = (q0 + (unsigned)i) * rowB + laneB;
+          if ((M >> i) & 1) {
             const fr_v4 ta = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(aI + off));
             ia[i] = make_float4(ta.x, ta.y, ta.z, ta.w);
             if (two) {
@@ -961,6 +964,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             if (two) ib[i] = *reinterpret_cast<const float4*>(bI + off);
           }
         }
+      };
+      if (cl) {
+        if (!row_inner) load8(std::integral_constant<int, 0>{});
+        else if (inB) load8(std::integral_constant<int, 6>{});            // positions 1, 2
+        else if (wl & 1) load8(std::integral_constant<int, 7>{});        // the right wave of a row: 0, 1, 2
+        else load8(std::integral_constant<int, 14>{});                   // the left wave: 1, 2, 3
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) Pw[slot0 + i][lane] = mixv(ia[i], ib[i]);
@@ -1902,12 +1911,15 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     const long long Tw = (long long)S * S * N;
     const dim3 gw((unsigned)Tw), bw(1024);
     const int s_strip = S | (g_r3_fr_walk << 20);
-    if (fused)
-      hipExtLaunchKernelGGL((fr_forward_nhwc_wide<true>), gw, bw, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, boxes, C,
-                            H, W, scale, s_strip, S * S, (int)Tw, out);
-    else
-      hipExtLaunchKernelGGL((fr_forward_nhwc_wide<false>), gw, bw, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, boxes,
-                            C, H, W, scale, s_strip, S * S, (int)Tw, out);
+#define R3_WIDE(F, T2, RS) \
+  hipExtLaunchKernelGGL((fr_forward_nhwc_wide<F, T2, RS>), gw, bw, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, boxes, C, H, \
+                        W, scale, s_strip, S * S, (int)Tw, out)
+    if (!fused) R3_WIDE(false, false, false);
+    else if (b && res) R3_WIDE(true, true, true);
+    else if (b) R3_WIDE(true, true, false);
+    else if (res) R3_WIDE(true, false, true);
+    else R3_WIDE(true, false, false);
+#undef R3_WIDE
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   const dim3 grid((unsigned)T), block(paired ? 512 : 256);
