@@ -28,6 +28,7 @@
 //           tiles' gradient rows are shared through LDS, so most entries are one LDS read instead of a row
 //           load, and the second use of every row meets the first in the same compute unit.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 #include "r3_fr_tap.h"
@@ -512,19 +513,29 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
         const int2 ci = *reinterpret_cast<const int2*>(ciI + q * 8u);
         st[i] = i < cnt ? ci.x : 0;
         len[i] = i < cnt ? ci.y : 0;
-        // (the 2 x 2 interior of a tile: its rows are sources of this workgroup's two tiles only, as long as a box
-        // samples within one cell of its transposed position -- non-temporal, like the output rows below; the forward
-        // kernel gained 7 % from the same hint, r3_fr.hip)
-        const bool inner = (wave == 1 || wave == 2) && (i == 1 || i == 2);
         gi[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < cnt && cl) {
-          if (inner) {
+      }
+      // The 2 x 2 interior of a tile: its rows are sources of this workgroup's two tiles only, as long as a box samples
+      // within one cell of its transposed position -- non-temporal, like the output rows below (the forward kernel
+      // gained 7 % from the same hint, r3_fr.hip).  The four loads as ONE straight-line block per kind of wave (the
+      // interior positions are a compile-time mask; clamped rows: a short last tile loads a row twice): with a
+      // scalar branch per row the compiler put a wait between the loads.
+      auto load4 = [&](auto mask_tag) {
+        constexpr int M = decltype(mask_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const unsigned q = q0 + (unsigned)min(i, max(cnt - 1, 0));
+          if ((M >> i) & 1) {
             const frb_v4 t4 = __builtin_nontemporal_load(reinterpret_cast<const frb_v4*>(gI + (q * rowB + laneB)));
             gi[i] = make_float4(t4.x, t4.y, t4.z, t4.w);
           } else {
             gi[i] = *reinterpret_cast<const float4*>(gI + (q * rowB + laneB));
           }
         }
+      };
+      if (cl && cnt > 0) {
+        if (wave == 1 || wave == 2) load4(std::integral_constant<int, 6>{});
+        else load4(std::integral_constant<int, 0>{});
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) Gs[own + i][lane] = gi[i];
@@ -556,8 +567,20 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
         float4 r[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) e[u] = k == 0 ? ef.e[u] : entry((unsigned)(st_i + k + u));
+        // (the rows from memory first, all of them, then the rows from LDS: with `r[u] = G(e[u].x)` entry by entry
+        // the LDS read of one entry waited for the pending row load of the entry before it -- vmcnt(0) in front of
+        // every ds_read -- and the batch's loads ran one after the other)
+        bool mem[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) r[u] = G(e[u].x);
+        for (int u = 0; u < 4; u++) mem[u] = !(e[u].x < 0 && (PAIRED || !(e[u].x & 0x40000000)));
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (mem[u])
+            r[u] = cl ? *reinterpret_cast<const float4*>(gI + (((unsigned)e[u].x & 0x3ffffffu) * rowB + laneB))
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (!mem[u]) r[u] = Gs[((e[u].x >> 26) & 31) ^ halfX][lane];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const float w = __int_as_float(e[u].y);
