@@ -503,18 +503,20 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
   for (int c0 = 0; c0 < C4; c0 += 64) {  // (wave-uniform trip count: the barriers are inside)
     const bool cl = c0 + lane < C4;
     const unsigned laneB = (unsigned)(c0 + lane) * 16u;  // this lane's 16 bytes inside a row
+    struct E4 { int2 e[4]; };
+    auto first4 = [&](const int st_i) -> E4 {  // (entries st .. st + 3 are inside the array, or the slack behind it)
+      E4 r;
+#pragma unroll
+      for (int u = 0; u < 4; u++) r.e[u] = entry((unsigned)(st_i + u));
+      return r;
+    };
     // phase 1: the gradient rows of the wave's own 4 cells and their {start, len}, all in flight together; rows to LDS
     int st[4], len[4];
+    E4 en_first;
     {
       float4 gi[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const unsigned q = q0 + (unsigned)min(i, max(cnt - 1, 0));
-        const int2 ci = *reinterpret_cast<const int2*>(ciI + q * 8u);
-        st[i] = i < cnt ? ci.x : 0;
-        len[i] = i < cnt ? ci.y : 0;
-        gi[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int i = 0; i < 4; i++) gi[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       // The 2 x 2 interior of a tile: its rows are sources of this workgroup's two tiles only, as long as a box samples
       // within one cell of its transposed position -- non-temporal, like the output rows below (the forward kernel
       // gained 7 % from the same hint, r3_fr.hip).  The four loads as ONE straight-line block per kind of wave (the
@@ -537,6 +539,20 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
         if (wave == 1 || wave == 2) load4(std::integral_constant<int, 6>{});
         else load4(std::integral_constant<int, 0>{});
       }
+      // (the cells' {start, len} behind the row loads: in front of them the wave waited for these scalar loads -- an
+      // L2 round trip -- before it requested its rows; the compiler barrier keeps the scheduler from hoisting them back)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const unsigned q = q0 + (unsigned)min(i, max(cnt - 1, 0));
+        const int2 ci = *reinterpret_cast<const int2*>(ciI + q * 8u);
+        st[i] = i < cnt ? ci.x : 0;
+        len[i] = i < cnt ? ci.y : 0;
+      }
+      // (... and a use right here keeps it from sinking them behind the barrier)
+      asm volatile("" ::"s"(st[0]), "s"(st[1]), "s"(st[2]), "s"(st[3]), "s"(len[0]), "s"(len[1]), "s"(len[2]), "s"(len[3]));
+      en_first = first4(st[0]);  // (the first cell's first entries too: the third dependent round trip of a wave)
+      asm volatile("" ::"s"(en_first.e[0].x), "s"(en_first.e[1].x), "s"(en_first.e[2].x), "s"(en_first.e[3].x));
 #pragma unroll
       for (int i = 0; i < 4; i++) Gs[own + i][lane] = gi[i];
     }
@@ -546,13 +562,6 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
       if (code < 0 && (PAIRED || !(code & 0x40000000))) return Gs[((code >> 26) & 31) ^ halfX][lane];
       return cl ? *reinterpret_cast<const float4*>(gI + (((unsigned)code & 0x3ffffffu) * rowB + laneB))
                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    struct E4 { int2 e[4]; };
-    auto first4 = [&](const int st_i) -> E4 {  // (entries st .. st + 3 are inside the array, or the slack behind it)
-      E4 r;
-#pragma unroll
-      for (int u = 0; u < 4; u++) r.e[u] = entry((unsigned)(st_i + u));
-      return r;
     };
     auto cell = [&](const int i, const int st_i, const int len_i, const E4& ef) {
       const unsigned q = q0 + (unsigned)i;
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
       }
     };
     // (the first entries of cell i + 1 are requested before cell i is worked on)
-    E4 en_next = first4(st[0]);
+    E4 en_next = en_first;
 #pragma unroll 1
     for (int i = 0; i < cnt; i++) {
       const int st_i = i == 0 ? st[0] : i == 1 ? st[1] : i == 2 ? st[2] : st[3];
