@@ -653,31 +653,37 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
       {
         float4 ia[4], ib[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const unsigned off = (q0 + (unsigned)min(i, max(cnt - 1, 0))) * rowB + laneB;
-          const bool on = i < cnt && cl;
-          // The 2 x 2 interior of a tile is asked for by no other workgroup as long as a box samples within one cell
-          // of its own transposed position: those rows need not stay in the L2, and a non-temporal load lands
-          // sooner.  Level 0, N = 4, rotating buffers, same run: 58.1 -> 53.9 us (FETCH 124.1 -> 122.2 K).  The same
-          // hint on ALL identity rows: 62.0 us (the neighbours' tap rows are gone from the L2: FETCH 133.2 K); on
-          // the out-of-tile tap rows: 58.9 us alone, 55.9 us with the interior hint (FETCH 118.6 K, but no faster);
-          // the residual row of position i + 1 requested before position i is worked on (63 VGPRs): +1.5 us.
-          const bool inner = NTI && (wave == 1 || wave == 2) && (i == 1 || i == 2);
-          if (inner) {
-            ia[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            ib[i] = ia[i];
-            if (on) {
+        for (int i = 0; i < 4; i++) ia[i] = ib[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // The 2 x 2 interior of a tile is asked for by no other workgroup as long as a box samples within one cell
+        // of its own transposed position: those rows need not stay in the L2, and a non-temporal load lands
+        // sooner.  Level 0, N = 4, rotating buffers, same run: 58.1 -> 53.9 us (FETCH 124.1 -> 122.2 K).  The same
+        // hint on ALL identity rows: 62.0 us (the neighbours' tap rows are gone from the L2: FETCH 133.2 K); on
+        // the out-of-tile tap rows: 58.9 us alone, 55.9 us with the interior hint (FETCH 118.6 K, but no faster);
+        // the residual row of position i + 1 requested before position i is worked on (63 VGPRs): +1.5 us.
+        // The eight loads are ONE straight-line block per kind of wave (interior positions = a compile-time mask,
+        // rows clamped into the tile: a short last tile loads a row twice): with a scalar branch per row the compiler
+        // put a wait between the loads (see fr_forward_nhwc_wide).
+        auto load8 = [&](auto mask_tag) {
+          constexpr int M = decltype(mask_tag)::value;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const unsigned off = (q0 + (unsigned)min(i, max(cnt - 1, 0))) * rowB + laneB;
+            if ((M >> i) & 1) {
               const fr_v4 ta = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(aI + off));
               ia[i] = make_float4(ta.x, ta.y, ta.z, ta.w);
               if (two) {
                 const fr_v4 tb = __builtin_nontemporal_load(reinterpret_cast<const fr_v4*>(bI + off));
                 ib[i] = make_float4(tb.x, tb.y, tb.z, tb.w);
               }
+            } else {
+              ia[i] = *reinterpret_cast<const float4*>(aI + off);
+              if (two) ib[i] = *reinterpret_cast<const float4*>(bI + off);
             }
-          } else {
-            ia[i] = on ? *reinterpret_cast<const float4*>(aI + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            ib[i] = (on && two) ? *reinterpret_cast<const float4*>(bI + off) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
+        };
+        if (cl && cnt > 0) {
+          if (NTI && (wave == 1 || wave == 2)) load8(std::integral_constant<int, 6>{});
+          else load8(std::integral_constant<int, 0>{});
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) Pf[own + i][lane] = mixv(ia[i], ib[i]);
