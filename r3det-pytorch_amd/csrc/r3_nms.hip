@@ -877,8 +877,9 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         const bool has = k < m;
         // (all of a row's loads unconditional, at row 0 for a thread without a row: one batch, no branch in between.
         // Measured and not kept: the same loads requested during the label compaction for the thread's first two rows
-        // of the label and handed over through LDS -- __syncthreads() waits for outstanding loads, so they cannot stay
-        // in flight across the compaction's barrier: compaction 9.8 k -> 33.9 k cycles.)
+        // of the label and handed over through LDS (with an LDS-only barrier, so that they stay in flight): the 2 %
+        // of threads with a third row of the label still wait for memory here, in four waves of five, and the extra
+        // registers spill: 33 k -> 54 k cycles.)
         rr[u] = has ? (int)rows_l[k] : 0;
         const int sv_l = svals[rr[u]];  // (the row's candidate index: for the keep bits behind the rounds)
         const int c_l = sd.ecnt[rr[u]];
