@@ -505,9 +505,12 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
     const unsigned laneB = (unsigned)(c0 + lane) * 16u;  // this lane's 16 bytes inside a row
     struct E4 { int2 e[4]; };
     auto first4 = [&](const int st_i) -> E4 {  // (entries st .. st + 3 are inside the array, or the slack behind it)
+      // (one 32-byte scalar load instead of four 8-byte ones: the entries of a cell are contiguous)
+      typedef int frb_i8 __attribute__((ext_vector_type(8), aligned(8)));
+      const frb_i8 v = *reinterpret_cast<const frb_i8*>(enI + (unsigned)st_i * 8u);
       E4 r;
-#pragma unroll
-      for (int u = 0; u < 4; u++) r.e[u] = entry((unsigned)(st_i + u));
+      r.e[0] = make_int2(v[0], v[1]); r.e[1] = make_int2(v[2], v[3]);
+      r.e[2] = make_int2(v[4], v[5]); r.e[3] = make_int2(v[6], v[7]);
       return r;
     };
     // phase 1: the gradient rows of the wave's own 4 cells and their {start, len}, all in flight together; rows to LDS
