@@ -326,29 +326,30 @@ int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxe
                                   int H, int W, float spatial_scale, int points,
                                   float* bottom_grad, int overwrite, void* stream);
 
-/* The same call with a caller-provided device workspace of r3det_fr_backward_workspace_bytes()
- * bytes (0 = the shape has no workspace path; ws may then be NULL).  With it, overwrite-mode
- * calls on 128 x 128 and 64 x 64 planes (points = 1) first sort each image's positions by sampled
- * cell (once for all C channels) and then accumulate every gradient plane in LDS with plain
- * read-modify-writes instead of float atomics (9 x faster at N = 4, C = 256, 128 x 128).  Same
- * values up to the summation order, which the reference's atomics leave open as well. */
+/* The same call with a caller-provided device workspace of r3det_fr_backward_workspace_bytes() bytes (0 = the
+ * shape has no workspace path -- a plane of more than 32768 cells, or one that does not fit the 160 KB of LDS;
+ * ws may then be NULL).  With it the scatter of the reference (five float atomics per element,
+ * feature_refine_kernel.cu:165-230) runs as a GATHER: the boxes of the level are turned into the inverse tap
+ * index (per cell the list of {source position, weight}, sorted, so the sum has ONE order and results are
+ * reproducible run to run; lists of more than 48 entries on planes the sorted index form does not take keep
+ * their arrival order), re-laid in slices of 64 cells (SELL-64); the gradient pass then stages whole planes in
+ * LDS and every lane sums its own cell's list -- no atomics, no zero-fill, points 1 or 5.  Same values as the
+ * reference up to the summation order, which the reference's atomics leave open as well.  overwrite == 0 adds to
+ * bottom_grad like the reference. */
 size_t r3det_fr_backward_workspace_bytes(int N, int H, int W, int points);
 int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bboxes, int N, int C, int H, int W,
                                      float spatial_scale, int points, float* bottom_grad, int overwrite, void* ws,
                                      size_t ws_bytes, void* stream);
 
-/* Split form of the call above (overwrite mode, points = 1): the sort of the positions depends on
- * the boxes only, so a training step can run it when the forward pass has the boxes -- on another
- * stream, off the backward's critical path (31 of 80 us at N = 4, 128 x 128) -- and hand the
- * workspace to the backward later.  _prepare: R3DET_EINVAL when the shape has no workspace path
- * (r3det_fr_backward_workspace_bytes() == 0).  _prepared: same boxes, scale and workspace as the
- * _prepare call; R3DET_EINVAL when this (shape, C) does not take the packed path (then use
- * r3det_feature_refine_backward_ws). */
-int r3det_feature_refine_backward_prepare(const float* best_bboxes, int N, int H, int W, float spatial_scale,
-                                          void* ws, size_t ws_bytes, void* stream);
-int r3det_feature_refine_backward_prepared(const float* top_grad, const float* best_bboxes, int N, int C, int H,
-                                           int W, float spatial_scale, float* bottom_grad, void* ws, size_t ws_bytes,
-                                           void* stream);
+/* Split form of the call above: the index depends on the boxes only, so a training step builds it when the
+ * forward pass has the boxes (feature_refine_module.py:18-26 saves them for the backward) and the backward proper
+ * is the gather alone.  _index: R3DET_EINVAL when the shape has no workspace path.  _indexed: same N, H, W, points
+ * and workspace as the _index call; R3DET_EINVAL when this (shape, C) has no gather form (then use
+ * r3det_feature_refine_backward). */
+int r3det_feature_refine_backward_index(const float* best_bboxes, int N, int H, int W, float spatial_scale, int points,
+                                        void* ws, size_t ws_bytes, void* stream);
+int r3det_feature_refine_backward_indexed(const float* top_grad, int N, int C, int H, int W, int points,
+                                          float* bottom_grad, int overwrite, void* ws, size_t ws_bytes, void* stream);
 
 /* feature_refine_cuda.backward on channels_last memory: top_grad / bottom_grad are (N, H, W, C) contiguous
  * (torch.channels_last of the (N, C, H, W) tensors), C % 4 == 0, 16-byte aligned.  Same values as

@@ -13,6 +13,18 @@ int g_r3_iou_dwgs = 0;
 int g_r3_nms_impl = 0;
 int g_r3_nms_qcap = 0;
 
+int r3_cu_count() {
+  static int n_cu[R3_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= R3_MAX_DEVICES) return 256;
+  if (n_cu[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    n_cu[dev] = n;
+  }
+  return n_cu[dev];
+}
+
 namespace {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int rc(int k) {
@@ -300,20 +312,17 @@ int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bb
                             overwrite, ws, ws_bytes, 0, S(stream)));
 }
 
-int r3det_feature_refine_backward_prepare(const float* best_bboxes, int N, int H, int W, float spatial_scale,
-                                          void* ws, size_t ws_bytes, void* stream) {
-  if (N <= 0 || H <= 0 || W <= 0) return R3DET_EINVAL;
-  return rc(r3k_fr_backward_prepare(best_bboxes, N, H, W, spatial_scale, ws, ws_bytes, S(stream)));
+int r3det_feature_refine_backward_index(const float* best_bboxes, int N, int H, int W, float spatial_scale, int points,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
+  return rc(r3k_frn_index(best_bboxes, N, H, W, spatial_scale, points, ws, ws_bytes, S(stream)));
 }
 
-int r3det_feature_refine_backward_prepared(const float* top_grad, const float* best_bboxes, int N, int C, int H,
-                                           int W, float spatial_scale, float* bottom_grad, void* ws, size_t ws_bytes,
-                                           void* stream) {
-  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || !top_grad || !best_bboxes || !bottom_grad || !ws) return R3DET_EINVAL;
-  if (ws_bytes < r3k_fr_backward_workspace_bytes(N, H, W, 1) || r3k_fr_backward_workspace_bytes(N, H, W, 1) == 0)
+int r3det_feature_refine_backward_indexed(const float* top_grad, int N, int C, int H, int W, int points,
+                                          float* bottom_grad, int overwrite, void* ws, size_t ws_bytes, void* stream) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5) || !top_grad || !bottom_grad || !ws)
     return R3DET_EINVAL;
-  return rc(r3k_fr_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, 1, bottom_grad, 1, ws, ws_bytes, 1,
-                            S(stream)));
+  return rc(r3k_frn_gather(top_grad, N, C, H, W, points, bottom_grad, overwrite, ws, ws_bytes, S(stream)));
 }
 
 size_t r3det_fr_backward_nhwc_workspace_bytes(int N, int H, int W, int points) {

@@ -1256,433 +1256,6 @@ __global__ __launch_bounds__(THREADS) void fr_forward_cell(const float* __restri
   phase(c + 1, std::false_type{}, std::false_type{});
 }
 
-// ----------------------------------------------------------------------------------------
-// "cell" BACKWARD kernel (points = 1, overwrite mode): the forward kernel's structure with the
-// gather turned into a scatter.  feature_refine_backward_kernel (feature_refine_kernel.cu:165-230)
-// does 5 global atomics per element; the plane kernel above accumulates a plane in LDS but
-// re-derives the taps per plane from the boxes (426 us at level 0).  Here, per plane c of the
-// workgroup's G channels, ONE barrier:
-//   readout  plane c-1 : bottom[p] = acc[(c-1)&1][p]                 (this thread's own cells)
-//   init     plane c+1 : acc[(c+1)&1][p] = top[c+1][p]  (identity term; same cells, same buffer)
-//   scatter  plane c   : 4 x ds_add_f32 of g * w into acc[c&1] at the position's cell
-// with the top-gradient planes streamed by the same rolling load pipeline and the plane's own g
-// values kept in registers (the accumulator cell already holds other positions' contributions).
-// The duplicate column / row and the zero cell of the layout only ever receive contributions
-// that the reference adds with weight 0 or skips (clamped neighbours, out-of-range samples); they
-// are never read back.  Summation order of the atomics is not deterministic (as in the reference).
-// ----------------------------------------------------------------------------------------
-template <int LOGW, int LOGH, int THREADS, int MODE = 0>
-__device__ __forceinline__ void fr_backward_cell_body(const float* __restrict__ top,
-                                                      const float* __restrict__ boxes, int C, int G, float scale,
-                                                      float* __restrict__ bottom) {
-  constexpr int FRC_BLOCK = THREADS;
-  constexpr int W = 1 << LOGW, H = 1 << LOGH, HW = W * H, K = HW / FRC_BLOCK, PITCH = W + 1;
-  constexpr int BUF = ((H + 3) * PITCH + 3) & ~3;
-  constexpr int KSTEP = FRC_BLOCK + FRC_BLOCK / W;
-  constexpr int D = K > 1 ? K / 2 : 0;
-  static_assert(K >= 1 && W <= FRC_BLOCK, "shape");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int groups = C / G;
-  const int n = blockIdx.x / groups;
-  const int c0 = (blockIdx.x - n * groups) * G;
-  const size_t plane0 = (size_t)n * C + c0;
-  float ty[K], tx[K];
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    const float* bp = boxes + ((size_t)n * HW + tid + k * FRC_BLOCK) * 5;
-    ty[k] = bp[0];
-    tx[k] = bp[1];
-  }
-#pragma unroll
-  for (int k = 0; k < K; k++) cell_tap(ty[k] * scale, tx[k] * scale, H, W, ty[k], tx[k]);
-  const int self0 = tid + (tid >> LOGW);
-  for (int i = tid; i < 2 * BUF; i += FRC_BLOCK) lds[i] = 0.f;  // incl. the never-read helper cells
-  float v[K], g[K];
-  {
-    const float* src = top + (plane0 << (LOGW + LOGH));
-#pragma unroll
-    for (int k = 0; k < K; k++) g[k] = src[tid + k * FRC_BLOCK];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; k++) lds[self0 + k * KSTEP] = g[k];
-    src += HW;
-#pragma unroll
-    for (int k = 0; k < D; k++) v[k] = src[tid + k * FRC_BLOCK];
-  }
-  __syncthreads();
-  auto phase = [&](int c, auto l1, auto l2, auto first) {
-    constexpr bool L1 = decltype(l1)::value, L2 = decltype(l2)::value, FIRST = decltype(first)::value;
-    float* acc = lds + (c & 1) * BUF;
-    float* other = lds + ((c + 1) & 1) * BUF;  // holds plane c - 1 (read out), then plane c + 1 (initialised)
-    const float* src1 = top + ((plane0 + c + 1) << (LOGW + LOGH));
-    float* dst = bottom + ((plane0 + c - 1) << (LOGW + LOGH));
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      if (k + D < K) {
-        if (L1) v[k + D] = src1[tid + (k + D) * FRC_BLOCK];
-      } else {
-        if (L2) v[k + D - K] = src1[HW + tid + (k + D - K) * FRC_BLOCK];
-      }
-      if (!FIRST) dst[tid + k * FRC_BLOCK] = other[self0 + k * KSTEP];
-      if (L1) other[self0 + k * KSTEP] = v[k];
-      float y = ty[k], x = tx[k];
-      asm volatile("" : "+v"(y), "+v"(x));  // (see fr_forward_cell)
-      const int yi = (int)y, xi = (int)x;
-      const float fy = __builtin_amdgcn_fractf(y), fx = __builtin_amdgcn_fractf(x);
-      const int a = (yi << LOGW) + yi + xi;
-      const float gk = g[k];
-      const fr_f2 hf = {1.f - fx, fx};
-      const fr_f2 wt = (1.f - fy) * hf, wb = fy * hf;  // {w1, w2}, {w3, w4}
-      if (MODE == 0) {
-        atomicAdd(&acc[a], gk * wt.x);
-        atomicAdd(&acc[a + 1], gk * wt.y);
-        atomicAdd(&acc[a + PITCH], gk * wb.x);
-        atomicAdd(&acc[a + PITCH + 1], gk * wb.y);
-      } else if (MODE == 1) {  // probe: plain stores at the same addresses
-        acc[a] = gk * wt.x;
-        acc[a + 1] = gk * wt.y;
-        acc[a + PITCH] = gk * wb.x;
-        acc[a + PITCH + 1] = gk * wb.y;
-      } else if (MODE == 2) {  // probe: atomics at conflict-free addresses
-        float* sp = &acc[self0 + k * KSTEP];
-        atomicAdd(sp, gk * wt.x);
-        atomicAdd(sp, gk * wt.y);
-        atomicAdd(sp, gk * wb.x);
-        atomicAdd(sp, gk * wb.y);
-      } else {  // probe: one atomic per position
-        atomicAdd(&acc[a], gk * (wt.x + wt.y + wb.x + wb.y));
-      }
-      if (L1) g[k] = v[k];
-    }
-    __syncthreads();
-  };
-  using T = std::true_type;
-  using F = std::false_type;
-  if (G > 2) phase(0, T{}, T{}, T{}); else phase(0, T{}, F{}, T{});
-  int c = 1;
-  for (; c + 2 < G; c++) phase(c, T{}, T{}, F{});
-  if (c + 1 < G) {
-    phase(c, T{}, F{}, F{});
-    c++;
-  }
-  phase(c, F{}, F{}, F{});
-  {  // plane G - 1
-    const float* acc = lds + ((G - 1) & 1) * BUF;
-    float* dst = bottom + ((plane0 + G - 1) << (LOGW + LOGH));
-#pragma unroll
-    for (int k = 0; k < K; k++) dst[tid + k * FRC_BLOCK] = acc[self0 + k * KSTEP];
-  }
-}
-
-// the same code as a real function: fr_backward_packed calls it for images it cannot pack
-// (inlined there it would share, and overflow, that kernel's register budget)
-template <int LOGW, int LOGH>
-__device__ __attribute__((noinline)) void fr_backward_cell_call(const float* __restrict__ top,
-                                                                const float* __restrict__ boxes, int C, int G,
-                                                                float scale, float* __restrict__ bottom) {
-  fr_backward_cell_body<LOGW, LOGH, 1024, 0>(top, boxes, C, G, scale, bottom);
-}
-
-template <int LOGW, int LOGH, int THREADS, int MODE = 0>
-__global__ __launch_bounds__(THREADS) void fr_backward_cell(const float* __restrict__ top,
-                                                            const float* __restrict__ boxes, int C, int G,
-                                                            float scale, float* __restrict__ bottom) {
-  fr_backward_cell_body<LOGW, LOGH, THREADS, MODE>(top, boxes, C, G, scale, bottom);
-}
-
-// ----------------------------------------------------------------------------------------
-// "packed" BACKWARD (points = 1, overwrite mode, 128 x 128 / 64 x 64; needs a workspace): the
-// scatter without LDS float atomics.  Measured on the cell kernel above (tools/fr_bwd_probe.py):
-// 359 us as is, 26 us with plain stores at the same addresses, 345 us with the atomics moved to
-// conflict-free addresses -- ds_add_f32 itself retires ~1 lane per 3 cycles, whatever it hits.
-//
-// fr_bwd_pack_kernel (one workgroup per image, once for all C channels) sorts the valid positions
-// ("sources") by their top-left cell a = yi * PITCH + xi (counting sort in LDS) and deals them out
-// in that order: wave w takes the cells whose first source has sorted index in [w * 64K, (w + 1) *
-// 64K), lane l of it the next KS slots.  So
-//   * all sources of a cell (a "run") sit in consecutive slots of one lane, or of two adjacent
-//     lanes of the same wave (runs longer than MAXRUN flag the image for the atomic kernel);
-//   * a thread holds its KS slots {source address, cell, fy, fx} in registers for all G planes.
-// fr_backward_packed then needs per plane: one gather g = plane[source] per slot, and for each
-// of the 4 taps d one PHASE: run sums of g * w_d along the slots (a run's head in the previous
-// lane arrives by one __shfl_up), and at each run end a plain read-modify-write of
-// acc[cell + d].  Within a phase cell -> cell + d is injective and every cell belongs to exactly
-// one run end, so no two lanes touch the same address; phases are separated by barriers.
-// The identity term is the accumulator's initial value (the staged plane itself), as above.
-// ----------------------------------------------------------------------------------------
-template <int LOGW, int LOGH>
-struct FrPack {
-  static constexpr int W = 1 << LOGW, H = 1 << LOGH, HW = W * H, K = HW / 1024, PITCH = W + 1;
-  static constexpr int KS = K + 1 > 8 ? K + 1 : 8;           // slots per thread
-  static constexpr int MAXRUN = KS + 1 < 16 ? KS + 1 : 16;   // longest run the layout supports
-  static constexpr int NCELL = H * PITCH;                    // cells a source can have as top-left
-  static constexpr int ZC = (H + 1) * PITCH;                 // the zero cell
-  static constexpr size_t TABLE = (size_t)1024 * 12 * KS;    // ap | fy | fx, each [KS][1024]
-  static constexpr size_t META = TABLE + 64;                 // flag (image not packed) | wave bases [15]
-  // between the two pack kernels: exclusive prefix of the run lengths [NCELL + 1], ranks [HW]
-  static constexpr size_t IMAGE_BYTES = (META + (size_t)4 * (NCELL + 1 + HW) + 15) & ~(size_t)15;
-  static constexpr int PACK_LDS_INTS = 2 * NCELL + 1 + 1024 + 16 + 3;
-  // slot word ap: bit 31 = last source of its run, bits 16..30 = cell, bits 0..15 = source address
-};
-
-template <int LOGW, int LOGH>
-__global__ __launch_bounds__(1024) void fr_bwd_pack_kernel(const float* __restrict__ boxes, float scale,
-                                                           char* __restrict__ table) {
-  using P = FrPack<LOGW, LOGH>;
-  constexpr int W = P::W, H = P::H, HW = P::HW, K = P::K, PITCH = P::PITCH, KS = P::KS, NCELL = P::NCELL;
-  constexpr int Q = 64 * K;                          // sorted sources per wave (by run start)
-  constexpr int CPT = (NCELL + 1 + 1023) / 1024;     // scan: cells per thread
-  extern __shared__ __attribute__((aligned(16))) int pk[];
-  int* cnt = pk;                    // [NCELL + 1] counts, then their exclusive prefix
-  int* owner = cnt + NCELL + 1;     // [NCELL] last writer of a ranking round
-  int* part = owner + NCELL;        // [1024]
-  int* wbase = part + 1024;         // [16] first sorted index of a wave
-  int* bad = wbase + 16;
-  int* more = bad + 1;              // [2] "unranked sources left" of the even / odd rounds
-  const int tid = threadIdx.x, n = blockIdx.x;
-  char* tb = table + (size_t)n * P::IMAGE_BYTES;
-  int* t_ap = reinterpret_cast<int*>(tb);
-  float* t_fy = reinterpret_cast<float*>(tb + (size_t)4 * KS * 1024);
-  float* t_fx = reinterpret_cast<float*>(tb + (size_t)8 * KS * 1024);
-  for (int i = tid; i < NCELL + 1; i += 1024) cnt[i] = 0;
-  if (tid < 16) wbase[tid] = 0x7fffffff;
-  if (tid == 0) *bad = more[0] = more[1] = 0;
-#pragma unroll
-  for (int j = 0; j < KS; j++) {  // empty slot: gathers the zero cell, never ends a run
-    t_ap[j * 1024 + tid] = (P::ZC << 16) | P::ZC;
-    t_fy[j * 1024 + tid] = 0.f;
-    t_fx[j * 1024 + tid] = 0.f;
-  }
-  int a[K], rank[K];
-  unsigned pending = 0;
-#pragma unroll
-  for (int k = 0; k < K; k++) {
-    const float* bp = boxes + ((size_t)n * HW + tid + k * 1024) * 5;
-    float y, x;
-    cell_tap(bp[0] * scale, bp[1] * scale, H, W, y, x);  // sic: row <- x_ctr
-    rank[k] = 0;
-    if (y > (float)H) {
-      a[k] = -1;  // out of range: no contribution (feature_refine_kernel.cu:72-79)
-    } else {
-      a[k] = (int)y * PITCH + (int)x;
-      pending |= 1u << k;
-    }
-  }
-  __syncthreads();
-  // rank of a source inside its run, without atomics (LDS atomics retire ~1 lane per 3 cycles, see
-  // above): per round every unranked source writes its id to its cell, the one that reads itself
-  // back takes the round number as rank.  Rounds = longest run; beyond MAXRUN the image is bad.
-  for (int round = 0; round < P::MAXRUN; round++) {
-#pragma unroll
-    for (int k = 0; k < K; k++)
-      if ((pending >> k) & 1) owner[a[k]] = tid * K + k;
-    __syncthreads();
-    if (tid == 0) more[(round + 1) & 1] = 0;
-#pragma unroll
-    for (int k = 0; k < K; k++)
-      if (((pending >> k) & 1) && owner[a[k]] == tid * K + k) {
-        rank[k] = round;
-        cnt[a[k]] = round + 1;
-        pending &= ~(1u << k);
-      }
-    if (pending) more[round & 1] = 1;
-    __syncthreads();
-    if (!more[round & 1]) break;
-  }
-  if (pending) *bad = 1;
-  {  // exclusive prefix of cnt[0 .. NCELL]; cnt[NCELL] becomes the number of sources
-    const int lo = min(tid * CPT, NCELL + 1), hi = min(lo + CPT, NCELL + 1);
-    int s = 0;
-    for (int i = lo; i < hi; i++) s += cnt[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const int v = tid >= off ? part[tid - off] : 0;
-      __syncthreads();
-      part[tid] += v;
-      __syncthreads();
-    }
-    int run = part[tid] - s;
-    for (int i = lo; i < hi; i++) {
-      const int c = cnt[i];
-      cnt[i] = run;
-      // a wave's first run starts less than MAXRUN after its quota boundary (or the image is bad)
-      if (c > 0 && run % Q < P::MAXRUN) atomicMin(&wbase[run / Q], run);
-      run += c;
-    }
-  }
-  __syncthreads();
-  int* m_flag = reinterpret_cast<int*>(tb + P::TABLE);
-  int* m_cum = reinterpret_cast<int*>(tb + P::META);
-  int* m_rank = m_cum + NCELL + 1;
-  for (int i = tid; i < NCELL + 1; i += 1024) m_cum[i] = cnt[i];
-#pragma unroll
-  for (int k = 0; k < K; k++) m_rank[tid + k * 1024] = (a[k] < 0 || ((pending >> k) & 1)) ? -1 : rank[k];
-  if (tid < 16 && tid > 0) m_flag[tid] = wbase[tid];
-  if (tid == 0) m_flag[0] = *bad | (wbase[0] != 0 && wbase[0] != 0x7fffffff);
-}
-
-// second half of the packing, one thread per source over the whole chip: the 12-byte slot entry at
-// its place (scattered 4-byte stores: 20 us when the one workgroup of an image did them itself)
-template <int LOGW, int LOGH>
-__global__ __launch_bounds__(256) void fr_bwd_place_kernel(const float* __restrict__ boxes, float scale,
-                                                           char* __restrict__ table) {
-  using P = FrPack<LOGW, LOGH>;
-  constexpr int W = P::W, H = P::H, HW = P::HW, K = P::K, PITCH = P::PITCH, KS = P::KS, NCELL = P::NCELL;
-  constexpr int Q = 64 * K;
-  const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-  char* tb = table + (size_t)n * P::IMAGE_BYTES;
-  const int* m_flag = reinterpret_cast<const int*>(tb + P::TABLE);
-  const int* m_cum = reinterpret_cast<const int*>(tb + P::META);
-  const int rank = m_cum[NCELL + 1 + p];
-  if (rank < 0) return;
-  const float* bp = boxes + ((size_t)n * HW + p) * 5;
-  float y, x;
-  cell_tap(bp[0] * scale, bp[1] * scale, H, W, y, x);  // sic: row <- x_ctr
-  const int a = (int)y * PITCH + (int)x;
-  const int c0 = m_cum[a], len = m_cum[a + 1] - c0;
-  const int w = c0 / Q;
-  const int li = c0 + rank - (w ? m_flag[w] : 0);
-  if (li < 0 || li >= 64 * KS) return;  // only in images flagged bad
-  const int lane = li / KS, slot = li - lane * KS, t = w * 64 + lane;
-  reinterpret_cast<int*>(tb)[slot * 1024 + t] =
-      (rank == len - 1 ? (int)0x80000000 : 0) | (a << 16) | (p + (p >> LOGW));
-  reinterpret_cast<float*>(tb + (size_t)4 * KS * 1024)[slot * 1024 + t] = __builtin_amdgcn_fractf(y);
-  reinterpret_cast<float*>(tb + (size_t)8 * KS * 1024)[slot * 1024 + t] = __builtin_amdgcn_fractf(x);
-}
-
-template <int LOGW, int LOGH>
-__global__ __launch_bounds__(1024) void fr_backward_packed(const float* __restrict__ top,
-                                                           const char* __restrict__ table,
-                                                           const float* __restrict__ boxes, float scale, int C, int G,
-                                                           float* __restrict__ bottom) {
-  using P = FrPack<LOGW, LOGH>;
-  constexpr int W = P::W, H = P::H, HW = P::HW, K = P::K, PITCH = P::PITCH, KS = P::KS;
-  constexpr int BUF = ((H + 3) * PITCH + 3) & ~3;
-  constexpr int KSTEP = 1024 + 1024 / W;
-  constexpr int D = K > 4 ? 4 : K / 2;  // load pipeline depth (registers are the limit here)
-  constexpr int BS = K > 4 ? 6 : 8;  // read-modify-writes in flight per batch
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x;
-  const int groups = C / G;
-  const int n = blockIdx.x / groups;
-  const int c0 = (blockIdx.x - n * groups) * G;
-  const size_t plane0 = (size_t)n * C + c0;
-  const char* tb = table + (size_t)n * P::IMAGE_BYTES;
-  if (*reinterpret_cast<const int*>(tb + P::TABLE)) {  // a box field the packing does not take
-    fr_backward_cell_call<LOGW, LOGH>(top, boxes, C, G, scale, bottom);
-    return;
-  }
-  int ap[KS];
-  float fy[KS], fx[KS];
-#pragma unroll
-  for (int j = 0; j < KS; j++) {
-    ap[j] = reinterpret_cast<const int*>(tb)[j * 1024 + tid];
-    fy[j] = reinterpret_cast<const float*>(tb + (size_t)4 * KS * 1024)[j * 1024 + tid];
-    fx[j] = reinterpret_cast<const float*>(tb + (size_t)8 * KS * 1024)[j * 1024 + tid];
-  }
-  unsigned em = 0;   // run-end slots
-  int fcell = P::ZC;  // cell of the first run end: where a run head from the previous lane is added
-#pragma unroll
-  for (int j = KS - 1; j >= 0; j--)
-    if (ap[j] < 0) {
-      em |= 1u << j;
-      fcell = (ap[j] >> 16) & 0x7fff;
-    }
-  const int self0 = tid + (tid >> LOGW);
-  for (int i = tid; i < 2 * BUF; i += 1024) lds[i] = 0.f;
-  float v[K];
-  {
-    const float* src = top + (plane0 << (LOGW + LOGH));
-#pragma unroll
-    for (int k = 0; k < K; k++) v[k] = src[tid + k * 1024];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; k++) lds[self0 + k * KSTEP] = v[k];
-    src += HW;
-#pragma unroll
-    for (int k = 0; k < D; k++) v[k] = src[tid + k * 1024];
-  }
-  __syncthreads();
-  auto plane = [&](int c, auto l1, auto l2, auto first) {
-    constexpr bool L1 = decltype(l1)::value, L2 = decltype(l2)::value, FIRST = decltype(first)::value;
-    float* acc = lds + (c & 1) * BUF;          // plane c: identity term, then + the 4 taps
-    float* other = lds + ((c + 1) & 1) * BUF;  // plane c - 1 (read out), then plane c + 1 (staged)
-    const float* src1 = top + ((plane0 + c + 1) << (LOGW + LOGH));
-    float* dst = bottom + ((plane0 + c - 1) << (LOGW + LOGH));
-    float g[KS];
-#pragma unroll
-    for (int j = 0; j < KS; j++) {
-      int apj = ap[j];
-      asm volatile("" : "+v"(apj));
-      g[j] = acc[apj & 0xffff];
-    }
-    __syncthreads();  // every gather of plane c precedes every update of it
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-      // a quarter of the staging sweep (same rolling load pipeline as the kernels above)
-#pragma unroll
-      for (int k = d * K / 4; k < (d + 1) * K / 4; k++) {
-        if (k + D < K) {
-          if (L1) v[k + D] = src1[tid + (k + D) * 1024];
-        } else {
-          if (L2) v[k + D - K] = src1[HW + tid + (k + D - K) * 1024];
-        }
-        if (!FIRST) dst[tid + k * 1024] = other[self0 + k * KSTEP];
-        if (L1) other[self0 + k * KSTEP] = v[k];
-      }
-      // tap d: contributions g * w_d (w1 = hy hx, w2 = hy lx, w3 = ly hx, w4 = ly lx)
-      const int doff = (d & 1) + (d >> 1) * PITCH;
-      float r = 0.f;
-#pragma unroll
-      for (int b0 = 0; b0 < KS; b0 += BS) {
-        float o[BS], t[BS];
-        auto cell = [&](int j) {
-          int apj = ap[j];
-          asm volatile("" : "+v"(apj));  // (unpacked copies hoisted out of the plane loop would spill)
-          return ((apj >> 16) & 0x7fff) + doff;
-        };
-#pragma unroll
-        for (int j = b0; j < b0 + BS && j < KS; j++)
-          if ((em >> j) & 1) o[j - b0] = acc[cell(j)];
-#pragma unroll
-        for (int j = b0; j < b0 + BS && j < KS; j++) {
-          float ly = fy[j], lx = fx[j];
-          asm volatile("" : "+v"(ly), "+v"(lx));  // keep the 4 x KS weights out of registers
-          const float wy = (d >> 1) ? ly : 1.f - ly, wx = (d & 1) ? lx : 1.f - lx;
-          r += g[j] * (wy * wx);
-          t[j - b0] = r;  // meaningful at run ends
-          if ((em >> j) & 1) r = 0.f;
-        }
-#pragma unroll
-        for (int j = b0; j < b0 + BS && j < KS; j++)
-          if ((em >> j) & 1) acc[cell(j)] = o[j - b0] + t[j - b0];
-      }
-      // r: head of a run that continues in the next lane, which adds it where that run ends
-      float carry = __shfl_up(r, 1);
-      if ((tid & 63) != 0 && em != 0) acc[fcell + doff] += carry;
-      __syncthreads();
-    }
-  };
-  using T = std::true_type;
-  using F = std::false_type;
-  if (G > 2) plane(0, T{}, T{}, T{}); else plane(0, T{}, F{}, T{});
-  int c = 1;
-  for (; c + 2 < G; c++) plane(c, T{}, T{}, F{});
-  if (c + 1 < G) {
-    plane(c, T{}, F{}, F{});
-    c++;
-  }
-  plane(c, F{}, F{}, F{});
-  {  // plane G - 1
-    const float* acc = lds + ((G - 1) & 1) * BUF;
-    float* dst = bottom + ((plane0 + G - 1) << (LOGW + LOGH));
-#pragma unroll
-    for (int k = 0; k < K; k++) dst[tid + k * 1024] = acc[self0 + k * KSTEP];
-  }
-}
-
 // dynamic LDS above 64 KB has to be opted into once per kernel
 template <typename K>
 inline void allow_big_lds(K kernel, int bytes) {
@@ -1728,17 +1301,7 @@ inline int plane_cpb(int C, int H, int W) {
   return cpb < 1 ? 0 : cpb;
 }
 
-inline int cu_count() {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  return n_cu;
-}
+inline int cu_count() { return r3_cu_count(); }
 
 }  // namespace
 
@@ -1770,11 +1333,13 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
   if ((g_r3_fr_impl == 10 || cell_auto) && points == 1 && cell_shape && G >= 2 && aligned16(feat) && aligned16(out)) {
     float* table = reinterpret_cast<float*>(ws);
     const int total = N * H * W;
-    static bool once = (allow_big_lds(fr_forward_cell<7, 7, 1024, false>, 160 * 1024),
-                        allow_big_lds(fr_forward_cell<7, 7, 1024, true>, 160 * 1024),
-                        allow_big_lds(fr_forward_cell<7, 7, 1024, false, 0, false>, 160 * 1024),
-                        allow_big_lds(fr_forward_cell<7, 7, 1024, true, 0, false>, 160 * 1024), true);
-    (void)once;
+    static R3DeviceOnce once;
+    if (once.first()) {
+      allow_big_lds(fr_forward_cell<7, 7, 1024, false>, 160 * 1024);
+      allow_big_lds(fr_forward_cell<7, 7, 1024, true>, 160 * 1024);
+      allow_big_lds(fr_forward_cell<7, 7, 1024, false, 0, false>, 160 * 1024);
+      allow_big_lds(fr_forward_cell<7, 7, 1024, true, 0, false>, 160 * 1024);
+    }
     const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
     // profiling mode (r3det_set_option("fr_profile", 1 | 2)): the launches carry their own start /
     // stop events, so the recorded durations are the kernels' and not the host's launch gaps
@@ -1804,12 +1369,14 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
     while (cpb > 1 && (size_t)N * ((C + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
     dim3 grid((C + cpb - 1) / cpb, N);
     size_t lds = (size_t)cpb * H * (W + 1) * sizeof(float);
-    static bool once = (allow_big_lds(fr_forward_plane<1, true, 1>, FRP_LDS_FLOATS * 4),
-                        allow_big_lds(fr_forward_plane<1, true, 2>, FRP_LDS_FLOATS * 4),
-                        allow_big_lds(fr_forward_plane<1, true, 0>, FRP_LDS_FLOATS * 4),
-                        allow_big_lds(fr_forward_plane<1, false, 0>, FRP_LDS_FLOATS * 4),
-                        allow_big_lds(fr_forward_plane<5, false, 0>, FRP_LDS_FLOATS * 4), true);
-    (void)once;
+    static R3DeviceOnce once;
+    if (once.first()) {
+      allow_big_lds(fr_forward_plane<1, true, 1>, FRP_LDS_FLOATS * 4);
+      allow_big_lds(fr_forward_plane<1, true, 2>, FRP_LDS_FLOATS * 4);
+      allow_big_lds(fr_forward_plane<1, true, 0>, FRP_LDS_FLOATS * 4);
+      allow_big_lds(fr_forward_plane<1, false, 0>, FRP_LDS_FLOATS * 4);
+      allow_big_lds(fr_forward_plane<5, false, 0>, FRP_LDS_FLOATS * 4);
+    }
     const bool vec = (W % 4 == 0) && aligned16(feat) && aligned16(boxes) && aligned16(out);
     const bool full = (C % cpb) == 0;  // every workgroup owns exactly cpb planes
 #define R3_FWD(P, V, K) hipLaunchKernelGGL((fr_forward_plane<P, V, K>), grid, dim3(FRP_BLOCK), lds, stream, feat, boxes, C, H, W, scale, cpb, out)
@@ -1864,10 +1431,12 @@ int r3k_fr_forward_prepared(const float* feat, const float* feat2, const float* 
   while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
   if (G < 2 || !aligned16(feat) || !aligned16(out) || !aligned16(table)) return -1;
   if ((feat2 && !aligned16(feat2)) || (res && !aligned16(res))) return -1;
-  static bool once = (allow_big_lds(fr_forward_cell<7, 7, 1024, false>, 160 * 1024),
-                      allow_big_lds(fr_forward_cell<7, 7, 1024, false, 1>, 160 * 1024),
-                      allow_big_lds(fr_forward_cell<7, 7, 1024, false, 2>, 160 * 1024), true);
-  (void)once;
+  static R3DeviceOnce once;
+    if (once.first()) {
+      allow_big_lds(fr_forward_cell<7, 7, 1024, false>, 160 * 1024);
+      allow_big_lds(fr_forward_cell<7, 7, 1024, false, 1>, 160 * 1024);
+      allow_big_lds(fr_forward_cell<7, 7, 1024, false, 2>, 160 * 1024);
+    }
   const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
   FrProfileSlot* ps = g_r3_fr_profile ? fr_profile_next(N, H) : nullptr;
   if (ps) ps->mode = 3;
@@ -1978,101 +1547,41 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// The NCHW backward is a gather over the inverse tap index of the boxes (r3_frb.hip: CSR + SELL-64, whole
+// gradient planes staged in LDS, no atomics, one summation order); shapes it does not take (planes beyond the LDS,
+// no workspace) fall back to the scatter kernels above.
 size_t r3k_fr_backward_workspace_bytes(int N, int H, int W, int points) {
-  if (points != 1 || N <= 0) return 0;
-  if (H == 128 && W == 128) return (size_t)N * FrPack<7, 7>::IMAGE_BYTES;
-  if (H == 64 && W == 64) return (size_t)N * FrPack<6, 6>::IMAGE_BYTES;
-  return 0;
+  if (points != 1 && points != 5) return 0;
+  return r3k_frn_workspace_bytes(N, H, W, points);
 }
 
-// the packing alone (depends on the boxes only: a training step can run it at forward time, off the
-// backward's critical path); -1 when the shape has no packed path
-int r3k_fr_backward_prepare(const float* boxes, int N, int H, int W, float scale, void* ws, size_t ws_bytes,
-                            hipStream_t stream) {
-  const size_t need = r3k_fr_backward_workspace_bytes(N, H, W, 1);
-  if (need == 0 || !boxes || !ws || !aligned16(ws)) return -1;
-  if (ws_bytes < need) return -3;
-  static bool once = (allow_big_lds(fr_bwd_pack_kernel<7, 7>, 160 * 1024), true);
-  (void)once;
-  char* table = static_cast<char*>(ws);
-  if (W == 128) {
-    using P = FrPack<7, 7>;
-    hipLaunchKernelGGL((fr_bwd_pack_kernel<7, 7>), dim3(N), dim3(1024), P::PACK_LDS_INTS * sizeof(int), stream, boxes,
-                       scale, table);
-    hipLaunchKernelGGL((fr_bwd_place_kernel<7, 7>), dim3(P::HW / 256, N), dim3(256), 0, stream, boxes, scale, table);
-  } else {
-    using P = FrPack<6, 6>;
-    hipLaunchKernelGGL((fr_bwd_pack_kernel<6, 6>), dim3(N), dim3(1024), P::PACK_LDS_INTS * sizeof(int), stream, boxes,
-                       scale, table);
-    hipLaunchKernelGGL((fr_bwd_place_kernel<6, 6>), dim3(P::HW / 256, N), dim3(256), 0, stream, boxes, scale, table);
-  }
-  return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
-// table_ready: ws already holds the packing of these boxes (r3k_fr_backward_prepare); the call
-// then fails with -1 instead of taking a path that would ignore it
+// index_ready: ws already holds r3k_frn_index of these boxes; the call then fails with -1 instead of taking a
+// path that would ignore it
 int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W,
                     float scale, int points, float* bottom_grad, int overwrite, void* ws, size_t ws_bytes,
-                    int table_ready, hipStream_t stream) {
+                    int index_ready, hipStream_t stream) {
   if (points != 1 && points != 5) return -1;
   if (N == 0 || C == 0 || H == 0 || W == 0) return 0;
+  const size_t need = r3k_fr_backward_workspace_bytes(N, H, W, points);
+  if (g_r3_fr_impl == 0 && need && ws && ws_bytes >= need && aligned16(ws)) {
+    if (!index_ready) {
+      const int rc = r3k_frn_index(boxes, N, H, W, scale, points, ws, ws_bytes, stream);
+      if (rc) return rc;
+    }
+    const int rc = r3k_frn_gather(top_grad, N, C, H, W, points, bottom_grad, overwrite, ws, ws_bytes, stream);
+    if (rc != -1 || index_ready) return rc;
+  } else if (index_ready) {
+    return -1;
+  }
   int cpb = plane_cpb(C, H, W);
   const bool plane = g_r3_fr_impl != 1 && cpb > 0;
-  {
-    // cell / packed backward (overwrite mode, points = 1, 128 x 128 / 64 x 64): level 0 at N = 4 426 -> 358 / 80 us
-    int G = 1;
-    while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
-    const bool cell_shape = (W == 128 && H == 128) || (W == 64 && H == 64);
-    if ((g_r3_fr_impl == 0 || g_r3_fr_impl == 10) && overwrite && points == 1 && cell_shape && G >= 2 &&
-        aligned16(top_grad) && aligned16(bottom_grad)) {
-      static bool once = (allow_big_lds(fr_backward_cell<7, 7, 1024>, 160 * 1024),
-                          allow_big_lds(fr_backward_cell<7, 7, 1024, 1>, 160 * 1024),
-                          allow_big_lds(fr_backward_cell<7, 7, 1024, 2>, 160 * 1024),
-                          allow_big_lds(fr_backward_cell<7, 7, 1024, 3>, 160 * 1024),
-                          allow_big_lds(fr_backward_packed<7, 7>, 160 * 1024),
-                          true);
-      (void)once;
-      const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
-      const dim3 grid(N * C / G), block(1024);
-      // packed path (no LDS float atomics) when the caller gave a workspace; an image whose box field
-      // it cannot pack is flagged and its workgroups run the atomic kernel's code instead
-      if (ws && ws_bytes >= r3k_fr_backward_workspace_bytes(N, H, W, points) && aligned16(ws) &&
-          g_r3_fr_impl == 0 && g_r3_fr_dbg == 0) {
-        char* table = static_cast<char*>(ws);
-        if (!table_ready) {
-          const int rc = r3k_fr_backward_prepare(boxes, N, H, W, scale, ws, ws_bytes, stream);
-          if (rc) return rc;
-        }
-        if (W == 128)
-          hipLaunchKernelGGL((fr_backward_packed<7, 7>), grid, block, lds, stream, top_grad, table, boxes, scale, C, G,
-                             bottom_grad);
-        else
-          hipLaunchKernelGGL((fr_backward_packed<6, 6>), grid, block, lds, stream, top_grad, table, boxes, scale, C, G,
-                             bottom_grad);
-      } else if (table_ready) {
-        return -1;
-      } else if (W == 128 && g_r3_fr_dbg >= 11 && g_r3_fr_dbg <= 13) {  // probes (wrong results)
-        if (g_r3_fr_dbg == 11) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 1>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad);
-        if (g_r3_fr_dbg == 12) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 2>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad);
-        if (g_r3_fr_dbg == 13) hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024, 3>), grid, block, lds, stream, top_grad, boxes, C, G, scale, bottom_grad);
-      } else if (W == 128)
-        hipLaunchKernelGGL((fr_backward_cell<7, 7, 1024>), grid, block, lds, stream, top_grad, boxes, C, G, scale,
-                           bottom_grad);
-      else
-        hipLaunchKernelGGL((fr_backward_cell<6, 6, 1024>), grid, block, lds, stream, top_grad, boxes, C, G, scale,
-                           bottom_grad);
-      return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
-  }
-  if (table_ready) return -1;  // (no packed path for this call)
   if (plane) {
     while (cpb > 1 && (size_t)N * ((C + cpb - 1) / cpb) < 512) cpb = (cpb + 1) / 2;
     dim3 grid((C + cpb - 1) / cpb, N);
     size_t lds = (size_t)cpb * H * (W + 1) * sizeof(float);
-    static bool once = (allow_big_lds(fr_backward_plane<1, true>, FRP_LDS_FLOATS * 4),
-                        allow_big_lds(fr_backward_plane<1, false>, FRP_LDS_FLOATS * 4),
-                        allow_big_lds(fr_backward_plane<5, false>, FRP_LDS_FLOATS * 4), true);
-    (void)once;
+    allow_big_lds(fr_backward_plane<1, true>, FRP_LDS_FLOATS * 4);
+    allow_big_lds(fr_backward_plane<1, false>, FRP_LDS_FLOATS * 4);
+    allow_big_lds(fr_backward_plane<5, false>, FRP_LDS_FLOATS * 4);
     const bool vec = (W % 4 == 0) && aligned16(top_grad) && aligned16(boxes) && aligned16(bottom_grad);
 #define R3_BWD(P, V) hipLaunchKernelGGL((fr_backward_plane<P, V>), grid, dim3(FRP_BLOCK), lds, stream, top_grad, boxes, C, H, W, scale, cpb, overwrite, bottom_grad)
     if (points == 1) { if (vec) R3_BWD(1, true); else R3_BWD(1, false); }

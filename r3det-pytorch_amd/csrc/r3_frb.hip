@@ -624,6 +624,262 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// NCHW gather (the reference's layout, feature_refine_kernel.cu:165-230): the same sum over the same index,
+// plane by plane.  In NCHW a cell's gradient is one float per plane, and the reference's row <- x_ctr,
+// column <- y_ctr swap puts the sources of a ROW of cells in a COLUMN of the plane: the only access pattern that
+// reads a plane coalesced is the whole plane, so a workgroup stages whole gradient planes in LDS -- CP channels
+// interleaved per cell (8 or 16 bytes: one ds_read serves CP planes and one index entry is amortised over them) --
+// and every lane owns a cell: bottom[q] = top[q] + sum over the entries of q.  The lists come from the inverse tap
+// index re-laid as SELL-64 (frb_sell_kernel): for a slice of 64 consecutive cells the k-th entries of all 64 lists
+// are contiguous, padded to the slice's longest list with {zero cell, weight 0} -- coalesced loads, no per-lane
+// offsets, no divergence inside a slice.  Lists longer than the SELL capacity
+// keep their tail in the CSR array and the owning lane walks it (piles of hundreds of sources on one cell: slow,
+// but exact and in the same fixed order).  No atomics, no zero-fill, one summation order.
+// ------------------------------------------------------------------------------------------------
+constexpr int FRN_T = 1024;  // threads of a gather workgroup (16 wavefronts, K consecutive slices each)
+
+struct FrnLayout {
+  FrbLayout csr;
+  int* slicehdr;  // [N][slices]  padded list length of the slice (multiple of 4, <= cap) | tail flag << 16
+  int4* sell;     // [N][slices][cap / 2][64] two entries {source cell index * 4 (pitch P), weight bits} each
+  int slices, cap, pitch;
+  size_t bytes;
+};
+
+inline int frn_pitch(int W) { return W | 1; }  // odd: the column walk of a regular field hits 64 different banks
+inline int frn_cap(int points) { return points == 1 ? 32 : 96; }
+
+inline FrnLayout frn_layout(void* ws, int N, int H, int W, int points) {
+  FrnLayout L;
+  L.csr = frb_layout(ws, N, H, W, points);
+  L.slices = (H * W + 63) / 64;
+  L.cap = frn_cap(points);
+  L.pitch = frn_pitch(W);
+  const size_t csr = (L.csr.bytes + 255) & ~(size_t)255;
+  const size_t hdr = ((size_t)N * L.slices * sizeof(int) + 255) & ~(size_t)255;
+  L.slicehdr = reinterpret_cast<int*>(static_cast<char*>(ws) + csr);
+  L.sell = reinterpret_cast<int4*>(static_cast<char*>(ws) + csr + hdr);
+  L.bytes = csr + hdr + (size_t)N * L.slices * L.cap * 64 * sizeof(int2);
+  return L;
+}
+
+// CSR -> SELL-64: one wavefront per slice.  Rows are stored in PAIRS -- {cell, weight, cell, weight} of entries 2p and
+// 2p + 1, 16 bytes per lane, 1 KB per wavefront load -- so that a wavefront has twice the bytes in flight per load
+// instruction (the gather is bound by the latency of these loads, not by their number).
+__global__ __launch_bounds__(256) void frb_sell_kernel(const int2* __restrict__ cellinfo, const int2* __restrict__ entries,
+                                                       int HW, int W, int P, int zero_cell, int EPI, int cap, int slices,
+                                                       int* __restrict__ slicehdr, int4* __restrict__ sell) {
+  const int lane = threadIdx.x & 63;
+  const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y;
+  if (slice >= slices) return;
+  const int q = slice * 64 + lane;
+  int2 ci = make_int2(0, 0);
+  if (q < HW) ci = cellinfo[(size_t)n * HW + q];
+  int m = ci.y;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  const int tail = m > cap;
+  const int mp = min(cap, (m + 1) & ~1);
+  if (lane == 0) slicehdr[(size_t)n * slices + slice] = mp | (tail << 16);
+  const int2* en = entries + (size_t)n * EPI + ci.x;
+  int4* out = sell + ((size_t)n * slices + slice) * (cap / 2) * 64 + lane;
+  auto entry = [&](int k) -> int2 {
+    if (k >= ci.y) return make_int2(zero_cell * 4, 0);
+    const int2 e = en[k];
+    const int s = e.x & 0x3ffffff, sy = s / W, sx = s - sy * W;
+    return make_int2((sy * P + sx) * 4, e.y);
+  };
+  for (int k = 0; k < mp; k += 2) {
+    const int2 e0 = entry(k), e1 = entry(k + 1);
+    out[(size_t)(k >> 1) * 64] = make_int4(e0.x, e0.y, e1.x, e1.y);
+  }
+}
+
+template <int CP> struct FrnVec;
+template <> struct FrnVec<1> { typedef float type; };
+template <> struct FrnVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct FrnVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int CP>
+__device__ __forceinline__ float frn_get(const typename FrnVec<CP>::type& v, int c) {
+  if constexpr (CP == 1) return v; else return v[c];
+}
+
+// A wavefront owns K consecutive slices (cells (wave * K + k) * 64 + lane): every wavefront sees all row phases of
+// a periodic field (with slices dealt round-robin the waves of rows 4b + 1, 4b + 2 did all the work of a field
+// whose 4 x 4 blocks regress to one centre), and its slice headers / SELL rows are consecutive in memory.
+template <int K, int CP>
+__global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restrict__ top, const int* __restrict__ slicehdr,
+                                                           const int4* __restrict__ sell,
+                                                           const int2* __restrict__ cellinfo,
+                                                           const int2* __restrict__ entries, int C, int H, int W, int cap,
+                                                           int EPI, int GP, int accum, float* __restrict__ bottom) {
+  typedef typename FrnVec<CP>::type V;
+  extern __shared__ __attribute__((aligned(16))) float frn_lds[];  // [(H * P + 1)][CP]; the last cell stays zero
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int HW = H * W, P = W | 1, slices = (HW + 63) >> 6, hcap = cap >> 1;
+  const int CG = C / CP, gpi = (CG + GP - 1) / GP;  // channel groups; workgroups per image
+  const int n = blockIdx.x / gpi, g0 = (blockIdx.x - n * gpi) * GP, gcount = min(GP, CG - g0);
+  const char* lds_b = reinterpret_cast<const char*>(frn_lds);
+  // LDS index of cell q (q < 2^24: the float quotient is off by at most one)
+  const float invW = 1.f / (float)W;
+  auto own_cell = [&](int q) -> int {
+    int y = (int)((float)q * invW);
+    const int r = q - y * W;
+    y += r < 0 ? -1 : r >= W ? 1 : 0;
+    return q + y * (P - W);
+  };
+  if (tid < CP) frn_lds[(size_t)H * P * CP + tid] = 0.f;
+  const int sl0 = wave * K;  // this wavefront's first slice
+  const int4* sell_n = sell + (size_t)n * slices * hcap * 64 + lane;
+  const size_t plane0 = ((size_t)n * C + (size_t)g0 * CP) * HW;
+  // A group's planes wait in registers while the previous group is gathered (PRE); with more than 32 values per
+  // thread (the big-plane shapes) they are staged in chunks when the LDS is free instead.
+  constexpr bool PRE = K * CP <= 16 || (K * CP <= 32 && CP <= 2 && K <= 16);
+  constexpr int KC = PRE ? K : (16 / CP);  // cells per staging chunk
+  float v[PRE ? K : KC][CP];
+  // (uniform 64-bit base per load + ONE per-lane byte offset: no address registers)
+  const unsigned lane4 = (unsigned)lane * 4u;
+  auto load_chunk = [&](int gi, int k0) {
+    const float* src = top + plane0 + (size_t)gi * CP * HW;
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+      const int qb = (sl0 + k0 + k) * 64;
+#pragma unroll
+      for (int c = 0; c < CP; c++) {
+        const char* pk = reinterpret_cast<const char*>(src + (size_t)c * HW + qb);
+        v[k][c] = qb + lane < HW ? __builtin_nontemporal_load(reinterpret_cast<const float*>(pk + lane4)) : 0.f;
+      }
+    }
+  };
+  auto store_chunk = [&](int k0) {
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+      V t;
+#pragma unroll
+      for (int c = 0; c < CP; c++) {
+        if constexpr (CP == 1) t = v[k][0]; else t[c] = v[k][c];
+      }
+      const int q = (sl0 + k0 + k) * 64 + lane;
+      if (q < HW) *reinterpret_cast<V*>(frn_lds + (size_t)own_cell(q) * CP) = t;
+    }
+  };
+  if (PRE) load_chunk(0, 0);
+  // The slices' padded list lengths, lane i holding slice sl0 + i's (read back with v_readlane: the walk below is
+  // all scalar).  K <= 32.
+  int hv = 0;
+  if (lane < K && sl0 + lane < slices) hv = slicehdr[(size_t)n * slices + sl0 + lane];
+  auto hdr_of = [&](int k) -> int { return __builtin_amdgcn_readlane(hv, k); };
+  // A wavefront's work is ONE stream of batches -- four row pairs (eight entries, 1 KB per load) of a slice; a slice
+  // without entries still has one (empty) batch -- walked by two scalar cursors: the loads run one batch ahead of the
+  // sums, in two register sets that alternate (a `cur = next` copy would wait for the loads it copies, and so did
+  // every load behind a branch: the loads are unconditional, at clamped addresses, and what a batch holds beyond its
+  // slice's length is never looked at).
+  struct B8 { int4 p[4]; };
+  struct Cursor { int k, j, mp; };
+  auto load_batch = [&](const Cursor& c, B8& r) {
+    const int sl = min(sl0 + min(c.k, K - 1), slices - 1);
+    const int4* p = sell_n + ((size_t)sl * hcap) * 64;
+#pragma unroll
+    for (int u = 0; u < 4; u++) r.p[u] = p[min((c.j >> 1) + u, hcap - 1) * 64];
+  };
+  auto advance = [&](Cursor& c) {
+    c.j += 8;
+    if (c.j >= c.mp) {
+      c.k++;
+      c.j = 0;
+      c.mp = c.k < K ? (hdr_of(c.k) & 0xffff) : 0;
+    }
+  };
+  for (int gi = 0; gi < gcount; gi++) {
+    const size_t pl = plane0 + (size_t)gi * CP * HW;
+    if (PRE) {
+      store_chunk(0);
+    } else {
+#pragma unroll 1
+      for (int k0 = 0; k0 < K; k0 += KC) {
+        load_chunk(gi, k0);
+        store_chunk(k0);
+      }
+    }
+    __syncthreads();
+    if (PRE && gi + 1 < gcount) load_chunk(gi + 1, 0);  // in flight while this group is gathered
+    V acc;
+    // one batch of the sums: c = where the batch lies; `pairs` row pairs of it are real
+    auto sum_pairs = [&](const B8& b, auto npairs) {
+      constexpr int NP = decltype(npairs)::value;
+      V g[2 * NP > 0 ? 2 * NP : 1];
+#pragma unroll
+      for (int u = 0; u < NP; u++) {
+        g[2 * u] = *reinterpret_cast<const V*>(lds_b + (unsigned)b.p[u].x * CP);
+        g[2 * u + 1] = *reinterpret_cast<const V*>(lds_b + (unsigned)b.p[u].z * CP);
+      }
+#pragma unroll
+      for (int u = 0; u < NP; u++) {
+        acc += __int_as_float(b.p[u].y) * g[2 * u];
+        acc += __int_as_float(b.p[u].w) * g[2 * u + 1];
+      }
+    };
+    auto step = [&](const B8& b, const Cursor& c) {
+      const int q = (sl0 + c.k) * 64 + lane;
+      if (c.j == 0) {  // first batch of a slice: the cell's own gradient
+        const int ak = q < HW ? own_cell(q) : H * P;
+        acc = *reinterpret_cast<const V*>(frn_lds + (size_t)ak * CP);
+        if (accum && q < HW) {
+#pragma unroll
+          for (int ch = 0; ch < CP; ch++) {
+            const float o = bottom[pl + (size_t)ch * HW + q];
+            if constexpr (CP == 1) acc = o + acc; else acc[ch] = o + acc[ch];
+          }
+        }
+      }
+      const int left = c.mp - c.j;  // rows of the slice from this batch on (even)
+      if (left >= 8) sum_pairs(b, std::integral_constant<int, 4>{});
+      else if (left == 6) sum_pairs(b, std::integral_constant<int, 3>{});
+      else if (left == 4) sum_pairs(b, std::integral_constant<int, 2>{});
+      else if (left == 2) sum_pairs(b, std::integral_constant<int, 1>{});
+      if (left <= 8) {  // last batch of the slice
+        const int hdr = hdr_of(c.k);
+        if (hdr >> 16) {  // lists beyond the SELL capacity: the rest from the CSR array, lane by lane
+          int2 ci = make_int2(0, 0);
+          if (q < HW) ci = cellinfo[(size_t)n * HW + q];
+          const int2* en = entries + (size_t)n * EPI + ci.x;
+          for (int t = cap; t < ci.y; t++) {
+            const int2 e = en[t];
+            const int s = e.x & 0x3ffffff, sy = s / W, sx = s - sy * W;
+            acc += __int_as_float(e.y) * *reinterpret_cast<const V*>(frn_lds + (size_t)(sy * P + sx) * CP);
+          }
+        }
+        if (q < HW) {
+#pragma unroll
+          for (int ch = 0; ch < CP; ch++)
+            __builtin_nontemporal_store(frn_get<CP>(acc, ch), bottom + pl + (size_t)ch * HW + q);
+        }
+      }
+    };
+    Cursor ci, cc;  // loads, sums
+    ci.k = 0, ci.j = 0, ci.mp = hdr_of(0) & 0xffff;
+    cc = ci;
+    B8 A, B;
+    load_batch(ci, A);
+    advance(ci);
+    for (;;) {
+      load_batch(ci, B);
+      advance(ci);
+      step(A, cc);
+      advance(cc);
+      if (cc.k >= K) break;
+      load_batch(ci, A);
+      advance(ci);
+      step(B, cc);
+      advance(cc);
+      if (cc.k >= K) break;
+    }
+    __syncthreads();  // every gather of this group precedes the next group's staging
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename K>
@@ -648,8 +904,8 @@ int r3k_frb_index(const float* boxes, int N, int H, int W, float scale, int poin
   if (ws_bytes < need) return -3;
   const FrbLayout L = frb_layout(ws, N, H, W, points);
   if (points == 1 && W <= IXS_CELLS && (long long)H * W <= (1LL << 22) && g_r3_frb_impl != 1) {
-    static bool once = (allow_big_lds(frb_index_sort_kernel, (int)sizeof(IxsLds)), true);
-    (void)once;
+    static R3DeviceOnce once;
+    if (once.first()) allow_big_lds(frb_index_sort_kernel, (int)sizeof(IxsLds));
     const int R = sort_band_rows(H, W);
     hipLaunchKernelGGL(frb_index_sort_kernel, dim3((H + R - 1) / R, N), dim3(IX_T), sizeof(IxsLds), stream, boxes, scale,
                        H, W, R, L.cellinfo, L.entries, (u64*)nullptr);
@@ -700,4 +956,92 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
   }
 #undef R3_ARGS
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCHW entry points: index (CSR + SELL) and gather
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr size_t FRN_LDS_MAX = 160 * 1024;
+
+// channels interleaved per staged cell: as many as fit the 160 KB of a compute unit next to nothing else
+inline int frn_cp(int C, int H, int W) {
+  const size_t cells = (size_t)H * frn_pitch(W) + 1;
+  for (int cp = 4; cp >= 1; cp >>= 1)
+    if (C % cp == 0 && cells * 4 * cp <= FRN_LDS_MAX) return cp;
+  return 0;
+}
+
+inline int frn_cu_count() { return r3_cu_count(); }
+
+template <int K, int CP>
+inline int frn_launch(const float* top, const FrnLayout& L, int N, int C, int H, int W, int points, int accum, float* bottom,
+                      hipStream_t stream) {
+  const int CG = C / CP;
+  // channel groups per workgroup: as many as still leave one workgroup per compute unit
+  int GP = (int)((long long)N * CG / frn_cu_count());
+  GP = GP < 1 ? 1 : GP > 8 ? 8 : GP;
+  const int gpi = (CG + GP - 1) / GP;
+  const size_t lds = ((size_t)H * L.pitch + 1) * 4 * CP;
+  static R3DeviceOnce once;  // (one per instantiation)
+  if (once.first()) allow_big_lds(frn_gather_kernel<K, CP>, (int)FRN_LDS_MAX);
+  hipLaunchKernelGGL((frn_gather_kernel<K, CP>), dim3((unsigned)(N * gpi)), dim3(FRN_T), lds, stream, top, L.slicehdr, L.sell,
+                     L.csr.cellinfo, L.csr.entries, C, H, W, L.cap, H * W * 4 * points, GP, accum, bottom);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace
+
+// 0: this (shape, C) has no NCHW gather form
+size_t r3k_frn_workspace_bytes(int N, int H, int W, int points) {
+  if (r3k_frb_workspace_bytes(N, H, W, points) == 0 || (long long)H * W > 32 * FRN_T ||
+      ((size_t)H * frn_pitch(W) + 1) * 4 > FRN_LDS_MAX)
+    return 0;
+  return frn_layout(nullptr, N, H, W, points).bytes;
+}
+
+int r3k_frn_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
+                  hipStream_t stream) {
+  const size_t need = r3k_frn_workspace_bytes(N, H, W, points);
+  if (need == 0 || !boxes || !ws || !aligned16(ws)) return -1;
+  if (ws_bytes < need) return -3;
+  const FrnLayout L = frn_layout(ws, N, H, W, points);
+  const int rc = r3k_frb_index(boxes, N, H, W, scale, points, ws, L.csr.bytes, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(frb_sell_kernel, dim3((L.slices + 3) / 4, N), dim3(256), 0, stream, L.csr.cellinfo, L.csr.entries,
+                     H * W, W, L.pitch, H * L.pitch, H * W * 4 * points, L.cap, L.slices, L.slicehdr, L.sell);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// bottom_grad (N, C, H, W) = [bottom_grad +] backward(top_grad) over the index in ws (r3k_frn_index of the boxes)
+int r3k_frn_gather(const float* top_grad, int N, int C, int H, int W, int points, float* bottom_grad, int overwrite,
+                   void* ws, size_t ws_bytes, hipStream_t stream) {
+  const size_t need = r3k_frn_workspace_bytes(N, H, W, points);
+  if (need == 0 || !top_grad || !bottom_grad || !ws || !aligned16(ws) || C <= 0) return -1;
+  if (ws_bytes < need) return -3;
+  const int cp = frn_cp(C, H, W);
+  if (cp == 0) return -1;
+  const FrnLayout L = frn_layout(ws, N, H, W, points);
+  const int cells = H * W, accum = overwrite ? 0 : 1;
+  int k = 1;
+  while (k * FRN_T < cells) k *= 2;
+#define R3_FRN(KK, CC) return frn_launch<KK, CC>(top_grad, L, N, C, H, W, points, accum, bottom_grad, stream)
+  if (cp == 4) {
+    if (k == 1) R3_FRN(1, 4);
+    if (k == 2) R3_FRN(2, 4);
+    if (k == 4) R3_FRN(4, 4);
+    if (k == 8) R3_FRN(8, 4);
+    if (k == 16) R3_FRN(16, 4);
+  } else if (cp == 2) {
+    if (k <= 8) R3_FRN(8, 2);
+    if (k == 16) R3_FRN(16, 2);
+    if (k == 32) R3_FRN(32, 2);
+  } else {
+    if (k <= 8) R3_FRN(8, 1);
+    if (k == 16) R3_FRN(16, 1);
+    if (k == 32) R3_FRN(32, 1);
+  }
+#undef R3_FRN
+  return -1;
 }

@@ -4,6 +4,22 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// Per-device state.  The dynamic-LDS opt-in (hipFuncSetAttribute) belongs to the CURRENT DEVICE's copy of a kernel and
+// the compute-unit count to the device: a process that drives several GPUs (the reference's ops run under
+// MMDataParallel) needs both per device, not per process.
+constexpr int R3_MAX_DEVICES = 64;
+struct R3DeviceOnce {
+  bool done[R3_MAX_DEVICES] = {};
+  bool first() {  // true the first time it is asked on the current device (always, beyond R3_MAX_DEVICES)
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= R3_MAX_DEVICES) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+int r3_cu_count();  // compute units of the current device (r3_api.hip)
+
 // return 0 ok, -1 bad argument, -2 launch failure, -3 workspace too small
 size_t r3k_iou_workspace_bytes(int n1, int n2);
 // ws may be null (single-kernel path); with a workspace the stream + drain pipeline runs
@@ -51,15 +67,18 @@ size_t r3k_fr_workspace_bytes(int N, int H, int W, int points);
 // ws may be null (taps derived per channel plane); with a workspace: tap table + unpack kernel
 int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, int W, float scale,
                    int points, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
-// ws may be null; with r3k_fr_backward_workspace_bytes() of workspace the 128 x 128 / 64 x 64
-// overwrite-mode call runs without LDS float atomics (packed path)
+// ws may be null; with r3k_fr_backward_workspace_bytes() of workspace the call is the gather over the inverse tap
+// index (r3_frb.hip); index_ready: ws holds r3k_frn_index of these boxes
 size_t r3k_fr_backward_workspace_bytes(int N, int H, int W, int points);
 int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W,
                     float scale, int points, float* bottom_grad, int overwrite, void* ws, size_t ws_bytes,
-                    int table_ready, hipStream_t stream);
-// the packing of the boxes alone (then r3k_fr_backward(..., table_ready = 1))
-int r3k_fr_backward_prepare(const float* boxes, int N, int H, int W, float scale, void* ws, size_t ws_bytes,
-                            hipStream_t stream);
+                    int index_ready, hipStream_t stream);
+// NCHW gather backward (r3_frb.hip): index = CSR + SELL-64 of the boxes, then the gather alone
+size_t r3k_frn_workspace_bytes(int N, int H, int W, int points);
+int r3k_frn_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
+                  hipStream_t stream);
+int r3k_frn_gather(const float* top_grad, int N, int C, int H, int W, int points, float* bottom_grad, int overwrite,
+                   void* ws, size_t ws_bytes, hipStream_t stream);
 
 // polygon ops outside the shipped configs (r3_poly.hip)
 int r3k_nms_reduce_dense(const unsigned long long* mask, int n, int cb, const int64_t* order, int64_t* keep_out,

@@ -1392,12 +1392,10 @@ inline int drain_blocks(size_t qcap) {
 inline void launch_reduce(int images, const u64* mask, const u64* side, int n, int cb, const int64_t* order,
                           int64_t* keep_out, int32_t* count_out, const Batch& bt, hipStream_t stream) {
   const size_t lds = reduce_lds_bytes(n > 0 ? n : (int)bt.rows, cb);  // (batched: n = 0, row capacity in bt)
-  static bool raised = false;  // the default cap on dynamic LDS is 64 KB
-  if (lds > 64 * 1024 && !raised) {
+  static R3DeviceOnce raised;  // the default cap on dynamic LDS is 64 KB; the opt-in is per device
+  if (lds > 64 * 1024 && raised.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_rounds_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    raised = true;
-  }
   hipLaunchKernelGGL(nms_reduce_rounds_kernel, dim3(1, 1, images), dim3(RTHREADS), lds, stream, mask, side, n, cb,
                      order, keep_out, count_out, bt);
 }
@@ -1981,12 +1979,10 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     // kernel itself falls back to one workgroup per image when the drain saw an edge between two groups
     const int groups = (cap <= RG_MAXN && g_r3_nms_impl != 2) ? RG_GROUPS : 1;
     const size_t lds = reduce_groups_lds_bytes(cap, L.cb, groups > 1);
-    static bool raised = false;  // the default cap on dynamic LDS is 64 KB
-    if (lds > 64 * 1024 && !raised) {
+    static R3DeviceOnce raised;  // the default cap on dynamic LDS is 64 KB; the opt-in is per device
+    if (lds > 64 * 1024 && raised.first())
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);  // (+ ~300 B static)
-      raised = true;
-    }
     if (lds > 160 * 1024 - 1024) return -1;  // (cap < 65536: 106 KB at most)
     hipLaunchKernelGGL(nms_reduce_groups_kernel, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
                        L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);

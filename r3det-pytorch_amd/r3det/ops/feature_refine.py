@@ -185,7 +185,7 @@ def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, over
     N, C, H, W = g.shape
     with torch.cuda.device(g.device):
         L = _C.lib()
-        wsb = int(L.r3det_fr_backward_workspace_bytes(N, H, W, int(points))) if overwrite else 0
+        wsb = int(L.r3det_fr_backward_workspace_bytes(N, H, W, int(points)))
         ws = torch.empty(wsb, dtype=torch.uint8, device=g.device)
         _C.check(L.r3det_feature_refine_backward_ws(_C.ptr(g), _C.ptr(b), N, C, H, W, float(spatial_scale),
                                                     int(points), _C.ptr(o), int(bool(overwrite)), _C.ptr(ws), wsb,
@@ -236,60 +236,43 @@ def fr_backward_nhwc_index(best_rbboxes, N, H, W, spatial_scale, points=1):
     return ws if _taken(rc, "fr_backward_nhwc_index") else None
 
 
-_pack_streams = {}
-# Sort the backward's positions at forward time on a side stream (split form of the packed backward).
-# Off by default: measured on one MI355X (tools/fr_train_probe.py) the step is 4 us shorter when 3.7 ms
-# of GEMMs sit between the sampler's forward and backward (the pack kernels take 4 CUs from them) and
-# 35 us LONGER when nothing does (events + stream switches on the host).
-PACK_AT_FORWARD = False
 NHWC_ONLY = False  # tests: fail instead of falling back when a channels_last module input does not take the NHWC launch
 
 
-def fr_backward_prepare_async(best_rbboxes, N, H, W, spatial_scale):
-    """The backward's sort of the positions (r3det_feature_refine_backward_prepare) launched on a side
-    stream as soon as the boxes exist: it depends on the boxes only, so a training step gets it off
-    the backward's critical path.  Returns (workspace, event) or None when the shape has no packed
-    backward."""
-    L = _C.lib()
-    wsb = int(L.r3det_fr_backward_workspace_bytes(N, H, W, 1))
-    if wsb == 0:
-        return None
+def fr_backward_index(best_rbboxes, N, H, W, spatial_scale, points=1):
+    """The inverse tap index of one level's boxes for the NCHW backward (r3det_feature_refine_backward_index):
+    depends on the boxes only, so the forward pass builds it (feature_refine_module.py:18-26 saves the boxes
+    there) and the backward proper is the gather alone.  None when the shape has no gather form."""
     b = _C.need_hip(best_rbboxes, "best_bboxes")
-    dev = b.device
-    with torch.cuda.device(dev):
-        side = _pack_streams.get(dev.index)
-        if side is None:
-            side = _pack_streams[dev.index] = torch.cuda.Stream(device=dev)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))  # the boxes are produced on the current stream
-        import ctypes
-        rc = L.r3det_feature_refine_backward_prepare(_C.ptr(b), N, H, W, float(spatial_scale), _C.ptr(ws), wsb,
-                                                     ctypes.c_void_p(side.cuda_stream))
-        if not _taken(rc, "fr_backward_prepare"):
-            return None
-        ev = torch.cuda.Event()
-        ev.record(side)
-        ws.record_stream(side)
-        b.record_stream(side)
-    return ws, ev
+    L = _C.lib()
+    wsb = int(L.r3det_fr_backward_workspace_bytes(N, H, W, int(points)))
+    if wsb == 0 or b.numel() != N * H * W * 5:
+        return None
+    with torch.cuda.device(b.device):
+        ws = torch.empty(wsb, dtype=torch.uint8, device=b.device)
+        rc = L.r3det_feature_refine_backward_index(_C.ptr(b), N, H, W, float(spatial_scale), int(points), _C.ptr(ws),
+                                                   wsb, _C.stream())
+    return ws if _taken(rc, "fr_backward_index") else None
 
 
-def fr_backward_prepared(top_grad, best_rbboxes, spatial_scale, bottom_grad, pack):
-    """Backward accumulate alone on a packing made by ``fr_backward_prepare_async``; False when the
-    library does not take this call in the split form (nothing was launched)."""
-    ws, ev = pack
+def fr_backward_indexed(top_grad, points, bottom_grad, index, overwrite=True):
+    """The gather alone over an index made by ``fr_backward_index`` (r3det_feature_refine_backward_indexed);
+    False when the library has no gather form for this (shape, C): nothing was launched."""
     g = _C.need_hip(top_grad, "top_grad")
+    o = _C.need_hip(bottom_grad, "bottom_grad")
     N, C, H, W = g.shape
+    if o.shape != g.shape:
+        raise RuntimeError("bottom_grad must have top_grad's shape")
     with torch.cuda.device(g.device):
-        torch.cuda.current_stream(g.device).wait_event(ev)
-        rc = _C.lib().r3det_feature_refine_backward_prepared(_C.ptr(g), _C.ptr(best_rbboxes), N, C, H, W,
-                                                             float(spatial_scale), _C.ptr(bottom_grad), _C.ptr(ws),
-                                                             ws.numel(), _C.stream())
-    return _taken(rc, "fr_backward_prepared")
+        rc = _C.lib().r3det_feature_refine_backward_indexed(_C.ptr(g), N, C, H, W, int(points), _C.ptr(o),
+                                                            int(bool(overwrite)), _C.ptr(index), index.numel(),
+                                                            _C.stream())
+    return _taken(rc, "fr_backward_indexed")
 
 
 class FeatureRefineFunction(Function):
-    """autograd wrapper (feature_refine_module.py:10-40); no gradient flows to the boxes."""
+    """autograd wrapper (feature_refine_module.py:10-40); no gradient flows to the boxes.  The backward's index of
+    the boxes is built here in ``forward``, where the boxes are at hand, so ``backward`` is one gather launch."""
 
     @staticmethod
     def forward(ctx, features, best_rbboxes, spatial_scale, points=1, table=None):
@@ -298,23 +281,25 @@ class FeatureRefineFunction(Function):
         ctx.save_for_backward(best_rbboxes)
         assert points in [1, 5]
         assert features.is_cuda
-        ctx.pack = None
+        ctx.index = None
         ctx.nhwc = False
+        N, _, H, W = features.shape
+        boxes = best_rbboxes.contiguous()
         if _is_cl(features):
             # channels_last pipelines (training included): sampler and its backward on (N, H, W, C) memory, no
             # layout switch around them
             output = torch.empty_like(features)  # (preserves channels_last)
-            if fr_forward_nhwc(features, best_rbboxes.contiguous(), spatial_scale, points, output):
+            if fr_forward_nhwc(features, boxes, spatial_scale, points, output):
                 ctx.nhwc = True
+                if ctx.needs_input_grad[0]:
+                    ctx.index = fr_backward_nhwc_index(boxes, N, H, W, spatial_scale, points)
                 return output
         features = features.contiguous()
         output = torch.empty_like(features)  # the kernel overwrites every element
         if table is None or not fr_forward_prepared(features, table, output):
-            fr_forward(features, best_rbboxes.contiguous(), spatial_scale, points, output)
-        if PACK_AT_FORWARD and points == 1 and ctx.needs_input_grad[0]:
-            N, _, H, W = features.shape
-            ctx.boxes_c = best_rbboxes.contiguous()
-            ctx.pack = fr_backward_prepare_async(ctx.boxes_c, N, H, W, spatial_scale)
+            fr_forward(features, boxes, spatial_scale, points, output)
+        if ctx.needs_input_grad[0]:
+            ctx.index = fr_backward_index(boxes, N, H, W, spatial_scale, points)
         return output
 
     @staticmethod
@@ -328,12 +313,11 @@ class FeatureRefineFunction(Function):
                 g = grad_output.contiguous(memory_format=torch.channels_last)
                 grad_input = torch.empty_like(g)
                 if fr_backward_nhwc(g, best_rbboxes.contiguous(), ctx.spatial_scale, ctx.points, grad_input,
-                                    overwrite=True):
+                                    overwrite=True, index=ctx.index):
                     return grad_input, None, None, None, None
             grad_output = grad_output.contiguous()
             grad_input = torch.empty_like(grad_output)
-            if ctx.pack is None or not fr_backward_prepared(grad_output, ctx.boxes_c, ctx.spatial_scale, grad_input,
-                                                            ctx.pack):
+            if ctx.nhwc or ctx.index is None or not fr_backward_indexed(grad_output, ctx.points, grad_input, ctx.index):
                 fr_backward(grad_output, best_rbboxes.contiguous(), ctx.spatial_scale, ctx.points, grad_input,
                             overwrite=True)
         return grad_input, None, None, None, None
@@ -395,7 +379,9 @@ class FeatureRefineModule(nn.Module):
         nhwc = [no_grad and is_cl(f) for f in x]
         # tap tables of the NCHW levels first: each sampler call below is then a single launch with no
         # dependent launch in front of it (the channels_last launch derives its taps from the boxes itself)
-        tables = [None if cl else fr_prepare(b, f.size(0), f.size(2), f.size(3), fr.spatial_scale, fr.points)
+        # (channels_last training levels take the NHWC sampler, which needs no table either)
+        tables = [None if cl or (is_cl(f) and not no_grad)
+                  else fr_prepare(b, f.size(0), f.size(2), f.size(3), fr.spatial_scale, fr.points)
                   for f, b, fr, cl in zip(x, per_level, self.fr, nhwc)]
         out = []
         for feat, boxes, fr, table, cl in zip(x, per_level, self.fr, tables, nhwc):

@@ -1,7 +1,7 @@
 """GPU parity: Feature Refinement forward / backward through the C ABI vs the oracle.
-Forward: bit-exact vs the twin oracle (tolerance bar of north_star is 1e-5).  Backward sums
-floating-point atomics in nondeterministic order => tolerance 1e-5 relative to the gradient
-scale, written below."""
+Forward: bit-exact vs the twin oracle (tolerance bar of north_star is 1e-5).  Backward: the library sums a cell's
+contributions in its own fixed order (gather over the inverse tap index), the oracle in the reference's loop order
+=> tolerance 1e-5 relative to the gradient scale, written below; run to run the library's results are bit-identical."""
 import numpy as np
 import pytest
 import torch
@@ -45,7 +45,7 @@ def test_forward_bit_exact(impl, shape, points, adversarial):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("shape", SHAPES[:5])
+@pytest.mark.parametrize("shape", SHAPES[:9])
 @pytest.mark.parametrize("points", [1, 5])
 def test_backward(impl, shape, points):
     from r3det.ops.feature_refine import fr_backward
@@ -92,9 +92,10 @@ def test_cell_kernel_long_channel_runs(shape):
 @pytest.mark.parametrize("shape", [(1, 512, 128, 128, 8), (1, 1024, 128, 128, 8), (2, 512, 64, 64, 16),
                                    (3, 512, 64, 64, 16)])
 @pytest.mark.parametrize("adversarial", [False, True])
-def test_backward_cell_kernel(shape, adversarial):
-    """The channel-group backward kernel (overwrite mode; G = 2, 4 channels per workgroup) against the
-    oracle and against the plane kernel; tolerance as in test_backward (atomics sum in any order)."""
+def test_backward_gather_full_channel_counts(shape, adversarial):
+    """The NCHW gather at the model's channel counts (two / four interleaved channels per staged cell, one to four
+    channel groups per workgroup: the register-prefetched steady state) against the oracle and against the
+    LDS-atomic plane kernel; twice: bit-identical run to run."""
     from r3det import _C
     from r3det.ops.feature_refine import fr_backward
     N, C, H, W, stride = shape
@@ -107,6 +108,9 @@ def test_backward_cell_kernel(shape, adversarial):
     g = torch.full((N, C, H, W), float('nan'), device='cuda')
     fr_backward(dev(top), dev(boxes), 1 / stride, 1, g, overwrite=True)
     assert np.abs(g[:, :8].cpu().numpy() - want).max() <= tol
+    again = torch.full((N, C, H, W), float('nan'), device='cuda')
+    fr_backward(dev(top), dev(boxes), 1 / stride, 1, again, overwrite=True)
+    assert torch.equal(g, again)
     _C.set_option("fr_impl", 2)
     g2 = torch.empty_like(g)
     fr_backward(dev(top), dev(boxes), 1 / stride, 1, g2, overwrite=True)
@@ -116,11 +120,10 @@ def test_backward_cell_kernel(shape, adversarial):
 
 @pytest.mark.parametrize("shape", [(2, 512, 128, 128, 8), (2, 512, 64, 64, 16)])
 @pytest.mark.parametrize("pile", [2, 9, 10, 16, 17, 300, -1])
-def test_backward_packed_runs_and_fallback(shape, pile):
-    """The packed backward (no LDS atomics) sorts positions by sampled cell and takes runs up to 16
-    (128 x 128) / 9 (64 x 64) positions per cell; an image with a longer run is handed to the atomic
-    code by the same launch.  `pile` positions of image 1 sample one cell (-1: every position of it),
-    image 0 keeps its regular field: both paths in one call, against the oracle."""
+def test_backward_piles_of_sources_on_one_cell(shape, pile):
+    """`pile` positions of image 1 sample one cell (-1: every position of it), image 0 keeps its regular field.
+    Lists up to the SELL capacity (32 entries) are summed from the slice layout, longer ones finish from the CSR
+    array lane by lane: both in one call, against the oracle."""
     from r3det.ops.feature_refine import fr_backward
     N, C, H, W, stride = shape
     r = np.random.default_rng(pile + 100)
@@ -214,9 +217,9 @@ def test_gradcheck_against_oracle_backward():
         feature_refine(x, dev(boxes), 1 / stride, 3)  # points must be 1 or 5
 
 
-def test_backward_ws_too_small_or_absent_uses_the_atomic_kernel():
-    """r3det_feature_refine_backward_ws with no / a short workspace must not touch it and still
-    give the gradient (the LDS-atomic kernel runs)."""
+def test_backward_ws_too_small_or_absent_uses_the_scatter_kernel():
+    """r3det_feature_refine_backward_ws with no / a short workspace must not touch it and still give the gradient
+    (the LDS-atomic plane kernel runs)."""
     from r3det import _C
     L = _C.lib()
     N, C, H, W, stride = 1, 512, 64, 64, 16
@@ -228,8 +231,10 @@ def test_backward_ws_too_small_or_absent_uses_the_atomic_kernel():
     tol = 1e-5 * max(1.0, np.abs(want).max())
     t, b = dev(top), dev(boxes)
     need = int(L.r3det_fr_backward_workspace_bytes(N, H, W, 1))
-    assert need > 0 and int(L.r3det_fr_backward_workspace_bytes(N, 32, 32, 1)) == 0
-    assert int(L.r3det_fr_backward_workspace_bytes(N, H, W, 5)) == 0
+    assert need > 0 and int(L.r3det_fr_backward_workspace_bytes(N, 32, 32, 1)) > 0
+    assert int(L.r3det_fr_backward_workspace_bytes(N, H, W, 5)) > need
+    assert int(L.r3det_fr_backward_workspace_bytes(N, 256, 256, 1)) == 0      # a plane beyond the LDS
+    assert int(L.r3det_fr_backward_workspace_bytes(N, H, W, 3)) == 0
     guard = torch.full((need,), 7, dtype=torch.uint8, device='cuda')
     for ws_ptr, ws_bytes in ((None, 0), (_C.ptr(guard), need - 16)):
         g = torch.full((N, C, H, W), float('nan'), device='cuda')
@@ -239,37 +244,47 @@ def test_backward_ws_too_small_or_absent_uses_the_atomic_kernel():
     assert bool((guard == 7).all())
 
 
-@pytest.mark.parametrize("shape", [(2, 512, 128, 128, 8), (2, 512, 64, 64, 16), (1, 8, 64, 64, 16), (2, 16, 32, 32, 32)])
-def test_autograd_backward_uses_packing_from_forward(shape):
-    """With PACK_AT_FORWARD feature_refine(x.requires_grad) sorts the positions on a side stream during the
-    forward and the backward consumes that workspace (split form); shapes / channel counts without a packed path
-    fall back inside the same function.  Gradient against the oracle either way."""
-    import sys
-    from r3det.ops.feature_refine import feature_refine
-    monkey = sys.modules['r3det.ops.feature_refine']
+@pytest.mark.parametrize("shape", [(2, 512, 128, 128, 8), (2, 512, 64, 64, 16), (1, 8, 64, 64, 16), (2, 16, 32, 32, 32),
+                                   (1, 6, 100, 167, 8), (1, 3, 150, 200, 8), (1, 2, 256, 256, 8)])
+@pytest.mark.parametrize("points", [1, 5])
+def test_autograd_backward_uses_the_index_from_forward(shape, points):
+    """feature_refine(x.requires_grad) builds the backward's index of the boxes in the forward pass (split form:
+    r3det_feature_refine_backward_index / _indexed); the backward is the gather alone.  Planes beyond the gather's
+    limits fall back inside the same function.  Gradient against the oracle either way; the C-ABI calls directly:
+    the split form == the one-call form, bit for bit, and argument errors are refused."""
+    from r3det import _C
+    from r3det.ops.feature_refine import feature_refine, fr_backward, fr_backward_index, fr_backward_indexed
     N, C, H, W, stride = shape
-    monkey.PACK_AT_FORWARD = True
-    try:
-        _autograd_with_packing(feature_refine, N, C, H, W, stride)
-    finally:
-        monkey.PACK_AT_FORWARD = False
-
-
-def _autograd_with_packing(feature_refine, N, C, H, W, stride):
     r = np.random.default_rng(5)
     x = dev(r.normal(size=(N, C, H, W)).astype(np.float32)).requires_grad_(True)
     top = r.normal(size=(N, C, H, W)).astype(np.float32)
     boxes = fr_boxes(N, H, W, stride, 9)
-    y = feature_refine(x, dev(boxes), 1 / stride, 1)
-    expect_pack = (H, W) in ((128, 128), (64, 64))
-    assert (y.grad_fn.pack is not None) == expect_pack
+    y = feature_refine(x, dev(boxes), 1 / stride, points)
+    assert (y.grad_fn.index is not None) == (H * W <= 32768)
     y.backward(dev(top))
+    nc = min(C, 4)
     with O.twin():
-        want = O.fr_backward(top[:, :4], boxes, 1 / stride, 1)
-    assert np.abs(x.grad[:, :4].cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
-    # no gradient wanted: no packing
-    y2 = feature_refine(x.detach(), dev(boxes), 1 / stride, 1)
+        want = O.fr_backward(top[:, :nc], boxes, 1 / stride, points)
+    assert np.abs(x.grad[:, :nc].cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    # no gradient wanted: no index
+    y2 = feature_refine(x.detach(), dev(boxes), 1 / stride, points)
     assert y2.grad_fn is None and torch.equal(y2, y.detach())
+    if H * W > 32768:
+        assert fr_backward_index(dev(boxes), N, H, W, 1 / stride, points) is None
+        return
+    index = fr_backward_index(dev(boxes), N, H, W, 1 / stride, points)
+    g1 = torch.full((N, C, H, W), float('nan'), device='cuda')
+    assert fr_backward_indexed(dev(top), points, g1, index)
+    g2 = torch.full((N, C, H, W), float('nan'), device='cuda')
+    fr_backward(dev(top), dev(boxes), 1 / stride, points, g2, overwrite=True)
+    assert torch.equal(g1, g2) and torch.equal(g1, x.grad)
+    L = _C.lib()
+    t = dev(top)
+    args = (_C.ptr(t), N, C, H, W, points, _C.ptr(g1), 1)
+    assert L.r3det_feature_refine_backward_indexed(*args, _C.ptr(index), index.numel() - 16, _C.stream()) == -3
+    assert L.r3det_feature_refine_backward_indexed(*args, None, 0, _C.stream()) == -1
+    assert L.r3det_feature_refine_backward_indexed(_C.ptr(t), N, C, H, W, 3, _C.ptr(g1), 1, _C.ptr(index),
+                                                   index.numel(), _C.stream()) == -1
 
 
 @pytest.mark.parametrize("points", [1, 5])

@@ -1,7 +1,8 @@
 """FR backward at the BASELINE training / inference shapes, both layouts, on rotating buffers (beyond the Infinity
 Cache) -- the driver for `rocprofv3 --kernel-trace` / PMC passes of the backward kernels:
   NHWC: r3det_feature_refine_backward_nhwc (frb_index_kernel + frb_gather_kernel)
-  NCHW: r3det_feature_refine_backward_ws  (fr_bwd_pack + fr_bwd_place + fr_backward_packed)
+  NCHW: r3det_feature_refine_backward_ws  (frb_index_sort_kernel + frb_sell_kernel + frn_gather_kernel), and the
+        gather alone on an index built ahead (r3det_feature_refine_backward_indexed: what a training step runs)
 FR_BWD_LEVEL (0), FR_BWD_N (4), FR_BWD_FIELD=regular|adversarial|trained."""
 import os
 import sys
@@ -12,7 +13,8 @@ for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
 import torch  # noqa: E402
 
 from r3det import synthetic as syn  # noqa: E402
-from r3det.ops.feature_refine import fr_backward, fr_backward_nhwc  # noqa: E402
+from r3det.ops.feature_refine import (fr_backward, fr_backward_index, fr_backward_indexed, fr_backward_nhwc,  # noqa: E402
+                                      fr_backward_nhwc_index)
 
 dev = torch.device("cuda")
 level, N, C = int(os.environ.get("FR_BWD_LEVEL", 0)), int(os.environ.get("FR_BWD_N", 4)), 256
@@ -47,6 +49,10 @@ def timed(name, fn, sets):
 
 
 timed("fr_backward_nhwc (index + gather)", lambda g, o: fr_backward_nhwc(g, boxes, 1.0 / stride, 1, o, overwrite=True), sets_cl)
+ix = fr_backward_nhwc_index(boxes, N, H, H, 1.0 / stride, 1)
+timed("fr_backward_nhwc (gather alone)", lambda g, o: fr_backward_nhwc(g, None, 1.0 / stride, 1, o, overwrite=True, index=ix), sets_cl)
 del sets_cl
 sets = [tuple(torch.randn(N, C, H, H, device=dev) for _ in range(2)) for _ in range(nset)]
-timed("fr_backward NCHW (pack + accumulate)", lambda g, o: fr_backward(g, boxes, 1.0 / stride, 1, o, overwrite=True), sets)
+timed("fr_backward NCHW (index + gather)", lambda g, o: fr_backward(g, boxes, 1.0 / stride, 1, o, overwrite=True), sets)
+ix = fr_backward_index(boxes, N, H, H, 1.0 / stride, 1)
+timed("fr_backward NCHW (gather alone)", lambda g, o: fr_backward_indexed(g, 1, o, ix), sets)
