@@ -343,11 +343,12 @@ int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bb
 
 /* Split form of the call above: the index depends on the boxes only, so a training step builds it when the
  * forward pass has the boxes (feature_refine_module.py:18-26 saves them for the backward) and the backward proper
- * is the gather alone.  _index: R3DET_EINVAL when the shape has no workspace path.  _indexed: same N, H, W, points
- * and workspace as the _index call; R3DET_EINVAL when this (shape, C) has no gather form (then use
- * r3det_feature_refine_backward). */
-int r3det_feature_refine_backward_index(const float* best_bboxes, int N, int H, int W, float spatial_scale, int points,
-                                        void* ws, size_t ws_bytes, void* stream);
+ * is the gather alone.  _index takes the channel count of the gradient it is for (C decides how many channels the
+ * gather interleaves per staged cell, and the index entries carry offsets of that layout): R3DET_EINVAL when the
+ * (shape, C) has no gather form (then use r3det_feature_refine_backward).  _indexed: same N, C, H, W, points and
+ * workspace as the _index call. */
+int r3det_feature_refine_backward_index(const float* best_bboxes, int N, int C, int H, int W, float spatial_scale,
+                                        int points, void* ws, size_t ws_bytes, void* stream);
 int r3det_feature_refine_backward_indexed(const float* top_grad, int N, int C, int H, int W, int points,
                                           float* bottom_grad, int overwrite, void* ws, size_t ws_bytes, void* stream);
 

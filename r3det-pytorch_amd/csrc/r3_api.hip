@@ -312,10 +312,10 @@ int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bb
                             overwrite, ws, ws_bytes, 0, S(stream)));
 }
 
-int r3det_feature_refine_backward_index(const float* best_bboxes, int N, int H, int W, float spatial_scale, int points,
-                                        void* ws, size_t ws_bytes, void* stream) {
-  if (N <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
-  return rc(r3k_frn_index(best_bboxes, N, H, W, spatial_scale, points, ws, ws_bytes, S(stream)));
+int r3det_feature_refine_backward_index(const float* best_bboxes, int N, int C, int H, int W, float spatial_scale,
+                                        int points, void* ws, size_t ws_bytes, void* stream) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
+  return rc(r3k_frn_index(best_bboxes, N, C, H, W, spatial_scale, points, ws, ws_bytes, S(stream)));
 }
 
 int r3det_feature_refine_backward_indexed(const float* top_grad, int N, int C, int H, int W, int points,
@@ -399,6 +399,8 @@ int r3det_set_option(const char* name, int value) {
   else if (!strcmp(name, "fr_walk")) g_r3_fr_walk = value < 0 ? 0 : value > 1024 ? 1024 : value;
   else if (!strcmp(name, "fr_profile")) g_r3_fr_profile = value;
   else if (!strcmp(name, "frb_impl")) g_r3_frb_impl = value;
+  else if (!strcmp(name, "frn_stamps_lo")) g_r3_frn_stamps = (g_r3_frn_stamps & 0xffffffff00000000ull) | (unsigned)value;
+  else if (!strcmp(name, "frn_stamps_hi")) g_r3_frn_stamps = (g_r3_frn_stamps & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32);
   else if (!strcmp(name, "iou_impl")) g_r3_iou_impl = value;
   else if (!strcmp(name, "iou_small")) g_r3_iou_small = value;
   else if (!strcmp(name, "iou_qcap")) g_r3_iou_qcap = value;

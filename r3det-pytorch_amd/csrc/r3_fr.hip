@@ -1565,7 +1565,7 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
   const size_t need = r3k_fr_backward_workspace_bytes(N, H, W, points);
   if (g_r3_fr_impl == 0 && need && ws && ws_bytes >= need && aligned16(ws)) {
     if (!index_ready) {
-      const int rc = r3k_frn_index(boxes, N, H, W, scale, points, ws, ws_bytes, stream);
+      const int rc = r3k_frn_index(boxes, N, C, H, W, scale, points, ws, ws_bytes, stream);
       if (rc) return rc;
     }
     const int rc = r3k_frn_gather(top_grad, N, C, H, W, points, bottom_grad, overwrite, ws, ws_bytes, stream);

@@ -28,6 +28,7 @@
 //           tiles' gradient rows are shared through LDS, so most entries are one LDS read instead of a row
 //           load, and the second use of every row meets the first in the same compute unit.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <type_traits>
 #include <hip/hip_ext.h>
 
@@ -630,69 +631,107 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
 // column <- y_ctr swap puts the sources of a ROW of cells in a COLUMN of the plane: the only access pattern that
 // reads a plane coalesced is the whole plane, so a workgroup stages whole gradient planes in LDS -- CP channels
 // interleaved per cell (8 or 16 bytes: one ds_read serves CP planes and one index entry is amortised over them) --
-// and every lane owns a cell: bottom[q] = top[q] + sum over the entries of q.  The lists come from the inverse tap
-// index re-laid as SELL-64 (frb_sell_kernel): for a slice of 64 consecutive cells the k-th entries of all 64 lists
-// are contiguous, padded to the slice's longest list with {zero cell, weight 0} -- coalesced loads, no per-lane
-// offsets, no divergence inside a slice.  Lists longer than the SELL capacity
-// keep their tail in the CSR array and the owning lane walks it (piles of hundreds of sources on one cell: slow,
-// but exact and in the same fixed order).  No atomics, no zero-fill, one summation order.
+// and every lane owns a cell: bottom[q] = top[q] + sum over the entries of q.
+// The lists come from the inverse tap index re-laid as SELL-64 (frb_sell_kernel): for a slice of 64 consecutive
+// cells the k-th entries of all 64 lists are contiguous, padded to the slice's longest list with {zero cell,
+// weight 0} -- coalesced loads, no per-lane offsets, no divergence inside a slice -- and the slices of a wavefront
+// (K consecutive ones) are ONE packed stream of 4 KB batches, so that the gather's loads run ahead of its sums with
+// nothing but a pointer increment.  Lists longer than the SELL capacity keep their tail in the CSR array and the
+// owning lane walks it (piles of hundreds of sources on one cell: slow, but exact and in the same fixed order).
+// No atomics, no zero-fill, one summation order.
+// What shaped it (rocprofv3 PMC on the first working version, 46 us at level 0, N = 4): the SIMDs issued
+// instructions 27 % of the time and half of those were scalar -- cursors over (slice, row), clamps, 64-bit address
+// products -- with 2.5 k vector instructions per wavefront of which the sums were a third; every load behind a
+// branch, and every `current = next` register copy, made the compiler wait for the load right there.
 // ------------------------------------------------------------------------------------------------
-constexpr int FRN_T = 1024;  // threads of a gather workgroup (16 wavefronts, K consecutive slices each)
+constexpr int FRN_T = 1024;  // threads of a gather workgroup: 16 wavefronts, K consecutive slices each
 
 struct FrnLayout {
   FrbLayout csr;
-  int* slicehdr;  // [N][slices]  padded list length of the slice (multiple of 4, <= cap) | tail flag << 16
-  int4* sell;     // [N][slices][cap / 2][64] two entries {source cell index * 4 (pitch P), weight bits} each
-  int slices, cap, pitch;
+  int* slicehdr;  // [N][slices]  padded list length of the slice (even, <= cap) | tail flag << 16
+  int4* sell;     // [N][slices][cap / 8 batches][4 row pairs][64 lanes] {weight, cell byte offset} x 2 (+ 1 batch)
+  int slices, cap, pitch, K, cp;
   size_t bytes;
 };
 
 inline int frn_pitch(int W) { return W | 1; }  // odd: the column walk of a regular field hits 64 different banks
 inline int frn_cap(int points) { return points == 1 ? 32 : 96; }
+constexpr size_t FRN_LDS_MAX = 160 * 1024;
+constexpr size_t FRN_TAB_BYTES = 16 * 128 * 4;  // the wavefronts' batch lists behind the plane
 
-inline FrnLayout frn_layout(void* ws, int N, int H, int W, int points) {
+// channels interleaved per staged cell (as many as fit the 160 KB of a compute unit) and slices per wavefront;
+// only the (K, CP) pairs the gather is instantiated for
+inline bool frn_config(int C, int H, int W, int& K, int& cp) {
+  const size_t cells = (size_t)H * frn_pitch(W) + 1;
+  const long long HW = (long long)H * W;
+  if (C <= 0 || HW > 32 * FRN_T) return false;
+  cp = 0;
+  for (int c = 4; c >= 1; c >>= 1)
+    if (C % c == 0 && cells * 4 * c + FRN_TAB_BYTES <= FRN_LDS_MAX) {
+      cp = c;
+      break;
+    }
+  if (cp == 0) return false;
+  K = 1;
+  while ((long long)K * FRN_T < HW) K *= 2;
+  if (cp < 4 && K < 8) K = 8;
+  return true;
+}
+
+inline FrnLayout frn_layout(void* ws, int N, int C, int H, int W, int points) {
   FrnLayout L;
   L.csr = frb_layout(ws, N, H, W, points);
   L.slices = (H * W + 63) / 64;
   L.cap = frn_cap(points);
   L.pitch = frn_pitch(W);
+  L.K = 1, L.cp = 1;
+  frn_config(C, H, W, L.K, L.cp);
   const size_t csr = (L.csr.bytes + 255) & ~(size_t)255;
   const size_t hdr = ((size_t)N * L.slices * sizeof(int) + 255) & ~(size_t)255;
   L.slicehdr = reinterpret_cast<int*>(static_cast<char*>(ws) + csr);
   L.sell = reinterpret_cast<int4*>(static_cast<char*>(ws) + csr + hdr);
-  L.bytes = csr + hdr + (size_t)N * L.slices * L.cap * 64 * sizeof(int2);
+  // (+ 1 batch: the gather's loads run one batch ahead of its sums)
+  L.bytes = csr + hdr + ((size_t)N * L.slices * (L.cap / 8) + 1) * 4096;
   return L;
 }
 
-// CSR -> SELL-64: one wavefront per slice.  Rows are stored in PAIRS -- {cell, weight, cell, weight} of entries 2p and
-// 2p + 1, 16 bytes per lane, 1 KB per wavefront load -- so that a wavefront has twice the bytes in flight per load
-// instruction (the gather is bound by the latency of these loads, not by their number).
+// One slice's rows from the CSR lists of its 64 cells (one wavefront): rows in PAIRS -- {weight, cell, weight, cell}
+// of entries 2p and 2p + 1, 16 bytes per lane, 1 KB per wavefront load; a batch is four row pairs; a slice's batches
+// lie at a fixed stride.  ascale = 4 * CP: the entry carries the byte offset of the source cell in the gather's LDS
+// plane.  Lists are padded to the slice's longest (rounded up to even) with {zero cell, weight 0}.
+__device__ __forceinline__ void frb_sell_slice(const int2* __restrict__ cellinfo_n, const int2* __restrict__ entries_n,
+                                               int slice, int lane, int HW, int W, int P, int zero_cell, int ascale,
+                                               int cap, int* __restrict__ slicehdr_n, int4* __restrict__ sell_n) {
+  const int q = slice * 64 + lane;
+  int2 ci = make_int2(0, 0);
+  if (q < HW) ci = cellinfo_n[q];
+  int m = ci.y;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  const int mp = min(cap, (m + 1) & ~1);
+  if (lane == 0) slicehdr_n[slice] = mp | ((m > cap) << 16);
+  const int2* en = entries_n + ci.x;
+  int4* out = sell_n + (size_t)slice * (cap >> 3) * 256 + lane;
+  auto entry = [&](int e) -> int2 {
+    if (e >= ci.y) return make_int2(zero_cell * ascale, 0);
+    const int2 v = en[e];
+    const int s = v.x & 0x3ffffff, sy = s / W, sx = s - sy * W;
+    return make_int2((sy * P + sx) * ascale, v.y);
+  };
+  for (int e = 0; e < mp; e += 2) {
+    const int2 e0 = entry(e), e1 = entry(e + 1);
+    out[(size_t)(e >> 1) * 64] = make_int4(e0.y, e0.x, e1.y, e1.x);
+  }
+}
+
+// CSR -> SELL-64 as a launch of its own (planes whose bands the index kernels do not re-lay themselves)
 __global__ __launch_bounds__(256) void frb_sell_kernel(const int2* __restrict__ cellinfo, const int2* __restrict__ entries,
-                                                       int HW, int W, int P, int zero_cell, int EPI, int cap, int slices,
-                                                       int* __restrict__ slicehdr, int4* __restrict__ sell) {
+                                                       int HW, int W, int P, int zero_cell, int ascale, int EPI, int cap,
+                                                       int slices, int* __restrict__ slicehdr, int4* __restrict__ sell) {
   const int lane = threadIdx.x & 63;
   const int slice = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y;
   if (slice >= slices) return;
-  const int q = slice * 64 + lane;
-  int2 ci = make_int2(0, 0);
-  if (q < HW) ci = cellinfo[(size_t)n * HW + q];
-  int m = ci.y;
-  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-  const int tail = m > cap;
-  const int mp = min(cap, (m + 1) & ~1);
-  if (lane == 0) slicehdr[(size_t)n * slices + slice] = mp | (tail << 16);
-  const int2* en = entries + (size_t)n * EPI + ci.x;
-  int4* out = sell + ((size_t)n * slices + slice) * (cap / 2) * 64 + lane;
-  auto entry = [&](int k) -> int2 {
-    if (k >= ci.y) return make_int2(zero_cell * 4, 0);
-    const int2 e = en[k];
-    const int s = e.x & 0x3ffffff, sy = s / W, sx = s - sy * W;
-    return make_int2((sy * P + sx) * 4, e.y);
-  };
-  for (int k = 0; k < mp; k += 2) {
-    const int2 e0 = entry(k), e1 = entry(k + 1);
-    out[(size_t)(k >> 1) * 64] = make_int4(e0.x, e0.y, e1.x, e1.y);
-  }
+  frb_sell_slice(cellinfo + (size_t)n * HW, entries + (size_t)n * EPI, slice, lane, HW, W, P, zero_cell, ascale, cap,
+                 slicehdr + (size_t)n * slices, sell + (size_t)n * slices * (cap >> 3) * 256);
 }
 
 template <int CP> struct FrnVec;
@@ -707,24 +746,41 @@ __device__ __forceinline__ float frn_get(const typename FrnVec<CP>::type& v, int
 
 // A wavefront owns K consecutive slices (cells (wave * K + k) * 64 + lane): every wavefront sees all row phases of
 // a periodic field (with slices dealt round-robin the waves of rows 4b + 1, 4b + 2 did all the work of a field
-// whose 4 x 4 blocks regress to one centre), and its slice headers / SELL rows are consecutive in memory.
+// whose 4 x 4 blocks regress to one centre).  A workgroup owns ONE group of CP channels of one image: the plane
+// loads of a second group, requested while the first is gathered, sit in front of every index load in the
+// wavefront's in-order memory queue -- the gather then waits for all of them before its first sum (measured: two
+// groups per workgroup took exactly twice one).
+typedef unsigned int frn_u4 __attribute__((ext_vector_type(4)));
+
 template <int K, int CP>
 __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restrict__ top, const int* __restrict__ slicehdr,
                                                            const int4* __restrict__ sell,
                                                            const int2* __restrict__ cellinfo,
-                                                           const int2* __restrict__ entries, int C, int H, int W, int cap,
-                                                           int EPI, int GP, int accum, float* __restrict__ bottom) {
+                                                           const int2* __restrict__ entries, int C, int H, int W,
+                                                           int wshift, int cap, int EPI, int accum, int xcd,
+                                                           float* __restrict__ bottom,
+                                                           unsigned long long* __restrict__ stamps) {
   typedef typename FrnVec<CP>::type V;
+  // (clock stamps of wavefront 0 at the phase boundaries: tools/frn_stamps.py)
+  auto stamp = [&](int i) {
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();  // (100 MHz, one clock for the chip)
+  };
+  stamp(0);
   extern __shared__ __attribute__((aligned(16))) float frn_lds[];  // [(H * P + 1)][CP]; the last cell stays zero
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int HW = H * W, P = W | 1, slices = (HW + 63) >> 6, hcap = cap >> 1;
-  const int CG = C / CP, gpi = (CG + GP - 1) / GP;  // channel groups; workgroups per image
-  const int n = blockIdx.x / gpi, g0 = (blockIdx.x - n * gpi) * GP, gcount = min(GP, CG - g0);
-  const char* lds_b = reinterpret_cast<const char*>(frn_lds);
-  // LDS index of cell q (q < 2^24: the float quotient is off by at most one)
+  const int HW = H * W, P = W | 1, slices = (HW + 63) >> 6, BPS = cap >> 3;
+  const int CG = C / CP;  // channel groups = workgroups per image
+  // workgroups of one image on as few XCDs as possible (blockIdx & 7 = XCD under round-robin dispatch): an XCD's L2
+  // then holds the index of one or two images instead of streaming all of them
+  unsigned bid = blockIdx.x;
+  if ((xcd & 1) && (gridDim.x & 7) == 0) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+  const int n = (int)bid / CG, g0 = (int)bid - n * CG;
+  // LDS index of cell q: a shift for the power-of-two widths of a pyramid; else by the float quotient (q < 2^24:
+  // off by at most one)
   const float invW = 1.f / (float)W;
   auto own_cell = [&](int q) -> int {
+    if (wshift >= 0) return q + (q >> wshift);  // (P = W + 1)
     int y = (int)((float)q * invW);
     const int r = q - y * W;
     y += r < 0 ? -1 : r >= W ? 1 : 0;
@@ -732,151 +788,188 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
   };
   if (tid < CP) frn_lds[(size_t)H * P * CP + tid] = 0.f;
   const int sl0 = wave * K;  // this wavefront's first slice
-  const int4* sell_n = sell + (size_t)n * slices * hcap * 64 + lane;
-  const size_t plane0 = ((size_t)n * C + (size_t)g0 * CP) * HW;
-  // A group's planes wait in registers while the previous group is gathered (PRE); with more than 32 values per
-  // thread (the big-plane shapes) they are staged in chunks when the LDS is free instead.
-  constexpr bool PRE = K * CP <= 16 || (K * CP <= 32 && CP <= 2 && K <= 16);
-  constexpr int KC = PRE ? K : (16 / CP);  // cells per staging chunk
-  float v[PRE ? K : KC][CP];
-  // (uniform 64-bit base per load + ONE per-lane byte offset: no address registers)
-  const unsigned lane4 = (unsigned)lane * 4u;
-  auto load_chunk = [&](int gi, int k0) {
-    const float* src = top + plane0 + (size_t)gi * CP * HW;
+  const int kend = min(K, slices - sl0);  // (<= 0: a wavefront beyond the map)
+  const size_t pl = ((size_t)n * C + (size_t)g0 * CP) * HW;
+  // Every memory operation below goes through a buffer descriptor (scalar base + bounds), a scalar offset and ONE
+  // per-lane offset register: no per-access address arithmetic in the vector unit (the first version of this kernel
+  // spent two thirds of its 2.1 k vector instructions per wavefront on 64-bit addresses, exec-mask bookkeeping of
+  // bounds tests and register copies); a lane beyond the plane reads 0 and its store is dropped by the bounds check.
+  __amdgpu_buffer_rsrc_t rtop[CP], rbot[CP];
 #pragma unroll
-    for (int k = 0; k < KC; k++) {
-      const int qb = (sl0 + k0 + k) * 64;
-#pragma unroll
-      for (int c = 0; c < CP; c++) {
-        const char* pk = reinterpret_cast<const char*>(src + (size_t)c * HW + qb);
-        v[k][c] = qb + lane < HW ? __builtin_nontemporal_load(reinterpret_cast<const float*>(pk + lane4)) : 0.f;
-      }
-    }
-  };
-  auto store_chunk = [&](int k0) {
-#pragma unroll
-    for (int k = 0; k < KC; k++) {
-      V t;
-#pragma unroll
-      for (int c = 0; c < CP; c++) {
-        if constexpr (CP == 1) t = v[k][0]; else t[c] = v[k][c];
-      }
-      const int q = (sl0 + k0 + k) * 64 + lane;
-      if (q < HW) *reinterpret_cast<V*>(frn_lds + (size_t)own_cell(q) * CP) = t;
-    }
-  };
-  if (PRE) load_chunk(0, 0);
-  // The slices' padded list lengths, lane i holding slice sl0 + i's (read back with v_readlane: the walk below is
-  // all scalar).  K <= 32.
+  for (int c = 0; c < CP; c++) {
+    rtop[c] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(top + pl + (size_t)c * HW), 0, HW * 4, 0x00020000);
+    rbot[c] = __builtin_amdgcn_make_buffer_rsrc(bottom + pl + (size_t)c * HW, 0, HW * 4, 0x00020000);
+  }
+  const __amdgpu_buffer_rsrc_t rsell = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int4*>(sell + (size_t)n * slices * BPS * 256), 0, (slices * BPS + 1) * 4096, 0x00020000);
+  const int lane4 = lane * 4, lane16 = lane * 16;
+  // the slices' padded list lengths, lane i holding slice sl0 + i's (read back with v_readlane: the walk below is
+  // all scalar); K <= 32
   int hv = 0;
-  if (lane < K && sl0 + lane < slices) hv = slicehdr[(size_t)n * slices + sl0 + lane];
-  auto hdr_of = [&](int k) -> int { return __builtin_amdgcn_readlane(hv, k); };
-  // A wavefront's work is ONE stream of batches -- four row pairs (eight entries, 1 KB per load) of a slice; a slice
-  // without entries still has one (empty) batch -- walked by two scalar cursors: the loads run one batch ahead of the
-  // sums, in two register sets that alternate (a `cur = next` copy would wait for the loads it copies, and so did
-  // every load behind a branch: the loads are unconditional, at clamped addresses, and what a batch holds beyond its
-  // slice's length is never looked at).
-  struct B8 { int4 p[4]; };
-  struct Cursor { int k, j, mp; };
-  auto load_batch = [&](const Cursor& c, B8& r) {
-    const int sl = min(sl0 + min(c.k, K - 1), slices - 1);
-    const int4* p = sell_n + ((size_t)sl * hcap) * 64;
-#pragma unroll
-    for (int u = 0; u < 4; u++) r.p[u] = p[min((c.j >> 1) + u, hcap - 1) * 64];
-  };
-  auto advance = [&](Cursor& c) {
-    c.j += 8;
-    if (c.j >= c.mp) {
-      c.k++;
-      c.j = 0;
-      c.mp = c.k < K ? (hdr_of(c.k) & 0xffff) : 0;
-    }
-  };
-  for (int gi = 0; gi < gcount; gi++) {
-    const size_t pl = plane0 + (size_t)gi * CP * HW;
-    if (PRE) {
-      store_chunk(0);
-    } else {
+  if (lane < kend) hv = slicehdr[(size_t)n * slices + sl0 + lane];
+  {  // staging: the group's planes, channels interleaved per cell (KC cells per round)
+    constexpr int KC = K * CP <= 32 ? (K < 16 ? K : 16) : 16 / CP;
 #pragma unroll 1
-      for (int k0 = 0; k0 < K; k0 += KC) {
-        load_chunk(gi, k0);
-        store_chunk(k0);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+      float v[KC][CP];
+      const int so = (sl0 + k0) * 256;
+#pragma unroll
+      for (int k = 0; k < KC; k++)
+#pragma unroll
+        for (int c = 0; c < CP; c++)
+          v[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rtop[c], lane4 + k * 256, so, 2));
+#pragma unroll
+      for (int k = 0; k < KC; k++) {
+        V t;
+#pragma unroll
+        for (int c = 0; c < CP; c++) {
+          if constexpr (CP == 1) t = v[k][0]; else t[c] = v[k][c];
+        }
+        const int q = (sl0 + k0 + k) * 64 + lane;
+        if (q < HW) *reinterpret_cast<V*>(frn_lds + (size_t)own_cell(q) * CP) = t;
       }
     }
+  }
+  stamp(1);
+  __syncthreads();
+  stamp(2);
+  if (kend <= 0) return;
+  // The wavefront's batches (four row pairs = eight entries per lane, 4 KB; a slice without entries still has one,
+  // never looked at) are listed ONCE, by a scalar walk over the slices, in two registers -- lane t: the t-th batch's
+  // offset and what the sums need to know about it -- so that the loop proper is: v_readlane, four loads two batches
+  // AHEAD of the sums (unconditional, into register sets that rotate: a `current = next` copy would wait for the loads
+  // it copies, and so did every load behind a branch), the sums.  The first version walked (slice, row) cursors on
+  // both sides: 50 scalar instructions per batch, and a compute unit issues ONE scalar instruction per cycle for all
+  // its wavefronts (PMC: 9.7 M scalar instructions per launch = 16 us of a 44 us kernel).
+  struct B8 { frn_u4 p[4]; };
+  int seq_so = 0, seq_f = 0;
+  // Listing the batches is vector work, once per wavefront (as a scalar walk it was 25 scalar instructions per
+  // batch): lane k < kend = slice k, a prefix sum of the batch counts over the lanes, every slice writes its (at most
+  // cap / 8) batches at their places of a small LDS table behind the plane, lane t reads entry t back.  More than 64
+  // batches (very long lists): window after window.
+  const int nbv = lane < kend ? max(1, ((hv & 0xffff) + 7) >> 3) : 0;
+  int startv = nbv;  // inclusive prefix over the lanes ...
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int up = __shfl_up(startv, o);
+    if (lane >= o) startv += up;
+  }
+  const int total_all = __builtin_amdgcn_readlane(startv, kend - 1);
+  startv -= nbv;  // ... exclusive
+  int* seq_tab = reinterpret_cast<int*>(frn_lds + ((size_t)H * P + 1) * CP) + wave * 128;
+  auto build = [&](int w0) -> int {  // the batches [w0, w0 + 64) of the wavefront; returns how many there are
+    const int mp = hv & 0xffff;
+    for (int b = 0; b < BPS; b++) {
+      const int idx = startv + b - w0;
+      if (b < nbv && idx >= 0 && idx < 64) {
+        const int left = mp - 8 * b;
+        const int np = left >= 8 ? 4 : (left >> 1);
+        seq_tab[idx] = ((sl0 + lane) * BPS + b) * 4096;
+        seq_tab[64 + idx] = np | ((b == 0) << 3) | ((b == nbv - 1) << 4) | (lane << 8);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = min(64, total_all - w0);
+    seq_so = lane < cnt ? seq_tab[lane] : 0;
+    seq_f = lane < cnt ? seq_tab[64 + lane] : 0;
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+  };
+  auto load_batch = [&](int t, B8& r) {  // (t beyond the list: some batch again)
+    const int so = __builtin_amdgcn_readlane(seq_so, t & 63);
+    const int np = __builtin_amdgcn_readlane(seq_f, t & 63) & 7;  // (only the batch's real row pairs: 1 KB each)
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (u < np) r.p[u] = __builtin_amdgcn_raw_buffer_load_b128(rsell, lane16 + u * 1024, so, 0);
+  };
+  // (the dynamic LDS starts at 0 -- no static __shared__ here -- so a byte offset IS the LDS address: without this
+  // the compiler adds the base, a `v_add 0`, in front of every ds_read)
+  typedef const V __attribute__((address_space(3))) * LdsV;
+  V acc;
+  auto fma_v = [&](float w, const V& g) {  // (one rounding per term instead of two: inside the backward's tolerance)
+    if constexpr (CP == 1) acc = __builtin_fmaf(w, g, acc);
+    else acc = __builtin_elementwise_fma(V(w), g, acc);
+  };
+  auto sum_pairs = [&](const B8& b, auto npairs) {
+    constexpr int NP = decltype(npairs)::value;
+    constexpr int UB = CP == 4 ? 2 : 4;  // row pairs whose rows are requested from the LDS together (registers)
+#pragma unroll
+    for (int u0 = 0; u0 < NP; u0 += UB) {
+      V g[2 * UB];
+#pragma unroll
+      for (int u = u0; u < NP && u < u0 + UB; u++) {
+        g[2 * (u - u0)] = *reinterpret_cast<LdsV>((uintptr_t)b.p[u].y);
+        g[2 * (u - u0) + 1] = *reinterpret_cast<LdsV>((uintptr_t)b.p[u].w);
+      }
+#pragma unroll
+      for (int u = u0; u < NP && u < u0 + UB; u++) {
+        // (__uint_as_float: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+        fma_v(__uint_as_float(b.p[u].x), g[2 * (u - u0)]);
+        fma_v(__uint_as_float(b.p[u].z), g[2 * (u - u0) + 1]);
+      }
+    }
+  };
+  // one batch of the sums; f: its entry of the list
+  const int sl0_256 = sl0 * 256, zero_b = H * P * 4 * CP;
+  auto step = [&](const B8& b, const int f) {
+    const int np = f & 7;
+    const int so = sl0_256 + (f & 0x7fffff00);  // byte offset of the slice in a plane
+    if (f & 8) {  // first batch of a slice: the cell's own gradient (the zero cell beyond the map)
+      const int q = (so >> 2) + lane;
+      acc = *reinterpret_cast<LdsV>((uintptr_t)min(own_cell(q) * (4 * CP), zero_b));
+      if (accum) {
+#pragma unroll
+        for (int ch = 0; ch < CP; ch++) {
+          const float o = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbot[ch], lane4, so, 0));
+          if constexpr (CP == 1) acc = o + acc; else acc[ch] = o + acc[ch];
+        }
+      }
+    }
+    if (np == 4) sum_pairs(b, std::integral_constant<int, 4>{});
+    else if (np == 3) sum_pairs(b, std::integral_constant<int, 3>{});
+    else if (np == 2) sum_pairs(b, std::integral_constant<int, 2>{});
+    else if (np == 1) sum_pairs(b, std::integral_constant<int, 1>{});
+    if (!(f & 16)) return;
+    // last batch of the slice
+    if (__builtin_amdgcn_readlane(hv, f >> 8) >> 16) {  // lists beyond the SELL capacity: the rest from the CSR array
+      const int q = (so >> 2) + lane;
+      int2 ci = make_int2(0, 0);
+      if (q < HW) ci = cellinfo[(size_t)n * HW + q];
+      const int2* en = entries + (size_t)n * EPI + ci.x;
+      for (int t = cap; t < ci.y; t++) {
+        const int2 e = en[t];
+        const int s = e.x & 0x3ffffff, sy = s / W, sx = s - sy * W;
+        fma_v(__int_as_float(e.y), *reinterpret_cast<const V*>(frn_lds + (size_t)(sy * P + sx) * CP));
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < CP; ch++)
+    {
+      const unsigned bits = __builtin_bit_cast(unsigned, frn_get<CP>(acc, ch));
+      __builtin_amdgcn_raw_buffer_store_b32(bits, rbot[ch], lane4, so, 2);
+    }
+  };
+  for (int w0 = 0; w0 < total_all; w0 += 64) {  // (one window unless lists are very long)
+    const int total = build(w0);
+    B8 A, B, D;
+    load_batch(0, A);
+    load_batch(1, B);
+#pragma unroll 1
+    for (int t = 0; t < total; t += 3) {  // (three sets: two batches in flight behind the one being summed)
+      load_batch(t + 2, D);
+      step(A, __builtin_amdgcn_readlane(seq_f, t));
+      load_batch(t + 3, A);
+      if (t + 1 < total) step(B, __builtin_amdgcn_readlane(seq_f, (t + 1) & 63));
+      load_batch(t + 4, B);
+      if (t + 2 < total) step(D, __builtin_amdgcn_readlane(seq_f, (t + 2) & 63));
+    }
+  }
+  stamp(3);
+  if (stamps) {
+    __builtin_amdgcn_s_waitcnt(0);
+    stamp(4);
     __syncthreads();
-    if (PRE && gi + 1 < gcount) load_chunk(gi + 1, 0);  // in flight while this group is gathered
-    V acc;
-    // one batch of the sums: c = where the batch lies; `pairs` row pairs of it are real
-    auto sum_pairs = [&](const B8& b, auto npairs) {
-      constexpr int NP = decltype(npairs)::value;
-      V g[2 * NP > 0 ? 2 * NP : 1];
-#pragma unroll
-      for (int u = 0; u < NP; u++) {
-        g[2 * u] = *reinterpret_cast<const V*>(lds_b + (unsigned)b.p[u].x * CP);
-        g[2 * u + 1] = *reinterpret_cast<const V*>(lds_b + (unsigned)b.p[u].z * CP);
-      }
-#pragma unroll
-      for (int u = 0; u < NP; u++) {
-        acc += __int_as_float(b.p[u].y) * g[2 * u];
-        acc += __int_as_float(b.p[u].w) * g[2 * u + 1];
-      }
-    };
-    auto step = [&](const B8& b, const Cursor& c) {
-      const int q = (sl0 + c.k) * 64 + lane;
-      if (c.j == 0) {  // first batch of a slice: the cell's own gradient
-        const int ak = q < HW ? own_cell(q) : H * P;
-        acc = *reinterpret_cast<const V*>(frn_lds + (size_t)ak * CP);
-        if (accum && q < HW) {
-#pragma unroll
-          for (int ch = 0; ch < CP; ch++) {
-            const float o = bottom[pl + (size_t)ch * HW + q];
-            if constexpr (CP == 1) acc = o + acc; else acc[ch] = o + acc[ch];
-          }
-        }
-      }
-      const int left = c.mp - c.j;  // rows of the slice from this batch on (even)
-      if (left >= 8) sum_pairs(b, std::integral_constant<int, 4>{});
-      else if (left == 6) sum_pairs(b, std::integral_constant<int, 3>{});
-      else if (left == 4) sum_pairs(b, std::integral_constant<int, 2>{});
-      else if (left == 2) sum_pairs(b, std::integral_constant<int, 1>{});
-      if (left <= 8) {  // last batch of the slice
-        const int hdr = hdr_of(c.k);
-        if (hdr >> 16) {  // lists beyond the SELL capacity: the rest from the CSR array, lane by lane
-          int2 ci = make_int2(0, 0);
-          if (q < HW) ci = cellinfo[(size_t)n * HW + q];
-          const int2* en = entries + (size_t)n * EPI + ci.x;
-          for (int t = cap; t < ci.y; t++) {
-            const int2 e = en[t];
-            const int s = e.x & 0x3ffffff, sy = s / W, sx = s - sy * W;
-            acc += __int_as_float(e.y) * *reinterpret_cast<const V*>(frn_lds + (size_t)(sy * P + sx) * CP);
-          }
-        }
-        if (q < HW) {
-#pragma unroll
-          for (int ch = 0; ch < CP; ch++)
-            __builtin_nontemporal_store(frn_get<CP>(acc, ch), bottom + pl + (size_t)ch * HW + q);
-        }
-      }
-    };
-    Cursor ci, cc;  // loads, sums
-    ci.k = 0, ci.j = 0, ci.mp = hdr_of(0) & 0xffff;
-    cc = ci;
-    B8 A, B;
-    load_batch(ci, A);
-    advance(ci);
-    for (;;) {
-      load_batch(ci, B);
-      advance(ci);
-      step(A, cc);
-      advance(cc);
-      if (cc.k >= K) break;
-      load_batch(ci, A);
-      advance(ci);
-      step(B, cc);
-      advance(cc);
-      if (cc.k >= K) break;
-    }
-    __syncthreads();  // every gather of this group precedes the next group's staging
+    stamp(5);
   }
 }
 
@@ -889,7 +982,9 @@ inline void allow_big_lds(K kernel, int bytes) {
 
 }  // namespace
 
-int g_r3_frb_impl = 0;  // 0 auto; 1: the general index form whatever the shape; 2: unpaired gather (A/B runs, tests)
+int g_r3_frb_impl = 0;
+unsigned long long g_r3_frn_stamps = 0;  // device address of a stamp buffer (probes), 0 = none
+  // 0 auto; 1: the general index form whatever the shape; 2: unpaired gather (A/B runs, tests)
 
 size_t r3k_frb_workspace_bytes(int N, int H, int W, int points) {
   if (N <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5) || W > IX_MAXCELLS || (long long)H * W > (1LL << 26)) return 0;
@@ -963,85 +1058,61 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr size_t FRN_LDS_MAX = 160 * 1024;
-
-// channels interleaved per staged cell: as many as fit the 160 KB of a compute unit next to nothing else
-inline int frn_cp(int C, int H, int W) {
-  const size_t cells = (size_t)H * frn_pitch(W) + 1;
-  for (int cp = 4; cp >= 1; cp >>= 1)
-    if (C % cp == 0 && cells * 4 * cp <= FRN_LDS_MAX) return cp;
-  return 0;
-}
-
-inline int frn_cu_count() { return r3_cu_count(); }
-
 template <int K, int CP>
 inline int frn_launch(const float* top, const FrnLayout& L, int N, int C, int H, int W, int points, int accum, float* bottom,
                       hipStream_t stream) {
-  const int CG = C / CP;
-  // channel groups per workgroup: as many as still leave one workgroup per compute unit
-  int GP = (int)((long long)N * CG / frn_cu_count());
-  GP = GP < 1 ? 1 : GP > 8 ? 8 : GP;
-  const int gpi = (CG + GP - 1) / GP;
-  const size_t lds = ((size_t)H * L.pitch + 1) * 4 * CP;
+  const size_t lds = ((size_t)H * L.pitch + 1) * 4 * CP + FRN_TAB_BYTES;
   static R3DeviceOnce once;  // (one per instantiation)
   if (once.first()) allow_big_lds(frn_gather_kernel<K, CP>, (int)FRN_LDS_MAX);
-  hipLaunchKernelGGL((frn_gather_kernel<K, CP>), dim3((unsigned)(N * gpi)), dim3(FRN_T), lds, stream, top, L.slicehdr, L.sell,
-                     L.csr.cellinfo, L.csr.entries, C, H, W, L.cap, H * W * 4 * points, GP, accum, bottom);
+  int wshift = -1;
+  if ((W & (W - 1)) == 0)
+    for (wshift = 0; (1 << wshift) < W; wshift++) {}
+  hipLaunchKernelGGL((frn_gather_kernel<K, CP>), dim3((unsigned)(N * (C / CP))), dim3(FRN_T), lds, stream, top, L.slicehdr,
+                     L.sell, L.csr.cellinfo, L.csr.entries, C, H, W, wshift, L.cap, H * W * 4 * points, accum,
+                     g_r3_frb_impl >= 4 ? (g_r3_frb_impl - 4) : 1, bottom,
+                     reinterpret_cast<unsigned long long*>(g_r3_frn_stamps));
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 }  // namespace
 
-// 0: this (shape, C) has no NCHW gather form
+// 0: this shape has no NCHW gather form (for any C)
 size_t r3k_frn_workspace_bytes(int N, int H, int W, int points) {
-  if (r3k_frb_workspace_bytes(N, H, W, points) == 0 || (long long)H * W > 32 * FRN_T ||
-      ((size_t)H * frn_pitch(W) + 1) * 4 > FRN_LDS_MAX)
-    return 0;
-  return frn_layout(nullptr, N, H, W, points).bytes;
+  int K, cp;
+  if (r3k_frb_workspace_bytes(N, H, W, points) == 0 || !frn_config(1, H, W, K, cp)) return 0;
+  return frn_layout(nullptr, N, 1, H, W, points).bytes;
 }
 
-int r3k_frn_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
+// the index of the boxes for gradients of C channels (C decides how many channels the gather interleaves, and the
+// entries carry byte offsets of that layout)
+int r3k_frn_index(const float* boxes, int N, int C, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
                   hipStream_t stream) {
   const size_t need = r3k_frn_workspace_bytes(N, H, W, points);
-  if (need == 0 || !boxes || !ws || !aligned16(ws)) return -1;
+  int K, cp;
+  if (need == 0 || !boxes || !ws || !aligned16(ws) || !frn_config(C, H, W, K, cp)) return -1;
   if (ws_bytes < need) return -3;
-  const FrnLayout L = frn_layout(ws, N, H, W, points);
+  const FrnLayout L = frn_layout(ws, N, C, H, W, points);
   const int rc = r3k_frb_index(boxes, N, H, W, scale, points, ws, L.csr.bytes, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(frb_sell_kernel, dim3((L.slices + 3) / 4, N), dim3(256), 0, stream, L.csr.cellinfo, L.csr.entries,
-                     H * W, W, L.pitch, H * L.pitch, H * W * 4 * points, L.cap, L.slices, L.slicehdr, L.sell);
+                     H * W, W, L.pitch, H * L.pitch, 4 * L.cp, H * W * 4 * points, L.cap, L.slices, L.slicehdr, L.sell);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// bottom_grad (N, C, H, W) = [bottom_grad +] backward(top_grad) over the index in ws (r3k_frn_index of the boxes)
+// bottom_grad (N, C, H, W) = [bottom_grad +] backward(top_grad) over the index in ws (r3k_frn_index for this C)
 int r3k_frn_gather(const float* top_grad, int N, int C, int H, int W, int points, float* bottom_grad, int overwrite,
                    void* ws, size_t ws_bytes, hipStream_t stream) {
   const size_t need = r3k_frn_workspace_bytes(N, H, W, points);
-  if (need == 0 || !top_grad || !bottom_grad || !ws || !aligned16(ws) || C <= 0) return -1;
+  int K, cp;
+  if (need == 0 || !top_grad || !bottom_grad || !ws || !aligned16(ws) || !frn_config(C, H, W, K, cp)) return -1;
   if (ws_bytes < need) return -3;
-  const int cp = frn_cp(C, H, W);
-  if (cp == 0) return -1;
-  const FrnLayout L = frn_layout(ws, N, H, W, points);
-  const int cells = H * W, accum = overwrite ? 0 : 1;
-  int k = 1;
-  while (k * FRN_T < cells) k *= 2;
-#define R3_FRN(KK, CC) return frn_launch<KK, CC>(top_grad, L, N, C, H, W, points, accum, bottom_grad, stream)
-  if (cp == 4) {
-    if (k == 1) R3_FRN(1, 4);
-    if (k == 2) R3_FRN(2, 4);
-    if (k == 4) R3_FRN(4, 4);
-    if (k == 8) R3_FRN(8, 4);
-    if (k == 16) R3_FRN(16, 4);
-  } else if (cp == 2) {
-    if (k <= 8) R3_FRN(8, 2);
-    if (k == 16) R3_FRN(16, 2);
-    if (k == 32) R3_FRN(32, 2);
-  } else {
-    if (k <= 8) R3_FRN(8, 1);
-    if (k == 16) R3_FRN(16, 1);
-    if (k == 32) R3_FRN(32, 1);
-  }
+  const FrnLayout L = frn_layout(ws, N, C, H, W, points);
+  const int accum = overwrite ? 0 : 1;
+#define R3_FRN(KK, CC) \
+  if (K == KK && cp == CC) return frn_launch<KK, CC>(top_grad, L, N, C, H, W, points, accum, bottom_grad, stream)
+  R3_FRN(1, 4); R3_FRN(2, 4); R3_FRN(4, 4); R3_FRN(8, 4); R3_FRN(16, 4);
+  R3_FRN(8, 2); R3_FRN(16, 2); R3_FRN(32, 2);
+  R3_FRN(8, 1); R3_FRN(16, 1); R3_FRN(32, 1);
 #undef R3_FRN
   return -1;
 }

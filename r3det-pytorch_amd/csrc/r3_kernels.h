@@ -75,7 +75,7 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
                     int index_ready, hipStream_t stream);
 // NCHW gather backward (r3_frb.hip): index = CSR + SELL-64 of the boxes, then the gather alone
 size_t r3k_frn_workspace_bytes(int N, int H, int W, int points);
-int r3k_frn_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
+int r3k_frn_index(const float* boxes, int N, int C, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
                   hipStream_t stream);
 int r3k_frn_gather(const float* top_grad, int N, int C, int H, int W, int points, float* bottom_grad, int overwrite,
                    void* ws, size_t ws_bytes, hipStream_t stream);
@@ -147,6 +147,7 @@ extern int g_r3_fr_profile;
 extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane, 3/4 tap-table, 5/6 persistent
 extern int g_r3_fr_dbg;    // ablation bits for the persistent forward kernel
 extern int g_r3_fr_walk;   // strip height of the tile-pair walk (0: row-major)
+extern unsigned long long g_r3_frn_stamps;
 extern int g_r3_frb_impl;  // 0 auto; 1 general index form always; 2 unpaired gather
 extern int g_r3_iou_impl;  // 0 auto, 1 one thread per pair, 2 one-launch compact kernel, 4 prep + stream + drain pipeline always
 extern int g_r3_iou_dwgs;  // 0 default (2048); > 0: workgroups of the IoU drain kernel (tuning)

@@ -51,7 +51,7 @@ SIGNATURES = {
     "r3det_feature_refine_module_prepared": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "r3det_feature_refine_backward": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp],
     "r3det_feature_refine_backward_ws": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _sz, _vp],
-    "r3det_feature_refine_backward_index": [_vp, _i, _i, _i, _f, _i, _vp, _sz, _vp],
+    "r3det_feature_refine_backward_index": [_vp, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp],
     "r3det_feature_refine_backward_indexed": [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
     "r3det_feature_refine_backward_nhwc": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _sz, _vp],
     "r3det_feature_refine_backward_nhwc_index": [_vp, _i, _i, _i, _f, _i, _vp, _sz, _vp],

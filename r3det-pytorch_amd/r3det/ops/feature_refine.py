@@ -239,10 +239,11 @@ def fr_backward_nhwc_index(best_rbboxes, N, H, W, spatial_scale, points=1):
 NHWC_ONLY = False  # tests: fail instead of falling back when a channels_last module input does not take the NHWC launch
 
 
-def fr_backward_index(best_rbboxes, N, H, W, spatial_scale, points=1):
-    """The inverse tap index of one level's boxes for the NCHW backward (r3det_feature_refine_backward_index):
-    depends on the boxes only, so the forward pass builds it (feature_refine_module.py:18-26 saves the boxes
-    there) and the backward proper is the gather alone.  None when the shape has no gather form."""
+def fr_backward_index(best_rbboxes, N, C, H, W, spatial_scale, points=1):
+    """The inverse tap index of one level's boxes for the NCHW backward of an (N, C, H, W) gradient
+    (r3det_feature_refine_backward_index): depends on the boxes only, so the forward pass builds it
+    (feature_refine_module.py:18-26 saves the boxes there) and the backward proper is the gather alone.  None when
+    the shape has no gather form."""
     b = _C.need_hip(best_rbboxes, "best_bboxes")
     L = _C.lib()
     wsb = int(L.r3det_fr_backward_workspace_bytes(N, H, W, int(points)))
@@ -250,8 +251,8 @@ def fr_backward_index(best_rbboxes, N, H, W, spatial_scale, points=1):
         return None
     with torch.cuda.device(b.device):
         ws = torch.empty(wsb, dtype=torch.uint8, device=b.device)
-        rc = L.r3det_feature_refine_backward_index(_C.ptr(b), N, H, W, float(spatial_scale), int(points), _C.ptr(ws),
-                                                   wsb, _C.stream())
+        rc = L.r3det_feature_refine_backward_index(_C.ptr(b), N, C, H, W, float(spatial_scale), int(points),
+                                                   _C.ptr(ws), wsb, _C.stream())
     return ws if _taken(rc, "fr_backward_index") else None
 
 
@@ -283,7 +284,7 @@ class FeatureRefineFunction(Function):
         assert features.is_cuda
         ctx.index = None
         ctx.nhwc = False
-        N, _, H, W = features.shape
+        N, C, H, W = features.shape
         boxes = best_rbboxes.contiguous()
         if _is_cl(features):
             # channels_last pipelines (training included): sampler and its backward on (N, H, W, C) memory, no
@@ -299,7 +300,7 @@ class FeatureRefineFunction(Function):
         if table is None or not fr_forward_prepared(features, table, output):
             fr_forward(features, boxes, spatial_scale, points, output)
         if ctx.needs_input_grad[0]:
-            ctx.index = fr_backward_index(boxes, N, H, W, spatial_scale, points)
+            ctx.index = fr_backward_index(boxes, N, C, H, W, spatial_scale, points)
         return output
 
     @staticmethod

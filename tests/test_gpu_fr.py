@@ -270,9 +270,9 @@ def test_autograd_backward_uses_the_index_from_forward(shape, points):
     y2 = feature_refine(x.detach(), dev(boxes), 1 / stride, points)
     assert y2.grad_fn is None and torch.equal(y2, y.detach())
     if H * W > 32768:
-        assert fr_backward_index(dev(boxes), N, H, W, 1 / stride, points) is None
+        assert fr_backward_index(dev(boxes), N, C, H, W, 1 / stride, points) is None
         return
-    index = fr_backward_index(dev(boxes), N, H, W, 1 / stride, points)
+    index = fr_backward_index(dev(boxes), N, C, H, W, 1 / stride, points)
     g1 = torch.full((N, C, H, W), float('nan'), device='cuda')
     assert fr_backward_indexed(dev(top), points, g1, index)
     g2 = torch.full((N, C, H, W), float('nan'), device='cuda')

@@ -54,5 +54,5 @@ timed("fr_backward_nhwc (gather alone)", lambda g, o: fr_backward_nhwc(g, None, 
 del sets_cl
 sets = [tuple(torch.randn(N, C, H, H, device=dev) for _ in range(2)) for _ in range(nset)]
 timed("fr_backward NCHW (index + gather)", lambda g, o: fr_backward(g, boxes, 1.0 / stride, 1, o, overwrite=True), sets)
-ix = fr_backward_index(boxes, N, H, H, 1.0 / stride, 1)
+ix = fr_backward_index(boxes, N, C, H, H, 1.0 / stride, 1)
 timed("fr_backward NCHW (gather alone)", lambda g, o: fr_backward_indexed(g, 1, o, ix), sets)
