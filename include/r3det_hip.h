@@ -352,6 +352,23 @@ int r3det_feature_refine_backward_index(const float* best_bboxes, int N, int C, 
 int r3det_feature_refine_backward_indexed(const float* top_grad, int N, int C, int H, int W, int points,
                                           float* bottom_grad, int overwrite, void* ws, size_t ws_bytes, void* stream);
 
+/* The backward of ALL pyramid levels of one FeatureRefineModule pass (fr/feature_refine_module.py:108-127 runs the
+ * sampler level by level; its autograd graph then calls feature_refine_cuda.backward once per level,
+ * feature_refine_module.py:28-40): one call builds the indexes of all levels when the forward pass has the boxes,
+ * one call runs all gathers when the gradients arrive.  best_bboxes / top_grads / bottom_grads: HOST arrays of
+ * `levels` device pointers; H, W, spatial_scales: host arrays; N, C, points common to the levels.  ws: ONE block of
+ * r3det_fr_backward_levels_workspace_bytes() bytes, the same block for both calls.  A level whose (shape, C) has no
+ * gather form takes the scatter kernels from its boxes inside the second call. */
+size_t r3det_fr_backward_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points);
+int r3det_feature_refine_backward_index_levels(int levels, const float* const* best_bboxes, int N, int C, const int* H,
+                                               const int* W, const float* spatial_scales, int points, void* ws,
+                                               size_t ws_bytes, void* stream);
+int r3det_feature_refine_backward_levels_indexed(int levels, const float* const* top_grads,
+                                                 const float* const* best_bboxes, int N, int C, const int* H,
+                                                 const int* W, const float* spatial_scales, int points,
+                                                 float* const* bottom_grads, int overwrite, void* ws, size_t ws_bytes,
+                                                 void* stream);
+
 /* feature_refine_cuda.backward on channels_last memory: top_grad / bottom_grad are (N, H, W, C) contiguous
  * (torch.channels_last of the (N, C, H, W) tensors), C % 4 == 0, 16-byte aligned.  Same values as
  * r3det_feature_refine_backward up to the summation order (kernel feature_refine_kernel.cu:165-230, caller

@@ -325,6 +325,74 @@ int r3det_feature_refine_backward_indexed(const float* top_grad, int N, int C, i
   return rc(r3k_frn_gather(top_grad, N, C, H, W, points, bottom_grad, overwrite, ws, ws_bytes, S(stream)));
 }
 
+// ---- all pyramid levels of one FeatureRefineModule pass in one call each (index when the forward has the boxes,
+//      gather when the gradient arrives): the per-level workspaces are one block, carved in level order
+namespace {
+inline size_t lvl_bytes(int N, int H, int W, int points) {
+  return (r3k_fr_backward_workspace_bytes(N, H, W, points) + 255) & ~(size_t)255;
+}
+}  // namespace
+
+size_t r3det_fr_backward_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points) {
+  if (levels < 0 || !H || !W) return 0;
+  size_t total = 0;
+  for (int l = 0; l < levels; l++) total += lvl_bytes(N, H[l], W[l], points);
+  return total;
+}
+
+int r3det_feature_refine_backward_index_levels(int levels, const float* const* best_bboxes, int N, int C, const int* H,
+                                               const int* W, const float* spatial_scales, int points, void* ws,
+                                               size_t ws_bytes, void* stream) {
+  if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5) ||
+      (levels > 0 && (!best_bboxes || !H || !W || !spatial_scales)))
+    return R3DET_EINVAL;
+  if (ws_bytes < r3det_fr_backward_levels_workspace_bytes(levels, N, H, W, points)) return R3DET_EWS;
+  char* p = static_cast<char*>(ws);
+  if (levels >= 1 && levels <= 8) {  // the bands of all levels as one grid, when every level takes that form
+    void* wl[8];
+    size_t wb[8];
+    char* q = p;
+    for (int l = 0; l < levels; l++) {
+      wl[l] = q, wb[l] = lvl_bytes(N, H[l], W[l], points);
+      q += wb[l];
+    }
+    const int k = r3k_frn_index_levels(levels, best_bboxes, N, C, H, W, spatial_scales, points, wl, wb, S(stream));
+    if (k <= 0) return rc(k);
+  }
+  for (int l = 0; l < levels; l++) {
+    const size_t part = lvl_bytes(N, H[l], W[l], points);
+    if (part) {  // (a level without a gather form has no index: its gradient pass reads the boxes)
+      const int k = r3k_frn_index(best_bboxes[l], N, C, H[l], W[l], spatial_scales[l], points, p, part, S(stream));
+      if (k != 0 && k != -1) return rc(k);
+    }
+    p += part;
+  }
+  return R3DET_OK;
+}
+
+int r3det_feature_refine_backward_levels_indexed(int levels, const float* const* top_grads,
+                                                 const float* const* best_bboxes, int N, int C, const int* H,
+                                                 const int* W, const float* spatial_scales, int points,
+                                                 float* const* bottom_grads, int overwrite, void* ws, size_t ws_bytes,
+                                                 void* stream) {
+  if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5) ||
+      (levels > 0 && (!top_grads || !best_bboxes || !H || !W || !spatial_scales || !bottom_grads)))
+    return R3DET_EINVAL;
+  if (ws_bytes < r3det_fr_backward_levels_workspace_bytes(levels, N, H, W, points)) return R3DET_EWS;
+  char* p = static_cast<char*>(ws);
+  for (int l = 0; l < levels; l++) {
+    const size_t part = lvl_bytes(N, H[l], W[l], points);
+    int k = -1;
+    if (part) k = r3k_frn_gather(top_grads[l], N, C, H[l], W[l], points, bottom_grads[l], overwrite, p, part, S(stream));
+    if (k == -1)  // no gather form for this (shape, C): the scatter kernels, from the boxes
+      k = r3k_fr_backward(top_grads[l], best_bboxes[l], N, C, H[l], W[l], spatial_scales[l], points, bottom_grads[l],
+                          overwrite, nullptr, 0, 0, S(stream));
+    if (k) return rc(k);
+    p += part;
+  }
+  return R3DET_OK;
+}
+
 size_t r3det_fr_backward_nhwc_workspace_bytes(int N, int H, int W, int points) {
   return r3k_frb_workspace_bytes(N, H, W, points);
 }

@@ -292,20 +292,67 @@ __device__ __forceinline__ void ixs_sort(u64* sk, int* hist, const int tid) {
   }
 }
 
-__global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __restrict__ boxes, float scale, int H, int W,
-                                                              int R, int2* __restrict__ cellinfo,
-                                                              int2* __restrict__ entries,
-                                                              u64* __restrict__ stamps = nullptr) {
+// Where a band's SELL-64 rows go when the index kernel re-lays them itself (the NCHW gather's form of the lists,
+// frn_gather_kernel below): hdr == nullptr: CSR only.
+struct FrbSellOut {
+  int* hdr;    // [N][slices] padded list length | tail flag << 16
+  int2* rows;  // [N][slices][cap / 8 batches][4 row pairs][64 lanes][2 entries] {weight, source cell byte offset}
+  int ascale, cap, pitch, slices;
+};
+
+// entry r of the cell in lane `lane` of slice `slice` (one image's rows)
+__device__ __forceinline__ size_t frb_sell_at(int slice, int lane, int r, int cap) {
+  return ((((size_t)slice * (cap >> 3) + (r >> 3)) * 4 + ((r >> 1) & 3)) * 64 + lane) * 2 + (r & 1);
+}
+
+// One slice's rows from the CSR lists of its 64 cells (one wavefront): rows in PAIRS -- {weight, cell, weight, cell}
+// of entries 2p and 2p + 1, 16 bytes per lane, 1 KB per wavefront load; a batch is four row pairs; a slice's batches
+// lie at a fixed stride.  ascale = 4 * CP: the entry carries the byte offset of the source cell in the gather's LDS
+// plane.  Lists are padded to the slice's longest (rounded up to even) with {zero cell, weight 0}.
+__device__ __forceinline__ void frb_sell_slice(const int2* __restrict__ cellinfo_n, const int2* __restrict__ entries_n,
+                                               int slice, int lane, int HW, int W, int P, int zero_cell, int ascale,
+                                               int cap, int* __restrict__ slicehdr_n, int4* __restrict__ sell_n) {
+  const int q = slice * 64 + lane;
+  int2 ci = make_int2(0, 0);
+  if (q < HW) ci = cellinfo_n[q];
+  int m = ci.y;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  const int mp = min(cap, (m + 1) & ~1);
+  if (lane == 0) slicehdr_n[slice] = mp | ((m > cap) << 16);
+  const int2* en = entries_n + ci.x;
+  int4* out = sell_n + (size_t)slice * (cap >> 3) * 256 + lane;
+  auto entry = [&](int e) -> int2 {
+    if (e >= ci.y) return make_int2(zero_cell * ascale, 0);
+    const int2 v = en[e];
+    const int s = v.x & 0x3ffffff, sy = s / W, sx = s - sy * W;
+    return make_int2((sy * P + sx) * ascale, v.y);
+  };
+  for (int e = 0; e < mp; e += 2) {
+    const int2 e0 = entry(e), e1 = entry(e + 1);
+    out[(size_t)(e >> 1) * 64] = make_int4(e0.y, e0.x, e1.y, e1.x);
+  }
+}
+
+// CSR = false (only with SELL output): the band writes its SELL rows and nothing else -- no {start, len} / entry
+// arrays, so no count of the entries in earlier rows and no column test in the scan (sources out of range in x are
+// dropped with their taps in phase B): the scan loads one float per source instead of two.  A band with a list longer
+// than the SELL capacity takes the general form, which writes the CSR lists of ITS cells (the gather reads them for
+// exactly those cells).
+template <bool CSR>
+__device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ boxes, float scale, int H, int W, int R,
+                                                    int2* __restrict__ cellinfo, int2* __restrict__ entries,
+                                                    const FrbSellOut& so, const int band, const int bands, const int n,
+                                                    u64* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) int ix[];
   IxsLds& S = *reinterpret_cast<IxsLds*>(ix);
   // (tools/probes/frb_index_probe.hip: clock stamps of one workgroup at the phase boundaries)
   auto stamp = [&](int k) {
-    if (stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
+    if (stamps && band == bands / 2 && n == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = blockIdx.y, r0 = blockIdx.x * R, r1 = min(H, r0 + R);
+  const int r0 = band * R, r1 = min(H, r0 + R);
   const int HW = H * W, CB = (r1 - r0) * W;
   const float* bx = boxes + (size_t)n * HW * 5;
   int2* ci = cellinfo + (size_t)n * HW;
@@ -329,7 +376,7 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __res
       // trips in a row, the whole of this phase)
       const int s = s0 + u * IX_T + tid;
       const float* bp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bx) + (unsigned)min(s, HW - 1) * 20u);
-      const float y = bp[0], x = bp[1];
+      const float y = bp[0], x = CSR ? bp[1] : 0.f;
       yv[u] = s < HW ? y : -3.0e38f;  // (beyond the map: out of range below)
       xv[u] = s < HW ? x : 0.f;
     }
@@ -340,10 +387,10 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __res
       // budget; with the validity test as a branch a third of it was exec-mask bookkeeping)
       float y = yv[u] * scale;
       const float x = xv[u] * scale;  // sic: row <- x_ctr, column <- y_ctr
-      const bool valid = !(y < -1.0 || y > H || x < -1.0 || x > W);  // (feature_refine_kernel.cu:72-79)
+      const bool valid = !(y < -1.0 || y > H || (CSR && (x < -1.0 || x > W)));  // (feature_refine_kernel.cu:72-79)
       y = y <= 0 ? 0.f : y;
       const int yl = min((int)y, H - 1), yh = min(yl + 1, H - 1);  // (= the reference's clamp: yl >= H - 1 -> both H - 1)
-      before += valid ? (yl < r0 ? 2 : 0) + (yh < r0 ? 2 : 0) : 0;
+      if (CSR) before += valid ? (yl < r0 ? 2 : 0) + (yh < r0 ? 2 : 0) : 0;
       const bool pass = valid && yl < r1 && yh >= r0;
       const u64 m = __ballot(pass);
       if (m == 0ULL) continue;
@@ -416,6 +463,15 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __res
   if (S.over || total > IXS_CAP) {  // more than the LDS list holds: the general form on the same band
     __syncthreads();
     frb_index_general_call(bx, scale, H, W, r0, r1, ix, ci, en);
+    if (so.hdr) {  // ... and the band's SELL rows from the lists it just wrote
+      __threadfence_block();
+      __syncthreads();
+      const int s0 = (r0 * W) >> 6, ns = CB >> 6;
+      if ((tid >> 6) < ns)
+        frb_sell_slice(ci, en, s0 + (tid >> 6), lane, HW, W, so.pitch, H * so.pitch, so.ascale, so.cap,
+                       so.hdr + (size_t)n * so.slices,
+                       reinterpret_cast<int4*>(so.rows) + (size_t)n * so.slices * (so.cap >> 3) * 256);
+    }
     return;
   }
   // C: stable sort by cell
@@ -433,17 +489,97 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __res
     const int c = (int)(k >> 56);
     if (i == 0 || (int)(S.sk[i - 1] >> 56) != c) S.cst[c] = i;
     if (i == total - 1 || (int)(S.sk[i + 1] >> 56) != c) S.cend[c] = i + 1;
-    const int s = (int)((k >> 34) & 0x3fffff);
-    const int sy = s / W, sx = s - sy * W, y = r0 + c / W, x = c - (c / W) * W;
-    en[base + i] = make_int2(frb_entry_code(sy, sx, y, x, W), (int)(unsigned)k);
+    if (CSR) {
+      const int s = (int)((k >> 34) & 0x3fffff);
+      const int sy = s / W, sx = s - sy * W, y = r0 + c / W, x = c - (c / W) * W;
+      en[base + i] = make_int2(frb_entry_code(sy, sx, y, x, W), (int)(unsigned)k);
+    }
   }
   __syncthreads();
-  for (int c = tid; c < CB; c += IX_T) ci[r0 * W + c] = make_int2(base + S.cst[c], S.cend[c] - S.cst[c]);
+  if (CSR)
+    for (int c = tid; c < CB; c += IX_T) ci[r0 * W + c] = make_int2(base + S.cst[c], S.cend[c] - S.cst[c]);
+  if (!CSR) {  // a list beyond the SELL capacity: the band through the general form (CSR lists + SELL rows from them)
+    if (tid < CB && S.cend[tid] - S.cst[tid] > so.cap) S.over = 1;
+    __syncthreads();
+    if (S.over) {
+      frb_index_general_call(bx, scale, H, W, r0, r1, ix, ci, en);
+      __threadfence_block();
+      __syncthreads();
+      const int s0 = (r0 * W) >> 6, ns = CB >> 6;
+      if ((tid >> 6) < ns)
+        frb_sell_slice(ci, en, s0 + (tid >> 6), lane, HW, W, so.pitch, H * so.pitch, so.ascale, so.cap,
+                       so.hdr + (size_t)n * so.slices,
+                       reinterpret_cast<int4*>(so.rows) + (size_t)n * so.slices * (so.cap >> 3) * 256);
+      return;
+    }
+  }
+  if (so.hdr) {
+    // E: the band's SELL-64 rows straight from the sorted list (the launcher sends only bands of whole slices here):
+    // entry r of a cell at its (batch, row pair, half); every list padded to its slice's longest (rounded up to even)
+    // with {weight 0, zero cell}
+    int2* rows = so.rows + (size_t)n * so.slices * (so.cap >> 3) * 512;
+    const int s0 = (r0 * W) >> 6;
+    for (int i = tid; i < total; i += IX_T) {
+      const u64 k = S.sk[i];
+      const int c = (int)(k >> 56), r = i - S.cst[c];
+      if (r < so.cap) {
+        const int s = (int)((k >> 34) & 0x3fffff);
+        const int sy = s / W, sx = s - sy * W;
+        rows[frb_sell_at(s0 + (c >> 6), c & 63, r, so.cap)] = make_int2((int)(unsigned)k, (sy * so.pitch + sx) * so.ascale);
+      }
+    }
+    if (tid < CB) {  // (CB <= 256: wavefront w = slice s0 + w)
+      const int len = S.cend[tid] - S.cst[tid];
+      int m = len;
+      for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+      const int mp = min(so.cap, (m + 1) & ~1);
+      if (lane == 0) so.hdr[(size_t)n * so.slices + s0 + (tid >> 6)] = mp | ((m > so.cap) << 16);
+      for (int r = len; r < mp; r++)
+        rows[frb_sell_at(s0 + (tid >> 6), lane, r, so.cap)] = make_int2(0, H * so.pitch * so.ascale);
+    }
+  }
   stamp(4);
-  if (stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (stamps && band == bands / 2 && n == 0 && threadIdx.x == 0) {
     stamps[5] = (u64)total;
     stamps[6] = (u64)wc;
   }
+}
+
+template <bool CSR>
+__global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __restrict__ boxes, float scale, int H, int W,
+                                                              int R, int2* __restrict__ cellinfo,
+                                                              int2* __restrict__ entries, FrbSellOut so,
+                                                              u64* __restrict__ stamps = nullptr) {
+  frb_index_sort_body<CSR>(boxes, scale, H, W, R, cellinfo, entries, so, blockIdx.x, gridDim.x, blockIdx.y, stamps);
+}
+
+// The bands of ALL pyramid levels of a FeatureRefineModule pass as one grid (levels in kernel arguments; a block finds
+// its level from the block ranges): the coarse levels' index kernels are 9-12 us of latency each on their own, here
+// they run beside level 0's bands.
+constexpr int FRB_MAX_LEVELS = 8;
+struct FrbLevelArgs {
+  const float* boxes;
+  int2* cellinfo;
+  int2* entries;
+  FrbSellOut so;
+  float scale;
+  int H, W, R, first;  // first: the level's first block
+};
+struct FrbLevelsArgs {
+  FrbLevelArgs l[FRB_MAX_LEVELS];
+  int n;
+};
+
+__global__ __launch_bounds__(IX_T) void frb_index_sort_levels_kernel(const FrbLevelsArgs A) {
+  int lv = 0;
+#pragma unroll
+  for (int i = 1; i < FRB_MAX_LEVELS; i++)
+    if (i < A.n && (int)blockIdx.x >= A.l[i].first) lv = i;
+  // (a uniform index into the by-value argument block: scalar loads)
+  const FrbLevelArgs& L = A.l[lv];
+  const int bands = (lv + 1 < A.n ? A.l[lv + 1].first : (int)gridDim.x) - L.first;
+  frb_index_sort_body<false>(L.boxes, L.scale, L.H, L.W, L.R, L.cellinfo, L.entries, L.so, (int)blockIdx.x - L.first, bands,
+                             blockIdx.y, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -695,34 +831,6 @@ inline FrnLayout frn_layout(void* ws, int N, int C, int H, int W, int points) {
   return L;
 }
 
-// One slice's rows from the CSR lists of its 64 cells (one wavefront): rows in PAIRS -- {weight, cell, weight, cell}
-// of entries 2p and 2p + 1, 16 bytes per lane, 1 KB per wavefront load; a batch is four row pairs; a slice's batches
-// lie at a fixed stride.  ascale = 4 * CP: the entry carries the byte offset of the source cell in the gather's LDS
-// plane.  Lists are padded to the slice's longest (rounded up to even) with {zero cell, weight 0}.
-__device__ __forceinline__ void frb_sell_slice(const int2* __restrict__ cellinfo_n, const int2* __restrict__ entries_n,
-                                               int slice, int lane, int HW, int W, int P, int zero_cell, int ascale,
-                                               int cap, int* __restrict__ slicehdr_n, int4* __restrict__ sell_n) {
-  const int q = slice * 64 + lane;
-  int2 ci = make_int2(0, 0);
-  if (q < HW) ci = cellinfo_n[q];
-  int m = ci.y;
-  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-  const int mp = min(cap, (m + 1) & ~1);
-  if (lane == 0) slicehdr_n[slice] = mp | ((m > cap) << 16);
-  const int2* en = entries_n + ci.x;
-  int4* out = sell_n + (size_t)slice * (cap >> 3) * 256 + lane;
-  auto entry = [&](int e) -> int2 {
-    if (e >= ci.y) return make_int2(zero_cell * ascale, 0);
-    const int2 v = en[e];
-    const int s = v.x & 0x3ffffff, sy = s / W, sx = s - sy * W;
-    return make_int2((sy * P + sx) * ascale, v.y);
-  };
-  for (int e = 0; e < mp; e += 2) {
-    const int2 e0 = entry(e), e1 = entry(e + 1);
-    out[(size_t)(e >> 1) * 64] = make_int4(e0.y, e0.x, e1.y, e1.x);
-  }
-}
-
 // CSR -> SELL-64 as a launch of its own (planes whose bands the index kernels do not re-lay themselves)
 __global__ __launch_bounds__(256) void frb_sell_kernel(const int2* __restrict__ cellinfo, const int2* __restrict__ entries,
                                                        int HW, int W, int P, int zero_cell, int ascale, int EPI, int cap,
@@ -910,6 +1018,13 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
     }
   };
   // one batch of the sums; f: its entry of the list
+  // The results of a wavefront's slices wait in registers and leave in ONE burst behind the sums (HOLD; up to 32
+  // registers): a store between the index loads sits in the same in-order memory queue, and with the chip's write
+  // bandwidth saturated (every compute unit is in this phase at the same time) the loads behind it waited -- the
+  // gather phase took the index time PLUS the write time.  Issued at the end, the writes drain while the compute
+  // unit's next workgroup stages its planes.
+  constexpr bool HOLD = K * CP <= 32 && !(K == 8 && CP == 4);
+  V res[HOLD ? K : 1];
   const int sl0_256 = sl0 * 256, zero_b = H * P * 4 * CP;
   auto step = [&](const B8& b, const int f) {
     const int np = f & 7;
@@ -942,9 +1057,12 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
         fma_v(__int_as_float(e.y), *reinterpret_cast<const V*>(frn_lds + (size_t)(sy * P + sx) * CP));
       }
     }
+    if (HOLD) {  // (a register array under a uniform index: s_set_gpr_idx, no scratch)
+      res[HOLD ? (f >> 8) & (K - 1) : 0] = acc;
+      return;
+    }
 #pragma unroll
-    for (int ch = 0; ch < CP; ch++)
-    {
+    for (int ch = 0; ch < CP; ch++) {
       const unsigned bits = __builtin_bit_cast(unsigned, frn_get<CP>(acc, ch));
       __builtin_amdgcn_raw_buffer_store_b32(bits, rbot[ch], lane4, so, 2);
     }
@@ -963,6 +1081,14 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
       load_batch(t + 4, B);
       if (t + 2 < total) step(D, __builtin_amdgcn_readlane(seq_f, (t + 2) & 63));
     }
+  }
+  if (HOLD) {  // (a slice beyond the map: its offset lies beyond the plane's descriptor, the store is dropped)
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+      for (int ch = 0; ch < CP; ch++)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, frn_get<CP>(res[HOLD ? k : 0], ch)), rbot[ch],
+                                              lane4, sl0_256 + k * 256, 2);
   }
   stamp(3);
   if (stamps) {
@@ -992,18 +1118,49 @@ size_t r3k_frb_workspace_bytes(int N, int H, int W, int points) {
 }
 
 // the inverse tap index of a level (depends on the boxes only)
+namespace {
+// the sort form re-lays a band's lists as SELL rows itself when its bands are whole slices
+inline bool frb_sort_form(int H, int W, int points) {
+  return points == 1 && W <= IXS_CELLS && (long long)H * W <= (1LL << 22) && g_r3_frb_impl != 1;
+}
+inline bool frb_fuses_sell(int H, int W, int points) {
+  if (!frb_sort_form(H, W, points) || g_r3_frb_impl == 3) return false;  // (frb_impl 3: the SELL launch always; tests)
+  const int R = sort_band_rows(H, W);
+  return (R * W) % 64 == 0 && R * W <= 256 && (H * W) % 64 == 0;  // (a last, shorter band is whole slices too)
+}
+int frb_index_launch(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
+                     const FrbSellOut& so, hipStream_t stream);
+}  // namespace
+
 int r3k_frb_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
                   hipStream_t stream) {
+  FrbSellOut none;
+  none.hdr = nullptr, none.rows = nullptr, none.ascale = none.cap = none.pitch = none.slices = 0;
+  return frb_index_launch(boxes, N, H, W, scale, points, ws, ws_bytes, none, stream);
+}
+
+namespace {
+int frb_index_launch(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
+                     const FrbSellOut& so, hipStream_t stream) {
   const size_t need = r3k_frb_workspace_bytes(N, H, W, points);
   if (need == 0 || !boxes || !ws || !aligned16(ws)) return -1;
   if (ws_bytes < need) return -3;
   const FrbLayout L = frb_layout(ws, N, H, W, points);
-  if (points == 1 && W <= IXS_CELLS && (long long)H * W <= (1LL << 22) && g_r3_frb_impl != 1) {
+  if (frb_sort_form(H, W, points)) {
     static R3DeviceOnce once;
-    if (once.first()) allow_big_lds(frb_index_sort_kernel, (int)sizeof(IxsLds));
+    if (once.first()) {
+      allow_big_lds(frb_index_sort_kernel<true>, (int)sizeof(IxsLds));
+      allow_big_lds(frb_index_sort_kernel<false>, (int)sizeof(IxsLds));
+    }
     const int R = sort_band_rows(H, W);
-    hipLaunchKernelGGL(frb_index_sort_kernel, dim3((H + R - 1) / R, N), dim3(IX_T), sizeof(IxsLds), stream, boxes, scale,
-                       H, W, R, L.cellinfo, L.entries, (u64*)nullptr);
+    const dim3 grid((H + R - 1) / R, N);
+    // (frb_impl 5: SELL rows AND the CSR lists from the one launch; tests)
+    if (so.hdr && g_r3_frb_impl != 5)
+      hipLaunchKernelGGL(frb_index_sort_kernel<false>, grid, dim3(IX_T), sizeof(IxsLds), stream, boxes, scale, H, W, R,
+                         L.cellinfo, L.entries, so, (u64*)nullptr);
+    else
+      hipLaunchKernelGGL(frb_index_sort_kernel<true>, grid, dim3(IX_T), sizeof(IxsLds), stream, boxes, scale, H, W, R,
+                         L.cellinfo, L.entries, so, (u64*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   const int R = general_band_rows(H, W);
@@ -1017,6 +1174,7 @@ int r3k_frb_index(const float* boxes, int N, int H, int W, float scale, int poin
                        L.entries);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+}  // namespace
 
 // bottom_grad (N, H, W, C) = [bottom_grad +] backward(top_grad); index_ready: ws holds r3k_frb_index of these boxes
 int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W, float scale, int points,
@@ -1092,10 +1250,44 @@ int r3k_frn_index(const float* boxes, int N, int C, int H, int W, float scale, i
   if (need == 0 || !boxes || !ws || !aligned16(ws) || !frn_config(C, H, W, K, cp)) return -1;
   if (ws_bytes < need) return -3;
   const FrnLayout L = frn_layout(ws, N, C, H, W, points);
-  const int rc = r3k_frb_index(boxes, N, H, W, scale, points, ws, L.csr.bytes, stream);
-  if (rc) return rc;
+  FrbSellOut so;
+  so.hdr = L.slicehdr, so.rows = reinterpret_cast<int2*>(L.sell), so.ascale = 4 * L.cp, so.cap = L.cap, so.pitch = L.pitch,
+  so.slices = L.slices;
+  const bool fused = frb_fuses_sell(H, W, points);
+  if (!fused) so.hdr = nullptr;
+  const int rc = frb_index_launch(boxes, N, H, W, scale, points, ws, L.csr.bytes, so, stream);
+  if (rc || fused) return rc;
   hipLaunchKernelGGL(frb_sell_kernel, dim3((L.slices + 3) / 4, N), dim3(256), 0, stream, L.csr.cellinfo, L.csr.entries,
                      H * W, W, L.pitch, H * L.pitch, 4 * L.cp, H * W * 4 * points, L.cap, L.slices, L.slicehdr, L.sell);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// The indexes of several levels (each with its own workspace, as r3k_frn_index would fill it) from ONE launch; 1 when
+// the levels do not all take the fused sort form (the caller then indexes level by level), else 0 / -2.
+int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, const int* H, const int* W,
+                         const float* scales, int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream) {
+  if (levels < 1 || levels > FRB_MAX_LEVELS || g_r3_frb_impl == 5 || g_r3_frb_impl == 6) return 1;  // (6: per level; tests)
+  FrbLevelsArgs A;
+  A.n = levels;
+  int blocks = 0;
+  for (int l = 0; l < levels; l++) {
+    int K, cp;
+    const size_t need = r3k_frn_workspace_bytes(N, H[l], W[l], points);
+    if (need == 0 || !boxes[l] || !ws[l] || !aligned16(ws[l]) || ws_bytes[l] < need || !frn_config(C, H[l], W[l], K, cp) ||
+        !frb_fuses_sell(H[l], W[l], points))
+      return 1;
+    const FrnLayout L = frn_layout(ws[l], N, C, H[l], W[l], points);
+    FrbLevelArgs& a = A.l[l];
+    a.boxes = boxes[l], a.cellinfo = L.csr.cellinfo, a.entries = L.csr.entries;
+    a.so.hdr = L.slicehdr, a.so.rows = reinterpret_cast<int2*>(L.sell), a.so.ascale = 4 * L.cp, a.so.cap = L.cap,
+    a.so.pitch = L.pitch, a.so.slices = L.slices;
+    a.scale = scales[l], a.H = H[l], a.W = W[l], a.R = sort_band_rows(H[l], W[l]), a.first = blocks;
+    blocks += (H[l] + a.R - 1) / a.R;
+  }
+  for (int l = levels; l < FRB_MAX_LEVELS; l++) A.l[l] = A.l[levels - 1];
+  static R3DeviceOnce once;
+  if (once.first()) allow_big_lds(frb_index_sort_levels_kernel, (int)sizeof(IxsLds));
+  hipLaunchKernelGGL(frb_index_sort_levels_kernel, dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

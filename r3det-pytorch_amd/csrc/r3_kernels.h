@@ -77,6 +77,8 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
 size_t r3k_frn_workspace_bytes(int N, int H, int W, int points);
 int r3k_frn_index(const float* boxes, int N, int C, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
                   hipStream_t stream);
+int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, const int* H, const int* W,
+                         const float* scales, int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream);
 int r3k_frn_gather(const float* top_grad, int N, int C, int H, int W, int points, float* bottom_grad, int overwrite,
                    void* ws, size_t ws_bytes, hipStream_t stream);
 

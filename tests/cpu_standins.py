@@ -27,16 +27,20 @@ def _feature_refine(features, best_rbboxes, spatial_scale, points=1, table=None)
     return torch_fr(features, best_rbboxes, spatial_scale, points)
 
 
+def _feature_refine_levels(features, best_rbboxes, spatial_scales, points=1):
+    return [torch_fr(f, b, s, points) for f, b, s in zip(features, best_rbboxes, spatial_scales)]
+
+
 @contextlib.contextmanager
 def cpu_kernels(twin=False):
     """``twin``: the oracle evaluates the kernels' own deterministic sincos instead of libm (bit-identical
     IoU to the HIP path: needed when exact ties between anchors decide the assignment)."""
     import r3det.core.bbox.iou_calculators.rotate_iou2d_calculator as calc
     import r3det.ops.feature_refine as frm
-    saved = calc.rbbox_iou, frm.feature_refine
-    calc.rbbox_iou, frm.feature_refine = _rbbox_iou, _feature_refine
+    saved = calc.rbbox_iou, frm.feature_refine, frm.feature_refine_levels
+    calc.rbbox_iou, frm.feature_refine, frm.feature_refine_levels = _rbbox_iou, _feature_refine, _feature_refine_levels
     try:
         with (O.twin() if twin else contextlib.nullcontext()):
             yield
     finally:
-        calc.rbbox_iou, frm.feature_refine = saved
+        calc.rbbox_iou, frm.feature_refine, frm.feature_refine_levels = saved

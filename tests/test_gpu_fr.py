@@ -111,6 +111,14 @@ def test_backward_gather_full_channel_counts(shape, adversarial):
     again = torch.full((N, C, H, W), float('nan'), device='cuda')
     fr_backward(dev(top), dev(boxes), 1 / stride, 1, again, overwrite=True)
     assert torch.equal(g, again)
+    # the index kernel re-lays the lists as SELL rows itself at these shapes; option frb_impl 3: the separate launch
+    # from the CSR lists instead -- the same rows, bit for bit; 1: the general index form (another list order)
+    for impl, exact in ((3, True), (5, True), (1, False)):
+        _C.set_option("frb_impl", impl)
+        other = torch.full((N, C, H, W), float('nan'), device='cuda')
+        fr_backward(dev(top), dev(boxes), 1 / stride, 1, other, overwrite=True)
+        _C.set_option("frb_impl", 0)
+        assert torch.equal(g, other) if exact else (g - other).abs().max().item() <= tol
     _C.set_option("fr_impl", 2)
     g2 = torch.empty_like(g)
     fr_backward(dev(top), dev(boxes), 1 / stride, 1, g2, overwrite=True)
@@ -285,6 +293,54 @@ def test_autograd_backward_uses_the_index_from_forward(shape, points):
     assert L.r3det_feature_refine_backward_indexed(*args, None, 0, _C.stream()) == -1
     assert L.r3det_feature_refine_backward_indexed(_C.ptr(t), N, C, H, W, 3, _C.ptr(g1), 1, _C.ptr(index),
                                                    index.numel(), _C.stream()) == -1
+
+
+@pytest.mark.parametrize("points", [1, 5])
+@pytest.mark.parametrize("NC", [(2, 16), (1, 6)])
+def test_levels_node_equals_per_level_nodes(points, NC):
+    """feature_refine_levels = one autograd node for the five pyramid levels (one library call each for the samplers,
+    the backward's indexes, the gathers): outputs and gradients bit-identical to one feature_refine node per level;
+    the C ABI's levels calls refuse a short workspace."""
+    import ctypes
+    from r3det import _C, synthetic as syn
+    from r3det.ops.feature_refine import feature_refine, feature_refine_levels
+    N, C = NC
+    feats, boxes = syn.fr_pyramid(N, C, 5, device='cuda')
+    scales = [1.0 / s for s in syn.STRIDES]
+    gs = [torch.randn_like(f) for f in feats]
+    xs = [f.clone().requires_grad_(True) for f in feats]
+    outs = feature_refine_levels(xs, boxes, scales, points)
+    torch.autograd.backward(outs, gs)
+    for f, b, s, o, x, g in zip(feats, boxes, scales, outs, xs, gs):
+        x1 = f.clone().requires_grad_(True)
+        o1 = feature_refine(x1, b, s, points)
+        o1.backward(g)
+        assert torch.equal(o, o1) and torch.equal(x.grad, x1.grad)
+    # the indexes of the levels from one grouped launch (default) == level by level (option frb_impl 6)
+    _C.set_option("frb_impl", 6)
+    xs6 = [f.clone().requires_grad_(True) for f in feats]
+    torch.autograd.backward(feature_refine_levels(xs6, boxes, scales, points), gs)
+    _C.set_option("frb_impl", 0)
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(xs6, xs))
+    # gradients only for some levels / none
+    xs2 = [f.clone().requires_grad_(i % 2 == 0) for i, f in enumerate(feats)]
+    outs2 = feature_refine_levels(xs2, boxes, scales, points)
+    torch.autograd.backward([o for i, o in enumerate(outs2) if i % 2 == 0], [g for i, g in enumerate(gs) if i % 2 == 0])
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(xs2[::2], xs[::2])) and xs2[1].grad is None
+    assert all(o.grad_fn is None for o in feature_refine_levels(feats, boxes, scales, points))
+    L = _C.lib()
+    n = len(feats)
+    arr_i, arr_p = ctypes.c_int * n, ctypes.c_void_p * n
+    H, W = arr_i(*[f.size(2) for f in feats]), arr_i(*[f.size(3) for f in feats])
+    sc = (ctypes.c_float * n)(*scales)
+    need = int(L.r3det_fr_backward_levels_workspace_bytes(n, N, H, W, points))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    bp = arr_p(*[b.data_ptr() for b in boxes])
+    assert L.r3det_feature_refine_backward_index_levels(n, bp, N, C, H, W, sc, points, _C.ptr(ws), need - 256,
+                                                        _C.stream()) == -3
+    assert L.r3det_feature_refine_backward_index_levels(n, None, N, C, H, W, sc, points, _C.ptr(ws), need,
+                                                        _C.stream()) == -1
 
 
 @pytest.mark.parametrize("points", [1, 5])

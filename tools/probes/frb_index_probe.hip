@@ -20,17 +20,24 @@ int main() {
       q[2] = 30; q[3] = 20; q[4] = -0.3f;
     }
   float* db; void* ws; u64* st;
-  const size_t need = r3k_frb_workspace_bytes(N, H, W, 1);
+  const size_t need = r3k_frn_workspace_bytes(N, H, W, 1);
   CK(hipMalloc(&db, b.size() * 4)); CK(hipMalloc(&ws, need)); CK(hipMalloc(&st, 64));
   CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
-  allow_big_lds(frb_index_sort_kernel, (int)sizeof(IxsLds));
+  allow_big_lds(frb_index_sort_kernel<true>, (int)sizeof(IxsLds));
+  allow_big_lds(frb_index_sort_kernel<false>, (int)sizeof(IxsLds));
+  const FrnLayout LN = frn_layout(ws, N, 256, H, W, 1);
+  FrbSellOut so{LN.slicehdr, reinterpret_cast<int2*>(LN.sell), 4 * LN.cp, LN.cap, LN.pitch, LN.slices};
   const FrbLayout L = frb_layout(ws, N, H, W, 1);
   const int R = sort_band_rows(H, W);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int it = 0; it < 3; it++) {
+  for (int it = 0; it < 6; it++) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(frb_index_sort_kernel, dim3((H + R - 1) / R, N), dim3(IX_T), sizeof(IxsLds), 0, db, 0.125f, H, W, R,
-                       L.cellinfo, L.entries, st);
+    if (it & 1)
+      hipLaunchKernelGGL(frb_index_sort_kernel<false>, dim3((H + R - 1) / R, N), dim3(IX_T), sizeof(IxsLds), 0, db, 0.125f, H, W, R,
+                         L.cellinfo, L.entries, so, st);
+    else
+      hipLaunchKernelGGL(frb_index_sort_kernel<true>, dim3((H + R - 1) / R, N), dim3(IX_T), sizeof(IxsLds), 0, db, 0.125f, H, W, R,
+                         L.cellinfo, L.entries, FrbSellOut{nullptr, nullptr, 0, 0, 0, 0}, st);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     u64 h[8]; CK(hipMemcpy(h, st, 64, hipMemcpyDeviceToHost));

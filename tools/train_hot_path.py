@@ -13,7 +13,7 @@ import torch  # noqa: E402
 
 from r3det import synthetic as syn  # noqa: E402
 from r3det.core.bbox.assigners import MaxIoUAssigner  # noqa: E402
-from r3det.ops.feature_refine import feature_refine  # noqa: E402
+from r3det.ops.feature_refine import feature_refine, feature_refine_levels  # noqa: E402
 
 dev = torch.device("cuda")
 B, K = 2, 128
@@ -33,10 +33,16 @@ def assign():
         asg2.assign(refined[i], gts[i])
 
 
-def fr():
+def fr_per_level():
     for x, b, g, s in zip(xs, boxes, gs, syn.STRIDES):
         x.grad = None
         feature_refine(x, b, 1.0 / s, 1).backward(g)
+
+
+def fr():  # what FeatureRefineModule runs in NCHW training: the five levels as one autograd node
+    for x in xs:
+        x.grad = None
+    torch.autograd.backward(feature_refine_levels(xs, boxes, [1.0 / s for s in syn.STRIDES], 1), gs)
 
 
 def timeit(fn, n=20):
@@ -54,6 +60,13 @@ def timeit(fn, n=20):
 
 
 ta, tf = timeit(assign), timeit(fr)
+print(f"(one autograd node per level: {timeit(fr_per_level):7.3f} ms)")
+from r3det import _C  # noqa: E402
+for rnd in range(2):
+    for impl, what in ((6, "index level by level"), (0, "indexes of all levels in one launch")):
+        _C.set_option("frb_impl", impl)
+        print(f"(levels node, {what}: {timeit(fr):7.3f} ms)")
+_C.set_option("frb_impl", 0)
 print(f"assignment ({B} x ({K} x {anchors.size(0)} + {K} x {refined[0].size(0)})): {ta:7.3f} ms")
 print(f"FeatureRefine fwd + bwd, 5 levels (N = {B}, C = 256):                 {tf:7.3f} ms")
 print(f"training hot path per step:                                           {ta + tf:7.3f} ms")
