@@ -187,10 +187,11 @@ def build_hot_workload(device, seed):
 def hot_path_step(wl):
     from r3det.core.post_processing import multiclass_nms_rotated_batch
     from r3det.ops import fr_boxes
-    from r3det.ops.feature_refine import fr_module_nhwc
-    for lv in wl["levels"]:
-        fr_module_nhwc(lv["a"], lv["b"], wl["bias"], wl["bias"], lv["res"], lv["boxes"], lv["scale"], 1, lv["out"])
+    from r3det.ops.feature_refine import fr_module_levels_nhwc
     L = wl["levels"]
+    # (what FeatureRefineModule.forward runs: the module tail of all levels in one library call)
+    fr_module_levels_nhwc([lv["a"] for lv in L], [lv["b"] for lv in L], wl["bias"], wl["bias"], [lv["res"] for lv in L],
+                          [lv["boxes"] for lv in L], [lv["scale"] for lv in L], 1, [lv["out"] for lv in L])
     fr_boxes.levels_pool([lv["cls"] for lv in L], [lv["reg"] for lv in L], [lv["rois"] for lv in L], 1, 15, 2000,
                          (IMG, IMG), wl["pool_boxes"], wl["pool_scores"])
     res = multiclass_nms_rotated_batch(wl["pool_boxes"], wl["pool_scores"], SCORE_THR, NMS_CFG, MAX_PER_IMG,
@@ -300,7 +301,7 @@ def fr_rates(device):
     same B_fr.  NCHW = the reference's layout (r3det_feature_refine_forward / _backward_ws), NHWC = channels_last
     (r3det_feature_refine_forward_nhwc / _backward_nhwc)."""
     from r3det import synthetic as syn
-    from r3det.ops.feature_refine import fr_backward, fr_backward_nhwc, fr_forward, fr_forward_nhwc
+    from r3det.ops import feature_refine as FRM
     cl = torch.channels_last
     out = {}
 
@@ -321,19 +322,38 @@ def fr_rates(device):
         def call():
             xs, os_ = sets[state[0] % nset]
             state[0] += 1
-            for x, o, b, sc in zip(xs, os_, boxes, scales):
-                fn(x, b, sc, points, o)
+            fn(xs, boxes, scales, points, os_)
         dt = timeit(call, reps)
         hw = sum(f.shape[-1] * f.shape[-2] for f in feats)
         nb = b_fr(N, hw, points)
-        out[name] = {"us_per_call": round(dt * 1e6, 1), "alg_bytes": nb, "launch_groups": len(lvls),
+        out[name] = {"us_per_call": round(dt * 1e6, 1), "alg_bytes": nb, "library_calls": 1 if len(lvls) > 1 else len(lvls),
                      "rotating_MB": round(per_set * nset / 1e6), "roofline": _roof(nb, dt)}
         del sets
 
-    fwd = {False: lambda x, b, sc, p, o: fr_forward(x, b, sc, p, o),
-           True: lambda x, b, sc, p, o: fr_forward_nhwc(x, b, sc, p, o)}
-    bwd = {False: lambda x, b, sc, p, o: fr_backward(x, b, sc, p, o, overwrite=True),
-           True: lambda x, b, sc, p, o: fr_backward_nhwc(x, b, sc, p, o, overwrite=True)}
+    # one level: the per-level entry points; the five levels: ONE library call (what FeatureRefineModule runs)
+    def fwd_nchw(xs, bs, scs, p, os_):
+        if len(xs) == 1:
+            FRM.fr_forward(xs[0], bs[0], scs[0], p, os_[0])
+        else:
+            FRM.fr_forward_levels(xs, bs, scs, p, os_)
+
+    def fwd_nhwc(xs, bs, scs, p, os_):
+        if len(xs) == 1:
+            FRM.fr_forward_nhwc(xs[0], bs[0], scs[0], p, os_[0])
+        else:
+            FRM.fr_forward_levels_nhwc(xs, bs, scs, p, os_)
+
+    def bwd_nchw(xs, bs, scs, p, os_):  # (index + gather: the whole backward op, as the reference's one call is)
+        if len(xs) == 1:
+            FRM.fr_backward(xs[0], bs[0], scs[0], p, os_[0], overwrite=True)
+        else:
+            FRM.fr_backward_levels(xs, bs, scs, p, os_)
+
+    def bwd_nhwc(xs, bs, scs, p, os_):
+        for x, b, sc, o in zip(xs, bs, scs, os_):
+            FRM.fr_backward_nhwc(x, b, sc, p, o, overwrite=True)
+
+    fwd, bwd = {False: fwd_nchw, True: fwd_nhwc}, {False: bwd_nchw, True: bwd_nhwc}
     for nhwc, lay in ((False, "nchw"), (True, "nhwc")):
         for points in (1, 5):
             for lvl in range(5):

@@ -307,6 +307,21 @@ int r3det_feature_refine_module_nhwc(const float* conv_a, const float* conv_b, c
                                      int C, int H, int W, float spatial_scale, int points, float* output,
                                      void* stream);
 
+/* The channels_last forms for ALL pyramid levels of a pass (the `for` over the levels of
+ * FeatureRefineModule.forward, fr/feature_refine_module.py:108-127) in one call: a level that takes the wide regions
+ * form (level 0 of a 1024^2 input) is one launch, ALL other levels together are one more (a grid over the tile pairs
+ * of every level: the coarse levels are launch-bound on their own).  Element for element the results of one
+ * r3det_feature_refine_forward_nhwc / _module_nhwc call per level.  features / conv_a / conv_b / residual /
+ * best_bboxes / outputs: HOST arrays of `levels` device pointers (conv_b may be NULL: no second addend); H, W,
+ * spatial_scales: host arrays; N, C, points and the biases common to the levels. */
+int r3det_feature_refine_forward_levels_nhwc(int levels, const float* const* features, const float* const* best_bboxes,
+                                             int N, int C, const int* H, const int* W, const float* spatial_scales,
+                                             int points, float* const* outputs, void* stream);
+int r3det_feature_refine_module_levels_nhwc(int levels, const float* const* conv_a, const float* const* conv_b,
+                                            const float* bias_a, const float* bias_b, const float* const* residual,
+                                            const float* const* best_bboxes, int N, int C, const int* H, const int* W,
+                                            const float* spatial_scales, int points, float* const* outputs, void* stream);
+
 /* The per-level loop of FeatureRefineModule.forward (fr/feature_refine_module.py:115-127) in one call:
  * `levels` sampler launches enqueued back to back (from Python each level costs ~10 us of host time, more
  * than the kernels of the three coarse levels).  features / best_bboxes / outputs: HOST arrays of `levels`

@@ -267,6 +267,26 @@ int r3det_feature_refine_module_nhwc(const float* conv_a, const float* conv_b, c
                                 points, output, S(stream)));
 }
 
+int r3det_feature_refine_forward_levels_nhwc(int levels, const float* const* features, const float* const* best_bboxes,
+                                             int N, int C, const int* H, const int* W, const float* spatial_scales,
+                                             int points, float* const* outputs, void* stream) {
+  if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
+  return rc(r3k_fr_forward_nhwc_levels(levels, features, nullptr, nullptr, nullptr, nullptr, best_bboxes, N, C, H, W,
+                                       spatial_scales, points, outputs, S(stream)));
+}
+
+int r3det_feature_refine_module_levels_nhwc(int levels, const float* const* conv_a, const float* const* conv_b,
+                                            const float* bias_a, const float* bias_b, const float* const* residual,
+                                            const float* const* best_bboxes, int N, int C, const int* H, const int* W,
+                                            const float* spatial_scales, int points, float* const* outputs, void* stream) {
+  if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5) || (levels > 0 && (!conv_a || !residual)))
+    return R3DET_EINVAL;
+  for (int l = 0; l < levels; l++)
+    if (!conv_a[l] || !residual[l] || (conv_b && conv_b[0] && !conv_b[l])) return R3DET_EINVAL;
+  return rc(r3k_fr_forward_nhwc_levels(levels, conv_a, conv_b, bias_a, bias_b, residual, best_bboxes, N, C, H, W,
+                                       spatial_scales, points, outputs, S(stream)));
+}
+
 size_t r3det_fr_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points) {
   size_t total = 0;
   for (int l = 0; l < levels; l++) total += r3k_fr_workspace_bytes(N, H[l], W[l], points);

@@ -564,10 +564,10 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_pipe(
 // waves per CU; and most tap rows never pass through the L1 at all (see the kernel's first comment).
 // VAR bit 0: boxes prefetched in phase 1; bit 1: non-temporal res / out; bit 2: 32-bit index arithmetic
 template <bool FUSED, bool PAIRED, int VAR = 0>
-__global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
+__device__ __forceinline__ void fr_forward_nhwc_occ_body(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
     const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
-    float scale, int tiles_xs, int tiles_per_img, int T, float* __restrict__ out) {
+    float scale, int tiles_xs, int tiles_per_img, int T, float* __restrict__ out, const unsigned block) {
   const int tiles_x = tiles_xs & 0xfffff, strip = tiles_xs >> 20;  // (the pair walk's strip height rides in the top bits)
   // The sampled map P = (a + bias_a) + (b + bias_b) of the workgroup's own positions is shared through LDS: each
   // wave computes P for its 4 positions once (their identity term), the barrier publishes the two 4 x 4 tiles, and
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
   const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-  unsigned t = blockIdx.x;
+  unsigned t = block;
   if ((T & 7) == 0) t = (t & 7u) * (unsigned)(T >> 3) + (t >> 3);  // XCD-contiguous bands of tiles
   const int n = (int)(t / (unsigned)tiles_per_img);
   const int tt = (int)(t - (unsigned)n * (unsigned)tiles_per_img);
@@ -865,6 +865,43 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
     }
     if (c0 + 64 < C4) __syncthreads();  // the next channel block overwrites Ps
   }
+}
+
+template <bool FUSED, bool PAIRED, int VAR = 0>
+__global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
+    const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
+    float scale, int tiles_xs, int tiles_per_img, int T, float* __restrict__ out) {
+  fr_forward_nhwc_occ_body<FUSED, PAIRED, VAR>(a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_xs, tiles_per_img, T,
+                                               out, blockIdx.x);
+}
+
+// Several pyramid levels of the channels_last sampler / module tail as ONE grid (the levels in kernel arguments, a
+// block finds its level from the block ranges): FeatureRefineModule.forward loops over the levels
+// (fr/feature_refine_module.py:108-127) and the four coarse levels are launch-bound on their own -- 52.6 us in the
+// model for a third of level 0's bytes.
+constexpr int FRL_MAX = 8;
+struct FrNhwcLevel {
+  const float *a, *b, *res, *boxes;
+  float* out;
+  float scale;
+  int H, W, tiles_xs, tiles_per_img, T, first;
+};
+struct FrNhwcLevels {
+  FrNhwcLevel l[FRL_MAX];
+  int n;
+};
+
+template <bool FUSED>
+__global__ __launch_bounds__(512) void fr_forward_nhwc_occ_levels(const FrNhwcLevels A, const float* __restrict__ bias_a,
+                                                                  const float* __restrict__ bias_b, int C) {
+  int lv = 0;
+#pragma unroll
+  for (int i = 1; i < FRL_MAX; i++)
+    if (i < A.n && (int)blockIdx.x >= A.l[i].first) lv = i;
+  const FrNhwcLevel& L = A.l[lv];
+  fr_forward_nhwc_occ_body<FUSED, true, 14>(L.a, L.b, bias_a, bias_b, L.res, L.boxes, C, L.H, L.W, L.scale, L.tiles_xs,
+                                            L.tiles_per_img, L.T, L.out, blockIdx.x - (unsigned)L.first);
 }
 
 // "Wide" form of the kernel above for square maps whose side is a multiple of 8: 64 positions and 16 waves per
@@ -1545,6 +1582,58 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   }
 #undef R3_ARGS
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// All levels of a channels_last pass in as few launches as the kernels allow: a level that takes the wide regions
+// form (level 0 of a 1024^2 input) is launched alone, the others -- 4 x 4 tile pairs -- as ONE grid.  Pointer arrays
+// are HOST arrays; b / res may be null arrays or hold nulls as in r3k_fr_forward_nhwc (uniform over the levels).
+int r3k_fr_forward_nhwc_levels(int levels, const float* const* a, const float* const* b, const float* bias_a,
+                               const float* bias_b, const float* const* res, const float* const* boxes, int N, int C,
+                               const int* H, const int* W, const float* scales, int points, float* const* out,
+                               hipStream_t stream) {
+  if (levels < 0 || !a || !boxes || !out || !H || !W || !scales) return -1;
+  FrNhwcLevels A;
+  A.n = 0;
+  int blocks = 0;
+  bool grouped[FRL_MAX] = {};
+  const bool has_b = b && levels > 0 && b[0], has_res = res && levels > 0 && res[0];
+  const bool fused = has_b || bias_a || bias_b || has_res;
+  for (int l = 0; l < levels && levels <= FRL_MAX; l++) {
+    const int tiles_x = (W[l] + 3) / 4, tiles_y = (H[l] + NH_ROWS - 1) / NH_ROWS;
+    const bool wide = H[l] == W[l] && (H[l] & 7) == 0 && (long long)(H[l] / 8) * (H[l] / 8) * N >= 512;
+    const bool big = (unsigned long long)N * H[l] * W[l] * C * 4ull >= (1ull << 32);
+    const bool ok = points == 1 && g_r3_fr_dbg == 0 && tiles_x == tiles_y && !wide && !big && N > 0 && C > 0 && !(C & 3) &&
+                    a[l] && boxes[l] && out[l] && aligned16(a[l]) && aligned16(out[l]) &&
+                    (!has_b || (b[l] && aligned16(b[l]))) && (!has_res || (res[l] && aligned16(res[l]))) &&
+                    (!bias_a || aligned16(bias_a)) && (!bias_b || aligned16(bias_b));
+    if (!ok) continue;
+    const int tpi = tiles_x * (tiles_x - 1) / 2 + (tiles_x + 1) / 2;
+    FrNhwcLevel& L = A.l[A.n++];
+    L.a = a[l], L.b = has_b ? b[l] : nullptr, L.res = has_res ? res[l] : nullptr, L.boxes = boxes[l], L.out = out[l];
+    L.scale = scales[l], L.H = H[l], L.W = W[l], L.tiles_xs = tiles_x | (g_r3_fr_walk << 20), L.tiles_per_img = tpi;
+    L.T = tpi * N, L.first = blocks;
+    blocks += L.T;
+    grouped[l] = true;
+  }
+  if (A.n < 2) {  // nothing to group
+    A.n = 0;
+    for (int l = 0; l < levels && l < FRL_MAX; l++) grouped[l] = false;
+  }
+  for (int l = 0; l < levels; l++) {
+    if (l < FRL_MAX && grouped[l]) continue;
+    const int k = r3k_fr_forward_nhwc(a[l], has_b ? b[l] : nullptr, bias_a, bias_b, has_res ? res[l] : nullptr, boxes[l], N, C,
+                                      H[l], W[l], scales[l], points, out[l], stream);
+    if (k) return k;
+  }
+  if (A.n) {
+    for (int i = A.n; i < FRL_MAX; i++) A.l[i] = A.l[A.n - 1];
+    if (fused)
+      hipLaunchKernelGGL(fr_forward_nhwc_occ_levels<true>, dim3(blocks), dim3(512), 0, stream, A, bias_a, bias_b, C);
+    else
+      hipLaunchKernelGGL(fr_forward_nhwc_occ_levels<false>, dim3(blocks), dim3(512), 0, stream, A, bias_a, bias_b, C);
+    if (hipGetLastError() != hipSuccess) return -2;
+  }
+  return 0;
 }
 
 // The NCHW backward is a gather over the inverse tap index of the boxes (r3_frb.hip: CSR + SELL-64, whole

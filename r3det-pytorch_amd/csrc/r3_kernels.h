@@ -133,6 +133,12 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
                         const float* boxes, int N, int C, int H, int W, float scale, int points, float* out,
                         hipStream_t stream);
 
+// ... all pyramid levels of a pass: levels without the wide form as ONE grid (host arrays of device pointers)
+int r3k_fr_forward_nhwc_levels(int levels, const float* const* a, const float* const* b, const float* bias_a,
+                               const float* bias_b, const float* const* res, const float* const* boxes, int N, int C,
+                               const int* H, const int* W, const float* scales, int points, float* const* out,
+                               hipStream_t stream);
+
 // channels_last backward (r3_frb.hip): inverse tap index of the boxes + gather; points 1 or 5, any H x W with W <= 4096
 size_t r3k_frb_workspace_bytes(int N, int H, int W, int points);
 int r3k_frb_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,

@@ -57,6 +57,8 @@ SIGNATURES = {
     "r3det_feature_refine_backward_nhwc_index": [_vp, _i, _i, _i, _f, _i, _vp, _sz, _vp],
     "r3det_feature_refine_backward_nhwc_indexed": [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
     "r3det_feature_refine_forward_levels": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp],
+    "r3det_feature_refine_forward_levels_nhwc": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "r3det_feature_refine_module_levels_nhwc": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "r3det_feature_refine_backward_index_levels": [_i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "r3det_feature_refine_backward_levels_indexed": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp],
     "r3det_set_option": [ctypes.c_char_p, _i],

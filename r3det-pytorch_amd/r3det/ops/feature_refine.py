@@ -176,6 +176,61 @@ def fr_module_nhwc(conv_a, conv_b, bias_a, bias_b, residual, best_rbboxes, spati
     return _taken(rc, "fr_module_nhwc")
 
 
+def _lvl_arrays(feats, scales):
+    import ctypes
+    n = len(feats)
+    arr_i = ctypes.c_int * n
+    return (arr_i(*[f.size(2) for f in feats]), arr_i(*[f.size(3) for f in feats]),
+            (ctypes.c_float * n)(*[float(s) for s in scales]), ctypes.c_void_p * n)
+
+
+def _ptr_array(ts):
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts])
+
+
+def fr_forward_levels_nhwc(features, best_rbboxes, spatial_scales, points, outputs):
+    """The channels_last sampler of all pyramid levels in one library call
+    (r3det_feature_refine_forward_levels_nhwc): the level that takes the wide form alone, all others as ONE launch.
+    False when nothing was launched (argument shapes the library does not take)."""
+    fs = [_need_cl(f, "features") for f in features]
+    os_ = [_need_cl(o, "output") for o in outputs]
+    bs = [_C.need_hip(b, "best_bboxes") for b in best_rbboxes]
+    N, C = fs[0].shape[:2]
+    for f, b, o in zip(fs, bs, os_):
+        if f.shape[:2] != (N, C) or b.numel() != N * f.size(2) * f.size(3) * 5 or o.shape != f.shape:
+            raise RuntimeError("levels must share N and C, bring N*H*W x 5 boxes and outputs of the features' shape")
+    H, W, sc, _ = _lvl_arrays(fs, spatial_scales)
+    with torch.cuda.device(fs[0].device):
+        rc = _C.lib().r3det_feature_refine_forward_levels_nhwc(len(fs), _ptr_array(fs), _ptr_array(bs), N, C, H, W, sc,
+                                                               int(points), _ptr_array(os_), _C.stream())
+    return _taken(rc, "fr_forward_levels_nhwc")
+
+
+def fr_module_levels_nhwc(conv_a, conv_b, bias_a, bias_b, residual, best_rbboxes, spatial_scales, points, outputs):
+    """The FeatureRefineModule tail of all pyramid levels in one library call
+    (r3det_feature_refine_module_levels_nhwc); per level as ``fr_module_nhwc``.  ``conv_b`` may be None."""
+    as_ = [_need_cl(t, "conv_a") for t in conv_a]
+    rs = [_need_cl(t, "residual") for t in residual]
+    os_ = [_need_cl(t, "output") for t in outputs]
+    cbs = [_need_cl(t, "conv_b") for t in conv_b] if conv_b is not None else None
+    bs = [_C.need_hip(b, "best_bboxes") for b in best_rbboxes]
+    N, C = as_[0].shape[:2]
+    for i, (a, r, o, b) in enumerate(zip(as_, rs, os_, bs)):
+        if a.shape[:2] != (N, C) or r.shape != a.shape or o.shape != a.shape or b.numel() != N * a.size(2) * a.size(3) * 5 \
+                or (cbs is not None and cbs[i].shape != a.shape):
+            raise RuntimeError("per level: conv_a, conv_b, residual and output of one shape; best_bboxes N*H*W x 5")
+    for t, nm in ((bias_a, "bias_a"), (bias_b, "bias_b")):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.numel() != C or not t.is_contiguous()):
+            raise RuntimeError(f"{nm} must be a contiguous fp32 CUDA tensor of C values")
+    H, W, sc, _ = _lvl_arrays(as_, spatial_scales)
+    with torch.cuda.device(as_[0].device):
+        rc = _C.lib().r3det_feature_refine_module_levels_nhwc(
+            len(as_), _ptr_array(as_), _ptr_array(cbs) if cbs is not None else None, _C.ptr(bias_a), _C.ptr(bias_b),
+            _ptr_array(rs), _ptr_array(bs), N, C, H, W, sc, int(points), _ptr_array(os_), _C.stream())
+    return _taken(rc, "fr_module_levels_nhwc")
+
+
 def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, overwrite=False):
     """feature_refine_cuda.backward (feature_refine_cuda.cpp:44-66): accumulates into
     ``bottom_grad`` (``overwrite=True``: writes it, no zero-fill needed)."""
@@ -190,6 +245,28 @@ def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, over
         _C.check(L.r3det_feature_refine_backward_ws(_C.ptr(g), _C.ptr(b), N, C, H, W, float(spatial_scale),
                                                     int(points), _C.ptr(o), int(bool(overwrite)), _C.ptr(ws), wsb,
                                                     _C.stream()), "fr_backward")
+    return 1
+
+
+def fr_backward_levels(top_grads, best_rbboxes, spatial_scales, points, bottom_grads):
+    """The backward of all pyramid levels (NCHW, overwrite mode) in two library calls: the indexes of the levels' boxes
+    from one grouped launch (r3det_feature_refine_backward_index_levels), then the gathers
+    (r3det_feature_refine_backward_levels_indexed)."""
+    gs = [_C.need_hip(g, "top_grad") for g in top_grads]
+    os_ = [_C.need_hip(o, "bottom_grad") for o in bottom_grads]
+    bs = [_C.need_hip(b, "best_bboxes") for b in best_rbboxes]
+    N, C = gs[0].shape[:2]
+    H, W, sc, _ = _lvl_arrays(gs, spatial_scales)
+    L = _C.lib()
+    n = len(gs)
+    with torch.cuda.device(gs[0].device):
+        wsb = int(L.r3det_fr_backward_levels_workspace_bytes(n, N, H, W, int(points)))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=gs[0].device)
+        _C.check(L.r3det_feature_refine_backward_index_levels(n, _ptr_array(bs), N, C, H, W, sc, int(points), _C.ptr(ws),
+                                                              wsb, _C.stream()), "fr_backward_index_levels")
+        _C.check(L.r3det_feature_refine_backward_levels_indexed(n, _ptr_array(gs), _ptr_array(bs), N, C, H, W, sc,
+                                                                int(points), _ptr_array(os_), 1, _C.ptr(ws), wsb,
+                                                                _C.stream()), "fr_backward_levels_indexed")
     return 1
 
 
@@ -327,14 +404,6 @@ class FeatureRefineFunction(Function):
 feature_refine = FeatureRefineFunction.apply
 
 
-def _lvl_arrays(feats, scales):
-    import ctypes
-    n = len(feats)
-    arr_i = ctypes.c_int * n
-    return (arr_i(*[f.size(2) for f in feats]), arr_i(*[f.size(3) for f in feats]),
-            (ctypes.c_float * n)(*[float(s) for s in scales]), ctypes.c_void_p * n)
-
-
 class FeatureRefineLevelsFunction(Function):
     """The sampler of ALL pyramid levels as one autograd node (NCHW): one library call for the samplers
     (r3det_feature_refine_forward_levels), one for the backward's indexes of the boxes -- built here, where the boxes
@@ -456,6 +525,22 @@ class FeatureRefineModule(nn.Module):
             sampled = feature_refine_levels(mixed, [b.contiguous() for b in per_level],
                                             [fr.spatial_scale for fr in self.fr], self.fr[0].points)
             return [f + o for f, o in zip(x, sampled)]
+        if all(nhwc) and len({f.shape[:2] for f in x}) == 1 and len({fr.points for fr in self.fr}) == 1:
+            # channels_last inference: the module tail of ALL levels in one library call -- level 0 (the wide regions
+            # form) one launch, the coarse levels together one more -- on channels_last memory: the two convolutions'
+            # bias adds, their sum, the sampler and the residual add (3 reads + 1 write per element); the results feed
+            # the refine head's channels_last convolutions directly
+            ras = [F.conv2d(self.conv_1_5(f), self.conv_5_1.weight, None, self.conv_5_1.stride, self.conv_5_1.padding)
+                   for f in x]
+            rbs = [F.conv2d(f, self.conv_1_1.weight, None, self.conv_1_1.stride, self.conv_1_1.padding) for f in x]
+            if all(is_cl(t) for t in ras) and all(is_cl(t) for t in rbs):
+                fused = [torch.empty_like(f) for f in x]  # (preserves channels_last)
+                if fr_module_levels_nhwc(ras, rbs, self.conv_5_1.bias, self.conv_1_1.bias, x,
+                                         [b.contiguous() for b in per_level], [fr.spatial_scale for fr in self.fr],
+                                         self.fr[0].points, fused):
+                    return fused
+            if NHWC_ONLY:
+                raise RuntimeError("channels_last FR module path not taken")
         # tap tables of the NCHW levels first: each sampler call below is then a single launch with no
         # dependent launch in front of it (the channels_last launch derives its taps from the boxes itself)
         # (channels_last training levels take the NHWC sampler, which needs no table either)

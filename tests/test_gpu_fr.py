@@ -361,6 +361,41 @@ def test_forward_levels_equals_per_level_calls(points):
         fr_forward_levels(feats, boxes[::-1], scales, points, outs)
 
 
+@pytest.mark.parametrize("NC", [(4, 256), (2, 64), (1, 12)])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_nhwc_levels_calls_equal_per_level_calls(NC, adversarial):
+    """r3det_feature_refine_forward_levels_nhwc / _module_levels_nhwc (level 0 in the wide form alone, the coarse levels
+    as ONE grid over their tile pairs) == one r3det_feature_refine_forward_nhwc / _module_nhwc call per level, bit for
+    bit; points = 5 (no grouped form) goes level by level inside the same call."""
+    from r3det import synthetic as syn
+    from r3det.ops.feature_refine import (fr_forward_levels_nhwc, fr_forward_nhwc, fr_module_levels_nhwc,
+                                          fr_module_nhwc)
+    N, C = NC
+    cl = torch.channels_last
+    feats, boxes = syn.fr_pyramid(N, C, 7, adversarial=adversarial, device='cuda')
+    g = torch.Generator(device='cuda').manual_seed(11)
+    mk = lambda f: torch.randn(f.shape, device='cuda', generator=g).contiguous(memory_format=cl)  # noqa: E731
+    a, b, r = [mk(f) for f in feats], [mk(f) for f in feats], [f.contiguous(memory_format=cl) for f in feats]
+    ba, bb = torch.randn(C, device='cuda', generator=g), torch.randn(C, device='cuda', generator=g)
+    scales = [1.0 / s for s in syn.STRIDES]
+    for points in (1, 5):
+        outs = [torch.full_like(t, float('nan')) for t in a]
+        assert fr_forward_levels_nhwc(a, boxes, scales, points, outs)
+        for t, bx, sc, o in zip(a, boxes, scales, outs):
+            want = torch.empty_like(t)
+            assert fr_forward_nhwc(t, bx, sc, points, want)
+            assert torch.equal(o, want)
+        for cb in (b, None):
+            outs = [torch.full_like(t, float('nan')) for t in a]
+            assert fr_module_levels_nhwc(a, cb, ba, bb, r, boxes, scales, points, outs)
+            for i, (t, rr, bx, sc, o) in enumerate(zip(a, r, boxes, scales, outs)):
+                want = torch.empty_like(t)
+                assert fr_module_nhwc(t, cb[i] if cb is not None else None, ba, bb, rr, bx, sc, points, want)
+                assert torch.equal(o, want)
+    with pytest.raises(RuntimeError):
+        fr_forward_levels_nhwc(a, boxes[::-1], scales, 1, outs)
+
+
 @pytest.mark.parametrize("shape", [(2, 512, 128, 128, 8), (1, 1024, 128, 128, 8), (3, 512, 64, 64, 16)])
 @pytest.mark.parametrize("adversarial", [False, True])
 def test_module_fused_sampler_bit_identical(shape, adversarial):
