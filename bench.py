@@ -88,11 +88,14 @@ def build_model(device, seed, kind="R3Det", batch=BATCH):
     return model, img
 
 
-def model_step(model, img):
+def model_step(model, img, batch_size=None):
+    """One inference step of a rank and the step's ONE exchange.  ``batch_size``: the configured per-rank batch (every
+    rank passes the same value; default: this rank's batch -- the bench's ranks all run the same synthetic batch): a
+    rank's short last batch is padded to it inside gather_detections with no extra collective and no host read."""
     from r3det import dist_infer as di
     res = model.simple_test(img)
     packed, counts = di.pack_detections([r[0] for r in res], [r[1] for r in res], MAX_PER_IMG)
-    di.gather_detections(packed, counts)  # (pads a short batch to the ranks' maximum itself)
+    di.gather_detections(packed, counts, batch_size=img.size(0) if batch_size is None else batch_size)
     return counts
 
 

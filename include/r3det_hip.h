@@ -457,15 +457,21 @@ int r3det_convex_sort(const float* pts, const unsigned char* masks, int B, int P
 int r3det_bias_act(float* y, const float* bias, const float* residual, long long outer, int C, long long inner,
                    int relu, void* stream);
 
-/* Kernel-selection knobs for A/B measurements and for the tests of rarely taken paths (not part of the
- * reference surface).  r3det_set_option("fr_impl", 0 auto | 1 generic | 2 lds-plane | 10 cell),
- * ("iou_impl", 0 auto | 1 one thread per pair | 2 one-launch tile kernel | 4 stream + drain always),
- * ("iou_small", columns from which the pipeline runs), ("iou_qcap", n: per-wave survivor capacity, small values
- * force the dense-tile path), ("iou_dwgs", drain workgroups), ("nms_impl", 0 | 1 tiles), ("nms_qcap", n: entries
- * per queue region, small values force the redo-tile path), ("fr_profile", 0 | 1 every kernel | 2 first start
- * and last stop only), ("fr_dbg", NCHW: 0 | 1 taps from the table kernel | 2 taps derived in the sampler;
- * NHWC: 1 no tile pairing | 2 the register-pipelined kernel | 9 the 4 x 4 tile pairs instead of the wide regions), ("fr_walk", strip height of the tile-pair launch
- * order of the channels_last sampler kernels, 0 row-major, default 8). */
+/* Kernel-selection switches for the tests of rarely taken paths (not part of the reference surface).  Each is read
+ * once per library call.  What the PRODUCT library knows:
+ *   ("fr_impl", 0 auto | 1 generic | 2 lds-plane | 10 cell)      NCHW sampler forward; backward: != 0 = scatter kernels
+ *   ("fr_dbg", 0 auto | 8 wide regions | 9 4 x 4 tile pairs)     channels_last sampler forward form
+ *   ("fr_walk", n)       strip height of the tile-pair launch order of the channels_last kernels (0 row-major, default 8)
+ *   ("fr_profile", 0 | 1 every kernel | 2 first start and last stop only)      see r3det_fr_profile_read
+ *   ("frb_impl", 0 auto | 1 general index form | 2 unpaired NHWC gather | 3 SELL rows by their own launch |
+ *                5 SELL rows and CSR lists from one launch | 6 pyramid levels indexed one by one)
+ *   ("iou_impl", 0 auto | 1 one thread per pair | 2 one-launch tile kernel | 4 stream + drain always),
+ *   ("iou_small", columns from which the pipeline runs), ("iou_qcap", n: per-wave survivor capacity, small values
+ *   force the dense-tile path), ("iou_dwgs", drain workgroups), ("nms_impl", 0 | 1 tiles | 2 one reducer workgroup),
+ *   ("nms_qcap", n: entries per queue region, small values force the redo-tile path).
+ * Launch variants that were measured and not shipped, and clock stamps inside kernels, exist only in the probes build
+ * of the same sources (`make probes`: libr3det_hip_probes.so, -DR3_PROBES; tools/ load it through R3DET_HIP_LIB);
+ * the product library reads their option values as 0. */
 int r3det_set_option(const char* name, int value);
 
 /* Measurement aid for bench.py (not part of the reference surface).  With option "fr_profile" = 1

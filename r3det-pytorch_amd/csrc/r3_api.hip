@@ -27,6 +27,26 @@ int r3_cu_count() {
 
 namespace {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// The device of a call is the device of its stream (the reference's extensions take a CUDAGuard on their tensors'
+// device, e.g. box_iou_rotated_cuda.cu:77, nms_rotated_cuda.cu:79): kernels are launched, attributes set and the
+// compute-unit count read on THAT device, whatever device is current for the caller, and the caller's current device
+// is restored on return.  The null stream belongs to the current device.
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(void* stream) {
+    if (!stream) return;
+    hipDevice_t dev = 0;
+    int cur = 0;
+    if (hipStreamGetDevice(S(stream), &dev) != hipSuccess || hipGetDevice(&cur) != hipSuccess || dev == cur) return;
+    if (hipSetDevice(dev) == hipSuccess) prev = cur;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 inline int rc(int k) {
   switch (k) {
     case 0: return R3DET_OK;
@@ -61,12 +81,14 @@ size_t r3det_iou_workspace_bytes(int n1, int n2) { return r3k_iou_workspace_byte
 
 int r3det_rbbox_geo_mat_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
                                 float* out, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (bad_iou_args(rb1, n1, rb2, n2, out)) return R3DET_EINVAL;
   return rc(r3k_iou_mat(R3DET_GEOM_V1, iof != 0, rb1, n1, rb2, n2, out, ws, ws_bytes, S(stream)));
 }
 
 int r3det_rbbox_geo_vec_iou_iof(const float* rb1, int n1, const float* rb2, int n2, int iof,
                                 float* out, void* stream) {
+  const DeviceGuard guard(stream);
   if (bad_iou_args(rb1, n1, rb2, n2, out)) return R3DET_EINVAL;
   return rc(r3k_iou_vec(R3DET_GEOM_V1, iof != 0, rb1, n1, rb2, n2, out, S(stream)));
 }
@@ -74,12 +96,14 @@ int r3det_rbbox_geo_vec_iou_iof(const float* rb1, int n1, const float* rb2, int 
 int r3det_box_iou_rotated_overlaps(const float* b1, int n1, const float* b2, int n2,
                                    int iou_or_iof, float* out, void* ws, size_t ws_bytes,
                                    void* stream) {
+  const DeviceGuard guard(stream);
   if (bad_iou_args(b1, n1, b2, n2, out)) return R3DET_EINVAL;
   return rc(r3k_iou_mat(R3DET_GEOM_V3, iou_or_iof == 0, b1, n1, b2, n2, out, ws, ws_bytes, S(stream)));
 }
 
 int r3det_obb_overlaps(const float* b1, int n1, const float* b2, int n2, int iou_or_iof, float* out, void* ws,
                        size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (bad_iou_args(b1, n1, b2, n2, out)) return R3DET_EINVAL;
   const int r = r3k_iou_mat(R3DET_GEOM_V3, iou_or_iof == 0, b1, n1, b2, n2, out, ws, ws_bytes, S(stream));
   if (r) return rc(r);
@@ -88,12 +112,14 @@ int r3det_obb_overlaps(const float* b1, int n1, const float* b2, int n2, int iou
 
 int r3det_box_iou_rotated_overlaps_aligned(const float* b1, const float* b2, int n,
                                            int iou_or_iof, float* out, void* stream) {
+  const DeviceGuard guard(stream);
   if (bad_iou_args(b1, n, b2, n, out)) return R3DET_EINVAL;
   return rc(r3k_iou_vec(R3DET_GEOM_V3, iou_or_iof == 0, b1, n, b2, n, out, S(stream)));
 }
 
 int r3det_mmcv_box_iou_rotated(const float* b1, int n1, const float* b2, int n2, int mode_flag,
                                int aligned, float* out, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (bad_iou_args(b1, n1, b2, n2, out)) return R3DET_EINVAL;
   if (mode_flag != 0 && mode_flag != 1) return R3DET_EINVAL;
   if (aligned) {
@@ -112,6 +138,7 @@ int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes,
                        int64_t* assigned_gt_inds, float* max_overlaps, int64_t* argmax_overlaps,
                        float* gt_max_overlaps, int64_t* gt_argmax_overlaps, void* ws, size_t ws_bytes,
                        void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_iou_assign(geom, gts, n_gt, boxes, n_boxes, pos_iou_thr, neg_iou_thr, min_pos_iou,
                            match_low_quality, gt_max_assign_all, assigned_gt_inds, max_overlaps, argmax_overlaps,
                            gt_max_overlaps, gt_argmax_overlaps, ws, ws_bytes, S(stream)));
@@ -121,12 +148,14 @@ size_t r3det_nms_workspace_bytes(int n) { return r3k_nms_workspace_bytes(n); }
 
 int r3det_rnms(const float* dets6, const int64_t* order, int n, float thr, int sort_ascending,
                void* ws, size_t ws_bytes, int64_t* keep_out, int32_t* count_out, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_nms(R3DET_GEOM_V1, dets6, 6, nullptr, order, n, thr, sort_ascending, ws, ws_bytes,
                     keep_out, count_out, S(stream)));
 }
 
 int r3det_nms_rotated(const float* dets5, const int64_t* order, int n, float thr, void* ws,
                       size_t ws_bytes, int64_t* keep_out, int32_t* count_out, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_nms(R3DET_GEOM_V3, dets5, 5, nullptr, order, n, thr, 0, ws, ws_bytes, keep_out,
                     count_out, S(stream)));
 }
@@ -134,6 +163,7 @@ int r3det_nms_rotated(const float* dets5, const int64_t* order, int n, float thr
 int r3det_ml_nms_rotated(const float* dets5, const int64_t* labels, const int64_t* order, int n,
                          float thr, void* ws, size_t ws_bytes, int64_t* keep_out,
                          int32_t* count_out, void* stream) {
+  const DeviceGuard guard(stream);
   if (n > 0 && !labels) return R3DET_EINVAL;
   return rc(r3k_nms(R3DET_GEOM_V2, dets5, 5, labels, order, n, thr, 0, ws, ws_bytes, keep_out,
                     count_out, S(stream)));
@@ -142,6 +172,7 @@ int r3det_ml_nms_rotated(const float* dets5, const int64_t* labels, const int64_
 int r3det_mmcv_nms_rotated(const float* dets5, const int64_t* labels, const int64_t* order, int n,
                            float thr, void* ws, size_t ws_bytes, int64_t* keep_out,
                            int32_t* count_out, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_nms(R3DET_GEOM_V2, dets5, 5, labels, order, n, thr, 0, ws, ws_bytes, keep_out,
                     count_out, S(stream)));
 }
@@ -151,6 +182,7 @@ size_t r3det_mcnms_select_workspace_bytes(int B, int n) { return r3k_mcnms_selec
 int r3det_mcnms_select(const float* boxes, const float* scores, int B, int n, int K, float score_thr,
                        int32_t* cand_row, int32_t* cand_label, float* cand_score, int32_t* cand_rank,
                        int32_t* counts, float* maxc, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_mcnms_select(boxes, scores, B, n, K, score_thr, cand_row, cand_label, cand_score, cand_rank, counts,
                              maxc, ws, ws_bytes, S(stream)));
 }
@@ -162,6 +194,7 @@ int r3det_mcnms_v1(const float* boxes, int B, int n, int K, const int32_t* cand_
                    const int32_t* counts, const float* maxc, int cap, float iou_thr, int out_cap, void* ws,
                    size_t ws_bytes, float* dets_out, int64_t* labels_out, int64_t* keep_idx_out,
                    int32_t* counts_out, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_mcnms_v1(boxes, B, n, K, cand_row, cand_label, cand_score, cand_rank, counts, maxc, cap, iou_thr,
                          out_cap, ws, ws_bytes, dets_out, labels_out, keep_idx_out, counts_out, S(stream)));
 }
@@ -170,6 +203,7 @@ int r3det_mcnms(int nms_type, const float* boxes, int B, int n, int K, const int
                 const int32_t* cand_label, const float* cand_score, int32_t* cand_rank, const int32_t* counts,
                 const float* maxc, int cap, float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out,
                 int64_t* labels_out, int64_t* keep_idx_out, int32_t* counts_out, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_mcnms_run(nms_type, boxes, B, n, K, cand_row, cand_label, cand_score, cand_rank, counts, maxc, cap,
                           iou_thr, out_cap, ws, ws_bytes, dets_out, labels_out, keep_idx_out, counts_out, S(stream)));
 }
@@ -178,12 +212,14 @@ size_t r3det_batched_rnms_workspace_bytes(int n) { return r3k_batched_rnms_works
 
 int r3det_batched_rnms(const float* bboxes, const float* scores, const int64_t* inds, int n, float nms_thr, void* ws,
                        size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, void* stream) {
+  const DeviceGuard guard(stream);
   if (n == 0) return R3DET_OK;
   return rc(r3k_batched_nms(1, bboxes, scores, inds, n, nms_thr, ws, ws_bytes, dets_out, keep_out, kept_out, S(stream)));
 }
 
 int r3det_obb_batched_nms(const float* bboxes, const float* scores, const int64_t* inds, int n, float nms_thr, void* ws,
                           size_t ws_bytes, float* dets_out, int64_t* keep_out, int32_t* kept_out, void* stream) {
+  const DeviceGuard guard(stream);
   if (n == 0) return R3DET_OK;
   return rc(r3k_batched_nms(3, bboxes, scores, inds, n, nms_thr, ws, ws_bytes, dets_out, keep_out, kept_out, S(stream)));
 }
@@ -195,6 +231,7 @@ size_t r3det_fr_workspace_bytes(int N, int H, int W, int points) {
 int r3det_feature_refine_forward(const float* features, const float* best_bboxes, int N, int C,
                                  int H, int W, float spatial_scale, int points, float* output,
                                  void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
   if ((size_t)N * C * H * W > 0 && (!features || !best_bboxes || !output)) return R3DET_EINVAL;
   return rc(r3k_fr_forward(features, best_bboxes, N, C, H, W, spatial_scale, points, output, ws,
@@ -205,22 +242,26 @@ size_t r3det_fr_table_bytes(int N, int H, int W) { return r3k_fr_table_bytes(N, 
 
 int r3det_feature_refine_prepare(const float* best_bboxes, int N, int H, int W, float spatial_scale, float* table,
                                  void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_fr_prepare(best_bboxes, N, H, W, spatial_scale, table, S(stream)));
 }
 
 int r3det_feature_refine_forward_prepared(const float* features, const float* table, int N, int C, int H, int W,
                                           float* output, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_fr_forward_prepared(features, nullptr, nullptr, table, N, C, H, W, output, S(stream)));
 }
 
 int r3det_frm_mix_nchw(const float* a_nhwc, const float* b_nhwc, const float* bias_a, const float* bias_b, int N,
                        int C, int H, int W, float* out_nchw, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_mix_to_nchw(a_nhwc, b_nhwc, bias_a, bias_b, N, C, H, W, out_nchw, S(stream)));
 }
 
 int r3det_feature_refine_module_prepared(const float* mixed_a, const float* mixed_b, const float* residual,
                                          const float* table, int N, int C, int H, int W, float* output,
                                          void* stream) {
+  const DeviceGuard guard(stream);
   if (!mixed_a || !residual) return R3DET_EINVAL;
   return rc(r3k_fr_forward_prepared(mixed_a, mixed_b, residual, table, N, C, H, W, output, S(stream)));
 }
@@ -233,6 +274,7 @@ int r3det_level_pool(const float* cls_score, const long long* cls_strides, const
                      const long long* reg_strides, const float* anchors, int anchors_per_image, int N, int A, int C,
                      int H, int W, int nms_pre, float max_ratio, float max_x, float max_y, float* pool_boxes,
                      float* pool_scores, int pool_rows, int row_offset, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_level_pool(cls_score, cls_strides, bbox_pred, reg_strides, anchors, anchors_per_image, N, A, C, H, W,
                            nms_pre, max_ratio, max_x, max_y, pool_boxes, pool_scores, pool_rows, row_offset, ws, ws_bytes,
                            S(stream)));
@@ -247,6 +289,7 @@ int r3det_levels_pool(int num_levels, const float* const* cls_scores, const long
                       int anchors_per_image, int N, const int* A, int C, const int* H, const int* W, int nms_pre,
                       float max_ratio, float max_x, float max_y, float* pool_boxes, float* pool_scores, int pool_rows,
                       void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_levels_pool(num_levels, cls_scores, cls_strides, bbox_preds, reg_strides, anchors, anchors_per_image, N, A,
                             C, H, W, nms_pre, max_ratio, max_x, max_y, pool_boxes, pool_scores, pool_rows, 0, ws, ws_bytes,
                             S(stream)));
@@ -254,6 +297,7 @@ int r3det_levels_pool(int num_levels, const float* const* cls_scores, const long
 
 int r3det_feature_refine_forward_nhwc(const float* features, const float* best_bboxes, int N, int C, int H, int W,
                                       float spatial_scale, int points, float* output, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_fr_forward_nhwc(features, nullptr, nullptr, nullptr, nullptr, best_bboxes, N, C, H, W, spatial_scale,
                                 points, output, S(stream)));
 }
@@ -262,6 +306,7 @@ int r3det_feature_refine_module_nhwc(const float* conv_a, const float* conv_b, c
                                      const float* bias_b, const float* residual, const float* best_bboxes, int N,
                                      int C, int H, int W, float spatial_scale, int points, float* output,
                                      void* stream) {
+  const DeviceGuard guard(stream);
   if (!conv_a || !residual) return R3DET_EINVAL;
   return rc(r3k_fr_forward_nhwc(conv_a, conv_b, bias_a, bias_b, residual, best_bboxes, N, C, H, W, spatial_scale,
                                 points, output, S(stream)));
@@ -270,6 +315,7 @@ int r3det_feature_refine_module_nhwc(const float* conv_a, const float* conv_b, c
 int r3det_feature_refine_forward_levels_nhwc(int levels, const float* const* features, const float* const* best_bboxes,
                                              int N, int C, const int* H, const int* W, const float* spatial_scales,
                                              int points, float* const* outputs, void* stream) {
+  const DeviceGuard guard(stream);
   if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
   return rc(r3k_fr_forward_nhwc_levels(levels, features, nullptr, nullptr, nullptr, nullptr, best_bboxes, N, C, H, W,
                                        spatial_scales, points, outputs, S(stream)));
@@ -279,6 +325,7 @@ int r3det_feature_refine_module_levels_nhwc(int levels, const float* const* conv
                                             const float* bias_a, const float* bias_b, const float* const* residual,
                                             const float* const* best_bboxes, int N, int C, const int* H, const int* W,
                                             const float* spatial_scales, int points, float* const* outputs, void* stream) {
+  const DeviceGuard guard(stream);
   if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5) || (levels > 0 && (!conv_a || !residual)))
     return R3DET_EINVAL;
   for (int l = 0; l < levels; l++)
@@ -296,6 +343,7 @@ size_t r3det_fr_levels_workspace_bytes(int levels, int N, const int* H, const in
 int r3det_feature_refine_forward_levels(int levels, const float* const* features, const float* const* best_bboxes,
                                         int N, int C, const int* H, const int* W, const float* spatial_scales,
                                         int points, float* const* outputs, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (levels < 0 || N < 0 || C < 0 || (levels > 0 && (!features || !best_bboxes || !H || !W || !spatial_scales || !outputs)))
     return R3DET_EINVAL;
   if (ws && ws_bytes < r3det_fr_levels_workspace_bytes(levels, N, H, W, points)) return R3DET_EWS;
@@ -313,6 +361,7 @@ int r3det_feature_refine_forward_levels(int levels, const float* const* features
 int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxes, int N, int C,
                                   int H, int W, float spatial_scale, int points,
                                   float* bottom_grad, int overwrite, void* stream) {
+  const DeviceGuard guard(stream);
   if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
   if ((size_t)N * C * H * W > 0 && (!top_grad || !best_bboxes || !bottom_grad)) return R3DET_EINVAL;
   return rc(r3k_fr_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, points, bottom_grad,
@@ -326,6 +375,7 @@ size_t r3det_fr_backward_workspace_bytes(int N, int H, int W, int points) {
 int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bboxes, int N, int C, int H, int W,
                                      float spatial_scale, int points, float* bottom_grad, int overwrite, void* ws,
                                      size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (N < 0 || C < 0 || H < 0 || W < 0) return R3DET_EINVAL;
   if ((size_t)N * C * H * W > 0 && (!top_grad || !best_bboxes || !bottom_grad)) return R3DET_EINVAL;
   return rc(r3k_fr_backward(top_grad, best_bboxes, N, C, H, W, spatial_scale, points, bottom_grad,
@@ -334,12 +384,14 @@ int r3det_feature_refine_backward_ws(const float* top_grad, const float* best_bb
 
 int r3det_feature_refine_backward_index(const float* best_bboxes, int N, int C, int H, int W, float spatial_scale,
                                         int points, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
   return rc(r3k_frn_index(best_bboxes, N, C, H, W, spatial_scale, points, ws, ws_bytes, S(stream)));
 }
 
 int r3det_feature_refine_backward_indexed(const float* top_grad, int N, int C, int H, int W, int points,
                                           float* bottom_grad, int overwrite, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5) || !top_grad || !bottom_grad || !ws)
     return R3DET_EINVAL;
   return rc(r3k_frn_gather(top_grad, N, C, H, W, points, bottom_grad, overwrite, ws, ws_bytes, S(stream)));
@@ -363,6 +415,7 @@ size_t r3det_fr_backward_levels_workspace_bytes(int levels, int N, const int* H,
 int r3det_feature_refine_backward_index_levels(int levels, const float* const* best_bboxes, int N, int C, const int* H,
                                                const int* W, const float* spatial_scales, int points, void* ws,
                                                size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5) ||
       (levels > 0 && (!best_bboxes || !H || !W || !spatial_scales)))
     return R3DET_EINVAL;
@@ -395,6 +448,7 @@ int r3det_feature_refine_backward_levels_indexed(int levels, const float* const*
                                                  const int* W, const float* spatial_scales, int points,
                                                  float* const* bottom_grads, int overwrite, void* ws, size_t ws_bytes,
                                                  void* stream) {
+  const DeviceGuard guard(stream);
   if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5) ||
       (levels > 0 && (!top_grads || !best_bboxes || !H || !W || !spatial_scales || !bottom_grads)))
     return R3DET_EINVAL;
@@ -420,6 +474,7 @@ size_t r3det_fr_backward_nhwc_workspace_bytes(int N, int H, int W, int points) {
 int r3det_feature_refine_backward_nhwc(const float* top_grad, const float* best_bboxes, int N, int C, int H, int W,
                                        float spatial_scale, int points, float* bottom_grad, int overwrite, void* ws,
                                        size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (N < 0 || C < 0 || H < 0 || W < 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
   if ((size_t)N * C * H * W == 0) return R3DET_OK;
   if (!top_grad || !best_bboxes || !bottom_grad || !ws) return R3DET_EINVAL;
@@ -429,6 +484,7 @@ int r3det_feature_refine_backward_nhwc(const float* top_grad, const float* best_
 
 int r3det_feature_refine_backward_nhwc_index(const float* best_bboxes, int N, int H, int W, float spatial_scale,
                                              int points, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
   if (N <= 0 || H <= 0 || W <= 0) return R3DET_EINVAL;
   return rc(r3k_frb_index(best_bboxes, N, H, W, spatial_scale, points, ws, ws_bytes, S(stream)));
 }
@@ -436,6 +492,7 @@ int r3det_feature_refine_backward_nhwc_index(const float* best_bboxes, int N, in
 int r3det_feature_refine_backward_nhwc_indexed(const float* top_grad, int N, int C, int H, int W, int points,
                                                float* bottom_grad, int overwrite, void* ws, size_t ws_bytes,
                                                void* stream) {
+  const DeviceGuard guard(stream);
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || !top_grad || !bottom_grad || !ws) return R3DET_EINVAL;
   return rc(r3k_frb_backward(top_grad, nullptr, N, C, H, W, 0.f, points, bottom_grad, overwrite, ws, ws_bytes, 1,
                              S(stream)));
@@ -445,16 +502,19 @@ int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, co
                         const long long* pred_strides, const float* anchors, int anchors_per_image, int N,
                         int num_anchors, int num_classes, int H, int W, float max_ratio, float* boxes_out,
                         void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_filter_bboxes(cls_score, cls_strides, bbox_pred, pred_strides, anchors, anchors_per_image, N,
                               num_anchors, num_classes, H, W, max_ratio, boxes_out, S(stream)));
 }
 
 int r3det_polygon_iou(const float* polys_a, int na, const float* polys_b, int nb, float* out, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_polygon_iou(polys_a, na, polys_b, nb, out, S(stream)));
 }
 
 int r3det_poly_iou_mat(const float* a, int na, int stride_a, const float* b, int nb, int stride_b, float* out,
                        void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_poly_iou_mat(a, na, stride_a, b, nb, stride_b, out, S(stream)));
 }
 
@@ -462,16 +522,19 @@ size_t r3det_poly_nms_workspace_bytes(int n) { return r3k_poly_nms_workspace_byt
 
 int r3det_nms_poly(const float* dets9, const int64_t* order, int n, float thr, void* ws, size_t ws_bytes,
                    int64_t* keep_out, int32_t* count_out, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_poly_nms(dets9, order, n, thr, ws, ws_bytes, keep_out, count_out, S(stream)));
 }
 
 int r3det_convex_sort(const float* pts, const unsigned char* masks, int B, int P, int circular, void* ws,
                       size_t ws_bytes, int64_t* index_out, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_convex_sort(pts, masks, B, P, circular, ws, ws_bytes, index_out, S(stream)));
 }
 
 int r3det_bias_act(float* y, const float* bias, const float* residual, long long outer, int C, long long inner,
                    int relu, void* stream) {
+  const DeviceGuard guard(stream);
   return rc(r3k_bias_act(y, bias, residual, outer, C, inner, relu, S(stream)));
 }
 

@@ -31,7 +31,7 @@
 #include "r3_trig.h"
 
 int g_r3_fr_impl = 0;
-int g_r3_fr_dbg = 0;  // spare switch for kernel experiments (unused by the shipped kernels)
+int g_r3_fr_dbg = 0;  // launch form of the forward kernels (r3_kernels.h r3_fr_dbg)
 int g_r3_fr_walk = 8; // strip height of the tile-pair walk (r3_fr_tap.h pair_walk; 0: row-major)
 int g_r3_fr_profile = 0;  // 1: cell-path launches record their own start / stop events
 
@@ -1366,7 +1366,8 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
   const bool have_ws = ws && ws_bytes >= r3k_fr_workspace_bytes(N, H, W, points) && aligned16(ws);
   // measured at N = 4 (tools/fr_dbg_sweep.py): 128 x 128 table 26.4 us vs boxes 27.2 (the 20-byte-strided box
   // reads make the prologue 2.5 x heavier than the 8-byte table); 64 x 64 boxes 12.7 vs table 15.6, plane 13.7
-  const bool from_boxes = g_r3_fr_dbg == 2 || (g_r3_fr_dbg != 1 && W == 64) || !have_ws;
+  const int dbg = r3_fr_dbg();  // (read once per call)
+  const bool from_boxes = dbg == 2 || (dbg != 1 && W == 64) || !have_ws;
   if ((g_r3_fr_impl == 10 || cell_auto) && points == 1 && cell_shape && G >= 2 && aligned16(feat) && aligned16(out)) {
     float* table = reinterpret_cast<float*>(ws);
     const int total = N * H * W;
@@ -1374,8 +1375,10 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
     if (once.first()) {
       allow_big_lds(fr_forward_cell<7, 7, 1024, false>, 160 * 1024);
       allow_big_lds(fr_forward_cell<7, 7, 1024, true>, 160 * 1024);
+#ifdef R3_PROBES
       allow_big_lds(fr_forward_cell<7, 7, 1024, false, 0, false>, 160 * 1024);
       allow_big_lds(fr_forward_cell<7, 7, 1024, true, 0, false>, 160 * 1024);
+#endif
     }
     const size_t lds = (size_t)2 * ((((size_t)H + 3) * (W + 1) + 3) & ~(size_t)3) * sizeof(float);
     // profiling mode (r3det_set_option("fr_profile", 1 | 2)): the launches carry their own start /
@@ -1390,11 +1393,16 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
       hipExtLaunchKernelGGL(fr_cell_table_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t0, t1, 0, boxes, N,
                             H, W, scale, table);
     // (64 x 64 with 512- or 256-thread workgroups, several per CU, measured 1-5 % slower than 1024)
+#ifdef R3_PROBES  // (fr_dbg 21: plain instead of non-temporal plane loads / stores, tools/fr_nchw_nt_ab.py)
 #define R3_CELL(LW, LH, FB, SRC) \
   do { \
-    if (g_r3_fr_dbg == 21) hipExtLaunchKernelGGL((fr_forward_cell<LW, LH, 1024, FB, 0, false>), grid, block, lds, stream, c0, c1, 0, feat, SRC, C, G, scale, out, (const float*)nullptr, (const float*)nullptr); \
+    if (dbg == 21) hipExtLaunchKernelGGL((fr_forward_cell<LW, LH, 1024, FB, 0, false>), grid, block, lds, stream, c0, c1, 0, feat, SRC, C, G, scale, out, (const float*)nullptr, (const float*)nullptr); \
     else hipExtLaunchKernelGGL((fr_forward_cell<LW, LH, 1024, FB>), grid, block, lds, stream, c0, c1, 0, feat, SRC, C, G, scale, out, (const float*)nullptr, (const float*)nullptr); \
   } while (0)
+#else
+#define R3_CELL(LW, LH, FB, SRC) \
+  hipExtLaunchKernelGGL((fr_forward_cell<LW, LH, 1024, FB>), grid, block, lds, stream, c0, c1, 0, feat, SRC, C, G, scale, out, (const float*)nullptr, (const float*)nullptr)
+#endif
     if (W == 128) { if (from_boxes) R3_CELL(7, 7, true, boxes); else R3_CELL(7, 7, false, table); }
     else { if (from_boxes) R3_CELL(6, 6, true, boxes); else R3_CELL(6, 6, false, table); }
 #undef R3_CELL
@@ -1501,10 +1509,11 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   const bool fused = b || bias_a || bias_b || res;
   // points = 1: the pipelined kernel on 4 x 4 tiles (square maps: transposed tile pairs per workgroup; fr_dbg 1
   // switches the pairing off for A/B runs); points = 5: the simple kernel
-  const bool occ = points == 1 && g_r3_fr_dbg != 2;  // fr_dbg 2: the register-pipelined kernel (A/B runs)
+  const int dbg = r3_fr_dbg();  // (read once per call)
+  const bool occ = points == 1 && dbg != 2;  // fr_dbg 2 (probes builds): the register-pipelined kernel
   const int kw = 4, kh = NH_ROWS;
   const int tiles_x = (W + kw - 1) / kw, tiles_y = (H + kh - 1) / kh;
-  const bool paired = points == 1 && tiles_x == tiles_y && g_r3_fr_dbg != 1;
+  const bool paired = points == 1 && tiles_x == tiles_y && dbg != 1;
   const int tpi = !paired ? tiles_x * tiles_y
                   : occ ? tiles_x * (tiles_x - 1) / 2 + (tiles_x + 1) / 2 : tiles_x * (tiles_x + 1) / 2;
   const long long T = (long long)tpi * N;
@@ -1517,7 +1526,7 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   // ... when that makes at least 512 workgroups (two per CU): 32 x 32 maps at N = 4 are 64 wide workgroups against
   // 144 pairs, 16.0 against 11.7 us inside the model; fr_dbg 8 forces the wide form (tests)
   if (occ && paired && H == W && (H & 7) == 0 &&
-      ((g_r3_fr_dbg == 0 && (long long)(H / 8) * (H / 8) * N >= 512) || g_r3_fr_dbg == 8) &&
+      ((dbg == 0 && (long long)(H / 8) * (H / 8) * N >= 512) || dbg == 8) &&
       (unsigned long long)N * H * W * C * 4ull < (1ull << 32)) {
     const int S = H / 8;
     const long long Tw = (long long)S * S * N;
@@ -1548,10 +1557,10 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     // unchanged FETCH.  What is left above the algorithmic bytes (+45 MB of 207 MB read) is exactly the out-of-tile
     // tap rows of about half the tile edges (fields without such taps: FETCH = 204 MB), whatever the launch order.
     const bool big = (unsigned long long)N * H * W * C * 4ull >= (1ull << 32);  // (32-bit byte offsets inside an image)
-    const int var = (g_r3_fr_dbg == 3 || big) ? 0 : g_r3_fr_dbg == 4 ? 1 : g_r3_fr_dbg == 5 ? 2
-                    : g_r3_fr_dbg == 6 ? 6 : 14;
+    const int var = (dbg == 3 || big) ? 0 : dbg == 4 ? 1 : dbg == 5 ? 2 : dbg == 6 ? 6 : 14;
 #undef R3_ARGS
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x | (g_r3_fr_walk << 20), tpi, (int)T, out
+#ifdef R3_PROBES  // (the variants measured on the way, tools/fr_nhwc_ab.py / fr_fwd_var_ab.py)
 #define R3_OCC(F, P) \
   do { \
     if (var == 0) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 0>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
@@ -1560,6 +1569,13 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     else if (var == 6) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 6>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
     else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 14>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
   } while (0)
+#else  // (the shipped form; tensors of 4 GB and more: the form with 64-bit offsets)
+#define R3_OCC(F, P) \
+  do { \
+    if (var == 0) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 0>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+    else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 14>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+  } while (0)
+#endif
     if (paired) {
       if (fused) R3_OCC(true, true); else R3_OCC(false, true);
     } else {
@@ -1568,6 +1584,7 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
 #undef R3_OCC
 #undef R3_ARGS
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x, tpi, (int)T, out
+#ifdef R3_PROBES
   } else if (points == 1) {
     if (paired) {
       if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<true, 4, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
@@ -1576,6 +1593,7 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
       if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<true, 4, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
       else hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<false, 4, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
     }
+#endif
   } else {
     if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc<5, true, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
     else hipExtLaunchKernelGGL((fr_forward_nhwc<5, false, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
@@ -1602,7 +1620,7 @@ int r3k_fr_forward_nhwc_levels(int levels, const float* const* a, const float* c
     const int tiles_x = (W[l] + 3) / 4, tiles_y = (H[l] + NH_ROWS - 1) / NH_ROWS;
     const bool wide = H[l] == W[l] && (H[l] & 7) == 0 && (long long)(H[l] / 8) * (H[l] / 8) * N >= 512;
     const bool big = (unsigned long long)N * H[l] * W[l] * C * 4ull >= (1ull << 32);
-    const bool ok = points == 1 && g_r3_fr_dbg == 0 && tiles_x == tiles_y && !wide && !big && N > 0 && C > 0 && !(C & 3) &&
+    const bool ok = points == 1 && r3_fr_dbg() == 0 && tiles_x == tiles_y && !wide && !big && N > 0 && C > 0 && !(C & 3) &&
                     a[l] && boxes[l] && out[l] && aligned16(a[l]) && aligned16(out[l]) &&
                     (!has_b || (b[l] && aligned16(b[l]))) && (!has_res || (res[l] && aligned16(res[l]))) &&
                     (!bias_a || aligned16(bias_a)) && (!bias_b || aligned16(bias_b));

@@ -347,7 +347,9 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
   IxsLds& S = *reinterpret_cast<IxsLds*>(ix);
   // (tools/probes/frb_index_probe.hip: clock stamps of one workgroup at the phase boundaries)
   auto stamp = [&](int k) {
+#ifdef R3_PROBES
     if (stamps && band == bands / 2 && n == 0 && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memtime();
+#endif
   };
   stamp(0);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -539,10 +541,12 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
     }
   }
   stamp(4);
+#ifdef R3_PROBES
   if (stamps && band == bands / 2 && n == 0 && threadIdx.x == 0) {
     stamps[5] = (u64)total;
     stamps[6] = (u64)wc;
   }
+#endif
 }
 
 template <bool CSR>
@@ -869,9 +873,12 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
                                                            float* __restrict__ bottom,
                                                            unsigned long long* __restrict__ stamps) {
   typedef typename FrnVec<CP>::type V;
-  // (clock stamps of wavefront 0 at the phase boundaries: tools/frn_stamps.py)
+  // (probes builds: clock stamps of wavefront 0 at the phase boundaries, tools/frn_stamps.py; s_memrealtime: 100 MHz,
+  // one clock for the chip)
   auto stamp = [&](int i) {
-    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();  // (100 MHz, one clock for the chip)
+#ifdef R3_PROBES
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+#endif
   };
   stamp(0);
   extern __shared__ __attribute__((aligned(16))) float frn_lds[];  // [(H * P + 1)][CP]; the last cell stays zero
@@ -882,7 +889,7 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
   // workgroups of one image on as few XCDs as possible (blockIdx & 7 = XCD under round-robin dispatch): an XCD's L2
   // then holds the index of one or two images instead of streaming all of them
   unsigned bid = blockIdx.x;
-  if ((xcd & 1) && (gridDim.x & 7) == 0) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+  if (xcd && (gridDim.x & 7) == 0) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
   const int n = (int)bid / CG, g0 = (int)bid - n * CG;
   // LDS index of cell q: a shift for the power-of-two widths of a pyramid; else by the float quotient (q < 2^24:
   // off by at most one)
@@ -1091,12 +1098,14 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
                                               lane4, sl0_256 + k * 256, 2);
   }
   stamp(3);
+#ifdef R3_PROBES
   if (stamps) {
     __builtin_amdgcn_s_waitcnt(0);
     stamp(4);
     __syncthreads();
     stamp(5);
   }
+#endif
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1227,8 +1236,8 @@ inline int frn_launch(const float* top, const FrnLayout& L, int N, int C, int H,
     for (wshift = 0; (1 << wshift) < W; wshift++) {}
   hipLaunchKernelGGL((frn_gather_kernel<K, CP>), dim3((unsigned)(N * (C / CP))), dim3(FRN_T), lds, stream, top, L.slicehdr,
                      L.sell, L.csr.cellinfo, L.csr.entries, C, H, W, wshift, L.cap, H * W * 4 * points, accum,
-                     g_r3_frb_impl >= 4 ? (g_r3_frb_impl - 4) : 1, bottom,
-                     reinterpret_cast<unsigned long long*>(g_r3_frn_stamps));
+                     (R3_HAS_PROBES && g_r3_frb_impl == 4) ? 0 : 1, bottom,  // (probes: frb_impl 4 = no XCD remap)
+                     R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps) : nullptr);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

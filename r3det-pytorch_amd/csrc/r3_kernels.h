@@ -20,6 +20,16 @@ struct R3DeviceOnce {
 };
 int r3_cu_count();  // compute units of the current device (r3_api.hip)
 
+// Experiment-only forms -- the A/B kernels of tools/ (launch variants that were measured and not shipped), clock
+// stamps inside kernels -- exist only in a library built with -DR3_PROBES (`make probes`: libr3det_hip_probes.so,
+// loaded when R3DET_HIP_LIB names it).  The product library keeps the switches its tests need (documented with
+// r3det_set_option in include/r3det_hip.h) and reads each ONCE per call.
+#ifdef R3_PROBES
+constexpr bool R3_HAS_PROBES = true;
+#else
+constexpr bool R3_HAS_PROBES = false;
+#endif
+
 // return 0 ok, -1 bad argument, -2 launch failure, -3 workspace too small
 size_t r3k_iou_workspace_bytes(int n1, int n2);
 // ws may be null (single-kernel path); with a workspace the stream + drain pipeline runs
@@ -153,7 +163,12 @@ extern int g_r3_fr_profile;
 
 // A/B knobs (r3det_set_option)
 extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane, 3/4 tap-table, 5/6 persistent
-extern int g_r3_fr_dbg;    // ablation bits for the persistent forward kernel
+extern int g_r3_fr_dbg;    // NHWC forward: 0 auto | 8 wide regions | 9 tile pairs; other values: probes builds only
+// (the value a call works with: what the product library does not know reads as 0)
+inline int r3_fr_dbg() {
+  const int v = g_r3_fr_dbg;
+  return (R3_HAS_PROBES || v == 8 || v == 9) ? v : 0;
+}
 extern int g_r3_fr_walk;   // strip height of the tile-pair walk (0: row-major)
 extern unsigned long long g_r3_frn_stamps;
 extern int g_r3_frb_impl;  // 0 auto; 1 general index form always; 2 unpaired gather

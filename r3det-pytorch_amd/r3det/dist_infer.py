@@ -61,10 +61,14 @@ def gather_detections(packed, counts, dst=0, batch_size=None):
     entry per rank, each ``batch_size`` images long with count -1 for the images a rank did not have
     (``unpack_detections`` skips them) -- and (None, None) elsewhere; single-process: passthrough.
 
-    ONE code path for RCCL ('nccl') and gloo: ``all_gather_into_tensor`` needs identical shapes on every rank, so
-    every rank first pads its batch to a common size -- ``batch_size`` when the caller knows the configured batch
-    (no extra collective), otherwise the MAX of the ranks' batch sizes (one 8-byte all-reduce) -- with count -1
-    marking the padding; an uneven last batch therefore neither hangs nor mixes up ranks."""
+    ONE collective per call, the same for RCCL ('nccl') and gloo: ``all_gather_into_tensor`` of the detections with
+    the counts riding as one more row per image (fp32 holds them exactly).  It needs identical shapes on every rank,
+    so every rank first pads its batch to a common size: ``batch_size`` -- the configured per-rank batch, which the
+    inference loop knows; EVERY rank must pass the same value (or all None), otherwise the collectives mismatch and
+    hang -- or, with None, the MAX of the ranks' batch sizes (one more 8-byte all-reduce and a host read).  A rank that
+    has run out of images still has to take part: it calls with an empty batch (B = 0).  Count -1 marks the padding;
+    an uneven last batch therefore neither hangs nor mixes up ranks.
+    Needs torch >= 1.13 (``all_gather_into_tensor`` on both backends)."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_group()):
         return [packed], [counts]
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -75,19 +79,20 @@ def gather_detections(packed, counts, dst=0, batch_size=None):
         batch_size = int(m.item())
     if B > batch_size:
         raise RuntimeError(f"rank {rank}: batch of {B} images exceeds the common batch size {batch_size}")
-    if B < batch_size:
-        packed = torch.cat([packed, packed.new_zeros((batch_size - B,) + tuple(packed.shape[1:]))])
-        counts = torch.cat([counts, counts.new_full((batch_size - B,), -1)])
-    # (concatenated along dim 0: the output form both RCCL and gloo take)
-    allp = packed.new_empty((world * batch_size,) + tuple(packed.shape[1:]))
-    allc = counts.new_empty((world * batch_size,))
-    # (RCCL has no native gather-to-one that beats all_gather at 56 KB / image: one collective launch per tensor)
-    dist.all_gather_into_tensor(allp, packed.contiguous())
-    dist.all_gather_into_tensor(allc, counts.contiguous())
+    # [batch_size, rows + 1, 7]: the images' detections, then one row whose first value is the count (-1: padding)
+    rows, cols = packed.size(1), packed.size(2)
+    mine = packed.new_zeros((batch_size, rows + 1, cols))
+    mine[:B, :rows] = packed
+    mine[:, rows, 0] = -1.0
+    mine[:B, rows, 0] = counts.to(packed.dtype)
+    everyone = packed.new_empty((world * batch_size, rows + 1, cols))
+    # (RCCL has no native gather-to-one that beats all_gather at 56 KB / image)
+    dist.all_gather_into_tensor(everyone, mine)
     if rank != dst:
         return None, None
     # (no host read here: the padding is marked in the counts)
-    return list(allp.split(batch_size)), list(allc.split(batch_size))
+    allc = everyone[:, rows, 0].to(counts.dtype)
+    return [p[:, :rows] for p in everyone.split(batch_size)], list(allc.split(batch_size))
 
 
 def unpack_detections(packed, counts):

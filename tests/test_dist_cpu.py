@@ -42,10 +42,14 @@ def _worker(rank, world, port, num_tiles, batch, out_path):
     assert (r, w) == (rank, world)
     mine = di.shard_tiles(num_tiles, rank, world)
     collected = {}
-    for b0 in range(0, len(mine), batch):
+    most = max(len(di.shard_tiles(num_tiles, r_, world)) for r_ in range(world))
+    for b0 in range(0, most, batch):  # (every rank takes part in every round: one that has run out calls with B = 0)
         tiles = mine[b0:b0 + batch]
         dl = [_fake_detections(t) for t in tiles]
-        packed, counts = di.pack_detections([d for d, _ in dl], [l for _, l in dl], max_per_img=64)
+        if tiles:
+            packed, counts = di.pack_detections([d for d, _ in dl], [l for _, l in dl], max_per_img=64)
+        else:
+            packed, counts = torch.zeros(0, 64, 7), torch.zeros(0, dtype=torch.int32)
         # a rank's last batch may be short (13 tiles over 2 ranks, batch 4: 4 + 3 and 4 + 2): gather_detections
         # pads it itself -- to the configured batch size in the even rounds, to the MAX over the ranks (one more
         # tiny all-reduce) in the odd ones -- and all ranks go through the same all_gather_into_tensor
@@ -67,8 +71,9 @@ def _worker(rank, world, port, num_tiles, batch, out_path):
     dist.destroy_process_group()
 
 
-def test_image_parallel_gather_world2(tmp_path):
-    world, num_tiles, batch = 2, 13, 4
+@pytest.mark.parametrize("num_tiles", [13, 9])  # 9: ranks with 4 + 1 and 4 + 0 tiles -- one rank misses a whole batch
+def test_image_parallel_gather_world2(tmp_path, num_tiles):
+    world, batch = 2, 4
     out = str(tmp_path / "collected.pt")
     mp.spawn(_worker, args=(world, _free_port(), num_tiles, batch, out), nprocs=world, join=True)
     got = torch.load(out)
@@ -125,10 +130,18 @@ def _bench_worker(rank, world, port, out_path):
     dev = torch.device("cpu")
     model = _StubModel(rank)
     img = torch.zeros(4 if rank == 0 else 3, 3, 8, 8)
-    counts = bench.model_step(model, img)            # pack + the step's one exchange (gather on rank 0)
+    # count the collectives of a step: ONE all_gather_into_tensor (the counts ride in it) and nothing else -- no
+    # all-reduce, no host read -- when the configured batch is passed, as bench.py does
+    calls = []
+    real_ag, real_ar = dist.all_gather_into_tensor, dist.all_reduce
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append("all_gather_into_tensor"), real_ag(*a, **k))[1]
+    dist.all_reduce = lambda *a, **k: (calls.append("all_reduce"), real_ar(*a, **k))[1]
+    counts = bench.model_step(model, img, batch_size=4)  # pack + the step's one exchange (gather on rank 0)
+    dist.all_gather_into_tensor, dist.all_reduce = real_ag, real_ar
+    assert calls == ["all_gather_into_tensor"], calls
     assert counts.tolist() == ([3, 5, 7, 9] if rank == 0 else [4, 0, 8])
-    elapsed, mine, last = bench.timed_region(lambda: bench.model_step(model, img), argparse.Namespace(steps=3, warmup=1),
-                                             dev, di)
+    elapsed, mine, last = bench.timed_region(lambda: bench.model_step(model, img, batch_size=4),
+                                             argparse.Namespace(steps=3, warmup=1), dev, di)
     assert elapsed >= mine - 1e-9 and torch.equal(last, counts)
     ranks = bench.per_rank_ms(mine, 3, dev, world)
     info = bench.dist_info()

@@ -2,6 +2,8 @@
 option fr_dbg 9 (4 x 4 tile pairs) / 0 (wide regions, the default), alternating, same process."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# launch variants that were not shipped / clock stamps live in the probes build of the library (make probes)
+os.environ.setdefault("R3DET_HIP_LIB", os.path.join(ROOT, "r3det-pytorch_amd", "libr3det_hip_probes.so"))
 for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")): sys.path.insert(0, p)
 import torch
 import bench

@@ -3,6 +3,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# launch variants that were not shipped / clock stamps live in the probes build of the library (make probes)
+os.environ.setdefault("R3DET_HIP_LIB", os.path.join(ROOT, "r3det-pytorch_amd", "libr3det_hip_probes.so"))
 for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
     sys.path.insert(0, p)
 import torch  # noqa: E402

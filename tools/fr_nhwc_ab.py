@@ -2,6 +2,8 @@
 pipeline on 4 x 4 tiles) at several batch sizes (the workgroup count per CU changes the tail)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# launch variants that were not shipped / clock stamps live in the probes build of the library (make probes)
+os.environ.setdefault("R3DET_HIP_LIB", os.path.join(ROOT, "r3det-pytorch_amd", "libr3det_hip_probes.so"))
 for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")): sys.path.insert(0, p)
 import torch
 from r3det import synthetic as syn, _C

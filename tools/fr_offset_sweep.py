@@ -4,6 +4,8 @@ tools/fr_bwd_prof.py (every 4 x 4 block of positions regresses to one centre) an
 when FR_MODEL_FIELD=1.  Both forms of the kernel (option fr_dbg 0 auto = wide / 9 pairs)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# launch variants that were not shipped / clock stamps live in the probes build of the library (make probes)
+os.environ.setdefault("R3DET_HIP_LIB", os.path.join(ROOT, "r3det-pytorch_amd", "libr3det_hip_probes.so"))
 for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")): sys.path.insert(0, p)
 import torch
 from r3det import synthetic as syn, _C
