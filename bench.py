@@ -438,7 +438,40 @@ def cpu_baseline():
         t = clock(lambda: O.ref_v1_rnms(d6, 0.1) if use_ref else O.nms(O.V1, sh, s, 0.1, ascending=True))
         per_op[f"nms_v1_{len(b)}"] = {"Mboxes_s_1thread": round(len(b) / t / 1e6, 4),
                                       "kind": "reference" if use_ref else "port"}
-    return {"value": round(1.0 / dt, 3), "unit": "img/s", "cores": cores,
+    # BASELINE.md section 3's v3 / v2 rows: the reference's own CPU code (oracle/_ref), one thread, bounded -- v3 IoU
+    # 1000 x 128 (~0.5 s per call), v3 and v2 (15 labels) NMS at 2000 / 8576: one timed call each
+    if use_ref:
+        def once(fn):
+            t = time.perf_counter()
+            fn()
+            return time.perf_counter() - t
+        t = once(lambda: O.ref_v3_iou_mat(a, g))
+        per_op["iou_v3_1000x128"] = {"Mpairs_s_1thread": round(128000 / t / 1e6, 3), "kind": "reference", "calls": 1}
+        for n in (2000, 8576):
+            pb, ps = syn.nms_pool(n * 10 // 6 + 64, 77 + n)
+            sc, lab = ps[:, :-1].max(1)
+            idx = torch.nonzero(sc > SCORE_THR).squeeze(1)[:n]
+            b, s_, l = pb[idx].numpy(), sc[idx].numpy(), lab[idx].numpy()
+            sh = b.copy()
+            sh[:, :2] += (l.astype(np.float32) * (b.max() + 1))[:, None]
+            t = once(lambda: O.ref_v3_nms(sh, s_, 0.1))
+            per_op[f"nms_v3_{len(b)}"] = {"Mboxes_s_1thread": round(len(b) / t / 1e6, 4), "kind": "reference", "calls": 1}
+            d6 = np.hstack([b, l.astype(np.float32)[:, None]])
+            t = once(lambda: O.ref_v2_nms(d6, s_, 0.1))
+            per_op[f"nms_v2_{len(b)}"] = {"Mboxes_s_1thread": round(len(b) / t / 1e6, 4), "kind": "reference", "calls": 1,
+                                          "note": "the reference's label-aware IoU (ml_nms_rotated's header) under the "
+                                                  "harness's greedy loop (oracle/ref_harness/harness_v2.cpp: the "
+                                                  "reference's own loop goes through at::Tensor indexing and took 2.3 s "
+                                                  "/ 22 s at 2000 / 8576 in the survey, BASELINE.md section 3)"}
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(1.0 / dt, 3), "unit": "img/s", "cores": cores, "cpu_model": cpu_model,
             "kind": "port",
             "compare_with": "hot_path.img_s (the custom ops alone on the GPU; its launches also carry the module's "
                             "elementwise adds and the per-level top-k pool, which this CPU sample does not run), not "
