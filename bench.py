@@ -679,6 +679,32 @@ def main():
             us = sum(r[4] for r in alone) / len(alone)
             alone_rec = {"avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
                          "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
+            # The same launch on other box fields: how far the boxes sample from their own cell decides how many tap
+            # rows leave the workgroup's regions -- the headline field is the survey's (centres
+            # jittered by 0.4 cells); "trained": every 4 x 4 block of positions regresses to one centre, what a
+            # trained detector produces around objects; sigma 4: the random-weight bench model's own stage-1 boxes
+            by_field = {"survey_sigma_0.4_cells": {"avg_launch_us": alone_rec["avg_launch_us"], "frac": alone_rec["frac"]}}
+            base = lv0["boxes"]
+            st = 8.0
+            trained = base.clone()
+            g = (base[:, :2] / (4 * st)).floor() * (4 * st) + 2 * st
+            trained[:, :2] = g + torch.randn_like(g) * 0.3 * st
+            far = base.clone()
+            far[:, :2] = base[:, :2] + torch.randn_like(g) * 4 * st
+            for name, bx in (("trained_piles_4x4", trained), ("sigma_4_cells", far)):
+                def rot2():
+                    a, b, r, o = sets[state[0] % 3]
+                    state[0] += 1
+                    fr_module_nhwc(a, b, wl["bias"], wl["bias"], r, bx, 1.0 / 8, 1, o)
+                _C.fr_profile_read()
+                _C.set_option("fr_profile", 2)
+                timeit(rot2, 10, warm=2)
+                _C.set_option("fr_profile", 0)
+                rec = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
+                if rec:
+                    u2 = sum(r[4] for r in rec) / len(rec)
+                    by_field[name] = {"avg_launch_us": round(u2, 2), "frac": round(alg_bytes / u2 / 1e3 / HBM_PEAK_GBS, 4)}
+            alone_rec["by_field"] = by_field
         del sets, wl
         if not args.no_ops:
             phase("op rates")
@@ -742,6 +768,13 @@ def main():
                                                     / alg_bytes, 4),
                          "sampler_only_note": "the same launch priced at SURVEY 8d's B_fr (1 read + 1 write per element: "
                                               "135.5 MB) instead of the 16 B / element the fused launch has to move",
+                         "by_field": dict((alone_rec or {}).get("by_field", {}),
+                                          in_model={"avg_launch_us": round(span_us, 2),
+                                                    "frac": round(in_model / HBM_PEAK_GBS, 4),
+                                                    "note": "the random-weight model's own stage-1 boxes (offsets of "
+                                                            "4.7 +- 1.9 cells), inputs Infinity-Cache warm"}),
+                         "by_field_note": "frac is a property of the launch AND of how far the boxes sample from their own "
+                                          "cell; `frac` above is the survey's field (centres jittered by 0.4 cells)",
                          "in_model_l3_assisted": {"avg_launch_us": round(span_us, 2), "achieved": round(in_model, 1),
                                                   "frac": round(in_model / HBM_PEAK_GBS, 4), "launches_timed": len(recs),
                                                   "what": "the same launch inside the timed model steps: its three "

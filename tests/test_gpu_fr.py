@@ -361,6 +361,35 @@ def test_forward_levels_equals_per_level_calls(points):
         fr_forward_levels(feats, boxes[::-1], scales, points, outs)
 
 
+@pytest.mark.parametrize("form", ["auto", "wide", "pairs"])
+def test_module_nhwc_bench_shape_directly_against_the_oracle(form):
+    """The roofline launch itself -- r3det_feature_refine_module_nhwc at (4, 256, 128, 128), the bench's box field --
+    against the ORACLE on a sample of channels of every image (not through the NCHW kernel): P = (a + bias_a) +
+    (b + bias_b) in fp32 on the host, out = residual + (P + sample(P)), bit for bit."""
+    from r3det import _C, synthetic as syn
+    from r3det.ops.feature_refine import fr_module_nhwc
+    N, C, H, W, stride = 4, 256, 128, 128, 8
+    cl = torch.channels_last
+    g = torch.Generator(device='cuda').manual_seed(5)
+    mk = lambda: torch.randn(N, C, H, W, device='cuda', generator=g).contiguous(memory_format=cl)  # noqa: E731
+    a, b, r = mk(), mk(), mk()
+    ba, bb = torch.randn(C, device='cuda', generator=g), torch.randn(C, device='cuda', generator=g)
+    boxes = syn.fr_level_boxes(N, H, W, stride, 3, device='cuda')
+    out = torch.full_like(a, float('nan'))
+    _C.set_option("fr_dbg", {"auto": 0, "wide": 8, "pairs": 9}[form])
+    try:
+        assert fr_module_nhwc(a, b, ba, bb, r, boxes, 1 / stride, 1, out)
+    finally:
+        _C.set_option("fr_dbg", 0)
+    chans = [0, 3, 64, 129, 255]
+    an, bn, rn = (t[:, chans].cpu().numpy() for t in (a, b, r))
+    ban, bbn = ba[chans].cpu().numpy()[None, :, None, None], bb[chans].cpu().numpy()[None, :, None, None]
+    P = (an + ban) + (bn + bbn)
+    with O.twin():
+        want = rn + O.fr_forward(np.ascontiguousarray(P), boxes.cpu().numpy(), 1 / stride, 1, threads=8)
+    assert np.array_equal(out[:, chans].cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("NC", [(4, 256), (2, 64), (1, 12)])
 @pytest.mark.parametrize("adversarial", [False, True])
 def test_nhwc_levels_calls_equal_per_level_calls(NC, adversarial):
