@@ -144,6 +144,24 @@ int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes,
                        float* gt_max_overlaps, int64_t* gt_argmax_overlaps, void* ws, size_t ws_bytes,
                        void* stream);
 
+/* Prepared columns.  The second operand of the training step's overlaps is the SAME anchor grid in every step
+ * (models/dense_heads/rotate_anchor_head.py:220-231 -> mat_iou_iof, rbbox_geo_kernel.cu:231-268, which recomputes the
+ * trigonometry of both boxes for every pair): r3det_iou_prepare_columns computes what the kernels need of a box list
+ * used as columns -- the exact per-box records, the data of the conservative disjointness test, the bounding box of
+ * every 256 consecutive columns -- ONCE into `prepared` (r3det_iou_prepared_bytes(n) bytes, 16-byte aligned); the
+ * _prepared entry points take it next to the boxes themselves and give bit for bit the results of the plain ones.
+ * geom: R3DET_GEOM_V1 / _V2 / _V3, the same in the prepare call and in every use.  mode of r3det_iou_mat_prepared: as the
+ * plain entry of the geometry takes it (v1 / v2: 1 = iof; v3: 0 = iof). */
+size_t r3det_iou_prepared_bytes(int n);
+int r3det_iou_prepare_columns(int geom, const float* boxes, int n, void* prepared, size_t prepared_bytes, void* stream);
+int r3det_iou_mat_prepared(int geom, const float* b1, int n1, const float* b2, int n2, const void* prepared, int mode,
+                           float* out, void* ws, size_t ws_bytes, void* stream);
+int r3det_rbbox_assign_prepared(int geom, const float* gts, int n_gt, const float* boxes, int n_boxes,
+                                const void* prepared, float pos_iou_thr, float neg_iou_thr, float min_pos_iou,
+                                int match_low_quality, int gt_max_assign_all, int64_t* assigned_gt_inds,
+                                float* max_overlaps, int64_t* argmax_overlaps, float* gt_max_overlaps,
+                                int64_t* gt_argmax_overlaps, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Batched post-processing: multiclass_nms_rotated for all images of a step.
  * Replaces, for nms type 'v1' and boxes shared by the classes, the per-image Python sequence

@@ -129,6 +129,35 @@ int r3det_mmcv_box_iou_rotated(const float* b1, int n1, const float* b2, int n2,
   return rc(r3k_iou_mat(R3DET_GEOM_V2, mode_flag, b1, n1, b2, n2, out, ws, ws_bytes, S(stream)));
 }
 
+size_t r3det_iou_prepared_bytes(int n) { return r3k_iou_prepared_bytes(n); }
+
+int r3det_iou_prepare_columns(int geom, const float* boxes, int n, void* prepared, size_t prepared_bytes, void* stream) {
+  const DeviceGuard guard(stream);
+  if (geom < 1 || geom > 3) return R3DET_EINVAL;
+  return rc(r3k_iou_prepare_columns(geom, boxes, n, prepared, prepared_bytes, S(stream)));
+}
+
+int r3det_iou_mat_prepared(int geom, const float* b1, int n1, const float* b2, int n2, const void* prepared, int mode,
+                           float* out, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
+  if (bad_iou_args(b1, n1, b2, n2, out) || geom < 1 || geom > 3 || (n2 > 0 && !prepared)) return R3DET_EINVAL;
+  // (mode: as the reference entry of the geometry takes it -- v1 / v2: 1 = iof; v3: 0 = iof)
+  const int iof = geom == 3 ? (mode == 0) : (mode != 0);
+  return rc(r3k_iou_mat(geom, iof, b1, n1, b2, n2, out, ws, ws_bytes, S(stream), prepared));
+}
+
+int r3det_rbbox_assign_prepared(int geom, const float* gts, int n_gt, const float* boxes, int n_boxes,
+                                const void* prepared, float pos_iou_thr, float neg_iou_thr, float min_pos_iou,
+                                int match_low_quality, int gt_max_assign_all, int64_t* assigned_gt_inds,
+                                float* max_overlaps, int64_t* argmax_overlaps, float* gt_max_overlaps,
+                                int64_t* gt_argmax_overlaps, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
+  if (n_boxes > 0 && !prepared) return R3DET_EINVAL;
+  return rc(r3k_iou_assign(geom, gts, n_gt, boxes, n_boxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality,
+                           gt_max_assign_all, assigned_gt_inds, max_overlaps, argmax_overlaps, gt_max_overlaps,
+                           gt_argmax_overlaps, ws, ws_bytes, S(stream), prepared));
+}
+
 size_t r3det_rbbox_assign_workspace_bytes(int n_gt, int n_boxes) {
   return r3k_iou_assign_workspace_bytes(n_gt, n_boxes);
 }

@@ -219,9 +219,12 @@ __device__ __forceinline__ float v1_pair_lds(const float* __restrict__ A, const 
 // ----------------------------------------------------------------------------------------
 // hull (v2 / v3)
 // ----------------------------------------------------------------------------------------
-template <bool V2, int STRIDE>
+// CAP < 24: the point list of a lane holds CAP slots; a pair with more candidate points sets *over and returns 0
+// (the caller redoes it with the full 24): two rectangles in general position give at most 8 crossings, and vertices
+// inside the other box only replace crossings, so 12 slots cover all but degenerate (touching / duplicate-vertex) pairs.
+template <bool V2, int STRIDE, int CAP = 24>
 __device__ __forceinline__ float hull_pair_lds(const float* __restrict__ A, const float* __restrict__ B,
-                                               bool iou_mode, const LanePts<STRIDE>& q) {
+                                               bool iou_mode, const LanePts<STRIDE>& q, bool* over = nullptr) {
   const float ax = A[0], ay = A[1], bx = B[0], by = B[1];
   const double csx = (double)(ax + bx) / 2.0;
   const double csy = (double)(ay + by) / 2.0;
@@ -258,7 +261,7 @@ __device__ __forceinline__ float hull_pair_lds(const float* __restrict__ A, cons
       const float n2 = crossp(vec1[i], vec12);
       if (unit_closed(n1, det) && unit_closed(n2, det)) {
         const float t1 = n1 / det;
-        q.set(num, Pt{pts1[i].x + vec1[i].x * t1, pts1[i].y + vec1[i].y * t1});
+        if (CAP == 24 || num < CAP) q.set(num, Pt{pts1[i].x + vec1[i].x * t1, pts1[i].y + vec1[i].y * t1});
         num++;
       }
     }
@@ -272,7 +275,7 @@ __device__ __forceinline__ float hull_pair_lds(const float* __restrict__ A, cons
       const float APdotAB = dotp(AP, AB);
       const float APdotAD = -dotp(AP, DA);
       if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) {
-        q.set(num, pts1[i]);
+        if (CAP == 24 || num < CAP) q.set(num, pts1[i]);
         num++;
       }
     }
@@ -286,10 +289,14 @@ __device__ __forceinline__ float hull_pair_lds(const float* __restrict__ A, cons
       const float APdotAB = dotp(AP, AB);
       const float APdotAD = -dotp(AP, DA);
       if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) {
-        q.set(num, pts2[i]);
+        if (CAP == 24 || num < CAP) q.set(num, pts2[i]);
         num++;
       }
     }
+  }
+  if (CAP < 24 && num > CAP) {
+    *over = true;
+    return 0.f;
   }
   float intersection = 0.f;
   if (num > 2) {

@@ -214,7 +214,9 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream_kernel(const float* __re
                                                                BoxRec* __restrict__ recsA,
                                                                BoxRec* __restrict__ recsB,
                                                                unsigned* __restrict__ gqueue,
-                                                               unsigned* __restrict__ counter) {
+                                                               unsigned* __restrict__ counter,
+                                                               const float4* __restrict__ prej = nullptr,
+                                                               const float* __restrict__ prad = nullptr) {
   __shared__ __attribute__((aligned(16))) float rows[S_ROWS][8];  // cx, cy, rad, ex, ey
   __shared__ unsigned short queue[S_QCAP];
   __shared__ int qcount;
@@ -241,7 +243,10 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream_kernel(const float* __re
 #pragma unroll
   for (int c = 0; c < T_CPT; c++) {
     cvalid[c] = (col0 + c) < n2;
-    if (cvalid[c]) {
+    if (cvalid[c] && prej) {  // prepared columns: the records exist (recsB IS the prepared array)
+      const float4 q = prej[col0 + c];
+      cq[c][0] = q.x, cq[c][1] = q.y, cq[c][2] = prad[col0 + c], cq[c][3] = q.z, cq[c][4] = q.w;
+    } else if (cvalid[c]) {
       BoxRec rec;
       make_record<GEOM>(b2 + (size_t)(col0 + c) * 5, 0.f, rec);
 #pragma unroll
@@ -346,12 +351,81 @@ __device__ __forceinline__ void reject_data(const float x, const float y, const 
   }
 }
 
-template <int GEOM, bool VEC>
+// ---- prepared columns.  The second operand of the assignment is the same anchor grid in every step
+// (rotate_anchor_head.py:220-231 -> rbbox_geo_kernel.cu:231-268 recomputes everything about it per pair): its exact
+// records (deterministic sincos, 64 B), the conservative-test data of its columns (centre + AABB half extents, radius)
+// and the bounding box of every 256 consecutive columns (a stream wavefront's columns) are computed ONCE
+// (r3det_iou_prepare_columns) and read back by every call -- the stream kernel's per-wavefront prologue was 45 % of its
+// instructions, the drain rebuilt a column's record for every surviving pair.
+struct ColPrep {
+  const BoxRec* rec;   // [n2]
+  const float4* rej;   // [n2] cx, cy, inflated AABB half extents (= rec.f[9], f[10], f[12], f[13])
+  const float* rad;    // [n2] inflated circumscribed radius (= rec.f[11])
+  const float4* wbox;  // [ceil(n2 / 256)] min x, max x, min y, max y over the 256 columns; NaN: no shortcut
+};
+
+inline size_t colprep_layout(int n2, const void* p, ColPrep* L) {
+  const size_t nw = ((size_t)n2 + 255) / 256;
+  const size_t o_rec = 0, o_rej = (o_rec + (size_t)n2 * sizeof(BoxRec) + 255) & ~(size_t)255;
+  const size_t o_rad = (o_rej + (size_t)n2 * 16 + 255) & ~(size_t)255, o_wb = (o_rad + (size_t)n2 * 4 + 255) & ~(size_t)255;
+  if (L) {
+    const char* c = static_cast<const char*>(p);
+    L->rec = reinterpret_cast<const BoxRec*>(c + o_rec);
+    L->rej = reinterpret_cast<const float4*>(c + o_rej);
+    L->rad = reinterpret_cast<const float*>(c + o_rad);
+    L->wbox = reinterpret_cast<const float4*>(c + o_wb);
+  }
+  return o_wb + nw * 16 + 256;
+}
+
+template <int GEOM>
+__global__ __launch_bounds__(256) void iou_prepare_kernel(const float* __restrict__ b2, int n2, BoxRec* __restrict__ rec,
+                                                          float4* __restrict__ rej, float* __restrict__ rad,
+                                                          float4* __restrict__ wbox) {
+  __shared__ float red[4][4];
+  __shared__ int bad;
+  const int c = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  float x0 = 3.0e38f, x1 = -3.0e38f, y0 = 3.0e38f, y1 = -3.0e38f;
+  bool fin = false;
+  if (c < n2) {
+    BoxRec r;
+    make_record<GEOM>(b2 + (size_t)c * 5, 0.f, r);
+    rec[c] = r;
+    rej[c] = make_float4(r.f[9], r.f[10], r.f[12], r.f[13]);
+    rad[c] = r.f[11];
+    x0 = r.f[9] - r.f[12], x1 = r.f[9] + r.f[12], y0 = r.f[10] - r.f[13], y1 = r.f[10] + r.f[13];
+    fin = (fabsf(r.f[9]) < 3.0e38f) && (fabsf(r.f[10]) < 3.0e38f) && (r.f[12] < 3.0e38f) && (r.f[13] < 3.0e38f);
+  }
+  if (!fin) bad = 1;  // (a column beyond the list, or a non-finite one: its 256 columns never take the shortcut)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    x0 = fminf(x0, __shfl_xor(x0, d));
+    x1 = fmaxf(x1, __shfl_xor(x1, d));
+    y0 = fminf(y0, __shfl_xor(y0, d));
+    y1 = fmaxf(y1, __shfl_xor(y1, d));
+  }
+  if (lane == 0) red[wave][0] = x0, red[wave][1] = x1, red[wave][2] = y0, red[wave][3] = y1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float nan = __builtin_nanf("");
+    float4 b = make_float4(fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0])),
+                           fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1])),
+                           fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2])),
+                           fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])));
+    if (bad) b = make_float4(nan, nan, nan, nan);
+    wbox[blockIdx.x] = b;
+  }
+}
+
+template <int GEOM, bool VEC, bool PREP = false>
 __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __restrict__ b1, int n1,
                                                                 const float* __restrict__ b2, int n2,
                                                                 float* __restrict__ out, BoxRec* __restrict__ recsA,
                                                                 int* __restrict__ tcount,
-                                                                unsigned short* __restrict__ slots, int wcap) {
+                                                                unsigned short* __restrict__ slots, int wcap,
+                                                                const ColPrep prep = ColPrep()) {
   __shared__ __attribute__((aligned(16))) float rows[P_ROWS][8];  // cx, cy, rad, ex, ey
   __shared__ unsigned short queue[4 * P_WSEG];
   __shared__ int wcount[4];
@@ -380,6 +454,23 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   }
   float cx[T_CPT], cy[T_CPT], cr[T_CPT], cex[T_CPT], cey[T_CPT];
   bool cvalid[T_CPT];
+  float bx0, bx1, by0, by1;
+  bool fin;
+  if (PREP) {  // (VEC form only: n2 % 4 == 0, so a lane's four columns are all valid or all beyond the list)
+    const bool v = col0 < n2;
+    const int cs = v ? col0 : 0;
+    const float4 r4 = *reinterpret_cast<const float4*>(prep.rad + cs);
+    cr[0] = r4.x, cr[1] = r4.y, cr[2] = r4.z, cr[3] = r4.w;
+#pragma unroll
+    for (int c = 0; c < T_CPT; c++) {
+      const float4 q = prep.rej[cs + c];
+      cx[c] = q.x, cy[c] = q.y, cex[c] = q.z, cey[c] = q.w;
+      cvalid[c] = v;
+    }
+    const float4 wb = prep.wbox[(colbase >> 8) + __builtin_amdgcn_readfirstlane(wave)];  // (NaN: never the shortcut)
+    bx0 = wb.x, bx1 = wb.y, by0 = wb.z, by1 = wb.w;
+    fin = true;
+  } else {
   {
     float raw[T_CPT * 5];
     if (col0 + T_CPT <= n2 && (reinterpret_cast<uintptr_t>(b2) & 15) == 0) {
@@ -406,13 +497,12 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
       reject_data(cx[c], cy[c], raw[c * 5 + 2], raw[c * 5 + 3], raw[c * 5 + 4], cr[c], cex[c], cey[c]);
     }
   }
-  const bool all_valid = cvalid[T_CPT - 1];
   // Bounding box of this WAVE's 256 columns (inflated extents included).  Anchors and refined boxes come in
   // spatial order, so for most (row, wave) combinations the row's box lies outside it: one wave-uniform test
   // then replaces the 4 per-column tests and the row segment is stored as zeros.  Waves with an invalid or
   // non-finite column never take the shortcut.
-  float bx0 = cx[0] - cex[0], bx1 = cx[0] + cex[0], by0 = cy[0] - cey[0], by1 = cy[0] + cey[0];
-  bool fin = all_valid;
+  bx0 = cx[0] - cex[0], bx1 = cx[0] + cex[0], by0 = cy[0] - cey[0], by1 = cy[0] + cey[0];
+  fin = cvalid[T_CPT - 1];
 #pragma unroll
   for (int c = 0; c < T_CPT; c++) {
     bx0 = fminf(bx0, cx[c] - cex[c]);
@@ -428,7 +518,9 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
     by0 = fminf(by0, __shfl_xor(by0, d));
     by1 = fmaxf(by1, __shfl_xor(by1, d));
   }
-  const bool wave_ok = VEC && (__ballot(fin) == ~0ULL);
+  }
+  const bool all_valid = cvalid[T_CPT - 1];
+  const bool wave_ok = VEC && (PREP || __ballot(fin) == ~0ULL);
   // survivors: one PRIVATE LDS segment per wave, its fill count in a wave-uniform register -- no LDS atomics,
   // nothing to wait for (a shared queue with one atomicAdd per ballot cost 12 of the kernel's 32 us)
   unsigned short* wq = queue + wave * P_WSEG;
@@ -490,14 +582,18 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __re
                                                                const BoxRec* __restrict__ recsA,
                                                                const int* __restrict__ tcount,
                                                                const unsigned short* __restrict__ slots, int tiles_x,
-                                                               int tiles, float* __restrict__ out) {
+                                                               int tiles, float* __restrict__ out,
+                                                               const BoxRec* __restrict__ recsB = nullptr) {
   // One clip takes a wave ~15 us from first load to store (long dependent chains through LDS), the ALUs are idle
   // most of that time, so what counts is how many waves a CU holds.  v1: 8 candidate slots per lane instead of
   // the reference's 16 (wave-private [slot][lane] regions of 4 KB) => 18 KB of LDS per workgroup, 8 workgroups
   // per CU; the rare pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region.
-  constexpr bool SHORT = GEOM == 1;
+  // v2 / v3 (hull): 12 of the 24 slots, redo with 24 by lanes 0..31 likewise => 24.5 KB instead of 49 KB per workgroup
+  // (the 49 KB form ran at occupancy 3: that was the 41 us v3 drain)
+  constexpr bool SHORT = true;
+  constexpr int CAPS = GEOM == 1 ? 8 : 12, CAPF = GEOM == 1 ? R3_V1_CAP : 24;  // short / full slots per lane
   constexpr int D_PAIRS = P_ROWS * T_COLS;  // a dense tile is enumerated pair by pair
-  __shared__ float2 pts[SHORT ? 8 * T_THREADS : pts_slots<GEOM>() * T_THREADS];
+  __shared__ float2 pts[CAPS * T_THREADS];
   __shared__ unsigned pre[P_GROUPS + 1];
   __shared__ unsigned wsum[4];
   const int tid = threadIdx.x;
@@ -568,17 +664,14 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __re
     if (valid) {
       const BoxRec A = recsA[r];
       BoxRec B;
-      make_record<GEOM>(b2 + (size_t)c * 5, 0.f, B);
+      if (recsB) B = recsB[c];  // (prepared columns)
+      else make_record<GEOM>(b2 + (size_t)c * 5, 0.f, B);
       float v = 0.f;
       // a dense tile's pairs were never tested with exact records: do it here (apart => 0, as in every form)
       if (!(dense && boxes_apart(A.f, B.f))) {
-        if (SHORT) {
-          const LanePts<64> lp{pts + wave * 512 + lane};
-          v = v1_pair_lds<64, 8>(A.f, B.f, iof != 0, lp, &over);
-        } else {
-          const LanePts<T_THREADS> lp{pts + tid};
-          v = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, iof != 0, lp);
-        }
+        const LanePts<64> lp{pts + wave * (64 * CAPS) + lane};  // wave-private [slot][lane] region
+        if (GEOM == 1) v = v1_pair_lds<64, CAPS>(A.f, B.f, iof != 0, lp, &over);
+        else v = hull_pair_lds<GEOM == 2, 64, CAPS>(A.f, B.f, iof == 0, lp, &over);
       }
       if (!over) out[(size_t)r * n2 + c] = v;
     }
@@ -594,9 +687,11 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __re
         if (lane < 32 && src >= 0) {
           const BoxRec A = recsA[rr];
           BoxRec B;
-          make_record<GEOM>(b2 + (size_t)cc * 5, 0.f, B);
-          const LanePts<32> lp{pts + wave * 512 + lane};
-          out[(size_t)rr * n2 + cc] = v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, iof != 0, lp);
+          if (recsB) B = recsB[cc];
+          else make_record<GEOM>(b2 + (size_t)cc * 5, 0.f, B);
+          const LanePts<32> lp{pts + wave * (64 * CAPS) + lane};  // (32 lanes x CAPF slots = the same region)
+          out[(size_t)rr * n2 + cc] = GEOM == 1 ? v1_pair_lds<32, CAPF>(A.f, B.f, iof != 0, lp)
+                                                : hull_pair_lds<GEOM == 2, 32, CAPF>(A.f, B.f, iof == 0, lp);
         }
         for (int k = 0; k < 32 && m; k++) m &= m - 1;
       }
@@ -823,7 +918,7 @@ void launch_compact(bool vec, int iof, const float* b1, int n1, const float* b2,
 
 template <int GEOM>
 int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float* out, void* ws,
-               size_t ws_bytes, hipStream_t stream) {
+               size_t ws_bytes, hipStream_t stream, const void* prepared = nullptr) {
   const bool vec = (n2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   if (g_r3_iou_impl == 1) {
     dim3 grid((n2 + IOU_BLOCK - 1) / IOU_BLOCK, (n1 + IOU_ROWS - 1) / IOU_ROWS);
@@ -854,14 +949,19 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
   const int maxb = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : 1536;
   if (blocks > maxb) blocks = maxb;
-  if (vec)
+  ColPrep P = ColPrep();
+  if (prepared) colprep_layout(n2, prepared, &P);
+  if (vec && prepared)
+    hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
+                       L.tcount, L.slots, wcap, P);
+  else if (vec)
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
-                       L.tcount, L.slots, wcap);
+                       L.tcount, L.slots, wcap, P);
   else
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
-                       L.tcount, L.slots, wcap);
+                       L.tcount, L.slots, wcap, P);
   hipLaunchKernelGGL(iou_drain3_kernel<GEOM>, dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
-                     L.tcount, L.slots, L.tiles_x, (int)tiles, out);
+                     L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr);
   return 0;
 }
 
@@ -909,16 +1009,39 @@ size_t r3k_iou_workspace_bytes(int n1, int n2) {
 }
 
 int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
-                void* ws, size_t ws_bytes, hipStream_t stream) {
+                void* ws, size_t ws_bytes, hipStream_t stream, const void* prepared) {
   if (n1 == 0 || n2 == 0) return 0;
   int rc;
   switch (geom) {
-    case 1: rc = launch_mat<1>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream); break;
-    case 2: rc = launch_mat<2>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream); break;
-    case 3: rc = launch_mat<3>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream); break;
+    case 1: rc = launch_mat<1>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream, prepared); break;
+    case 2: rc = launch_mat<2>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream, prepared); break;
+    case 3: rc = launch_mat<3>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream, prepared); break;
     default: return -1;
   }
   if (rc) return rc;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+size_t r3k_iou_prepared_bytes(int n2) { return n2 > 0 ? colprep_layout(n2, nullptr, nullptr) : 256; }
+
+// the exact records, conservative-test data and 256-column bounding boxes of a box list used as the COLUMNS of many
+// matrices / assignments (the anchor grid)
+int r3k_iou_prepare_columns(int geom, const float* b2, int n2, void* prepared, size_t bytes, hipStream_t stream) {
+  if (n2 <= 0 || !b2 || !prepared || (reinterpret_cast<uintptr_t>(prepared) & 15)) return -1;
+  if (bytes < r3k_iou_prepared_bytes(n2)) return -3;
+  ColPrep P;
+  colprep_layout(n2, prepared, &P);
+  const dim3 grid((n2 + 255) / 256), block(256);
+#define R3_PREP(G) \
+  hipLaunchKernelGGL(iou_prepare_kernel<G>, grid, block, 0, stream, b2, n2, const_cast<BoxRec*>(P.rec), \
+                     const_cast<float4*>(P.rej), const_cast<float*>(P.rad), const_cast<float4*>(P.wbox))
+  switch (geom) {
+    case 1: R3_PREP(1); break;
+    case 2: R3_PREP(2); break;
+    case 3: R3_PREP(3); break;
+    default: return -1;
+  }
+#undef R3_PREP
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -954,13 +1077,16 @@ inline size_t assign_layout(int n1, int n2, void* ws, AssignLayout* L) {
 
 template <int GEOM>
 void launch_assign(const float* gts, int n1, const float* boxes, int n2, const AssignLayout& L, float min_pos_iou,
-                   int match_low, int assign_all, hipStream_t stream) {
+                   int match_low, int assign_all, hipStream_t stream, const void* prepared) {
+  ColPrep P = ColPrep();
+  if (prepared) colprep_layout(n2, prepared, &P);
+  const BoxRec* recsB = prepared ? P.rec : L.recsB;
   const int nmax = n1 > n2 ? n1 : n2;
   hipLaunchKernelGGL(assign_init_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, L.rowkey, n1, L.colkey,
                      L.lowq, n2, L.counter);
   dim3 grid((n2 + T_COLS - 1) / T_COLS, (n1 + S_ROWS - 1) / S_ROWS);
   hipLaunchKernelGGL((iou_stream_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
-                     (float*)nullptr, L.recsA, L.recsB, L.gqueue, L.counter);
+                     (float*)nullptr, L.recsA, L.recsB, L.gqueue, L.counter, P.rej, P.rad);
   unsigned long long pairs = (unsigned long long)n1 * n2;
   int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
   if (blocks > 2048) blocks = 2048;
@@ -969,7 +1095,7 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
   const int n1_lds = n1 < 2048 ? n1 : 2048;
   const int dmax = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : 2048;  // (measured: 512 -> 62 us, 1024 -> 58, 1536 -> 55, 2048 -> 53)
   hipLaunchKernelGGL(assign_drain_kernel<GEOM>, dim3(blocks < dmax ? blocks : dmax), dim3(T_THREADS),
-                     (size_t)n1_lds * sizeof(u64k), stream, L.recsA, L.recsB, n2, L.gqueue, L.counter, L.qiou, L.rowkey,
+                     (size_t)n1_lds * sizeof(u64k), stream, L.recsA, recsB, n2, L.gqueue, L.counter, L.qiou, L.rowkey,
                      L.colkey, n1_lds);
   if (match_low)
     hipLaunchKernelGGL(assign_lowq_kernel, dim3(blocks), dim3(256), 0, stream, L.gqueue, L.counter, L.qiou, n2,
@@ -986,7 +1112,7 @@ size_t r3k_iou_assign_workspace_bytes(int n1, int n2) {
 int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n2, float pos_thr, float neg_thr,
                    float min_pos_iou, int match_low, int assign_all, int64_t* assigned, float* max_overlaps,
                    int64_t* argmax, float* gt_max, int64_t* gt_argmax, void* ws, size_t ws_bytes,
-                   hipStream_t stream) {
+                   hipStream_t stream, const void* prepared) {
   if (n1 <= 0 || n2 <= 0 || !gts || !boxes || !assigned || !max_overlaps || !ws) return -1;
   if ((gt_max == nullptr) != (gt_argmax == nullptr)) return -1;
   if ((unsigned long long)n1 * (unsigned long long)n2 >= 0xffffffffULL) return -1;
@@ -994,9 +1120,9 @@ int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n
   AssignLayout L;
   assign_layout(n1, n2, ws, &L);
   switch (geom) {
-    case 1: launch_assign<1>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream); break;
-    case 2: launch_assign<2>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream); break;
-    case 3: launch_assign<3>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream); break;
+    case 1: launch_assign<1>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream, prepared); break;
+    case 2: launch_assign<2>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream, prepared); break;
+    case 3: launch_assign<3>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream, prepared); break;
     default: return -1;
   }
   const int nmax = n1 > n2 ? n1 : n2;

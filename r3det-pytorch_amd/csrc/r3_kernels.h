@@ -33,8 +33,11 @@ constexpr bool R3_HAS_PROBES = false;
 // return 0 ok, -1 bad argument, -2 launch failure, -3 workspace too small
 size_t r3k_iou_workspace_bytes(int n1, int n2);
 // ws may be null (single-kernel path); with a workspace the stream + drain pipeline runs
+// prepared: r3k_iou_prepare_columns of b2 for this geom (or null)
 int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
-                void* ws, size_t ws_bytes, hipStream_t stream);
+                void* ws, size_t ws_bytes, hipStream_t stream, const void* prepared = nullptr);
+size_t r3k_iou_prepared_bytes(int n2);
+int r3k_iou_prepare_columns(int geom, const float* b2, int n2, void* prepared, size_t bytes, hipStream_t stream);
 // obb_overlaps' epilogue: zero the rows / columns of boxes with min(w, h) < 1e-3
 int r3k_iou_zero_thin(const float* b1, int n1, const float* b2, int n2, float* out, hipStream_t stream);
 int r3k_iou_vec(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
@@ -45,7 +48,7 @@ size_t r3k_iou_assign_workspace_bytes(int n1, int n2);
 int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n2, float pos_thr, float neg_thr,
                    float min_pos_iou, int match_low, int assign_all, int64_t* assigned, float* max_overlaps,
                    int64_t* argmax, float* gt_max, int64_t* gt_argmax, void* ws, size_t ws_bytes,
-                   hipStream_t stream);
+                   hipStream_t stream, const void* prepared = nullptr);
 
 size_t r3k_nms_workspace_bytes(int n);
 // dets: (n, det_stride) original order; labels: int64 (n,) or null; order: int64 (n,)

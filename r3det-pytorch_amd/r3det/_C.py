@@ -23,6 +23,9 @@ SIGNATURES = {
     "r3det_box_iou_rotated_overlaps_aligned": [_vp, _vp, _i, _i, _vp, _vp],
     "r3det_mmcv_box_iou_rotated": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp],
     "r3det_rbbox_assign": [_i, _vp, _i, _vp, _i, _f, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "r3det_iou_prepare_columns": [_i, _vp, _i, _vp, _sz, _vp],
+    "r3det_iou_mat_prepared": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp],
+    "r3det_rbbox_assign_prepared": [_i, _vp, _i, _vp, _i, _vp, _f, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "r3det_rnms": [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp],
     "r3det_nms_rotated": [_vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
     "r3det_ml_nms_rotated": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],
@@ -109,6 +112,8 @@ def lib():
         L.r3det_fr_backward_workspace_bytes.restype = _sz
         L.r3det_fr_backward_nhwc_workspace_bytes.argtypes = [_i, _i, _i, _i]
         L.r3det_fr_backward_nhwc_workspace_bytes.restype = _sz
+        L.r3det_iou_prepared_bytes.argtypes = [_i]
+        L.r3det_iou_prepared_bytes.restype = _sz
         L.r3det_iou_workspace_bytes.argtypes = [_i, _i]
         L.r3det_iou_workspace_bytes.restype = _sz
         L.r3det_error_string.argtypes = [_i]

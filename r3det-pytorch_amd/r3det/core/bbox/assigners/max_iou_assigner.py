@@ -62,7 +62,10 @@ class MaxIoUAssigner:
                 return None
         return geom
 
-    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None, with_gt_stats=False):
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None, with_gt_stats=False, shared_key=None):
+        """``shared_key`` (not in mmdet's signature): a hashable that names ``bboxes`` when they are the SAME list in
+        every call -- the anchor grid of a training run: what the kernels need of it is then computed once
+        (r3det_iou_prepare_columns) and reused, whatever tensor object carries the boxes."""
         geom = self._fusable(bboxes, gt_bboxes, gt_bboxes_ignore)
         if geom is None:
             overlaps = self.iou_calculator(gt_bboxes, bboxes)
@@ -87,11 +90,26 @@ class MaxIoUAssigner:
             argmax = torch.empty(n2, dtype=torch.int64, device=b.device)
             gmax = torch.empty(n1, dtype=torch.float32, device=b.device)
             gargmax = torch.empty(n1, dtype=torch.int64, device=b.device)
-            _C.check(L.r3det_rbbox_assign(geom, _C.ptr(g), n1, _C.ptr(b), n2, float(self.pos_iou_thr),
-                                          float(self.neg_iou_thr), float(self.min_pos_iou),
-                                          int(self.match_low_quality), int(self.gt_max_assign_all), _C.ptr(gt_inds),
-                                          _C.ptr(max_ov), _C.ptr(argmax), _C.ptr(gmax), _C.ptr(gargmax), _C.ptr(ws),
-                                          nbytes, _C.stream()), "r3det_rbbox_assign")
+            prep = None
+            if shared_key is not None:
+                cache = self.__dict__.setdefault('_prepared_columns', {})
+                k = (shared_key, geom, n2, b.device)
+                prep = cache.get(k)
+                if prep is None:
+                    pb = int(L.r3det_iou_prepared_bytes(n2))
+                    prep = torch.empty(pb, dtype=torch.uint8, device=b.device)
+                    _C.check(L.r3det_iou_prepare_columns(geom, _C.ptr(b), n2, _C.ptr(prep), pb, _C.stream()),
+                             "iou_prepare_columns")
+                    cache.clear()  # (one anchor grid at a time)
+                    cache[k] = prep
+            tail = (float(self.pos_iou_thr), float(self.neg_iou_thr), float(self.min_pos_iou),
+                    int(self.match_low_quality), int(self.gt_max_assign_all), _C.ptr(gt_inds), _C.ptr(max_ov),
+                    _C.ptr(argmax), _C.ptr(gmax), _C.ptr(gargmax), _C.ptr(ws), nbytes, _C.stream())
+            if prep is not None:
+                _C.check(L.r3det_rbbox_assign_prepared(geom, _C.ptr(g), n1, _C.ptr(b), n2, _C.ptr(prep), *tail),
+                         "r3det_rbbox_assign_prepared")
+            else:
+                _C.check(L.r3det_rbbox_assign(geom, _C.ptr(g), n1, _C.ptr(b), n2, *tail), "r3det_rbbox_assign")
         res = AssignResult(n1, gt_inds, max_ov, self._labels(gt_inds, gt_labels))
         if with_gt_stats:
             res.argmax_overlaps, res.gt_max_overlaps, res.gt_argmax_overlaps = argmax, gmax, gargmax

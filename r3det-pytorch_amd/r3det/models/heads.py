@@ -152,6 +152,11 @@ class RRetinaHead(nn.Module):
     def anchors(self, featmap_sizes, device):
         return self.anchor_generator.grid_priors([tuple(fs) for fs in featmap_sizes], device=device)
 
+    def _grid_key(self, anchor_list):
+        """Names the anchor list for the assigner's prepared columns when it IS the generator's grid (the anchor head;
+        the refine head's anchors are the previous stage's boxes: None)."""
+        return ('anchor_grid', tuple(int(a.size(0)) for a in anchor_list[0]), str(anchor_list[0][0].device))
+
     # ------------------------------------------------------------------ training
     def get_anchors(self, featmap_sizes, img_metas, device):
         """list[img] of list[lvl] anchors (shared) and, per image, whether every anchor is valid /
@@ -167,7 +172,8 @@ class RRetinaHead(nn.Module):
                 [tuple(fs) for fs in featmap_sizes], meta['pad_shape'], device=device)))
         return [lvl for _ in img_metas], flags
 
-    def _targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta, gt_bboxes_ignore=None):
+    def _targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta, gt_bboxes_ignore=None,
+                        grid_key=None):
         """rotate_anchor_head.py:172-277 for one image, PseudoSampler configuration: every assigned
         anchor is a positive, every anchor with gt_inds == 0 a negative.  Returns labels (n,),
         label_weights (n,), bbox_targets (n, 5), bbox_weights (n, 5), number of positives (0-dim)."""
@@ -185,7 +191,10 @@ class RRetinaHead(nn.Module):
         if self.assign_by_circumhbbox is not None and gt_bboxes.size(0) > 0:
             gt_assign = obb2hbb(gt_bboxes, self.assign_by_circumhbbox)
         # (labels are derived below with masks: passing gt_labels would make the assigner run nonzero(), a host sync)
-        res = self.assigner.assign(anchors, gt_assign, gt_bboxes_ignore, None)
+        # (grid_key: the anchors are the generator's grid of these feature-map sizes, the same list in every step and for
+        # every image: the assigner prepares its columns once)
+        res = self.assigner.assign(anchors, gt_assign, gt_bboxes_ignore, None,
+                                   shared_key=grid_key if inside is None else None)
         gt_inds = res.gt_inds
         pos = gt_inds > 0
         n = anchors.size(0)
@@ -219,8 +228,9 @@ class RRetinaHead(nn.Module):
         num_level_anchors = [a.size(0) for a in anchor_list[0]]
         if gt_bboxes_ignore_list is None:
             gt_bboxes_ignore_list = [None] * len(img_metas)
+        grid_key = self._grid_key(anchor_list)
         per_img = [self._targets_single(torch.cat(anchor_list[i]), valid_flag_list[i], gt_bboxes_list[i],
-                                        gt_labels_list[i], img_metas[i], gt_bboxes_ignore_list[i])
+                                        gt_labels_list[i], img_metas[i], gt_bboxes_ignore_list[i], grid_key)
                    for i in range(len(img_metas))]
         if any(r is None for r in per_img):
             return None
@@ -390,6 +400,9 @@ class RRetinaRefineHead(RRetinaHead):
         super().__init__(num_classes, in_channels, stacked_convs, feat_channels, test_cfg=test_cfg, train_cfg=train_cfg,
                          assign_by_circumhbbox=assign_by_circumhbbox, anchor_generator=anchor_generator, **kwargs)
         self.bboxes_as_anchors = None
+
+    def _grid_key(self, anchor_list):
+        return None  # (the anchors are the previous stage's boxes: different in every step)
 
     def get_anchors(self, featmap_sizes, img_metas, device):
         """The previous stage's boxes are the anchors (rotate_retina_refine_head.py:99-125); the

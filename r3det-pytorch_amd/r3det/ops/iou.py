@@ -20,12 +20,34 @@ def _as_boxes(t, name):
     return t
 
 
-def rbbox_iou(rb1, rb2, vec=False, iof=False):
+GEOM = {'v1': 1, 'v2': 2, 'v3': 3}
+
+
+def prepare_columns(boxes, version='v1'):
+    """What the overlap kernels need of a box list that is the SECOND operand of many matrices / assignments -- the
+    anchor grid of a training run -- computed once (r3det_iou_prepare_columns): exact per-box records, the data of the
+    conservative disjointness test, the bounding box of every 256 consecutive boxes.  Returns an opaque device buffer
+    for ``rbbox_iou(..., prepared=)`` / ``MaxIoUAssigner.assign(..., shared_key=)``; valid for exactly these boxes
+    and this geometry."""
+    b = _as_boxes(boxes, "boxes")
+    n = b.size(0)
+    L = _C.lib()
+    with torch.cuda.device(b.device):
+        nbytes = int(L.r3det_iou_prepared_bytes(n))
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+        if n:
+            _C.check(L.r3det_iou_prepare_columns(GEOM[version], _C.ptr(b), n, _C.ptr(buf), nbytes, _C.stream()),
+                     "iou_prepare_columns")
+    return buf
+
+
+def rbbox_iou(rb1, rb2, vec=False, iof=False, prepared=None):
     """IoU (or IoF) of rotated boxes with the v1 vertex/segment geometry.
 
     ``vec=False`` -> (n1, n2) matrix (mat_iou_iof); ``vec=True`` -> (max(n1, n2),) with modulo
     broadcast (vec_iou_iof).  Inputs must be contiguous fp32 device tensors, as the
-    reference's CHECK_INPUT demands (rbbox_geo_cuda.cpp:6-18).
+    reference's CHECK_INPUT demands (rbbox_geo_cuda.cpp:6-18).  ``prepared``: ``prepare_columns(rb2, 'v1')``
+    (matrix form only; same results).
     """
     rb1, rb2 = _as_boxes(rb1, "rb1"), _as_boxes(rb2, "rb2")
     n1, n2 = rb1.size(0), rb2.size(0)
@@ -40,8 +62,13 @@ def rbbox_iou(rb1, rb2, vec=False, iof=False):
             out = rb1.new_empty((n1, n2))
             if n1 and n2:
                 ws, wsb = _C.iou_workspace(n1, n2, rb1.device)
-                _C.check(L.r3det_rbbox_geo_mat_iou_iof(_C.ptr(rb1), n1, _C.ptr(rb2), n2, int(bool(iof)),
-                                                       _C.ptr(out), _C.ptr(ws), wsb, _C.stream()), "mat_iou_iof")
+                if prepared is not None:
+                    _C.check(L.r3det_iou_mat_prepared(1, _C.ptr(rb1), n1, _C.ptr(rb2), n2, _C.ptr(prepared),
+                                                      int(bool(iof)), _C.ptr(out), _C.ptr(ws), wsb, _C.stream()),
+                             "iou_mat_prepared")
+                else:
+                    _C.check(L.r3det_rbbox_geo_mat_iou_iof(_C.ptr(rb1), n1, _C.ptr(rb2), n2, int(bool(iof)),
+                                                           _C.ptr(out), _C.ptr(ws), wsb, _C.stream()), "mat_iou_iof")
     return out
 
 

@@ -125,3 +125,25 @@ def test_ignore_regions_mark_anchors_ignored(wrt_candidates):
     # an empty ignore set, or the threshold off: unchanged, fused
     plain = make('RBboxOverlaps2D_v1', match_low_quality=False).assign(boxes, gts)
     assert torch.equal(asg.assign(boxes, gts, gt_bboxes_ignore=ign[:0]).gt_inds, plain.gt_inds)
+
+
+def test_assignment_with_prepared_anchor_grid_equals_plain():
+    """MaxIoUAssigner.assign(..., shared_key=) prepares the anchor grid's columns once (r3det_iou_prepare_columns) and
+    reuses them for every image / step (r3det_rbbox_assign_prepared): the same assignment, bit for bit, as the plain
+    call; a different grid under another key replaces the cache."""
+    from r3det import synthetic as syn
+    from r3det.core.bbox.assigners import MaxIoUAssigner
+    anchors = syn.anchor_grid(device='cuda')
+    a = MaxIoUAssigner(0.5, 0.4, 0., iou_calculator=dict(type='RBboxOverlaps2D_v1'))
+    for seed in (1, 2, 3):
+        gt = syn.dota_like_rboxes(128, seed, device='cuda')
+        plain = a.assign(anchors, gt, with_gt_stats=True)
+        prep = a.assign(anchors.clone(), gt, with_gt_stats=True, shared_key=('grid', 1024))
+        assert torch.equal(plain.gt_inds, prep.gt_inds) and torch.equal(plain.max_overlaps, prep.max_overlaps)
+        assert torch.equal(plain.gt_max_overlaps, prep.gt_max_overlaps)
+        assert torch.equal(plain.gt_argmax_overlaps, prep.gt_argmax_overlaps)
+    assert len(a._prepared_columns) == 1
+    small = anchors[:4096].contiguous()
+    gt = syn.dota_like_rboxes(16, 9, device='cuda')
+    assert torch.equal(a.assign(small, gt).gt_inds, a.assign(small, gt, shared_key=('grid', 64)).gt_inds)
+    assert len(a._prepared_columns) == 1

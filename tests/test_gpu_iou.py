@@ -222,3 +222,39 @@ def test_errors():
         rbbox_iou(a.t().contiguous().t(), a)
     with pytest.raises(RuntimeError):
         rbbox_iou(a.double(), a)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2", "v3"])
+@pytest.mark.parametrize("shape", [(128, 21824), (37, 4096), (5, 1000)])
+def test_prepared_columns_give_the_same_matrix_bit_for_bit(version, shape):
+    """r3det_iou_prepare_columns + r3det_iou_mat_prepared == the plain matrix entry of the geometry (the exact records
+    are the same code, the conservative data only filters); the anchor grid's spatial order and a random list; a
+    non-finite column disables the 256-column shortcut for its block only."""
+    import ctypes
+    from r3det import _C, synthetic as syn
+    from r3det.ops.iou import GEOM, prepare_columns
+    n1, n2 = shape
+    gt = syn.dota_like_rboxes(n1, 5, device='cuda')
+    cols = syn.anchor_grid(device='cuda')[-n2:].contiguous() if n2 == 21824 else syn.rand_rboxes(n2, 3, device='cuda')
+    cols = cols.clone()
+    cols[n2 // 2, 4] = float('inf')      # one non-finite column
+    L = _C.lib()
+    geom = GEOM[version]
+    prep = prepare_columns(cols, version)
+    ws, wsb = _C.iou_workspace(n1, n2, gt.device)
+    for mode in (0, 1):
+        want = torch.full((n1, n2), float('nan'), device='cuda')
+        plain = {1: L.r3det_rbbox_geo_mat_iou_iof, 3: L.r3det_box_iou_rotated_overlaps}.get(geom)
+        if geom == 2:
+            _C.check(L.r3det_mmcv_box_iou_rotated(_C.ptr(gt), n1, _C.ptr(cols), n2, mode, 0, _C.ptr(want), _C.ptr(ws), wsb,
+                                                  _C.stream()), "v2")
+        else:
+            _C.check(plain(_C.ptr(gt), n1, _C.ptr(cols), n2, mode, _C.ptr(want), _C.ptr(ws), wsb, _C.stream()), "plain")
+        got = torch.full((n1, n2), float('nan'), device='cuda')
+        _C.check(L.r3det_iou_mat_prepared(geom, _C.ptr(gt), n1, _C.ptr(cols), n2, _C.ptr(prep), mode, _C.ptr(got),
+                                          _C.ptr(ws), wsb, _C.stream()), "prepared")
+        assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+    assert L.r3det_iou_prepare_columns(geom, _C.ptr(cols), n2, _C.ptr(prep), prep.numel() - 256, _C.stream()) == -3
+    assert L.r3det_iou_prepare_columns(7, _C.ptr(cols), n2, _C.ptr(prep), prep.numel(), _C.stream()) == -1
+    assert L.r3det_iou_mat_prepared(geom, _C.ptr(gt), n1, _C.ptr(cols), n2, None, 0, _C.ptr(got), _C.ptr(ws), wsb,
+                                    _C.stream()) == -1
