@@ -3,9 +3,9 @@
 # of the bench step, the training step, configs[1], the IoU and NMS ops, and the PMC passes (separate runs,
 # --kernel-trace only) of the roofline kernel and of the IoU / NMS kernels.  Output: gpurun_out/profiles_<tag>/,
 # copied into profiles/ by hand (tracked).
-#   bash tools/make_profiles.sh r03
+#   bash tools/make_profiles.sh r04
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(pwd)
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
@@ -38,6 +38,8 @@ for shp in 128x196416 512x196416 128x21824 1000x128 v3_128x196416; do
   python3 $R/tools/kstats.py /tmp/kt_run iou_ fill >> $O/${TAG}_iou_kernel_stats.txt
 done
 unset IOU_PROF_SHAPE
+# 4b. plain against prepared columns (r3det_iou_prepare_columns), same process
+python3 $R/tools/iou_prepared_ab.py > $O/${TAG}_iou_prepared_ab.txt 2>&1
 # 5. NMS op, per size, and the batched pipeline
 : > $O/${TAG}_nms_kernel_stats.txt
 for n in 2000 5344 8576 32768 v3_8576; do
@@ -60,12 +62,17 @@ for cfg in "0 4 regular" "1 4 regular" "0 2 regular" "0 4 trained" "0 4 adversar
   export FR_BWD_LEVEL=$1 FR_BWD_N=$2 FR_BWD_FIELD=$3
   kt /tmp/kt_one.txt "python3 tools/fr_bwd_prof.py  (FR_BWD_LEVEL=$1 FR_BWD_N=$2 FR_BWD_FIELD=$3)" python3 $R/tools/fr_bwd_prof.py
   cat /tmp/kt_one.txt >> $O/${TAG}_fr_backward_kernel_stats.txt
-  python3 $R/tools/kstats.py /tmp/kt_run frb_ fr_b >> $O/${TAG}_fr_backward_kernel_stats.txt
+  python3 $R/tools/kstats.py /tmp/kt_run frb_ frn_ fr_b >> $O/${TAG}_fr_backward_kernel_stats.txt
 done
 unset FR_BWD_LEVEL FR_BWD_N FR_BWD_FIELD
 cd $R
 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_fr_backward_pmc.txt fr "FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/fr_bwd_prof.py > /dev/null
 cd /tmp
+# 6b'. the training step's FR forward + backward over the pyramid (one autograd node for the five levels) and the
+#      assignment, kernels by name
+kt $O/${TAG}_train_hot_path_kernel_stats.txt "python3 tools/train_hot_path.py" python3 $R/tools/train_hot_path.py
+grep "ms" /tmp/kt_run.log | tail -8 | sed 's/^/# /' >> $O/${TAG}_train_hot_path_kernel_stats.txt
+python3 $R/tools/kstats.py /tmp/kt_run fr_ frb_ frn_ iou_ assign_ >> $O/${TAG}_train_hot_path_kernel_stats.txt
 # 6c. the plain samplers (the reference's API: r3det_feature_refine_forward NCHW, _forward_nhwc) per level, N = 4
 kt $O/${TAG}_fr_forward_kernel_stats.txt "python3 tools/fr_fwd_prof.py" python3 $R/tools/fr_fwd_prof.py
 python3 $R/tools/kstats.py /tmp/kt_run fr_ >> $O/${TAG}_fr_forward_kernel_stats.txt
