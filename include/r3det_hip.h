@@ -482,7 +482,8 @@ int r3det_bias_act(float* y, const float* bias, const float* residual, long long
  *   ("fr_walk", n)       strip height of the tile-pair launch order of the channels_last kernels (0 row-major, default 8)
  *   ("fr_profile", 0 | 1 every kernel | 2 first start and last stop only)      see r3det_fr_profile_read
  *   ("frb_impl", 0 auto | 1 general index form | 2 unpaired NHWC gather | 3 SELL rows by their own launch |
- *                5 SELL rows and CSR lists from one launch | 6 pyramid levels indexed one by one)
+ *                5 SELL rows and CSR lists from one launch | 6 pyramid levels one launch each: indexes, coarse-level
+ *                samplers and gathers)
  *   ("iou_impl", 0 auto | 1 one thread per pair | 2 one-launch tile kernel | 4 stream + drain always),
  *   ("iou_small", columns from which the pipeline runs), ("iou_qcap", n: per-wave survivor capacity, small values
  *   force the dense-tile path), ("iou_dwgs", drain workgroups), ("nms_impl", 0 | 1 tiles | 2 one reducer workgroup),

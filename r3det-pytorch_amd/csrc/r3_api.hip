@@ -1,5 +1,6 @@
 // r3_api.hip -- extern "C" entry points declared in include/r3det_hip.h.
 // Argument validation + dispatch only; kernels live in r3_iou.hip / r3_nms.hip / r3_fr.hip.
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -376,15 +377,12 @@ int r3det_feature_refine_forward_levels(int levels, const float* const* features
   if (levels < 0 || N < 0 || C < 0 || (levels > 0 && (!features || !best_bboxes || !H || !W || !spatial_scales || !outputs)))
     return R3DET_EINVAL;
   if (ws && ws_bytes < r3det_fr_levels_workspace_bytes(levels, N, H, W, points)) return R3DET_EWS;
-  char* p = static_cast<char*>(ws);
   for (int l = 0; l < levels; l++) {
-    const size_t part = r3k_fr_workspace_bytes(N, H[l], W[l], points);
-    const int k = r3det_feature_refine_forward(features[l], best_bboxes[l], N, C, H[l], W[l], spatial_scales[l], points,
-                                               outputs[l], p, p ? part : 0, stream);
-    if (k != R3DET_OK) return k;
-    if (p) p += part;
+    if (H[l] < 0 || W[l] < 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
+    if ((size_t)N * C * H[l] * W[l] > 0 && (!features[l] || !best_bboxes[l] || !outputs[l])) return R3DET_EINVAL;
   }
-  return R3DET_OK;
+  return rc(r3k_fr_forward_levels(levels, features, best_bboxes, N, C, H, W, spatial_scales, points, outputs, ws, ws_bytes,
+                                  S(stream)));
 }
 
 int r3det_feature_refine_backward(const float* top_grad, const float* best_bboxes, int N, int C,
@@ -482,16 +480,23 @@ int r3det_feature_refine_backward_levels_indexed(int levels, const float* const*
       (levels > 0 && (!top_grads || !best_bboxes || !H || !W || !spatial_scales || !bottom_grads)))
     return R3DET_EINVAL;
   if (ws_bytes < r3det_fr_backward_levels_workspace_bytes(levels, N, H, W, points)) return R3DET_EWS;
+  std::vector<void*> parts(levels);
+  std::vector<size_t> part_bytes(levels);
+  std::vector<int> taken(levels);
   char* p = static_cast<char*>(ws);
   for (int l = 0; l < levels; l++) {
-    const size_t part = lvl_bytes(N, H[l], W[l], points);
-    int k = -1;
-    if (part) k = r3k_frn_gather(top_grads[l], N, C, H[l], W[l], points, bottom_grads[l], overwrite, p, part, S(stream));
-    if (k == -1)  // no gather form for this (shape, C): the scatter kernels, from the boxes
-      k = r3k_fr_backward(top_grads[l], best_bboxes[l], N, C, H[l], W[l], spatial_scales[l], points, bottom_grads[l],
-                          overwrite, nullptr, 0, 0, S(stream));
-    if (k) return rc(k);
-    p += part;
+    part_bytes[l] = lvl_bytes(N, H[l], W[l], points);
+    parts[l] = part_bytes[l] ? p : nullptr;
+    p += part_bytes[l];
+  }
+  const int k = r3k_frn_gather_levels(levels, top_grads, N, C, H, W, points, bottom_grads, overwrite, parts.data(), part_bytes.data(),
+                                      taken.data(),                                      S(stream));
+  if (k) return rc(k);
+  for (int l = 0; l < levels; l++) {
+    if (taken[l]) continue;  // no gather form for this (shape, C): the scatter kernels, from the boxes
+    const int k2 = r3k_fr_backward(top_grads[l], best_bboxes[l], N, C, H[l], W[l], spatial_scales[l], points, bottom_grads[l],
+                                   overwrite, nullptr, 0, 0, S(stream));
+    if (k2) return rc(k2);
   }
   return R3DET_OK;
 }

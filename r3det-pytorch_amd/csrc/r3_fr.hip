@@ -121,21 +121,21 @@ constexpr int FRP_STAGE_UNROLL = 4;
 // global (contiguous nc planes of HW floats) -> LDS planes with row pitch W+1
 template <bool VEC>
 __device__ __forceinline__ void stage_planes(const float* __restrict__ src, float* lds, int nc, int HW,
-                                             int W, int pitch, int psz) {
+                                             int W, int pitch, int psz, const int tid, const int T) {
   const int total = nc * HW;
   if (VEC) {
     const float4* s4 = reinterpret_cast<const float4*>(src);
     const int total4 = total >> 2;
-    for (int base = threadIdx.x; base < total4; base += FRP_BLOCK * FRP_STAGE_UNROLL) {
+    for (int base = tid; base < total4; base += T * FRP_STAGE_UNROLL) {
       float4 v[FRP_STAGE_UNROLL];
 #pragma unroll
       for (int k = 0; k < FRP_STAGE_UNROLL; k++) {
-        int i = base + k * FRP_BLOCK;
+        int i = base + k * T;
         if (i < total4) v[k] = s4[i];
       }
 #pragma unroll
       for (int k = 0; k < FRP_STAGE_UNROLL; k++) {
-        int i = base + k * FRP_BLOCK;
+        int i = base + k * T;
         if (i < total4) {
           int e = i << 2;
           int ch = e / HW, r = e - ch * HW;
@@ -146,7 +146,7 @@ __device__ __forceinline__ void stage_planes(const float* __restrict__ src, floa
       }
     }
   } else {
-    for (int e = threadIdx.x; e < total; e += FRP_BLOCK) {
+    for (int e = tid; e < total; e += T) {
       int ch = e / HW, r = e - ch * HW;
       int y = r / W, x = r - y * W;
       lds[ch * psz + y * pitch + x] = src[e];
@@ -159,16 +159,18 @@ __device__ __forceinline__ void stage_planes(const float* __restrict__ src, floa
 // waits for every store issued before them unless the boxes were requested BEFORE those stores
 // and the compiler can count the younger stores (s_waitcnt vmcnt(NC) instead of vmcnt(0)).
 template <int POINTS, bool VEC, int NC>
-__global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __restrict__ feat,
-                                                              const float* __restrict__ boxes,
-                                                              int C, int H, int W, float scale,
-                                                              int cpb, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// (tid, T: the thread's index among the T threads that work on this (image, channel group) -- the whole workgroup
+// for the per-level launches, a quarter of it in the levels grid; lds_off: where their planes start)
+__device__ __forceinline__ void fr_forward_plane_body(const float* __restrict__ feat, const float* __restrict__ boxes,
+                                                      int C, int H, int W, float scale, int cpb,
+                                                      float* __restrict__ out, const int bx, const int n, const int tid,
+                                                      const int T, const int lds_off) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  float* lds = lds_all + lds_off;
   const int HW = H * W;
   const int pitch = W + 1;
   const int psz = H * pitch;
-  const int n = blockIdx.y;
-  const int c0 = blockIdx.x * cpb;
+  const int c0 = bx * cpb;
   const int nc = NC > 0 ? NC : min(cpb, C - c0);
   const float* src = feat + ((size_t)n * C + c0) * HW;
   float* dst = out + ((size_t)n * C + c0) * HW;
@@ -176,19 +178,19 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __res
     const float4* bx4 = reinterpret_cast<const float4*>(boxes + (size_t)n * HW * 5);
     const int quads = HW >> 2;
     float4 nb[5];  // boxes of this thread's first quad: requested before staging
-    if ((int)threadIdx.x < quads) {
+    if (tid < quads) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) nb[k] = bx4[threadIdx.x * 5 + k];
+      for (int k = 0; k < 5; k++) nb[k] = bx4[tid * 5 + k];
     }
-    stage_planes<true>(src, lds, nc, HW, W, pitch, psz);
+    stage_planes<true>(src, lds, nc, HW, W, pitch, psz, tid, T);
     __syncthreads();
-    for (int qd = threadIdx.x; qd < quads; qd += FRP_BLOCK) {
+    for (int qd = tid; qd < quads; qd += T) {
       float bq[20];
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         bq[4 * k] = nb[k].x; bq[4 * k + 1] = nb[k].y; bq[4 * k + 2] = nb[k].z; bq[4 * k + 3] = nb[k].w;
       }
-      const int nq = qd + FRP_BLOCK;
+      const int nq = qd + T;
       if (nq < quads) {
 #pragma unroll
         for (int k = 0; k < 5; k++) nb[k] = bx4[nq * 5 + k];  // next quad: before this quad's stores
@@ -216,9 +218,9 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __res
       }
     }
   } else {
-    stage_planes<false>(src, lds, nc, HW, W, pitch, psz);
+    stage_planes<false>(src, lds, nc, HW, W, pitch, psz, tid, T);
     __syncthreads();
-    for (int hw = threadIdx.x; hw < HW; hw += FRP_BLOCK) {
+    for (int hw = tid; hw < HW; hw += T) {
       Tap taps[POINTS];
       make_taps<POINTS>(boxes + ((size_t)n * HW + hw) * 5, scale, H, W, pitch, taps);
       const int y = hw / W, x = hw - y * W;
@@ -232,6 +234,93 @@ __global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __res
       }
     }
   }
+}
+
+template <int POINTS, bool VEC, int NC>
+__global__ __launch_bounds__(FRP_BLOCK) void fr_forward_plane(const float* __restrict__ feat,
+                                                              const float* __restrict__ boxes,
+                                                              int C, int H, int W, float scale,
+                                                              int cpb, float* __restrict__ out) {
+  fr_forward_plane_body<POINTS, VEC, NC>(feat, boxes, C, H, W, scale, cpb, out, blockIdx.x, blockIdx.y, threadIdx.x,
+                                         FRP_BLOCK, 0);
+}
+
+// Several levels of a pyramid as ONE grid (points = 1, the float4 form): the coarse levels of a 1024^2 input are
+// 4-6 us launches of latency each on their own.  The levels ride in the kernel arguments, a block finds its level from
+// block ranges (as fr_forward_nhwc_occ_levels does); the body is the per-level kernel's.
+constexpr int FRPL_MAX = 8;
+constexpr int FRPL_T = 256;      // threads per (image, channel group) in the levels grid
+constexpr int FRPL_BLOCK = 256;  // threads per workgroup of the levels grid
+struct FrPlaneLevel {
+  const float* feat;
+  const float* boxes;
+  float* out;
+  float scale;
+  int H, W, cpb, gx, first, N;  // gx: channel groups per image; first: the level's first block
+};
+struct FrPlaneLevels {
+  FrPlaneLevel l[FRPL_MAX];
+  int n;
+  // the tap table of a level that takes the cell kernel (blocks from tfirst on; none: tfirst < 0): the small launch
+  // in front of that kernel rides in this grid, which then goes first
+  const float* tboxes;
+  float* table;
+  float tscale;
+  int tN, tH, tW, tfirst;
+};
+
+// sample coordinates (row y <- x_ctr * scale, column x <- y_ctr * scale) -> the tap the cell kernel
+// keeps: the clamps of bilinear_interpolate (feature_refine_kernel.cu:22-47) applied once; an
+// out-of-range sample points at the zero cell (row H + 1)
+__device__ __forceinline__ void cell_tap(float y, float x, int H, int W, float& ty, float& tx) {
+  if (y < -1.0 || y > H || x < -1.0 || x > W) {
+    y = (float)(H + 1);
+    x = 0.f;
+  } else {
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    if ((int)y >= H - 1) y = (float)(H - 1);
+    if ((int)x >= W - 1) x = (float)(W - 1);
+  }
+  ty = y;
+  tx = x;
+}
+
+__device__ __forceinline__ void fr_cell_table_body(const float* __restrict__ boxes, int N, int H, int W, float scale,
+                                                   float* __restrict__ table, const int pos) {
+  const int HW = H * W;
+  if (pos >= N * HW) return;
+  float y, x;
+  cell_tap(boxes[(size_t)pos * 5] * scale, boxes[(size_t)pos * 5 + 1] * scale, H, W, y, x);  // sic: row <- x_ctr
+  const int n = pos / HW, p = pos - n * HW;
+  table[(size_t)n * 2 * HW + p] = y;  // per image: [y: HW floats][x: HW floats]
+  table[(size_t)n * 2 * HW + HW + p] = x;
+}
+
+__global__ __launch_bounds__(FRPL_BLOCK) void fr_forward_plane_levels(const FrPlaneLevels A, int C) {
+  if (A.tfirst >= 0 && (int)blockIdx.x >= A.tfirst) {
+    fr_cell_table_body(A.tboxes, A.tN, A.tH, A.tW, A.tscale, A.table, ((int)blockIdx.x - A.tfirst) * FRPL_BLOCK + (int)threadIdx.x);
+    return;
+  }
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < FRPL_MAX; i++)
+    if (i < A.n && (int)blockIdx.x >= A.l[i].first) k = i;
+  const FrPlaneLevel& L = A.l[k];
+  // A coarse level's plane is 16 ... 256 quads of positions: FRPL_T threads work on one (image, channel group), a
+  // workgroup on FRPL_BLOCK / FRPL_T of them side by side.
+  const int unit = ((int)blockIdx.x - L.first) * (FRPL_BLOCK / FRPL_T) + (int)(threadIdx.x / FRPL_T);
+  const int tid = threadIdx.x & (FRPL_T - 1);
+  const int n = unit / L.gx, bx = unit - n * L.gx;
+  if (n >= L.N) {  // (a last workgroup's idle quarters keep the barrier)
+    __syncthreads();
+    return;
+  }
+  const int off = (int)(threadIdx.x / FRPL_T) * L.cpb * L.H * (L.W + 1);
+  // (planes per unit at compile time where it is 1 or 2, as the per-level launches have it)
+  if (L.cpb == 1) fr_forward_plane_body<1, true, 1>(L.feat, L.boxes, C, L.H, L.W, L.scale, 1, L.out, bx, n, tid, FRPL_T, off);
+  else if (L.cpb == 2) fr_forward_plane_body<1, true, 2>(L.feat, L.boxes, C, L.H, L.W, L.scale, 2, L.out, bx, n, tid, FRPL_T, off);
+  else fr_forward_plane_body<1, true, 0>(L.feat, L.boxes, C, L.H, L.W, L.scale, L.cpb, L.out, bx, n, tid, FRPL_T, off);
 }
 
 // backward: accumulate the plane's gradient in LDS (ds_add_f32), then one coalesced
@@ -1108,33 +1197,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 //   * weights in packed fp32: {w1, w2} = hy * {hx, lx}, {w3, w4} = ly * {hx, lx}; products and
 //     the left-to-right sum keep the reference's operation order (bit-identical results).
 // ----------------------------------------------------------------------------------------
-// sample coordinates (row y <- x_ctr * scale, column x <- y_ctr * scale) -> the tap the cell kernel
-// keeps: the clamps of bilinear_interpolate (feature_refine_kernel.cu:22-47) applied once; an
-// out-of-range sample points at the zero cell (row H + 1)
-__device__ __forceinline__ void cell_tap(float y, float x, int H, int W, float& ty, float& tx) {
-  if (y < -1.0 || y > H || x < -1.0 || x > W) {
-    y = (float)(H + 1);
-    x = 0.f;
-  } else {
-    if (y <= 0) y = 0;
-    if (x <= 0) x = 0;
-    if ((int)y >= H - 1) y = (float)(H - 1);
-    if ((int)x >= W - 1) x = (float)(W - 1);
-  }
-  ty = y;
-  tx = x;
-}
-
 __global__ __launch_bounds__(256) void fr_cell_table_kernel(const float* __restrict__ boxes, int N, int H, int W,
                                                             float scale, float* __restrict__ table) {
-  const int HW = H * W;
-  const int pos = blockIdx.x * 256 + threadIdx.x;
-  if (pos >= N * HW) return;
-  float y, x;
-  cell_tap(boxes[(size_t)pos * 5] * scale, boxes[(size_t)pos * 5 + 1] * scale, H, W, y, x);  // sic: row <- x_ctr
-  const int n = pos / HW, p = pos - n * HW;
-  table[(size_t)n * 2 * HW + p] = y;  // per image: [y: HW floats][x: HW floats]
-  table[(size_t)n * 2 * HW + HW + p] = x;
+  fr_cell_table_body(boxes, N, H, W, scale, table, blockIdx.x * 256 + threadIdx.x);
 }
 
 typedef float fr_f2 __attribute__((ext_vector_type(2)));
@@ -1450,6 +1515,98 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
       hipLaunchKernelGGL(fr_forward_generic<5>, grid, dim3(FR_BLOCK), 0, stream, feat, boxes, C, H, W, scale, cpbk, out);
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// All levels of an NCHW pass: the levels that take the float4 plane kernel (the coarse levels of a pyramid) are ONE
+// grid, every other level (the cell kernel's 128 x 128 / 64 x 64 planes, points = 5, odd shapes) its own launch as
+// r3k_fr_forward would make it.  Pointer arrays are HOST arrays; ws (may be null) is carved level by level into
+// r3k_fr_workspace_bytes parts.
+int r3k_fr_forward_levels(int levels, const float* const* feat, const float* const* boxes, int N, int C, const int* H,
+                          const int* W, const float* scales, int points, float* const* out, void* ws, size_t ws_bytes,
+                          hipStream_t stream) {
+  if (levels < 0 || (levels > 0 && (!feat || !boxes || !H || !W || !scales || !out))) return -1;
+  FrPlaneLevels A;
+  A.n = 0;
+  int blocks = 0;
+  size_t lds = 0;
+  bool grouped[FRPL_MAX] = {};
+  for (int l = 0; l < levels && levels <= FRPL_MAX; l++) {
+    if (points != 1 || g_r3_fr_impl != 0 || g_r3_frb_impl == 6 || r3_fr_dbg() != 0 || N <= 0 || C <= 0 || H[l] <= 0 || W[l] <= 0) break;
+    // (64 x 64 as planes inside the grid instead of the cell kernel in front of it, measured: 48.7-49.4 against 46.0 us
+    // for the five levels at N = 4, 45 against 30.7 at N = 2)
+    const bool cell_shape = (W[l] == 128 && H[l] == 128) || (W[l] == 64 && H[l] == 64);
+    int cpb = plane_cpb(C, H[l], W[l]);
+    const bool vec = (W[l] % 4 == 0) && feat[l] && boxes[l] && out[l] && aligned16(feat[l]) && aligned16(boxes[l]) &&
+                     aligned16(out[l]);
+    if (cell_shape || cpb <= 0 || !vec || (FRPL_BLOCK / FRPL_T) * H[l] * (W[l] + 1) > FRP_LDS_FLOATS) continue;
+    FrPlaneLevel& L = A.l[A.n++];
+    L.feat = feat[l], L.boxes = boxes[l], L.out = out[l], L.scale = scales[l], L.H = H[l], L.W = W[l], L.cpb = cpb;
+    grouped[l] = true;
+  }
+  // a level that takes the cell kernel with a tap table (128 x 128): its table rides in the grid
+  int tl = -1;
+  char* tws = nullptr;
+  if (A.n >= 1 && !g_r3_fr_profile) {
+    char* q = static_cast<char*>(ws);
+    size_t left = ws_bytes;
+    for (int l = 0; l < levels && q; l++) {
+      const size_t part = r3k_fr_workspace_bytes(N, H[l], W[l], points);
+      int G = 1;
+      while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
+      if (tl < 0 && W[l] == 128 && H[l] == 128 && G >= 2 && left >= part && aligned16(q) && feat[l] && boxes[l] && out[l] &&
+          aligned16(feat[l]) && aligned16(out[l]) && (long long)N * H[l] * W[l] < (1LL << 30)) {
+        tl = l;
+        tws = q;
+      }
+      q += part;
+      left = left >= part ? left - part : 0;
+    }
+  }
+  if (A.n + (tl >= 0 ? 1 : 0) < 2) {  // nothing to group
+    A.n = 0;
+    tl = -1;
+    for (int l = 0; l < FRPL_MAX; l++) grouped[l] = false;
+  }
+  for (int i = 0; i < A.n; i++) {
+    FrPlaneLevel& L = A.l[i];
+    int cpb = L.cpb;  // (what the LDS holds)
+    constexpr int U = FRPL_BLOCK / FRPL_T;  // (image, channel group) units per workgroup
+    while (cpb > 1 && ((size_t)N * ((C + cpb - 1) / cpb) < 512 || C % cpb || U * cpb * L.H * (L.W + 1) > FRP_LDS_FLOATS))
+      cpb = (cpb + 1) / 2;  // (spread as r3k_fr_forward spreads them)
+    L.cpb = cpb, L.gx = C / cpb, L.first = blocks, L.N = N;
+    blocks += (L.gx * N + U - 1) / U;
+    lds = std::max(lds, (size_t)U * cpb * L.H * (L.W + 1) * sizeof(float));
+  }
+  A.tfirst = -1, A.tboxes = nullptr, A.table = nullptr, A.tscale = 0.f, A.tN = A.tH = A.tW = 0;
+  if (tl >= 0) {
+    A.tfirst = blocks, A.tboxes = boxes[tl], A.table = reinterpret_cast<float*>(tws), A.tscale = scales[tl];
+    A.tN = N, A.tH = H[tl], A.tW = W[tl];
+    blocks += (N * H[tl] * W[tl] + FRPL_BLOCK - 1) / FRPL_BLOCK;
+  }
+  if (A.n) {  // (first: the cell kernel below reads the table)
+    for (int i = A.n; i < FRPL_MAX; i++) A.l[i] = A.l[A.n - 1];
+    static R3DeviceOnce once;
+    if (once.first()) allow_big_lds(fr_forward_plane_levels, FRP_LDS_FLOATS * 4);
+    hipLaunchKernelGGL(fr_forward_plane_levels, dim3(blocks), dim3(FRPL_BLOCK), lds, stream, A, C);
+    if (hipGetLastError() != hipSuccess) return -2;
+  }
+  char* p = static_cast<char*>(ws);
+  for (int l = 0; l < levels; l++) {
+    const size_t part = r3k_fr_workspace_bytes(N, H[l], W[l], points);
+    if (l == tl) {
+      const int k = r3k_fr_forward_prepared(feat[l], nullptr, nullptr, A.table, N, C, H[l], W[l], out[l], stream);
+      if (k) return k;
+    } else if (!(l < FRPL_MAX && grouped[l])) {
+      const int k = r3k_fr_forward(feat[l], boxes[l], N, C, H[l], W[l], scales[l], points, out[l], p,
+                                   p && ws_bytes >= part ? part : 0, stream);
+      if (k) return k;
+    }
+    if (p) {
+      p += part;
+      ws_bytes = ws_bytes >= part ? ws_bytes - part : 0;
+    }
+  }
+  return 0;
 }
 
 // Split form of the cell path: the tap table of a level is built ahead of time (for instance for all

@@ -865,13 +865,12 @@ __device__ __forceinline__ float frn_get(const typename FrnVec<CP>::type& v, int
 typedef unsigned int frn_u4 __attribute__((ext_vector_type(4)));
 
 template <int K, int CP>
-__global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restrict__ top, const int* __restrict__ slicehdr,
-                                                           const int4* __restrict__ sell,
-                                                           const int2* __restrict__ cellinfo,
-                                                           const int2* __restrict__ entries, int C, int H, int W,
-                                                           int wshift, int cap, int EPI, int accum, int xcd,
-                                                           float* __restrict__ bottom,
-                                                           unsigned long long* __restrict__ stamps) {
+__device__ __forceinline__ void frn_gather_body(const float* __restrict__ top, const int* __restrict__ slicehdr,
+                                                const int4* __restrict__ sell, const int2* __restrict__ cellinfo,
+                                                const int2* __restrict__ entries, int C, int H, int W, int wshift,
+                                                int cap, int EPI, int accum, int xcd, float* __restrict__ bottom,
+                                                unsigned long long* __restrict__ stamps, const unsigned block,
+                                                const unsigned nblocks) {
   typedef typename FrnVec<CP>::type V;
   // (probes builds: clock stamps of wavefront 0 at the phase boundaries, tools/frn_stamps.py; s_memrealtime: 100 MHz,
   // one clock for the chip)
@@ -888,8 +887,8 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
   const int CG = C / CP;  // channel groups = workgroups per image
   // workgroups of one image on as few XCDs as possible (blockIdx & 7 = XCD under round-robin dispatch): an XCD's L2
   // then holds the index of one or two images instead of streaming all of them
-  unsigned bid = blockIdx.x;
-  if (xcd && (gridDim.x & 7) == 0) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+  unsigned bid = block;
+  if (xcd && (nblocks & 7) == 0) bid = (bid & 7u) * (nblocks >> 3) + (bid >> 3);
   const int n = (int)bid / CG, g0 = (int)bid - n * CG;
   // LDS index of cell q: a shift for the power-of-two widths of a pyramid; else by the float quotient (q < 2^24:
   // off by at most one)
@@ -1108,6 +1107,50 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
 #endif
 }
 
+template <int K, int CP>
+__global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restrict__ top, const int* __restrict__ slicehdr,
+                                                           const int4* __restrict__ sell,
+                                                           const int2* __restrict__ cellinfo,
+                                                           const int2* __restrict__ entries, int C, int H, int W,
+                                                           int wshift, int cap, int EPI, int accum, int xcd,
+                                                           float* __restrict__ bottom,
+                                                           unsigned long long* __restrict__ stamps) {
+  frn_gather_body<K, CP>(top, slicehdr, sell, cellinfo, entries, C, H, W, wshift, cap, EPI, accum, xcd, bottom, stamps,
+                         blockIdx.x, gridDim.x);
+}
+
+// The coarse levels of a pyramid (planes of at most 4096 cells: one or four slices per wavefront, four channels per
+// workgroup) as ONE grid: each is a 5-9 us launch of latency on its own.  Levels in the kernel arguments, a block finds its level
+// from block ranges; the body is the per-level kernel's.
+constexpr int FRNL_MAX = 8;
+struct FrnLevel {
+  const float* top;
+  const int* slicehdr;
+  const int4* sell;
+  const int2* cellinfo;
+  const int2* entries;
+  float* bottom;
+  int H, W, wshift, cap, EPI, first, K;
+};
+struct FrnLevels {
+  FrnLevel l[FRNL_MAX];
+  int n;
+};
+
+__global__ __launch_bounds__(FRN_T) void frn_gather_levels_kernel(const FrnLevels A, int C, int accum) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < FRNL_MAX; i++)
+    if (i < A.n && (int)blockIdx.x >= A.l[i].first) k = i;
+  const FrnLevel& L = A.l[k];
+  if (L.K == 4)
+    frn_gather_body<4, 4>(L.top, L.slicehdr, L.sell, L.cellinfo, L.entries, C, L.H, L.W, L.wshift, L.cap, L.EPI, accum, 0,
+                          L.bottom, nullptr, blockIdx.x - (unsigned)L.first, 0u);
+  else
+    frn_gather_body<1, 4>(L.top, L.slicehdr, L.sell, L.cellinfo, L.entries, C, L.H, L.W, L.wshift, L.cap, L.EPI, accum, 0,
+                          L.bottom, nullptr, blockIdx.x - (unsigned)L.first, 0u);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename K>
@@ -1298,6 +1341,57 @@ int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, co
   if (once.first()) allow_big_lds(frb_index_sort_levels_kernel, (int)sizeof(IxsLds));
   hipLaunchKernelGGL(frb_index_sort_levels_kernel, dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// The gathers of several levels over their indexes (ws[l]: r3k_frn_index / r3k_frn_index_levels for this C): the
+// levels of at most 4096 cells as ONE grid, the others one launch each.  taken[l] = 0 for a level without a gather
+// form (the caller's scatter kernels), else 1.  Pointer arrays are HOST arrays.
+int r3k_frn_gather_levels(int levels, const float* const* top_grad, int N, int C, const int* H, const int* W, int points,
+                          float* const* bottom_grad, int overwrite, void* const* ws, const size_t* ws_bytes, int* taken,
+                          hipStream_t stream) {
+  FrnLevels A;
+  A.n = 0;
+  int blocks = 0;
+  size_t lds = 0;
+  bool grouped[FRNL_MAX] = {};
+  for (int l = 0; l < levels && levels <= FRNL_MAX && g_r3_frb_impl != 6; l++) {
+    int K, cp;
+    const size_t need = r3k_frn_workspace_bytes(N, H[l], W[l], points);
+    if (need == 0 || !top_grad[l] || !bottom_grad[l] || !ws[l] || !aligned16(ws[l]) || ws_bytes[l] < need ||
+        !frn_config(C, H[l], W[l], K, cp) || (K != 1 && K != 4) || cp != 4)
+      continue;
+    const FrnLayout L = frn_layout(ws[l], N, C, H[l], W[l], points);
+    FrnLevel& a = A.l[A.n++];
+    a.top = top_grad[l], a.slicehdr = L.slicehdr, a.sell = L.sell, a.cellinfo = L.csr.cellinfo, a.entries = L.csr.entries;
+    a.bottom = bottom_grad[l], a.H = H[l], a.W = W[l], a.cap = L.cap, a.EPI = H[l] * W[l] * 4 * points, a.first = blocks;
+    a.K = K, a.wshift = -1;
+    if ((W[l] & (W[l] - 1)) == 0)
+      for (a.wshift = 0; (1 << a.wshift) < W[l]; a.wshift++) {}
+    blocks += N * (C / 4);
+    lds = std::max(lds, ((size_t)H[l] * L.pitch + 1) * 4 * 4 + FRN_TAB_BYTES);
+    grouped[l] = true;
+  }
+  if (A.n < 2) {
+    A.n = 0;
+    for (int l = 0; l < FRNL_MAX; l++) grouped[l] = false;
+  }
+  for (int l = 0; l < levels; l++) {
+    taken[l] = 1;
+    if (l < FRNL_MAX && grouped[l]) continue;
+    const int k = ws[l] ? r3k_frn_gather(top_grad[l], N, C, H[l], W[l], points, bottom_grad[l], overwrite, ws[l], ws_bytes[l],
+                                         stream)
+                        : -1;
+    if (k == -1) taken[l] = 0;
+    else if (k) return k;
+  }
+  if (A.n) {
+    for (int i = A.n; i < FRNL_MAX; i++) A.l[i] = A.l[A.n - 1];
+    static R3DeviceOnce once;
+    if (once.first()) allow_big_lds(frn_gather_levels_kernel, (int)FRN_LDS_MAX);
+    hipLaunchKernelGGL(frn_gather_levels_kernel, dim3(blocks), dim3(FRN_T), lds, stream, A, C, overwrite ? 0 : 1);
+    if (hipGetLastError() != hipSuccess) return -2;
+  }
+  return 0;
 }
 
 // bottom_grad (N, C, H, W) = [bottom_grad +] backward(top_grad) over the index in ws (r3k_frn_index for this C)

@@ -80,6 +80,9 @@ size_t r3k_fr_workspace_bytes(int N, int H, int W, int points);
 // ws may be null (taps derived per channel plane); with a workspace: tap table + unpack kernel
 int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, int W, float scale,
                    int points, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
+int r3k_fr_forward_levels(int levels, const float* const* feat, const float* const* boxes, int N, int C, const int* H,
+                          const int* W, const float* scales, int points, float* const* out, void* ws, size_t ws_bytes,
+                          hipStream_t stream);
 // ws may be null; with r3k_fr_backward_workspace_bytes() of workspace the call is the gather over the inverse tap
 // index (r3_frb.hip); index_ready: ws holds r3k_frn_index of these boxes
 size_t r3k_fr_backward_workspace_bytes(int N, int H, int W, int points);
@@ -94,6 +97,9 @@ int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, co
                          const float* scales, int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream);
 int r3k_frn_gather(const float* top_grad, int N, int C, int H, int W, int points, float* bottom_grad, int overwrite,
                    void* ws, size_t ws_bytes, hipStream_t stream);
+int r3k_frn_gather_levels(int levels, const float* const* top_grad, int N, int C, const int* H, const int* W, int points,
+                          float* const* bottom_grad, int overwrite, void* const* ws, const size_t* ws_bytes, int* taken,
+                          hipStream_t stream);
 
 // polygon ops outside the shipped configs (r3_poly.hip)
 int r3k_nms_reduce_dense(const unsigned long long* mask, int n, int cb, const int64_t* order, int64_t* keep_out,
