@@ -700,7 +700,7 @@ __device__ __forceinline__ void fr_forward_nhwc_occ_body(
   }
   if (LEAN) {
     // The same kernel with 32-bit index arithmetic (per-image base pointers, unsigned byte offsets: the launcher
-    // sends tensors of 4 GB and more through the other form) and the taps as (row, column) pairs instead of plane
+    // sends images of 4 GB and more through the other form) and the taps as (row, column) pairs instead of plane
     // offsets that have to be divided by W again: the first form issues ~2.3 instructions for every one here, and a
     // compute unit issues one scalar instruction per cycle for all its waves (PMC, r3_frb.hip's gather: same finding).
     const int h = ty * NH_ROWS + wave;
@@ -1684,7 +1684,7 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   // 144 pairs, 16.0 against 11.7 us inside the model; fr_dbg 8 forces the wide form (tests)
   if (occ && paired && H == W && (H & 7) == 0 &&
       ((dbg == 0 && (long long)(H / 8) * (H / 8) * N >= 512) || dbg == 8) &&
-      (unsigned long long)N * H * W * C * 4ull < (1ull << 32)) {
+      (unsigned long long)H * W * C * 4ull < (1ull << 32)) {
     const int S = H / 8;
     const long long Tw = (long long)S * S * N;
     const dim3 gw((unsigned)Tw), bw(1024);
@@ -1713,7 +1713,7 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     // residual rows in phase 1 (16 more VGPRs) 60.6 us.  The pair walk in strips (r3_fr_tap.h) 60.9 -> 59.4 us at
     // unchanged FETCH.  What is left above the algorithmic bytes (+45 MB of 207 MB read) is exactly the out-of-tile
     // tap rows of about half the tile edges (fields without such taps: FETCH = 204 MB), whatever the launch order.
-    const bool big = (unsigned long long)N * H * W * C * 4ull >= (1ull << 32);  // (32-bit byte offsets inside an image)
+    const bool big = (unsigned long long)H * W * C * 4ull >= (1ull << 32);  // (32-bit byte offsets inside an image)
     const int var = (dbg == 3 || big) ? 0 : dbg == 4 ? 1 : dbg == 5 ? 2 : dbg == 6 ? 6 : 14;
 #undef R3_ARGS
 #define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x | (g_r3_fr_walk << 20), tpi, (int)T, out
@@ -1726,7 +1726,7 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     else if (var == 6) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 6>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
     else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 14>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
   } while (0)
-#else  // (the shipped form; tensors of 4 GB and more: the form with 64-bit offsets)
+#else  // (the shipped form; images of 4 GB and more: the form with 64-bit offsets)
 #define R3_OCC(F, P) \
   do { \
     if (var == 0) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 0>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
@@ -1776,7 +1776,7 @@ int r3k_fr_forward_nhwc_levels(int levels, const float* const* a, const float* c
   for (int l = 0; l < levels && levels <= FRL_MAX; l++) {
     const int tiles_x = (W[l] + 3) / 4, tiles_y = (H[l] + NH_ROWS - 1) / NH_ROWS;
     const bool wide = H[l] == W[l] && (H[l] & 7) == 0 && (long long)(H[l] / 8) * (H[l] / 8) * N >= 512;
-    const bool big = (unsigned long long)N * H[l] * W[l] * C * 4ull >= (1ull << 32);
+    const bool big = (unsigned long long)H[l] * W[l] * C * 4ull >= (1ull << 32);
     const bool ok = points == 1 && r3_fr_dbg() == 0 && tiles_x == tiles_y && !wide && !big && N > 0 && C > 0 && !(C & 3) &&
                     a[l] && boxes[l] && out[l] && aligned16(a[l]) && aligned16(out[l]) &&
                     (!has_b || (b[l] && aligned16(b[l]))) && (!has_res || (res[l] && aligned16(res[l]))) &&

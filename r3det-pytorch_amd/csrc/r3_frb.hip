@@ -592,7 +592,7 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_levels_kernel(const FrbLe
 // PAIRED (square tile grids): 8 waves = the 4 x 4 cell tile (i, j) and its transpose (j, i), four waves each;
 // the diagonal tiles two by two (every workgroup has two full halves).  Tiles are dealt to the XCDs in
 // contiguous bands (blockIdx & 7 = XCD under round-robin dispatch).
-// All index arithmetic in 32 bits (the launcher refuses tensors of 4 GB and more), everything about a cell's list in
+// All index arithmetic in 32 bits (the launcher refuses IMAGES of 4 GB and more), everything about a cell's list in
 // scalar registers: the first version of this kernel spent 640 scalar instructions per wavefront on 64-bit address
 // arithmetic and register spills and was bound by their issue (PMC: 10.5 M scalar of 15.5 M instructions).
 template <bool ACCUM, bool PAIRED>
@@ -1235,6 +1235,8 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
   if (!top_grad || !bottom_grad || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (C & 3) || !aligned16(top_grad) ||
       !aligned16(bottom_grad))
     return -1;
+  // (32-bit byte offsets inside an IMAGE, 64-bit image bases; tested before anything is launched: -1 = nothing ran)
+  if ((unsigned long long)H * W * C * 4ull >= (1ull << 32)) return -1;
   if (!index_ready) {
     const int rc = r3k_frb_index(boxes, N, H, W, scale, points, ws, ws_bytes, stream);
     if (rc) return rc;
@@ -1242,7 +1244,6 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
              ws_bytes < r3k_frb_workspace_bytes(N, H, W, points)) {
     return -1;
   }
-  if ((unsigned long long)N * H * W * C * 4ull >= (1ull << 32)) return -1;  // (32-bit byte offsets inside an image)
   const FrbLayout L = frb_layout(ws, N, H, W, points);
   const int tiles_x = (W + 3) / 4, tiles_y = (H + 3) / 4;
   const bool paired = tiles_x == tiles_y && g_r3_frb_impl != 2;

@@ -326,3 +326,58 @@ def test_rretinanet_full_size_config1():
     assert len(res) == 2 and all(r[0].size(1) == 6 and 0 < r[0].size(0) <= 2000 for r in res)
     # (MIOpen may pick another kernel for the repeated forward: counts agree to the rounding of a few scores)
     assert all(abs(r[0].size(0) - g[0].size(0)) <= max(5, g[0].size(0) // 50) for r, g in zip(res, got))
+
+
+@pytest.mark.gpu
+def test_r3det_full_size_config2_composed_as_the_bench_composes_it():
+    """BASELINE configs[2]: r3det_r50_fpn v1, batch 4 x 1024^2, built exactly as bench.py builds it (conv + BN fused,
+    channels_last).  Stage by stage on the full-size tensors: the FeatureRefineModule's two-launch channels_last levels
+    call gives, bit for bit, x + (P + sample(P)) with P = (conv_5_1(conv_1_5(x)) + bias) + (conv_1_1(x) + bias) put
+    together from torch ops and the plain sampler operator, and the module's own output is that up to the convolutions'
+    run-to-run noise; the refine head's pools are 5344 boxes per
+    image; the batched multiclass NMS returns, image by image, exactly what the per-image operator path returns; and
+    the bench's own step (simple_test + pack + gather) reports the same counts."""
+    import os
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    import bench
+    from r3det.core.post_processing import multiclass_nms_rotated, multiclass_nms_rotated_batch
+    from r3det.ops.feature_refine import fr_forward_nhwc, fr_module_levels_nhwc
+    dev = torch.device('cuda')
+    model, img = bench.build_model(dev, 21, "R3Det", batch=4)
+    assert img.shape == (4, 3, 1024, 1024)
+    with torch.no_grad():
+        x = model.extract_feat(img)
+        assert [tuple(f.shape) for f in x] == [(4, 256, s, s) for s in (128, 64, 32, 16, 8)]
+        cls, reg = model.bbox_head(x)
+        rois = model.bbox_head.filter_bboxes(cls, reg)
+        frm = model.feat_refine_module[0]
+        x_refine = frm(x, rois)
+        per_level = [torch.cat(lvl).contiguous() for lvl in zip(*rois)]
+        # (MIOpen's convolutions of the coarse levels are not bit-reproducible run to run -- 1e-7 of the scale -- so the
+        # module's two convolutions run ONCE here and feed both the library call the module makes and the composition)
+        ras = [F.conv2d(frm.conv_1_5(f), frm.conv_5_1.weight, None, frm.conv_5_1.stride, frm.conv_5_1.padding) for f in x]
+        rbs = [F.conv2d(f, frm.conv_1_1.weight, None, frm.conv_1_1.stride, frm.conv_1_1.padding) for f in x]
+        fused = [torch.full_like(f, float('nan')) for f in x]
+        assert fr_module_levels_nhwc(ras, rbs, frm.conv_5_1.bias, frm.conv_1_1.bias, x, per_level,
+                                     [fr.spatial_scale for fr in frm.fr], frm.fr[0].points, fused)
+        for lvl, (f, ra, rb, got, mod, boxes, fr) in enumerate(zip(x, ras, rbs, fused, x_refine, per_level, frm.fr)):
+            assert f.is_contiguous(memory_format=torch.channels_last) and mod.is_contiguous(memory_format=torch.channels_last)
+            P = (ra + frm.conv_5_1.bias.view(1, -1, 1, 1)) + (rb + frm.conv_1_1.bias.view(1, -1, 1, 1))
+            P = P.contiguous(memory_format=torch.channels_last)
+            o = torch.empty_like(P)
+            assert fr_forward_nhwc(P, boxes, fr.spatial_scale, fr.points, o)
+            assert torch.equal(got, f + o), lvl
+            assert (mod - got).abs().max().item() <= 1e-6 * got.abs().max().item(), lvl  # (the module's own call)
+        cls, reg = model.refine_head[0](x_refine)
+        boxes, scores = model.refine_head[-1].decode_bboxes(cls, reg, img.shape[-2:], model.test_cfg, rois=rois)
+        assert boxes.shape == (4, 5344, 5) and scores.shape == (4, 5344, 16)
+        cfg = model.test_cfg
+        got = multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+        for i, (d, l) in enumerate(got):
+            wd, wl = multiclass_nms_rotated(boxes[i], scores[i], cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+            assert d.size(0) > 50 and torch.equal(d, wd) and torch.equal(l, wl), i
+        counts = bench.model_step(model, img, batch_size=4)
+    # (MIOpen may pick another kernel for the repeated forward: counts agree to the rounding of a few scores)
+    assert all(abs(int(c) - g[0].size(0)) <= max(5, g[0].size(0) // 50) for c, g in zip(counts.tolist(), got))
