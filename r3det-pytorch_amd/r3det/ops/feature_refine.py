@@ -248,10 +248,11 @@ def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, over
     return 1
 
 
-def fr_backward_levels(top_grads, best_rbboxes, spatial_scales, points, bottom_grads):
-    """The backward of all pyramid levels (NCHW, overwrite mode) in two library calls: the indexes of the levels' boxes
-    from one grouped launch (r3det_feature_refine_backward_index_levels), then the gathers
-    (r3det_feature_refine_backward_levels_indexed)."""
+def fr_backward_levels(top_grads, best_rbboxes, spatial_scales, points, bottom_grads, overwrite=True):
+    """The backward of all pyramid levels (NCHW) in two library calls: the indexes of the levels' boxes from one grouped
+    launch (r3det_feature_refine_backward_index_levels), then the gathers
+    (r3det_feature_refine_backward_levels_indexed).  ``overwrite=False`` accumulates into ``bottom_grads`` as the
+    reference's backward does (feature_refine_cuda.cpp:44-66)."""
     gs = [_C.need_hip(g, "top_grad") for g in top_grads]
     os_ = [_C.need_hip(o, "bottom_grad") for o in bottom_grads]
     bs = [_C.need_hip(b, "best_bboxes") for b in best_rbboxes]
@@ -265,8 +266,9 @@ def fr_backward_levels(top_grads, best_rbboxes, spatial_scales, points, bottom_g
         _C.check(L.r3det_feature_refine_backward_index_levels(n, _ptr_array(bs), N, C, H, W, sc, int(points), _C.ptr(ws),
                                                               wsb, _C.stream()), "fr_backward_index_levels")
         _C.check(L.r3det_feature_refine_backward_levels_indexed(n, _ptr_array(gs), _ptr_array(bs), N, C, H, W, sc,
-                                                                int(points), _ptr_array(os_), 1, _C.ptr(ws), wsb,
-                                                                _C.stream()), "fr_backward_levels_indexed")
+                                                                int(points), _ptr_array(os_), int(bool(overwrite)),
+                                                                _C.ptr(ws), wsb, _C.stream()),
+                 "fr_backward_levels_indexed")
     return 1
 
 

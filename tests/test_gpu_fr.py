@@ -343,6 +343,33 @@ def test_levels_node_equals_per_level_nodes(points, NC):
                                                         _C.stream()) == -1
 
 
+@pytest.mark.parametrize("NC", [(2, 16), (4, 256)])
+def test_backward_levels_equals_per_level_calls_in_both_modes(NC):
+    """r3det_feature_refine_backward_index_levels + _backward_levels_indexed (the coarse levels' gathers one grid) =
+    one r3det_feature_refine_backward_ws call per level, bit for bit, writing and ACCUMULATING into bottom_grad
+    (feature_refine_cuda.cpp:44-66 accumulates), and with one launch per level (option frb_impl 6)."""
+    from r3det import _C, synthetic as syn
+    from r3det.ops.feature_refine import fr_backward, fr_backward_levels
+    N, C = NC
+    feats, boxes = syn.fr_pyramid(N, C, 11, device='cuda')
+    scales = [1.0 / s for s in syn.STRIDES]
+    gs = [torch.randn_like(f) for f in feats]
+    pre = [torch.randn_like(f) for f in feats]
+    for overwrite in (True, False):
+        want = [p.clone() for p in pre]
+        for g, b, s, o in zip(gs, boxes, scales, want):
+            fr_backward(g, b, s, 1, o, overwrite=overwrite)
+        for impl in (0, 6):
+            got = [p.clone() for p in pre]
+            _C.set_option("frb_impl", impl)
+            try:
+                fr_backward_levels(gs, boxes, scales, 1, got, overwrite=overwrite)
+            finally:
+                _C.set_option("frb_impl", 0)
+            for lvl, (a, w) in enumerate(zip(got, want)):
+                assert torch.equal(a, w), (overwrite, impl, lvl)
+
+
 @pytest.mark.parametrize("points", [1, 5])
 def test_forward_levels_equals_per_level_calls(points):
     """r3det_feature_refine_forward_levels = the module's per-level loop: bit-identical outputs."""
