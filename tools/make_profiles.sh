@@ -55,6 +55,8 @@ python3 $R/tools/kstats.py /tmp/kt_run fr_forward >> $O/${TAG}_fr_nhwc_kernel_st
 cd $R
 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_fr_nhwc_pmc.txt fr_forward_nhwc "FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" tools/fr_nhwc_prof.py > /dev/null
 python3 tools/make_roofline_pmc.py gpurun_out/profiles_$TAG/${TAG}_fr_nhwc_pmc.txt gpurun_out/profiles_$TAG/roofline_kernel_pmc.json
+# (bench.py below reads the tracked copy: this run's own counters, for this r3_fr.hip)
+cp gpurun_out/profiles_$TAG/roofline_kernel_pmc.json profiles/roofline_kernel_pmc.json
 # 6b. FR backward, both layouts (rotating buffers): level 0 / 1 at N = 4, level 0 at N = 2, and the "trained" field
 : > $O/${TAG}_fr_backward_kernel_stats.txt
 for cfg in "0 4 regular" "1 4 regular" "0 2 regular" "0 4 trained" "0 4 adversarial"; do
@@ -76,6 +78,10 @@ python3 $R/tools/kstats.py /tmp/kt_run fr_ frb_ frn_ iou_ assign_ >> $O/${TAG}_t
 # 6c. the plain samplers (the reference's API: r3det_feature_refine_forward NCHW, _forward_nhwc) per level, N = 4
 kt $O/${TAG}_fr_forward_kernel_stats.txt "python3 tools/fr_fwd_prof.py" python3 $R/tools/fr_fwd_prof.py
 python3 $R/tools/kstats.py /tmp/kt_run fr_ >> $O/${TAG}_fr_forward_kernel_stats.txt
+# 6c'. the NCHW pyramid pass: coarse levels one grid against one launch per level (both in one process)
+kt $O/${TAG}_fr_levels_ab.txt "python3 tools/fr_levels_ab.py" python3 $R/tools/fr_levels_ab.py
+python3 $R/tools/kstats.py /tmp/kt_run fr_forward frn_ frb_ fr_cell >> $O/${TAG}_fr_levels_ab.txt
+python3 $R/tools/fr_levels_ab.py 2>/dev/null | grep "^N=" | sed 's/^/# (no profiler) /' >> $O/${TAG}_fr_levels_ab.txt
 # 6d. the pre-NMS pool at the two models' shapes: per level (r3det_level_pool) and the whole head in one call (r3det_levels_pool)
 kt $O/${TAG}_pool_kernel_stats.txt "python3 tools/pool_prof.py" python3 $R/tools/pool_prof.py
 python3 $R/tools/kt_by_grid.py $(find /tmp/kt_run -name "*kernel_trace.csv" | head -1) pool_ fill >> $O/${TAG}_pool_kernel_stats.txt
