@@ -134,7 +134,7 @@ def train_custom_op_ms(tr, device):
     FR sampler forward + packed backward over the pyramid (no convolutions, no losses)."""
     from r3det import synthetic as syn
     from r3det.core import obb2hbb
-    from r3det.ops.feature_refine import feature_refine, feature_refine_levels
+    from r3det.ops.feature_refine import feature_refine_levels
     m = tr["model"]
     anchors = torch.cat(m.bbox_head.anchors([(IMG // s, IMG // s) for s in syn.STRIDES], device))
     feats, boxes = syn.fr_pyramid(TRAIN_BATCH, C, 9, device=device)
@@ -152,11 +152,8 @@ def train_custom_op_ms(tr, device):
     def fr():
         for x in xs:
             x.grad = None
-        if tr["channels_last"]:
-            for x, b, gr, s in zip(xs, boxes, gs, syn.STRIDES):
-                feature_refine(x, b, 1.0 / s, 1).backward(gr)
-        else:  # what FeatureRefineModule runs in NCHW training: the five levels as one autograd node
-            torch.autograd.backward(feature_refine_levels(xs, boxes, [1.0 / s for s in syn.STRIDES], 1), gs)
+        # what FeatureRefineModule runs in training: the five levels as one autograd node (both layouts)
+        torch.autograd.backward(feature_refine_levels(xs, boxes, [1.0 / s for s in syn.STRIDES], 1), gs)
     return timeit(assign, 10) * 1e3, timeit(fr, 10) * 1e3
 
 

@@ -422,6 +422,21 @@ int r3det_feature_refine_backward_nhwc_index(const float* best_bboxes, int N, in
 int r3det_feature_refine_backward_nhwc_indexed(const float* top_grad, int N, int C, int H, int W, int points,
                                                float* bottom_grad, int overwrite, void* ws, size_t ws_bytes,
                                                void* stream);
+/* All pyramid levels of a channels_last FeatureRefineModule pass (feature_refine_module.py:108-127 loops over the
+ * levels) in one call each: _index_levels when the forward pass has the boxes -- the bands of all levels ONE grid when
+ * every level takes the sorted index form, else level by level -- and _levels_indexed when the gradients arrive: the
+ * levels of at most 4096 cells ONE grid, the others one launch each.  Results: bit for bit those of the per-level
+ * calls.  Pointer / shape arrays are HOST arrays of `levels` entries; every level must have a workspace form
+ * (r3det_fr_backward_nhwc_workspace_bytes != 0), else R3DET_EINVAL; ws: one block of
+ * r3det_fr_backward_nhwc_levels_workspace_bytes() bytes, carved in level order. */
+size_t r3det_fr_backward_nhwc_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points);
+int r3det_feature_refine_backward_nhwc_index_levels(int levels, const float* const* best_bboxes, int N, const int* H,
+                                                    const int* W, const float* spatial_scales, int points, void* ws,
+                                                    size_t ws_bytes, void* stream);
+int r3det_feature_refine_backward_nhwc_levels_indexed(int levels, const float* const* top_grads, int N, int C,
+                                                      const int* H, const int* W, int points,
+                                                      float* const* bottom_grads, int overwrite, void* ws,
+                                                      size_t ws_bytes, void* stream);
 
 /* Producer of the FR boxes: RRetinaHead.filter_bboxes
  * (models/dense_heads/rotate_retina_head.py:117-179) and, with num_anchors = 1 and

@@ -532,6 +532,73 @@ int r3det_feature_refine_backward_nhwc_indexed(const float* top_grad, int N, int
                              S(stream)));
 }
 
+namespace {
+inline size_t nhwc_lvl_bytes(int N, int H, int W, int points) {
+  return (r3k_frb_workspace_bytes(N, H, W, points) + 255) & ~(size_t)255;
+}
+}  // namespace
+
+size_t r3det_fr_backward_nhwc_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points) {
+  if (levels < 0 || !H || !W) return 0;
+  size_t total = 0;
+  for (int l = 0; l < levels; l++) {
+    const size_t part = nhwc_lvl_bytes(N, H[l], W[l], points);
+    if (!part) return 0;  // (a level without a workspace form: no levels call)
+    total += part;
+  }
+  return total;
+}
+
+int r3det_feature_refine_backward_nhwc_index_levels(int levels, const float* const* best_bboxes, int N, const int* H,
+                                                    const int* W, const float* spatial_scales, int points, void* ws,
+                                                    size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
+  if (levels < 0 || N <= 0 || (points != 1 && points != 5) || (levels > 0 && (!best_bboxes || !H || !W || !spatial_scales)))
+    return R3DET_EINVAL;
+  const size_t need = r3det_fr_backward_nhwc_levels_workspace_bytes(levels, N, H, W, points);
+  if (levels > 0 && need == 0) return R3DET_EINVAL;
+  if (ws_bytes < need || (need && !ws)) return R3DET_EWS;
+  std::vector<void*> parts(levels);
+  std::vector<size_t> part_bytes(levels);
+  char* p = static_cast<char*>(ws);
+  for (int l = 0; l < levels; l++) {
+    if (!best_bboxes[l]) return R3DET_EINVAL;
+    parts[l] = p, part_bytes[l] = nhwc_lvl_bytes(N, H[l], W[l], points);
+    p += part_bytes[l];
+  }
+  const int k = r3k_frb_index_levels(levels, best_bboxes, N, H, W, spatial_scales, points, parts.data(), part_bytes.data(),
+                                     S(stream));
+  if (k <= 0) return rc(k);
+  for (int l = 0; l < levels; l++) {  // (not every level takes the sorted form: level by level)
+    const int k2 = r3k_frb_index(best_bboxes[l], N, H[l], W[l], spatial_scales[l], points, parts[l], part_bytes[l], S(stream));
+    if (k2) return rc(k2);
+  }
+  return R3DET_OK;
+}
+
+int r3det_feature_refine_backward_nhwc_levels_indexed(int levels, const float* const* top_grads, int N, int C,
+                                                      const int* H, const int* W, int points,
+                                                      float* const* bottom_grads, int overwrite, void* ws,
+                                                      size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
+  if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5) ||
+      (levels > 0 && (!top_grads || !H || !W || !bottom_grads)))
+    return R3DET_EINVAL;
+  const size_t need = r3det_fr_backward_nhwc_levels_workspace_bytes(levels, N, H, W, points);
+  if (levels > 0 && need == 0) return R3DET_EINVAL;
+  if (ws_bytes < need || (need && !ws)) return R3DET_EWS;
+  std::vector<void*> parts(levels);
+  std::vector<size_t> part_bytes(levels);
+  char* p = static_cast<char*>(ws);
+  for (int l = 0; l < levels; l++) {
+    if (!top_grads[l] || !bottom_grads[l]) return R3DET_EINVAL;
+    parts[l] = p, part_bytes[l] = nhwc_lvl_bytes(N, H[l], W[l], points);
+    p += part_bytes[l];
+  }
+  return rc(r3k_frb_gather_levels(levels, top_grads, N, C, H, W, points, bottom_grads, overwrite, parts.data(),
+                                  part_bytes.data(), S(stream)));
+}
+
 int r3det_filter_bboxes(const float* cls_score, const long long* cls_strides, const float* bbox_pred,
                         const long long* pred_strides, const float* anchors, int anchors_per_image, int N,
                         int num_anchors, int num_classes, int H, int W, float max_ratio, float* boxes_out,

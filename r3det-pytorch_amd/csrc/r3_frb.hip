@@ -574,6 +574,7 @@ struct FrbLevelsArgs {
   int n;
 };
 
+template <bool CSR>
 __global__ __launch_bounds__(IX_T) void frb_index_sort_levels_kernel(const FrbLevelsArgs A) {
   int lv = 0;
 #pragma unroll
@@ -582,8 +583,8 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_levels_kernel(const FrbLe
   // (a uniform index into the by-value argument block: scalar loads)
   const FrbLevelArgs& L = A.l[lv];
   const int bands = (lv + 1 < A.n ? A.l[lv + 1].first : (int)gridDim.x) - L.first;
-  frb_index_sort_body<false>(L.boxes, L.scale, L.H, L.W, L.R, L.cellinfo, L.entries, L.so, (int)blockIdx.x - L.first, bands,
-                             blockIdx.y, nullptr);
+  frb_index_sort_body<CSR>(L.boxes, L.scale, L.H, L.W, L.R, L.cellinfo, L.entries, L.so, (int)blockIdx.x - L.first, bands,
+                           blockIdx.y, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,17 +597,16 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_levels_kernel(const FrbLe
 // scalar registers: the first version of this kernel spent 640 scalar instructions per wavefront on 64-bit address
 // arithmetic and register spills and was bound by their issue (PMC: 10.5 M scalar of 15.5 M instructions).
 template <bool ACCUM, bool PAIRED>
-__global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const float* __restrict__ top,
-                                                                        const int2* __restrict__ cellinfo,
-                                                                        const int2* __restrict__ entries, int C, int H,
-                                                                        int W, int EPI, int tiles_xs, int tiles_per_img,
-                                                                        int T, float* __restrict__ bottom) {
+__device__ __forceinline__ void frb_gather_body(const float* __restrict__ top, const int2* __restrict__ cellinfo,
+                                                const int2* __restrict__ entries, int C, int H, int W, int EPI,
+                                                int tiles_xs, int tiles_per_img, int T, float* __restrict__ bottom,
+                                                const unsigned block) {
   const int tiles_x = tiles_xs & 0xfffff, strip = tiles_xs >> 20;  // (the pair walk's strip height rides in the top bits)
   __shared__ float4 Gs[PAIRED ? 32 : 16][64];  // slot (half * 16 + row of the tile * 4 + column) x lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
   const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-  unsigned t = blockIdx.x;
+  unsigned t = block;
   if ((T & 7) == 0) t = (t & 7u) * (unsigned)(T >> 3) + (t >> 3);  // XCD-contiguous bands of tiles
   const int n = (int)(t / (unsigned)tiles_per_img);
   const int tt = (int)(t - (unsigned)n * (unsigned)tiles_per_img);
@@ -763,6 +763,42 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const fl
     }
     if (c0 + 64 < C4) __syncthreads();  // the next channel block overwrites Gs
   }
+}
+
+template <bool ACCUM, bool PAIRED>
+__global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const float* __restrict__ top,
+                                                                        const int2* __restrict__ cellinfo,
+                                                                        const int2* __restrict__ entries, int C, int H,
+                                                                        int W, int EPI, int tiles_xs, int tiles_per_img,
+                                                                        int T, float* __restrict__ bottom) {
+  frb_gather_body<ACCUM, PAIRED>(top, cellinfo, entries, C, H, W, EPI, tiles_xs, tiles_per_img, T, bottom, blockIdx.x);
+}
+
+// Several levels' gathers (square tile grids: the paired form) as ONE grid: levels in the kernel arguments, a block
+// finds its level from block ranges; the body is the per-level kernel's.
+constexpr int FRBG_MAX = 8;
+struct FrbGatherLevel {
+  const float* top;
+  const int2* cellinfo;
+  const int2* entries;
+  float* bottom;
+  int H, W, EPI, tiles_xs, tiles_per_img, T, first;
+};
+struct FrbGatherLevels {
+  FrbGatherLevel l[FRBG_MAX];
+  int n;
+};
+
+template <bool ACCUM>
+__global__ __launch_bounds__(512) void frb_gather_levels_kernel(const FrbGatherLevels A, int C) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < FRBG_MAX; i++)
+    if (i < A.n && (int)blockIdx.x >= A.l[i].first) k = i;
+  const FrbGatherLevel& L = A.l[k];
+  // (T | 1: no XCD remap -- a level's blocks are a slice of the grid, not a multiple of 8 from block 0)
+  frb_gather_body<ACCUM, true>(L.top, L.cellinfo, L.entries, C, L.H, L.W, L.EPI, L.tiles_xs, L.tiles_per_img, L.T | 1, L.bottom,
+                               blockIdx.x - (unsigned)L.first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1264,6 +1300,51 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// The channels_last gathers of several levels over their indexes (ws[l]: r3k_frb_index / r3k_frb_index_levels): the
+// levels of at most 4096 cells with square tile grids as ONE grid, the others one launch each.  Pointer arrays are HOST
+// arrays.
+int r3k_frb_gather_levels(int levels, const float* const* top_grad, int N, int C, const int* H, const int* W, int points,
+                          float* const* bottom_grad, int overwrite, void* const* ws, const size_t* ws_bytes,
+                          hipStream_t stream) {
+  FrbGatherLevels A;
+  A.n = 0;
+  int blocks = 0;
+  bool grouped[FRBG_MAX] = {};
+  for (int l = 0; l < levels && levels <= FRBG_MAX && g_r3_frb_impl != 6 && g_r3_frb_impl != 2; l++) {
+    const size_t need = r3k_frb_workspace_bytes(N, H[l], W[l], points);
+    const int tiles_x = (W[l] + 3) / 4, tiles_y = (H[l] + 3) / 4;
+    if (need == 0 || !top_grad[l] || !bottom_grad[l] || !ws[l] || !aligned16(ws[l]) || ws_bytes[l] < need ||
+        N <= 0 || C <= 0 || (C & 3) || !aligned16(top_grad[l]) || !aligned16(bottom_grad[l]) || tiles_x != tiles_y ||
+        (long long)H[l] * W[l] > 4096 || (unsigned long long)H[l] * W[l] * C * 4ull >= (1ull << 32))
+      continue;
+    const FrbLayout L = frb_layout(ws[l], N, H[l], W[l], points);
+    FrbGatherLevel& a = A.l[A.n++];
+    a.top = top_grad[l], a.cellinfo = L.cellinfo, a.entries = L.entries, a.bottom = bottom_grad[l];
+    a.H = H[l], a.W = W[l], a.EPI = H[l] * W[l] * 4 * points, a.tiles_xs = tiles_x | (g_r3_fr_walk << 20);
+    a.tiles_per_img = tiles_x * (tiles_x - 1) / 2 + (tiles_x + 1) / 2;
+    a.T = a.tiles_per_img * N, a.first = blocks;
+    blocks += a.T;
+    grouped[l] = true;
+  }
+  if (A.n < 2) {
+    A.n = 0;
+    for (int l = 0; l < FRBG_MAX; l++) grouped[l] = false;
+  }
+  for (int l = 0; l < levels; l++) {
+    if (l < FRBG_MAX && grouped[l]) continue;
+    const int k = r3k_frb_backward(top_grad[l], nullptr, N, C, H[l], W[l], 0.f, points, bottom_grad[l], overwrite, ws[l],
+                                   ws_bytes[l], 1, stream);
+    if (k) return k;
+  }
+  if (A.n) {
+    for (int i = A.n; i < FRBG_MAX; i++) A.l[i] = A.l[A.n - 1];
+    if (overwrite) hipLaunchKernelGGL(frb_gather_levels_kernel<false>, dim3(blocks), dim3(512), 0, stream, A, C);
+    else hipLaunchKernelGGL(frb_gather_levels_kernel<true>, dim3(blocks), dim3(512), 0, stream, A, C);
+    if (hipGetLastError() != hipSuccess) return -2;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // NCHW entry points: index (CSR + SELL) and gather
 // ------------------------------------------------------------------------------------------------
@@ -1339,8 +1420,33 @@ int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, co
   }
   for (int l = levels; l < FRB_MAX_LEVELS; l++) A.l[l] = A.l[levels - 1];
   static R3DeviceOnce once;
-  if (once.first()) allow_big_lds(frb_index_sort_levels_kernel, (int)sizeof(IxsLds));
-  hipLaunchKernelGGL(frb_index_sort_levels_kernel, dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
+  if (once.first()) allow_big_lds(frb_index_sort_levels_kernel<false>, (int)sizeof(IxsLds));
+  hipLaunchKernelGGL(frb_index_sort_levels_kernel<false>, dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// The same for the channels_last gather's CSR lists (r3k_frb_index per level): ws[l] as r3k_frb_workspace_bytes sizes it.
+int r3k_frb_index_levels(int levels, const float* const* boxes, int N, const int* H, const int* W, const float* scales,
+                         int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream) {
+  if (levels < 1 || levels > FRB_MAX_LEVELS || g_r3_frb_impl == 6) return 1;
+  FrbLevelsArgs A;
+  A.n = levels;
+  int blocks = 0;
+  for (int l = 0; l < levels; l++) {
+    const size_t need = r3k_frb_workspace_bytes(N, H[l], W[l], points);
+    if (need == 0 || !boxes[l] || !ws[l] || !aligned16(ws[l]) || ws_bytes[l] < need || !frb_sort_form(H[l], W[l], points))
+      return 1;
+    const FrbLayout L = frb_layout(ws[l], N, H[l], W[l], points);
+    FrbLevelArgs& a = A.l[l];
+    a.boxes = boxes[l], a.cellinfo = L.cellinfo, a.entries = L.entries;
+    a.so.hdr = nullptr, a.so.rows = nullptr, a.so.ascale = a.so.cap = a.so.pitch = a.so.slices = 0;
+    a.scale = scales[l], a.H = H[l], a.W = W[l], a.R = sort_band_rows(H[l], W[l]), a.first = blocks;
+    blocks += (H[l] + a.R - 1) / a.R;
+  }
+  for (int l = levels; l < FRB_MAX_LEVELS; l++) A.l[l] = A.l[levels - 1];
+  static R3DeviceOnce once;
+  if (once.first()) allow_big_lds(frb_index_sort_levels_kernel<true>, (int)sizeof(IxsLds));
+  hipLaunchKernelGGL(frb_index_sort_levels_kernel<true>, dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -97,6 +97,11 @@ int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, co
                          const float* scales, int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream);
 int r3k_frn_gather(const float* top_grad, int N, int C, int H, int W, int points, float* bottom_grad, int overwrite,
                    void* ws, size_t ws_bytes, hipStream_t stream);
+int r3k_frb_index_levels(int levels, const float* const* boxes, int N, const int* H, const int* W, const float* scales,
+                         int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream);
+int r3k_frb_gather_levels(int levels, const float* const* top_grad, int N, int C, const int* H, const int* W, int points,
+                          float* const* bottom_grad, int overwrite, void* const* ws, const size_t* ws_bytes,
+                          hipStream_t stream);
 int r3k_frn_gather_levels(int levels, const float* const* top_grad, int N, int C, const int* H, const int* W, int points,
                           float* const* bottom_grad, int overwrite, void* const* ws, const size_t* ws_bytes, int* taken,
                           hipStream_t stream);

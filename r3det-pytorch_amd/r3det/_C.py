@@ -63,6 +63,8 @@ SIGNATURES = {
     "r3det_feature_refine_forward_levels_nhwc": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "r3det_feature_refine_module_levels_nhwc": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "r3det_feature_refine_backward_index_levels": [_i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp],
+    "r3det_feature_refine_backward_nhwc_index_levels": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp],
+    "r3det_feature_refine_backward_nhwc_levels_indexed": [_i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp],
     "r3det_feature_refine_backward_levels_indexed": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp],
     "r3det_set_option": [ctypes.c_char_p, _i],
     "r3det_fr_profile_read": [_vp, _i],
@@ -108,6 +110,8 @@ def lib():
         L.r3det_fr_levels_workspace_bytes.restype = _sz
         L.r3det_fr_backward_levels_workspace_bytes.argtypes = [_i, _i, _vp, _vp, _i]
         L.r3det_fr_backward_levels_workspace_bytes.restype = _sz
+        L.r3det_fr_backward_nhwc_levels_workspace_bytes.argtypes = [_i, _i, _vp, _vp, _i]
+        L.r3det_fr_backward_nhwc_levels_workspace_bytes.restype = _sz
         L.r3det_fr_backward_workspace_bytes.argtypes = [_i, _i, _i, _i]
         L.r3det_fr_backward_workspace_bytes.restype = _sz
         L.r3det_fr_backward_nhwc_workspace_bytes.argtypes = [_i, _i, _i, _i]

@@ -407,24 +407,42 @@ feature_refine = FeatureRefineFunction.apply
 
 
 class FeatureRefineLevelsFunction(Function):
-    """The sampler of ALL pyramid levels as one autograd node (NCHW): one library call for the samplers
+    """The sampler of ALL pyramid levels as one autograd node: one library call for the samplers
     (r3det_feature_refine_forward_levels), one for the backward's indexes of the boxes -- built here, where the boxes
     are at hand -- and one for the gathers (r3det_feature_refine_backward_index_levels / _levels_indexed); one
-    workspace each.  The reference runs one FeatureRefineFunction per level (feature_refine_module.py:108-127); from
-    Python every level costs ~10 us of host time per call, more than the kernels of the three coarse levels."""
+    workspace each.  Channels_last inputs (all levels) stay on (N, H, W, C) memory: the _nhwc forms of the three calls.
+    The reference runs one FeatureRefineFunction per level (feature_refine_module.py:108-127); from Python every level
+    costs ~10 us of host time per call, more than the kernels of the three coarse levels."""
 
     @staticmethod
     def forward(ctx, spatial_scales, points, n, *tensors):
-        feats = [t.contiguous() for t in tensors[:n]]
         boxes = [t.contiguous() for t in tensors[n:2 * n]]
-        assert points in [1, 5] and all(f.is_cuda for f in feats)
-        N, C = feats[0].shape[:2]
-        outs = [torch.empty_like(f) for f in feats]
-        fr_forward_levels(feats, boxes, spatial_scales, points, outs)
+        assert points in [1, 5] and all(f.is_cuda for f in tensors[:n])
+        N, C = tensors[0].shape[:2]
         ctx.scales, ctx.points, ctx.n = list(spatial_scales), points, n
-        ctx.shape = [tuple(f.shape) for f in feats]
+        ctx.shape = [tuple(f.shape) for f in tensors[:n]]
         ctx.save_for_backward(*boxes)
         ctx.index = None
+        ctx.nhwc = False
+        L = _C.lib()
+        if all(_is_cl(f) for f in tensors[:n]) and C % 4 == 0:
+            feats = list(tensors[:n])
+            H, W, sc, arr_p = _lvl_arrays(feats, spatial_scales)
+            wsb = int(L.r3det_fr_backward_nhwc_levels_workspace_bytes(n, N, H, W, int(points)))
+            outs = [torch.empty_like(f) for f in feats]  # (preserves channels_last)
+            if wsb and fr_forward_levels_nhwc(feats, boxes, spatial_scales, points, outs):
+                ctx.nhwc = True
+                if any(ctx.needs_input_grad[3:3 + n]):
+                    with torch.cuda.device(feats[0].device):
+                        ws = torch.empty(wsb, dtype=torch.uint8, device=feats[0].device)
+                        _C.check(L.r3det_feature_refine_backward_nhwc_index_levels(
+                            n, arr_p(*[b.data_ptr() for b in boxes]), N, H, W, sc, int(points), _C.ptr(ws), wsb,
+                            _C.stream()), "fr_backward_nhwc_index_levels")
+                    ctx.index = (ws, wsb)
+                return tuple(outs)
+        feats = [t.contiguous() for t in tensors[:n]]
+        outs = [torch.empty_like(f) for f in feats]
+        fr_forward_levels(feats, boxes, spatial_scales, points, outs)
         if any(ctx.needs_input_grad[3:3 + n]):
             L = _C.lib()
             H, W, sc, arr_p = _lvl_arrays(feats, spatial_scales)
@@ -443,13 +461,21 @@ class FeatureRefineLevelsFunction(Function):
         n, boxes = ctx.n, ctx.saved_tensors
         if ctx.index is None:
             return (None, None, None) + (None,) * (2 * n)
-        gs = [(g if g is not None else torch.zeros(shp, device=boxes[0].device)).contiguous()
+        fmt = torch.channels_last if ctx.nhwc else torch.contiguous_format
+        gs = [(g if g is not None else torch.zeros(shp, device=boxes[0].device)).contiguous(memory_format=fmt)
               for g, shp in zip(grads, ctx.shape)]
-        outs = [torch.empty_like(g) for g in gs]
+        outs = [torch.empty_like(g) for g in gs]  # (preserves the layout)
         N, C = gs[0].shape[:2]
         L = _C.lib()
         H, W, sc, arr_p = _lvl_arrays(gs, ctx.scales)
         ws, wsb = ctx.index
+        if ctx.nhwc:
+            with torch.cuda.device(gs[0].device):
+                _C.check(L.r3det_feature_refine_backward_nhwc_levels_indexed(
+                    n, arr_p(*[g.data_ptr() for g in gs]), N, C, H, W, int(ctx.points),
+                    arr_p(*[o.data_ptr() for o in outs]), 1, _C.ptr(ws), wsb, _C.stream()),
+                    "fr_backward_nhwc_levels_indexed")
+            return (None, None, None) + tuple(outs) + (None,) * n
         with torch.cuda.device(gs[0].device):
             _C.check(L.r3det_feature_refine_backward_levels_indexed(
                 n, arr_p(*[g.data_ptr() for g in gs]), arr_p(*[b.data_ptr() for b in boxes]), N, C, H, W, sc,
@@ -459,8 +485,8 @@ class FeatureRefineLevelsFunction(Function):
 
 
 def feature_refine_levels(features, best_rbboxes, spatial_scales, points=1):
-    """``[feature_refine(f, b, s, points) for f, b, s in zip(...)]`` as one autograd node (NCHW, levels sharing N and
-    C)."""
+    """``[feature_refine(f, b, s, points) for f, b, s in zip(...)]`` as one autograd node (levels sharing N and C;
+    NCHW, or channels_last when every level is)."""
     n = len(features)
     return list(FeatureRefineLevelsFunction.apply(tuple(float(s) for s in spatial_scales), points, n, *features,
                                                   *best_rbboxes))
@@ -519,14 +545,15 @@ class FeatureRefineModule(nn.Module):
 
         is_cl = _is_cl
         nhwc = [no_grad and is_cl(f) for f in x]
-        if not no_grad and not any(is_cl(f) for f in x) and len({f.shape[:2] for f in x}) == 1 \
-                and len({fr.points for fr in self.fr}) == 1:
-            # NCHW training: the samplers of all levels as ONE autograd node (one library call each for the samplers,
-            # the backward's indexes and the gathers)
+        if not no_grad and len({f.shape[:2] for f in x}) == 1 and len({fr.points for fr in self.fr}) == 1 \
+                and (not any(is_cl(f) for f in x) or all(is_cl(f) for f in x)):
+            # training: the samplers of all levels as ONE autograd node (one library call each for the samplers, the
+            # backward's indexes and the gathers); NCHW, or everything on channels_last memory
             mixed = [self.conv_5_1(self.conv_1_5(f)) + self.conv_1_1(f) for f in x]
-            sampled = feature_refine_levels(mixed, [b.contiguous() for b in per_level],
-                                            [fr.spatial_scale for fr in self.fr], self.fr[0].points)
-            return [f + o for f, o in zip(x, sampled)]
+            if not is_cl(x[0]) or all(is_cl(t) for t in mixed):
+                sampled = feature_refine_levels(mixed, [b.contiguous() for b in per_level],
+                                                [fr.spatial_scale for fr in self.fr], self.fr[0].points)
+                return [f + o for f, o in zip(x, sampled)]
         if all(nhwc) and len({f.shape[:2] for f in x}) == 1 and len({fr.points for fr in self.fr}) == 1:
             # channels_last inference: the module tail of ALL levels in one library call -- level 0 (the wide regions
             # form) one launch, the coarse levels together one more -- on channels_last memory: the two convolutions'

@@ -343,6 +343,61 @@ def test_levels_node_equals_per_level_nodes(points, NC):
                                                         _C.stream()) == -1
 
 
+@pytest.mark.parametrize("points", [1, 5])
+@pytest.mark.parametrize("NC", [(2, 16), (2, 256)])
+def test_levels_node_channels_last_equals_per_level_nodes(points, NC):
+    """feature_refine_levels on channels_last inputs: the _nhwc forms of the three levels calls (samplers; the indexes
+    of all levels from one grouped launch; the coarse levels' gathers one grid) -- outputs and gradients bit-identical
+    to one feature_refine node per level, stay channels_last, and equal one launch per level (option frb_impl 6);
+    overwrite and accumulate mode of the C ABI's gather call."""
+    import ctypes
+    from r3det import _C, synthetic as syn
+    from r3det.ops.feature_refine import feature_refine, feature_refine_levels
+    N, C = NC
+    cl = torch.channels_last
+    feats, boxes = syn.fr_pyramid(N, C, 7, device='cuda')
+    feats = [f.contiguous(memory_format=cl) for f in feats]
+    scales = [1.0 / s for s in syn.STRIDES]
+    gs = [torch.randn_like(f) for f in feats]
+    xs = [f.clone().requires_grad_(True) for f in feats]
+    outs = feature_refine_levels(xs, boxes, scales, points)
+    torch.autograd.backward(outs, gs)
+    for f, b, s, o, x, g in zip(feats, boxes, scales, outs, xs, gs):
+        x1 = f.clone().requires_grad_(True)
+        o1 = feature_refine(x1, b, s, points)
+        o1.backward(g)
+        if f.size(2) > 1:  # (1 x 1 maps are both layouts at once)
+            assert o.is_contiguous(memory_format=cl) and x.grad.is_contiguous(memory_format=cl)
+        assert torch.equal(o, o1) and torch.equal(x.grad, x1.grad)
+    _C.set_option("frb_impl", 6)
+    try:
+        xs6 = [f.clone().requires_grad_(True) for f in feats]
+        torch.autograd.backward(feature_refine_levels(xs6, boxes, scales, points), gs)
+    finally:
+        _C.set_option("frb_impl", 0)
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(xs6, xs))
+    # the C ABI: accumulate mode, short workspace
+    L = _C.lib()
+    n = len(feats)
+    arr_i, arr_p = ctypes.c_int * n, ctypes.c_void_p * n
+    H, W = arr_i(*[f.size(2) for f in feats]), arr_i(*[f.size(3) for f in feats])
+    sc = (ctypes.c_float * n)(*scales)
+    need = int(L.r3det_fr_backward_nhwc_levels_workspace_bytes(n, N, H, W, points))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    bp = arr_p(*[b.data_ptr() for b in boxes])
+    assert L.r3det_feature_refine_backward_nhwc_index_levels(n, bp, N, H, W, sc, points, _C.ptr(ws), need - 256,
+                                                             _C.stream()) == -3
+    assert L.r3det_feature_refine_backward_nhwc_index_levels(n, bp, N, H, W, sc, points, _C.ptr(ws), need, _C.stream()) == 0
+    pre = [torch.randn_like(f) for f in feats]
+    acc = [p.clone(memory_format=torch.preserve_format) for p in pre]
+    assert L.r3det_feature_refine_backward_nhwc_levels_indexed(
+        n, arr_p(*[g.data_ptr() for g in gs]), N, C, H, W, points, arr_p(*[a.data_ptr() for a in acc]), 0, _C.ptr(ws),
+        need, _C.stream()) == 0
+    for a, p, x in zip(acc, pre, xs):
+        assert (a - (p + x.grad)).abs().max().item() <= 1e-5 * max(1.0, x.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("NC", [(2, 16), (4, 256)])
 def test_backward_levels_equals_per_level_calls_in_both_modes(NC):
     """r3det_feature_refine_backward_index_levels + _backward_levels_indexed (the coarse levels' gathers one grid) =
