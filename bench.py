@@ -350,8 +350,10 @@ def fr_rates(device):
             FRM.fr_backward_levels(xs, bs, scs, p, os_)
 
     def bwd_nhwc(xs, bs, scs, p, os_):
-        for x, b, sc, o in zip(xs, bs, scs, os_):
-            FRM.fr_backward_nhwc(x, b, sc, p, o, overwrite=True)
+        if len(xs) == 1:
+            FRM.fr_backward_nhwc(xs[0], bs[0], scs[0], p, os_[0], overwrite=True)
+        else:
+            FRM.fr_backward_levels_nhwc(xs, bs, scs, p, os_)
 
     fwd, bwd = {False: fwd_nchw, True: fwd_nhwc}, {False: bwd_nchw, True: bwd_nhwc}
     for nhwc, lay in ((False, "nchw"), (True, "nhwc")):

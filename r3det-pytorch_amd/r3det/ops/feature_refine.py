@@ -272,6 +272,32 @@ def fr_backward_levels(top_grads, best_rbboxes, spatial_scales, points, bottom_g
     return 1
 
 
+def fr_backward_levels_nhwc(top_grads, best_rbboxes, spatial_scales, points, bottom_grads, overwrite=True):
+    """The channels_last backward of all pyramid levels in two library calls
+    (r3det_feature_refine_backward_nhwc_index_levels: the CSR indexes of all levels from one grouped launch, then
+    r3det_feature_refine_backward_nhwc_levels_indexed: the gathers, the coarse levels one grid).  False when a level
+    has no workspace form: nothing was launched."""
+    gs = [_need_cl(g, "top_grad") for g in top_grads]
+    os_ = [_need_cl(o, "bottom_grad") for o in bottom_grads]
+    bs = [_C.need_hip(b, "best_bboxes") for b in best_rbboxes]
+    N, C = gs[0].shape[:2]
+    H, W, sc, _ = _lvl_arrays(gs, spatial_scales)
+    L = _C.lib()
+    n = len(gs)
+    with torch.cuda.device(gs[0].device):
+        wsb = int(L.r3det_fr_backward_nhwc_levels_workspace_bytes(n, N, H, W, int(points)))
+        if wsb == 0:
+            return False
+        ws = torch.empty(wsb, dtype=torch.uint8, device=gs[0].device)
+        _C.check(L.r3det_feature_refine_backward_nhwc_index_levels(n, _ptr_array(bs), N, H, W, sc, int(points), _C.ptr(ws),
+                                                                   wsb, _C.stream()), "fr_backward_nhwc_index_levels")
+        _C.check(L.r3det_feature_refine_backward_nhwc_levels_indexed(n, _ptr_array(gs), N, C, H, W, int(points),
+                                                                     _ptr_array(os_), int(bool(overwrite)), _C.ptr(ws),
+                                                                     wsb, _C.stream()),
+                 "fr_backward_nhwc_levels_indexed")
+    return True
+
+
 def fr_backward_nhwc(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, overwrite=False, index=None):
     """feature_refine_cuda.backward on channels_last memory (r3det_feature_refine_backward_nhwc): ``top_grad`` /
     ``bottom_grad`` are (N, C, H, W) tensors in torch.channels_last.  A gather over the inverse tap index of the
