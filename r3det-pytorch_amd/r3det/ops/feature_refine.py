@@ -571,15 +571,14 @@ class FeatureRefineModule(nn.Module):
 
         is_cl = _is_cl
         nhwc = [no_grad and is_cl(f) for f in x]
-        if not no_grad and len({f.shape[:2] for f in x}) == 1 and len({fr.points for fr in self.fr}) == 1 \
-                and (not any(is_cl(f) for f in x) or all(is_cl(f) for f in x)):
+        if not no_grad and len({f.shape[:2] for f in x}) == 1 and len({fr.points for fr in self.fr}) == 1:
             # training: the samplers of all levels as ONE autograd node (one library call each for the samplers, the
-            # backward's indexes and the gathers); NCHW, or everything on channels_last memory
+            # backward's indexes and the gathers) -- on channels_last memory when every level's convolution output is,
+            # else on NCHW planes
             mixed = [self.conv_5_1(self.conv_1_5(f)) + self.conv_1_1(f) for f in x]
-            if not is_cl(x[0]) or all(is_cl(t) for t in mixed):
-                sampled = feature_refine_levels(mixed, [b.contiguous() for b in per_level],
-                                                [fr.spatial_scale for fr in self.fr], self.fr[0].points)
-                return [f + o for f, o in zip(x, sampled)]
+            sampled = feature_refine_levels(mixed, [b.contiguous() for b in per_level],
+                                            [fr.spatial_scale for fr in self.fr], self.fr[0].points)
+            return [f + o for f, o in zip(x, sampled)]
         if all(nhwc) and len({f.shape[:2] for f in x}) == 1 and len({fr.points for fr in self.fr}) == 1:
             # channels_last inference: the module tail of ALL levels in one library call -- level 0 (the wide regions
             # form) one launch, the coarse levels together one more -- on channels_last memory: the two convolutions'
