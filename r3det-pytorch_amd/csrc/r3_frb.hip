@@ -218,7 +218,7 @@ struct IxsLds {
   u64 sk[IXS_CAP];              // (cell in the band << 56) | (source << 34) | (tap << 32) | weight bits
   int seg[IX_WAVES * IXS_SEG];  // sources that reach the band, per wave
   int cst[IXS_CELLS], cend[IXS_CELLS];
-  int hist[16 * 8 * IX_WAVES + IX_WAVES];  // the sort's block counts (E <= 8)
+  int hist[256 * 2 * IX_WAVES + IX_WAVES];  // the sort's block counts (one 8-bit pass: E <= 2; two 4-bit passes: E <= 8)
   int wcnt[IX_WAVES];
   int part[IX_WAVES];
   int total, over;
@@ -290,6 +290,64 @@ __device__ __forceinline__ void ixs_sort(u64* sk, int* hist, const int tid) {
     for (int e = 0; e < E; e++) v[e] = sk[e * IX_T + tid];
     __syncthreads();
   }
+}
+
+// The same sort in ONE pass over the whole byte, for E <= 2 (up to 2048 keys: 256 x 32 block counts fit the table):
+// a wavefront finds the lanes that hold its key's byte with 8 ballots (one per bit; the two 4-bit passes took 16 ballots
+// each with a rank and a count per digit), the lowest such lane writes the count.  Half the barriers, a quarter of the
+// ranking instructions (clock stamps, tools/probes/frb_index_probe.hip: the sort was a third of the kernel).
+template <int E>
+__device__ __forceinline__ void ixs_sort8(u64* sk, int* hist, const int tid) {
+  constexpr int NB = E * IX_WAVES;  // 64-key blocks
+  constexpr int CNT = 256 * NB, CPT = CNT / IX_T;
+  const int lane = tid & 63, wave = tid >> 6;
+  u64 v[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) v[e] = sk[e * IX_T + tid];
+#pragma unroll
+  for (int q = 0; q < CPT; q++) hist[q * IX_T + tid] = 0;
+  __syncthreads();
+  int rank[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int dg = (int)(v[e] >> 56);
+    u64 m = ~0ULL;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (dg >> b) & 1;
+      const u64 bb = __ballot(bit);
+      m &= bit ? bb : ~bb;
+    }
+    rank[e] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (rank[e] == 0) hist[dg * NB + e * IX_WAVES + wave] = __popcll(m);
+  }
+  __syncthreads();
+  {  // exclusive scan of the 256 NB counts (digit-major): CPT consecutive counts per thread
+    int c[CPT], mine = 0;
+#pragma unroll
+    for (int q = 0; q < CPT; q++) {
+      c[q] = hist[tid * CPT + q];
+      mine += c[q];
+    }
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) hist[CNT + wave] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int w = 0; w < wave; w++) run += hist[CNT + w];
+#pragma unroll
+    for (int q = 0; q < CPT; q++) {
+      hist[tid * CPT + q] = run;
+      run += c[q];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; e++) sk[hist[(int)(v[e] >> 56) * NB + e * IX_WAVES + wave] + rank[e]] = v[e];
+  __syncthreads();
 }
 
 // Where a band's SELL-64 rows go when the index kernel re-lays them itself (the NCHW gather's form of the lists,
@@ -414,13 +472,24 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
   // tap) order: first the wave's count, then -- behind the waves before it -- the entries
   const int wcc = min(wc, IXS_SEG);
   int wtot = 0;
+  // (the taps of a wave's first 64 reaching sources -- usually all of them -- are computed once and kept for the write
+  // pass behind the barrier: computed again there they cost a second round trip to the boxes)
+  TapYX t_first;
+  t_first.valid = false;
+  int s_first = 0;
+  if (lane < wcc) {
+    s_first = S.seg[wave * IXS_SEG + lane];
+    t_first = make_tap_yx(H, W, bx[(size_t)s_first * 5] * scale, bx[(size_t)s_first * 5 + 1] * scale);
+  }
   for (int i0 = 0; i0 < wcc; i0 += 64) {
     const int i = i0 + lane;
-    TapYX t;
-    t.valid = false;
-    if (i < wcc) {
-      const int s = S.seg[wave * IXS_SEG + i];
-      t = make_tap_yx(H, W, bx[(size_t)s * 5] * scale, bx[(size_t)s * 5 + 1] * scale);
+    TapYX t = t_first;
+    if (i0 > 0) {
+      t.valid = false;
+      if (i < wcc) {
+        const int s = S.seg[wave * IXS_SEG + i];
+        t = make_tap_yx(H, W, bx[(size_t)s * 5] * scale, bx[(size_t)s * 5 + 1] * scale);
+      }
     }
 #pragma unroll
     for (int d = 0; d < 4; d++) {
@@ -439,12 +508,15 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
   if (!S.over && total <= IXS_CAP) {
     for (int i0 = 0; i0 < wcc; i0 += 64) {
       const int i = i0 + lane;
-      TapYX t;
-      t.valid = false;
-      int s = 0;
-      if (i < wcc) {
-        s = S.seg[wave * IXS_SEG + i];
-        t = make_tap_yx(H, W, bx[(size_t)s * 5] * scale, bx[(size_t)s * 5 + 1] * scale);
+      TapYX t = t_first;
+      int s = s_first;
+      if (i0 > 0) {
+        t.valid = false;
+        s = 0;
+        if (i < wcc) {
+          s = S.seg[wave * IXS_SEG + i];
+          t = make_tap_yx(H, W, bx[(size_t)s * 5] * scale, bx[(size_t)s * 5 + 1] * scale);
+        }
       }
 #pragma unroll
       for (int d = 0; d < 4; d++) {
@@ -480,8 +552,8 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
   const int npad = total <= IX_T ? IX_T : total <= 2 * IX_T ? 2 * IX_T : total <= 4 * IX_T ? 4 * IX_T : 8 * IX_T;
   for (int i = total + tid; i < npad; i += IX_T) S.sk[i] = ~0ull;
   __syncthreads();
-  if (npad == IX_T) ixs_sort<1>(S.sk, S.hist, tid);
-  else if (npad == 2 * IX_T) ixs_sort<2>(S.sk, S.hist, tid);
+  if (npad == IX_T) ixs_sort8<1>(S.sk, S.hist, tid);
+  else if (npad == 2 * IX_T) ixs_sort8<2>(S.sk, S.hist, tid);
   else if (npad == 4 * IX_T) ixs_sort<4>(S.sk, S.hist, tid);
   else ixs_sort<8>(S.sk, S.hist, tid);
   stamp(3);
