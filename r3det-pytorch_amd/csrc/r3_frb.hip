@@ -992,7 +992,9 @@ __device__ __forceinline__ float frn_get(const typename FrnVec<CP>::type& v, int
 // groups per workgroup took exactly twice one).
 typedef unsigned int frn_u4 __attribute__((ext_vector_type(4)));
 
-template <int K, int CP>
+// DEEP: three batches in flight behind the one being summed (four register sets) and the results stored slice by slice
+// instead of held for one burst -- the registers of the held results pay for the fourth set.
+template <int K, int CP, bool DEEP = false>
 __device__ __forceinline__ void frn_gather_body(const float* __restrict__ top, const int* __restrict__ slicehdr,
                                                 const int4* __restrict__ sell, const int2* __restrict__ cellinfo,
                                                 const int2* __restrict__ entries, int C, int H, int W, int wshift,
@@ -1157,7 +1159,7 @@ __device__ __forceinline__ void frn_gather_body(const float* __restrict__ top, c
   // bandwidth saturated (every compute unit is in this phase at the same time) the loads behind it waited -- the
   // gather phase took the index time PLUS the write time.  Issued at the end, the writes drain while the compute
   // unit's next workgroup stages its planes.
-  constexpr bool HOLD = K * CP <= 32 && !(K == 8 && CP == 4);
+  constexpr bool HOLD = !DEEP && K * CP <= 32 && !(K == 8 && CP == 4);
   V res[HOLD ? K : 1];
   const int sl0_256 = sl0 * 256, zero_b = H * P * 4 * CP;
   auto step = [&](const B8& b, const int f) {
@@ -1201,6 +1203,30 @@ __device__ __forceinline__ void frn_gather_body(const float* __restrict__ top, c
       __builtin_amdgcn_raw_buffer_store_b32(bits, rbot[ch], lane4, so, 2);
     }
   };
+  if constexpr (DEEP) {
+    // The index stream is a latency x depth product: with two 4 KB batches in flight per wavefront a compute unit has
+    // 128 KB on the way and gets the 42 B / clock the stamps showed; with three, 128 x 128 at N = 4: 44.3 -> 41.7 us,
+    // N = 2: 23.2 -> 21.2 us (tools/frn_ab.py; four in flight: no better -- a wavefront has ~19 batches -- and with the
+    // results held as well the kernel spills).
+    for (int w0 = 0; w0 < total_all; w0 += 64) {
+      const int total = build(w0);
+      B8 A, B, Cc, D;
+      load_batch(0, A);
+      load_batch(1, B);
+      load_batch(2, Cc);
+#pragma unroll 1
+      for (int t = 0; t < total; t += 4) {
+        load_batch(t + 3, D);
+        step(A, __builtin_amdgcn_readlane(seq_f, t));
+        load_batch(t + 4, A);
+        if (t + 1 < total) step(B, __builtin_amdgcn_readlane(seq_f, (t + 1) & 63));
+        load_batch(t + 5, B);
+        if (t + 2 < total) step(Cc, __builtin_amdgcn_readlane(seq_f, (t + 2) & 63));
+        load_batch(t + 6, Cc);
+        if (t + 3 < total) step(D, __builtin_amdgcn_readlane(seq_f, (t + 3) & 63));
+      }
+    }
+  } else
   for (int w0 = 0; w0 < total_all; w0 += 64) {  // (one window unless lists are very long)
     const int total = build(w0);
     B8 A, B, D;
@@ -1243,8 +1269,9 @@ __global__ __launch_bounds__(FRN_T) void frn_gather_kernel(const float* __restri
                                                            int wshift, int cap, int EPI, int accum, int xcd,
                                                            float* __restrict__ bottom,
                                                            unsigned long long* __restrict__ stamps) {
-  frn_gather_body<K, CP>(top, slicehdr, sell, cellinfo, entries, C, H, W, wshift, cap, EPI, accum, xcd, bottom, stamps,
-                         blockIdx.x, gridDim.x);
+  // (the deep form where it was measured: whole 128 x 128 planes of two channels)
+  frn_gather_body<K, CP, K == 16 && CP == 2>(top, slicehdr, sell, cellinfo, entries, C, H, W, wshift, cap, EPI, accum, xcd,
+                                             bottom, stamps, blockIdx.x, gridDim.x);
 }
 
 // The coarse levels of a pyramid (planes of at most 4096 cells: one or four slices per wavefront, four channels per
