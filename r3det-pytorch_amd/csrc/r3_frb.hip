@@ -1075,9 +1075,11 @@ __device__ __forceinline__ void frn_gather_body(const float* __restrict__ top, c
     }
   }
   stamp(1);
-  __syncthreads();
-  stamp(2);
-  if (kend <= 0) return;
+  if constexpr (!DEEP) {  // (DEEP: the barrier comes behind the first index loads, below)
+    __syncthreads();
+    stamp(2);
+    if (kend <= 0) return;
+  }
   // The wavefront's batches (four row pairs = eight entries per lane, 4 KB; a slice without entries still has one,
   // never looked at) are listed ONCE, by a scalar walk over the slices, in two registers -- lane t: the t-th batch's
   // offset and what the sums need to know about it -- so that the loop proper is: v_readlane, four loads two batches
@@ -1098,7 +1100,7 @@ __device__ __forceinline__ void frn_gather_body(const float* __restrict__ top, c
     const int up = __shfl_up(startv, o);
     if (lane >= o) startv += up;
   }
-  const int total_all = __builtin_amdgcn_readlane(startv, kend - 1);
+  const int total_all = kend > 0 ? __builtin_amdgcn_readlane(startv, max(kend, 1) - 1) : 0;
   startv -= nbv;  // ... exclusive
   int* seq_tab = reinterpret_cast<int*>(frn_lds + ((size_t)H * P + 1) * CP) + wave * 128;
   auto build = [&](int w0) -> int {  // the batches [w0, w0 + 64) of the wavefront; returns how many there are
@@ -1208,12 +1210,27 @@ __device__ __forceinline__ void frn_gather_body(const float* __restrict__ top, c
     // 128 KB on the way and gets the 42 B / clock the stamps showed; with three, 128 x 128 at N = 4: 44.3 -> 41.7 us,
     // N = 2: 23.2 -> 21.2 us (tools/frn_ab.py; four in flight: no better -- a wavefront has ~19 batches -- and with the
     // results held as well the kernel spills).
-    for (int w0 = 0; w0 < total_all; w0 += 64) {
-      const int total = build(w0);
-      B8 A, B, Cc, D;
+    // The first batches are requested BEFORE the barrier behind the staging (they do not depend on the planes): a
+    // wavefront waited 2.7 us there for the slowest one and then one more round trip for its first index rows.
+    B8 A, B, Cc, D;
+    int total0 = 0;
+    if (total_all > 0) {
+      total0 = build(0);
       load_batch(0, A);
       load_batch(1, B);
       load_batch(2, Cc);
+    }
+    __syncthreads();
+    stamp(2);
+    if (kend <= 0) return;
+    for (int w0 = 0; w0 < total_all; w0 += 64) {
+      int total = total0;
+      if (w0 > 0) {
+        total = build(w0);
+        load_batch(0, A);
+        load_batch(1, B);
+        load_batch(2, Cc);
+      }
 #pragma unroll 1
       for (int t = 0; t < total; t += 4) {
         load_batch(t + 3, D);
