@@ -89,6 +89,29 @@ def test_cell_kernel_long_channel_runs(shape):
         assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 100, 100, 8), (2, 6, 100, 128, 8), (1, 2, 90, 100, 8)])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_backward_gather_planes_that_leave_wavefronts_without_slices(shape, adversarial):
+    """Planes of 8 193 ... 16 383 cells whose two-channel form takes 16 slices per wavefront (the form with three index
+    batches in flight and its first loads in front of the barrier): the last wavefronts own a partial set of slices or
+    none at all and must still meet the barrier; against the oracle, overwrite and accumulate."""
+    from r3det.ops.feature_refine import fr_backward
+    N, C, H, W, stride = shape
+    r = np.random.default_rng(23)
+    top = r.normal(size=(N, C, H, W)).astype(np.float32)
+    boxes = fr_boxes(N, H, W, stride, 9, adversarial=adversarial)
+    with O.twin():
+        want = O.fr_backward(top, boxes, 1 / stride, 1)
+    tol = 1e-5 * max(1.0, np.abs(want).max())
+    g = torch.full((N, C, H, W), float('nan'), device='cuda')
+    fr_backward(dev(top), dev(boxes), 1 / stride, 1, g, overwrite=True)
+    assert np.abs(g.cpu().numpy() - want).max() <= tol
+    pre = r.normal(size=(N, C, H, W)).astype(np.float32)
+    g2 = dev(pre)
+    fr_backward(dev(top), dev(boxes), 1 / stride, 1, g2, overwrite=False)
+    assert np.abs(g2.cpu().numpy() - (pre + want)).max() <= 2 * tol
+
+
 @pytest.mark.parametrize("shape", [(1, 512, 128, 128, 8), (1, 1024, 128, 128, 8), (2, 512, 64, 64, 16),
                                    (3, 512, 64, 64, 16)])
 @pytest.mark.parametrize("adversarial", [False, True])
