@@ -286,6 +286,152 @@ __device__ __forceinline__ void cell_tap(float y, float x, int H, int W, float& 
   tx = x;
 }
 
+typedef float fr_f2 __attribute__((ext_vector_type(2)));
+
+// points = 5 (feature_refine_kernel.cu:137-151: the centre and the four corners of the box), NCHW, the cell kernel's
+// plane layout -- whole plane in LDS, pitch W + 1, the last column and row staged twice so that the upper taps are
+// always one step away, an invalid sample reads the zero rows behind them -- with what five points per position need:
+// the sample points live in registers (two floats per point: the clamped coordinates; cell, fractions and address are
+// recomputed per plane, 8 vector instructions for 4 LDS reads), so a thread keeps KQ <= 4 positions, and a plane of more
+// than 4096 positions is worked on by Q workgroups that each stage the WHOLE plane (from the L2: one of them brought
+// it in) and sample a Q-th of the positions.  The plane kernel this replaces for points = 5 rebuilt all taps (a sincos
+// and five clamps per position) for every plane: 222 us at level 0, N = 4.
+template <int POINTS, int KQ>
+__global__ __launch_bounds__(1024) void fr_forward_points_kernel(const float* __restrict__ feat,
+                                                                 const float* __restrict__ boxes, int C, int H, int W,
+                                                                 float scale, int G, int Q, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // (H + 3) rows of pitch W + 1
+  const int tid = threadIdx.x, HW = H * W, PITCH = W + 1;
+  const int groups = C / G;
+  const int n = blockIdx.x / (groups * Q);
+  const int rem = blockIdx.x - n * groups * Q;
+  const int grp = rem / Q, q = rem - grp * Q;
+  float ty[KQ][POINTS], tx[KQ][POINTS];
+  int own[KQ];
+#pragma unroll
+  for (int k = 0; k < KQ; k++) {
+    const int p = (q * KQ + k) * 1024 + tid;
+    own[k] = -1;
+#pragma unroll
+    for (int i = 0; i < POINTS; i++) ty[k][i] = (float)(H + 1), tx[k][i] = 0.f;
+    if (p < HW) {
+      const float* box = boxes + ((size_t)n * HW + p) * 5;
+      const int y = p / W;
+      own[k] = p + y;  // (y * PITCH + x)
+      const float roi_y = box[0] * scale;  // sic: row <- x_ctr
+      const float roi_x = box[1] * scale;  //      col <- y_ctr
+      cell_tap(roi_y, roi_x, H, W, ty[k][0], tx[k][0]);
+      if (POINTS > 1) {
+        const float roi_w = box[2] * scale, roi_h = box[3] * scale, roi_a = box[4];
+        const float w_2 = roi_w / 2, h_2 = roi_h / 2;
+        float sina, cosa;
+        r3_sincos(roi_a, sina, cosa);
+        const float wx = cosa * w_2, wy = sina * w_2;
+        const float hx = -sina * h_2, hy = cosa * h_2;
+        cell_tap(roi_y + wy + hy, roi_x + wx + hx, H, W, ty[k][1], tx[k][1]);
+        cell_tap(roi_y - wy + hy, roi_x - wx + hx, H, W, ty[k][2], tx[k][2]);
+        cell_tap(roi_y - wy - hy, roi_x - wx - hx, H, W, ty[k][3], tx[k][3]);
+        cell_tap(roi_y + wy - hy, roi_x + wx - hx, H, W, ty[k][4], tx[k][4]);
+      }
+    }
+  }
+  // Two plane buffers: the next plane's elements are requested before the current plane is sampled and written to the
+  // idle buffer behind it -- one workgroup per compute unit (79 VGPRs at four positions per thread), so nothing else
+  // would hide the loads; one barrier per plane.
+  const int BUF = (H + 3) * PITCH;
+  for (int i = tid; i < 2 * PITCH; i += 1024) lds[(H + 1) * PITCH + i] = lds[BUF + (H + 1) * PITCH + i] = 0.f;  // zero rows
+  const size_t plane0 = ((size_t)n * C + (size_t)grp * G) * HW;
+  constexpr int SV = 8;  // elements of HALF a plane per thread (HW <= 16 384: the launcher); 16 in flight: spills
+  float sv[SV];
+  auto request = [&](const float* src, const int half) {
+#pragma unroll
+    for (int u = 0; u < SV; u++) {
+      const int i = (half * SV + u) * 1024 + tid;
+      sv[u] = i < HW ? src[i] : 0.f;
+    }
+  };
+  // (a thread's elements are 1024 apart: for the widths of a pyramid -- W divides 1024 -- the same column, rows a
+  // constant step apart)
+  const bool wdiv = (1024 % W) == 0;
+  const int y0 = tid / W, x0 = tid - y0 * W, ystep = 1024 / W;
+  auto deposit = [&](float* buf, const int half) {
+#pragma unroll
+    for (int u = 0; u < SV; u++) {
+      const int i = (half * SV + u) * 1024 + tid;
+      if (i < HW) {
+        const int y = wdiv ? y0 + (half * SV + u) * ystep : i / W, x = wdiv ? x0 : i - (i / W) * W;
+        buf[y * PITCH + x] = sv[u];
+        if (x == W - 1) buf[y * PITCH + W] = sv[u];  // last column twice
+        if (y == H - 1) {                            // last row twice (and its corner)
+          buf[H * PITCH + x] = sv[u];
+          if (x == W - 1) buf[H * PITCH + W] = sv[u];
+        }
+      }
+    }
+  };
+  request(feat + plane0, 0);
+  deposit(lds, 0);
+  request(feat + plane0, 1);
+  deposit(lds, 1);
+  __syncthreads();
+  for (int c = 0; c < G; c++) {
+    const float* buf = lds + (c & 1) * BUF;
+    float* dst = out + plane0 + (size_t)c * HW;
+    // (the next plane in two halves: half of it requested in front of each half of this plane's positions)
+    float* nbuf = lds + ((c + 1) & 1) * BUF;
+    if (c + 1 < G) request(feat + plane0 + (size_t)(c + 1) * HW, 0);
+#pragma unroll
+    for (int k = 0; k < KQ; k++) {
+      if (k == (KQ + 1) / 2 && c + 1 < G) {
+        deposit(nbuf, 0);
+        request(feat + plane0 + (size_t)(c + 1) * HW, 1);
+      }
+      if (own[k] < 0) continue;
+      // (the cells of up to three points of a position requested together -- the two of a row as one 8-byte pair --
+      // then the sums in the reference's order, weights in packed fp32 as in fr_forward_cell; all five at once: spills)
+      float v = buf[own[k]];
+#pragma unroll
+      for (int i0 = 0; i0 < POINTS; i0 += 3) {
+        constexpr int PB = 3;
+        fr_f2 top[PB], bot[PB];
+        float fy[PB], fx[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+          const int i = i0 + j;
+          if (i < POINTS) {
+            float y = ty[k][i], x = tx[k][i];
+            asm volatile("" : "+v"(y), "+v"(x));  // (else cell / fractions / address of all points are hoisted: spills)
+            const int yi = (int)y, xi = (int)x;
+            fy[j] = __builtin_amdgcn_fractf(y), fx[j] = __builtin_amdgcn_fractf(x);
+            const int a = yi * PITCH + xi;
+            top[j] = fr_f2{buf[a], buf[a + 1]};
+            bot[j] = fr_f2{buf[a + PITCH], buf[a + PITCH + 1]};
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+          if (i0 + j < POINTS) {
+            // (1.f - f == (float)(1. - (double)f) for f in [0, 1): see fr_forward_cell)
+            const fr_f2 hf = {1.f - fx[j], fx[j]};
+            const fr_f2 pt = ((1.f - fy[j]) * hf) * top[j];  // {w1 * lt, w2 * rt}
+            const fr_f2 pb = (fy[j] * hf) * bot[j];          // {w3 * lb, w4 * rb}
+            v += pt.x + pt.y + pb.x + pb.y;
+          }
+        }
+      }
+      dst[(q * KQ + k) * 1024 + tid] = v;
+    }
+    if (c + 1 < G) {
+      if (KQ == 1) {  // (no second half of positions to put the first deposit in front of)
+        deposit(nbuf, 0);
+        request(feat + plane0 + (size_t)(c + 1) * HW, 1);
+      }
+      deposit(nbuf, 1);
+    }
+    __syncthreads();
+  }
+}
+
 __device__ __forceinline__ void fr_cell_table_body(const float* __restrict__ boxes, int N, int H, int W, float scale,
                                                    float* __restrict__ table, const int pos) {
   const int HW = H * W;
@@ -1202,7 +1348,6 @@ __global__ __launch_bounds__(256) void fr_cell_table_kernel(const float* __restr
   fr_cell_table_body(boxes, N, H, W, scale, table, blockIdx.x * 256 + threadIdx.x);
 }
 
-typedef float fr_f2 __attribute__((ext_vector_type(2)));
 
 // FROM_BOXES: `table` is the (N*H*W, 5) box array itself and the taps are derived in the prologue
 // (no table kernel, no dependent launch: worth ~6 us per call at N = 4, where the table kernel
@@ -1471,6 +1616,27 @@ int r3k_fr_forward(const float* feat, const float* boxes, int N, int C, int H, i
     if (W == 128) { if (from_boxes) R3_CELL(7, 7, true, boxes); else R3_CELL(7, 7, false, table); }
     else { if (from_boxes) R3_CELL(6, 6, true, boxes); else R3_CELL(6, 6, false, table); }
 #undef R3_CELL
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
+  if (plane && points == 5 && g_r3_fr_impl == 0 && (size_t)(H + 3) * (W + 1) * 8 <= 156 * 1024 && H * W <= 16384) {
+    // points = 5: the sample points in registers, whole planes in LDS, Q workgroups per plane above 4096 positions
+    const int HWp = H * W;
+    const int Q = (HWp + 4095) / 4096;
+    const int need = (HWp + Q * 1024 - 1) / (Q * 1024);  // positions per thread
+    const int KQ = need <= 1 ? 1 : need <= 2 ? 2 : 4;
+    int Gc = 1;
+    while (Gc * 2 <= 16 && C % (Gc * 2) == 0 && (size_t)N * (C / (Gc * 2)) * Q >= (size_t)cu_count()) Gc *= 2;
+    const size_t ldsb = (size_t)(H + 3) * (W + 1) * 8;  // two buffers
+    static R3DeviceOnce once;
+    if (once.first()) {
+      allow_big_lds(fr_forward_points_kernel<5, 1>, 160 * 1024);
+      allow_big_lds(fr_forward_points_kernel<5, 2>, 160 * 1024);
+      allow_big_lds(fr_forward_points_kernel<5, 4>, 160 * 1024);
+    }
+    const dim3 pgrid((unsigned)(N * (C / Gc) * Q));
+#define R3_P5(KK) hipLaunchKernelGGL((fr_forward_points_kernel<5, KK>), pgrid, dim3(1024), ldsb, stream, feat, boxes, C, H, W, scale, Gc, Q, out)
+    if (KQ == 1) R3_P5(1); else if (KQ == 2) R3_P5(2); else R3_P5(4);
+#undef R3_P5
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   if (plane) {
