@@ -688,12 +688,23 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_levels_kernel(const FrbLe
 // All index arithmetic in 32 bits (the launcher refuses IMAGES of 4 GB and more), everything about a cell's list in
 // scalar registers: the first version of this kernel spent 640 scalar instructions per wavefront on 64-bit address
 // arithmetic and register spills and was bound by their issue (PMC: 10.5 M scalar of 15.5 M instructions).
+#ifdef R3_PROBES
+__device__ unsigned long long* d_frb_stamps = nullptr;  // (tools/frb_stamps.py: clock stamps of thread 0 of every workgroup)
+#endif
+
 template <bool ACCUM, bool PAIRED>
 __device__ __forceinline__ void frb_gather_body(const float* __restrict__ top, const int2* __restrict__ cellinfo,
                                                 const int2* __restrict__ entries, int C, int H, int W, int EPI,
                                                 int tiles_xs, int tiles_per_img, int T, float* __restrict__ bottom,
                                                 const unsigned block) {
   const int tiles_x = tiles_xs & 0xfffff, strip = tiles_xs >> 20;  // (the pair walk's strip height rides in the top bits)
+  auto stamp = [&](int i) {
+#ifdef R3_PROBES
+    unsigned long long* st = d_frb_stamps;
+    if (st && threadIdx.x == 0) st[(size_t)block * 8 + i] = __builtin_amdgcn_s_memrealtime();
+#endif
+  };
+  stamp(0);
   __shared__ float4 Gs[PAIRED ? 32 : 16][64];  // slot (half * 16 + row of the tile * 4 + column) x lane
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
@@ -792,7 +803,9 @@ __device__ __forceinline__ void frb_gather_body(const float* __restrict__ top, c
 #pragma unroll
       for (int i = 0; i < 4; i++) Gs[own + i][lane] = gi[i];
     }
+    stamp(1);
     __syncthreads();
+    stamp(2);
     // an entry's gradient row: from either tile of the workgroup (LDS) or from memory
     auto G = [&](const int code) -> float4 {  // wave-uniform
       if (code < 0 && (PAIRED || !(code & 0x40000000))) return Gs[((code >> 26) & 31) ^ halfX][lane];
@@ -852,11 +865,18 @@ __device__ __forceinline__ void frb_gather_body(const float* __restrict__ top, c
       const E4 en_cur = en_next;
       en_next = first4(i == 0 ? st[1] : i == 1 ? st[2] : st[3]);
       cell(i, st_i, len_i, en_cur);
+      if (i == 0) stamp(3);
     }
+    stamp(4);
     if (c0 + 64 < C4) __syncthreads();  // the next channel block overwrites Gs
   }
 }
 
+// (Residency, measured with clock stamps and tools/probes/occupancy_probe2.hip: with its 94 scalar registers a
+// wavefront is allocated 112 -- 16 beyond the granule of 16 are set aside per wavefront on this stack -- so a SIMD holds
+// 7 of them and a compute unit THREE of these 8-wave workgroups, not the four the runtime's occupancy query
+// answers; capped at 78 (amdgpu_num_sgpr(80)) four are resident, each lives 10.4 us instead of 8.1 and the launch
+// takes the same 31-32 us at N = 4 (17.5 instead of 18.8 at N = 2): the launch is bound by what it moves.  Not capped.)
 template <bool ACCUM, bool PAIRED>
 __global__ __launch_bounds__(PAIRED ? 512 : 256) void frb_gather_kernel(const float* __restrict__ top,
                                                                         const int2* __restrict__ cellinfo,
@@ -1425,6 +1445,12 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
   const int EPI = H * W * 4 * points;
   const dim3 grid((unsigned)T), block(paired ? 512 : 256);
 #define R3_ARGS top_grad, L.cellinfo, L.entries, C, H, W, EPI, tiles_x | (g_r3_fr_walk << 20), tpi, (int)T, bottom_grad
+#ifdef R3_PROBES
+  {  // (clock stamps, tools/frb_stamps.py: the buffer set through frn_stamps_lo / _hi)
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(g_r3_frn_stamps);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_frb_stamps), &sp, sizeof(sp), 0, hipMemcpyHostToDevice, stream);
+  }
+#endif
   if (paired) {
     if (overwrite) hipLaunchKernelGGL((frb_gather_kernel<false, true>), grid, block, 0, stream, R3_ARGS);
     else hipLaunchKernelGGL((frb_gather_kernel<true, true>), grid, block, 0, stream, R3_ARGS);
