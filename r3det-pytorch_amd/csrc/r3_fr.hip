@@ -662,6 +662,96 @@ __global__ __launch_bounds__(256) void fr_forward_nhwc(const float* __restrict__
   }
 }
 
+// points = 5 on channels_last memory (plain sampler): the simple kernel above reads 21 rows of 1 KB per position
+// through the L2 -- 1.4 GB per launch at level 0, N = 4, which is what its 101 us are.  Here a workgroup owns an 8 x 8
+// tile of positions and stages, per block of 64 channels (256 bytes per row), the rows its samples can reach: by the
+// reference's row <- x_ctr / column <- y_ctr swap the TRANSPOSED tile, +- P5_R cells for the corners of the boxes
+// (16 x 16 rows, 64 KB); a cell outside that region (a box larger than 2 P5_R cells) is read from memory.  The sample
+// geometry of the 64 positions is computed once (one thread per position: a sincos and five clamps) into an LDS table
+// of cell coordinates and weights and serves all channel blocks.  Same operations in the same order as the simple
+// kernel: bit-identical.
+constexpr int P5_T = 8, P5_R = 4, P5_REG = P5_T + 2 * P5_R, P5_ROWS = P5_REG * P5_REG;
+struct P5Tap {
+  short yl, xl, yh, xh;  // cells of the map; yl < 0: the sample is outside the map (contributes nothing)
+  float w[4];
+};
+
+__global__ __launch_bounds__(1024) void fr_forward_nhwc_p5(const float* __restrict__ a, const float* __restrict__ boxes,
+                                                          int C, int H, int W, float scale, int tiles_x,
+                                                          int tiles_per_img, int T, float* __restrict__ out) {
+  __shared__ float4 reg[P5_ROWS][16];  // the region's rows, 64 channels of them
+  __shared__ P5Tap taps[P5_T * P5_T][5];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned t = blockIdx.x;
+  if ((T & 7) == 0) t = (t & 7u) * (unsigned)(T >> 3) + (t >> 3);  // XCD-contiguous bands of tiles
+  const int n = (int)(t / (unsigned)tiles_per_img);
+  const int tt = (int)(t - (unsigned)n * (unsigned)tiles_per_img);
+  const int tyi = tt / tiles_x, txi = tt - tyi * tiles_x;
+  const int py0 = tyi * P5_T, px0 = txi * P5_T;      // the tile of positions
+  const int ry0 = px0 - P5_R, rx0 = py0 - P5_R;      // the region of cells: rows <- columns of the tile, and back
+  const int HW = H * W, C4 = C >> 2;
+  const size_t img = (size_t)n * HW;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  if (tid < P5_T * P5_T) {
+    const int py = py0 + (tid >> 3), px = px0 + (tid & 7);  // (H, W multiples of 8: the launcher)
+    TapYX tp[5];
+    make_taps_yx<5>(boxes + (img + (size_t)py * W + px) * 5, scale, H, W, tp);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      P5Tap e;
+      e.yl = tp[i].valid ? (short)tp[i].yl : (short)-1;
+      e.xl = (short)tp[i].xl, e.yh = (short)tp[i].yh, e.xh = (short)tp[i].xh;
+      e.w[0] = tp[i].w[0], e.w[1] = tp[i].w[1], e.w[2] = tp[i].w[2], e.w[3] = tp[i].w[3];
+      taps[tid][i] = e;
+    }
+  }
+  const int grp = lane >> 4, ch = lane & 15;  // four positions of a wave at a time, 16 lanes x 16 bytes each
+  for (int c0 = 0; c0 < C4; c0 += 16) {
+    // staging: 256 rows x 16 float4, four per thread (16 wavefronts: a position's five points are one wavefront round;
+    // with four wavefronts per workgroup and two workgroups per compute unit nothing hid the latencies: 108 us)
+    {
+      float4 sv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = u * 64 + (tid >> 4);
+        const int y = ry0 + r / P5_REG, x = rx0 + r % P5_REG;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        sv[u] = in ? a4[(img + (size_t)y * W + x) * C4 + c0 + ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) reg[u * 64 + (tid >> 4)][ch] = sv[u];
+    }
+    __syncthreads();  // (also: the tap table is complete)
+    // a cell's row: from the region or from memory
+    auto row = [&](const int y, const int x) -> float4 {
+      const int i = y - ry0, j = x - rx0;
+      if ((unsigned)i < (unsigned)P5_REG && (unsigned)j < (unsigned)P5_REG) return reg[i * P5_REG + j][ch];
+      return a4[(img + (size_t)y * W + x) * C4 + c0 + ch];
+    };
+    {
+      const int pl = wave * 4 + grp;  // position inside the tile
+      const int py = py0 + (pl >> 3), px = px0 + (pl & 7);
+      const size_t q = (img + (size_t)py * W + px) * C4 + c0 + ch;
+      float4 v = a4[q];
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        const P5Tap tp = taps[pl][i];
+        if (tp.yl < 0) continue;
+        const float4 lt = row(tp.yl, tp.xl), rt = row(tp.yl, tp.xh), lb = row(tp.yh, tp.xl), rb = row(tp.yh, tp.xh);
+        float4 sm;
+        sm.x = tp.w[0] * lt.x + tp.w[1] * rt.x + tp.w[2] * lb.x + tp.w[3] * rb.x;
+        sm.y = tp.w[0] * lt.y + tp.w[1] * rt.y + tp.w[2] * lb.y + tp.w[3] * rb.y;
+        sm.z = tp.w[0] * lt.z + tp.w[1] * rt.z + tp.w[2] * lb.z + tp.w[3] * rb.z;
+        sm.w = tp.w[0] * lt.w + tp.w[1] * rt.w + tp.w[2] * lb.w + tp.w[3] * rb.w;
+        v.x += sm.x; v.y += sm.y; v.z += sm.z; v.w += sm.w;
+      }
+      o4[q] = v;
+    }
+    if (c0 + 16 < C4) __syncthreads();  // the next channel block overwrites the region
+  }
+}
+
 // Software-pipelined form for points = 1 (the shipped configuration).  The simple kernel above is latency-bound:
 // per position a wave waits for the box, derives the tap, waits for its 11 loads, stores (3.2 TB/s on four streams
 // with one position per wave, less with more).  Here a wave walks KW consecutive columns of its row with a
@@ -1917,6 +2007,14 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
       else hipExtLaunchKernelGGL((fr_forward_nhwc_pipe<false, 4, false>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
     }
 #endif
+  } else if (!fused && dbg == 0 && (H & 7) == 0 && (W & 7) == 0 && (C & 63) == 0 && H < 32768 && W < 32768 &&
+             (long long)(H / P5_T) * (W / P5_T) * N <= 0x7fffffffLL && (long long)(H / P5_T) * (W / P5_T) * N >= r3_cu_count()) {
+    // points = 5, plain sampler: 8 x 8 tiles of positions with their sample region in LDS -- from one workgroup per
+    // compute unit up (level 0, N = 4: 104 -> 77 us, level 1: 29.6 -> 23.3; the coarse levels, 16-64 workgroups of 4
+    // channel passes each: 16-19 us against the simple kernel's 12: tools/fr_p5_nhwc_ab.py)
+    const int ptx = W / P5_T, ptpi = ptx * (H / P5_T), pT = ptpi * N;
+    hipLaunchKernelGGL(fr_forward_nhwc_p5, dim3((unsigned)pT), dim3(1024), 0, stream, a, boxes, C, H, W, scale, ptx, ptpi, pT,
+                       out);
   } else {
     if (fused) hipExtLaunchKernelGGL((fr_forward_nhwc<5, true, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);
     else hipExtLaunchKernelGGL((fr_forward_nhwc<5, false, 4>), grid, block, 0, stream, e0, e1, 0, R3_ARGS);

@@ -84,6 +84,7 @@ python3 $R/tools/kstats.py /tmp/kt_run fr_forward frn_ frb_ fr_cell >> $O/${TAG}
 python3 $R/tools/fr_levels_ab.py 2>/dev/null | grep "^N=" | sed 's/^/# (no profiler) /' >> $O/${TAG}_fr_levels_ab.txt
 # 6c''. points = 5, NCHW: the points kernel against the plane kernel, per level (no profiler)
 python3 $R/tools/fr_p5_ab.py > $O/${TAG}_fr_p5_ab.txt 2>/dev/null
+python3 $R/tools/fr_p5_nhwc_ab.py >> $O/${TAG}_fr_p5_ab.txt 2>/dev/null
 # 6d. the pre-NMS pool at the two models' shapes: per level (r3det_level_pool) and the whole head in one call (r3det_levels_pool)
 kt $O/${TAG}_pool_kernel_stats.txt "python3 tools/pool_prof.py" python3 $R/tools/pool_prof.py
 python3 $R/tools/kt_by_grid.py $(find /tmp/kt_run -name "*kernel_trace.csv" | head -1) pool_ fill >> $O/${TAG}_pool_kernel_stats.txt
