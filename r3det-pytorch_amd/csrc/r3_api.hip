@@ -9,6 +9,7 @@
 
 int g_r3_iou_impl = 0;
 int g_r3_iou_small = 0;
+int g_r3_clip_impl = 0;
 int g_r3_iou_qcap = 0;
 int g_r3_iou_dwgs = 0;
 int g_r3_nms_impl = 0;
@@ -655,6 +656,7 @@ int r3det_set_option(const char* name, int value) {
   else if (!strcmp(name, "frn_stamps_hi")) g_r3_frn_stamps = (g_r3_frn_stamps & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32);
   else if (!strcmp(name, "iou_impl")) g_r3_iou_impl = value;
   else if (!strcmp(name, "iou_small")) g_r3_iou_small = value;
+  else if (!strcmp(name, "clip_impl")) g_r3_clip_impl = value;
   else if (!strcmp(name, "iou_qcap")) g_r3_iou_qcap = value;
   else if (!strcmp(name, "iou_dwgs")) g_r3_iou_dwgs = value;
   else if (!strcmp(name, "nms_impl")) g_r3_nms_impl = value;

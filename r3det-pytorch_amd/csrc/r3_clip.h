@@ -1,0 +1,230 @@
+// r3_clip.h -- the v1 pair clip (rbbox_geo_kernel.cu:88-268 == rnms_kernel.cu:15-200) as STRAIGHT-LINE code for
+// pairs in general position; everything else is flagged and redone by the exact branchy form (r3_geom_lds.h).
+//
+// Round 5.  The drains (iou_drain3 / nms_drain / assign_drain) were bound by the instructions they issue: per wave
+// and clip ~1500 vector + ~1400 scalar instructions, the scalar half exec-mask bookkeeping of lane-divergent
+// branches, and long dependent chains through LDS (de-dup, insertion sort, shoelace walk the candidate list slot by
+// slot).  This form issues ~40 % fewer vector instructions and almost no scalar ones:
+//
+//   * WHICH edge pairs cross is decided from signs, without dividing and without the 16 branchy segment tests.
+//     With ns(i,j) = cross(v1[i] - v2[j], B_j) and nt(i,j) = -cross(A_i, v1[i] - v2[j]) -- the very numerators the
+//     reference divides (rbbox_geo_kernel.cu:111-112) -- exact arithmetic gives ns(i+1,j) = ns(i,j) - D(i,j) and
+//     nt(i,j+1) = nt(i,j) - D(i,j), D = -cross(A_i, B_j).  So 0 <= ns/D < 1 <=> ns(i,j), ns(i+1,j) have opposite
+//     signs, and likewise for nt.  In floating point this holds whenever all 32 numerators are larger in magnitude
+//     than 3 delta, delta = 8.2 u max(|C|,|E|) |E| the rounding-error bound of a numerator / of D (u = 2^-24; |C|
+//     the largest vertex difference, |E| the largest edge component) -- proof in DESIGN 4.1.  Such a pair has no
+//     coincident vertices (C == 0 => ns == 0), no parallel-and-collinear edges (D == 0 needs nt == 0 to produce a
+//     point) and no quotient near 0 or 1, i.e. none of the reference's special branches (:99-103, :118-139) can fire.
+//     A pair with a smaller numerator is FLAGGED (`redo`) and the caller runs the exact form on it.
+//   * the accepted crossings (<= 2 per edge of box 1 in general position; a third flags the pair) are selected with
+//     conditional moves, divided (the reference's s = ns / D, correctly rounded) and appended in the reference's order:
+//     vertices of 1 inside 2, vertices of 2 inside 1 (the reference's own dot-product tests, :157-175), crossings
+//     edge-major.  The only use of LDS is as the dynamic index it is good at: a candidate is written at slot `cnt`
+//     and the <= 8 candidates are read back into registers at static slots (two convex quadrilaterals in general
+//     position meet in <= 8 points; a 9th flags the pair).
+//   * de-dup (:196-209), insertion sort (:210-215) and shoelace (:216-227) on registers, fully unrolled: the
+//     de-dup is the reference's sequential rule evaluated with predicates; the sort is a RANK: one cross product per
+//     unordered pair (cross(b, a) is exactly -cross(a, b) in floating point) says which of the two the stable
+//     insertion sort leaves in front; if the 21 answers form a total order (every rank taken once) the insertion
+//     sort, which only ever asks those questions, must produce it -- otherwise the pair is flagged.  The kept
+//     candidates go to LDS slot `rank`, come back in order, and the shoelace sum adds them in the reference's order.
+//
+// Every float produced here that reaches the result is produced by the reference's own operation on the reference's
+// own operands (IEEE + - * /, no contraction: -ffp-contract=off), so an unflagged pair is bit-identical to the exact
+// form.  The functions are __host__ __device__: tests/test_clip_host.py compiles this header with the host compiler
+// and checks 10^6s of pairs against the oracle without a GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define R3_CLIP_SLOTS 9  // 8 candidates + the dump slot that takes the writes of rejected candidates
+
+// candidate store of ONE pair: slot -> point.  Device: wave-private LDS, [slot][lane] (conflict-free 8-byte words).
+template <int STRIDE>
+struct ClipLds {
+  float2* base;  // already offset by the lane
+  __device__ __forceinline__ void set(int s, float x, float y) const { base[s * STRIDE] = make_float2(x, y); }
+  __device__ __forceinline__ void get(int s, float& x, float& y) const {
+    const float2 v = base[s * STRIDE];
+    x = v.x;
+    y = v.y;
+  }
+};
+struct ClipHost {  // (the host harness of the tests)
+  mutable float px[R3_CLIP_SLOTS], py[R3_CLIP_SLOTS];
+  void set(int s, float x, float y) const { px[s] = x, py[s] = y; }
+  void get(int s, float& x, float& y) const { x = px[s], y = py[s]; }
+};
+
+// A, B: v1 records (r3_geom.h): f[0..7] the vertices (x0, y0, .., x3, y3), f[8] = w * h.
+// Returns the IoU / IoF of an unflagged pair; `redo` = the pair needs the exact form (the value is then meaningless).
+template <class Store>
+__host__ __device__ __forceinline__ float v1_clip_fast(const float* __restrict__ A, const float* __restrict__ B,
+                                                       const bool iof, const Store& st, bool& redo) {
+  float ax[4], ay[4], bx[4], by[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    ax[i] = A[2 * i], ay[i] = A[2 * i + 1];
+    bx[i] = B[2 * i], by[i] = B[2 * i + 1];
+  }
+  float Ax[4], Ay[4], Bx[4], By[4];  // edges: v[i + 1] - v[i] (:183-186 hand a1 = v[i], a2 = v[i + 1] to the segment test)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    Ax[i] = ax[(i + 1) & 3] - ax[i], Ay[i] = ay[(i + 1) & 3] - ay[i];
+    Bx[i] = bx[(i + 1) & 3] - bx[i], By[i] = by[(i + 1) & 3] - by[i];
+  }
+  int cnt = 0;
+  bool bad = false;
+  // ---- vertices strictly inside the other box (vertex_in_rbbox, :157-175): the reference's own arithmetic
+  {
+    const float cx = 0.5f * (bx[0] + bx[2]), cy = 0.5f * (by[0] + by[2]);
+    const float wx = 0.5f * Bx[0], wy = 0.5f * By[0], hx = 0.5f * Bx[1], hy = 0.5f * By[1];
+    const float h2 = hx * hx + hy * hy, w2 = wx * wx + wy * wy;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float px = ax[i] - cx, py = ay[i] - cy;
+      const bool in = (fabsf(px * hx + py * hy) < h2) & (fabsf(px * wx + py * wy) < w2);
+      st.set(in ? cnt : 8, ax[i], ay[i]);
+      cnt += in ? 1 : 0;
+    }
+  }
+  {
+    const float cx = 0.5f * (ax[0] + ax[2]), cy = 0.5f * (ay[0] + ay[2]);
+    const float wx = 0.5f * Ax[0], wy = 0.5f * Ay[0], hx = 0.5f * Ax[1], hy = 0.5f * Ay[1];
+    const float h2 = hx * hx + hy * hy, w2 = wx * wx + wy * wy;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float px = bx[i] - cx, py = by[i] - cy;
+      const bool in = (fabsf(px * hx + py * hy) < h2) & (fabsf(px * wx + py * wy) < w2);
+      st.set(in ? cnt : 8, bx[i], by[i]);
+      cnt += in ? 1 : 0;
+    }
+  }
+  // ---- the 32 numerators (rbbox_geo_kernel.cu:105-112: C = a1 - b1, s = cross(C, B) / D, t = -cross(A, C) / D)
+  float ns[4][4], nt[4][4];
+  float cmax = 0.f, emax = 0.f, nmin = 3.0e38f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    emax = fmaxf(emax, fmaxf(fmaxf(fabsf(Ax[i]), fabsf(Ay[i])), fmaxf(fabsf(Bx[i]), fabsf(By[i]))));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float Cx = ax[i] - bx[j], Cy = ay[i] - by[j];
+      ns[i][j] = Cx * By[j] - Bx[j] * Cy;
+      nt[i][j] = -(Ax[i] * Cy - Cx * Ay[i]);
+      cmax = fmaxf(cmax, fmaxf(fabsf(Cx), fabsf(Cy)));
+      nmin = fminf(nmin, fminf(fabsf(ns[i][j]), fabsf(nt[i][j])));
+    }
+  }
+  // general position: every numerator beyond 3.5 x the rounding bound, the scale itself sane (no overflow /
+  // underflow of the products; NaN / Inf anywhere fails one of the comparisons)
+  {
+    // (fmaxf / fminf drop NaN operands: a sum of all coordinates, times zero, carries NaN / Inf into the limit)
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) z += (ax[i] + ay[i]) + (bx[i] + by[i]);
+    const float big = fmaxf(cmax, emax);
+    const float lim = 1.8e-6f * big * emax + z * 0.f;  // 3.5 * 8.2 * 2^-24 = 1.71e-6
+    bad = bad | !(nmin > lim) | !(big < 1.0e15f) | !(emax > 1.0e-12f);
+  }
+  // ---- crossings, edge-major (rbbox_border_intsec, :177-191)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int i1 = (i + 1) & 3;
+    bool acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int j1 = (j + 1) & 3;
+      // opposite signs (none of them is zero here, or the pair is flagged)
+      const bool so = (ns[i][j] < 0.f) != (ns[i1][j] < 0.f);
+      const bool to = (nt[i][j] < 0.f) != (nt[i][j1] < 0.f);
+      acc[j] = so & to;
+    }
+    const int na = (int)acc[0] + (int)acc[1] + (int)acc[2] + (int)acc[3];
+    bad = bad | (na > 2);
+    // first / second accepted j
+    const bool f0 = acc[0], f1 = !acc[0] & acc[1], f2 = !acc[0] & !acc[1] & acc[2];
+    const float n0 = f0 ? ns[i][0] : f1 ? ns[i][1] : f2 ? ns[i][2] : ns[i][3];
+    const float bx0 = f0 ? Bx[0] : f1 ? Bx[1] : f2 ? Bx[2] : Bx[3];
+    const float by0 = f0 ? By[0] : f1 ? By[1] : f2 ? By[2] : By[3];
+    const bool s1 = acc[0] & acc[1], s2 = (acc[0] | acc[1]) & acc[2] & !s1;
+    const float n1 = s1 ? ns[i][1] : s2 ? ns[i][2] : ns[i][3];
+    const float bx1 = s1 ? Bx[1] : s2 ? Bx[2] : Bx[3];
+    const float by1 = s1 ? By[1] : s2 ? By[2] : By[3];
+    {
+      const float D = -(Ax[i] * by0 - bx0 * Ay[i]);
+      const float s = n0 / D;
+      const bool ok = na >= 1;
+      st.set(ok ? (cnt < 8 ? cnt : 8) : 8, ax[i] + s * Ax[i], ay[i] + s * Ay[i]);
+      cnt += ok ? 1 : 0;
+    }
+    {
+      const float D = -(Ax[i] * by1 - bx1 * Ay[i]);
+      const float s = n1 / D;
+      const bool ok = na >= 2;
+      st.set(ok ? (cnt < 8 ? cnt : 8) : 8, ax[i] + s * Ax[i], ay[i] + s * Ay[i]);
+      cnt += ok ? 1 : 0;
+    }
+  }
+  bad = bad | (cnt > 8);
+  redo = bad;
+  // ---- area (:193-228) on registers
+  float ux[8], uy[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) st.get(k, ux[k], uy[k]);
+  const float numthres = (float)1e-2;
+  float dx[8], dy[8];
+  bool kept[8];
+  kept[0] = true;
+  dx[0] = dy[0] = 0.f;
+  int n = 1;
+#pragma unroll
+  for (int i = 1; i < 8; i++) {
+    dx[i] = ux[i] - ux[0], dy[i] = uy[i] - uy[0];
+    bool clean = (i < cnt) & !((fabsf(dx[i]) < numthres) & (fabsf(dy[i]) < numthres));  // against vs[0] = the origin
+#pragma unroll
+    for (int j = 1; j < i; j++) {
+      const float fx = dx[i] - dx[j], fy = dy[i] - dy[j];
+      clean = clean & !(kept[j] & (fabsf(fx) < numthres) & (fabsf(fy) < numthres));
+    }
+    kept[i] = clean;
+    n += clean ? 1 : 0;
+  }
+  // rank of every kept point in the order the stable insertion sort (operator< :74-79 = cross > 0) leaves
+  int rank[8];
+#pragma unroll
+  for (int i = 1; i < 8; i++) rank[i] = 1;
+#pragma unroll
+  for (int i = 1; i < 8; i++) {
+#pragma unroll
+    for (int j = i + 1; j < 8; j++) {
+      const float c = dx[i] * dy[j] - dx[j] * dy[i];  // cross(d_i, d_j); cross(d_j, d_i) is exactly -c
+      const bool both = kept[i] & kept[j];
+      const bool jfirst = c < 0.f;  // d_j < d_i: the later key moves in front of d_i
+      rank[i] += (both & jfirst) ? 1 : 0;
+      rank[j] += (both & !jfirst) ? 1 : 0;
+    }
+  }
+  unsigned taken = 0;
+#pragma unroll
+  for (int i = 1; i < 8; i++) {
+    taken += kept[i] ? (1u << rank[i]) : 0u;  // (a sum: a rank taken twice carries into a wrong pattern or beyond)
+    st.set(kept[i] ? rank[i] : 8, dx[i], dy[i]);
+  }
+  redo = bad | (taken != (1u << n) - 2u);
+  float vx[8], vy[8];
+#pragma unroll
+  for (int k = 1; k < 8; k++) st.get(k, vx[k], vy[k]);
+  float a = 0.f;
+#pragma unroll
+  for (int k = 1; k < 7; k++) {
+    const float t = vx[k] * vy[k + 1] - vx[k + 1] * vy[k];
+    a = (k + 1 < n) ? a + t : a;
+  }
+  // (the closing term cross(vs[n - 1], origin) is +-0 and a is never -0: adding it changes nothing)
+  float su = a / 2;
+  const float s1 = A[8], s2 = B[8];
+  su = (s1 < su) ? s1 : su;
+  su = (s2 < su) ? s2 : su;
+  su = (su < 0.f) ? 0.f : su;
+  const float r = iof ? su / s1 : su / (s1 + s2 - su);
+  return cnt >= 3 ? r : 0.f;
+}

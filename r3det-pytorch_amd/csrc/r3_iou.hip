@@ -20,6 +20,7 @@
 //     evaluated per box, never per pair.
 #include <hip/hip_runtime.h>
 
+#include "r3_clip.h"
 #include "r3_geom_lds.h"
 #include "r3_kernels.h"
 
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
     }
     const float4 wb = prep.wbox[(colbase >> 8) + __builtin_amdgcn_readfirstlane(wave)];  // (NaN: never the shortcut)
     bx0 = wb.x, bx1 = wb.y, by0 = wb.z, by1 = wb.w;
-    fin = true;
+    fin = v;  // (a wavefront with a lane beyond the list never takes the wave shortcut: its wbox entry may be padding)
   } else {
   {
     float raw[T_CPT * 5];
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   }
   }
   const bool all_valid = cvalid[T_CPT - 1];
-  const bool wave_ok = VEC && (PREP || __ballot(fin) == ~0ULL);
+  const bool wave_ok = VEC && __ballot(fin) == ~0ULL;
   // survivors: one PRIVATE LDS segment per wave, its fill count in a wave-uniform register -- no LDS atomics,
   // nothing to wait for (a shared queue with one atomicAdd per ballot cost 12 of the kernel's 32 us)
   unsigned short* wq = queue + wave * P_WSEG;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   for (int q = lane; q < cnt; q += 64) slot[q] = wq[q];
 }
 
-template <int GEOM>
+template <int GEOM, bool FAST = false>
 __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __restrict__ b1, int n1,
                                                                const float* __restrict__ b2, int n2, int iof,
                                                                const BoxRec* __restrict__ recsA,
@@ -590,8 +591,11 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __re
   // per CU; the rare pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region.
   // v2 / v3 (hull): 12 of the 24 slots, redo with 24 by lanes 0..31 likewise => 24.5 KB instead of 49 KB per workgroup
   // (the 49 KB form ran at occupancy 3: that was the 41 us v3 drain)
+  // Round 5, v1 (FAST): the straight-line clip of r3_clip.h -- crossings decided from signs, candidates in registers,
+  // LDS only as the dynamic index (9 slots per lane: 8 candidates + the dump slot); a pair it flags (not in general
+  // position: ~2e-4 of random pairs) is redone by lanes 0..31 with the exact 16-slot form in the same region.
   constexpr bool SHORT = true;
-  constexpr int CAPS = GEOM == 1 ? 8 : 12, CAPF = GEOM == 1 ? R3_V1_CAP : 24;  // short / full slots per lane
+  constexpr int CAPS = GEOM == 1 ? (FAST ? R3_CLIP_SLOTS : 8) : 12, CAPF = GEOM == 1 ? R3_V1_CAP : 24;  // short / full slots per lane
   constexpr int D_PAIRS = P_ROWS * T_COLS;  // a dense tile is enumerated pair by pair
   __shared__ float2 pts[CAPS * T_THREADS];
   __shared__ unsigned pre[P_GROUPS + 1];
@@ -670,7 +674,8 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __re
       // a dense tile's pairs were never tested with exact records: do it here (apart => 0, as in every form)
       if (!(dense && boxes_apart(A.f, B.f))) {
         const LanePts<64> lp{pts + wave * (64 * CAPS) + lane};  // wave-private [slot][lane] region
-        if (GEOM == 1) v = v1_pair_lds<64, CAPS>(A.f, B.f, iof != 0, lp, &over);
+        if constexpr (GEOM == 1 && FAST) v = v1_clip_fast(A.f, B.f, iof != 0, ClipLds<64>{pts + wave * (64 * CAPS) + lane}, over);
+        else if constexpr (GEOM == 1) v = v1_pair_lds<64, CAPS>(A.f, B.f, iof != 0, lp, &over);
         else v = hull_pair_lds<GEOM == 2, 64, CAPS>(A.f, B.f, iof == 0, lp, &over);
       }
       if (!over) out[(size_t)r * n2 + c] = v;
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(256) void assign_init_kernel(u64k* __restrict__ row
   }
 }
 
-template <int GEOM>
+template <int GEOM, bool FAST = false>
 __global__ __launch_bounds__(T_THREADS) void assign_drain_kernel(const BoxRec* __restrict__ recsA,
                                                                  const BoxRec* __restrict__ recsB, int n2,
                                                                  const unsigned* __restrict__ gqueue,
@@ -736,8 +741,10 @@ __global__ __launch_bounds__(T_THREADS) void assign_drain_kernel(const BoxRec* _
                                                                  u64k* __restrict__ colkey, int n1_lds) {
   // v1: the 8-slot clip of the IoU drain (wave-private [slot][lane] regions, 16 KB per workgroup instead of 32: twice
   // the resident waves; a pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region)
+  // Round 5 (FAST): the straight-line clip (r3_clip.h), 9 slots per lane; flagged pairs take the same redo
   constexpr bool SHORT = GEOM == 1;
-  __shared__ float2 pts[SHORT ? 8 * T_THREADS : pts_slots<GEOM>() * T_THREADS];
+  constexpr int CAPS = FAST ? R3_CLIP_SLOTS : 8;
+  __shared__ float2 pts[SHORT ? CAPS * T_THREADS : pts_slots<GEOM>() * T_THREADS];
   extern __shared__ __attribute__((aligned(16))) u64k rowbest[];  // n1_lds entries (0 = none): per-workgroup row maxima
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned total = *counter;
@@ -769,8 +776,10 @@ __global__ __launch_bounds__(T_THREADS) void assign_drain_kernel(const BoxRec* _
       const BoxRec A = recsA[r];
       const BoxRec B = recsB[c];
       float v;
-      if (SHORT) {
-        const LanePts<64> lp8{pts + wave * 512 + lane};
+      if constexpr (SHORT && FAST) {
+        v = v1_clip_fast(A.f, B.f, false, ClipLds<64>{pts + wave * (64 * CAPS) + lane}, over);
+      } else if constexpr (SHORT) {
+        const LanePts<64> lp8{pts + wave * (64 * CAPS) + lane};
         v = v1_pair_lds<64, 8>(A.f, B.f, false, lp8, &over);
       } else {
         const LanePts<T_THREADS> lp{pts + threadIdx.x};
@@ -791,7 +800,7 @@ __global__ __launch_bounds__(T_THREADS) void assign_drain_kernel(const BoxRec* _
         if (lane < 32 && src >= 0) {
           const BoxRec A = recsA[rr];
           const BoxRec B = recsB[cc];
-          const LanePts<32> lp16{pts + wave * 512 + lane};
+          const LanePts<32> lp16{pts + wave * (64 * CAPS) + lane};
           record(qq, rr, cc, v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, false, lp16));
         }
         for (int k = 0; k < 32 && m; k++) m &= m - 1;
@@ -960,8 +969,12 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   else
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
                        L.tcount, L.slots, wcap, P);
-  hipLaunchKernelGGL(iou_drain3_kernel<GEOM>, dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
-                     L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr);
+  if (GEOM == 1 && g_r3_clip_impl == 0)
+    hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM == 1>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
+                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr);
+  else
+    hipLaunchKernelGGL((iou_drain3_kernel<GEOM, false>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
+                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr);
   return 0;
 }
 
@@ -1094,9 +1107,14 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
   // columns: 243 us instead of 55 -- a few hundred addresses take every pair's update.)
   const int n1_lds = n1 < 2048 ? n1 : 2048;
   const int dmax = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : 2048;  // (measured: 512 -> 62 us, 1024 -> 58, 1536 -> 55, 2048 -> 53)
-  hipLaunchKernelGGL(assign_drain_kernel<GEOM>, dim3(blocks < dmax ? blocks : dmax), dim3(T_THREADS),
-                     (size_t)n1_lds * sizeof(u64k), stream, L.recsA, recsB, n2, L.gqueue, L.counter, L.qiou, L.rowkey,
-                     L.colkey, n1_lds);
+  if (GEOM == 1 && g_r3_clip_impl == 0)
+    hipLaunchKernelGGL((assign_drain_kernel<GEOM, GEOM == 1>), dim3(blocks < dmax ? blocks : dmax), dim3(T_THREADS),
+                       (size_t)n1_lds * sizeof(u64k), stream, L.recsA, recsB, n2, L.gqueue, L.counter, L.qiou, L.rowkey,
+                       L.colkey, n1_lds);
+  else
+    hipLaunchKernelGGL((assign_drain_kernel<GEOM, false>), dim3(blocks < dmax ? blocks : dmax), dim3(T_THREADS),
+                       (size_t)n1_lds * sizeof(u64k), stream, L.recsA, recsB, n2, L.gqueue, L.counter, L.qiou, L.rowkey,
+                       L.colkey, n1_lds);
   if (match_low)
     hipLaunchKernelGGL(assign_lowq_kernel, dim3(blocks), dim3(256), 0, stream, L.gqueue, L.counter, L.qiou, n2,
                        L.rowkey, min_pos_iou, assign_all, L.lowq);

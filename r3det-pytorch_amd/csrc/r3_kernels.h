@@ -187,6 +187,7 @@ extern int g_r3_fr_walk;   // strip height of the tile-pair walk (0: row-major)
 extern unsigned long long g_r3_frn_stamps;
 extern int g_r3_frb_impl;  // 0 auto; 1 general index form always; 2 unpaired gather
 extern int g_r3_iou_impl;  // 0 auto, 1 one thread per pair, 2 one-launch compact kernel, 4 prep + stream + drain pipeline always
+extern int g_r3_clip_impl; // v1 pair clip of the drains: 0 straight-line form (r3_clip.h), 1 the LDS-list form (r3_geom_lds.h, rounds 2-4)
 extern int g_r3_iou_dwgs;  // 0 default (2048); > 0: workgroups of the IoU drain kernel (tuning)
 extern int g_r3_iou_qcap;  // 0 default; > 0 caps the IoU pipeline's global pair queue (tests the overflow path)
 extern int g_r3_iou_small; // 0 default (513); > 0: column count from which the pipeline runs

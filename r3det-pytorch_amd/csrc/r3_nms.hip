@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#include "r3_clip.h"
 #include "r3_geom_lds.h"
 #include "r3_kernels.h"
 
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
   }
 }
 
-template <int GEOM, bool LABEL>
+template <int GEOM, bool LABEL, bool FAST = false>
 __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict__ recs, int n, int cb, float thr,
                                                         const unsigned* __restrict__ gqueue, unsigned qcap,
                                                         unsigned* __restrict__ counter,
@@ -361,8 +362,10 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
   // v1: 8 candidate slots per lane in wave-private [slot][lane] regions (half the LDS of the reference's 16 slots:
   // twice the resident waves; one clip is ~15 us of latency, so an image's pairs should take ONE trip); the rare
   // pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region (as in the IoU drain)
+  // Round 5 (FAST): the straight-line clip (r3_clip.h), 9 slots per lane; flagged pairs take the same redo
   constexpr bool SHORT = GEOM == 1;
-  __shared__ float2 pts[SHORT ? 8 * 256 : pts_slots<GEOM>() * 256];
+  constexpr int CAPS = FAST ? R3_CLIP_SLOTS : 8;
+  __shared__ float2 pts[SHORT ? CAPS * 256 : pts_slots<GEOM>() * 256];
   __shared__ unsigned pre[Q_NREG + 1];  // exclusive prefix of the regions' (clamped) fills
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (bt.counts) {
@@ -397,8 +400,10 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
       const BoxRec A = recs[i];
       const BoxRec B = recs[j];
       float v;
-      if (SHORT) {
-        const LanePts<64> lp8{pts + wave * 512 + lane};
+      if constexpr (SHORT && FAST) {
+        v = v1_clip_fast(A.f, B.f, false, ClipLds<64>{pts + wave * (64 * CAPS) + lane}, over);
+      } else if constexpr (SHORT) {
+        const LanePts<64> lp8{pts + wave * (64 * CAPS) + lane};
         v = v1_pair_lds<64, 8>(A.f, B.f, false, lp8, &over);
       } else {
         const LanePts<256> lp{pts + threadIdx.x};
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict
         if (lane < 32 && src >= 0) {
           const BoxRec A = recs[ii];
           const BoxRec B = recs[jj];
-          const LanePts<32> lp16{pts + wave * 512 + lane};
+          const LanePts<32> lp16{pts + wave * (64 * CAPS) + lane};
           const float v = v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, false, lp16);
           if (v > thr) {
             mark_pair(mask, sd, ii, jj, cb);
@@ -1421,8 +1426,12 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
   if (hipMemsetAsync(L.mask, 0, zbytes, stream) != hipSuccess) return -2;
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, L.gqueue, L.qcap,
                      L.counter, L.redo, single_problem(n));
-  hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL>), dim3(drain_blocks((size_t)L.qcap * Q_NREG)), dim3(256), 0, stream, L.recs, n, cb,
-                     thr, L.gqueue, L.qcap, L.counter, L.redo, L.mask, L.nz, single_problem(n));
+  if (GEOM == 1 && g_r3_clip_impl == 0)
+    hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, GEOM == 1>), dim3(drain_blocks((size_t)L.qcap * Q_NREG)), dim3(256), 0, stream, L.recs, n, cb,
+                       thr, L.gqueue, L.qcap, L.counter, L.redo, L.mask, L.nz, single_problem(n));
+  else
+    hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, false>), dim3(drain_blocks((size_t)L.qcap * Q_NREG)), dim3(256), 0, stream, L.recs, n, cb,
+                       thr, L.gqueue, L.qcap, L.counter, L.redo, L.mask, L.nz, single_problem(n));
   launch_reduce(1, L.mask, L.nz, n, cb, order, keep_out, count_out, single_problem(n), stream);
   return 0;
 }
@@ -1967,8 +1976,12 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
                      L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16);                  \
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, L.gqueue,      \
                      (unsigned)L.qcap, L.counter, L.redo, bt);                                                    \
-  hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb, iou_thr,      \
-                     L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt)
+  if (GEOM == 1 && g_r3_clip_impl == 0)                                                                            \
+    hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, GEOM == 1>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb,   \
+                       iou_thr, L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt);                  \
+  else                                                                                                             \
+    hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, false>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb,       \
+                       iou_thr, L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt)
   if (geom == 1) { R3_MC(1, false, maxc); }
   else if (geom == 3) { R3_MC(3, false, L.extent); }
   else { R3_MC(2, true, (const float*)nullptr); }

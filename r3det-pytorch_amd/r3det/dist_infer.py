@@ -73,6 +73,8 @@ def gather_detections(packed, counts, dst=0, batch_size=None):
         return [packed], [counts]
     world, rank = dist.get_world_size(), dist.get_rank()
     B = packed.size(0)
+    if packed.dtype != torch.float32:  # the counts ride in the detections' tensor: exact up to 2^24 in fp32 only
+        raise TypeError(f"gather_detections needs fp32 detections, got {packed.dtype}")
     if batch_size is None:
         m = torch.tensor([B], dtype=torch.int64, device=packed.device)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)

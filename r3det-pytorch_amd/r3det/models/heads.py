@@ -155,7 +155,10 @@ class RRetinaHead(nn.Module):
     def _grid_key(self, anchor_list):
         """Names the anchor list for the assigner's prepared columns when it IS the generator's grid (the anchor head;
         the refine head's anchors are the previous stage's boxes: None)."""
-        return ('anchor_grid', tuple(int(a.size(0)) for a in anchor_list[0]), str(anchor_list[0][0].device))
+        # (the level tensors are the generator's cached ones, one set per tuple of feature-map SIZES: their addresses tell
+        # a 64 x 100 grid from a 100 x 64 one, which the per-level counts do not)
+        return ('anchor_grid', id(self.anchor_generator), tuple((int(a.size(0)), int(a.data_ptr())) for a in anchor_list[0]),
+                str(anchor_list[0][0].device))
 
     # ------------------------------------------------------------------ training
     def get_anchors(self, featmap_sizes, img_metas, device):

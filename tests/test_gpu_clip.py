@@ -1,0 +1,101 @@
+"""GPU parity of the round-5 straight-line v1 clip (csrc/r3_clip.h) inside the three drains
+(iou_drain3 / nms_drain / assign_drain): bit-exact against the oracle in twin mode AND identical to the LDS-list form
+of rounds 2-4 (`clip_impl` = 1), on general-position inputs and on inputs where most pairs are flagged and redone
+(integer axis-aligned boxes: shared edges, coincident vertices; duplicates)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import anchor_grid, dota_like_gt, rand_boxes
+from oracle import api as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(params=[0, 1], ids=["straight-line", "lds-list"])
+def clip_impl(request):
+    from r3det import _C
+    _C.set_option("clip_impl", request.param)
+    yield request.param
+    _C.set_option("clip_impl", 0)
+
+
+def integer_boxes(n, seed, span=64, angle=0.0):
+    r = np.random.default_rng(seed)
+    return np.stack([r.integers(0, span, n), r.integers(0, span, n), r.integers(1, 32, n), r.integers(1, 32, n),
+                     np.full(n, angle)], 1).astype(np.float32)
+
+
+def families():
+    a = rand_boxes(300, 3, span=150.0)
+    dup = np.concatenate([a, a[:100], a[:50] + np.float32(1e-3)]).astype(np.float32)
+    return [
+        ("dense random", rand_boxes(257, 1, span=200.0, amin=-np.pi, amax=np.pi), rand_boxes(2051, 2, span=200.0)),
+        ("integer axis-aligned", integer_boxes(200, 4), integer_boxes(1500, 5)),
+        ("integer vs -pi/2", integer_boxes(200, 6), integer_boxes(1500, 7, angle=-np.pi / 2)),
+        ("duplicates", dup[:200], np.concatenate([dup, dup, dup])[:1300]),
+        ("thin and tiny", np.concatenate([rand_boxes(100, 8, span=60.0, lo=0.001, hi=0.05), rand_boxes(100, 9, span=60.0)]),
+         np.concatenate([rand_boxes(700, 10, span=60.0, lo=0.01, hi=40.0), rand_boxes(300, 11, span=60.0, lo=1e-6, hi=1e-3)])),
+    ]
+
+
+@pytest.mark.parametrize("iof", [False, True])
+def test_iou_pipeline_bit_exact(clip_impl, iof):
+    from r3det import _C
+    from r3det.ops import rbbox_iou
+    _C.set_option("iou_impl", 4)  # stream + drain whatever the size
+    try:
+        for name, a, b in families():
+            with O.twin():
+                want = O.iou_mat(O.V1, a, b, iof=iof, threads=8)
+            got = rbbox_iou(dev(a), dev(b), False, iof).cpu().numpy()
+            assert np.array_equal(got, want, equal_nan=True), name
+            assert (want > 0).mean() > 0.01, name
+    finally:
+        _C.set_option("iou_impl", 0)
+
+
+def test_iou_assignment_shape_same_in_both_forms():
+    from r3det import _C
+    from r3det.ops import rbbox_iou
+    anchors, gt = dev(anchor_grid()), dev(dota_like_gt(128, 5))
+    got = rbbox_iou(gt, anchors)
+    _C.set_option("clip_impl", 1)
+    try:
+        old = rbbox_iou(gt, anchors)
+    finally:
+        _C.set_option("clip_impl", 0)
+    assert torch.equal(got, old)
+    assert (got > 0).sum() > 100000
+
+
+@pytest.mark.parametrize("thr", [0.1, 0.5])
+def test_nms_keep_lists(clip_impl, thr):
+    from r3det.ops import rnms
+    for name, a, b in families():
+        boxes = np.concatenate([a, b])
+        scores = np.random.default_rng(len(boxes)).uniform(0.05, 1, len(boxes)).astype(np.float32)
+        dets = np.concatenate([boxes, scores[:, None]], 1)
+        with O.twin():
+            want = O.nms(O.V1, boxes, scores, thr, strict=True, ascending=True)
+        _, keep = rnms(dev(dets), thr)
+        assert np.array_equal(keep.cpu().numpy(), want), name
+
+
+def test_fused_assignment(clip_impl):
+    from r3det.core.bbox.assigners import MaxIoUAssigner
+    asg = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0., ignore_iof_thr=-1,
+                         iou_calculator=dict(type='RBboxOverlaps2D_v1'))
+    for name, a, b in families():
+        gts, boxes = dev(a[:128]), dev(b)
+        fused = asg.assign(boxes, gts, with_gt_stats=True)
+        with O.twin():
+            m = O.iou_mat(O.V1, a[:128], b, threads=8)
+        mo = m.max(0)
+        assert np.array_equal(fused.max_overlaps.cpu().numpy(), mo, equal_nan=True), name
+        gm = m.max(1)
+        assert np.array_equal(fused.gt_max_overlaps.cpu().numpy(), gm, equal_nan=True), name

@@ -9,6 +9,9 @@ dev = torch.device("cuda")
 if os.environ.get("IOU_DWGS"):
     from r3det import _C
     _C.set_option("iou_dwgs", int(os.environ["IOU_DWGS"]))
+if os.environ.get("CLIP_IMPL"):  # A/B: 1 = the LDS-list clip of rounds 2-4
+    from r3det import _C
+    _C.set_option("clip_impl", int(os.environ["CLIP_IMPL"]))
 anchors = syn.anchor_grid(device=dev)
 gt = syn.dota_like_rboxes(128, 5, device=dev)
 a = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1, iou_calculator=dict(type='RBboxOverlaps2D_v1'))
