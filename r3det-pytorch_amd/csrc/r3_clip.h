@@ -48,11 +48,14 @@ struct ClipLds {
     x = v.x;
     y = v.y;
   }
+  // true in every lane when the condition holds in any lane: rare paths are wave-uniform branches
+  __device__ __forceinline__ bool any(bool c) const { return __builtin_amdgcn_ballot_w64(c) != 0; }
 };
 struct ClipHost {  // (the host harness of the tests)
   mutable float px[R3_CLIP_SLOTS], py[R3_CLIP_SLOTS];
   void set(int s, float x, float y) const { px[s] = x, py[s] = y; }
   void get(int s, float& x, float& y) const { x = px[s], y = py[s]; }
+  bool any(bool c) const { return c; }
 };
 
 // A, B: v1 records (r3_geom.h): f[0..7] the vertices (x0, y0, .., x3, y3), f[8] = w * h.
@@ -114,38 +117,59 @@ __host__ __device__ __forceinline__ float v1_clip_fast(const float* __restrict__
       nmin = fminf(nmin, fminf(fabsf(ns[i][j]), fabsf(nt[i][j])));
     }
   }
-  // general position: every numerator beyond 3.5 x the rounding bound, the scale itself sane (no overflow /
-  // underflow of the products; NaN / Inf anywhere fails one of the comparisons)
+  // general position: every numerator beyond 3.5 x the rounding bound (`unc` otherwise).  Flagged outright: a scale
+  // that is not sane (overflow / underflow of the products) and NaN / Inf (fmaxf / fminf drop NaN operands, so a sum
+  // of all coordinates times zero carries them).
+  bool unc;
   {
-    // (fmaxf / fminf drop NaN operands: a sum of all coordinates, times zero, carries NaN / Inf into the limit)
     float z = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; i++) z += (ax[i] + ay[i]) + (bx[i] + by[i]);
     const float big = fmaxf(cmax, emax);
-    const float lim = 1.8e-6f * big * emax + z * 0.f;  // 3.5 * 8.2 * 2^-24 = 1.71e-6
-    bad = bad | !(nmin > lim) | !(big < 1.0e15f) | !(emax > 1.0e-12f);
+    const float lim = 1.8e-6f * big * emax;  // 3.5 * 8.2 * 2^-24 = 1.71e-6
+    unc = !(nmin > lim);
+    bad = bad | !(z * 0.f == 0.f) | !(big < 1.0e15f) | !(emax > 1.0e-12f);
   }
-  // ---- crossings, edge-major (rbbox_border_intsec, :177-191)
+  // ---- which edge pairs cross (rbbox_border_intsec, :177-191 x LinSeg::InterSectWith, :94-140)
+  bool acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int i1 = (i + 1) & 3;
-    bool acc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int j1 = (j + 1) & 3;
-      // opposite signs (none of them is zero here, or the pair is flagged)
-      const bool so = (ns[i][j] < 0.f) != (ns[i1][j] < 0.f);
-      const bool to = (nt[i][j] < 0.f) != (nt[i][j1] < 0.f);
-      acc[j] = so & to;
+      // opposite signs <=> the reference's 0 <= s < 1 (and t), in general position
+      const bool so = (ns[i][j] < 0.f) != (ns[(i + 1) & 3][j] < 0.f);
+      const bool to = (nt[i][j] < 0.f) != (nt[i][(j + 1) & 3] < 0.f);
+      acc[i][j] = so & to;
     }
-    const int na = (int)acc[0] + (int)acc[1] + (int)acc[2] + (int)acc[3];
+  }
+  // A numerator too small to trust its sign (~4e-4 of overlapping pairs, 2-3 % of wavefronts): the reference's own
+  // tests, with its divisions, for every edge pair of the wavefront's pairs (for the lanes in general position they
+  // give the sign rule's answer).  What stays flagged is what makes the reference leave its main branch: coincident
+  // vertices (C == 0, :99-103) and parallel collinear edges (D == 0 and cross(A, C) == 0, :118-139).
+  if (st.any(unc)) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float Cx = ax[i] - bx[j], Cy = ay[i] - by[j];
+        const float D = -(Ax[i] * By[j] - Bx[j] * Ay[i]);
+        const float s = ns[i][j] / D, t = nt[i][j] / D;
+        acc[i][j] = (D != 0.f) & (0.f <= s) & (s < 1.f) & (0.f <= t) & (t < 1.f);
+        bad = bad | ((Cx == 0.f) & (Cy == 0.f)) | ((D == 0.f) & (nt[i][j] == 0.f));
+      }
+    }
+  }
+  // ---- crossings, edge-major: the (at most two) accepted edge pairs of every edge of box 1
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int na = (int)acc[i][0] + (int)acc[i][1] + (int)acc[i][2] + (int)acc[i][3];
     bad = bad | (na > 2);
     // first / second accepted j
-    const bool f0 = acc[0], f1 = !acc[0] & acc[1], f2 = !acc[0] & !acc[1] & acc[2];
+    const bool f0 = acc[i][0], f1 = !acc[i][0] & acc[i][1], f2 = !acc[i][0] & !acc[i][1] & acc[i][2];
     const float n0 = f0 ? ns[i][0] : f1 ? ns[i][1] : f2 ? ns[i][2] : ns[i][3];
     const float bx0 = f0 ? Bx[0] : f1 ? Bx[1] : f2 ? Bx[2] : Bx[3];
     const float by0 = f0 ? By[0] : f1 ? By[1] : f2 ? By[2] : By[3];
-    const bool s1 = acc[0] & acc[1], s2 = (acc[0] | acc[1]) & acc[2] & !s1;
+    const bool s1 = acc[i][0] & acc[i][1], s2 = (acc[i][0] | acc[i][1]) & acc[i][2] & !s1;
     const float n1 = s1 ? ns[i][1] : s2 ? ns[i][2] : ns[i][3];
     const float bx1 = s1 ? Bx[1] : s2 ? Bx[2] : Bx[3];
     const float by1 = s1 ? By[1] : s2 ? By[2] : By[3];
@@ -165,7 +189,6 @@ __host__ __device__ __forceinline__ float v1_clip_fast(const float* __restrict__
     }
   }
   bad = bad | (cnt > 8);
-  redo = bad;
   // ---- area (:193-228) on registers
   float ux[8], uy[8];
 #pragma unroll
@@ -173,6 +196,7 @@ __host__ __device__ __forceinline__ float v1_clip_fast(const float* __restrict__
   const float numthres = (float)1e-2;
   float dx[8], dy[8];
   bool kept[8];
+  int before[8];  // kept points in front of point i in candidate order (the origin, slot 0, not counted)
   kept[0] = true;
   dx[0] = dy[0] = 0.f;
   int n = 1;
@@ -186,29 +210,34 @@ __host__ __device__ __forceinline__ float v1_clip_fast(const float* __restrict__
       clean = clean & !(kept[j] & (fabsf(fx) < numthres) & (fabsf(fy) < numthres));
     }
     kept[i] = clean;
+    before[i] = n - 1;
     n += clean ? 1 : 0;
   }
-  // rank of every kept point in the order the stable insertion sort (operator< :74-79 = cross > 0) leaves
-  int rank[8];
+  // Rank of every kept point in the order the stable insertion sort (operator< :74-79 = cross > 0) leaves: point j
+  // (the later key) ends in front of point i < j  <=>  cross(d_j, d_i) > 0  <=>  cross(d_i, d_j) < 0.  Dropped points
+  // take part as (0, 0): their cross products are +-0, never < 0.  The seven counters "moved in front of me - I moved in
+  // front of" share one register, four bits each, biased by 8.
+  float zx[8], zy[8];
 #pragma unroll
-  for (int i = 1; i < 8; i++) rank[i] = 1;
+  for (int i = 1; i < 8; i++) zx[i] = kept[i] ? dx[i] : 0.f, zy[i] = kept[i] ? dy[i] : 0.f;
+  unsigned packed = 0x88888880u;
 #pragma unroll
   for (int i = 1; i < 8; i++) {
 #pragma unroll
     for (int j = i + 1; j < 8; j++) {
-      const float c = dx[i] * dy[j] - dx[j] * dy[i];  // cross(d_i, d_j); cross(d_j, d_i) is exactly -c
-      const bool both = kept[i] & kept[j];
-      const bool jfirst = c < 0.f;  // d_j < d_i: the later key moves in front of d_i
-      rank[i] += (both & jfirst) ? 1 : 0;
-      rank[j] += (both & !jfirst) ? 1 : 0;
+      const float c = zx[i] * zy[j] - zx[j] * zy[i];  // cross(d_i, d_j); cross(d_j, d_i) is exactly -c
+      packed += (c < 0.f) ? (1u << (4 * i)) - (1u << (4 * j)) : 0u;
     }
   }
   unsigned taken = 0;
 #pragma unroll
   for (int i = 1; i < 8; i++) {
-    taken += kept[i] ? (1u << rank[i]) : 0u;  // (a sum: a rank taken twice carries into a wrong pattern or beyond)
-    st.set(kept[i] ? rank[i] : 8, dx[i], dy[i]);
+    const int rank = before[i] + (int)((packed >> (4 * i)) & 15u) - 7;  // 1 + before + (field - 8)
+    taken += kept[i] ? (1u << (rank & 31)) : 0u;  // (a sum: a rank taken twice carries into a wrong pattern or beyond)
+    st.set(kept[i] ? (rank & 7) : 8, dx[i], dy[i]);
   }
+  // (the 21 answers form a total order <=> every rank 1 .. n - 1 is taken once; the insertion sort, which only ever asks
+  // these questions, then produces that order)
   redo = bad | (taken != (1u << n) - 2u);
   float vx[8], vy[8];
 #pragma unroll

@@ -578,13 +578,25 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
 }
 
 template <int GEOM, bool FAST = false>
-__global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __restrict__ b1, int n1,
+__global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(const float* __restrict__ b1, int n1,
                                                                const float* __restrict__ b2, int n2, int iof,
                                                                const BoxRec* __restrict__ recsA,
                                                                const int* __restrict__ tcount,
                                                                const unsigned short* __restrict__ slots, int tiles_x,
                                                                int tiles, float* __restrict__ out,
-                                                               const BoxRec* __restrict__ recsB = nullptr) {
+                                                               const BoxRec* __restrict__ recsB = nullptr,
+                                                               unsigned long long* __restrict__ stamps = nullptr) {
+  // (probes build, tools/iou_drain_stamps.py: wave 0 of every workgroup stamps its phases with the 100 MHz clock)
+#ifdef R3_PROBES
+#define R3_DSTAMP(k)                                                                             \
+  if (stamps && threadIdx.x == 0) {                                                              \
+    __builtin_amdgcn_s_waitcnt(0);                                                               \
+    stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                     \
+  }
+#else
+#define R3_DSTAMP(k)
+#endif
+  R3_DSTAMP(0)
   // One clip takes a wave ~15 us from first load to store (long dependent chains through LDS), the ALUs are idle
   // most of that time, so what counts is how many waves a CU holds.  v1: 8 candidate slots per lane instead of
   // the reference's 16 (wave-private [slot][lane] regions of 4 KB) => 18 KB of LDS per workgroup, 8 workgroups
@@ -636,6 +648,8 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __re
   if (tid == T_THREADS - 1) pre[P_GROUPS] = base;
   __syncthreads();
   const unsigned total = pre[P_GROUPS];
+  R3_DSTAMP(1)
+  int trips = 0;
   for (unsigned qb = blockIdx.x * T_THREADS + wave * 64; qb < total; qb += gridDim.x * T_THREADS) {  // wave-uniform
     const unsigned q = qb + lane;
     bool valid = q < total;
@@ -665,11 +679,13 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __re
       valid = r < (unsigned)n1 && c < (unsigned)n2;  // dense edge tiles enumerate beyond the matrix
     }
     bool over = false;
+    if ((trips & 0xffff) == 0) { R3_DSTAMP(2) }
     if (valid) {
       const BoxRec A = recsA[r];
       BoxRec B;
       if (recsB) B = recsB[c];  // (prepared columns)
       else make_record<GEOM>(b2 + (size_t)c * 5, 0.f, B);
+      if ((trips & 0xffff) == 0) { R3_DSTAMP(3) }
       float v = 0.f;
       // a dense tile's pairs were never tested with exact records: do it here (apart => 0, as in every form)
       if (!(dense && boxes_apart(A.f, B.f))) {
@@ -678,10 +694,14 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __re
         else if constexpr (GEOM == 1) v = v1_pair_lds<64, CAPS>(A.f, B.f, iof != 0, lp, &over);
         else v = hull_pair_lds<GEOM == 2, 64, CAPS>(A.f, B.f, iof == 0, lp, &over);
       }
+      if ((trips & 0xffff) == 0) { R3_DSTAMP(4) }
       if (!over) out[(size_t)r * n2 + c] = v;
     }
+    if ((trips & 0xffff) == 0) { R3_DSTAMP(5) }
+    trips++;
     if (SHORT) {
       unsigned long long m = __ballot(over);
+      if (m) trips += 0x10000;  // (probe: redo passes in the high half)
       while (m) {  // rare: lane k < 32 redoes the k-th flagged pair with the full 16 slots
         int src = -1, seen = 0;
         for (unsigned long long t2 = m; t2; t2 &= t2 - 1) {
@@ -702,6 +722,11 @@ __global__ __launch_bounds__(T_THREADS) void iou_drain3_kernel(const float* __re
       }
     }
   }
+  R3_DSTAMP(6)
+#ifdef R3_PROBES
+  if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)trips;
+#endif
+#undef R3_DSTAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -733,7 +758,7 @@ __global__ __launch_bounds__(256) void assign_init_kernel(u64k* __restrict__ row
 }
 
 template <int GEOM, bool FAST = false>
-__global__ __launch_bounds__(T_THREADS) void assign_drain_kernel(const BoxRec* __restrict__ recsA,
+__global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void assign_drain_kernel(const BoxRec* __restrict__ recsA,
                                                                  const BoxRec* __restrict__ recsB, int n2,
                                                                  const unsigned* __restrict__ gqueue,
                                                                  const unsigned* __restrict__ counter,
@@ -956,7 +981,10 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   const dim3 grid(L.tiles_x, L.tiles_y);
   // drain: enough workgroups to fill the chip at the kernel's occupancy (6 per CU measured best: 1024 -> 33 us, 1536 -> 28, 1792 and more -> 32); grid-stride inside
   int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
-  const int maxb = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : 1536;
+  // (round 5, straight-line clip: 4 waves per SIMD of registers => 4 workgroups per CU are resident; a larger grid's
+  // second wave of workgroups pays the 6 us prefix / lookup / record-load preamble again: 1024 -> 23.4 us of stamps, 1536 -> 26.7)
+  const bool fast = GEOM == 1 && g_r3_clip_impl == 0;
+  const int maxb = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : fast ? 4 * r3_cu_count() : 1536;
   if (blocks > maxb) blocks = maxb;
   ColPrep P = ColPrep();
   if (prepared) colprep_layout(n2, prepared, &P);
@@ -969,12 +997,14 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   else
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
                        L.tcount, L.slots, wcap, P);
+  // (probes build: the stamp buffer named by the frn_stamps_lo / _hi options, shared with the FR gather's probe)
+  unsigned long long* const dstamps = R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps) : nullptr;
   if (GEOM == 1 && g_r3_clip_impl == 0)
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM == 1>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
-                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr);
+                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps);
   else
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, false>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
-                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr);
+                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps);
   return 0;
 }
 
@@ -1106,7 +1136,8 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
   // rows reduced in LDS (16 KB); the rest goes straight to global.  (Look + global atomicMax for the rows as for the
   // columns: 243 us instead of 55 -- a few hundred addresses take every pair's update.)
   const int n1_lds = n1 < 2048 ? n1 : 2048;
-  const int dmax = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : 2048;  // (measured: 512 -> 62 us, 1024 -> 58, 1536 -> 55, 2048 -> 53)
+  // (LDS-list clip, measured: 512 -> 62 us, 1024 -> 58, 1536 -> 55, 2048 -> 53; the straight-line clip holds 4 workgroups per CU)
+  const int dmax = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : (GEOM == 1 && g_r3_clip_impl == 0) ? 4 * r3_cu_count() : 2048;
   if (GEOM == 1 && g_r3_clip_impl == 0)
     hipLaunchKernelGGL((assign_drain_kernel<GEOM, GEOM == 1>), dim3(blocks < dmax ? blocks : dmax), dim3(T_THREADS),
                        (size_t)n1_lds * sizeof(u64k), stream, L.recsA, recsB, n2, L.gqueue, L.counter, L.qiou, L.rowkey,

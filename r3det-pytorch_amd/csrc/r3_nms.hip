@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
 }
 
 template <int GEOM, bool LABEL, bool FAST = false>
-__global__ __launch_bounds__(256) void nms_drain_kernel(const BoxRec* __restrict__ recs, int n, int cb, float thr,
+__global__ __launch_bounds__(256, FAST ? 4 : 1) void nms_drain_kernel(const BoxRec* __restrict__ recs, int n, int cb, float thr,
                                                         const unsigned* __restrict__ gqueue, unsigned qcap,
                                                         unsigned* __restrict__ counter,
                                                         const unsigned* __restrict__ redo,
@@ -1388,9 +1388,11 @@ inline size_t layout(int n, void* ws, Layout* L) {
   return off + 256;
 }
 
-inline int drain_blocks(size_t qcap) {
+// (chip_wgs: what the chip holds at once -- 2048 for the LDS-list clips (16 KB of LDS per workgroup, 8 per CU); the
+// straight-line v1 clip takes 4 waves per SIMD of registers: 4 workgroups per CU)
+inline int drain_blocks(size_t qcap, int chip_wgs = 2048) {
   size_t blocks = (qcap + 255) / 256;
-  return blocks > 2048 ? 2048 : blocks < 1 ? 1 : (int)blocks;  // (v1: 16 KB of LDS per workgroup, 8 per CU)
+  return blocks > (size_t)chip_wgs ? chip_wgs : blocks < 1 ? 1 : (int)blocks;
 }
 
 // greedy reduction of `images` problems (blockIdx.z)
@@ -1427,7 +1429,7 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, L.gqueue, L.qcap,
                      L.counter, L.redo, single_problem(n));
   if (GEOM == 1 && g_r3_clip_impl == 0)
-    hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, GEOM == 1>), dim3(drain_blocks((size_t)L.qcap * Q_NREG)), dim3(256), 0, stream, L.recs, n, cb,
+    hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, GEOM == 1>), dim3(drain_blocks((size_t)L.qcap * Q_NREG, 4 * r3_cu_count())), dim3(256), 0, stream, L.recs, n, cb,
                        thr, L.gqueue, L.qcap, L.counter, L.redo, L.mask, L.nz, single_problem(n));
   else
     hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, false>), dim3(drain_blocks((size_t)L.qcap * Q_NREG)), dim3(256), 0, stream, L.recs, n, cb,
@@ -1964,8 +1966,9 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   // (mask + side tables are adjacent and 256-byte aligned: zeroed by the begin kernel, whose grid is widened so that
   // the fill runs at memory speed)
   const dim3 pgrid((cap + RP_C - 1) / RP_C, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
-  int dblocks = drain_blocks(L.qstride);
-  if (dblocks > 2048 / B) dblocks = 2048 / B > 0 ? 2048 / B : 1;  // B images share the chip
+  const int chip_wgs = (geom == 1 && g_r3_clip_impl == 0) ? 4 * r3_cu_count() : 2048;
+  int dblocks = drain_blocks(L.qstride, chip_wgs);
+  if (dblocks > chip_wgs / B) dblocks = chip_wgs / B > 0 ? chip_wgs / B : 1;  // B images share the chip
   const dim3 dgrid(dblocks, 1, B);
   if (geom == 3)  // (reads the raw counts and clamps them itself: the clamped copy is written by the next kernel)
     hipLaunchKernelGGL(mc_hbb_extent_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, S, counts, cap, L.extent);

@@ -4,7 +4,9 @@
 #   bash tools/clip_ab.sh <out.txt>      (on the GPU box, from the repo root)
 set -u
 R=$(pwd)
-OUT=${1:-$R/gpurun_out/clip_ab.txt}
+OUT=${1:-gpurun_out/clip_ab.txt}
+case $OUT in /*) ;; *) OUT=$R/$OUT ;; esac
+mkdir -p $(dirname $OUT)
 export TMPDIR=/tmp
 cd /tmp
 : > $OUT
