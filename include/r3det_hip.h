@@ -231,6 +231,22 @@ int r3det_mcnms(int nms_type, const float* boxes, int B, int n, int K, const int
                 const float* maxc, int cap, float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out,
                 int64_t* labels_out, int64_t* keep_idx_out, int32_t* counts_out, void* stream);
 
+/* r3det_mcnms with the PADDED result a detector hands on (round 5): what R3Det.simple_test returns per image after
+ * multiclass_nms_rotated goes through rbbox2result (models/detectors/r3det.py:137-143, core/bbox/rtransforms.py:10-25)
+ * or, image-parallel, through one gather of [max_per_img, 7] rows per image.  dets7_out: (B, out_cap, 7)
+ * fp32 = [cx, cy, w, h, theta, score, label], `img_stride` floats from one image to the next (>= out_cap * 7: the
+ * caller may leave room for a row of its own behind every image), rows beyond the kept count ZEROED; counts_out (B)
+ * int32; count_f32_out (may be NULL): the count also as fp32 at count_f32_out[img * count_f32_stride]; overflow_out
+ * (B) int32 (may be NULL): 1 when the image had more than `cap` candidates -- its result is then that of its first
+ * cap candidates and the caller repeats the call with a larger cap.  Nothing here needs the host to look at a count
+ * between r3det_mcnms_select and this call: with a fixed cap both are plain enqueues (stream capture records them).
+ * Same candidate arrays, workspace and orders as r3det_mcnms; rows and values equal its (dets, labels) lists. */
+int r3det_mcnms_padded(int nms_type, const float* boxes, int B, int n, int K, const int32_t* cand_row,
+                       const int32_t* cand_label, const float* cand_score, int32_t* cand_rank, const int32_t* counts,
+                       const float* maxc, int cap, float iou_thr, int out_cap, void* ws, size_t ws_bytes,
+                       float* dets7_out, size_t img_stride, int32_t* counts_out, float* count_f32_out,
+                       size_t count_f32_stride, int32_t* overflow_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Feature refinement (rotated feature-align sampler)
  * ------------------------------------------------------------------------------------- */

@@ -239,6 +239,17 @@ int r3det_mcnms(int nms_type, const float* boxes, int B, int n, int K, const int
                           iou_thr, out_cap, ws, ws_bytes, dets_out, labels_out, keep_idx_out, counts_out, S(stream)));
 }
 
+int r3det_mcnms_padded(int nms_type, const float* boxes, int B, int n, int K, const int32_t* cand_row,
+                       const int32_t* cand_label, const float* cand_score, int32_t* cand_rank, const int32_t* counts,
+                       const float* maxc, int cap, float iou_thr, int out_cap, void* ws, size_t ws_bytes,
+                       float* dets7_out, size_t img_stride, int32_t* counts_out, float* count_f32_out,
+                       size_t count_f32_stride, int32_t* overflow_out, void* stream) {
+  const DeviceGuard guard(stream);
+  const R3kMcPadded pd{img_stride, count_f32_out, count_f32_stride, overflow_out};
+  return rc(r3k_mcnms_run(nms_type, boxes, B, n, K, cand_row, cand_label, cand_score, cand_rank, counts, maxc, cap,
+                          iou_thr, out_cap, ws, ws_bytes, dets7_out, nullptr, nullptr, counts_out, S(stream), &pd));
+}
+
 size_t r3det_batched_rnms_workspace_bytes(int n) { return r3k_batched_rnms_workspace_bytes(n); }
 
 int r3det_batched_rnms(const float* bboxes, const float* scores, const int64_t* inds, int n, float nms_thr, void* ws,

@@ -71,10 +71,18 @@ int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, c
                  float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
                  int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream);
 // geom 1 = v1 (same as above), 3 = obb_batched_nms, 2 = ml_nms_rotated; 2/3 emit score order
+// padded (or null): dets_out is (B, out_cap, 7) = [box, score, label] with img_stride floats between images, rows beyond
+// the count zeroed; the count also as fp32 at count_f32[img * count_f32_stride]; overflow[img] = counts[img] > cap
+struct R3kMcPadded {
+  size_t img_stride;
+  float* count_f32;
+  size_t count_f32_stride;
+  int32_t* overflow;
+};
 int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
                   const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
                   float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
-                  int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream);
+                  int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream, const R3kMcPadded* padded = nullptr);
 
 size_t r3k_fr_workspace_bytes(int N, int H, int W, int points);
 // ws may be null (taps derived per channel plane); with a workspace: tap table + unpack kernel

@@ -1742,16 +1742,58 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
   if (GEOM == 3) dead[img * recs_stride + c] = is_dead;
 }
 
+// Where the finish kernels write.  List form (the reference's return values, bbox_nms_rotated.py:127-131): dets
+// (B, out_cap, 6) = [box, score], labels int64, rows beyond the count untouched.  Padded form (round 5: the buffer the
+// step's exchange sends, core/bbox/rtransforms.py:10-25 rbbox2result's input): cols = 7 = [box, score, label as fp32],
+// `img_stride` floats between images, the rows beyond the count ZEROED, the count also as fp32 at
+// count_f32[img * count_f32_stride] (the row gather_detections appends) and overflow[img] = (the image had more
+// candidates than `cap`: the result is that of its first cap candidates and the caller redoes the step).
+struct McOut {
+  float* dets;
+  int cols;           // 6 | 7
+  size_t img_stride;  // floats
+  int64_t* labels;    // may be null when cols == 7
+  int64_t* keep_idx;  // may be null
+  int32_t* counts;
+  float* count_f32;   // may be null
+  size_t count_f32_stride;
+  int32_t* overflow;  // may be null
+  const int* raw_counts;
+  int cap;
+  int pad;  // zero the rows beyond the count
+};
+
+__device__ __forceinline__ void mc_emit(const McOut& o, int img, int out_cap, int pos, const float* __restrict__ b,
+                                        float score, int label, int cand) {
+  float* d = o.dets + (size_t)img * o.img_stride + (size_t)pos * o.cols;
+  d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
+  d[5] = score;
+  if (o.cols == 7) d[6] = (float)label;
+  if (o.labels) o.labels[(size_t)img * out_cap + pos] = label;
+  if (o.keep_idx) o.keep_idx[(size_t)img * out_cap + pos] = cand;
+}
+
+// one workgroup of an image: the count (both forms), the overflow flag, the zero rows behind the kept ones
+__device__ __forceinline__ void mc_tail(const McOut& o, int img, int out_cap, int total) {
+  const int kept = min(total, out_cap);
+  if (threadIdx.x == 0) {
+    o.counts[img] = kept;
+    if (o.count_f32) o.count_f32[(size_t)img * o.count_f32_stride] = (float)kept;
+    if (o.overflow) o.overflow[img] = o.raw_counts[img] > o.cap ? 1 : 0;
+  }
+  if (o.pad) {
+    float* d = o.dets + (size_t)img * o.img_stride;
+    for (int e = kept * o.cols + (int)threadIdx.x; e < out_cap * o.cols; e += (int)blockDim.x) d[e] = 0.f;
+  }
+}
+
 __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict__ boxes, int n,
                                                          const int* __restrict__ cand_row,
                                                          const int* __restrict__ cand_label,
                                                          const float* __restrict__ cand_score, int cand_stride,
                                                          const int* __restrict__ counts,
                                                          const u64* __restrict__ fbits, size_t fbits_stride, int out_cap,
-                                                         float* __restrict__ dets_out,
-                                                         int64_t* __restrict__ labels_out,
-                                                         int64_t* __restrict__ keep_idx_out,
-                                                         int32_t* __restrict__ counts_out) {
+                                                         const McOut o) {
   // Ascending keep: the reducer left a bit per kept CANDIDATE (fbits).  grid = (chunks of 1024 candidates, images):
   // a workgroup counts the kept candidates in front of its chunk (popcounts of at most 1023 words), then every
   // thread emits its own candidate.  (One workgroup per image that first translated the sorted rows to candidates
@@ -1790,19 +1832,15 @@ __global__ __launch_bounds__(1024) void mc_finish_kernel(const float* __restrict
     base += wsum[0][w];
     tot += wsum[1][w];
   }
-  if (blockIdx.x == 0 && tid == 0) counts_out[img] = min(tot, out_cap);
+  if (blockIdx.x == 0) mc_tail(o, img, out_cap, tot);
   const int i = i0 + tid;
   if (i >= M) return;
   const u64 wbits = fbits[wmine];
   if (!((wbits >> lane) & 1ULL)) return;
   const int pos = base + __popcll(wbits & ((1ULL << lane) - 1ULL));
   if (pos >= out_cap) return;
-  const float* b = boxes + ((size_t)img * n + cand_row[cbase + i]) * 5;
-  float* d = dets_out + ((size_t)img * out_cap + pos) * 6;
-  d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
-  d[5] = cand_score[cbase + i];
-  labels_out[(size_t)img * out_cap + pos] = cand_label[cbase + i];
-  if (keep_idx_out) keep_idx_out[(size_t)img * out_cap + pos] = i;  // candidate index, ascending
+  mc_emit(o, img, out_cap, pos, boxes + ((size_t)img * n + cand_row[cbase + i]) * 5, cand_score[cbase + i],
+          cand_label[cbase + i], i);  // (keep_idx: the candidate index, ascending)
 }
 
 // finish for the score-ordered families (v3 obb_nms, v2 ml_nms_rotated): the keep list already is in
@@ -1816,10 +1854,7 @@ __global__ __launch_bounds__(1024) void mc_finish_score_kernel(const float* __re
                                                                const u64* __restrict__ kbits, size_t kbits_stride,
                                                                size_t rows_stride,
                                                                const uint8_t* __restrict__ dead, int out_cap,
-                                                               float* __restrict__ dets_out,
-                                                               int64_t* __restrict__ labels_out,
-                                                               int64_t* __restrict__ keep_idx_out,
-                                                               int32_t* __restrict__ counts_out) {
+                                                               const McOut o) {
   __shared__ int part[1024];
   const int tid = threadIdx.x;
   const int img = blockIdx.x;
@@ -1848,15 +1883,11 @@ __global__ __launch_bounds__(1024) void mc_finish_score_kernel(const float* __re
   for (int r = lo; r < hi && pos < out_cap; r++) {
     if (!live(r)) continue;
     const int cand = sorted_vals[r];
-    const float* b = boxes + ((size_t)img * n + cand_row[cbase + cand]) * 5;
-    float* d = dets_out + ((size_t)img * out_cap + pos) * 6;
-    d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
-    d[5] = cand_score[cbase + cand];
-    labels_out[(size_t)img * out_cap + pos] = cand_label[cbase + cand];
-    if (keep_idx_out) keep_idx_out[(size_t)img * out_cap + pos] = cand;
+    mc_emit(o, img, out_cap, pos, boxes + ((size_t)img * n + cand_row[cbase + cand]) * 5, cand_score[cbase + cand],
+            cand_label[cbase + cand], cand);
     pos++;
   }
-  if (tid == 1023) counts_out[img] = min(part[1023], out_cap);
+  mc_tail(o, img, out_cap, part[1023]);
 }
 
 struct McLayout {
@@ -1946,12 +1977,16 @@ size_t r3k_mcnms_workspace_bytes(int B, int cap) {
 int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* cand_row, const int* cand_label,
                   const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
                   float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
-                  int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream) {
+                  int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream, const R3kMcPadded* padded) {
   if (geom < 1 || geom > 3) return -1;
   if (B <= 0 || n <= 0 || K <= 0 || cap <= 0 || out_cap <= 0 || cap >= 65536 || !(iou_thr >= 0.f)) return -1;
   if (!boxes || !cand_row || !cand_label || !cand_score || !cand_rank || !counts || !ws || !dets_out ||
-      !labels_out || !counts_out || (geom == 1 && !maxc))
+      (!labels_out && !padded) || !counts_out || (geom == 1 && !maxc))
     return -1;
+  if (padded && padded->img_stride < (size_t)out_cap * 7) return -1;
+  McOut mo{dets_out, padded ? 7 : 6, padded ? padded->img_stride : (size_t)out_cap * 6, labels_out, keep_idx_out,
+           counts_out, padded ? padded->count_f32 : nullptr, padded ? padded->count_f32_stride : 0,
+           padded ? padded->overflow : nullptr, counts, cap, padded ? 1 : 0};
   if (ws_bytes < r3k_mcnms_workspace_bytes(B, cap)) return -3;
   const int S = n * K;
   McLayout L;
@@ -2005,13 +2040,11 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   }
   if (geom == 1)
     hipLaunchKernelGGL(mc_finish_kernel, dim3((cap + 1023) / 1024, B), dim3(1024), 0, stream, boxes, n, cand_row,
-                       cand_label, cand_score, S, counts, L.fbits, cbq, out_cap, dets_out, labels_out, keep_idx_out,
-                       counts_out);
+                       cand_label, cand_score, S, counts, L.fbits, cbq, out_cap, mo);
   else
     hipLaunchKernelGGL(mc_finish_score_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, cand_label,
                        cand_score, S, L.svals, counts, L.kbits, cbq, (size_t)cap,
-                       geom == 3 ? L.dead : (const uint8_t*)nullptr, out_cap, dets_out, labels_out, keep_idx_out,
-                       counts_out);
+                       geom == 3 ? L.dead : (const uint8_t*)nullptr, out_cap, mo);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -2095,7 +2128,7 @@ int r3k_batched_nms(int geom, const float* boxes, const float* scores, const int
   const int cap = (n + 63) / 64 * 64;
   hipLaunchKernelGGL(rnms_begin_kernel, dim3(1), dim3(1024), 0, stream, boxes, inds, n, L.row, L.lab, L.cnt, L.maxc);
   return r3k_mcnms_run(geom, boxes, 1, n, 1, L.row, L.lab, scores, L.rank, L.cnt, L.maxc, cap, thr, n, L.mc,
-                       r3k_mcnms_workspace_bytes(1, cap), dets_out, L.labels_out, keep_out, kept_out, stream);
+                       r3k_mcnms_workspace_bytes(1, cap), dets_out, L.labels_out, keep_out, kept_out, stream, nullptr);
 }
 
 
@@ -2104,7 +2137,7 @@ int r3k_mcnms_v1(const float* boxes, int B, int n, int K, const int* cand_row, c
                  float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
                  int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream) {
   return r3k_mcnms_run(1, boxes, B, n, K, cand_row, cand_label, cand_score, cand_rank, counts, maxc, cap, iou_thr,
-                       out_cap, ws, ws_bytes, dets_out, labels_out, keep_idx_out, counts_out, stream);
+                       out_cap, ws, ws_bytes, dets_out, labels_out, keep_idx_out, counts_out, stream, nullptr);
 }
 
 // greedy reduction of a dense upper-triangle mask (rows in score order); used by poly_nms

@@ -35,6 +35,8 @@ SIGNATURES = {
     "r3det_batched_rnms": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp],
     "r3det_obb_batched_nms": [_vp, _vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp, _vp],
     "r3det_mcnms": [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
+    "r3det_mcnms_padded": [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _sz, _vp, _sz, _vp, _vp, _sz,
+                           _vp, _vp],
     "r3det_polygon_iou": [_vp, _i, _vp, _i, _vp, _vp],
     "r3det_poly_iou_mat": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
     "r3det_nms_poly": [_vp, _vp, _i, _f, _vp, _sz, _vp, _vp, _vp],

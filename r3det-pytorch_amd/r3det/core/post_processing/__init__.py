@@ -1,3 +1,3 @@
-from .bbox_nms_rotated import CapacityHint, multiclass_nms_rotated, multiclass_nms_rotated_batch
+from .bbox_nms_rotated import CapacityHint, PaddedNms, multiclass_nms_rotated, multiclass_nms_rotated_batch
 
-__all__ = ['multiclass_nms_rotated', 'multiclass_nms_rotated_batch', 'CapacityHint']
+__all__ = ['multiclass_nms_rotated', 'multiclass_nms_rotated_batch', 'CapacityHint', 'PaddedNms']

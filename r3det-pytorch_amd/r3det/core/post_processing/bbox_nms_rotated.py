@@ -195,3 +195,105 @@ def multiclass_nms_rotated_batch(multi_bboxes, multi_scores, score_thr, nms, max
         if geom == 2 and max_num <= 0:  # the reference's v2 branch slices [:max_num] whenever kept > max_num (:63-65)
             kept = [max(k + max_num, 0) if max_num < 0 else 0 for k in kept]
     return [(dets[i, :kept[i]], labels[i, :kept[i]]) for i in range(B)]
+
+
+class PaddedNms:
+    """``multiclass_nms_rotated`` for a whole batch with NO host synchronisation (round 5): the result is the padded
+    tensor a detector hands on -- what ``rbbox2result`` (core/bbox/rtransforms.py:10-25, models/detectors/r3det.py:137-143)
+    or the image-parallel gather consumes -- instead of per-image lists whose lengths the host has to read.
+
+    ``out = nms(multi_bboxes (B, n, 5), multi_scores (B, n, C + 1))`` -> ``out`` (B, max_num + 1, 7) fp32: rows
+    [0, max_num) of image i = [cx, cy, w, h, theta, score, label], zero beyond its count; row ``max_num`` =
+    [count, 0, ...] (the layout ``dist_infer.gather_detections`` sends).  ``nms.counts`` (B,) int32 holds the counts,
+    ``nms.overflow`` (B,) int32 is 1 where an image had more candidates than the fixed capacity: its rows are then the
+    result for its first ``cap`` candidates.  Both calls of the pipeline (r3det_mcnms_select, r3det_mcnms_padded) are
+    plain enqueues on the current stream with every buffer allocated up front, so the step can be recorded in a HIP
+    graph.  The caller looks at ``overflow`` when it next touches the host anyway (``check()``: a pinned 4 * B byte
+    copy made behind the step, read one step late) and ``grow()``s + repeats that step in the rare case.
+
+    Rows and values equal ``multiclass_nms_rotated_batch``'s lists (tests/test_gpu_mcnms.py)."""
+
+    def __init__(self, B, n, K, score_thr, nms, max_num, cap, device):
+        version = nms.get('type', 'v1')
+        self.geom = {'v1': 1, 'v2': 2, 'v3': 3}.get(version, 0)
+        if not self.geom or max_num <= 0:
+            raise NotImplementedError("PaddedNms: nms types v1 / v2 / v3 with max_num > 0")
+        self.B, self.n, self.K, self.max_num = B, n, K, int(max_num)
+        self.score_thr, self.iou_thr = float(score_thr), float(_get(nms, 'iou_thr'))
+        self.device = device
+        self._alloc(cap)
+        self.flags_host = torch.zeros(B, dtype=torch.int32).pin_memory()
+        self.flags_event = None
+
+    def _alloc(self, cap):
+        L = _C.lib()
+        B, n, K, dev = self.B, self.n, self.K, self.device
+        self.cap = min(MAX_CAP, max(64, (int(cap) + 63) // 64 * 64))
+        S = n * K
+        with torch.cuda.device(dev):
+            self.sel_bytes = int(L.r3det_mcnms_select_workspace_bytes(B, n))
+            self.ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, self.cap))
+            words = 4 * B * S + 2 * B + B
+            pad = (-words) % 64
+            blob = torch.empty(4 * (words + pad) + self.sel_bytes + self.ws_bytes, dtype=torch.uint8, device=dev)
+        i32 = blob[:4 * words].view(torch.int32)
+        self.cand_row, self.cand_label, self.cand_rank = (i32[k * B * S:(k + 1) * B * S] for k in (0, 1, 2))
+        self.cand_score = i32[3 * B * S:4 * B * S].view(torch.float32)
+        self.counts = i32[4 * B * S:4 * B * S + B]        # detections kept
+        self.cand_counts = i32[4 * B * S + B:4 * B * S + 2 * B]
+        self.maxc = i32[4 * B * S + 2 * B:words].view(torch.float32)
+        self.sel_ws = blob[4 * (words + pad):4 * (words + pad) + self.sel_bytes]
+        self.ws = blob[4 * (words + pad) + self.sel_bytes:]
+        self._blob = blob
+        self.out = torch.zeros((B, self.max_num + 1, 7), dtype=torch.float32, device=dev)
+        self.overflow = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def grow(self, factor=2.0):
+        """A larger candidate capacity (after ``check()`` reported an overflow).  New buffers: a graph that recorded
+        the old ones has to be recorded again."""
+        if self.cap >= MAX_CAP:
+            raise RuntimeError("PaddedNms: more candidates per image than the batched kernels take; use the list form")
+        self._alloc(int(self.cap * factor))
+
+    def __call__(self, multi_bboxes, multi_scores):
+        boxes = _C.need_hip(multi_bboxes, "multi_bboxes")
+        scores = _C.need_hip(multi_scores, "multi_scores")
+        B, n, K = self.B, self.n, self.K
+        if tuple(boxes.shape) != (B, n, 5) or tuple(scores.shape) != (B, n, K + 1):
+            raise RuntimeError(f"PaddedNms was built for boxes {(B, n, 5)} / scores {(B, n, K + 1)}")
+        L = _C.lib()
+        out = self.out
+        _C.check(L.r3det_mcnms_select(_C.ptr(boxes), _C.ptr(scores), B, n, K, self.score_thr, _C.ptr(self.cand_row),
+                                      _C.ptr(self.cand_label), _C.ptr(self.cand_score), _C.ptr(self.cand_rank),
+                                      _C.ptr(self.cand_counts), _C.ptr(self.maxc), _C.ptr(self.sel_ws), self.sel_bytes,
+                                      _C.stream()), "r3det_mcnms_select")
+        rows = self.max_num + 1
+        import ctypes
+        count_row = ctypes.c_void_p(out.data_ptr() + 4 * self.max_num * 7)  # out[0, max_num, 0]
+        _C.check(L.r3det_mcnms_padded(self.geom, _C.ptr(boxes), B, n, K, _C.ptr(self.cand_row), _C.ptr(self.cand_label),
+                                      _C.ptr(self.cand_score), _C.ptr(self.cand_rank), _C.ptr(self.cand_counts),
+                                      _C.ptr(self.maxc), self.cap, self.iou_thr, self.max_num, _C.ptr(self.ws),
+                                      self.ws_bytes, _C.ptr(out), rows * 7, _C.ptr(self.counts), count_row, rows * 7,
+                                      _C.ptr(self.overflow), _C.stream()), "r3det_mcnms_padded")
+        return out
+
+    def post_flags(self):
+        """Behind a step (outside a graph): start the 4 * B byte copy of the overflow flags to pinned memory."""
+        self.flags_host.copy_(self.overflow, non_blocking=True)
+        self.flags_event = torch.cuda.Event()
+        self.flags_event.record()
+
+    def check(self):
+        """True when the step whose flags were last posted overflowed the capacity (waits for THAT copy only -- one
+        step late, it has long arrived)."""
+        if self.flags_event is None:
+            return False
+        self.flags_event.synchronize()
+        self.flags_event = None
+        return bool(self.flags_host.any())
+
+    def lists(self):
+        """The reference's per-image return values from the padded result (reads the counts: a host synchronisation;
+        for tests and for callers that want ``multiclass_nms_rotated``'s lists)."""
+        kept = self.counts.tolist()
+        return [(self.out[i, :k, :6], self.out[i, :k, 6].long()) for i, k in enumerate(kept)]

@@ -97,6 +97,29 @@ def gather_detections(packed, counts, dst=0, batch_size=None):
     return [p[:, :rows] for p in everyone.split(batch_size)], list(allc.split(batch_size))
 
 
+def gather_padded(mine, dst=0):
+    """The step's ONE exchange on the buffer the detector already laid out (``PaddedNms.out`` /
+    ``GraphedStep``): (batch_size, rows + 1, 7) fp32, row ``rows`` of every image = [count, 0, ...] (-1: an image this
+    rank did not have).  No packing pass, no host read; every rank passes the same shape.  Returns the gathered
+    (world * batch_size, rows + 1, 7) tensor on ``dst`` (``split_gathered`` turns it into gather_detections' lists),
+    None elsewhere; single process: ``mine`` itself."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_group()):
+        return mine
+    if mine.dtype != torch.float32:
+        raise TypeError(f"gather_padded needs fp32 detections, got {mine.dtype}")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    everyone = mine.new_empty((world * mine.size(0),) + tuple(mine.shape[1:]))
+    dist.all_gather_into_tensor(everyone, mine)
+    return everyone if rank == dst else None
+
+
+def split_gathered(everyone, batch_size):
+    """gather_padded's tensor -> gather_detections' (list_of_packed, list_of_counts), one entry per rank."""
+    rows = everyone.size(1) - 1
+    allc = everyone[:, rows, 0].to(torch.int32)
+    return [p[:, :rows] for p in everyone.split(batch_size)], list(allc.split(batch_size))
+
+
 def unpack_detections(packed, counts):
     """Inverse of pack_detections for one rank's tensors -> [(dets (k,6), labels (k,))]; entries with count -1 (the
     padding ``gather_detections`` adds behind a short batch) are skipped."""

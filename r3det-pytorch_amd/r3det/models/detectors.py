@@ -225,6 +225,74 @@ class GraphedDense:
                                             hint=self.model.refine_head[-1].nms_hint)
 
 
+class GraphedStep:
+    """The WHOLE inference step of a detector -- network, box decoding, per-level pool, multiclass NMS and the padded
+    result -- captured in ONE HIP graph (round 5; GraphedDense stops in front of the NMS because
+    ``multiclass_nms_rotated_batch`` reads the kept counts on the host).  The NMS is ``PaddedNms`` with a fixed
+    candidate capacity: nothing in the step looks at a count, the result is the (B, max_per_img + 1, 7) buffer
+    ``dist_infer.gather_padded`` sends (rows of [cx, cy, w, h, theta, score, label], the count in the extra row).
+
+    ``step(img)`` replays the graph and returns that buffer; the capacity's overflow flags are copied to pinned memory
+    behind the replay and looked at one step late: the rare step whose pool outgrew the capacity is reported by the
+    NEXT call (``redo`` = True in its return), after the graph has been recorded again with twice the capacity -- the
+    caller repeats the step it had just run.  Reference semantics: models/detectors/r3det.py:112-143."""
+
+    def __init__(self, model, example, cap=None, warmup=3):
+        from ..core.post_processing import PaddedNms
+        self.model = model
+        self.static_in = example.clone(memory_format=torch.preserve_format)
+        cfg = model.test_cfg
+        dev = example.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                boxes, scores = model.dense_test(self.static_in)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        B, n = boxes.shape[:2]
+        K = scores.size(2) - 1
+        if cap is None:  # the warm-up pool's largest image, with room (a host read, once, outside the steps)
+            m = int((scores[..., :-1] > cfg['score_thr']).flatten(1).sum(1).max().item())
+            cap = max(1024, int(m * 1.3))
+        self.nms = PaddedNms(B, n, K, cfg['score_thr'], cfg['nms'], cfg['max_per_img'], cap, dev)
+        self._record()
+
+    def _record(self):
+        dev = self.static_in.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # (the library's one-time attribute calls happen outside the capture)
+            self.nms(*self.model.dense_test(self.static_in))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            boxes, scores = self.model.dense_test(self.static_in)
+            self.static_out = self.nms(boxes.contiguous(), scores.contiguous())
+
+    @torch.no_grad()
+    def step(self, img):
+        """-> (out (B, max_per_img + 1, 7), redo).  ``redo``: the PREVIOUS step overflowed the candidate capacity
+        (its result covered its first ``cap`` candidates only); the graph now has twice the capacity -- run that step
+        again."""
+        redo = self.nms.check()
+        if redo:
+            self.nms.grow()
+            self._record()
+        if img.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(img)
+        self.graph.replay()
+        self.nms.post_flags()
+        return self.static_out, redo
+
+    @torch.no_grad()
+    def simple_test(self, img):
+        """The reference's per-image (dets, labels) lists (reads the counts: one host synchronisation)."""
+        self.step(img)
+        return self.nms.lists()
+
+
 for _c in (R3Det, RRetinaNet):
     if _c.__name__ not in DETECTORS:
         DETECTORS.register_module(module=_c)

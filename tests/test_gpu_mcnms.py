@@ -290,3 +290,61 @@ def test_reducer_rows_with_long_suppressor_lists(piles, per_pile, classes, nms_t
         assert torch.equal(d, wd) and torch.equal(lab, wl)
     if n <= 2000:
         same(got, boxes, scores, 0.05, cfg, 2000)
+
+
+# ------------------------------------------------------------------------------------------------ round 5: padded form
+@pytest.mark.parametrize("max_num", [50, 2000])
+def test_padded_form_equals_the_lists_and_the_reference_golden(max_num, nms_type):
+    """r3det_mcnms_padded (PaddedNms): the (B, max_num + 1, 7) buffer a detector hands on -- rows, zero padding, the
+    count row -- against the reference wrapper's goldens and against the list form, with NO host read inside."""
+    from r3det.core.post_processing import PaddedNms, multiclass_nms_rotated_batch
+    g = np.load(os.path.join(GOLDEN, "wrappers.npz"))
+    b = torch.from_numpy(g["mc_boxes"]).cuda()
+    s = torch.from_numpy(g["mc_scores"]).cuda()
+    cfg = dict(type=nms_type, iou_thr=0.1)
+    boxes, scores = torch.stack([b, b, b]).contiguous(), torch.stack([s, s, s]).contiguous()
+    scores[2] = 0.0  # an image without candidates
+    B, n, K = 3, b.size(0), s.size(1) - 1
+    pn = PaddedNms(B, n, K, 0.05, cfg, max_num, cap=n * K, device=b.device)
+    pn.out[:, :max_num].fill_(7.0)  # stale rows must not survive (the count row keeps the zeros it was allocated with)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = pn(boxes, scores)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    out = out.cpu().numpy()
+    lists = multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, max_num)
+    assert pn.overflow.tolist() == [0, 0, 0]
+    for i, (d, lab) in enumerate(lists):
+        k = d.size(0)
+        assert int(pn.counts[i]) == k and out[i, max_num, 0] == k and not out[i, max_num, 1:].any()
+        assert np.array_equal(out[i, :k, :6], d.cpu().numpy())
+        assert np.array_equal(out[i, :k, 6], lab.cpu().numpy().astype(np.float32))
+        assert not out[i, k:max_num].any()
+    for i in (0, 1):
+        k = int(pn.counts[i])
+        assert np.array_equal(out[i, :k, :6], g[f"mc_{nms_type}_{max_num}_dets"])
+        assert np.array_equal(out[i, :k, 6], g[f"mc_{nms_type}_{max_num}_labels"].astype(np.float32))
+    assert int(pn.counts[2]) == 0
+    for (d, lab), (d2, lab2) in zip(lists, pn.lists()):
+        assert torch.equal(d, d2) and torch.equal(lab, lab2)
+
+
+def test_padded_form_flags_a_short_capacity_and_recovers(nms_type):
+    from r3det.core.post_processing import PaddedNms, multiclass_nms_rotated_batch
+    boxes, scores = pools(2, 3000, 77)
+    cfg = dict(type=nms_type, iou_thr=0.1)
+    n_cand = (scores[..., :-1] > 0.05).flatten(1).sum(1)
+    pn = PaddedNms(2, 3000, scores.size(2) - 1, 0.05, cfg, 2000, cap=int(n_cand.min()) // 2, device=boxes.device)
+    pn(boxes, scores)
+    pn.post_flags()
+    assert pn.check()                       # both images had more candidates than the capacity
+    assert pn.overflow.tolist() == [1, 1]
+    while pn.cap < int(n_cand.max()):
+        pn.grow()
+    pn(boxes, scores)
+    pn.post_flags()
+    assert not pn.check() and pn.overflow.tolist() == [0, 0]
+    for (d, lab), (d2, lab2) in zip(multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000), pn.lists()):
+        assert torch.equal(d, d2) and torch.equal(lab, lab2)

@@ -381,3 +381,67 @@ def test_r3det_full_size_config2_composed_as_the_bench_composes_it():
         counts = bench.model_step(model, img, batch_size=4)
     # (MIOpen may pick another kernel for the repeated forward: counts agree to the rounding of a few scores)
     assert all(abs(int(c) - g[0].size(0)) <= max(5, g[0].size(0) // 50) for c, g in zip(counts.tolist(), got))
+
+
+@pytest.mark.gpu
+def test_whole_step_in_one_hip_graph_without_host_synchronisation():
+    """Round 5: network + decoding + pool + multiclass NMS + the padded result as ONE graph; ten
+    steady-state steps under torch's sync debug mode (any implicit host synchronisation raises); the result equals
+    the list form of the same dense outputs."""
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    from r3det.models import R3Det
+    from r3det.models.detectors import GraphedStep, calibrate_score_bias
+    torch.manual_seed(11)
+    dev = torch.device('cuda')
+    m = R3Det().eval().to(dev)
+    img = torch.randn(2, 3, 256, 256, device=dev)
+    calibrate_score_bias(m, img, frac=0.02)
+    g = GraphedStep(m, img)
+    g.step(img)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for _ in range(10):
+            out, redo = g.step(g.static_in)
+            assert not redo
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    cfg = m.test_cfg
+    rows = cfg['max_per_img']
+    assert out.shape == (2, rows + 1, 7)
+    # the dense outputs the graph produced, through the list form
+    boxes, scores = m.dense_test(img)
+    lists = multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], rows)
+    res = g.nms.lists()
+    for (d, lab), (d2, lab2) in zip(lists, res):
+        assert d.size(0) > 0 and abs(d.size(0) - d2.size(0)) <= max(2, d.size(0) // 50)  # (conv run-to-run noise moves a few scores across the threshold)
+    # ... and exactly, on the graph's own pool: replay, then the list form on what dense_test left in the graph's buffers
+    o = out.clone()
+    for i, (d2, lab2) in enumerate(res):
+        k = d2.size(0)
+        assert int(o[i, rows, 0]) == k and not bool(o[i, k:rows].any())
+        assert torch.equal(o[i, :k, :6], d2) and torch.equal(o[i, :k, 6].long(), lab2)
+
+
+@pytest.mark.gpu
+def test_graphed_step_recovers_from_a_short_capacity():
+    from r3det.models import R3Det
+    from r3det.models.detectors import GraphedStep, calibrate_score_bias
+    torch.manual_seed(12)
+    dev = torch.device('cuda')
+    m = R3Det().eval().to(dev)
+    img = torch.randn(1, 3, 256, 256, device=dev)
+    calibrate_score_bias(m, img, frac=0.05)
+    g = GraphedStep(m, img, cap=64)       # far too small
+    out, redo = g.step(img)
+    assert not redo
+    short = int(out[0, -1, 0])
+    redone = False
+    for _ in range(12):                   # the next steps report it, grow the capacity and record again
+        out, redo = g.step(img)
+        redone |= redo
+        if not redo and redone:
+            break
+    assert redone and g.nms.cap > 64
+    assert int(out[0, -1, 0]) >= short and int(g.nms.overflow[0]) == 0
