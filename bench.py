@@ -64,7 +64,7 @@ def sha16(path):
 
 
 # ------------------------------------------------------------------------------------ inference
-def build_model(device, seed, kind="R3Det", batch=BATCH):
+def build_model(device, seed, kind="R3Det", batch=BATCH, spread=True):
     from r3det.models import R3Det, RRetinaNet
     from r3det.models.detectors import calibrate_score_bias
     torch.manual_seed(seed)
@@ -84,7 +84,9 @@ def build_model(device, seed, kind="R3Det", batch=BATCH):
             for m in getattr(model, "feat_refine_module", []):
                 m.to(memory_format=torch.contiguous_format)
         img = img.contiguous(memory_format=torch.channels_last)
-    calibrate_score_bias(model, img, frac=0.01)  # ~3.3 k NMS candidates / image
+    # ~3.3 k NMS candidates / image; spread: every one of the 15 classes the same share of them (the
+    # DOTA-shaped pool); otherwise ONE common shift, which leaves ~90 % of a random head's candidates in one class
+    calibrate_score_bias(model, img, frac=0.01, per_class=spread)
     return model, img
 
 
@@ -97,6 +99,68 @@ def model_step(model, img, batch_size=None):
     packed, counts = di.pack_detections([r[0] for r in res], [r[1] for r in res], MAX_PER_IMG)
     di.gather_detections(packed, counts, batch_size=img.size(0) if batch_size is None else batch_size)
     return counts
+
+
+class WholeStep:
+    """The timed inference step: R3Det.simple_test as ONE HIP graph (network, decoding, pool, multiclass NMS, padded
+    result: models/detectors.py::GraphedStep) + the step's one exchange on the buffer the graph wrote
+    (dist_infer.gather_padded).  No host synchronisation inside; the capacity's overflow flags are looked at one step
+    late (a step that overflowed is run again, inside the timed region, after the graph was recorded anew)."""
+
+    def __init__(self, model, img):
+        from r3det.models.detectors import GraphedStep
+        self.g = GraphedStep(model, img)
+        self.img = img
+        self.redone = 0
+
+    def __call__(self):
+        from r3det import dist_infer as di
+        out, redo = self.g.step(self.img)
+        if redo:  # the previous step's pool outgrew the capacity: that step again (the graph now has twice the room)
+            self.redone += 1
+            out, _ = self.g.step(self.img)
+        di.gather_padded(out)
+        return out
+
+    def counts(self):
+        return [int(c) for c in self.g.static_out[:, -1, 0].tolist()]
+
+
+def host_results(out, num_classes=15):
+    """What the reference's timed call ends in (tools/analysis_tools/benchmark.py:104-110 -> simple_test ->
+    rbbox2result, models/detectors/r3det.py:137-143, core/bbox/rtransforms.py:10-25): detections to the host, one
+    ndarray per class and image."""
+    from r3det.core.bbox.rtransforms import rbbox2result
+    o = out.cpu()
+    rows = o.size(1) - 1
+    res = []
+    for i in range(o.size(0)):
+        k = int(o[i, rows, 0])
+        res.append(rbbox2result(o[i, :k, :6], o[i, :k, 6].long(), num_classes))
+    return res
+
+
+def device_time_ms(fn, reps=10, lead_ms=4.0):
+    """GPU time of ``fn`` per call with the HOST out of the picture: a spin kernel keeps the stream busy while the
+    host enqueues `reps` calls, so the device runs them back to back; events around them.  (The wall figure of a
+    launch-wait-launch loop next to it says how much of an operator's time is the host's.)"""
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(lead_ms * 2.0e6))  # (~2 GHz cycles)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def spread_stats(samples_s):
+    """median / min / max of wall samples (seconds) in ms."""
+    srt = sorted(samples_s)
+    return {"median": round(srt[len(srt) // 2] * 1e3, 3), "min": round(srt[0] * 1e3, 3), "max": round(srt[-1] * 1e3, 3),
+            "n": len(srt)}
 
 
 # ------------------------------------------------------------------------------------ training
@@ -154,7 +218,25 @@ def train_custom_op_ms(tr, device):
             x.grad = None
         # what FeatureRefineModule runs in training: the five levels as one autograd node (both layouts)
         torch.autograd.backward(feature_refine_levels(xs, boxes, [1.0 / s for s in syn.STRIDES], 1), gs)
-    return timeit(assign, 10) * 1e3, timeit(fr, 10) * 1e3
+    def samples(fn, n=9, reps=5):  # n wall figures of `reps` calls each
+        fn()
+        out = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            out.append((time.perf_counter() - t) / reps)
+        return out
+    sa, sf = samples(assign), samples(fr)
+    detail = {"what": "wall = launch-wait-launch loops of 5 calls, median / min / max of 9; device = GPU time of the same "
+                      "calls with the stream kept busy while the host enqueues them (HIP events): the difference is the "
+                      "host's share",
+              "assign_ms_wall": spread_stats(sa), "assign_ms_device": round(device_time_ms(assign, reps=5), 3),
+              "fr_fwd_bwd_ms_wall": spread_stats(sf), "fr_fwd_bwd_ms_device": round(device_time_ms(fr, reps=5), 3)}
+    train_custom_op_ms.detail = detail
+    return sorted(sa)[len(sa) // 2] * 1e3, sorted(sf)[len(sf) // 2] * 1e3
 
 
 # ------------------------------------------------------------------------------------ custom ops alone
@@ -181,7 +263,7 @@ def build_hot_workload(device, seed):
     n = sum(lv["rows"] for lv in levels)
     return dict(levels=levels, bias=torch.randn(C, device=device, generator=g),
                 pool_boxes=torch.empty(BATCH, n, 5, device=device), pool_scores=torch.empty(BATCH, n, 16, device=device),
-                nms_hint=CapacityHint())
+                nms_hint=CapacityHint(), pnms=None)
 
 
 def hot_path_step(wl):
@@ -197,6 +279,23 @@ def hot_path_step(wl):
     res = multiclass_nms_rotated_batch(wl["pool_boxes"], wl["pool_scores"], SCORE_THR, NMS_CFG, MAX_PER_IMG,
                                        hint=wl["nms_hint"])
     return sum(d.size(0) for d, _ in res)
+
+
+def hot_path_step_sync_free(wl):
+    """The same three calls with the padded NMS result (r3det_mcnms_padded): no host read anywhere."""
+    from r3det.core.post_processing import PaddedNms
+    from r3det.ops import fr_boxes
+    from r3det.ops.feature_refine import fr_module_levels_nhwc
+    L = wl["levels"]
+    fr_module_levels_nhwc([lv["a"] for lv in L], [lv["b"] for lv in L], wl["bias"], wl["bias"], [lv["res"] for lv in L],
+                          [lv["boxes"] for lv in L], [lv["scale"] for lv in L], 1, [lv["out"] for lv in L])
+    fr_boxes.levels_pool([lv["cls"] for lv in L], [lv["reg"] for lv in L], [lv["rois"] for lv in L], 1, 15, 2000,
+                         (IMG, IMG), wl["pool_boxes"], wl["pool_scores"])
+    if wl["pnms"] is None:  # (first call: the capacity from this pool, with room)
+        m = int((wl["pool_scores"][..., :-1] > SCORE_THR).flatten(1).sum(1).max().item())
+        wl["pnms"] = PaddedNms(BATCH, wl["pool_boxes"].size(1), 15, SCORE_THR, NMS_CFG, MAX_PER_IMG, int(m * 1.3),
+                               wl["pool_boxes"].device)
+    return wl["pnms"](wl["pool_boxes"], wl["pool_scores"])
 
 
 def timeit(fn, reps, warm=2):
@@ -598,7 +697,8 @@ def main():
                         final_loss=round(float(loss), 4),
                         custom_ops={"what": "the step's custom ops timed on their own (isolated, same shapes)",
                                     "assign_ms": round(ta, 3), "fr_fwd_bwd_ms": round(tf, 3),
-                                    "share_of_step": round((ta + tf) / ms, 4)})
+                                    "share_of_step": round((ta + tf) / ms, 4),
+                                    "detail": getattr(train_custom_op_ms, "detail", None)})
             print(json.dumps(line))
         if world > 1:
             di.barrier(device)
@@ -655,7 +755,24 @@ def main():
                "ms_per_step": round(dt * 1e3, 3), "img_s": round(BATCH / dt, 1),
                "ms_per_step_mean": round(sum(per) / len(per) * 1e3, 3), "steps": len(per),
                "slowest_step": {"index": worst, "ms": round(per[worst] * 1e3, 3), "device_allocs_in_it": allocs[worst]},
-               "measured": "before the model is built"}
+               "measured": "before the model is built",
+               "ms_per_step_spread": spread_stats(per)}
+        # the same step without the host in it: padded NMS result (no count read), wall and device time
+        hot_path_step_sync_free(wl)
+        sf = []
+        for i in range(3 + 15):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            hot_path_step_sync_free(wl)
+            torch.cuda.synchronize()
+            if i >= 3:
+                sf.append(time.perf_counter() - t)
+        hot["sync_free"] = {"what": "the same calls with r3det_mcnms_padded (PaddedNms): nothing reads a count; wall = one "
+                                    "step, launched and waited for; device = GPU time per step with the stream kept busy "
+                                    "while the host enqueues 10 steps (HIP events) -- what the step costs inside the "
+                                    "whole-step graph",
+                            "ms_per_step_wall": spread_stats(sf),
+                            "ms_per_step_device": round(device_time_ms(lambda: hot_path_step_sync_free(wl)), 3)}
         # the roofline kernel alone, rotating over three buffer sets (3 x 268 MB): every launch reads and
         # writes lines that are NOT in the 256 MiB Infinity Cache -> an HBM figure
         from r3det.ops.feature_refine import fr_module_nhwc
@@ -714,18 +831,27 @@ def main():
 
     phase("infer: build + calibrate")
     model, img = build_model(device, seed=100 + rank)
-    phase("infer: warm-up + timed steps")
-    for _ in range(args.warmup):
-        model_step(model, img)
-    torch.cuda.synchronize()
+    eager = os.environ.get("R3DET_BENCH_EAGER", "0") == "1"
+    phase("infer: capture + warm-up + timed steps")
+    whole = None if eager else WholeStep(model, img)
+    step = (lambda: model_step(model, img)) if eager else whole
+    elapsed, mine, last = timed_region(step, args, device, di)
+    ranks = per_rank_ms(mine, args.steps, device, world)
+    counts = last.tolist() if eager else whole.counts()
+    # ---- beside the headline (rank 0's own clock, a few steps each): the eager step (every launch from Python, the
+    # kept counts read by the host, lists packed again: rounds 1-4's timed step) -- its FR launches carry events: the
+    # in-model duration of the roofline kernel -- and the step followed by what the reference's timed call ends in
+    side = argparse.Namespace(steps=min(args.steps, 10), warmup=2)
     _C.fr_profile_read()                # empty the ring
-    _C.set_option("fr_profile", 2)      # the sampler launches of the timed steps carry a start / stop event
-    args_w = argparse.Namespace(**vars(args))
-    args_w.warmup = 0
-    elapsed, mine, counts = timed_region(lambda: model_step(model, img), args_w, device, di)
+    _C.set_option("fr_profile", 2)      # the sampler launches of these steps carry a start / stop event
+    e_eager, _, _ = timed_region(lambda: model_step(model, img), side, device, di)
     _C.set_option("fr_profile", 0)
     recs = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
-    ranks = per_rank_ms(mine, args.steps, device, world)
+    ms_eager = e_eager / side.steps * 1e3
+    ms_host = None
+    if whole is not None:
+        e_host, _, _ = timed_region(lambda: host_results(whole()), side, device, di)
+        ms_host = e_host / side.steps * 1e3
 
     if rank == 0:
         # Events attached to the launch itself (hipExtLaunchKernelGGL), not stream events around the call:
@@ -779,8 +905,50 @@ def main():
                                                   "what": "the same launch inside the timed model steps: its three "
                                                           "inputs were just written by the convolutions (Infinity "
                                                           "Cache-assisted, not an HBM fraction)"}},
-            "kept_per_image": [int(c) for c in counts.tolist()],
+            "kept_per_image": [int(c) for c in counts],
+            "timed_step": {
+                "what": ("R3Det.simple_test as ONE HIP graph per step (backbone, neck, heads, FRM, decoding, per-level "
+                         "pool, batched multiclass NMS, padded [B, 2000 + 1, 7] result) + the step's one exchange "
+                         "(gather_padded); no host synchronisation inside, detections stay on the device")
+                if not eager else "eager step (R3DET_BENCH_EAGER=1): every launch from Python, kept counts read by the host",
+                "rbbox2result_inside": False,
+                "note": "the reference's timed call (tools/analysis_tools/benchmark.py:104-110) ends in rbbox2result "
+                        "(models/detectors/r3det.py:137-143: detections to the host, per-class numpy lists); "
+                        "ms_per_step_with_host_results is the same step followed by exactly that",
+                "ms_per_step_with_host_results": None if ms_host is None else round(ms_host, 3),
+                "img_s_with_host_results": None if ms_host is None else round(world * BATCH / ms_host * 1e3, 2),
+                "ms_per_step_eager": round(ms_eager, 3),
+                "steps_of_the_side_figures": side.steps,
+                "capacity_redos": 0 if whole is None else whole.redone,
+                "candidate_capacity": None if whole is None else whole.g.nms.cap},
         })
+        if whole is not None and not args.model_only:
+            phase("infer: the two candidate pools")
+
+            def pool_record(ws, ms):
+                boxes, scores = ws.g.model.dense_test(ws.g.static_in)
+                boxes, scores = boxes.contiguous(), scores.contiguous()
+                per_class = (scores[..., :-1] > SCORE_THR).sum((0, 1)).float()
+                nms_ms = device_time_ms(lambda: ws.g.nms(boxes, scores))
+                return {"ms_per_step": round(ms, 3), "img_s": round(BATCH / ms * 1e3, 2),
+                        "candidates_per_image": int(per_class.sum().item() / BATCH),
+                        "largest_class_share": round(float(per_class.max() / per_class.sum().clamp(min=1)), 3),
+                        "kept_per_image": ws.counts(),
+                        "nms_device_us": round(nms_ms * 1e3, 1)}
+            by_pool = {"what": "the same step on the two calibrations of the random-weight model's score bias; "
+                               "nms_device_us = r3det_mcnms_select + r3det_mcnms_padded on the step's own pool, GPU time "
+                               "with the queue kept full (no host in it)",
+                       "spread_15_classes": dict(pool_record(whole, elapsed / args.steps * 1e3),
+                                                 note="the headline: one bias shift per class, equal shares (SURVEY 8d)")}
+            if world == 1:
+                m1, i1 = build_model(device, seed=100 + rank, spread=False)
+                w1 = WholeStep(m1, i1)
+                e1, _, _ = timed_region(w1, side, device, di)
+                by_pool["one_label"] = dict(pool_record(w1, e1 / side.steps * 1e3),
+                                            note="rounds 1-4's pool: ONE common shift (bounded: "
+                                                 f"{side.steps} steps)")
+                del m1, i1, w1
+            line["by_pool"] = by_pool
         if hot is not None:
             line["hot_path"] = hot
         if ops is not None:
@@ -815,7 +983,8 @@ def main():
                              "final_loss": round(float(loss), 4),
                              "layout": "channels_last" if TRAIN_CHANNELS_LAST else "NCHW",
                              "custom_ops_isolated": {"assign_ms": round(ta, 3), "fr_fwd_bwd_ms": round(tf, 3),
-                                                     "share_of_step": round((ta + tf) / ms3, 4)}}
+                                                     "share_of_step": round((ta + tf) / ms3, 4),
+                                                     "detail": getattr(train_custom_op_ms, "detail", None)}}
             del tr
             torch.cuda.empty_cache()
             # the same step in the other layout (3 steps): channels_last runs the FR sampler + backward on NHWC memory

@@ -15,6 +15,31 @@ int g_r3_iou_dwgs = 0;
 int g_r3_nms_impl = 0;
 int g_r3_nms_qcap = 0;
 
+namespace {
+__global__ __launch_bounds__(256) void r3_zero_kernel(unsigned* __restrict__ p, size_t words, size_t head, size_t quads) {
+  // [0, head) single words up to the first 16-byte boundary, then `quads` uint4, then the tail
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  for (size_t k = i; k < quads; k += stride) q[k] = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t k = i; k < head; k += stride) p[k] = 0u;
+  for (size_t k = head + 4 * quads + i; k < words; k += stride) p[k] = 0u;
+}
+}  // namespace
+
+int r3k_zero_async(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return 0;
+  if (!p || (reinterpret_cast<uintptr_t>(p) & 3) || (bytes & 3)) return -2;
+  const size_t words = bytes / 4;
+  size_t head = ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) / 4;
+  if (head > words) head = words;
+  const size_t quads = (words - head) / 4;
+  size_t blocks = (quads + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(r3_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<unsigned*>(p), words, head, quads);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int r3_cu_count() {
   static int n_cu[R3_MAX_DEVICES] = {};
   int dev = 0;

@@ -2117,8 +2117,7 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
 #undef R3_BWD
   } else {
     if (overwrite) {
-      if (hipMemsetAsync(bottom_grad, 0, (size_t)N * C * H * W * sizeof(float), stream) != hipSuccess)
-        return -2;
+      if (r3k_zero_async(bottom_grad, (size_t)N * C * H * W * sizeof(float), stream) != 0) return -2;
     }
     int HW = H * W;
     int xb = (HW + FR_BLOCK - 1) / FR_BLOCK;

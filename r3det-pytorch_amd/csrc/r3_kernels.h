@@ -19,6 +19,12 @@ struct R3DeviceOnce {
   }
 };
 int r3_cu_count();  // compute units of the current device (r3_api.hip)
+// Zero `bytes` bytes at p (both multiples of 4) with a KERNEL.  Not hipMemsetAsync: a memset node inside a captured HIP
+// graph faulted on replay ("Memory access fault by GPU") whenever an ordinary kernel or copy had been enqueued on the
+// stream in front of the graph launch (round 5, ROCm 7.2: tools/dense_graph_bisect.py -- the graph of the whole dense
+// step replays cleanly up to the refine head, faults with the pre-NMS pool's one memset in it, and is clean again with
+// this kernel in its place).  Returns 0 / -2.
+int r3k_zero_async(void* p, size_t bytes, hipStream_t stream);
 
 // Experiment-only forms -- the A/B kernels of tools/ (launch variants that were measured and not shipped), clock
 // stamps inside kernels -- exist only in a library built with -DR3_PROBES (`make probes`: libr3det_hip_probes.so,

@@ -1425,7 +1425,7 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
   }
   // mask + nz are adjacent: one fill
   size_t zbytes = (size_t)((char*)L.counter - (char*)L.mask);
-  if (hipMemsetAsync(L.mask, 0, zbytes, stream) != hipSuccess) return -2;
+  if (r3k_zero_async(L.mask, zbytes, stream) != 0) return -2;
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, L.gqueue, L.qcap,
                      L.counter, L.redo, single_problem(n));
   if (GEOM == 1 && g_r3_clip_impl == 0)
@@ -2159,7 +2159,7 @@ int r3k_nms(int geom, const float* dets, int det_stride, const int64_t* labels,
             int64_t* keep_out, int32_t* count_out, hipStream_t stream) {
   if (n < 0 || !count_out) return -1;
   if (n == 0) {
-    return hipMemsetAsync(count_out, 0, sizeof(int32_t), stream) == hipSuccess ? 0 : -2;
+    return r3k_zero_async(count_out, sizeof(int32_t), stream);
   }
   if (!dets || !order || !ws || !keep_out) return -1;
   if (ws_bytes < r3k_nms_workspace_bytes(n)) return -3;

@@ -277,7 +277,7 @@ size_t r3k_poly_nms_workspace_bytes(int n) {
 int r3k_poly_nms(const float* dets9, const int64_t* order, int n, float thr, void* ws, size_t ws_bytes,
                  int64_t* keep_out, int32_t* count_out, hipStream_t stream) {
   if (n < 0 || !count_out) return -1;
-  if (n == 0) return hipMemsetAsync(count_out, 0, sizeof(int32_t), stream) == hipSuccess ? 0 : -2;
+  if (n == 0) return r3k_zero_async(count_out, sizeof(int32_t), stream);
   if (!dets9 || !order || !ws || !keep_out) return -1;
   if (ws_bytes < r3k_poly_nms_workspace_bytes(n)) return -3;
   const int cb = (n + 63) / 64;

@@ -647,7 +647,7 @@ int r3k_levels_pool(int nlevels, const float* const* cls, const long long* cls_s
       const int steps = ((V.Lpad >> 2) + PS_T * PS_U - 1) / (PS_T * PS_U);
       if (steps > max_steps) max_steps = steps;
     }
-    if (hipMemsetAsync(p, 0, (size_t)nsel * (hist_bytes + meta_bytes), stream) != hipSuccess) return -2;
+    if (r3k_zero_async(p, (size_t)nsel * (hist_bytes + meta_bytes), stream) != 0) return -2;  // (a kernel, not a memset node: r3_kernels.h)
     hipLaunchKernelGGL(pool_keys_kernel, dim3((unsigned)kblocks, N), dim3(256), 0, stream, P);
     hipLaunchKernelGGL(pool_select_kernel, dim3(N, nsel, max_steps), dim3(PS_T), 0, stream, P, (u64*)nullptr);
   }

@@ -235,7 +235,8 @@ class PaddedNms:
             self.ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, self.cap))
             words = 4 * B * S + 2 * B + B
             pad = (-words) % 64
-            blob = torch.empty(4 * (words + pad) + self.sel_bytes + self.ws_bytes, dtype=torch.uint8, device=dev)
+            sel_room = (self.sel_bytes + 255) // 256 * 256  # (the suppression workspace behind it stays 256-byte aligned)
+            blob = torch.empty(4 * (words + pad) + sel_room + self.ws_bytes, dtype=torch.uint8, device=dev)
         i32 = blob[:4 * words].view(torch.int32)
         self.cand_row, self.cand_label, self.cand_rank = (i32[k * B * S:(k + 1) * B * S] for k in (0, 1, 2))
         self.cand_score = i32[3 * B * S:4 * B * S].view(torch.float32)
@@ -243,7 +244,7 @@ class PaddedNms:
         self.cand_counts = i32[4 * B * S + B:4 * B * S + 2 * B]
         self.maxc = i32[4 * B * S + 2 * B:words].view(torch.float32)
         self.sel_ws = blob[4 * (words + pad):4 * (words + pad) + self.sel_bytes]
-        self.ws = blob[4 * (words + pad) + self.sel_bytes:]
+        self.ws = blob[4 * (words + pad) + sel_room:]
         self._blob = blob
         self.out = torch.zeros((B, self.max_num + 1, 7), dtype=torch.float32, device=dev)
         self.overflow = torch.zeros(B, dtype=torch.int32, device=dev)

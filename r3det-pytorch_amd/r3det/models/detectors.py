@@ -311,10 +311,14 @@ def build_detector(cfg, train_cfg=None, test_cfg=None):
 
 
 @torch.no_grad()
-def calibrate_score_bias(model, img, frac=0.01):
+def calibrate_score_bias(model, img, frac=0.01, per_class=False):
     """Synthetic-weight runs give sigmoid ~ 0.01 < score_thr everywhere, i.e.
     an empty NMS pool.  Shift the last head's classification bias so that `frac` of the
-    (position, class) scores exceed score_thr -- the sparsity of a trained detector."""
+    (position, class) scores exceed score_thr -- the sparsity of a trained detector.
+
+    per_class: one shift PER CLASS, every class the same share of the candidates ("15 labels spread", the
+    DOTA-shaped pool; configs/r3det/r3det_r50_fpn_1x_dota_v1.py:99-104).  One common shift leaves ~90 % of a
+    random-weight model's candidates in a single class -- an artefact of the random head, not of the dataset."""
     head = model.refine_head[-1] if isinstance(model, R3Det) else model.bbox_head
     x = model.extract_feat(img)
     if isinstance(model, R3Det):
@@ -322,9 +326,19 @@ def calibrate_score_bias(model, img, frac=0.01):
         rois = model.bbox_head.filter_bboxes(cls, reg)
         x = model.feat_refine_module[-1](x, rois)
     cls, _ = head(x)
+    thr = model.test_cfg['score_thr']
+    target = torch.log(torch.tensor(thr / (1 - thr)))
+    if per_class:
+        C = head.cls_out_channels
+        A = cls[0].size(1) // C
+        per = [c.reshape(c.size(0), A, C, -1).permute(2, 0, 1, 3).reshape(C, -1) for c in cls]  # channel = a * C + c
+        logits = torch.cat(per, 1).float()                                                       # (C, everything else)
+        k = max(1, int(logits.size(1) * frac))
+        kth = logits.topk(k, dim=1)[0][:, -1]
+        shift = (target.to(kth.device) - kth + 1e-3).to(head.retina_cls.bias.dtype)
+        head.retina_cls.bias.add_(shift.repeat(A))
+        return
     logits = torch.cat([c.flatten() for c in cls])
     k = max(1, int(logits.numel() * frac))
     kth = logits.float().topk(k)[0][-1]
-    thr = model.test_cfg['score_thr']
-    target = torch.log(torch.tensor(thr / (1 - thr)))
     head.retina_cls.bias.add_(float(target - kth) + 1e-3)

@@ -162,3 +162,55 @@ def test_bench_step_gather_and_rank_metadata_world2(tmp_path):
     got = torch.load(out)
     assert got["info"]["rccl_ranks"] == 2 and len(got["ranks"]) == 2
     assert got["elapsed"] * 1e3 / 3 >= max(got["ranks"]) - 1e-3  # (the per-rank times are rounded to 1 us)
+
+
+def _padded_worker(rank, world, port, out_path):
+    for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from r3det import dist_infer as di
+    di.init(backend="gloo")
+    batch, rows = 3, 16
+    # the buffer a detector's padded NMS writes (PaddedNms.out / GraphedStep): rows of 7, then the count row;
+    # rank 1 has only two images of the batch: the third is marked -1
+    mine = torch.zeros(batch, rows + 1, 7)
+    want = {}
+    for i in range(batch if rank == 0 else 2):
+        k = 2 + 3 * i + rank
+        g = torch.Generator().manual_seed(50 * rank + i)
+        d = torch.rand(k, 6, generator=g)
+        lab = torch.randint(0, 15, (k,), generator=g)
+        mine[i, :k, :6], mine[i, :k, 6], mine[i, rows, 0] = d, lab.float(), k
+        want[i] = (d, lab)
+    if rank == 1:
+        mine[2, rows, 0] = -1.0
+    calls = []
+    real_ag, real_ar = dist.all_gather_into_tensor, dist.all_reduce
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append("all_gather_into_tensor"), real_ag(*a, **k))[1]
+    dist.all_reduce = lambda *a, **k: (calls.append("all_reduce"), real_ar(*a, **k))[1]
+    everyone = di.gather_padded(mine, dst=0)
+    dist.all_gather_into_tensor, dist.all_reduce = real_ag, real_ar
+    assert calls == ["all_gather_into_tensor"], calls  # the step's ONE exchange, on the buffer as it is
+    if rank == 0:
+        packed, counts = di.split_gathered(everyone, batch)
+        assert [c.tolist() for c in counts] == [[2, 5, 8], [3, 6, -1]]
+        got0 = di.unpack_detections(packed[0], counts[0])
+        got1 = di.unpack_detections(packed[1], counts[1])
+        assert len(got0) == 3 and len(got1) == 2  # (the image rank 1 did not have is skipped)
+        for i, (d, lab) in enumerate(got0):
+            assert torch.equal(d, want[i][0]) and torch.equal(lab, want[i][1])
+        torch.save(dict(n=[len(got0), len(got1)]), out_path)
+    else:
+        assert everyone is None
+    di.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_padded_world2(tmp_path):
+    """Round 5: the exchange on the padded buffer the whole-step graph writes -- one all_gather_into_tensor, no packing
+    pass, no host read; an image a rank does not have is marked -1 in its count row."""
+    out = str(tmp_path / "padded.pt")
+    mp.spawn(_padded_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert torch.load(out)["n"] == [3, 2]
