@@ -24,6 +24,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The entry points below are the library's WHOLE dynamic symbol table: it is built with -fvisibility=hidden, and this
+ * block gives the declarations default visibility (tests/test_abi.py compares `nm -D` with this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define R3DET_OK 0
 #define R3DET_EINVAL (-1)  /* bad argument (null pointer, negative size, bad enum)      */
@@ -518,7 +523,12 @@ int r3det_bias_act(float* y, const float* bias, const float* residual, long long
  *   ("iou_impl", 0 auto | 1 one thread per pair | 2 one-launch tile kernel | 4 stream + drain always),
  *   ("iou_small", columns from which the pipeline runs), ("iou_qcap", n: per-wave survivor capacity, small values
  *   force the dense-tile path), ("iou_dwgs", drain workgroups), ("nms_impl", 0 | 1 tiles | 2 one reducer workgroup),
- *   ("nms_qcap", n: entries per queue region, small values force the redo-tile path).
+ *   ("nms_qcap", n: entries per queue region, small values force the redo-tile path),
+ *   ("clip_impl", 0 the straight-line v1 pair clip of the drains (round 5, csrc/r3_clip.h) | 1 the LDS-list form of
+ *                 rounds 2-4: same results bit for bit, kept for the A/B in tools/clip_ab.sh).
+ * Thread safety: the switches are process-wide relaxed atomics, each read once per operator call -- a call sees one
+ * consistent value of every switch it reads, whichever thread sets them; a caller that needs "this call with that
+ * setting" still has to order the two itself.
  * Launch variants that were measured and not shipped, and clock stamps inside kernels, exist only in the probes build
  * of the same sources (`make probes`: libr3det_hip_probes.so, -DR3_PROBES; tools/ load it through R3DET_HIP_LIB);
  * the product library reads their option values as 0. */
@@ -533,6 +543,9 @@ int r3det_set_option(const char* name, int value);
  * kernels, their gap included) is the figure that agrees with the profiler's sum. */
 int r3det_fr_profile_read(float* records, int capacity);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -7,13 +7,13 @@
 #include "../../include/r3det_hip.h"
 #include "r3_kernels.h"
 
-int g_r3_iou_impl = 0;
-int g_r3_iou_small = 0;
-int g_r3_clip_impl = 0;
-int g_r3_iou_qcap = 0;
-int g_r3_iou_dwgs = 0;
-int g_r3_nms_impl = 0;
-int g_r3_nms_qcap = 0;
+R3Option g_r3_iou_impl{0};
+R3Option g_r3_iou_small{0};
+R3Option g_r3_clip_impl{0};
+R3Option g_r3_iou_qcap{0};
+R3Option g_r3_iou_dwgs{0};
+R3Option g_r3_nms_impl{0};
+R3Option g_r3_nms_qcap{0};
 
 namespace {
 __global__ __launch_bounds__(256) void r3_zero_kernel(unsigned* __restrict__ p, size_t words, size_t head, size_t quads) {

@@ -30,10 +30,10 @@
 #include "r3_kernels.h"
 #include "r3_trig.h"
 
-int g_r3_fr_impl = 0;
-int g_r3_fr_dbg = 0;  // launch form of the forward kernels (r3_kernels.h r3_fr_dbg)
-int g_r3_fr_walk = 8; // strip height of the tile-pair walk (r3_fr_tap.h pair_walk; 0: row-major)
-int g_r3_fr_profile = 0;  // 1: cell-path launches record their own start / stop events
+R3Option g_r3_fr_impl{0};
+R3Option g_r3_fr_dbg{0};  // launch form of the forward kernels (r3_kernels.h r3_fr_dbg)
+R3Option g_r3_fr_walk{8}; // strip height of the tile-pair walk (r3_fr_tap.h pair_walk; 0: row-major)
+R3Option g_r3_fr_profile{0};  // 1: cell-path launches record their own start / stop events
 
 namespace {
 

@@ -1352,8 +1352,8 @@ inline void allow_big_lds(K kernel, int bytes) {
 
 }  // namespace
 
-int g_r3_frb_impl = 0;
-unsigned long long g_r3_frn_stamps = 0;  // device address of a stamp buffer (probes), 0 = none
+R3Option g_r3_frb_impl{0};
+R3Option64 g_r3_frn_stamps{0};  // device address of a stamp buffer (probes), 0 = none
   // 0 auto; 1: the general index form whatever the shape; 2: unpaired gather (A/B runs, tests)
 
 size_t r3k_frb_workspace_bytes(int N, int H, int W, int points) {
@@ -1447,7 +1447,7 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
 #define R3_ARGS top_grad, L.cellinfo, L.entries, C, H, W, EPI, tiles_x | (g_r3_fr_walk << 20), tpi, (int)T, bottom_grad
 #ifdef R3_PROBES
   {  // (clock stamps, tools/frb_stamps.py: the buffer set through frn_stamps_lo / _hi)
-    unsigned long long* sp = reinterpret_cast<unsigned long long*>(g_r3_frn_stamps);
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(g_r3_frn_stamps.get());
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_frb_stamps), &sp, sizeof(sp), 0, hipMemcpyHostToDevice, stream);
   }
 #endif
@@ -1524,7 +1524,7 @@ inline int frn_launch(const float* top, const FrnLayout& L, int N, int C, int H,
   hipLaunchKernelGGL((frn_gather_kernel<K, CP>), dim3((unsigned)(N * (C / CP))), dim3(FRN_T), lds, stream, top, L.slicehdr,
                      L.sell, L.csr.cellinfo, L.csr.entries, C, H, W, wshift, L.cap, H * W * 4 * points, accum,
                      (R3_HAS_PROBES && g_r3_frb_impl == 4) ? 0 : 1, bottom,  // (probes: frb_impl 4 = no XCD remap)
-                     R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps) : nullptr);
+                     R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps.get()) : nullptr);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

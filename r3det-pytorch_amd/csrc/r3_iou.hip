@@ -35,6 +35,10 @@ __global__ __launch_bounds__(IOU_BLOCK) void iou_mat_kernel(const float* __restr
                                                             const float* __restrict__ b2, int n2,
                                                             int iof, float* __restrict__ out) {
   __shared__ BoxRec rows[IOU_ROWS];
+  // (round 5: the candidate list in LDS, [slot][lane], as everywhere else -- the register form of r3_geom.h took
+  // 416-640 B of scratch per lane here)
+  __shared__ float2 pts[pts_slots<GEOM>() * IOU_BLOCK];
+  const LanePts<IOU_BLOCK> lp{pts + threadIdx.x};
   const int col = blockIdx.x * IOU_BLOCK + threadIdx.x;
   const int row0 = blockIdx.y * IOU_ROWS;
   const int nrows = min(IOU_ROWS, n1 - row0);
@@ -54,10 +58,7 @@ __global__ __launch_bounds__(IOU_BLOCK) void iou_mat_kernel(const float* __restr
     if (circles_apart(A.f[9], A.f[10], A.f[11], mine.f[9], mine.f[10], mine.f[11])) {
       v = 0.f;
     } else {
-      BoxRec a = A;
-      if (GEOM == 1) v = v1_pair_slow(a, mine, iof != 0);
-      else if (GEOM == 2) v = hull_pair_slow<true>(a, mine, iof == 0);
-      else v = hull_pair_slow<false>(a, mine, iof == 0);
+      v = pair_slow_lds<GEOM, IOU_BLOCK>(A.f, mine.f, iof != 0, lp);
     }
     o[(size_t)r * n2] = v;
   }
@@ -1015,7 +1016,7 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
                        L.tcount, L.slots, wcap, P);
   // (probes build: the stamp buffer named by the frn_stamps_lo / _hi options, shared with the FR gather's probe)
-  unsigned long long* const dstamps = R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps) : nullptr;
+  unsigned long long* const dstamps = R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps.get()) : nullptr;
   if (GEOM == 1 && g_r3_clip_impl == 0)
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM == 1>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
                        L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps);

@@ -4,6 +4,30 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
+// The switches of r3det_set_option: process-wide, written by any thread, read (once per call) by whichever thread runs an
+// operator -- relaxed atomics, so that two threads flipping options and calling operators do not race (round 5).
+struct R3Option {
+  std::atomic<int> v;
+  explicit constexpr R3Option(int x) : v(x) {}
+  operator int() const { return v.load(std::memory_order_relaxed); }
+  R3Option& operator=(int x) {
+    v.store(x, std::memory_order_relaxed);
+    return *this;
+  }
+};
+struct R3Option64 {
+  std::atomic<unsigned long long> v;
+  explicit constexpr R3Option64(unsigned long long x) : v(x) {}
+  unsigned long long get() const { return v.load(std::memory_order_relaxed); }
+  operator unsigned long long() const { return v.load(std::memory_order_relaxed); }
+  R3Option64& operator=(unsigned long long x) {
+    v.store(x, std::memory_order_relaxed);
+    return *this;
+  }
+};
+
 // Per-device state.  The dynamic-LDS opt-in (hipFuncSetAttribute) belongs to the CURRENT DEVICE's copy of a kernel and
 // the compute-unit count to the device: a process that drives several GPUs (the reference's ops run under
 // MMDataParallel) needs both per device, not per process.
@@ -187,23 +211,23 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
 
 // profiling ring of the FR cell path (see r3det_fr_profile_read)
 int r3k_fr_profile_read(float* records, int capacity);
-extern int g_r3_fr_profile;
+extern R3Option g_r3_fr_profile;
 
 // A/B knobs (r3det_set_option)
-extern int g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane, 3/4 tap-table, 5/6 persistent
-extern int g_r3_fr_dbg;    // NHWC forward: 0 auto | 8 wide regions | 9 tile pairs; other values: probes builds only
+extern R3Option g_r3_fr_impl;   // 0 auto, 1 generic, 2 lds-plane, 3/4 tap-table, 5/6 persistent
+extern R3Option g_r3_fr_dbg;    // NHWC forward: 0 auto | 8 wide regions | 9 tile pairs; other values: probes builds only
 // (the value a call works with: what the product library does not know reads as 0)
 inline int r3_fr_dbg() {
   const int v = g_r3_fr_dbg;
   return (R3_HAS_PROBES || v == 8 || v == 9) ? v : 0;
 }
-extern int g_r3_fr_walk;   // strip height of the tile-pair walk (0: row-major)
-extern unsigned long long g_r3_frn_stamps;
-extern int g_r3_frb_impl;  // 0 auto; 1 general index form always; 2 unpaired gather
-extern int g_r3_iou_impl;  // 0 auto, 1 one thread per pair, 2 one-launch compact kernel, 4 prep + stream + drain pipeline always
-extern int g_r3_clip_impl; // v1 pair clip of the drains: 0 straight-line form (r3_clip.h), 1 the LDS-list form (r3_geom_lds.h, rounds 2-4)
-extern int g_r3_iou_dwgs;  // 0 default (2048); > 0: workgroups of the IoU drain kernel (tuning)
-extern int g_r3_iou_qcap;  // 0 default; > 0 caps the IoU pipeline's global pair queue (tests the overflow path)
-extern int g_r3_iou_small; // 0 default (513); > 0: column count from which the pipeline runs
-extern int g_r3_nms_impl;  // 0 auto (queue pipeline), 1 tile kernels
-extern int g_r3_nms_qcap;  // 0 default; > 0 caps the global pair queue (tests the overflow path)
+extern R3Option g_r3_fr_walk;   // strip height of the tile-pair walk (0: row-major)
+extern R3Option64 g_r3_frn_stamps;
+extern R3Option g_r3_frb_impl;  // 0 auto; 1 general index form always; 2 unpaired gather
+extern R3Option g_r3_iou_impl;  // 0 auto, 1 one thread per pair, 2 one-launch compact kernel, 4 prep + stream + drain pipeline always
+extern R3Option g_r3_clip_impl; // v1 pair clip of the drains: 0 straight-line form (r3_clip.h), 1 the LDS-list form (r3_geom_lds.h, rounds 2-4)
+extern R3Option g_r3_iou_dwgs;  // 0 default (2048); > 0: workgroups of the IoU drain kernel (tuning)
+extern R3Option g_r3_iou_qcap;  // 0 default; > 0 caps the IoU pipeline's global pair queue (tests the overflow path)
+extern R3Option g_r3_iou_small; // 0 default (513); > 0: column count from which the pipeline runs
+extern R3Option g_r3_nms_impl;  // 0 auto (queue pipeline), 1 tile kernels
+extern R3Option g_r3_nms_qcap;  // 0 default; > 0 caps the global pair queue (tests the overflow path)

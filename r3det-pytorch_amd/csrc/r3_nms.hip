@@ -134,6 +134,9 @@ template <int GEOM, bool LABEL>
 __global__ __launch_bounds__(NT) void nms_mask_kernel(const BoxRec* __restrict__ recs, int n, int cb,
                                                       float thr, u64* __restrict__ mask) {
   __shared__ BoxRec cols[MASK_WAVES][TILE];
+  // (round 5: the candidate list in LDS, [slot][lane] -- the register form of r3_geom.h spilled 416-640 B per lane here)
+  __shared__ float2 pts[pts_slots<GEOM>() * NT];
+  const LanePts<NT> lp{pts + threadIdx.x};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rb = blockIdx.y;
   const int cblk = blockIdx.x * MASK_WAVES + wave;
@@ -159,11 +162,7 @@ __global__ __launch_bounds__(NT) void nms_mask_kernel(const BoxRec* __restrict__
       continue;
     }
     if (shortcut && circles_apart(A.f[9], A.f[10], A.f[11], B.f[9], B.f[10], B.f[11])) continue;
-    BoxRec b = B;
-    float v;
-    if (GEOM == 1) v = v1_pair_slow(A, b, false);
-    else if (GEOM == 2) v = hull_pair_slow<true>(A, b, true);
-    else v = hull_pair_slow<false>(A, b, true);
+    const float v = pair_slow_lds<GEOM, NT>(A.f, B.f, false, lp);
     if (v > thr) t |= 1ULL << i;
   }
   mask[(size_t)row * cb + cblk] = t;

@@ -38,6 +38,17 @@ def test_header_symbols_are_exported(built):
         assert n in names
 
 
+def test_dynamic_symbol_table_is_exactly_the_header(built):
+    """Round 5 (-fvisibility=hidden + csrc/exports.map): `nm -D --defined-only` lists the header's entry points and
+    nothing else -- no C++ launch functions, no option globals (VERDICT r4 weak #11)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", built.LIB_PATH], check=True, stdout=subprocess.PIPE, text=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == declared_symbols()
+
+
 def test_error_strings_and_workspace(built):
     L = built.lib()
     assert L.r3det_error_string(0) == b"ok"

@@ -58,9 +58,11 @@ def test_forward_train_full_size_finite_and_frm_grads_match_generic_backward(mod
     from r3det.models.detectors import parse_losses
     img, gtb, gtl = batch(2, 1024, 128, 11, 'cuda')
     grads = {}
-    for impl in (0, 1):  # 0: automatic (packed backward at 128^2 / 64^2); 1: generic kernels (global atomics)
+    # 0: automatic (packed backward at 128^2 / 64^2); 1: generic kernels (global atomics); 2 = 0 once more: the
+    # run-to-run noise of two identical passes (the convolutions' own atomics), which bounds what a comparison can ask
+    for impl in (0, 1, 2):
         model.zero_grad(set_to_none=True)
-        _C.set_option("fr_impl", impl)
+        _C.set_option("fr_impl", impl % 2)
         try:
             losses = model(img, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
             loss, log_vars = parse_losses(losses)
@@ -82,8 +84,9 @@ def test_forward_train_full_size_finite_and_frm_grads_match_generic_backward(mod
         # failed on that bound in round 4 with nothing but MIOpen between the two passes); a wrong FR gradient is an
         # error of order 1, so the bounds below still separate the two
         d = grads[0][n] - grads[1][n]
-        assert float(d.abs().max()) <= 5e-4 * scale, n
-        assert float(d.norm()) <= 5e-5 * float(grads[1][n].norm()), n
+        noise = grads[0][n] - grads[2][n]
+        assert float(d.abs().max()) <= max(5e-4 * scale, 4 * float(noise.abs().max())), n
+        assert float(d.norm()) <= max(5e-5 * float(grads[1][n].norm()), 4 * float(noise.norm())), n
 
 
 def test_targets_on_device_equal_cpu_path():
