@@ -1315,6 +1315,143 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* 
                               &s_nbig, &s_m, wsum, stamps);
 }
 
+// ---------------------------------------------------------------------------- reduce by a walk in score order (round 5)
+// The dependency-round reducer above pays a workgroup barrier and a pass over its rows per ROUND; on the detector's own
+// pool (boxes decoded from neighbouring positions, iou_thr 0.1: suppression chains of 8-10 links) that was 65 us of the
+// step's 140 us of NMS with 64 workgroups of 1024 threads mostly waiting (profiles/r05_bench_kernel_stats.txt).  Here
+// ONE WAVEFRONT owns a label group of an image (the groups share no suppressor edge -- the drain raises Q_XFLAG
+// otherwise and group 0's wavefront then walks the whole image) and walks its rows in score order, 64 at a time:
+//   * the group's rows are compacted once (ascending = score order) with their position in the group (posmap);
+//   * a block of 64 rows: every lane stages its row's suppressor list (64 B) in LDS and sorts the entries in two --
+//     suppressors in EARLIER blocks are final (one LDS bit test each: any kept => removed), suppressors in the SAME
+//     block become a 64-bit lane mask D;
+//   * the block resolves with ballots alone: a lane is removed once a lane of D is kept, kept once every lane of D is
+//     decided and none kept; the lowest undecided lane always decides, so the loop ends -- whatever the chain depth,
+//     an iteration is a handful of scalar instructions, not a barrier;
+//   * rows with more than EL suppressors also scan their overflow row of the transposed mask.
+// Greedy NMS in score order has ONE answer (row kept <=> no kept suppressor), so the result is the rounds reducer's.
+constexpr int WALK_MAXN = 8192;  // rows per image (LDS: 2 x u16 per row + the kept bits + one block's lists = 37 KB)
+
+__global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restrict__ maskT, u64* __restrict__ side, int cb,
+                                                             const unsigned* __restrict__ counter,
+                                                             u64* __restrict__ kbits, size_t kbits_stride,
+                                                             const int* __restrict__ svals, u64* __restrict__ fbits,
+                                                             Batch bt) {
+  __shared__ u64 Kb[WALK_MAXN / 64];
+  __shared__ unsigned short posmap[WALK_MAXN];
+  __shared__ unsigned short rows_l[WALK_MAXN];
+  __shared__ __attribute__((aligned(16))) uint4 el4[64][4];
+  const int img = blockIdx.z, group = blockIdx.x, lane = threadIdx.x;
+  const int n = bt.counts[img];
+  const bool grouped = gridDim.x > 1 && bt.rlab && counter[img * bt.counter + Q_XFLAG] == 0u;
+  if (!grouped && group != 0) return;
+  if (n <= 0) return;
+  maskT += img * bt.mask;
+  kbits += img * kbits_stride;
+  svals += (size_t)img * bt.rows;
+  if (fbits) fbits += img * kbits_stride;
+  const Side sd = side_tables(side + img * bt.nz, bt.rows);
+  const uint8_t* rlab = grouped ? bt.rlab + (size_t)img * bt.rows : nullptr;
+  const int cbn = (n + TILE - 1) / TILE;
+  for (int w = lane; w < cbn; w += 64) Kb[w] = 0;
+  const u64 below = (1ULL << lane) - 1ULL;
+  // ---- the group's rows, ascending, and each row's position among them
+  int m = 0;
+  if (grouped) {
+    for (int base = 0; base < n; base += 256) {  // (four independent byte loads in flight)
+      unsigned char lb[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = base + u * 64 + lane;
+        lb[u] = r < n ? rlab[r] : (unsigned char)0xff;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = base + u * 64 + lane;
+        const bool mine = r < n && (lb[u] & (RG_GROUPS - 1)) == group;
+        const u64 mk = __ballot(mine);
+        if (mine) {
+          const int k = m + __popcll(mk & below);
+          rows_l[k] = (unsigned short)r;
+          posmap[r] = (unsigned short)k;
+        }
+        m += __popcll(mk);
+      }
+    }
+  } else {
+    m = n;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const unsigned short* el = reinterpret_cast<const unsigned short*>(&el4[lane][0]);
+  for (int t0 = 0; t0 < m; t0 += 64) {
+    const int k = t0 + lane;
+    const bool valid = k < m;
+    const int r = valid ? (grouped ? (int)rows_l[k] : k) : 0;
+    const int firstrow = grouped ? (int)rows_l[t0] : t0;  // suppressors below it are final
+    int c = 0;
+    if (valid) {
+      c = sd.ecnt[r];
+      if (c > 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
+        const int quads = (min(c, EL) + 7) >> 3;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (q < quads) el4[lane][q] = src[q];
+      }
+    }
+    const int cl = min(c, EL);
+    int maxc = cl;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
+    bool rem = false;
+    u64 D = 0;
+    for (int e = 0; e < maxc; e++) {
+      if (e < cl) {
+        const int i = el[e];
+        if (i < firstrow) rem |= (Kb[i >> 6] >> (i & 63)) & 1ULL;
+        else D |= 1ULL << ((grouped ? (int)posmap[i] : i) - t0);
+      }
+    }
+    if (c > EL) {  // the suppressors beyond the list: row r of the transposed mask (bits i < r)
+      const u64* row = maskT + (size_t)r * cb;
+      const int fw = firstrow >> 6;
+      for (int q = 0; q < fw; q++) rem |= (row[q] & Kb[q]) != 0ULL;
+      for (int q = fw; q <= (r >> 6); q++) {
+        u64 w = row[q];
+        while (w) {
+          const int i = q * 64 + __builtin_ctzll(w);
+          w &= w - 1;
+          if (i < firstrow) rem |= (Kb[q] >> (i & 63)) & 1ULL;
+          else if (i < r) D |= 1ULL << ((grouped ? (int)posmap[i] : i) - t0);
+        }
+      }
+    }
+    // ---- the block resolves with ballots
+    u64 und = __ballot(valid && !rem), Kc = 0;
+    while (und) {
+      const bool mineu = (und >> lane) & 1ULL;
+      const u64 nk = __ballot(mineu && !(D & Kc) && !(D & und));
+      const u64 nr = __ballot(mineu && (D & Kc));
+      Kc |= nk;
+      und &= ~(nk | nr);
+    }
+    if ((Kc >> lane) & 1ULL) {
+      atomicOr(&Kb[r >> 6], 1ULL << (r & 63));
+      if (fbits) {
+        const int cand = svals[r];
+        atomicOr(&fbits[cand >> 6], 1ULL << (cand & 63));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int w = lane; w < cbn; w += 64) {
+    const u64 kb = Kb[w];
+    if (kb) atomicOr(&kbits[w], kb);  // (a word holds rows of several label groups)
+  }
+}
+
 // rnms returns keep sorted by original index (rnms_kernel.cu:331-334): mark kept originals,
 // then an ordered compaction by one workgroup.
 __global__ __launch_bounds__(1024) void nms_ascending_kernel(int n, uint8_t* __restrict__ flags,
@@ -2028,6 +2165,11 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     // one reducer workgroup per (image, label group = label mod 16) when the pool is small enough for its LDS; the
     // kernel itself falls back to one workgroup per image when the drain saw an edge between two groups
     const int groups = (cap <= RG_MAXN && g_r3_nms_impl != 2) ? RG_GROUPS : 1;
+    if (cap <= WALK_MAXN && g_r3_nms_impl != 2 && g_r3_nms_impl != 3) {
+      // (round 5) pools of a detection step: one wavefront per (image, label group) walks its rows in score order
+      hipLaunchKernelGGL(nms_reduce_walk_kernel, dim3(RG_GROUPS, 1, B), dim3(64), 0, stream, L.mask, L.nz, L.cb,
+                         L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt);
+    } else {
     const size_t lds = reduce_groups_lds_bytes(cap, L.cb, groups > 1);
     static R3DeviceOnce raised;  // the default cap on dynamic LDS is 64 KB; the opt-in is per device
     if (lds > 64 * 1024 && raised.first())
@@ -2036,6 +2178,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     if (lds > 160 * 1024 - 1024) return -1;  // (cap < 65536: 106 KB at most)
     hipLaunchKernelGGL(nms_reduce_groups_kernel, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
                        L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);
+    }
   }
   if (geom == 1)
     hipLaunchKernelGGL(mc_finish_kernel, dim3((cap + 1023) / 1024, B), dim3(1024), 0, stream, boxes, n, cand_row,

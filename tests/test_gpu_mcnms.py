@@ -348,3 +348,54 @@ def test_padded_form_flags_a_short_capacity_and_recovers(nms_type):
     assert not pn.check() and pn.overflow.tolist() == [0, 0]
     for (d, lab), (d2, lab2) in zip(multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000), pn.lists()):
         assert torch.equal(d, d2) and torch.equal(lab, lab2)
+
+
+# ------------------------------------------------------------------------------------------------ round 5: walk reducer
+@pytest.fixture(params=[0, 3], ids=["walk", "rounds"])
+def reducer(request):
+    """nms_impl 0: one wavefront per (image, label group) walks its rows in score order (nms_reduce_walk_kernel);
+    3: the dependency-round reducer of rounds 2-4.  Greedy NMS has one answer: both must give it."""
+    from r3det import _C
+    _C.set_option("nms_impl", request.param)
+    yield request.param
+    _C.set_option("nms_impl", 0)
+
+
+def test_reducers_on_chains_clusters_and_ragged_batches(reducer, nms_type):
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    cfg = dict(type=nms_type, iou_thr=0.1)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    n, K = 1500, 15
+    boxes = torch.zeros(3, n, 5, device='cuda')
+    scores = torch.zeros(3, n, K + 1, device='cuda')
+    # image 0: per class a line of boxes where box k overlaps only its neighbours, scores falling along the line: the
+    # answer alternates kept / removed, the dependency chain is 100 long (chains across blocks of 64 rows)
+    k = torch.arange(n, device='cuda')
+    cls = k % K
+    pos = k // K
+    boxes[0, :, 0] = 10.0 + 6.0 * pos
+    boxes[0, :, 1] = 50.0 + 40.0 * cls
+    boxes[0, :, 2], boxes[0, :, 3] = 10.0, 20.0
+    scores[0, k, cls] = 0.9 - 0.008 * pos.float() + 0.0004 * cls.float()
+    # image 1: clusters of ~150 near-duplicates (rows with far more than 32 suppressors: the overflow rows of the mask)
+    centre = torch.rand(10, 2, device='cuda', generator=g) * 800 + 100
+    which = torch.randint(0, 10, (n,), device='cuda', generator=g)
+    boxes[1, :, :2] = centre[which] + torch.randn(n, 2, device='cuda', generator=g) * 2.0
+    boxes[1, :, 2] = 60 + torch.rand(n, device='cuda', generator=g) * 5
+    boxes[1, :, 3] = 30 + torch.rand(n, device='cuda', generator=g) * 5
+    boxes[1, :, 4] = -0.3 + torch.rand(n, device='cuda', generator=g) * 0.05
+    scores[1, k, which % K] = 0.1 + 0.8 * torch.rand(n, device='cuda', generator=g)
+    # image 2: a handful of candidates only
+    b2, s2 = pools(1, n, 99)
+    boxes[2], scores[2] = b2[0], s2[0]
+    scores[2, 40:] = 0.0
+    out = multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000)
+    assert out[0][0].size(0) == K * 50 and 10 <= out[1][0].size(0) <= 40
+    same(out, boxes, scores, 0.05, cfg, 2000)
+
+
+def test_reducers_agree_on_random_pools(reducer, nms_type, qcap):
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    boxes, scores = pools(4, 5344, 4242)
+    cfg = dict(type=nms_type, iou_thr=0.1)
+    same(multiclass_nms_rotated_batch(boxes, scores, 0.05, cfg, 2000), boxes, scores, 0.05, cfg, 2000)
