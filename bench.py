@@ -350,11 +350,15 @@ def op_rates(device):
                                    ("iou_v1_512x196416", rbbox_iou, gt512, anchors, 10),
                                    ("iou_v1_128x21824", rbbox_iou, gt, refined, 50),
                                    ("iou_v1_1000x128", rbbox_iou, a, g, 50),
-                                   ("iou_v3_128x196416", obb_overlaps, gt, anchors, 10)):
+                                   ("iou_v3_128x196416", obb_overlaps, gt, anchors, 10),
+                                   ("iou_v3_1000x128", obb_overlaps, a, g, 50)):
         dt = timeit(lambda: fn(b1, b2), reps)
         m, n = b1.size(0), b2.size(0)
+        dev_us = device_time_ms(lambda: fn(b1, b2), reps=10, lead_ms=2.0) * 1e3  # GPU time, the host out of the picture
         out[name] = {"Mpairs_s": round(m * n / dt / 1e6, 1), "us_per_call": round(dt * 1e6, 2),
-                     "alg_bytes": b_iou(m, n), "roofline": _roof(b_iou(m, n), dt)}
+                     "us_per_call_device": round(dev_us, 2),
+                     "alg_bytes": b_iou(m, n), "roofline": _roof(b_iou(m, n), dt),
+                     "roofline_device": _roof(b_iou(m, n), dev_us * 1e-6)}
     for n, fn, tag in ((2000, batched_rnms, "v1"), (5344, batched_rnms, "v1"), (8576, batched_rnms, "v1"),
                        (32768, batched_rnms, "v1"), (8576, obb_batched_nms, "v3")):
         mb, ms = syn.nms_pool(n * 10 // 6 + 64, 77 + n, device=device)

@@ -172,21 +172,49 @@ __device__ __forceinline__ void compact_tile(const int bx, const int by, const f
     // ---------------- phase B: drain the queue, one pair per lane
     const int total = *qc;
     if (tid == 0) qcount[(sub + 1) & 1] = 0;
-    for (int q = tid; q < total; q += T_THREADS) {
-      const unsigned e = queue[q];
+    const int wv = tid >> 6;
+    for (int qb = wv * 64; qb < total; qb += T_THREADS) {  // (wave-uniform trips: the hull form's redo is a wave-level pass)
+      const int q = qb + lane;
+      const bool valid = q < total;
+      const unsigned e = valid ? queue[q] : 0u;
       const int r = e >> CSH;
       const int col = colbase + (int)(e & (unsigned)(COLS - 1));
-      BoxRec Bc;
-      make_record<GEOM>(b2 + (size_t)col * 5, 0.f, Bc);
-      float v;
       if constexpr (GEOM == 1) {  // round 5: the straight-line clip; what it flags takes the exact list form (same region)
-        bool flagged = false;
-        v = v1_clip_fast(rows[rbase + r], Bc.f, iof != 0, ClipLds<T_THREADS>{pts + tid}, flagged);
-        if (flagged) v = pair_slow_lds<GEOM, T_THREADS>(rows[rbase + r], Bc.f, iof != 0, lp);
+        if (valid) {
+          BoxRec Bc;
+          make_record<GEOM>(b2 + (size_t)col * 5, 0.f, Bc);
+          bool flagged = false;
+          float v = v1_clip_fast(rows[rbase + r], Bc.f, iof != 0, ClipLds<T_THREADS>{pts + tid}, flagged);
+          if (flagged) v = pair_slow_lds<GEOM, T_THREADS>(rows[rbase + r], Bc.f, iof != 0, lp);
+          out[(size_t)(row0 + rbase + r) * n2 + col] = v;
+        }
       } else {
-        v = pair_slow_lds<GEOM, T_THREADS>(rows[rbase + r], Bc.f, iof != 0, lp);
+        // hull: 12 of the 24 slots in the wave's private region; a pair with a 13th point is redone by lanes 0..31
+        // with 24 slots in the same region (round 5: 49 KB -> 24.5 KB of LDS per workgroup)
+        bool over = false;
+        if (valid) {
+          BoxRec Bc;
+          make_record<GEOM>(b2 + (size_t)col * 5, 0.f, Bc);
+          const float v = hull_pair_lds<GEOM == 2, 64, 12>(rows[rbase + r], Bc.f, iof == 0, LanePts<64>{pts + wv * (64 * 12) + lane}, &over);
+          if (!over) out[(size_t)(row0 + rbase + r) * n2 + col] = v;
+        }
+        unsigned long long m = __ballot(over);
+        while (m) {
+          int src = -1, seen = 0;
+          for (unsigned long long t2 = m; t2; t2 &= t2 - 1) {
+            if (seen == lane) src = __builtin_ctzll(t2);
+            seen++;
+          }
+          const int rr = __shfl(r, src < 0 ? 0 : src), cc = __shfl(col, src < 0 ? 0 : src);
+          if (lane < 32 && src >= 0) {
+            BoxRec Bc;
+            make_record<GEOM>(b2 + (size_t)cc * 5, 0.f, Bc);
+            out[(size_t)(row0 + rbase + rr) * n2 + cc] =
+                hull_pair_lds<GEOM == 2, 32, 24>(rows[rbase + rr], Bc.f, iof == 0, LanePts<32>{pts + wv * (64 * 12) + lane});
+          }
+          for (int k = 0; k < 32 && m; k++) m &= m - 1;
+        }
       }
-      out[(size_t)(row0 + rbase + r) * n2 + col] = v;
     }
     __syncthreads();
   }
@@ -199,7 +227,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float*
   __shared__ __attribute__((aligned(16))) float rows[ROWS][R3_REC];
   __shared__ unsigned short queue[T_SUB * T_THREADS * CPT];
   __shared__ int qcount[2];
-  __shared__ float2 pts[pts_slots<GEOM>() * T_THREADS];
+  __shared__ float2 pts[(GEOM == 1 ? R3_V1_CAP : 12) * T_THREADS];
   compact_tile<GEOM, VEC, CPT, ROWS, T_SUB>(blockIdx.x, blockIdx.y, b1, n1, b2, n2, iof, out, rows, queue, qcount, pts);
 }
 
@@ -777,9 +805,10 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void assign_drain_kernel(c
   // v1: the 8-slot clip of the IoU drain (wave-private [slot][lane] regions, 16 KB per workgroup instead of 32: twice
   // the resident waves; a pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region)
   // Round 5 (FAST): the straight-line clip (r3_clip.h), 9 slots per lane; flagged pairs take the same redo
-  constexpr bool SHORT = GEOM == 1;
-  constexpr int CAPS = FAST ? R3_CLIP_SLOTS : 8;
-  __shared__ float2 pts[SHORT ? CAPS * T_THREADS : pts_slots<GEOM>() * T_THREADS];
+  // v2 / v3 (hull): 12 of the 24 slots per lane with the same redo (round 5: 49 KB -> 24.5 KB of LDS, occupancy 3 -> 5+)
+  constexpr bool SHORT = true;
+  constexpr int CAPS = GEOM == 1 ? (FAST ? R3_CLIP_SLOTS : 8) : 12;
+  __shared__ float2 pts[CAPS * T_THREADS];
   extern __shared__ __attribute__((aligned(16))) u64k rowbest[];  // n1_lds entries (0 = none): per-workgroup row maxima
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned total = *counter;
@@ -811,14 +840,14 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void assign_drain_kernel(c
       const BoxRec A = recsA[r];
       const BoxRec B = recsB[c];
       float v;
-      if constexpr (SHORT && FAST) {
+      if constexpr (GEOM == 1 && FAST) {
         v = v1_clip_fast(A.f, B.f, false, ClipLds<64>{pts + wave * (64 * CAPS) + lane}, over);
-      } else if constexpr (SHORT) {
+      } else if constexpr (GEOM == 1) {
         const LanePts<64> lp8{pts + wave * (64 * CAPS) + lane};
         v = v1_pair_lds<64, 8>(A.f, B.f, false, lp8, &over);
       } else {
-        const LanePts<T_THREADS> lp{pts + threadIdx.x};
-        v = pair_slow_lds<GEOM, T_THREADS>(A.f, B.f, false, lp);
+        const LanePts<64> lp12{pts + wave * (64 * CAPS) + lane};
+        v = hull_pair_lds<GEOM == 2, 64, 12>(A.f, B.f, true, lp12, &over);
       }
       if (!over) record(q, r, c, v);
     }
@@ -835,8 +864,9 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void assign_drain_kernel(c
         if (lane < 32 && src >= 0) {
           const BoxRec A = recsA[rr];
           const BoxRec B = recsB[cc];
-          const LanePts<32> lp16{pts + wave * (64 * CAPS) + lane};
-          record(qq, rr, cc, v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, false, lp16));
+          const LanePts<32> lpf{pts + wave * (64 * CAPS) + lane};  // (32 lanes x the full slots = the same region)
+          if constexpr (GEOM == 1) record(qq, rr, cc, v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, false, lpf));
+          else record(qq, rr, cc, hull_pair_lds<GEOM == 2, 32, 24>(A.f, B.f, true, lpf));
         }
         for (int k = 0; k < 32 && m; k++) m &= m - 1;
       }
@@ -913,24 +943,56 @@ template <int GEOM>
 __global__ __launch_bounds__(256) void iou_vec_kernel(const float* __restrict__ b1, int n1,
                                                       const float* __restrict__ b2, int n2,
                                                       int iof, float* __restrict__ out) {
-  __shared__ float2 pts[pts_slots<GEOM>() * 256];
+  // v1: the straight-line clip (9 slots), the exact list form (16) for what it flags; hull: 12 of the 24 slots in
+  // wave-private regions, a pair with a 13th point redone by lanes 0..31 with 24 slots (round 5: 49 KB -> 24.5 KB)
+  __shared__ float2 pts[(GEOM == 1 ? R3_V1_CAP : 12) * 256];
   const LanePts<256> lp{pts + threadIdx.x};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = max(n1, n2);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.x) {
+  for (int i0 = blockIdx.x * 256 + wave * 64; i0 < n; i0 += 256 * (int)gridDim.x) {  // (wave-uniform trips)
+    const int i = i0 + lane;
+    const bool valid = i < n;
     BoxRec A, B;
-    make_record<GEOM>(b1 + (size_t)(i % n1) * 5, 0.f, A);
-    make_record<GEOM>(b2 + (size_t)(i % n2) * 5, 0.f, B);
-    float v = 0.f;
-    if (!boxes_apart(A.f, B.f)) {
-      if constexpr (GEOM == 1) {  // round 5: the straight-line clip; what it flags takes the exact list form
-        bool flagged = false;
-        v = v1_clip_fast(A.f, B.f, iof != 0, ClipLds<256>{pts + threadIdx.x}, flagged);
-        if (flagged) v = pair_slow_lds<GEOM, 256>(A.f, B.f, iof != 0, lp);
-      } else {
-        v = pair_slow_lds<GEOM, 256>(A.f, B.f, iof != 0, lp);
+    bool apart = true;
+    if (valid) {
+      make_record<GEOM>(b1 + (size_t)(i % n1) * 5, 0.f, A);
+      make_record<GEOM>(b2 + (size_t)(i % n2) * 5, 0.f, B);
+      apart = boxes_apart(A.f, B.f);
+    }
+    if constexpr (GEOM == 1) {
+      if (valid) {
+        float v = 0.f;
+        if (!apart) {
+          bool flagged = false;
+          v = v1_clip_fast(A.f, B.f, iof != 0, ClipLds<256>{pts + threadIdx.x}, flagged);
+          if (flagged) v = pair_slow_lds<GEOM, 256>(A.f, B.f, iof != 0, lp);
+        }
+        out[i] = v;
+      }
+    } else {
+      bool over = false;
+      if (valid) {
+        float v = 0.f;
+        if (!apart) v = hull_pair_lds<GEOM == 2, 64, 12>(A.f, B.f, iof == 0, LanePts<64>{pts + wave * (64 * 12) + lane}, &over);
+        if (!over) out[i] = v;
+      }
+      unsigned long long m = __ballot(over);
+      while (m) {
+        int src = -1, seen = 0;
+        for (unsigned long long t2 = m; t2; t2 &= t2 - 1) {
+          if (seen == lane) src = __builtin_ctzll(t2);
+          seen++;
+        }
+        const int ii = __shfl(i, src < 0 ? 0 : src);
+        if (lane < 32 && src >= 0) {
+          BoxRec A2, B2;
+          make_record<GEOM>(b1 + (size_t)(ii % n1) * 5, 0.f, A2);
+          make_record<GEOM>(b2 + (size_t)(ii % n2) * 5, 0.f, B2);
+          out[ii] = hull_pair_lds<GEOM == 2, 32, 24>(A2.f, B2.f, iof == 0, LanePts<32>{pts + wave * (64 * 12) + lane});
+        }
+        for (int k = 0; k < 32 && m; k++) m &= m - 1;
       }
     }
-    out[i] = v;
   }
 }
 

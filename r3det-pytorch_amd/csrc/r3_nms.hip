@@ -362,9 +362,11 @@ __global__ __launch_bounds__(256, FAST ? 4 : 1) void nms_drain_kernel(const BoxR
   // twice the resident waves; one clip is ~15 us of latency, so an image's pairs should take ONE trip); the rare
   // pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region (as in the IoU drain)
   // Round 5 (FAST): the straight-line clip (r3_clip.h), 9 slots per lane; flagged pairs take the same redo
-  constexpr bool SHORT = GEOM == 1;
-  constexpr int CAPS = FAST ? R3_CLIP_SLOTS : 8;
-  __shared__ float2 pts[SHORT ? CAPS * 256 : pts_slots<GEOM>() * 256];
+  // Round 5, v2 / v3 (hull): 12 of the 24 slots per lane and the same redo (a pair with a 13th point is redone by lanes
+  // 0..31 with 24 slots in the same region): 24.5 KB of LDS instead of 49 KB, occupancy 3 -> 5+ (the IoU drain's form)
+  constexpr bool SHORT = true;
+  constexpr int CAPS = GEOM == 1 ? (FAST ? R3_CLIP_SLOTS : 8) : 12;
+  __shared__ float2 pts[CAPS * 256];
   __shared__ unsigned pre[Q_NREG + 1];  // exclusive prefix of the regions' (clamped) fills
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (bt.counts) {
@@ -399,14 +401,14 @@ __global__ __launch_bounds__(256, FAST ? 4 : 1) void nms_drain_kernel(const BoxR
       const BoxRec A = recs[i];
       const BoxRec B = recs[j];
       float v;
-      if constexpr (SHORT && FAST) {
+      if constexpr (GEOM == 1 && FAST) {
         v = v1_clip_fast(A.f, B.f, false, ClipLds<64>{pts + wave * (64 * CAPS) + lane}, over);
-      } else if constexpr (SHORT) {
+      } else if constexpr (GEOM == 1) {
         const LanePts<64> lp8{pts + wave * (64 * CAPS) + lane};
         v = v1_pair_lds<64, 8>(A.f, B.f, false, lp8, &over);
       } else {
-        const LanePts<256> lp{pts + threadIdx.x};
-        v = pair_slow_lds<GEOM, 256>(A.f, B.f, false, lp);
+        const LanePts<64> lp12{pts + wave * (64 * CAPS) + lane};
+        v = hull_pair_lds<GEOM == 2, 64, 12>(A.f, B.f, true, lp12, &over);
       }
       if (!over && v > thr) {
         mark_pair(mask, sd, i, j, cb);
@@ -425,8 +427,10 @@ __global__ __launch_bounds__(256, FAST ? 4 : 1) void nms_drain_kernel(const BoxR
         if (lane < 32 && src >= 0) {
           const BoxRec A = recs[ii];
           const BoxRec B = recs[jj];
-          const LanePts<32> lp16{pts + wave * (64 * CAPS) + lane};
-          const float v = v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, false, lp16);
+          const LanePts<32> lpf{pts + wave * (64 * CAPS) + lane};  // (32 lanes x the full slots = the same region)
+          float v;
+          if constexpr (GEOM == 1) v = v1_pair_lds<32, R3_V1_CAP>(A.f, B.f, false, lpf);
+          else v = hull_pair_lds<GEOM == 2, 32, 24>(A.f, B.f, true, lpf);
           if (v > thr) {
             mark_pair(mask, sd, ii, jj, cb);
             if (rlab && ((rlab[ii] ^ rlab[jj]) & (RG_GROUPS - 1))) counter[Q_XFLAG] = 1u;
@@ -1330,7 +1334,7 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* 
 //     an iteration is a handful of scalar instructions, not a barrier;
 //   * rows with more than EL suppressors also scan their overflow row of the transposed mask.
 // Greedy NMS in score order has ONE answer (row kept <=> no kept suppressor), so the result is the rounds reducer's.
-constexpr int WALK_MAXN = 8192;  // rows per image (LDS: 2 x u16 per row + the kept bits + one block's lists = 37 KB)
+constexpr int WALK_MAXN = 12288;  // rows per image (static LDS: 2 x u16 per row + the kept bits + one block's lists = 55 KB)
 
 __global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restrict__ maskT, u64* __restrict__ side, int cb,
                                                              const unsigned* __restrict__ counter,
@@ -1390,8 +1394,16 @@ __global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restri
     const int r = valid ? (grouped ? (int)rows_l[k] : k) : 0;
     const int firstrow = grouped ? (int)rows_l[t0] : t0;  // suppressors below it are final
     int c = 0;
+    bool rem = false;
     if (valid) {
       c = sd.ecnt[r];
+      if (c > 0) {
+        // the highest-scored suppressor first: it is very often the kept head of the row's cluster, and a row it
+        // removes needs neither its list nor its overflow row
+        const int i0 = 65535 - sd.msup[r];
+        if (i0 < firstrow) rem = (Kb[i0 >> 6] >> (i0 & 63)) & 1ULL;
+        if (rem) c = 0;
+      }
       if (c > 0) {
         const uint4* src = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
         const int quads = (min(c, EL) + 7) >> 3;
@@ -1404,7 +1416,6 @@ __global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restri
     int maxc = cl;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
-    bool rem = false;
     u64 D = 0;
     for (int e = 0; e < maxc; e++) {
       if (e < cl) {
@@ -1413,18 +1424,39 @@ __global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restri
         else D |= 1ULL << ((grouped ? (int)posmap[i] : i) - t0);
       }
     }
-    if (c > EL) {  // the suppressors beyond the list: row r of the transposed mask (bits i < r)
-      const u64* row = maskT + (size_t)r * cb;
+    // the suppressors beyond the list (rows of dense clusters the shortcut did not settle): row r of the transposed
+    // mask (bits i < r), one row at a time, the wavefront's lanes a word each
+    u64 ovm = __ballot(valid && !rem && c > EL);
+    while (ovm) {
+      const int srcl = __builtin_ctzll(ovm);
+      ovm &= ovm - 1;
+      const int rs = __shfl(r, srcl);
+      const u64* row = maskT + (size_t)rs * cb;
       const int fw = firstrow >> 6;
-      for (int q = 0; q < fw; q++) rem |= (row[q] & Kb[q]) != 0ULL;
-      for (int q = fw; q <= (r >> 6); q++) {
+      bool hit = false;
+      u64 dpart = 0;
+      for (int q = lane; q <= (rs >> 6); q += 64) {
         u64 w = row[q];
-        while (w) {
-          const int i = q * 64 + __builtin_ctzll(w);
-          w &= w - 1;
-          if (i < firstrow) rem |= (Kb[q] >> (i & 63)) & 1ULL;
-          else if (i < r) D |= 1ULL << ((grouped ? (int)posmap[i] : i) - t0);
+        if (q < fw) {
+          hit |= (w & Kb[q]) != 0ULL;
+        } else {
+          while (w) {
+            const int i = q * 64 + __builtin_ctzll(w);
+            w &= w - 1;
+            if (i < firstrow) hit |= (Kb[q] >> (i & 63)) & 1ULL;
+            else if (i < rs) dpart |= 1ULL << ((grouped ? (int)posmap[i] : i) - t0);
+          }
         }
+      }
+      const bool anyhit = __ballot(hit) != 0ULL;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)(dpart & 0xffffffffULL), d), hi = __shfl_xor((unsigned)(dpart >> 32), d);
+        dpart |= ((u64)hi << 32) | lo;
+      }
+      if (lane == srcl) {
+        rem |= anyhit;
+        D |= dpart;
       }
     }
     // ---- the block resolves with ballots
@@ -2165,8 +2197,11 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     // one reducer workgroup per (image, label group = label mod 16) when the pool is small enough for its LDS; the
     // kernel itself falls back to one workgroup per image when the drain saw an edge between two groups
     const int groups = (cap <= RG_MAXN && g_r3_nms_impl != 2) ? RG_GROUPS : 1;
-    if (cap <= WALK_MAXN && g_r3_nms_impl != 2 && g_r3_nms_impl != 3) {
-      // (round 5) pools of a detection step: one wavefront per (image, label group) walks its rows in score order
+    if (cap <= WALK_MAXN && g_r3_nms_impl == 4) {
+      // (round 5, measured and NOT the default: one wavefront per (image, label group) walks its rows in score order --
+      // 13.1 us against the round reducer's 9.7 at n = 2000, 54.6 against 16.4 at 8576, 64 against 65 on the random-weight
+      // model's own pool (chains 90 deep, 10 % of the rows with > 32 suppressors): a block of 64 rows costs the walk three
+      // dependent memory round trips, which the round reducer's 1024 threads overlap; profiles/r05_nms_reducer_ab.txt)
       hipLaunchKernelGGL(nms_reduce_walk_kernel, dim3(RG_GROUPS, 1, B), dim3(64), 0, stream, L.mask, L.nz, L.cb,
                          L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt);
     } else {
