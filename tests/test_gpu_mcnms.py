@@ -351,10 +351,10 @@ def test_padded_form_flags_a_short_capacity_and_recovers(nms_type):
 
 
 # ------------------------------------------------------------------------------------------------ round 5: walk reducer
-@pytest.fixture(params=[0, 3], ids=["walk", "rounds"])
+@pytest.fixture(params=[4, 0], ids=["walk", "rounds"])
 def reducer(request):
-    """nms_impl 0: one wavefront per (image, label group) walks its rows in score order (nms_reduce_walk_kernel);
-    3: the dependency-round reducer of rounds 2-4.  Greedy NMS has one answer: both must give it."""
+    """nms_impl 4: one wavefront per (image, label group) walks its rows in score order (nms_reduce_walk_kernel, round 5:
+    measured, not the default); 0: the dependency-round reducer.  Greedy NMS has one answer: both must give it."""
     from r3det import _C
     _C.set_option("nms_impl", request.param)
     yield request.param
