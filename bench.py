@@ -210,14 +210,29 @@ def train_custom_op_ms(tr, device):
 
     def assign():
         for i in range(TRAIN_BATCH):
-            m.bbox_head.assigner.assign(anchors, obb2hbb(tr["gtb"][i], 'v1'), None, tr["gtl"][i])
+            # (the anchor head names its grid: the assigner keeps the grid's prepared columns, as in the step itself)
+            m.bbox_head.assigner.assign(anchors, obb2hbb(tr["gtb"][i], 'v1'), None, tr["gtl"][i],
+                                        shared_key=('bench_anchor_grid', anchors.data_ptr()))
             m.refine_head[0].assigner.assign(refined[i], tr["gtb"][i], None, tr["gtl"][i])
 
+    from r3det.ops.feature_refine import feature_refine_module_levels
+    as_ = [torch.randn_like(f).requires_grad_(True) for f in feats]  # (the module's two convolution outputs)
+    bs_ = [torch.randn_like(f).requires_grad_(True) for f in feats]
+    scales = [1.0 / s for s in syn.STRIDES]
+
     def fr():
-        for x in xs:
-            x.grad = None
-        # what FeatureRefineModule runs in training: the five levels as one autograd node (both layouts)
-        torch.autograd.backward(feature_refine_levels(xs, boxes, [1.0 / s for s in syn.STRIDES], 1), gs)
+        for t in xs + as_ + bs_:
+            t.grad = None
+        # what FeatureRefineModule runs in training (round 5): add, samplers and residual add of the five levels as ONE
+        # autograd node (both layouts)
+        torch.autograd.backward(feature_refine_module_levels(as_, bs_, xs, boxes, scales, 1), gs)
+
+    def fr_three_step():
+        for t in xs + as_ + bs_:
+            t.grad = None
+        # rounds 3-4: the samplers as one node, the two elementwise passes per level around it
+        sampled = feature_refine_levels([a + b for a, b in zip(as_, bs_)], boxes, scales, 1)
+        torch.autograd.backward([x + o for x, o in zip(xs, sampled)], gs)
     def samples(fn, n=9, reps=5):  # n wall figures of `reps` calls each
         fn()
         out = []
@@ -229,12 +244,16 @@ def train_custom_op_ms(tr, device):
             torch.cuda.synchronize()
             out.append((time.perf_counter() - t) / reps)
         return out
-    sa, sf = samples(assign), samples(fr)
+    sa, sf, s3 = samples(assign), samples(fr), samples(fr_three_step)
     detail = {"what": "wall = launch-wait-launch loops of 5 calls, median / min / max of 9; device = GPU time of the same "
                       "calls with the stream kept busy while the host enqueues them (HIP events): the difference is the "
                       "host's share",
               "assign_ms_wall": spread_stats(sa), "assign_ms_device": round(device_time_ms(assign, reps=5), 3),
-              "fr_fwd_bwd_ms_wall": spread_stats(sf), "fr_fwd_bwd_ms_device": round(device_time_ms(fr, reps=5), 3)}
+              "fr_fwd_bwd_ms_wall": spread_stats(sf), "fr_fwd_bwd_ms_device": round(device_time_ms(fr, reps=5), 3),
+              "fr_what": "module tail of the five levels (add, samplers, residual add; backward: the gathers) as one autograd "
+                         "node; three_step = the same work as rounds 3-4 ran it (elementwise adds outside the node)",
+              "fr_three_step_ms_wall": spread_stats(s3),
+              "fr_three_step_ms_device": round(device_time_ms(fr_three_step, reps=5), 3)}
     train_custom_op_ms.detail = detail
     return sorted(sa)[len(sa) // 2] * 1e3, sorted(sf)[len(sf) // 2] * 1e3
 

@@ -342,6 +342,9 @@ def fr_backward_nhwc_index(best_rbboxes, N, H, W, spatial_scale, points=1):
 
 
 NHWC_ONLY = False  # tests: fail instead of falling back when a channels_last module input does not take the NHWC launch
+# training: FeatureRefineModule's tail (add, samplers, residual add) as one autograd node (False: the three-step form of
+# rounds 1-4 around FeatureRefineLevelsFunction; tests and tools/train_hot_path.py flip it for the A/B)
+TRAIN_FUSED_TAIL = True
 
 
 def fr_backward_index(best_rbboxes, N, C, H, W, spatial_scale, points=1):
@@ -510,6 +513,100 @@ class FeatureRefineLevelsFunction(Function):
         return (None, None, None) + tuple(outs) + (None,) * n
 
 
+class FeatureRefineModuleLevelsFunction(Function):
+    """The TAIL of FeatureRefineModule for all pyramid levels as one autograd node (round 5, SURVEY 8f rank 2 for the
+    training step): ``out_l = x_l + fr(a_l + b_l, boxes_l)`` with a_l = conv_5_1(conv_1_5(x_l)), b_l = conv_1_1(x_l)
+    (feature_refine_module.py:120-126).  Forward = the launches inference uses -- the add in front of the sampler and
+    the residual add behind it ride in the sampler launch (r3det_feature_refine_module_levels_nhwc on channels_last
+    memory; r3det_feature_refine_module_prepared per NCHW level where it takes the shape, the three-step form
+    elsewhere) -- instead of two elementwise passes per level around FeatureRefineLevelsFunction.  Backward = the
+    gather over the inverse tap index built in the forward pass: d = fr_backward(g) is the gradient of BOTH a and b
+    (their sum is the sampler's input), g itself the gradient of x; no elementwise pass either side."""
+
+    @staticmethod
+    def forward(ctx, spatial_scales, points, n, *tensors):
+        a_in, b_in, x_in = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        boxes = [t.contiguous() for t in tensors[3 * n:4 * n]]
+        assert points in [1, 5] and all(f.is_cuda for f in x_in)
+        N, C = x_in[0].shape[:2]
+        ctx.scales, ctx.points, ctx.n = list(spatial_scales), points, n
+        ctx.shape = [tuple(f.shape) for f in x_in]
+        ctx.save_for_backward(*boxes)
+        ctx.index, ctx.nhwc = None, False
+        need = any(ctx.needs_input_grad[3:3 + 3 * n])
+        L = _C.lib()
+        if all(_is_cl(f) for f in a_in + b_in + x_in) and C % 4 == 0:
+            H, W, sc, arr_p = _lvl_arrays(list(x_in), spatial_scales)
+            wsb = int(L.r3det_fr_backward_nhwc_levels_workspace_bytes(n, N, H, W, int(points)))
+            outs = [torch.empty_like(f) for f in x_in]  # (preserves channels_last)
+            if wsb and fr_module_levels_nhwc(list(a_in), list(b_in), None, None, list(x_in), boxes, spatial_scales,
+                                             points, outs):
+                ctx.nhwc = True
+                if need:
+                    with torch.cuda.device(x_in[0].device):
+                        ws = torch.empty(wsb, dtype=torch.uint8, device=x_in[0].device)
+                        _C.check(L.r3det_feature_refine_backward_nhwc_index_levels(
+                            n, arr_p(*[b.data_ptr() for b in boxes]), N, H, W, sc, int(points), _C.ptr(ws), wsb,
+                            _C.stream()), "fr_backward_nhwc_index_levels")
+                    ctx.index = (ws, wsb)
+                return tuple(outs)
+        a_c, b_c, x_c = ([t.contiguous() for t in ts] for ts in (a_in, b_in, x_in))
+        outs = []
+        for a, b, x, bx, s in zip(a_c, b_c, x_c, boxes, spatial_scales):
+            o = torch.empty_like(x)
+            table = fr_prepare(bx, x.size(0), x.size(2), x.size(3), s, points)
+            if table is None or not fr_module_prepared(a, b, x, table, o):
+                m = a + b
+                fr_forward(m, bx, s, points, o)
+                o += x
+            outs.append(o)
+        if need:
+            H, W, sc, arr_p = _lvl_arrays(x_c, spatial_scales)
+            with torch.cuda.device(x_c[0].device):
+                wsb = int(L.r3det_fr_backward_levels_workspace_bytes(n, N, H, W, int(points)))
+                ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x_c[0].device)
+                _C.check(L.r3det_feature_refine_backward_index_levels(
+                    n, arr_p(*[b.data_ptr() for b in boxes]), N, C, H, W, sc, int(points), _C.ptr(ws), wsb, _C.stream()),
+                    "fr_backward_index_levels")
+            ctx.index = (ws, wsb)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        n, boxes = ctx.n, ctx.saved_tensors
+        if ctx.index is None:
+            return (None, None, None) + (None,) * (4 * n)
+        fmt = torch.channels_last if ctx.nhwc else torch.contiguous_format
+        gs = [(g if g is not None else torch.zeros(shp, device=boxes[0].device)).contiguous(memory_format=fmt)
+              for g, shp in zip(grads, ctx.shape)]
+        ds = [torch.empty_like(g) for g in gs]  # (preserves the layout)
+        N, C = gs[0].shape[:2]
+        L = _C.lib()
+        H, W, sc, arr_p = _lvl_arrays(gs, ctx.scales)
+        ws, wsb = ctx.index
+        with torch.cuda.device(gs[0].device):
+            if ctx.nhwc:
+                _C.check(L.r3det_feature_refine_backward_nhwc_levels_indexed(
+                    n, arr_p(*[g.data_ptr() for g in gs]), N, C, H, W, int(ctx.points),
+                    arr_p(*[o.data_ptr() for o in ds]), 1, _C.ptr(ws), wsb, _C.stream()),
+                    "fr_backward_nhwc_levels_indexed")
+            else:
+                _C.check(L.r3det_feature_refine_backward_levels_indexed(
+                    n, arr_p(*[g.data_ptr() for g in gs]), arr_p(*[b.data_ptr() for b in boxes]), N, C, H, W, sc,
+                    int(ctx.points), arr_p(*[o.data_ptr() for o in ds]), 1, _C.ptr(ws), wsb, _C.stream()),
+                    "fr_backward_levels_indexed")
+        ds = tuple(ds)
+        return (None, None, None) + ds + ds + tuple(gs) + (None,) * n
+
+
+def feature_refine_module_levels(conv_a, conv_b, x, best_rbboxes, spatial_scales, points=1):
+    """``[x_l + feature_refine(a_l + b_l, boxes_l, s_l, points)]`` over the pyramid as ONE autograd node."""
+    n = len(x)
+    return list(FeatureRefineModuleLevelsFunction.apply(tuple(float(s) for s in spatial_scales), points, n, *conv_a,
+                                                        *conv_b, *x, *best_rbboxes))
+
+
 def feature_refine_levels(features, best_rbboxes, spatial_scales, points=1):
     """``[feature_refine(f, b, s, points) for f, b, s in zip(...)]`` as one autograd node (levels sharing N and C;
     NCHW, or channels_last when every level is)."""
@@ -575,6 +672,13 @@ class FeatureRefineModule(nn.Module):
             # training: the samplers of all levels as ONE autograd node (one library call each for the samplers, the
             # backward's indexes and the gathers) -- on channels_last memory when every level's convolution output is,
             # else on NCHW planes
+            if TRAIN_FUSED_TAIL:
+                # round 5: the add in front of the samplers and the residual add behind them inside the node (the
+                # forward is the inference launch, the backward the gather alone: FeatureRefineModuleLevelsFunction)
+                return feature_refine_module_levels([self.conv_5_1(self.conv_1_5(f)) for f in x],
+                                                    [self.conv_1_1(f) for f in x], list(x),
+                                                    [b.contiguous() for b in per_level],
+                                                    [fr.spatial_scale for fr in self.fr], self.fr[0].points)
             mixed = [self.conv_5_1(self.conv_1_5(f)) + self.conv_1_1(f) for f in x]
             sampled = feature_refine_levels(mixed, [b.contiguous() for b in per_level],
                                             [fr.spatial_scale for fr in self.fr], self.fr[0].points)

@@ -151,3 +151,44 @@ def test_frm_training_path_not_fused_when_any_parameter_needs_grad():
     with torch.no_grad():
         fused = m([x], [[boxes]])[0]
     assert not fused.requires_grad and torch.equal(fused, out.detach())
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_module_tail_as_one_autograd_node_equals_the_three_step_form(layout):
+    """Round 5: FeatureRefineModule in training with the add in front of the samplers and the
+    residual add behind them INSIDE the levels node (forward = the inference launch, backward = the gather) against the
+    three-step form around FeatureRefineLevelsFunction: the outputs bit for bit (the launches fold the same operations in
+    the same order), every gradient -- convolution weights and biases, the input features -- within 1e-5 of its scale."""
+    from r3det import synthetic as syn
+    from r3det.ops import FeatureRefineModule
+    from r3det.ops import feature_refine as frm
+    torch.manual_seed(3)
+    N, C = 2, 32
+    strides = list(syn.STRIDES)
+    feats, boxes = syn.fr_pyramid(N, C, 21, device='cuda', size=1024)  # (128^2 and 64^2 planes: the NCHW fused launch)
+    rois = [[b.view(N, -1, 5)[i] for b in boxes] for i in range(N)]
+    m = FeatureRefineModule(C, strides).cuda()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, 0, 0.2)
+    if layout == "channels_last":
+        m = m.to(memory_format=torch.channels_last)
+        feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+    gs = [torch.randn_like(f) for f in feats]
+    res = {}
+    for fused in (True, False):
+        frm.TRAIN_FUSED_TAIL = fused
+        try:
+            xs = [f.clone().requires_grad_(True) for f in feats]
+            m.zero_grad(set_to_none=True)
+            outs = m(xs, rois)
+            torch.autograd.backward(outs, gs)
+        finally:
+            frm.TRAIN_FUSED_TAIL = True
+        res[fused] = ([o.detach() for o in outs], [x.grad for x in xs], {n: p.grad.clone() for n, p in m.named_parameters()})
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    for n in res[True][2]:
+        a, b = res[True][2][n], res[False][2][n]
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), n
