@@ -3,9 +3,9 @@
 # of the bench step, the training step, configs[1], the IoU and NMS ops, and the PMC passes (separate runs,
 # --kernel-trace only) of the roofline kernel and of the IoU / NMS kernels.  Output: gpurun_out/profiles_<tag>/,
 # copied into profiles/ by hand (tracked).
-#   bash tools/make_profiles.sh r04
+#   bash tools/make_profiles.sh r05
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$(pwd)
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
@@ -93,6 +93,13 @@ cd $R
 IOU_PROF_SHAPE=128x196416 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_iou_pmc.txt iou_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/iou_prof.py > /dev/null
 NMS_PROF_N=8576 bash tools/pmc_groups.sh gpurun_out/profiles_$TAG/${TAG}_nms_pmc.txt nms_ "FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" tools/nms_prof.py > /dev/null
 ls -la $O
+# 7b. round 5: the straight-line v1 clip against the LDS-list form in the three drains (same process per form), the
+#     drain's phase stamps (probes build), the whole-step graph against the eager step
+bash tools/clip_ab.sh gpurun_out/profiles_$TAG/${TAG}_clip_ab.txt > /dev/null 2>&1
+{ for impl in 0 1; do CLIP_IMPL=$impl python3 tools/iou_drain_stamps.py 2>&1 | grep -v amdgpu.ids; done; } > $O/${TAG}_iou_drain_stamps.txt
+python3 tools/whole_step_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_whole_step_graph.txt
+python3 tools/pool_edge_stats.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_model_pool_edges.txt
+POOL_SPREAD=0 python3 tools/pool_edge_stats.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed 's/^/one-label calibration: /' >> $O/${TAG}_model_pool_edges.txt
 # 8. the bench lines themselves (no profiler attached)
 python3 $R/bench.py --steps 30 --warmup 5 > $O/${TAG}_bench.json 2> /dev/null
 python3 $R/bench.py --mode train --steps 10 --warmup 3 > $O/${TAG}_train.json 2> /dev/null
