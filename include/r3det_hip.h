@@ -520,7 +520,8 @@ int r3det_bias_act(float* y, const float* bias, const float* residual, long long
  *   ("frb_impl", 0 auto | 1 general index form | 2 unpaired NHWC gather | 3 SELL rows by their own launch |
  *                5 SELL rows and CSR lists from one launch | 6 pyramid levels one launch each: indexes, coarse-level
  *                samplers and gathers)
- *   ("iou_impl", 0 auto | 1 one thread per pair | 2 one-launch tile kernel | 4 stream + drain always),
+ *   ("iou_impl", 0 auto | 1 one thread per pair | 2 one-launch tile kernel | 4 stream + drain always | 3 the fused
+ *                assignment on its global pair queue of rounds 2-4 instead of the matrix path's tile queue; a plain matrix call reads 3 as 0),
  *   ("iou_small", columns from which the pipeline runs), ("iou_qcap", n: per-wave survivor capacity, small values
  *   force the dense-tile path), ("iou_dwgs", drain workgroups), ("nms_impl", 0 | 1 tiles | 2 one reducer workgroup | 4 the batched
  *   pipeline's reducer as a walk in score order, one wavefront per image and label group),

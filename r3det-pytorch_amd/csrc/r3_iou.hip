@@ -20,6 +20,8 @@
 //     evaluated per box, never per pair.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "r3_clip.h"
 #include "r3_geom_lds.h"
 #include "r3_kernels.h"
@@ -568,8 +570,8 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
     const float* A = rows[r];
     const float ax = A[0], ay = A[1], ar = A[2], aex = A[3], aey = A[4];
     if (wave_ok && ((ax - aex > bx1) | (ax + aex < bx0) | (ay - aey > by1) | (ay + aey < by0))) {
-      *reinterpret_cast<float4*>(out + (size_t)(row0 + r) * n2 + col0) = make_float4(0.f, 0.f, 0.f, 0.f);
-      continue;
+      if (out) *reinterpret_cast<float4*>(out + (size_t)(row0 + r) * n2 + col0) = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;  // (out == nullptr: the fused assignment has no matrix)
     }
     bool pend[T_CPT];
     bool any = false;
@@ -581,13 +583,15 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
       pend[c] = cvalid[c] && !apart;
       any |= pend[c];
     }
-    float* o = out + (size_t)(row0 + r) * n2 + col0;
-    if (VEC && all_valid && !any) {
-      *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
+    if (out) {
+      float* o = out + (size_t)(row0 + r) * n2 + col0;
+      if (VEC && all_valid && !any) {
+        *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
 #pragma unroll
-      for (int c = 0; c < T_CPT; c++)
-        if (cvalid[c] && !pend[c]) o[c] = 0.f;
+        for (int c = 0; c < T_CPT; c++)
+          if (cvalid[c] && !pend[c]) o[c] = 0.f;
+      }
     }
     if (__ballot(any)) {
       if (cnt + 256 > wcap) {
@@ -613,7 +617,25 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   for (int q = lane; q < cnt; q += 64) slot[q] = wq[q];
 }
 
-template <int GEOM, bool FAST = false>
+// (the fused assignment's packed (IoU bits << 32 | ~index) keys: larger IoU wins a 64-bit atomicMax, then the SMALLER index)
+typedef unsigned long long u64k;
+
+__device__ __forceinline__ u64k pack_key(float iou, unsigned idx) {
+  return ((u64k)__float_as_uint(iou) << 32) | (u64k)(0xffffffffu - idx);
+}
+__device__ __forceinline__ float key_iou(u64k k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ unsigned key_idx(u64k k) { return 0xffffffffu - (unsigned)(k & 0xffffffffu); }
+
+// ASSIGN (round 5): the fused assignment's drain on the same queue -- instead of the matrix element a clipped pair
+// updates the per-column / per-row keys and leaves its IoU in siou[tile * 8192 + entry] for the low-quality sweep.
+struct AssignOut {
+  float* siou;     // [tiles][P_ROWS * T_COLS]
+  u64k* rowkey;    // [n1]
+  u64k* colkey;    // [n2]
+  int n1_lds;      // rows whose maxima are reduced in LDS first (dynamic LDS: n1_lds u64)
+};
+
+template <int GEOM, bool FAST = false, bool ASSIGN = false>
 __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(const float* __restrict__ b1, int n1,
                                                                const float* __restrict__ b2, int n2, int iof,
                                                                const BoxRec* __restrict__ recsA,
@@ -621,7 +643,8 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
                                                                const unsigned short* __restrict__ slots, int tiles_x,
                                                                int tiles, float* __restrict__ out,
                                                                const BoxRec* __restrict__ recsB = nullptr,
-                                                               unsigned long long* __restrict__ stamps = nullptr) {
+                                                               unsigned long long* __restrict__ stamps = nullptr,
+                                                               const AssignOut ao = AssignOut()) {
   // (probes build, tools/iou_drain_stamps.py: wave 0 of every workgroup stamps its phases with the 100 MHz clock)
 #ifdef R3_PROBES
 #define R3_DSTAMP(k)                                                                             \
@@ -648,6 +671,26 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
   __shared__ float2 pts[CAPS * T_THREADS];
   __shared__ unsigned pre[P_GROUPS + 1];
   __shared__ unsigned wsum[4];
+  extern __shared__ __attribute__((aligned(16))) u64k rowbest[];  // ASSIGN: n1_lds entries (0 = none)
+  if (ASSIGN) {
+    for (int i = threadIdx.x; i < ao.n1_lds; i += T_THREADS) rowbest[i] = 0;  // (visible behind the prefix barriers below)
+  }
+  // what a clipped pair leaves behind: the matrix element, or (ASSIGN) its IoU for the low-quality sweep and the keys --
+  // the few hundred gt rows take ~5 k updates each (global atomics on 128 addresses serialise: 0.6 ms), so rows are
+  // reduced in LDS and flushed once per workgroup; columns are many and rarely contended: look, then atomicMax
+  auto emit = [&](const unsigned r, const unsigned c, const float v, const unsigned t, const unsigned off) {
+    if (!ASSIGN) {
+      out[(size_t)r * n2 + c] = v;
+    } else {
+      ao.siou[(size_t)t * D_PAIRS + off] = v;
+      if (v > 0.f) {
+        const u64k kc = pack_key(v, r), kr = pack_key(v, c);
+        if (kc > __builtin_nontemporal_load(&ao.colkey[c])) atomicMax(&ao.colkey[c], kc);
+        if ((int)r < ao.n1_lds) atomicMax(&rowbest[r], kr);
+        else if (kr > __builtin_nontemporal_load(&ao.rowkey[r])) atomicMax(&ao.rowkey[r], kr);
+      }
+    }
+  };
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -690,7 +733,7 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
     const unsigned q = qb + lane;
     bool valid = q < total;
     bool dense = false;
-    unsigned r = 0, c = 0;
+    unsigned r = 0, c = 0, et = 0, eoff = 0;  // (et, eoff: the entry's tile and offset in it)
     if (valid) {
       int g = 0;  // group of entry q: largest g with pre[g] <= q
 #pragma unroll
@@ -711,6 +754,7 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
         t++;
       }
       const unsigned e = dense ? off : slots[(size_t)t * P_SLOT + off];
+      et = (unsigned)t, eoff = off;
       const int by = t / tiles_x, bx = t - by * tiles_x;
       r = (unsigned)(by * P_ROWS) + (e >> 10);
       c = (unsigned)(bx * T_COLS) + (e & 1023u);
@@ -733,7 +777,9 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
         else v = hull_pair_lds<GEOM == 2, 64, CAPS>(A.f, B.f, iof == 0, lp, &over);
       }
       if ((trips & 0xffff) == 0) { R3_DSTAMP(4) }
-      if (!over) out[(size_t)r * n2 + c] = v;
+      if (!over) emit(r, c, v, et, eoff);
+    } else if (ASSIGN && q < total) {
+      ao.siou[(size_t)et * D_PAIRS + eoff] = 0.f;  // (a dense edge tile's entry beyond the matrix: nothing for the sweep)
     }
     if ((trips & 0xffff) == 0) { R3_DSTAMP(5) }
     trips++;
@@ -746,15 +792,16 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
           if (seen == lane) src = __builtin_ctzll(t2);
           seen++;
         }
-        const unsigned rr = __shfl(r, src < 0 ? 0 : src), cc = __shfl(c, src < 0 ? 0 : src);
+        const int sl = src < 0 ? 0 : src;
+        const unsigned rr = __shfl(r, sl), cc = __shfl(c, sl), tt = __shfl(et, sl), oo = __shfl(eoff, sl);
         if (lane < 32 && src >= 0) {
           const BoxRec A = recsA[rr];
           BoxRec B;
           if (recsB) B = recsB[cc];
           else make_record<GEOM>(b2 + (size_t)cc * 5, 0.f, B);
           const LanePts<32> lp{pts + wave * (64 * CAPS) + lane};  // (32 lanes x CAPF slots = the same region)
-          out[(size_t)rr * n2 + cc] = GEOM == 1 ? v1_pair_lds<32, CAPF>(A.f, B.f, iof != 0, lp)
-                                                : hull_pair_lds<GEOM == 2, 32, CAPF>(A.f, B.f, iof == 0, lp);
+          emit(rr, cc, GEOM == 1 ? v1_pair_lds<32, CAPF>(A.f, B.f, iof != 0, lp)
+                                 : hull_pair_lds<GEOM == 2, 32, CAPF>(A.f, B.f, iof == 0, lp), tt, oo);
         }
         for (int k = 0; k < 32 && m; k++) m &= m - 1;
       }
@@ -765,6 +812,13 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
   if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)trips;
 #endif
 #undef R3_DSTAMP
+  if (ASSIGN) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ao.n1_lds; i += T_THREADS) {
+      const u64k k = rowbest[i];
+      if (k && k > __builtin_nontemporal_load(&ao.rowkey[i])) atomicMax(&ao.rowkey[i], k);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -775,13 +829,6 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
 // a 64-bit atomicMax (larger IoU wins, then the SMALLER index: the torch-CPU / numpy tie rule)
 // and keeps its IoU next to its queue entry; a second sweep over the queue finds the pairs that
 // equal their gt's maximum; the last kernel applies the thresholds.
-typedef unsigned long long u64k;
-
-__device__ __forceinline__ u64k pack_key(float iou, unsigned idx) {
-  return ((u64k)__float_as_uint(iou) << 32) | (u64k)(0xffffffffu - idx);
-}
-__device__ __forceinline__ float key_iou(u64k k) { return __uint_as_float((unsigned)(k >> 32)); }
-__device__ __forceinline__ unsigned key_idx(u64k k) { return 0xffffffffu - (unsigned)(k & 0xffffffffu); }
 
 __global__ __launch_bounds__(256) void assign_init_kernel(u64k* __restrict__ rowkey, int n1, u64k* __restrict__ colkey,
                                                           int* __restrict__ lowq, int n2,
@@ -893,6 +940,27 @@ __global__ __launch_bounds__(256) void assign_lowq_kernel(const unsigned* __rest
     const unsigned e = gqueue[q];
     const unsigned r = e / (unsigned)n2;
     const unsigned c = e - r * (unsigned)n2;
+    const u64k rk = rowkey[r];
+    if (v == key_iou(rk) && v >= min_pos_iou && (assign_all || key_idx(rk) == c)) atomicMax(&lowq[c], (int)r + 1);
+  }
+}
+
+// ... the same sweep over the stream + drain queue (round 5): one workgroup per tile, its entries' IoUs in siou
+__global__ __launch_bounds__(256) void assign_lowq3_kernel(const int* __restrict__ tcount,
+                                                           const unsigned short* __restrict__ slots, int tiles_x,
+                                                           const float* __restrict__ siou, int n1, int n2,
+                                                           const u64k* __restrict__ rowkey, float min_pos_iou,
+                                                           int assign_all, int* __restrict__ lowq) {
+  const int t = blockIdx.x;  // (blockIdx.y: a quarter of the tile's entries -- most tiles have none and leave at once)
+  const int tc = tcount[t];
+  if (tc == 0) return;
+  const int cnt = tc < 0 ? P_ROWS * T_COLS : tc;
+  const int by = t / tiles_x, bx = t - by * tiles_x;
+  for (int off = blockIdx.y * 256 + threadIdx.x; off < cnt; off += 256 * (int)gridDim.y) {
+    const float v = siou[(size_t)t * (P_ROWS * T_COLS) + off];
+    if (!(v > 0.f)) continue;
+    const unsigned e = tc < 0 ? (unsigned)off : slots[(size_t)t * P_SLOT + off];
+    const unsigned r = (unsigned)(by * P_ROWS) + (e >> 10), c = (unsigned)(bx * T_COLS) + (e & 1023u);
     const u64k rk = rowkey[r];
     if (v == key_iou(rk) && v >= min_pos_iou && (assign_all || key_idx(rk) == c)) atomicMax(&lowq[c], (int)r + 1);
   }
@@ -1177,23 +1245,46 @@ struct AssignLayout {
   float* qiou;
   u64k *rowkey, *colkey;
   int* lowq;
+  // round 5, the stream + drain queue of the matrix path (tiles <= P_MAX_TILES): gqueue / qiou hold these instead
+  bool tiled;
+  int tiles_x, tiles_y;
+  int* tcount;
+  unsigned short* slots;
+  float* siou;
 };
 
-inline size_t assign_layout(int n1, int n2, void* ws, AssignLayout* L) {
+// Two forms share one workspace size (the larger): the tile queue of the matrix path (tile counts, one 8 KB slot and
+// 8192 IoUs per 8 x 1024 tile), taken when the matrix has at most P_MAX_TILES tiles, else the global queue of rounds 2-4.
+inline bool assign_tiled(int n1, int n2) {
+  const long long tx = ((long long)n2 + T_COLS - 1) / T_COLS, ty = ((long long)n1 + P_ROWS - 1) / P_ROWS;
+  return tx * ty <= P_MAX_TILES && g_r3_iou_impl != 3;  // (iou_impl 3: the global-queue form whatever the size, for the A/B)
+}
+
+inline size_t assign_layout(int n1, int n2, void* ws, AssignLayout* L, const bool tiled) {
+  const long long tx = ((long long)n2 + T_COLS - 1) / T_COLS, ty = ((long long)n1 + P_ROWS - 1) / P_ROWS;
   size_t off = 0;
   char* p = (char*)ws;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
   char* counter = take(256);
   char* ra = take((size_t)n1 * sizeof(BoxRec));
   char* rb = take((size_t)n2 * sizeof(BoxRec));
-  char* gq = take((size_t)n1 * n2 * 4);
-  char* qi = take((size_t)n1 * n2 * 4);
   char* rk = take((size_t)n1 * 8);
   char* ck = take((size_t)n2 * 8);
   char* lq = take((size_t)n2 * 4);
+  char *gq = nullptr, *qi = nullptr, *tc = nullptr, *sl = nullptr, *si = nullptr;
+  if (tiled) {
+    tc = take((size_t)(tx * ty) * 4);
+    sl = take((size_t)(tx * ty) * P_SLOT * 2);
+    si = take((size_t)(tx * ty) * P_ROWS * T_COLS * 4);
+  } else {
+    gq = take((size_t)n1 * n2 * 4);
+    qi = take((size_t)n1 * n2 * 4);
+  }
   if (L) {
     L->counter = (unsigned*)counter; L->recsA = (BoxRec*)ra; L->recsB = (BoxRec*)rb; L->gqueue = (unsigned*)gq;
     L->qiou = (float*)qi; L->rowkey = (u64k*)rk; L->colkey = (u64k*)ck; L->lowq = (int*)lq;
+    L->tiled = tiled; L->tiles_x = (int)tx; L->tiles_y = (int)ty; L->tcount = (int*)tc; L->slots = (unsigned short*)sl;
+    L->siou = (float*)si;
   }
   return off + 256;
 }
@@ -1207,6 +1298,41 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
   const int nmax = n1 > n2 ? n1 : n2;
   hipLaunchKernelGGL(assign_init_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, L.rowkey, n1, L.colkey,
                      L.lowq, n2, L.counter);
+  if (L.tiled) {
+    // round 5: the matrix path's queue -- stream3 (per-wave segments, no atomics, the wave-level bounding box; no
+    // matrix: out = nullptr) -> the drain with the keys as its result -> the low-quality sweep tile by tile.
+    // (iou_stream_kernel + one global queue behind an atomic counter: 37 us of stream at 128 x 196 416, this: ~20)
+    const int tiles = L.tiles_x * L.tiles_y;
+    const dim3 sgrid(L.tiles_x, L.tiles_y);
+    const int wcap3 = g_r3_iou_qcap > 0 && g_r3_iou_qcap < P_WSEG ? g_r3_iou_qcap : P_WSEG;  // (small: the dense-tile path)
+    if (prepared && n2 % 4 == 0)
+      hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, true>), sgrid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
+                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap3, P);
+    else
+      hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), sgrid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
+                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap3, P);
+    const bool fast = GEOM == 1 && g_r3_clip_impl == 0;
+    unsigned long long pairs3 = (unsigned long long)n1 * n2;
+    int blocks3 = (int)((pairs3 + T_THREADS - 1) / T_THREADS);
+    const int maxb3 = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : fast ? 4 * r3_cu_count() : 1536;
+    if (blocks3 > maxb3) blocks3 = maxb3;
+    const int n1_lds3 = n1 < 2048 ? n1 : 2048;
+    const AssignOut ao{L.siou, L.rowkey, L.colkey, n1_lds3};
+    if (fast)
+      hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM == 1, true>), dim3(blocks3), dim3(T_THREADS),
+                         (size_t)n1_lds3 * sizeof(u64k), stream, gts, n1, boxes, n2, 0, L.recsA, L.tcount, L.slots,
+                         L.tiles_x, tiles, (float*)nullptr, prepared ? P.rec : (const BoxRec*)nullptr,
+                         (unsigned long long*)nullptr, ao);
+    else
+      hipLaunchKernelGGL((iou_drain3_kernel<GEOM, false, true>), dim3(blocks3), dim3(T_THREADS),
+                         (size_t)n1_lds3 * sizeof(u64k), stream, gts, n1, boxes, n2, 0, L.recsA, L.tcount, L.slots,
+                         L.tiles_x, tiles, (float*)nullptr, prepared ? P.rec : (const BoxRec*)nullptr,
+                         (unsigned long long*)nullptr, ao);
+    if (match_low)
+      hipLaunchKernelGGL(assign_lowq3_kernel, dim3(tiles, 4), dim3(256), 0, stream, L.tcount, L.slots, L.tiles_x, L.siou, n1,
+                         n2, L.rowkey, min_pos_iou, assign_all, L.lowq);
+    return;
+  }
   dim3 grid((n2 + T_COLS - 1) / T_COLS, (n1 + S_ROWS - 1) / S_ROWS);
   hipLaunchKernelGGL((iou_stream_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
                      (float*)nullptr, L.recsA, L.recsB, L.gqueue, L.counter, P.rej, P.rad);
@@ -1235,7 +1361,10 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
 
 size_t r3k_iou_assign_workspace_bytes(int n1, int n2) {
   if (n1 <= 0 || n2 <= 0) return 256;
-  return assign_layout(n1, n2, nullptr, nullptr);
+  // (either form must fit: the option that picks the form may change between this query and the call)
+  const long long tx = ((long long)n2 + T_COLS - 1) / T_COLS, ty = ((long long)n1 + P_ROWS - 1) / P_ROWS;
+  const size_t global_q = assign_layout(n1, n2, nullptr, nullptr, false);
+  return tx * ty <= P_MAX_TILES ? std::max(global_q, assign_layout(n1, n2, nullptr, nullptr, true)) : global_q;
 }
 
 int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n2, float pos_thr, float neg_thr,
@@ -1247,7 +1376,7 @@ int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n
   if ((unsigned long long)n1 * (unsigned long long)n2 >= 0xffffffffULL) return -1;
   if (ws_bytes < r3k_iou_assign_workspace_bytes(n1, n2)) return -3;
   AssignLayout L;
-  assign_layout(n1, n2, ws, &L);
+  assign_layout(n1, n2, ws, &L, assign_tiled(n1, n2));
   switch (geom) {
     case 1: launch_assign<1>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream, prepared); break;
     case 2: launch_assign<2>(gts, n1, boxes, n2, L, min_pos_iou, match_low, assign_all, stream, prepared); break;

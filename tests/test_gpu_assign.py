@@ -38,9 +38,22 @@ def check_same(asg, boxes, gts, labels=None):
     return fused
 
 
+@pytest.fixture(params=[(0, 0), (0, 100), (3, 0)], ids=["tile-queue", "tile-queue-dense-tiles", "global-queue"])
+def assign_form(request):
+    """Round 5: the fused assignment runs on the matrix path's queue (stream3 -> drain with the keys as its result -> the
+    low-quality sweep tile by tile); iou_qcap 100 marks every tile with a fuller wave dense (the drain enumerates and
+    tests its 8192 pairs); iou_impl 3: the global pair queue of rounds 2-4."""
+    from r3det import _C
+    _C.set_option("iou_impl", request.param[0])
+    _C.set_option("iou_qcap", request.param[1])
+    yield request.param
+    _C.set_option("iou_impl", 0)
+    _C.set_option("iou_qcap", 0)
+
+
 @pytest.mark.parametrize("calc", CALCS)
 @pytest.mark.parametrize("k,n,span", [(1, 100, 150.), (5, 1000, 300.), (37, 5000, 600.), (128, 20000, 1000.)])
-def test_matches_dense_rules(calc, k, n, span):
+def test_matches_dense_rules(calc, k, n, span, assign_form):
     gts = dev(rand_boxes(k, 10 + k, span=span))
     boxes = dev(rand_boxes(n, 20 + n, span=span))
     labels = torch.randint(0, 15, (k,), device='cuda')
@@ -49,7 +62,7 @@ def test_matches_dense_rules(calc, k, n, span):
         check_same(make(calc, **kw), boxes, gts, labels)
 
 
-def test_assignment_shape_full_size():
+def test_assignment_shape_full_size(assign_form):
     """128 DOTA-like gts against the real 196 416-anchor grid (BASELINE training-step shape)."""
     from r3det import synthetic as syn
     anchors = syn.anchor_grid(device='cuda')
