@@ -197,7 +197,8 @@ __device__ __forceinline__ void compact_tile(const int bx, const int by, const f
         if (valid) {
           BoxRec Bc;
           make_record<GEOM>(b2 + (size_t)col * 5, 0.f, Bc);
-          const float v = hull_pair_lds<GEOM == 2, 64, 12>(rows[rbase + r], Bc.f, iof == 0, LanePts<64>{pts + wv * (64 * 12) + lane}, &over);
+          // (round 5: the straight-line hull clip; what it flags takes the redo below)
+          const float v = hull_clip_fast<GEOM == 2>(rows[rbase + r], Bc.f, iof == 0, ClipLds<64>{pts + wv * (64 * 12) + lane}, over);
           if (!over) out[(size_t)(row0 + rbase + r) * n2 + col] = v;
         }
         unsigned long long m = __ballot(over);
@@ -774,6 +775,7 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
         const LanePts<64> lp{pts + wave * (64 * CAPS) + lane};  // wave-private [slot][lane] region
         if constexpr (GEOM == 1 && FAST) v = v1_clip_fast(A.f, B.f, iof != 0, ClipLds<64>{pts + wave * (64 * CAPS) + lane}, over);
         else if constexpr (GEOM == 1) v = v1_pair_lds<64, CAPS>(A.f, B.f, iof != 0, lp, &over);
+        else if constexpr (FAST) v = hull_clip_fast<GEOM == 2>(A.f, B.f, iof == 0, ClipLds<64>{pts + wave * (64 * CAPS) + lane}, over);
         else v = hull_pair_lds<GEOM == 2, 64, CAPS>(A.f, B.f, iof == 0, lp, &over);
       }
       if ((trips & 0xffff) == 0) { R3_DSTAMP(4) }
@@ -1041,7 +1043,7 @@ __global__ __launch_bounds__(256) void iou_vec_kernel(const float* __restrict__ 
       bool over = false;
       if (valid) {
         float v = 0.f;
-        if (!apart) v = hull_pair_lds<GEOM == 2, 64, 12>(A.f, B.f, iof == 0, LanePts<64>{pts + wave * (64 * 12) + lane}, &over);
+        if (!apart) v = hull_clip_fast<GEOM == 2>(A.f, B.f, iof == 0, ClipLds<64>{pts + wave * (64 * 12) + lane}, over);
         if (!over) out[i] = v;
       }
       unsigned long long m = __ballot(over);
@@ -1131,7 +1133,7 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
   // (round 5, straight-line clip: 4 waves per SIMD of registers => 4 workgroups per CU are resident; a larger grid's
   // second wave of workgroups pays the 6 us prefix / lookup / record-load preamble again: 1024 -> 23.4 us of stamps, 1536 -> 26.7)
-  const bool fast = GEOM == 1 && g_r3_clip_impl == 0;
+  const bool fast = g_r3_clip_impl == 0;
   const int maxb = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : fast ? 4 * r3_cu_count() : 1536;
   if (blocks > maxb) blocks = maxb;
   ColPrep P = ColPrep();
@@ -1147,8 +1149,8 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
                        L.tcount, L.slots, wcap, P);
   // (probes build: the stamp buffer named by the frn_stamps_lo / _hi options, shared with the FR gather's probe)
   unsigned long long* const dstamps = R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps.get()) : nullptr;
-  if (GEOM == 1 && g_r3_clip_impl == 0)
-    hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM == 1>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
+  if (g_r3_clip_impl == 0)
+    hipLaunchKernelGGL((iou_drain3_kernel<GEOM, true>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
                        L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps);
   else
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, false>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
@@ -1311,7 +1313,7 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
     else
       hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), sgrid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
                          (float*)nullptr, L.recsA, L.tcount, L.slots, wcap3, P);
-    const bool fast = GEOM == 1 && g_r3_clip_impl == 0;
+    const bool fast = g_r3_clip_impl == 0;
     unsigned long long pairs3 = (unsigned long long)n1 * n2;
     int blocks3 = (int)((pairs3 + T_THREADS - 1) / T_THREADS);
     const int maxb3 = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : fast ? 4 * r3_cu_count() : 1536;
@@ -1319,7 +1321,8 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
     const int n1_lds3 = n1 < 2048 ? n1 : 2048;
     const AssignOut ao{L.siou, L.rowkey, L.colkey, n1_lds3};
     if (fast)
-      hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM == 1, true>), dim3(blocks3), dim3(T_THREADS),
+      // (v3 with the keys as its result: the straight-line form spills 12 B per lane at 128 registers -- the list form there)
+      hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM != 3, true>), dim3(blocks3), dim3(T_THREADS),
                          (size_t)n1_lds3 * sizeof(u64k), stream, gts, n1, boxes, n2, 0, L.recsA, L.tcount, L.slots,
                          L.tiles_x, tiles, (float*)nullptr, prepared ? P.rec : (const BoxRec*)nullptr,
                          (unsigned long long*)nullptr, ao);

@@ -30,6 +30,7 @@ def harness(tmp_path_factory):
                     "-I" + CSRC, os.path.join(HERE, "native", "clip_harness.hip"), "-o", out], check=True)
     L = ctypes.CDLL(out)
     L.clip_fast_batch.argtypes = [F, F, ctypes.c_int, ctypes.c_int, F, U8]
+    L.hull_clip_fast_batch.argtypes = [F, F, ctypes.c_int, ctypes.c_int, ctypes.c_int, F, U8]
     return L
 
 
@@ -139,3 +140,88 @@ def test_degenerate_families_are_flagged_or_exact(harness):
     aa[::7, 0], aa[::11, 4], aa[::13, 2] = np.nan, np.inf, np.inf
     frac, _ = run(harness, aa, b)
     assert frac >= 1 / 7                     # non-finite boxes never take the straight-line form
+
+
+# ------------------------------------------------------------------------------------------------ hull geometry (v2 / v3)
+def hull_records(b):
+    """make_record<2 | 3> (csrc/r3_geom.h): centre, the four half products, w * h."""
+    b = np.ascontiguousarray(b, np.float32)
+    x, y, w, h, a = [b[:, k] for k in range(5)]
+    s, c = O.sincos(a)
+    half = np.float32(0.5)
+    with np.errstate(all="ignore"):
+        c2, s2 = c * half, s * half
+        r = np.empty((b.shape[0], 7), np.float32)
+        r[:, 0], r[:, 1] = x, y
+        r[:, 2], r[:, 3], r[:, 4], r[:, 5] = s2 * h, c2 * w, c2 * h, s2 * w
+        r[:, 6] = w * h
+    return r
+
+
+def run_hull(L, geom, b1, b2, iof=False):
+    n = b1.shape[0]
+    ra, rb = hull_records(b1), hull_records(b2)
+    out = np.empty(n, np.float32)
+    redo = np.empty(n, np.uint8)
+    L.hull_clip_fast_batch(ra.ctypes.data_as(F), rb.ctypes.data_as(F), n, int(geom == O.V2), int(not iof),
+                           out.ctypes.data_as(F), redo.ctypes.data_as(U8))
+    with O.twin():
+        want = O.iou_vec(geom, b1, b2, iof)
+    ok = redo == 0
+    same = (out.view(np.uint32) == want.view(np.uint32)) | (np.isnan(out) & np.isnan(want))
+    assert np.all(same[ok]), f"{np.sum(~same & ok)} unflagged pairs differ from the oracle"
+    return redo.mean(), want
+
+
+@pytest.mark.parametrize("geom", [O.V3, O.V2])
+def test_hull_clip_random_and_assignment_shaped(harness, geom):
+    a, b = near_pairs(300000, 1)
+    frac, want = run_hull(harness, geom, a, b)
+    assert np.mean(want > 0) > 0.5 and frac < 2e-3
+    if geom == O.V3:
+        run_hull(harness, geom, a, b, iof=True)
+    anc, gt = anchor_grid(), dota_like_gt(128, 3)
+    r = np.random.default_rng(5)
+    gi, ai = r.integers(0, 128, 800000), r.integers(0, anc.shape[0], 800000)
+    d = np.hypot(anc[ai, 0] - gt[gi, 0], anc[ai, 1] - gt[gi, 1])
+    m = d < (np.hypot(anc[ai, 2], anc[ai, 3]) + np.hypot(gt[gi, 2], gt[gi, 3])) / 2
+    frac, want = run_hull(harness, geom, gt[gi[m]], anc[ai[m]])
+    assert frac < 5e-3 and np.mean(want > 0) > 0.3
+
+
+@pytest.mark.parametrize("geom", [O.V3, O.V2])
+def test_hull_clip_degenerate_families(harness, geom):
+    r = np.random.default_rng(11)
+    n = 100000
+    ia = np.stack([r.integers(0, 64, n), r.integers(0, 64, n), r.integers(1, 32, n), r.integers(1, 32, n),
+                   np.zeros(n)], 1).astype(np.float32)
+    ib = np.stack([r.integers(0, 64, n), r.integers(0, 64, n), r.integers(1, 32, n), r.integers(1, 32, n),
+                   np.zeros(n)], 1).astype(np.float32)
+    run_hull(harness, geom, ia, ib)
+    a, b = near_pairs(100000, 7)
+    frac, _ = run_hull(harness, geom, a, a.copy())
+    assert frac == 1.0                       # identical boxes: every numerator is zero
+    for eps in (1e-3, 1e-1):
+        c = a.copy()
+        c[:, :4] += r.normal(0, eps, (n, 4)).astype(np.float32)
+        run_hull(harness, geom, a, c)
+    for sc in (1e-3, 1e-6, 1e4, 1e8, 1e14, 1e-20):
+        aa, bb = a.copy(), b.copy()
+        aa[:, :4] *= sc
+        bb[:, :4] *= sc
+        run_hull(harness, geom, aa, bb)
+    aa, bb = a.copy(), b.copy()
+    aa[:, :2] += 1e5
+    bb[:, :2] += 1e5
+    run_hull(harness, geom, aa, bb)
+    aa, bb = a.copy(), b.copy()
+    aa[:, 3], bb[:, 2] = 0.01, 0.05
+    run_hull(harness, geom, aa, bb)
+    aa[:, 3] = 0
+    run_hull(harness, geom, aa, bb)          # zero height: area < 1e-14 => 0
+    aa = a.copy()
+    aa[:, 2] *= -1
+    run_hull(harness, geom, aa, b)
+    aa = a.copy()
+    aa[::7, 0], aa[::11, 4], aa[::13, 2] = np.nan, np.inf, np.inf
+    run_hull(harness, geom, aa, b)
