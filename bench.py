@@ -687,6 +687,8 @@ def main():
     from r3det import _C
     from r3det import dist_infer as di
     _C.lib()  # fail loudly if the HIP library is missing
+    if os.environ.get("R3DET_NMS_IMPL"):  # (tools/nms_reducer_ab.sh: the reducer form of the batched NMS)
+        _C.set_option("nms_impl", int(os.environ["R3DET_NMS_IMPL"]))
     rank, local_rank, world = di.env_world()
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")

@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* 
 //     an iteration is a handful of scalar instructions, not a barrier;
 //   * rows with more than EL suppressors also scan their overflow row of the transposed mask.
 // Greedy NMS in score order has ONE answer (row kept <=> no kept suppressor), so the result is the rounds reducer's.
-constexpr int WALK_MAXN = 12288;  // rows per image (static LDS: 2 x u16 per row + the kept bits + one block's lists = 55 KB)
+constexpr int WALK_MAXN = 12288;  // rows per image (static LDS: 2 x u16 per row + the kept bits = 51 KB)
 
 __global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restrict__ maskT, u64* __restrict__ side, int cb,
                                                              const unsigned* __restrict__ counter,
@@ -1346,7 +1346,6 @@ __global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restri
   __shared__ u64 Kb[WALK_MAXN / 64];
   __shared__ unsigned short posmap[WALK_MAXN];
   __shared__ unsigned short rows_l[WALK_MAXN];
-  __shared__ __attribute__((aligned(16))) uint4 el4[64][4];
   const int img = blockIdx.z, group = blockIdx.x, lane = threadIdx.x;
   const int n = bt.counts[img];
   const bool grouped = gridDim.x > 1 && bt.rlab && counter[img * bt.counter + Q_XFLAG] == 0u;
@@ -1364,66 +1363,109 @@ __global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restri
   // ---- the group's rows, ascending, and each row's position among them
   int m = 0;
   if (grouped) {
-    for (int base = 0; base < n; base += 256) {  // (four independent byte loads in flight)
-      unsigned char lb[4];
+    // every label of the image is requested at once -- a lane takes four consecutive rows of every 256 -- and only then
+    // looked at (a loop with its loads inside is one memory round trip per 256 rows: 34 us at n = 8576)
+    constexpr int KMAX = WALK_MAXN / 256;
+    unsigned lb[KMAX];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int r = base + u * 64 + lane;
-        lb[u] = r < n ? rlab[r] : (unsigned char)0xff;
+    for (int u = 0; u < KMAX; u++) {
+      const int r4 = u * 256 + 4 * lane;
+      lb[u] = r4 < n ? *reinterpret_cast<const unsigned*>(rlab + r4) : 0xffffffffu;  // (rows are padded to 64: in bounds)
+    }
+#pragma unroll
+    for (int u = 0; u < KMAX; u++) {
+      if (u * 256 >= n) break;
+      const int r4 = u * 256 + 4 * lane;
+      bool mine[4];
+      int cl4 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        mine[k] = (r4 + k < n) && (int)((lb[u] >> (8 * k)) & (RG_GROUPS - 1)) == group;
+        cl4 += mine[k] ? 1 : 0;
       }
+      int incl = cl4;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int r = base + u * 64 + lane;
-        const bool mine = r < n && (lb[u] & (RG_GROUPS - 1)) == group;
-        const u64 mk = __ballot(mine);
-        if (mine) {
-          const int k = m + __popcll(mk & below);
-          rows_l[k] = (unsigned short)r;
-          posmap[r] = (unsigned short)k;
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      int pos = m + incl - cl4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (mine[k]) {
+          rows_l[pos] = (unsigned short)(r4 + k);
+          posmap[r4 + k] = (unsigned short)pos;
+          pos++;
         }
-        m += __popcll(mk);
       }
+      m += __shfl(incl, 63);
     }
   } else {
     m = n;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS only: a fence would also wait for the NEXT block's loads)
   __builtin_amdgcn_wave_barrier();
-  const unsigned short* el = reinterpret_cast<const unsigned short*>(&el4[lane][0]);
-  for (int t0 = 0; t0 < m; t0 += 64) {
+  // A block's loads -- the row's count, its best suppressor, its 64-byte list -- depend on the row only: the NEXT block's
+  // are issued before this block is resolved, so a block costs the resolution, not three memory round trips.
+  struct Blk {
+    int r, c, i0;
+    bool valid;
+    uint4 l[4];
+  };
+  auto load_blk = [&](const int t0) {
+    Blk b;
     const int k = t0 + lane;
-    const bool valid = k < m;
-    const int r = valid ? (grouped ? (int)rows_l[k] : k) : 0;
-    const int firstrow = grouped ? (int)rows_l[t0] : t0;  // suppressors below it are final
-    int c = 0;
-    bool rem = false;
-    if (valid) {
-      c = sd.ecnt[r];
-      if (c > 0) {
-        // the highest-scored suppressor first: it is very often the kept head of the row's cluster, and a row it
-        // removes needs neither its list nor its overflow row
-        const int i0 = 65535 - sd.msup[r];
-        if (i0 < firstrow) rem = (Kb[i0 >> 6] >> (i0 & 63)) & 1ULL;
-        if (rem) c = 0;
-      }
-      if (c > 0) {
-        const uint4* src = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
-        const int quads = (min(c, EL) + 7) >> 3;
+    b.valid = k < m;
+    b.r = b.valid ? (grouped ? (int)rows_l[k] : k) : 0;
+    b.c = 0;
+    b.i0 = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-          if (q < quads) el4[lane][q] = src[q];
-      }
+    for (int q = 0; q < 4; q++) b.l[q] = make_uint4(0u, 0u, 0u, 0u);
+    if (b.valid) {
+      b.c = sd.ecnt[b.r];
+      b.i0 = 65535 - sd.msup[b.r];
+      const uint4* src = reinterpret_cast<const uint4*>(sd.elist + (size_t)b.r * EL);
+#pragma unroll
+      for (int q = 0; q < 4; q++) b.l[q] = src[q];  // (a row's 64 bytes: entries beyond its count are stale, never read)
+    }
+    return b;
+  };
+  Blk nxt = load_blk(0);
+  for (int t0 = 0; t0 < m; t0 += 64) {
+    const Blk cur = nxt;
+    if (t0 + 64 < m) nxt = load_blk(t0 + 64);
+    const bool valid = cur.valid;
+    const int r = cur.r;
+    const int firstrow = grouped ? (int)rows_l[t0] : t0;  // suppressors below it are final
+    int c = cur.c;
+    bool rem = false;
+    if (valid && c > 0) {
+      // the highest-scored suppressor first: it is very often the kept head of the row's cluster, and a row it
+      // removes needs neither its list nor its overflow row
+      if (cur.i0 < firstrow) rem = (Kb[cur.i0 >> 6] >> (cur.i0 & 63)) & 1ULL;
+      if (rem) c = 0;
     }
     const int cl = min(c, EL);
     int maxc = cl;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
     u64 D = 0;
-    for (int e = 0; e < maxc; e++) {
-      if (e < cl) {
-        const int i = el[e];
-        if (i < firstrow) rem |= (Kb[i >> 6] >> (i & 63)) & 1ULL;
-        else D |= 1ULL << ((grouped ? (int)posmap[i] : i) - t0);
+    // the list from registers, eight entries (one 16-byte quad) per wave-uniform step: the LDS lookups of a step do not
+    // depend on each other
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (maxc <= q * 8) break;
+      const unsigned w4[4] = {cur.l[q].x, cur.l[q].y, cur.l[q].z, cur.l[q].w};
+#pragma unroll
+      for (int h = 0; h < 8; h++) {
+        const int e = q * 8 + h;
+        const int i = min((int)((h & 1) ? (w4[h >> 1] >> 16) : (w4[h >> 1] & 0xffffu)), n - 1);
+        const bool early = (Kb[i >> 6] >> (i & 63)) & 1ULL;
+        const int pl = (grouped ? (int)posmap[i] : i) - t0;
+        if (e < cl) {
+          if (i < firstrow) rem |= early;
+          else D |= 1ULL << (pl & 63);
+        }
       }
     }
     // the suppressors beyond the list (rows of dense clusters the shortcut did not settle): row r of the transposed
@@ -1477,7 +1519,7 @@ __global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restri
         atomicOr(&fbits[cand >> 6], 1ULL << (cand & 63));
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS only: a fence would also wait for the NEXT block's loads)
     __builtin_amdgcn_wave_barrier();
   }
   for (int w = lane; w < cbn; w += 64) {

@@ -18,6 +18,8 @@ from r3det import _C  # noqa: E402
 
 if os.environ.get("NMS_PROF_clip_impl"):  # A/B: 1 = the LDS-list clip of rounds 2-4
     _C.set_option("clip_impl", int(os.environ["NMS_PROF_clip_impl"]))
+if os.environ.get("NMS_PROF_nms_impl"):   # A/B: 4 = the walk reducer
+    _C.set_option("nms_impl", int(os.environ["NMS_PROF_nms_impl"]))
 
 sizes = [os.environ["NMS_PROF_N"]] if os.environ.get("NMS_PROF_N") else [2000, 5344, 8576]
 for n in sizes:
