@@ -140,12 +140,20 @@ def host_results(out, num_classes=15):
     return res
 
 
-def device_time_ms(fn, reps=10, lead_ms=4.0):
+def device_time_ms(fn, reps=10, lead_ms=None):
     """GPU time of ``fn`` per call with the HOST out of the picture: a spin kernel keeps the stream busy while the
     host enqueues `reps` calls, so the device runs them back to back; events around them.  (The wall figure of a
-    launch-wait-launch loop next to it says how much of an operator's time is the host's.)"""
+    launch-wait-launch loop next to it says how much of an operator's time is the host's.)  The spin lasts 1.5 x what
+    the host needed for the same `reps` calls a moment before, so the queue cannot run dry behind it."""
     fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    host_ms = (time.perf_counter() - t0) * 1e3  # (enqueue time only: no synchronize inside)
+    torch.cuda.synchronize()
+    if lead_ms is None:
+        lead_ms = max(2.0, 1.5 * host_ms)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda._sleep(int(lead_ms * 2.0e6))  # (~2 GHz cycles)
     s.record()
@@ -373,7 +381,7 @@ def op_rates(device):
                                    ("iou_v3_1000x128", obb_overlaps, a, g, 50)):
         dt = timeit(lambda: fn(b1, b2), reps)
         m, n = b1.size(0), b2.size(0)
-        dev_us = device_time_ms(lambda: fn(b1, b2), reps=10, lead_ms=2.0) * 1e3  # GPU time, the host out of the picture
+        dev_us = device_time_ms(lambda: fn(b1, b2), reps=10) * 1e3  # GPU time, the host out of the picture
         out[name] = {"Mpairs_s": round(m * n / dt / 1e6, 1), "us_per_call": round(dt * 1e6, 2),
                      "us_per_call_device": round(dev_us, 2),
                      "alg_bytes": b_iou(m, n), "roofline": _roof(b_iou(m, n), dt),

@@ -193,17 +193,17 @@ def test_module_training_channels_last():
     m1 = m1.to(memory_format=CL)
     xs = [torch.randn(N, C, h, w, device='cuda') for h, w in sizes]
     rois = [[dev(fr_boxes(1, h, w, s, 10 * i + s)) for (h, w), s in zip(sizes, strides)] for i in range(N)]
-    # (the levels node: one channels_last library call for the samplers of both levels, the gradients come back
-    # channels_last from the _nhwc gathers)
+    # (the levels node -- round 5: the module's TAIL of both levels, add + samplers + residual add, as ONE channels_last
+    # library call; the gradients come back channels_last from the _nhwc gathers)
     calls = []
-    real = M.fr_forward_levels_nhwc
-    M.fr_forward_levels_nhwc = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    real = M.fr_module_levels_nhwc
+    M.fr_module_levels_nhwc = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     try:
         x1 = [x.contiguous(memory_format=CL).requires_grad_(True) for x in xs]
         o1 = m1(x1, rois)
         sum((o * (i + 1)).sum() for i, o in enumerate(o1)).backward()
     finally:
-        M.fr_forward_levels_nhwc = real
+        M.fr_module_levels_nhwc = real
     assert len(calls) == 1 and all(o.is_contiguous(memory_format=CL) for o in o1)
     assert all(x.grad.is_contiguous(memory_format=CL) for x in x1)
     x2 = [x.clone().requires_grad_(True) for x in xs]
