@@ -99,6 +99,14 @@ class RRetinaNet(_Detector):
         cls, reg = self.bbox_head(x)
         return self.bbox_head.get_bboxes(cls, reg, img.shape[-2:], self.test_cfg)
 
+    @torch.no_grad()
+    def dense_test(self, img):
+        """Network + decoding + per-level pool (static shapes, no host synchronisation): what GraphedDense /
+        GraphedStep record; the multiclass NMS follows (rretinanet.py:23-46)."""
+        x = self.extract_feat(img)
+        cls, reg = self.bbox_head(x)
+        return self.bbox_head.decode_bboxes(cls, reg, img.shape[-2:], self.test_cfg)
+
 
 class R3Det(_Detector):
     """num_refine_stages x (FeatureRefineModule -> RRetinaRefineHead) after the base head;
@@ -207,7 +215,7 @@ class GraphedDense:
         torch.cuda.current_stream(example.device).wait_stream(side)
         torch.cuda.synchronize(example.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):  # (RCCL's watchdog thread may query events meanwhile)
             self.static_out = model.dense_test(self.static_in)
 
     @torch.no_grad()
@@ -267,7 +275,7 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):  # (RCCL's watchdog thread may query events meanwhile)
             boxes, scores = self.model.dense_test(self.static_in)
             self.static_out = self.nms(boxes.contiguous(), scores.contiguous())
 

@@ -29,6 +29,24 @@ gp, gc = di.gather_detections(packed, counts)
 assert len(gp) == 1 and torch.equal(gp[0], packed) and gc[0].tolist() == [5, 0]
 assert abs(di.max_over_ranks(1.25, device) - 1.25) < 1e-12
 di.barrier(device)
+# round 5: the whole inference step as one HIP graph, recorded while the process group is alive, and the step's exchange
+# on the buffer the graph wrote (gather_padded -> all_gather_into_tensor over RCCL)
+from r3det.models.detectors import GraphedStep, calibrate_score_bias  # noqa: E402
+torch.manual_seed(5)
+infer = R3Det().eval().to(device)
+im = torch.randn(2, 3, 256, 256, device=device)
+calibrate_score_bias(infer, im, frac=0.02, per_class=True)
+gstep = GraphedStep(infer, im)
+for _ in range(3):
+    out, redo = gstep.step(im)
+    everyone = di.gather_padded(out)
+    assert not redo and everyone.shape == out.shape
+torch.cuda.synchronize()
+assert torch.equal(everyone, out)
+gpk, gcn = di.split_gathered(everyone, 2)
+assert len(gpk) == 1 and gcn[0].tolist() == [int(c) for c in out[:, -1, 0].tolist()] and min(gcn[0].tolist()) > 0
+di.barrier(device)
+del infer, gstep
 # training: DDP over RCCL, one step on a tiny batch
 from test_train_cpu import tiny_batch  # noqa: E402
 torch.manual_seed(7)
