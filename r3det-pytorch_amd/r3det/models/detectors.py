@@ -94,10 +94,11 @@ class RRetinaNet(_Detector):
         return self.bbox_head.loss(cls, reg, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
 
     @torch.no_grad()
-    def simple_test(self, img):
-        x = self.extract_feat(img)
-        cls, reg = self.bbox_head(x)
-        return self.bbox_head.get_bboxes(cls, reg, img.shape[-2:], self.test_cfg)
+    def simple_test(self, img, img_metas=None, rescale=False):
+        """``simple_test(img, img_metas, rescale=False)`` (rretinanet.py:23-46): with ``img_metas`` the reference's return
+        value (per image a list over classes of (k, 6) ndarrays); without, (dets, labels) tensors per image."""
+        boxes, scores = self.dense_test(img)
+        return _test_results(self.bbox_head, boxes, scores, self.test_cfg, img_metas, rescale, self.bbox_head.nms_hint)
 
     @torch.no_grad()
     def dense_test(self, img):
@@ -106,6 +107,26 @@ class RRetinaNet(_Detector):
         x = self.extract_feat(img)
         cls, reg = self.bbox_head(x)
         return self.bbox_head.decode_bboxes(cls, reg, img.shape[-2:], self.test_cfg)
+
+
+def _test_results(head, boxes, scores, cfg, img_metas, rescale, hint):
+    """The tail of the reference's ``simple_test`` (models/detectors/r3det.py:136-143, rretinanet.py:38-46) on the dense
+    outputs: ``rescale`` divides cx, cy, w, h by the image's ``scale_factor`` BEFORE the NMS (``_get_bboxes_single``,
+    rotate_anchor_head.py:657-660: the angle is not rescaled); with ``img_metas`` the detections leave as the
+    reference returns them -- per image a list over the classes of (k, 6) float32 ndarrays (``rbbox2result``); without
+    (this package's callers: bench, tests) as (dets, labels) tensors on the device."""
+    if rescale:
+        if img_metas is None:
+            raise ValueError('rescale=True needs img_metas with scale_factor')
+        sf = torch.stack([boxes.new_tensor(m['scale_factor']).expand(4) if torch.as_tensor(m['scale_factor']).numel() == 1
+                          else boxes.new_tensor(m['scale_factor']).reshape(4) for m in img_metas])
+        boxes = boxes.clone()
+        boxes[..., :4] = boxes[..., :4] / sf[:, None, :]
+    res = multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'], hint=hint)
+    if img_metas is None:
+        return res
+    from ..core.bbox.rtransforms import rbbox2result
+    return [rbbox2result(d, lab, head.num_classes) for d, lab in res]
 
 
 class R3Det(_Detector):
@@ -174,11 +195,12 @@ class R3Det(_Detector):
         return losses
 
     @torch.no_grad()
-    def simple_test(self, img):
+    def simple_test(self, img, img_metas=None, rescale=False):
+        """``simple_test(img, img_meta, rescale=False)`` (models/detectors/r3det.py:112-143): with ``img_metas`` the
+        reference's return value (per image a list over classes of (k, 6) ndarrays); without, (dets, labels) tensors."""
         boxes, scores = self.dense_test(img)
-        cfg = self.test_cfg
-        return multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'],
-                                            hint=self.refine_head[-1].nms_hint)
+        return _test_results(self.refine_head[-1], boxes, scores, self.test_cfg, img_metas, rescale,
+                             self.refine_head[-1].nms_hint)
 
     @torch.no_grad()
     def dense_test(self, img):

@@ -445,3 +445,39 @@ def test_graphed_step_recovers_from_a_short_capacity():
             break
     assert redone and g.nms.cap > 64
     assert int(out[0, -1, 0]) >= short and int(g.nms.overflow[0]) == 0
+
+
+@pytest.mark.gpu
+def test_simple_test_with_img_metas_returns_what_the_reference_returns():
+    """``simple_test(img, img_metas, rescale)`` (models/detectors/r3det.py:112-143): per image a list over the classes of
+    (k, 6) float32 ndarrays (rbbox2result); rescale divides cx, cy, w, h by scale_factor BEFORE the NMS
+    (rotate_anchor_head.py:657-660), the angle stays."""
+    import numpy as np
+
+    from r3det.core.post_processing import multiclass_nms_rotated
+    from r3det.models import R3Det
+    from r3det.models.detectors import calibrate_score_bias
+    torch.manual_seed(13)
+    dev = torch.device('cuda')
+    m = R3Det().eval().to(dev)
+    img = torch.randn(2, 3, 256, 256, device=dev)
+    calibrate_score_bias(m, img, frac=0.02, per_class=True)
+    metas = [dict(img_shape=(256, 256, 3), scale_factor=np.array([2.0, 2.0, 2.0, 2.0], np.float32)),
+             dict(img_shape=(256, 256, 3), scale_factor=0.5)]
+    res = m.simple_test(img, metas)          # the structure the reference returns
+    assert len(res) == 2 and all(len(r) == 15 for r in res)
+    assert all(a.dtype == np.float32 and a.shape[1] == 6 for r in res for a in r) and sum(a.shape[0] for a in res[0]) > 0
+    # the values, on ONE set of dense outputs (two passes of the network differ in their last bits: MIOpen's atomics)
+    from r3det.models.detectors import _test_results
+    boxes, scores = m.dense_test(img)
+    cfg, head = m.test_cfg, m.refine_head[-1]
+    for rescale in (False, True):
+        got = _test_results(head, boxes, scores, cfg, metas, rescale, None)
+        for i, sf in enumerate((2.0, 0.5)):
+            b = boxes[i].clone()
+            if rescale:
+                b[:, :4] = b[:, :4] / sf     # (before the NMS; the angle stays: rotate_anchor_head.py:657-660)
+            d, lab = multiclass_nms_rotated(b, scores[i], cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+            assert d.size(0) > 0 and sum(a.shape[0] for a in got[i]) == d.size(0)
+            for c, a in enumerate(got[i]):
+                assert np.array_equal(a, d[lab == c].cpu().numpy())
