@@ -37,10 +37,13 @@ def cpu_kernels(twin=False):
     IoU to the HIP path: needed when exact ties between anchors decide the assignment)."""
     import r3det.core.bbox.iou_calculators.rotate_iou2d_calculator as calc
     import r3det.ops.feature_refine as frm
-    saved = calc.rbbox_iou, frm.feature_refine, frm.feature_refine_levels
+    saved = calc.rbbox_iou, frm.feature_refine, frm.feature_refine_levels, frm.feature_refine_module_levels
     calc.rbbox_iou, frm.feature_refine, frm.feature_refine_levels = _rbbox_iou, _feature_refine, _feature_refine_levels
+    # (round 5: the module's tail as one node -- on the CPU the same three steps in plain torch)
+    frm.feature_refine_module_levels = lambda a, b, x, boxes, scales, points=1: [
+        xi + o for xi, o in zip(x, _feature_refine_levels([ai + bi for ai, bi in zip(a, b)], boxes, scales, points))]
     try:
         with (O.twin() if twin else contextlib.nullcontext()):
             yield
     finally:
-        calc.rbbox_iou, frm.feature_refine, frm.feature_refine_levels = saved
+        calc.rbbox_iou, frm.feature_refine, frm.feature_refine_levels, frm.feature_refine_module_levels = saved
