@@ -913,45 +913,62 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         xs[u] = 0;
         xl[u] = 0;
         u64 need = __ballot(state[u] == 0 && c[u] > EL);
+        // (round 5: the rows' mask words are requested EIGHT ROWS AT A TIME and each row's first 64 words are read once --
+        // the dense class of the bench model's pool has 71 such rows in one group, 18 per wavefront, and two dependent
+        // passes per row, one row after the other, were 45 us of the kernel's 65)
         while (need) {
-          const int src = __builtin_ctzll(need);
-          need &= need - 1;
-          const int r = __builtin_amdgcn_readlane(rr[u], src);
-          const u64* row = maskT + (size_t)r * cb;
-          const int nw = (r >> 6) + 1;
-          int base = 0, total = 0;
-          for (int w0 = 0; w0 < nw; w0 += 64) {  // (first pass: the number of entries)
-            const u64 wd = (w0 + lane < nw) ? row[w0 + lane] : 0ULL;
-            int pc = __popcll(wd);
+          constexpr int OB = 8;
+          int srcl[OB], rowi[OB];
+          u64 w0d[OB];
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
-            total += pc;
+          for (int b = 0; b < OB; b++) {
+            srcl[b] = need ? __builtin_ctzll(need) : -1;
+            need &= need - 1;  // (0 stays 0)
+            rowi[b] = srcl[b] >= 0 ? __shfl(rr[u], srcl[b]) : 0;
+            const u64* row = maskT + (size_t)rowi[b] * cb;
+            w0d[b] = (srcl[b] >= 0 && lane <= (rowi[b] >> 6)) ? row[lane] : 0ULL;
           }
-          if (lane == 0) base = atomicAdd(s_nbig, total);
-          base = __builtin_amdgcn_readfirstlane(base);
-          const bool fits = base + total <= R_BLIST;
-          if (fits) {
-            int at = base;
-            for (int w0 = 0; w0 < nw; w0 += 64) {
-              u64 wd = (w0 + lane < nw) ? row[w0 + lane] : 0ULL;
-              const int pc = __popcll(wd);
-              int incl = pc;
 #pragma unroll
-              for (int d = 1; d < 64; d <<= 1) {
-                const int v = __shfl_up(incl, d);
-                if (lane >= d) incl += v;
-              }
-              int o = at + incl - pc;
-              while (wd) {
-                ext[o++] = (unsigned short)((w0 + lane) * 64 + __builtin_ctzll(wd));
-                wd &= wd - 1;
-              }
-              at += __builtin_amdgcn_readlane(incl, 63);
+          for (int b = 0; b < OB; b++) {
+            if (srcl[b] < 0) break;  // (wave-uniform)
+            const int r = rowi[b];
+            const u64* row = maskT + (size_t)r * cb;
+            const int nw = (r >> 6) + 1;
+            int total = 0;
+            for (int w0 = 0; w0 < nw; w0 += 64) {  // (the number of entries; words 64.. only for rows beyond 4096)
+              const u64 wd = w0 == 0 ? w0d[b] : ((w0 + lane < nw) ? row[w0 + lane] : 0ULL);
+              int pc = __popcll(wd);
+#pragma unroll
+              for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
+              total += pc;
             }
-          }
-          if (lane == src) {
-            xs[u] = fits ? base : -1;
-            xl[u] = total;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(s_nbig, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const bool fits = base + total <= R_BLIST;
+            if (fits) {
+              int at = base;
+              for (int w0 = 0; w0 < nw; w0 += 64) {
+                u64 wd = w0 == 0 ? w0d[b] : ((w0 + lane < nw) ? row[w0 + lane] : 0ULL);
+                const int pc = __popcll(wd);
+                int incl = pc;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                  const int v = __shfl_up(incl, d);
+                  if (lane >= d) incl += v;
+                }
+                int o = at + incl - pc;
+                while (wd) {
+                  ext[o++] = (unsigned short)((w0 + lane) * 64 + __builtin_ctzll(wd));
+                  wd &= wd - 1;
+                }
+                at += __builtin_amdgcn_readlane(incl, 63);
+              }
+            }
+            if (lane == srcl[b]) {
+              xs[u] = fits ? base : -1;
+              xl[u] = total;
+            }
           }
         }
       }

@@ -16,6 +16,7 @@ model, img = bench.build_model(dev, 100, spread=os.environ.get("POOL_SPREAD", "1
 boxes, scores = model.dense_test(img)
 b, s = boxes[0], scores[0, :, :-1]
 tot, over, depth_max, ecs = 0, 0, 0, []
+rounds_all, und_tot = [], {}
 for c in range(s.size(1)):
     idx = torch.nonzero(s[:, c] > 0.05).squeeze(1)
     if idx.numel() == 0:
@@ -42,9 +43,31 @@ for c in range(s.size(1)):
         keptc[j] = not bool(keptc[si].any())
         depthc[j] = int(depthc[si].max()) + 1
     depth_max = max(depth_max, int(depthc.max()))
+    # the round reducer's own schedule: a row is removed once a suppressor is known kept, kept once all are known removed
+    state = torch.zeros(m, dtype=torch.int8)  # 0 undecided, 1 kept, 2 removed
+    supf = supc.float()
+    und_after = {}
+    for rnd in range(1, 200):
+        keptv, remv = (state == 1).float(), (state == 2).float()
+        any_kept = (supf * keptv[:, None]).sum(0) > 0
+        all_rem = (supf * (1 - remv)[:, None]).sum(0) == 0
+        new = state.clone()
+        new[(state == 0) & any_kept] = 2
+        new[(state == 0) & ~any_kept & all_rem] = 1
+        state = new
+        und = int((state == 0).sum())
+        if rnd in (4, 8, 16, 32):
+            und_after[rnd] = und
+        if und == 0:
+            break
+    rounds_all.append(rnd)
+    for k_ in (4, 8, 16, 32):
+        und_tot[k_] = und_tot.get(k_, 0) + und_after.get(k_, 0)
     if c < 3:
         print(f"class {c}: {m} candidates, kept {int(keptc.sum())}, suppressors per row mean {float(ec.float().mean()):.1f} max {int(ec.max())}, "
               f"rows > 32: {int((ec > 32).sum())}, dependency depth {int(depthc.max())}")
 ec = torch.cat(ecs).float()
 print(f"image 0: {tot} candidates; suppressors per row mean {float(ec.mean()):.1f}, median {float(ec.median()):.0f}, 90 % {float(ec.quantile(0.9)):.0f}, "
       f"max {int(ec.max())}; rows with > 32: {over} ({over / tot:.1%}); deepest dependency chain {depth_max}")
+print(f"dependency rounds per class until every row is decided: max {max(rounds_all)}, mean {sum(rounds_all) / len(rounds_all):.1f}; "
+      f"rows still undecided after 4 / 8 / 16 / 32 rounds (all classes): {und_tot.get(4, 0)} / {und_tot.get(8, 0)} / {und_tot.get(16, 0)} / {und_tot.get(32, 0)}")

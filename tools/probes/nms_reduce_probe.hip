@@ -8,7 +8,17 @@
 #include <cmath>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
-int g_r3_nms_impl = 0, g_r3_nms_qcap = 0;
+R3Option g_r3_nms_impl{0}, g_r3_nms_qcap{0}, g_r3_clip_impl{0};
+int r3_cu_count() { return 256; }
+namespace {
+__global__ void probe_zero_kernel(unsigned* p, size_t words) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+int r3k_zero_async(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes) hipLaunchKernelGGL(probe_zero_kernel, dim3(1024), dim3(256), 0, stream, (unsigned*)p, bytes / 4);
+  return 0;
+}
 static float urand() { return (float)(rand() % 1000003) / 1000003.f; }
 static float nrand() { return sqrtf(-2.f * logf(urand() + 1e-7f)) * cosf(6.2831853f * urand()); }
 int main(int argc, char** argv) {
