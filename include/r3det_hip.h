@@ -527,7 +527,10 @@ int r3det_bias_act(float* y, const float* bias, const float* residual, long long
  *   pipeline's reducer as a walk in score order, one wavefront per image and label group),
  *   ("nms_qcap", n: entries per queue region, small values force the redo-tile path),
  *   ("clip_impl", 0 the straight-line v1 pair clip of the drains (round 5, csrc/r3_clip.h) | 1 the LDS-list form of
- *                 rounds 2-4: same results bit for bit, kept for the A/B in tools/clip_ab.sh).
+ *                 rounds 2-4: same results bit for bit, kept for the A/B in tools/clip_ab.sh),
+ *   ("iou_order", -1 every workgroup of the matrix stream kernel zeroes its tile before its tests | b in 0..30: those
+ *                 with bit b of their linear index set, the others after their tests | 31 all after; same results,
+ *                 tools/iou_order_ab.sh).
  * Thread safety: the switches are process-wide relaxed atomics, each read once per operator call -- a call sees one
  * consistent value of every switch it reads, whichever thread sets them; a caller that needs "this call with that
  * setting" still has to order the two itself.

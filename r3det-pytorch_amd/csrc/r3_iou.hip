@@ -379,9 +379,11 @@ constexpr int P_MAX_TILES = 16384;     // beyond: the one-launch form (a group w
 // |angle| < 64; larger finite angles use the circle's AABB; non-finite angles give NaN = "never apart")
 __device__ __forceinline__ void reject_data(const float x, const float y, const float w, const float h, const float a,
                                             float& rad, float& ex, float& ey) {
-  rad = r3_radius(x, y, w, h);
-  const float aw = 0.5f * fabsf(w), ah = 0.5f * fabsf(h);
+  // (r3_radius with the hardware square root: 1 ulp against the 1e-3 inflation, a denormal sum of squares against the
+  // absolute 1e-6 -- the correctly rounded sqrtf is ~20 instructions, 5 of them per thread were a third of the prologue)
   const float slack = 2e-6f * (fabsf(x) + fabsf(y)) + 1e-6f;
+  rad = 0.5f * __builtin_amdgcn_sqrtf(w * w + h * h) * 1.001f + slack;
+  const float aw = 0.5f * fabsf(w), ah = 0.5f * fabsf(h);
   if (fabsf(a) < 64.f) {
     const float ac = fabsf(__cosf(a)) + 1e-3f, as = fabsf(__sinf(a)) + 1e-3f;
     ex = (ac * aw + as * ah) * 1.001f + slack;
@@ -465,8 +467,10 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
                                                                 float* __restrict__ out, BoxRec* __restrict__ recsA,
                                                                 int* __restrict__ tcount,
                                                                 unsigned short* __restrict__ slots, int wcap,
-                                                                const ColPrep prep = ColPrep()) {
-  __shared__ __attribute__((aligned(16))) float rows[P_ROWS][8];  // cx, cy, rad, ex, ey
+                                                                const ColPrep prep = ColPrep(), const int probe = 0, const int order = -1) {
+  // (probe: probes build only, tools/iou_stream_phases.sh -- 1 leave after the zeros, 2 after the prologue, 3 before the
+  // queue flush: what each part of the kernel adds to the plain fill)
+  __shared__ __attribute__((aligned(16))) float rows[P_ROWS][12];  // cx, cy, rad, ex, ey, -, -, -, cx - ex, cx + ex, cy - ey, cy + ey
   __shared__ unsigned short queue[4 * P_WSEG];
   __shared__ int wcount[4];
   const int tid = threadIdx.x;
@@ -479,18 +483,41 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   const int col0 = colbase + tid * T_CPT;
   const int row0 = blockIdx.y * P_ROWS;
   const int nrows = min(P_ROWS, n1 - row0);
+  // Round 5: the tile's zeros go out EARLY and unconditionally -- their addresses depend on the block index alone, so
+  // they drain while the boxes are tested (they used to wait behind each row's tests).  A surviving pair's element is
+  // zeroed too: the drain, a later launch, overwrites it.  They are issued right AFTER the box loads: gfx9 counts
+  // loads and stores in one in-order vmcnt, so a load issued behind the stores waits for all of them to be
+  // acknowledged (measured, tools/iou_stream_phases.sh: stores first = fill 14.2 + prologue 2.8 + row loop 4.4 us,
+  // nothing overlapped).
+  // order: -1 every workgroup stores early; 0..30 the workgroups whose linear index has that bit set store early and
+  // the others after their tests (so a CU holds both kinds: one kind's stores run under the other's tests); 31 all late
+  const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool early = order < 0 || ((lin >> order) & 1u);
+  auto zero_tile = [&](const bool late) {
+    if (!late) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads have landed, nothing below waits on vmcnt again
+    if (!out || late == early || (R3_HAS_PROBES && probe >= 16)) return;  // (probe 16 + p: phase p without the zeros)
+    if (VEC && col0 + T_CPT <= n2) {
+#pragma unroll
+      for (int r = 0; r < P_ROWS; r++)
+        if (r < nrows) *reinterpret_cast<float4*>(out + (size_t)(row0 + r) * n2 + col0) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int r = 0; r < P_ROWS; r++)
+#pragma unroll
+        for (int c = 0; c < T_CPT; c++)
+          if (r < nrows && col0 + c < n2) out[(size_t)(row0 + r) * n2 + col0 + c] = 0.f;
+    }
+  };
+  float rowraw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (tid < nrows) {
     const float* b = b1 + (size_t)(row0 + tid) * 5;
-    const float x = b[0], y = b[1];
-    float rad, ex, ey;
-    reject_data(x, y, b[2], b[3], b[4], rad, ex, ey);
-    rows[tid][0] = x; rows[tid][1] = y; rows[tid][2] = rad; rows[tid][3] = ex; rows[tid][4] = ey;
+#pragma unroll
+    for (int k = 0; k < 5; k++) rowraw[k] = b[k];
   }
-  // the exact row records for the drain kernel: written once, by the middle column tile's workgroups
-  if (blockIdx.x == gridDim.x / 2 && tid >= 64 && tid < 64 + nrows) {
-    BoxRec rec;
-    make_record<GEOM>(b1 + (size_t)(row0 + tid - 64) * 5, 0.f, rec);
-    recsA[row0 + tid - 64] = rec;
+  if (R3_HAS_PROBES && (probe & 15) == 1) {
+    zero_tile(false);
+    if (tid == 0) tcount[blockIdx.y * gridDim.x + bx] = 0;
+    return;
   }
   float cx[T_CPT], cy[T_CPT], cr[T_CPT], cex[T_CPT], cey[T_CPT];
   bool cvalid[T_CPT];
@@ -508,6 +535,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
       cvalid[c] = v;
     }
     const float4 wb = prep.wbox[(colbase >> 8) + __builtin_amdgcn_readfirstlane(wave)];  // (NaN: never the shortcut)
+    zero_tile(false);
     bx0 = wb.x, bx1 = wb.y, by0 = wb.z, by1 = wb.w;
     fin = v;  // (a wavefront with a lane beyond the list never takes the wave shortcut: its wbox entry may be padding)
   } else {
@@ -530,6 +558,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
         for (int k = 0; k < 5; k++) raw[c * 5 + k] = cvalid[c] ? b2[(size_t)(col0 + c) * 5 + k] : 0.f;
       }
     }
+    zero_tile(false);
 #pragma unroll
     for (int c = 0; c < T_CPT; c++) {
       cx[c] = raw[c * 5];
@@ -537,43 +566,51 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
       reject_data(cx[c], cy[c], raw[c * 5 + 2], raw[c * 5 + 3], raw[c * 5 + 4], cr[c], cex[c], cey[c]);
     }
   }
-  // Bounding box of this WAVE's 256 columns (inflated extents included).  Anchors and refined boxes come in
-  // spatial order, so for most (row, wave) combinations the row's box lies outside it: one wave-uniform test
-  // then replaces the 4 per-column tests and the row segment is stored as zeros.  Waves with an invalid or
-  // non-finite column never take the shortcut.
+  // Bounding box of this LANE's 4 columns (inflated extents included).  Anchors and refined boxes come in spatial
+  // order, so for most (row, wave) combinations the row's box lies outside every lane's box: one compare per lane
+  // and a ballot then replace the 4 per-column tests.  A lane with a non-finite column never counts as outside.
+  // (Until round 5 the box was reduced over the wave -- 24 ds_bpermute + 24 min/max per thread for a uniform test
+  // that costs the same four compares.)
   bx0 = cx[0] - cex[0], bx1 = cx[0] + cex[0], by0 = cy[0] - cey[0], by1 = cy[0] + cey[0];
-  fin = cvalid[T_CPT - 1];
+  float fsum = (bx0 + bx1) + (by0 + by1);
 #pragma unroll
-  for (int c = 0; c < T_CPT; c++) {
-    bx0 = fminf(bx0, cx[c] - cex[c]);
-    bx1 = fmaxf(bx1, cx[c] + cex[c]);
-    by0 = fminf(by0, cy[c] - cey[c]);
-    by1 = fmaxf(by1, cy[c] + cey[c]);
-    fin = fin && (fabsf(cx[c]) < 3.0e38f) && (fabsf(cy[c]) < 3.0e38f) && (cex[c] < 3.0e38f) && (cey[c] < 3.0e38f);
+  for (int c = 1; c < T_CPT; c++) {
+    const float x0 = cx[c] - cex[c], x1 = cx[c] + cex[c], y0 = cy[c] - cey[c], y1 = cy[c] + cey[c];
+    bx0 = fminf(bx0, x0);
+    bx1 = fmaxf(bx1, x1);
+    by0 = fminf(by0, y0);
+    by1 = fmaxf(by1, y1);
+    fsum += (x0 + x1) + (y0 + y1);
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    bx0 = fminf(bx0, __shfl_xor(bx0, d));
-    bx1 = fmaxf(bx1, __shfl_xor(bx1, d));
-    by0 = fminf(by0, __shfl_xor(by0, d));
-    by1 = fmaxf(by1, __shfl_xor(by1, d));
+  fin = fabsf(fsum) < 3.0e38f;  // (NaN / inf in any centre or extent, or an overflowing sum: never outside)
   }
+  if (tid < nrows) {
+    float rad, ex, ey;
+    reject_data(rowraw[0], rowraw[1], rowraw[2], rowraw[3], rowraw[4], rad, ex, ey);
+    rows[tid][0] = rowraw[0]; rows[tid][1] = rowraw[1]; rows[tid][2] = rad; rows[tid][3] = ex; rows[tid][4] = ey;
+    rows[tid][8] = rowraw[0] - ex; rows[tid][9] = rowraw[0] + ex; rows[tid][10] = rowraw[1] - ey; rows[tid][11] = rowraw[1] + ey;
   }
-  const bool all_valid = cvalid[T_CPT - 1];
-  const bool wave_ok = VEC && __ballot(fin) == ~0ULL;
+  // the exact row records for the drain kernel: written once, by the middle column tile's workgroups
+  if (blockIdx.x == gridDim.x / 2 && tid >= 64 && tid < 64 + nrows) {
+    BoxRec rec;
+    make_record<GEOM>(b1 + (size_t)(row0 + tid - 64) * 5, 0.f, rec);
+    recsA[row0 + tid - 64] = rec;
+  }
   // survivors: one PRIVATE LDS segment per wave, its fill count in a wave-uniform register -- no LDS atomics,
   // nothing to wait for (a shared queue with one atomicAdd per ballot cost 12 of the kernel's 32 us)
   unsigned short* wq = queue + wave * P_WSEG;
   int cnt = 0;
   bool full = false;
   __syncthreads();
+  if (R3_HAS_PROBES && (probe & 15) == 2) {
+    if (tid == 0) tcount[blockIdx.y * gridDim.x + bx] = bx0 + bx1 + by0 + by1 + cx[0] + cr[1] == 12345.f;  // (keeps the prologue alive)
+    return;
+  }
   for (int r = 0; r < nrows; r++) {
     const float* A = rows[r];
+    const float4 ab = *reinterpret_cast<const float4*>(A + 8);
+    if (__builtin_amdgcn_ballot_w64(fin & ((ab.x > bx1) | (ab.y < bx0) | (ab.z > by1) | (ab.w < by0))) == ~0ULL) continue;
     const float ax = A[0], ay = A[1], ar = A[2], aex = A[3], aey = A[4];
-    if (wave_ok && ((ax - aex > bx1) | (ax + aex < bx0) | (ay - aey > by1) | (ay + aey < by0))) {
-      if (out) *reinterpret_cast<float4*>(out + (size_t)(row0 + r) * n2 + col0) = make_float4(0.f, 0.f, 0.f, 0.f);
-      continue;  // (out == nullptr: the fused assignment has no matrix)
-    }
     bool pend[T_CPT];
     bool any = false;
 #pragma unroll
@@ -583,16 +620,6 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
       bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + cex[c]) | (fabsf(dy) > aey + cey[c]);
       pend[c] = cvalid[c] && !apart;
       any |= pend[c];
-    }
-    if (out) {
-      float* o = out + (size_t)(row0 + r) * n2 + col0;
-      if (VEC && all_valid && !any) {
-        *reinterpret_cast<float4*>(o) = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-#pragma unroll
-        for (int c = 0; c < T_CPT; c++)
-          if (cvalid[c] && !pend[c]) o[c] = 0.f;
-      }
     }
     if (__ballot(any)) {
       if (cnt + 256 > wcap) {
@@ -607,12 +634,17 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
       }
     }
   }
+  if (R3_HAS_PROBES && (probe & 15) == 3) {
+    if (lane == 0) tcount[blockIdx.y * gridDim.x + bx] = cnt == 123456789;
+    return;
+  }
   if (lane == 0) wcount[wave] = full ? -1 : cnt;
   __syncthreads();
   const int c0 = wcount[0], c1 = wcount[1], c2 = wcount[2], c3 = wcount[3];
   const bool dense = (c0 | c1 | c2 | c3) < 0;
   const int tile = (int)(blockIdx.y * gridDim.x) + bx;
   if (tid == 0) tcount[tile] = dense ? -1 : c0 + c1 + c2 + c3;
+  zero_tile(true);
   if (dense) return;
   unsigned short* slot = slots + (size_t)tile * P_SLOT + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
   for (int q = lane; q < cnt; q += 64) slot[q] = wq[q];
@@ -1138,15 +1170,17 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   if (blocks > maxb) blocks = maxb;
   ColPrep P = ColPrep();
   if (prepared) colprep_layout(n2, prepared, &P);
+  const int sorder = (int)g_r3_iou_order;
+  const int sprobe = R3_HAS_PROBES ? (int)g_r3_fr_walk - 1000 : 0;  // (probes build: option fr_walk 1001 / 1002 / 1003 = stream phase probe)
   if (vec && prepared)
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
-                       L.tcount, L.slots, wcap, P);
+                       L.tcount, L.slots, wcap, P, sprobe, sorder);
   else if (vec)
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
-                       L.tcount, L.slots, wcap, P);
+                       L.tcount, L.slots, wcap, P, sprobe, sorder);
   else
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
-                       L.tcount, L.slots, wcap, P);
+                       L.tcount, L.slots, wcap, P, sprobe, sorder);
   // (probes build: the stamp buffer named by the frn_stamps_lo / _hi options, shared with the FR gather's probe)
   unsigned long long* const dstamps = R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps.get()) : nullptr;
   if (g_r3_clip_impl == 0)

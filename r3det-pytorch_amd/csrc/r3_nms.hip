@@ -1376,7 +1376,6 @@ __global__ __launch_bounds__(64) void nms_reduce_walk_kernel(const u64* __restri
   const uint8_t* rlab = grouped ? bt.rlab + (size_t)img * bt.rows : nullptr;
   const int cbn = (n + TILE - 1) / TILE;
   for (int w = lane; w < cbn; w += 64) Kb[w] = 0;
-  const u64 below = (1ULL << lane) - 1ULL;
   // ---- the group's rows, ascending, and each row's position among them
   int m = 0;
   if (grouped) {
