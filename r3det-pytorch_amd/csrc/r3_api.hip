@@ -686,7 +686,7 @@ int r3det_set_option(const char* name, int value) {
   if (!name) return R3DET_EINVAL;
   if (!strcmp(name, "fr_impl")) g_r3_fr_impl = value;
   else if (!strcmp(name, "fr_dbg")) g_r3_fr_dbg = value;
-  else if (!strcmp(name, "fr_walk")) g_r3_fr_walk = value < 0 ? 0 : value > 1024 ? 1024 : value;
+  else if (!strcmp(name, "fr_walk")) g_r3_fr_walk = value < 0 ? 0 : value > 1024 && !R3_HAS_PROBES ? 1024 : value;
   else if (!strcmp(name, "fr_profile")) g_r3_fr_profile = value;
   else if (!strcmp(name, "frb_impl")) g_r3_frb_impl = value;
   else if (!strcmp(name, "frn_stamps_lo")) g_r3_frn_stamps = (g_r3_frn_stamps & 0xffffffff00000000ull) | (unsigned)value;

@@ -461,13 +461,22 @@ __global__ __launch_bounds__(256) void iou_prepare_kernel(const float* __restric
   }
 }
 
+// The fused assignment's key arrays, zeroed by the stream kernel's first row / column of workgroups (the drain, a later
+// launch, is their first user): all-zero row / column = maximum 0 at index 0 = key 0x00000000ffffffff (pack_key(0, 0)).
+struct AssignZero {
+  unsigned long long* rowkey;  // [n1] or nullptr
+  unsigned long long* colkey;  // [n2]
+  int* lowq;                   // [n2]
+};
+
 template <int GEOM, bool VEC, bool PREP = false>
 __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __restrict__ b1, int n1,
                                                                 const float* __restrict__ b2, int n2,
                                                                 float* __restrict__ out, BoxRec* __restrict__ recsA,
                                                                 int* __restrict__ tcount,
                                                                 unsigned short* __restrict__ slots, int wcap,
-                                                                const ColPrep prep = ColPrep(), const int probe = 0, const int order = -1) {
+                                                                const ColPrep prep = ColPrep(), const int probe = 0, const int order = -1,
+                                                                const AssignZero az = AssignZero()) {
   // (probe: probes build only, tools/iou_stream_phases.sh -- 1 leave after the zeros, 2 after the prologue, 3 before the
   // queue flush: what each part of the kernel adds to the plain fill)
   __shared__ __attribute__((aligned(16))) float rows[P_ROWS][12];  // cx, cy, rad, ex, ey, -, -, -, cx - ex, cx + ex, cy - ey, cy + ey
@@ -491,6 +500,9 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   // nothing overlapped).
   // order: -1 every workgroup stores early; 0..30 the workgroups whose linear index has that bit set store early and
   // the others after their tests (so a CU holds both kinds: one kind's stores run under the other's tests); 31 all late
+  // (Measured and not kept, tools/iou_order_ab.sh: one or two EXTRA wavefronts per workgroup that do nothing but store the
+  // zeros while the four others only test -- 21.3 / 19.8 us against 19.2; and mixing early / late workgroups by a bit of
+  // their index -- 18.6 .. 20.2.  Where the zeros are issued is not what the kernel's time is made of.)
   const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
   const bool early = order < 0 || ((lin >> order) & 1u);
   auto zero_tile = [&](const bool late) {
@@ -508,6 +520,14 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
           if (r < nrows && col0 + c < n2) out[(size_t)(row0 + r) * n2 + col0 + c] = 0.f;
     }
   };
+  if (az.colkey) {
+    if (blockIdx.y == 0) {
+#pragma unroll
+      for (int c = 0; c < T_CPT; c++)
+        if (col0 + c < n2) az.colkey[col0 + c] = 0xffffffffULL, az.lowq[col0 + c] = 0;
+    }
+    if (blockIdx.x == 0 && tid < nrows) az.rowkey[row0 + tid] = 0xffffffffULL;
+  }
   float rowraw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (tid < nrows) {
     const float* b = b1 + (size_t)(row0 + tid) * 5;
@@ -666,6 +686,7 @@ struct AssignOut {
   u64k* rowkey;    // [n1]
   u64k* colkey;    // [n2]
   int n1_lds;      // rows whose maxima are reduced in LDS first (dynamic LDS: n1_lds u64)
+  int probe;       // (probes build, tools/assign_emit_ab.sh: 1 no column keys, 2 a look before the column atomic, 3 no siou, 4 no row keys, 5 no row flush, 6 a look before the flush's atomics)
 };
 
 template <int GEOM, bool FAST = false, bool ASSIGN = false>
@@ -715,10 +736,18 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
     if (!ASSIGN) {
       out[(size_t)r * n2 + c] = v;
     } else {
-      ao.siou[(size_t)t * D_PAIRS + off] = v;
+      const int pb = R3_HAS_PROBES ? ao.probe : 0;
+      if (pb != 3) ao.siou[(size_t)t * D_PAIRS + off] = v;
       if (v > 0.f) {
         const u64k kc = pack_key(v, r), kr = pack_key(v, c);
-        if (kc > __builtin_nontemporal_load(&ao.colkey[c])) atomicMax(&ao.colkey[c], kc);
+        // (no look at the key first: the nontemporal load in front of the atomic was 8 of the drain's 44 us, and 16 more
+        // in front of the row flush below -- tools/assign_emit_ab.sh; probes 2 / 6 bring the looks back)
+        if (pb == 2) {
+          if (kc > __builtin_nontemporal_load(&ao.colkey[c])) atomicMax(&ao.colkey[c], kc);
+        } else if (pb != 1) {
+          atomicMax(&ao.colkey[c], kc);
+        }
+        if (pb == 4) return;
         if ((int)r < ao.n1_lds) atomicMax(&rowbest[r], kr);
         else if (kr > __builtin_nontemporal_load(&ao.rowkey[r])) atomicMax(&ao.rowkey[r], kr);
       }
@@ -850,7 +879,9 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
     __syncthreads();
     for (int i = threadIdx.x; i < ao.n1_lds; i += T_THREADS) {
       const u64k k = rowbest[i];
-      if (k && k > __builtin_nontemporal_load(&ao.rowkey[i])) atomicMax(&ao.rowkey[i], k);
+      const int pb = R3_HAS_PROBES ? ao.probe : 0;  // (5: no flush, 6: flush without the look)
+      if (pb == 5) continue;
+      if (k && (pb != 6 || k > __builtin_nontemporal_load(&ao.rowkey[i]))) atomicMax(&ao.rowkey[i], k);
     }
   }
 }
@@ -904,7 +935,7 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void assign_drain_kernel(c
     qiou[q] = v;
     if (v > 0.f) {
       const u64k kc = pack_key(v, r), kr = pack_key(v, c);
-      if (kc > __builtin_nontemporal_load(&colkey[c])) atomicMax(&colkey[c], kc);
+      atomicMax(&colkey[c], kc);
       if ((int)r < n1_lds) atomicMax(&rowbest[r], kr);
       else if (kr > __builtin_nontemporal_load(&rowkey[r])) atomicMax(&rowkey[r], kr);
     }
@@ -956,7 +987,7 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void assign_drain_kernel(c
   __syncthreads();
   for (int i = threadIdx.x; i < n1_lds; i += T_THREADS) {
     const u64k k = rowbest[i];
-    if (k && k > __builtin_nontemporal_load(&rowkey[i])) atomicMax(&rowkey[i], k);
+    if (k) atomicMax(&rowkey[i], k);
   }
 }
 
@@ -1332,8 +1363,9 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
   if (prepared) colprep_layout(n2, prepared, &P);
   const BoxRec* recsB = prepared ? P.rec : L.recsB;
   const int nmax = n1 > n2 ? n1 : n2;
-  hipLaunchKernelGGL(assign_init_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, L.rowkey, n1, L.colkey,
-                     L.lowq, n2, L.counter);
+  if (!L.tiled)
+    hipLaunchKernelGGL(assign_init_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, L.rowkey, n1, L.colkey,
+                       L.lowq, n2, L.counter);
   if (L.tiled) {
     // round 5: the matrix path's queue -- stream3 (per-wave segments, no atomics, the wave-level bounding box; no
     // matrix: out = nullptr) -> the drain with the keys as its result -> the low-quality sweep tile by tile.
@@ -1341,19 +1373,20 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
     const int tiles = L.tiles_x * L.tiles_y;
     const dim3 sgrid(L.tiles_x, L.tiles_y);
     const int wcap3 = g_r3_iou_qcap > 0 && g_r3_iou_qcap < P_WSEG ? g_r3_iou_qcap : P_WSEG;  // (small: the dense-tile path)
+    const AssignZero az{L.rowkey, L.colkey, L.lowq};  // (round 5: assign_init_kernel's work, one launch less)
     if (prepared && n2 % 4 == 0)
       hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, true>), sgrid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
-                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap3, P);
+                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap3, P, 0, -1, az);
     else
       hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), sgrid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
-                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap3, P);
+                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap3, P, 0, -1, az);
     const bool fast = g_r3_clip_impl == 0;
     unsigned long long pairs3 = (unsigned long long)n1 * n2;
     int blocks3 = (int)((pairs3 + T_THREADS - 1) / T_THREADS);
     const int maxb3 = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : fast ? 4 * r3_cu_count() : 1536;
     if (blocks3 > maxb3) blocks3 = maxb3;
     const int n1_lds3 = n1 < 2048 ? n1 : 2048;
-    const AssignOut ao{L.siou, L.rowkey, L.colkey, n1_lds3};
+    const AssignOut ao{L.siou, L.rowkey, L.colkey, n1_lds3, R3_HAS_PROBES ? (int)g_r3_fr_walk - 2000 : 0};
     if (fast)
       // (v3 with the keys as its result: the straight-line form spills 12 B per lane at 128 registers -- the list form there)
       hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM != 3, true>), dim3(blocks3), dim3(T_THREADS),

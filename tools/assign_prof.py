@@ -12,6 +12,9 @@ if os.environ.get("IOU_DWGS"):
 if os.environ.get("CLIP_IMPL"):  # A/B: 1 = the LDS-list clip of rounds 2-4
     from r3det import _C
     _C.set_option("clip_impl", int(os.environ["CLIP_IMPL"]))
+if os.environ.get("ASSIGN_PROBE"):  # probes build: what the drain emits (r3_iou.hip AssignOut.probe)
+    from r3det import _C
+    _C.set_option("fr_walk", 2000 + int(os.environ["ASSIGN_PROBE"]))
 anchors = syn.anchor_grid(device=dev)
 gt = syn.dota_like_rboxes(128, 5, device=dev)
 a = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1, iou_calculator=dict(type='RBboxOverlaps2D_v1'))
