@@ -808,6 +808,32 @@ def main():
                                     "whole-step graph",
                             "ms_per_step_wall": spread_stats(sf),
                             "ms_per_step_device": round(device_time_ms(lambda: hot_path_step_sync_free(wl)), 3)}
+        # ... and as what it is inside GraphedStep: ONE HIP graph, replayed and waited for (wall clock per replay)
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                hot_path_step_sync_free(wl)
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            hg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(hg, capture_error_mode="thread_local"):
+                hot_path_step_sync_free(wl)
+            sg = []
+            for i in range(3 + 15):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                hg.replay()
+                torch.cuda.synchronize()
+                if i >= 3:
+                    sg.append(time.perf_counter() - t)
+            hot["sync_free"]["ms_per_step_graph"] = spread_stats(sg)
+            hot["sync_free"]["graph_what"] = ("the same calls captured once in a HIP graph (torch.cuda.CUDAGraph), one replay "
+                                              "launched and waited for per figure: the form the step has inside GraphedStep")
+            del hg
+        except Exception as e:  # (a capture failure must not cost the bench line)
+            hot["sync_free"]["ms_per_step_graph"] = None
+            hot["sync_free"]["graph_error"] = repr(e)[:200]
         # the roofline kernel alone, rotating over three buffer sets (3 x 268 MB): every launch reads and
         # writes lines that are NOT in the 256 MiB Infinity Cache -> an HBM figure
         from r3det.ops.feature_refine import fr_module_nhwc

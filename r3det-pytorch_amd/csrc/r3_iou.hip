@@ -372,7 +372,15 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream_kernel(const float* __re
 constexpr int P_ROWS = 8;  // (rows per tile, measured at 128 x 196 416 with prepared columns: 4 -> 52, 8 -> 48, 16 -> 50, 32 -> 55 us)
 constexpr int P_WSEG = P_ROWS * 128;   // entries of a wave's LDS segment: half of its 8 x 256 pairs
 constexpr int P_SLOT = 4 * P_WSEG;     // u16 entries of a tile's slot in the workspace (16 KB)
-constexpr int P_GROUPS = 1024;         // tile groups whose prefix a drain workgroup keeps in LDS
+constexpr int P_GROUPS = 3072;         // tile groups whose prefix a drain workgroup keeps in LDS (12 KB; round 5: 1024 -> 3072, so
+                                       // that at 128 x 196 416 a group IS a tile -- no walk through global counts behind the search)
+constexpr int P_GPT = P_GROUPS / T_THREADS;  // groups per thread of the prefix phase
+static_assert(P_GROUPS % (4 * T_THREADS) == 0, "a thread's groups are whole int4 loads");
+// ints of the tile-count array: the prefix phase reads P_GROUPS * G of them (those beyond the tiles count as empty)
+inline size_t tcount_ints(long long tiles) {
+  const long long G = (tiles + P_GROUPS - 1) / P_GROUPS;
+  return (size_t)(tiles > P_GROUPS * G ? tiles : P_GROUPS * G);
+}
 constexpr int P_MAX_TILES = 16384;     // beyond: the one-launch form (a group would span > 16 tiles)
 
 // centre / radius / AABB half extents for the conservative test, from hardware sine / cosine (|error| < 1e-3 on
@@ -756,20 +764,49 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  // prefix over the tile counts in groups of G consecutive tiles; thread t owns groups 4t .. 4t+3
+  // prefix over the tile counts in groups of G consecutive tiles; thread t owns groups P_GPT * t .. P_GPT * t + P_GPT - 1.
+  // Round 5: a thread's counts are P_GPT * G consecutive ints -- at G = 1 (up to 3072 tiles) three 16-byte loads in
+  // flight together; the loop of scalar loads it replaces was 12 L2 round trips one after the other, 2.4 us in front of
+  // every workgroup's first clip.
   const int G = (tiles + P_GROUPS - 1) / P_GROUPS;
-  unsigned gs[4];
+  unsigned gs[P_GPT];
   unsigned mine = 0;
+  if (G == 1) {
+    const int4* p4 = reinterpret_cast<const int4*>(tcount) + tid * (P_GPT / 4);
+    int4 v[P_GPT / 4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    unsigned sum = 0;
-    const int t0 = (tid * 4 + k) * G;
-    for (int t = t0; t < t0 + G && t < tiles; t++) {
-      const int c = tcount[t];
-      sum += c < 0 ? (unsigned)D_PAIRS : (unsigned)c;
+    for (int j = 0; j < P_GPT / 4; j++) v[j] = p4[j];
+#pragma unroll
+    for (int j = 0; j < P_GPT / 4; j++) {
+      const int c[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int t = tid * P_GPT + j * 4 + e;
+        gs[j * 4 + e] = t < tiles ? (c[e] < 0 ? (unsigned)D_PAIRS : (unsigned)c[e]) : 0u;
+        mine += gs[j * 4 + e];
+      }
     }
-    gs[k] = sum;
-    mine += sum;
+  } else {
+#pragma unroll
+    for (int k = 0; k < P_GPT; k++) {
+      unsigned sum = 0;
+      const int t0 = (tid * P_GPT + k) * G;
+      if ((G & 3) == 0) {  // (512 x 196 416: G = 4)
+        for (int t = t0; t < t0 + G; t += 4) {
+          const int4 v = *reinterpret_cast<const int4*>(tcount + t);
+          const int c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) sum += t + e < tiles ? (c[e] < 0 ? (unsigned)D_PAIRS : (unsigned)c[e]) : 0u;
+        }
+      } else {
+        for (int t = t0; t < t0 + G && t < tiles; t++) {
+          const int c = tcount[t];
+          sum += c < 0 ? (unsigned)D_PAIRS : (unsigned)c;
+        }
+      }
+      gs[k] = sum;
+      mine += sum;
+    }
   }
   unsigned incl = mine;
 #pragma unroll
@@ -782,8 +819,8 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
   unsigned base = incl - mine;
   for (int w = 0; w < wave; w++) base += wsum[w];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    pre[tid * 4 + k] = base;
+  for (int k = 0; k < P_GPT; k++) {
+    pre[tid * P_GPT + k] = base;
     base += gs[k];
   }
   if (tid == T_THREADS - 1) pre[P_GROUPS] = base;
@@ -799,11 +836,12 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
     if (valid) {
       int g = 0;  // group of entry q: largest g with pre[g] <= q
 #pragma unroll
-      for (int step = P_GROUPS / 2; step >= 1; step >>= 1)
-        if (pre[g + step] <= q) g += step;
+      for (int step = 2048; step >= 1; step >>= 1)
+        if (g + step <= P_GROUPS && pre[g + step] <= q) g += step;
       unsigned off = q - pre[g];
       int t = g * G;
-      for (;;) {  // tile inside the group (G = 3 at 1536 tiles)
+      if (G == 1) dense = pre[g + 1] - pre[g] == (unsigned)D_PAIRS;  // (a tile's queue holds at most 4 * P_WSEG < D_PAIRS entries)
+      else for (;;) {  // tile inside the group
         // (round 5, measured and dropped: the tile counts kept in LDS as well, so that this walk needs no global load --
         // the lookup 1.8 -> 1.5 us, the prefix phase 2.4 -> 3.3 us)
         const int tc = tcount[t];
@@ -1144,7 +1182,7 @@ inline size_t pipe_layout(int n1, int n2, void* ws, PipeLayout* L) {
   size_t off = 0;
   char* p = (char*)ws;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
-  char* tc = take((size_t)tx * ty * 4);
+  char* tc = take(tcount_ints((long long)tx * ty) * 4);
   char* ra = take((size_t)n1 * sizeof(BoxRec));
   char* sl = take((size_t)tx * ty * P_SLOT * 2);
   if (L) {
@@ -1340,7 +1378,7 @@ inline size_t assign_layout(int n1, int n2, void* ws, AssignLayout* L, const boo
   char* lq = take((size_t)n2 * 4);
   char *gq = nullptr, *qi = nullptr, *tc = nullptr, *sl = nullptr, *si = nullptr;
   if (tiled) {
-    tc = take((size_t)(tx * ty) * 4);
+    tc = take(tcount_ints(tx * ty) * 4);
     sl = take((size_t)(tx * ty) * P_SLOT * 2);
     si = take((size_t)(tx * ty) * P_ROWS * T_COLS * 4);
   } else {
