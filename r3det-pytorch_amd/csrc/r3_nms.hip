@@ -1705,6 +1705,14 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* wsum, int& total
 // (15 DOTA classes) are 64 aligned bytes: four 16-byte loads instead of 15 scalar ones at a 64-byte lane stride.
 __device__ __forceinline__ int count_above(const float* __restrict__ s, int K, float thr) {
   int cnt = 0;
+  if (K == 15 && (reinterpret_cast<uintptr_t>(s) & 15) == 0) {
+    // (DOTA: the row's four loads in flight together -- the loop below waits for each of its loads in turn, four L2
+    // round trips per row: that was most of mc_count_kernel's 6.5 us)
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    const float4 a = s4[0], b = s4[1], c = s4[2], d = s4[3];
+    return (a.x > thr) + (a.y > thr) + (a.z > thr) + (a.w > thr) + (b.x > thr) + (b.y > thr) + (b.z > thr) + (b.w > thr) +
+           (c.x > thr) + (c.y > thr) + (c.z > thr) + (c.w > thr) + (d.x > thr) + (d.y > thr) + (d.z > thr);
+  }
   if (((K + 1) & 3) == 0 && (reinterpret_cast<uintptr_t>(s) & 15) == 0) {
     const float4* s4 = reinterpret_cast<const float4*>(s);
     const int nq = (K + 1) >> 2;
@@ -1796,6 +1804,130 @@ __global__ __launch_bounds__(SEL_T) void mc_write_kernel(const float* __restrict
         cand_rank[cb + pos] = 0;
         pos++;
       }
+    }
+  }
+}
+
+// select in ONE launch (round 5; mc_count_kernel + mc_write_kernel above remain for the A/B, option nms_impl 5): a part's
+// workgroup counts the candidates of the parts in front of it itself -- one row per thread and earlier part, all loads
+// independent -- instead of waiting for a count launch (4.9 us + the gap behind it); the LAST part, which looks at every
+// other part anyway, writes the image's count and box maximum.  The part's own rows are read once: the write loop works on the
+// registers the count came from (it used to re-read the K scores one dependent load after the other).
+__global__ __launch_bounds__(SEL_T) void mc_select_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                          int n, int K, float thr, int parts, int cand_stride,
+                                                          int* __restrict__ cand_row, int* __restrict__ cand_label,
+                                                          float* __restrict__ cand_score, int* __restrict__ cand_rank,
+                                                          int* __restrict__ counts, float* __restrict__ maxc) {
+  __shared__ int wsum[SEL_T / 64];
+  __shared__ int wbef[SEL_T / 64];
+  __shared__ float wmax[SEL_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int img = blockIdx.y, part = blockIdx.x, row = part * SEL_T + tid;
+  const bool last = part == (int)gridDim.x - 1;  // (it looks at every other part anyway: the image's count and box maximum are its job)
+  auto box_max = [&](const int r) {
+    const float* b = boxes + ((size_t)img * n + r) * 5;
+    return fmaxf(fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])), b[4]);
+  };
+  // the part's own row: 16 floats in registers when a row is 64 aligned bytes (15 classes + background)
+  const float* s = scores + ((size_t)img * n + row) * (K + 1);
+  const bool quad = K == 15 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;
+  float4 v4[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f),
+                  make_float4(0.f, 0.f, 0.f, 0.f)};
+  if (quad && row < n) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) v4[q] = reinterpret_cast<const float4*>(s)[q];
+  }
+  int before = 0;
+  float mx = -INFINITY;
+  const int q0 = 0, q1 = part;
+  auto count16 = [&](const float4* w) {
+    return (w[0].x > thr) + (w[0].y > thr) + (w[0].z > thr) + (w[0].w > thr) + (w[1].x > thr) + (w[1].y > thr) +
+           (w[1].z > thr) + (w[1].w > thr) + (w[2].x > thr) + (w[2].y > thr) + (w[2].z > thr) + (w[2].w > thr) +
+           (w[3].x > thr) + (w[3].y > thr) + (w[3].z > thr);
+  };
+  if (quad) {
+    // four earlier rows per step, their sixteen loads requested together at clamped
+    // addresses: no branch between a load and the next (with one, every row waited for its own round trip)
+    for (int qb = q0; qb < q1; qb += 4) {
+      float4 w[4][4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = (qb + u) * SEL_T + tid;
+        ok[u] = qb + u < q1 && r < n;
+        const int rc = r < n ? r : n - 1;
+        const float4* p4 = reinterpret_cast<const float4*>(scores + ((size_t)img * n + rc) * 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[u][k] = p4[k];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = ok[u] ? count16(w[u]) : 0;
+        before += c;
+        if (last && c) mx = fmaxf(mx, box_max((qb + u) * SEL_T + tid));  // (candidate rows only: a box is 20 B at a 20 B stride)
+      }
+    }
+  } else {
+    for (int q = q0; q < q1; q++) {
+      const int r = q * SEL_T + tid;
+      if (r < n) {
+        const int c = count_above(scores + ((size_t)img * n + r) * (K + 1), K, thr);
+        before += c;
+        if (last && c) mx = fmaxf(mx, box_max(r));
+      }
+    }
+  }
+  int cnt = 0;
+  if (row < n) {
+    if (quad) {
+      cnt = count16(v4);
+    } else {
+      cnt = count_above(s, K, thr);
+    }
+    if (last && cnt) mx = fmaxf(mx, box_max(row));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    before += __shfl_xor(before, d);
+    mx = fmaxf(mx, __shfl_xor(mx, d));
+  }
+  if (lane == 0) {
+    wbef[wave] = before;
+    wmax[wave] = mx;
+  }
+  int total;
+  const int excl = block_exclusive_scan(cnt, wsum, total);  // (its barrier also publishes wbef / wmax)
+  int bsum = 0;
+#pragma unroll
+  for (int w = 0; w < SEL_T / 64; w++) bsum += wbef[w];
+  if (last && tid == 0) {
+    float m = wmax[0];
+    for (int w = 1; w < SEL_T / 64; w++) m = fmaxf(m, wmax[w]);
+    counts[img] = bsum + total;
+    maxc[img] = m;
+  }
+  int pos = bsum + excl;
+  if (cnt) {
+    const size_t cb = (size_t)img * cand_stride;
+    auto put = [&](const int k, const float v) {
+      if (v > thr) {
+        cand_row[cb + pos] = row;
+        cand_label[cb + pos] = k;
+        cand_score[cb + pos] = v;
+        cand_rank[cb + pos] = 0;
+        pos++;
+      }
+    };
+    if (quad) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        put(q * 4, v4[q].x);
+        put(q * 4 + 1, v4[q].y);
+        put(q * 4 + 2, v4[q].z);
+        if (q < 3) put(q * 4 + 3, v4[q].w);
+      }
+    } else {
+      for (int k = 0; k < K; k++) put(k, s[k]);
     }
   }
 }
@@ -2202,6 +2334,11 @@ int r3k_mcnms_select(const float* boxes, const float* scores, int B, int n, int 
   const int parts = select_parts(n);
   int* part_cnt = (int*)ws;
   float* part_max = (float*)((char*)ws + align256((size_t)B * parts * 4));
+  if (g_r3_nms_impl != 5) {
+    hipLaunchKernelGGL(mc_select_kernel, dim3(parts, B), dim3(SEL_T), 0, stream, boxes, scores, n, K, score_thr, parts,
+                       n * K, cand_row, cand_label, cand_score, cand_rank, counts, maxc);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   hipLaunchKernelGGL(mc_count_kernel, dim3(parts, B), dim3(SEL_T), 0, stream, boxes, scores, n, K, score_thr, parts,
                      part_cnt, part_max);
   hipLaunchKernelGGL(mc_write_kernel, dim3(parts, B), dim3(SEL_T), 0, stream, scores, n, K, score_thr, parts,
