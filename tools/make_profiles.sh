@@ -96,10 +96,16 @@ ls -la $O
 # 7b. round 5: the straight-line v1 clip against the LDS-list form in the three drains (same process per form), the
 #     drain's phase stamps (probes build), the whole-step graph against the eager step
 bash tools/clip_ab.sh gpurun_out/profiles_$TAG/${TAG}_clip_ab.txt > /dev/null 2>&1
-{ for impl in 0 1; do CLIP_IMPL=$impl python3 tools/iou_drain_stamps.py 2>&1 | grep -v amdgpu.ids; done; } > $O/${TAG}_iou_drain_stamps.txt
+{ for impl in 0 1; do CLIP_IMPL=$impl IOU_DWGS=$((impl == 0 ? 1024 : 1536)) python3 tools/iou_drain_stamps.py 2>&1 | grep -v amdgpu.ids; done; } > $O/${TAG}_iou_drain_stamps.txt
 python3 tools/whole_step_probe.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_whole_step_graph.txt
 python3 tools/pool_edge_stats.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_model_pool_edges.txt
 POOL_SPREAD=0 python3 tools/pool_edge_stats.py 2>&1 | grep -v amdgpu.ids | tail -1 | sed 's/^/one-label calibration: /' >> $O/${TAG}_model_pool_edges.txt
+# 7c. round 5, second half: what each part of the IoU stream kernel adds to the plain fill (probes build), where its zeros
+#     are issued, what the assignment's drain pays for what it emits (probes build), the candidate selection in one launch
+bash tools/iou_stream_phases.sh gpurun_out/profiles_$TAG/${TAG}_iou_stream_phases.txt > /dev/null 2>&1
+ORDERS="-1 31 0 3 8" bash tools/iou_order_ab.sh gpurun_out/profiles_$TAG/${TAG}_iou_order_ab.txt > /dev/null 2>&1
+bash tools/assign_emit_ab.sh gpurun_out/profiles_$TAG/${TAG}_assign_emit_ab.txt > /dev/null 2>&1
+bash tools/mc_select_ab.sh gpurun_out/profiles_$TAG/${TAG}_mc_select_ab.txt > /dev/null 2>&1
 # 8. the bench lines themselves (no profiler attached)
 python3 $R/bench.py --steps 30 --warmup 5 > $O/${TAG}_bench.json 2> /dev/null
 python3 $R/bench.py --mode train --steps 10 --warmup 3 > $O/${TAG}_train.json 2> /dev/null
