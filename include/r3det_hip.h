@@ -529,6 +529,8 @@ int r3det_bias_act(float* y, const float* bias, const float* residual, long long
  *   ("nms_qcap", n: entries per queue region, small values force the redo-tile path),
  *   ("clip_impl", 0 the straight-line v1 pair clip of the drains (round 5, csrc/r3_clip.h) | 1 the LDS-list form of
  *                 rounds 2-4: same results bit for bit, kept for the A/B in tools/clip_ab.sh),
+ *   ("iou_dyn", 1 the IoU drain's wavefronts draw their blocks of 64 queue entries behind the first from atomic tickets
+ *               when there are three or more per wavefront | 0 always the static stride; same results, tools/iou_dyn_ab.sh),
  *   ("iou_order", -1 every workgroup of the matrix stream kernel zeroes its tile before its tests | b in 0..30: those
  *                 with bit b of their linear index set, the others after their tests | 31 all after; same results,
  *                 tools/iou_order_ab.sh).

@@ -13,6 +13,7 @@ R3Option g_r3_clip_impl{0};
 R3Option g_r3_iou_qcap{0};
 R3Option g_r3_iou_dwgs{0};
 R3Option g_r3_iou_order{-1};
+R3Option g_r3_iou_dyn{1};
 R3Option g_r3_nms_impl{0};
 R3Option g_r3_nms_qcap{0};
 
@@ -696,6 +697,7 @@ int r3det_set_option(const char* name, int value) {
   else if (!strcmp(name, "clip_impl")) g_r3_clip_impl = value;
   else if (!strcmp(name, "iou_qcap")) g_r3_iou_qcap = value;
   else if (!strcmp(name, "iou_dwgs")) g_r3_iou_dwgs = value;
+  else if (!strcmp(name, "iou_dyn")) g_r3_iou_dyn = value != 0;
   else if (!strcmp(name, "iou_order")) g_r3_iou_order = value < -1 ? -1 : value > 31 ? 31 : value;
   else if (!strcmp(name, "nms_impl")) g_r3_nms_impl = value;
   else if (!strcmp(name, "nms_qcap")) g_r3_nms_qcap = value;

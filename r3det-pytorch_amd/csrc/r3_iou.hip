@@ -377,10 +377,17 @@ constexpr int P_GROUPS = 3072;         // tile groups whose prefix a drain workg
 constexpr int P_GPT = P_GROUPS / T_THREADS;  // groups per thread of the prefix phase
 static_assert(P_GROUPS % (4 * T_THREADS) == 0, "a thread's groups are whole int4 loads");
 // ints of the tile-count array: the prefix phase reads P_GROUPS * G of them (those beyond the tiles count as empty)
-inline size_t tcount_ints(long long tiles) {
+__host__ __device__ inline size_t tcount_ints(long long tiles) {
   const long long G = (tiles + P_GROUPS - 1) / P_GROUPS;
   return (size_t)(tiles > P_GROUPS * G ? tiles : P_GROUPS * G);
 }
+// ... and behind them the drain's TICKET: a drain wavefront's first 64 entries are its own (wave index), every further
+// block of 64 is handed out by an atomic counter, zeroed by the stream kernel (option iou_dyn 0: the static stride of the
+// first half of the round).  Static shares are equal in entries, not in time: clips differ (rare block, redo), and a SIMD
+// whose four wavefronts drew the long ones was the kernel's tail.
+constexpr int P_TICKETS = 64;      // counters, 128 B apart: wavefront w draws from counter w % 64 (ONE counter for the 7 k blocks of
+                                   // 128 x 196 416 made the drain 93 us instead of 23: a same-address returning atomic is ~10 ns, in turn)
+constexpr int P_TICKET_PAD = P_TICKETS * 32;  // ints kept behind the counts
 constexpr int P_MAX_TILES = 16384;     // beyond: the one-launch form (a group would span > 16 tiles)
 
 // centre / radius / AABB half extents for the conservative test, from hardware sine / cosine (|error| < 1e-3 on
@@ -528,6 +535,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
           if (r < nrows && col0 + c < n2) out[(size_t)(row0 + r) * n2 + col0 + c] = 0.f;
     }
   };
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < P_TICKETS) tcount[tcount_ints((long long)gridDim.x * gridDim.y) + tid * 32] = 0;  // the drain's tickets
   if (az.colkey) {
     if (blockIdx.y == 0) {
 #pragma unroll
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
                                                                int tiles, float* __restrict__ out,
                                                                const BoxRec* __restrict__ recsB = nullptr,
                                                                unsigned long long* __restrict__ stamps = nullptr,
-                                                               const AssignOut ao = AssignOut()) {
+                                                               const AssignOut ao = AssignOut(), const int dyn = 0) {
   // (probes build, tools/iou_drain_stamps.py: wave 0 of every workgroup stamps its phases with the 100 MHz clock)
 #ifdef R3_PROBES
 #define R3_DSTAMP(k)                                                                             \
@@ -828,7 +836,18 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
   const unsigned total = pre[P_GROUPS];
   R3_DSTAMP(1)
   int trips = 0;
-  for (unsigned qb = blockIdx.x * T_THREADS + wave * 64; qb < total; qb += gridDim.x * T_THREADS) {  // wave-uniform
+  const unsigned nwaves = gridDim.x * (T_THREADS / 64);
+  const unsigned wid = blockIdx.x * (T_THREADS / 64) + wave;
+  // (blocks are dealt in P_TICKETS classes, block b in class b % P_TICKETS: a wavefront's first block is its own index, the
+  // class's further blocks come from the class's counter)
+  // (only where a wavefront has three blocks or more: at 1.7 blocks per wavefront -- 128 x 196 416 -- there is nothing to even
+  // out, 23.3 us both ways; 512 x 196 416, 7 blocks: 104 -> 92-95 us; tools/iou_dyn_ab.sh)
+  unsigned* const ticket = (dyn && nwaves % P_TICKETS == 0 && total >= 3u * 64u * nwaves)
+      ? reinterpret_cast<unsigned*>(const_cast<int*>(tcount)) + tcount_ints(tiles) + (wid % P_TICKETS) * 32 : nullptr;
+  for (unsigned qb = wid * 64; qb < total;) {  // wave-uniform
+    // the block after this one: by ticket (requested here, looked at behind the clip) or at the static stride
+    unsigned tk = 0;
+    if (ticket && lane == 0) tk = atomicAdd(ticket, 1u);
     const unsigned q = qb + lane;
     bool valid = q < total;
     bool dense = false;
@@ -907,6 +926,7 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
         for (int k = 0; k < 32 && m; k++) m &= m - 1;
       }
     }
+    qb = ticket ? (nwaves + (unsigned)__builtin_amdgcn_readfirstlane((int)tk) * P_TICKETS + wid % P_TICKETS) * 64u : qb + nwaves * 64u;
   }
   R3_DSTAMP(6)
 #ifdef R3_PROBES
@@ -1182,7 +1202,7 @@ inline size_t pipe_layout(int n1, int n2, void* ws, PipeLayout* L) {
   size_t off = 0;
   char* p = (char*)ws;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return p ? p + o : nullptr; };
-  char* tc = take(tcount_ints((long long)tx * ty) * 4);
+  char* tc = take((tcount_ints((long long)tx * ty) + P_TICKET_PAD) * 4);
   char* ra = take((size_t)n1 * sizeof(BoxRec));
   char* sl = take((size_t)tx * ty * P_SLOT * 2);
   if (L) {
@@ -1254,10 +1274,12 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   unsigned long long* const dstamps = R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps.get()) : nullptr;
   if (g_r3_clip_impl == 0)
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, true>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
-                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps);
+                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps, AssignOut(),
+                       (int)g_r3_iou_dyn);
   else
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, false>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
-                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps);
+                       L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps, AssignOut(),
+                       (int)g_r3_iou_dyn);
   return 0;
 }
 
@@ -1378,7 +1400,7 @@ inline size_t assign_layout(int n1, int n2, void* ws, AssignLayout* L, const boo
   char* lq = take((size_t)n2 * 4);
   char *gq = nullptr, *qi = nullptr, *tc = nullptr, *sl = nullptr, *si = nullptr;
   if (tiled) {
-    tc = take(tcount_ints(tx * ty) * 4);
+    tc = take((tcount_ints(tx * ty) + P_TICKET_PAD) * 4);
     sl = take((size_t)(tx * ty) * P_SLOT * 2);
     si = take((size_t)(tx * ty) * P_ROWS * T_COLS * 4);
   } else {
@@ -1430,12 +1452,12 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
       hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM != 3, true>), dim3(blocks3), dim3(T_THREADS),
                          (size_t)n1_lds3 * sizeof(u64k), stream, gts, n1, boxes, n2, 0, L.recsA, L.tcount, L.slots,
                          L.tiles_x, tiles, (float*)nullptr, prepared ? P.rec : (const BoxRec*)nullptr,
-                         (unsigned long long*)nullptr, ao);
+                         (unsigned long long*)nullptr, ao, (int)g_r3_iou_dyn);
     else
       hipLaunchKernelGGL((iou_drain3_kernel<GEOM, false, true>), dim3(blocks3), dim3(T_THREADS),
                          (size_t)n1_lds3 * sizeof(u64k), stream, gts, n1, boxes, n2, 0, L.recsA, L.tcount, L.slots,
                          L.tiles_x, tiles, (float*)nullptr, prepared ? P.rec : (const BoxRec*)nullptr,
-                         (unsigned long long*)nullptr, ao);
+                         (unsigned long long*)nullptr, ao, (int)g_r3_iou_dyn);
     if (match_low)
       hipLaunchKernelGGL(assign_lowq3_kernel, dim3(tiles, 4), dim3(256), 0, stream, L.tcount, L.slots, L.tiles_x, L.siou, n1,
                          n2, L.rowkey, min_pos_iou, assign_all, L.lowq);

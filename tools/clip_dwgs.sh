@@ -23,7 +23,7 @@ for d in ${DWGS:-512 768 1024 1280 1536 2048}; do
   kt python3 $R/tools/assign_prof.py
   echo "## iou_dwgs=$d assignment" >> $OUT
   grep "^assign" /tmp/kt_run.log | sed 's/^/# /' >> $OUT
-  python3 $R/tools/kstats.py /tmp/kt_run assign_drain >> $OUT
+  python3 $R/tools/kstats.py /tmp/kt_run assign_drain iou_drain >> $OUT
   unset IOU_DWGS
 done
 cat $OUT

@@ -15,7 +15,7 @@ from r3det.ops import rbbox_iou  # noqa: E402
 from r3det import _C  # noqa: E402
 
 dev = torch.device("cuda")
-for opt in ("iou_impl", "iou_qcap", "iou_small", "iou_dwgs", "clip_impl", "fr_walk", "iou_order"):  # A/B knobs, e.g. IOU_PROF_iou_qcap=100
+for opt in ("iou_impl", "iou_qcap", "iou_small", "iou_dwgs", "clip_impl", "fr_walk", "iou_order", "iou_dyn"):  # A/B knobs, e.g. IOU_PROF_iou_qcap=100
     if os.environ.get("IOU_PROF_" + opt):
         _C.set_option(opt, int(os.environ["IOU_PROF_" + opt]))
 which = os.environ.get("IOU_PROF_SHAPE", "all")

@@ -106,6 +106,7 @@ bash tools/iou_stream_phases.sh gpurun_out/profiles_$TAG/${TAG}_iou_stream_phase
 ORDERS="-1 31 0 3 8" bash tools/iou_order_ab.sh gpurun_out/profiles_$TAG/${TAG}_iou_order_ab.txt > /dev/null 2>&1
 bash tools/assign_emit_ab.sh gpurun_out/profiles_$TAG/${TAG}_assign_emit_ab.txt > /dev/null 2>&1
 bash tools/mc_select_ab.sh gpurun_out/profiles_$TAG/${TAG}_mc_select_ab.txt > /dev/null 2>&1
+bash tools/iou_dyn_ab.sh gpurun_out/profiles_$TAG/${TAG}_iou_dyn_ab.txt > /dev/null 2>&1
 # 8. the bench lines themselves (no profiler attached)
 python3 $R/bench.py --steps 30 --warmup 5 > $O/${TAG}_bench.json 2> /dev/null
 python3 $R/bench.py --mode train --steps 10 --warmup 3 > $O/${TAG}_train.json 2> /dev/null
