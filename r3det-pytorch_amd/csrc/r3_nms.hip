@@ -792,6 +792,9 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
+  constexpr int OVQ = 1024;  // overflow rows a workgroup converts together (grouped form)
+  __shared__ unsigned short ovq[OVQ];
+  __shared__ int ovx[OVQ], ovl[OVQ];
   const int cbn = (n + TILE - 1) / TILE;
   const int nb = (n + 15) & ~15;
   unsigned char* st = smem8;                               // row state: 0 undecided, 1 kept, 2 removed
@@ -908,68 +911,130 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       // bench model's pool.)  xs < 0: the list is full, that row keeps the per-round scan.
       int xs[RPT], xl[RPT];
       unsigned short* ext = blist;  // (the long-row worklist of the general form: unused here)
+      // one such row: a wavefront, lanes <-> mask words -- counts the entries, reserves their place in ext, writes them
+      auto convert_rows = [&](const int (&rowi)[8], const int (&srcl)[8], int (&res_base)[8], int (&res_total)[8]) {
+        constexpr int OB = 8;
+        u64 w0d[OB];
+#pragma unroll
+        for (int b = 0; b < OB; b++) {
+          const u64* row = maskT + (size_t)rowi[b] * cb;
+          w0d[b] = (srcl[b] >= 0 && lane <= (rowi[b] >> 6)) ? row[lane] : 0ULL;
+        }
+#pragma unroll
+        for (int b = 0; b < OB; b++) {
+          res_base[b] = -1;
+          res_total[b] = 0;
+          if (srcl[b] < 0) continue;  // (wave-uniform)
+          const int r = rowi[b];
+          const u64* row = maskT + (size_t)r * cb;
+          const int nw = (r >> 6) + 1;
+          int total = 0;
+          for (int w0 = 0; w0 < nw; w0 += 64) {  // (the number of entries; words 64.. only for rows beyond 4096)
+            const u64 wd = w0 == 0 ? w0d[b] : ((w0 + lane < nw) ? row[w0 + lane] : 0ULL);
+            int pc = __popcll(wd);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
+            total += pc;
+          }
+          int base = 0;
+          if (lane == 0) base = atomicAdd(s_nbig, total);
+          base = __builtin_amdgcn_readfirstlane(base);
+          const bool fits = base + total <= R_BLIST;
+          if (fits) {
+            int at = base;
+            for (int w0 = 0; w0 < nw; w0 += 64) {
+              u64 wd = w0 == 0 ? w0d[b] : ((w0 + lane < nw) ? row[w0 + lane] : 0ULL);
+              const int pc = __popcll(wd);
+              int incl = pc;
+#pragma unroll
+              for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+              }
+              int o = at + incl - pc;
+              while (wd) {
+                ext[o++] = (unsigned short)((w0 + lane) * 64 + __builtin_ctzll(wd));
+                wd &= wd - 1;
+              }
+              at += __builtin_amdgcn_readlane(incl, 63);
+            }
+          }
+          res_base[b] = fits ? base : -1;
+          res_total[b] = total;
+        }
+      };
+      // (round 5, second half) The rows are ENLISTED for the whole workgroup and converted by all sixteen wavefronts, eight
+      // rows per step each: a 218-row class lives in the first four wavefronts, which converted its 71 overflow rows alone
+      // (18 rows per wavefront, ~1000 cycles each: 45-73 k cycles in front of the first round on the bench model's pool).
+      int myov[RPT];
 #pragma unroll
       for (int u = 0; u < RPT; u++) {
         xs[u] = 0;
         xl[u] = 0;
-        u64 need = __ballot(state[u] == 0 && c[u] > EL);
-        // (round 5: the rows' mask words are requested EIGHT ROWS AT A TIME and each row's first 64 words are read once --
-        // the dense class of the bench model's pool has 71 such rows in one group, 18 per wavefront, and two dependent
-        // passes per row, one row after the other, were 45 us of the kernel's 65)
-        while (need) {
-          constexpr int OB = 8;
-          int srcl[OB], rowi[OB];
-          u64 w0d[OB];
+        myov[u] = -1;
+        const bool want = state[u] == 0 && c[u] > EL;
+        const u64 need = __ballot(want);
+        if (need) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(s_m, __popcll(need));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (want) {
+            const int e = base + __popcll(need & ((1ULL << lane) - 1ULL));
+            if (e < OVQ) {
+              ovq[e] = (unsigned short)rr[u];
+              myov[u] = e;
+            } else {
+              myov[u] = -2;  // (no room on the list: this wavefront converts it itself below)
+            }
+          }
+        }
+      }
+      __syncthreads();
+      {
+        const int nov = min(*s_m, OVQ);
+        for (int e0 = wave * 8; e0 < nov; e0 += (RTHREADS / 64) * 8) {
+          int rowi[8], srcl[8], rb[8], rt[8];
 #pragma unroll
-          for (int b = 0; b < OB; b++) {
+          for (int b = 0; b < 8; b++) {
+            srcl[b] = e0 + b < nov ? 0 : -1;
+            rowi[b] = e0 + b < nov ? (int)ovq[e0 + b] : 0;
+          }
+          convert_rows(rowi, srcl, rb, rt);
+          if (lane < 8 && e0 + lane < nov) {
+            int vb = rb[0], vt = rt[0];
+#pragma unroll
+            for (int b = 1; b < 8; b++) {
+              vb = lane == b ? rb[b] : vb;
+              vt = lane == b ? rt[b] : vt;
+            }
+            ovx[e0 + lane] = vb;
+            ovl[e0 + lane] = vt;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < RPT; u++) {
+        if (myov[u] >= 0) {
+          xs[u] = ovx[myov[u]];
+          xl[u] = ovl[myov[u]];
+        }
+        u64 need = __ballot(myov[u] == -2);  // (beyond the list's capacity: the owner's wavefront, as before)
+        while (need) {
+          int srcl[8], rowi[8], rb[8], rt[8];
+#pragma unroll
+          for (int b = 0; b < 8; b++) {
             srcl[b] = need ? __builtin_ctzll(need) : -1;
             need &= need - 1;  // (0 stays 0)
             rowi[b] = srcl[b] >= 0 ? __shfl(rr[u], srcl[b]) : 0;
-            const u64* row = maskT + (size_t)rowi[b] * cb;
-            w0d[b] = (srcl[b] >= 0 && lane <= (rowi[b] >> 6)) ? row[lane] : 0ULL;
           }
+          convert_rows(rowi, srcl, rb, rt);
 #pragma unroll
-          for (int b = 0; b < OB; b++) {
-            if (srcl[b] < 0) break;  // (wave-uniform)
-            const int r = rowi[b];
-            const u64* row = maskT + (size_t)r * cb;
-            const int nw = (r >> 6) + 1;
-            int total = 0;
-            for (int w0 = 0; w0 < nw; w0 += 64) {  // (the number of entries; words 64.. only for rows beyond 4096)
-              const u64 wd = w0 == 0 ? w0d[b] : ((w0 + lane < nw) ? row[w0 + lane] : 0ULL);
-              int pc = __popcll(wd);
-#pragma unroll
-              for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
-              total += pc;
+          for (int b = 0; b < 8; b++)
+            if (srcl[b] >= 0 && lane == srcl[b]) {
+              xs[u] = rb[b];
+              xl[u] = rt[b];
             }
-            int base = 0;
-            if (lane == 0) base = atomicAdd(s_nbig, total);
-            base = __builtin_amdgcn_readfirstlane(base);
-            const bool fits = base + total <= R_BLIST;
-            if (fits) {
-              int at = base;
-              for (int w0 = 0; w0 < nw; w0 += 64) {
-                u64 wd = w0 == 0 ? w0d[b] : ((w0 + lane < nw) ? row[w0 + lane] : 0ULL);
-                const int pc = __popcll(wd);
-                int incl = pc;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                  const int v = __shfl_up(incl, d);
-                  if (lane >= d) incl += v;
-                }
-                int o = at + incl - pc;
-                while (wd) {
-                  ext[o++] = (unsigned short)((w0 + lane) * 64 + __builtin_ctzll(wd));
-                  wd &= wd - 1;
-                }
-                at += __builtin_amdgcn_readlane(incl, 63);
-              }
-            }
-            if (lane == srcl[b]) {
-              xs[u] = fits ? base : -1;
-              xl[u] = total;
-            }
-          }
         }
       }
 #pragma unroll
@@ -988,7 +1053,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         // What a round costs is LDS reads of scattered state bytes (bank conflicts: ~12 cycles per wave read, 16 waves
         // on one LDS) and the slowest wave in front of the barrier.  So: a wave whose rows are all decided reads
         // nothing; the best suppressor and the first 8 entries are read together (most rows have fewer than 8);
-        // entries 8..31 in one batch, only in waves with an undecided row that long; the overflow entries 4 at a time.
+        // entries 8..31 in one batch, only in waves with an undecided row that long; the overflow entries 16 at a time.
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
           const bool act = state[u] == 0;
@@ -1027,15 +1092,19 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
             if (__ballot(ovf) != 0ULL) {
               if (ovf && xs[u] < 0) aR = false;  // (the LDS list was full: left to the tail below)
               const int len = (ovf && xs[u] >= 0) ? xl[u] : 0;
-              for (int e0 = 0; __ballot(e0 < len) != 0ULL; e0 += 4) {  // suppressors beyond the list: their LDS entries
-                unsigned short xi[4];
-                unsigned char xv[4];
+              // suppressors beyond the list: their LDS entries, SIXTEEN per step (round 5; four per step were two dependent
+              // LDS round trips per four entries: 18 steps for a row with 70 of them, 4-9 k cycles of a dense class's round),
+              // and no further once every such row of the wavefront has met a kept suppressor
+              constexpr int XE = 16;
+              for (int e0 = 0; __ballot(e0 < len && !aK) != 0ULL; e0 += XE) {
+                unsigned short xi[XE];
+                unsigned char xv[XE];
 #pragma unroll
-                for (int e = 0; e < 4; e++) xi[e] = e0 + e < len ? ext[xs[u] + e0 + e] : (unsigned short)r;
+                for (int e = 0; e < XE; e++) xi[e] = e0 + e < len ? ext[xs[u] + e0 + e] : (unsigned short)r;
 #pragma unroll
-                for (int e = 0; e < 4; e++) xv[e] = st[xi[e]];
+                for (int e = 0; e < XE; e++) xv[e] = st[xi[e]];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
+                for (int e = 0; e < XE; e++) {
                   aK |= e0 + e < len && xv[e] == 1;
                   aR &= !(e0 + e < len) || xv[e] == 2;
                 }
@@ -2418,10 +2487,10 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     } else {
     const size_t lds = reduce_groups_lds_bytes(cap, L.cb, groups > 1);
     static R3DeviceOnce raised;  // the default cap on dynamic LDS is 64 KB; the opt-in is per device
-    if (lds > 64 * 1024 && raised.first())
+    if (lds + 11 * 1024 > 64 * 1024 && raised.first())
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);  // (+ ~300 B static)
-    if (lds > 160 * 1024 - 1024) return -1;  // (cap < 65536: 106 KB at most)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 12 * 1024);  // (+ ~10.5 KB static)
+    if (lds > 160 * 1024 - 12 * 1024) return -1;  // (cap < 65536: 106 KB at most)
     hipLaunchKernelGGL(nms_reduce_groups_kernel, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
                        L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);
     }
