@@ -532,8 +532,8 @@ int r3det_bias_act(float* y, const float* bias, const float* residual, long long
  *   ("iou_dyn", 1 the IoU drain's wavefronts draw their blocks of 64 queue entries behind the first from atomic tickets
  *               when there are three or more per wavefront | 0 always the static stride; same results, tools/iou_dyn_ab.sh),
  *   ("iou_order", -1 every workgroup of the matrix stream kernel zeroes its tile before its tests | b in 0..30: those
- *                 with bit b of their linear index set, the others after their tests | 31 all after; same results,
- *                 tools/iou_order_ab.sh).
+ *                 with bit b of their linear index set, the others after their tests (default 8) | 31 all after; same
+ *                 results, tools/iou_order_ab.sh).
  * Thread safety: the switches are process-wide relaxed atomics, each read once per operator call -- a call sees one
  * consistent value of every switch it reads, whichever thread sets them; a caller that needs "this call with that
  * setting" still has to order the two itself.

@@ -12,7 +12,7 @@ R3Option g_r3_iou_small{0};
 R3Option g_r3_clip_impl{0};
 R3Option g_r3_iou_qcap{0};
 R3Option g_r3_iou_dwgs{0};
-R3Option g_r3_iou_order{-1};
+R3Option g_r3_iou_order{8};  // (measured: 18.8-19.0 us against 19.3-19.5 with every workgroup early, three alternations on one box)
 R3Option g_r3_iou_dyn{1};
 R3Option g_r3_nms_impl{0};
 R3Option g_r3_nms_qcap{0};
