@@ -515,9 +515,10 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   // nothing overlapped).
   // order: -1 every workgroup stores early; 0..30 the workgroups whose linear index has that bit set store early and
   // the others after their tests (so a CU holds both kinds: one kind's stores run under the other's tests); 31 all late
-  // (Measured and not kept, tools/iou_order_ab.sh: one or two EXTRA wavefronts per workgroup that do nothing but store the
-  // zeros while the four others only test -- 21.3 / 19.8 us against 19.2; and mixing early / late workgroups by a bit of
-  // their index -- 18.6 .. 20.2.  Where the zeros are issued is not what the kernel's time is made of.)
+  // (option iou_order, default 8: 18.8-19.0 us against 19.3-19.5 for -1 in three alternations on one box; other bits 18.6 ..
+  // 20.2.  Measured and not kept, tools/iou_order_ab.sh: one or two EXTRA wavefronts per workgroup that do nothing but
+  // store the zeros while the four others only test -- 21.3 / 19.8 us.  Where the zeros are issued is not what the
+  // kernel's time is made of.)
   const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
   const bool early = order < 0 || ((lin >> order) & 1u);
   auto zero_tile = [&](const bool late) {

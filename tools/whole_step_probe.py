@@ -42,9 +42,7 @@ print("first replay: capacity overflow of the step before =", redo, "; kept", [i
 print(f"whole-step graph  {timeit(lambda: g.step(img)):7.3f} ms", flush=True)
 res = g.nms.lists()
 # (two passes of the network are not bit-identical on this stack -- MIOpen's convolutions --, so the comparison is on the
-# kept counts and the largest difference between the rows; the graph's NMS against the list form on ONE dense output is
+# kept counts only (near-tied scores change places between two passes); the graph's NMS against the list form on ONE dense output is
 # tests/test_model.py's bit-exact check)
 same_counts = [int(a[0].size(0)) == int(b[0].size(0)) for a, b in zip(eager, res)]
-diff = max((float((a[0] - b[0]).abs().max()) if a[0].shape == b[0].shape and a[0].numel() else float("nan"))
-           for a, b in zip(eager, res))
-print("kept counts equal to the eager step's:", all(same_counts), "; largest |difference| of a detection row:", diff)
+print("kept counts equal to the eager step's:", all(same_counts))
