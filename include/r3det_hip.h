@@ -155,7 +155,9 @@ int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes,
  * used as columns -- the exact per-box records, the data of the conservative disjointness test, the bounding box of
  * every 256 consecutive columns -- ONCE into `prepared` (r3det_iou_prepared_bytes(n) bytes, 16-byte aligned); the
  * _prepared entry points take it next to the boxes themselves and give bit for bit the results of the plain ones.
- * geom: R3DET_GEOM_V1 / _V2 / _V3, the same in the prepare call and in every use.  mode of r3det_iou_mat_prepared: as the
+ * geom: R3DET_GEOM_V1 / _V2 / _V3, the same in the prepare call and in every use: the library remembers (on the host, per
+ * buffer address) what it prepared a buffer for, and the _prepared entry points return R3DET_EINVAL for another geometry or
+ * column count; an address it has not prepared itself is taken as it is.  mode of r3det_iou_mat_prepared: as the
  * plain entry of the geometry takes it (v1 / v2: 1 = iof; v3: 0 = iof). */
 size_t r3det_iou_prepared_bytes(int n);
 int r3det_iou_prepare_columns(int geom, const float* boxes, int n, void* prepared, size_t prepared_bytes, void* stream);

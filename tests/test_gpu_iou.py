@@ -258,3 +258,27 @@ def test_prepared_columns_give_the_same_matrix_bit_for_bit(version, shape):
     assert L.r3det_iou_prepare_columns(7, _C.ptr(cols), n2, _C.ptr(prep), prep.numel(), _C.stream()) == -1
     assert L.r3det_iou_mat_prepared(geom, _C.ptr(gt), n1, _C.ptr(cols), n2, None, 0, _C.ptr(got), _C.ptr(ws), wsb,
                                     _C.stream()) == -1
+
+
+def test_prepared_buffer_refused_for_another_shape():
+    """A buffer prepared for (geometry, n2) is refused by the consumers for any other (it used to give wrong IoUs
+    silently); the library remembers what it prepared per buffer address, on the host."""
+    from r3det import _C
+    from r3det import synthetic as syn
+    L = _C.lib()
+    dev = torch.device("cuda")
+    cols = syn.rand_rboxes(2048, 3, device=dev)
+    rows = syn.rand_rboxes(16, 4, device=dev)
+    pb = int(L.r3det_iou_prepared_bytes(2048))
+    prep = torch.empty(pb, dtype=torch.uint8, device=dev)
+    _C.check(L.r3det_iou_prepare_columns(1, _C.ptr(cols), 2048, _C.ptr(prep), pb, _C.stream()), "prepare")
+    out = torch.empty(16, 2048, device=dev)
+    wsb = int(L.r3det_iou_workspace_bytes(16, 2048))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ok = L.r3det_iou_mat_prepared(1, _C.ptr(rows), 16, _C.ptr(cols), 2048, _C.ptr(prep), 0, _C.ptr(out), _C.ptr(ws), wsb, _C.stream())
+    assert ok == 0
+    for geom, n2 in ((1, 2044), (3, 2048)):
+        rc = L.r3det_iou_mat_prepared(geom, _C.ptr(rows), 16, _C.ptr(cols), n2, _C.ptr(prep), 0, _C.ptr(out), _C.ptr(ws), wsb,
+                                      _C.stream())
+        assert rc != 0
+    torch.cuda.synchronize()
