@@ -282,3 +282,31 @@ def test_prepared_buffer_refused_for_another_shape():
                                       _C.stream())
         assert rc != 0
     torch.cuda.synchronize()
+
+
+def test_drain_tickets_equal_static_stride_at_512_rows():
+    """512 x 196 416 (SURVEY 8d's fourth size) is where the drain hands out its blocks by atomic tickets (three or more
+    per wavefront; option iou_dyn): bit-identical to the static stride, and sampled columns bit-exact against the twin
+    oracle -- the size-independent check of a path the small fixtures never take."""
+    from r3det import _C
+    anchors = anchor_grid()
+    gt = dota_like_gt(512, 6)
+    got = run(O.V1, gt, anchors)
+    _C.set_option("iou_dyn", 0)
+    try:
+        static = run(O.V1, gt, anchors)
+    finally:
+        _C.set_option("iou_dyn", 1)
+    assert got.shape == (512, 196416) and np.array_equal(got, static)
+    cols = np.unique(np.concatenate([np.random.default_rng(1).choice(196416, 1500, replace=False),
+                                     np.argsort(got.max(0))[-1500:]]))
+    with O.twin():
+        want = O.iou_mat(O.V1, gt, anchors[cols], threads=8)
+    assert same(got[:, cols], want)
+    got3 = run(O.V3, gt, anchors)
+    _C.set_option("iou_dyn", 0)
+    try:
+        static3 = run(O.V3, gt, anchors)
+    finally:
+        _C.set_option("iou_dyn", 1)
+    assert np.array_equal(got3, static3)
