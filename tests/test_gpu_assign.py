@@ -160,3 +160,22 @@ def test_assignment_with_prepared_anchor_grid_equals_plain():
     gt = syn.dota_like_rboxes(16, 9, device='cuda')
     assert torch.equal(a.assign(small, gt).gt_inds, a.assign(small, gt, shared_key=('grid', 64)).gt_inds)
     assert len(a._prepared_columns) == 1
+
+
+def test_drain_tickets_in_the_assignment_at_512_gts():
+    """512 gts against the 196 416-anchor grid: the fused assignment's drain draws its blocks by atomic tickets there
+    (option iou_dyn): the same result as with the static stride, and as the dense rules on the overlap matrix."""
+    from r3det import _C
+    from r3det import synthetic as syn
+    anchors = syn.anchor_grid(device='cuda')
+    gts = syn.dota_like_rboxes(512, 6, device='cuda')
+    asg = make('RBboxOverlaps2D_v1')
+    dyn = check_same(asg, anchors, gts)
+    _C.set_option("iou_dyn", 0)
+    try:
+        sta = asg.assign(anchors, gts, with_gt_stats=True)
+    finally:
+        _C.set_option("iou_dyn", 1)
+    for a, b in ((dyn.gt_inds, sta.gt_inds), (dyn.max_overlaps, sta.max_overlaps), (dyn.argmax_overlaps, sta.argmax_overlaps),
+                 (dyn.gt_max_overlaps, sta.gt_max_overlaps), (dyn.gt_argmax_overlaps, sta.gt_argmax_overlaps)):
+        assert torch.equal(a, b)
