@@ -3,7 +3,7 @@ Cache) -- the driver for `rocprofv3 --kernel-trace` / PMC passes of the backward
   NHWC: r3det_feature_refine_backward_nhwc (frb_index_kernel + frb_gather_kernel)
   NCHW: r3det_feature_refine_backward_ws  (frb_index_sort_kernel + frb_sell_kernel + frn_gather_kernel), and the
         gather alone on an index built ahead (r3det_feature_refine_backward_indexed: what a training step runs)
-FR_BWD_LEVEL (0), FR_BWD_N (4), FR_BWD_FIELD=regular|adversarial|trained."""
+FR_BWD_LEVEL (0), FR_BWD_N (4), FR_BWD_FIELD=regular|adversarial|trained|grid."""
 import os
 import sys
 
@@ -25,6 +25,11 @@ cl = torch.channels_last
 boxes = syn.fr_level_boxes(N, H, H, stride, 3, device=dev)
 if field == "adversarial":
     boxes[:, :2] = torch.rand(boxes.shape[0], 2, device=dev) * (H * stride)
+elif field == "grid":  # no jitter at all: every box sits on its own cell's centre (what the gather's LDS reads cost without it)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev), torch.arange(H, dtype=torch.float32, device=dev),
+                            indexing='ij')
+    boxes[:, 0] = (xs.reshape(-1) * stride).repeat(N)
+    boxes[:, 1] = (ys.reshape(-1) * stride).repeat(N)
 elif field == "trained":  # every position regresses to the centre of the object it lies on: piles of ~9-25 per cell
     g = (boxes[:, :2] / (4 * stride)).floor() * (4 * stride) + 2 * stride
     boxes[:, :2] = g + torch.randn_like(g) * 0.3 * stride
