@@ -113,7 +113,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
                   const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
                   float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
                   int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream, const R3kMcPadded* padded = nullptr,
-                  bool have_extent = false);  // (have_extent: the v3 class-offset extent is already in the workspace)
+                  int scale_parts = 0);  // (scale_parts > 0: maxc holds rnms_begin_kernel's partial results, r3_nms.hip)
 
 size_t r3k_fr_workspace_bytes(int N, int H, int W, int points);
 // ws may be null (taps derived per channel plane); with a workspace: tap table + unpack kernel

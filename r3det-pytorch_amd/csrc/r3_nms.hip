@@ -2071,7 +2071,7 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
     const float* __restrict__ cand_score, int cand_stride, const int* __restrict__ counts_raw, int cap,
     int* __restrict__ ccounts, const float* __restrict__ scale, BoxRec* __restrict__ recs, size_t recs_stride,
     int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab,
-    unsigned* __restrict__ counter, size_t counter_stride, uint4* __restrict__ zero, size_t zero16) {
+    unsigned* __restrict__ counter, size_t counter_stride, uint4* __restrict__ zero, size_t zero16, int sparts) {
   __shared__ __attribute__((aligned(16))) unsigned keys[RP_TJ];
   __shared__ int partial[RP_P][RP_C];
   const int img = blockIdx.y, tid = threadIdx.x;
@@ -2149,12 +2149,33 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
   const float lab = (float)cand_label[cbase + c];
   float d[5] = {b[0], b[1], b[2], b[3], b[4]};
   bool is_dead = false;
+  // the class offsets' scale: one float per image, or (sparts > 0, the one-pool entries, round 5) the partial results of
+  // rnms_begin_kernel's sparts workgroups -- v1: their maxima (NaN where a workgroup saw one); v3: minima, then maxima
+  auto scale_of = [&]() -> float {
+    if (sparts <= 0) return scale[img];
+    if (GEOM == 1) {
+      float m = scale[0];
+      bool bad = m != m;
+      for (int g = 1; g < sparts; g++) {
+        const float v = scale[g];
+        bad |= v != v;
+        m = fmaxf(m, v);
+      }
+      return bad ? __builtin_nanf("") : m;
+    }
+    float lo = scale[0], hi = scale[sparts];
+    for (int g = 1; g < sparts; g++) {
+      lo = fminf(lo, scale[g]);
+      hi = fmaxf(hi, scale[sparts + g]);
+    }
+    return hi - lo + 1.f;
+  };
   if (GEOM == 1) {
-    const float off = lab * (scale[img] + 1.f);
+    const float off = lab * (scale_of() + 1.f);
     d[0] += off;
     d[1] += off;
   } else if (GEOM == 3) {
-    const float off = lab * scale[img];
+    const float off = lab * scale_of();
     d[0] += off;
     d[1] += off;
     is_dead = fminf(b[2], b[3]) < 0.001f;
@@ -2427,7 +2448,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
                   const float* cand_score, int* cand_rank, const int* counts, const float* maxc, int cap,
                   float iou_thr, int out_cap, void* ws, size_t ws_bytes, float* dets_out, int64_t* labels_out,
                   int64_t* keep_idx_out, int32_t* counts_out, hipStream_t stream, const R3kMcPadded* padded,
-                  bool have_extent) {
+                  int scale_parts) {
   if (geom < 1 || geom > 3) return -1;
   if (B <= 0 || n <= 0 || K <= 0 || cap <= 0 || out_cap <= 0 || cap >= 65536 || !(iou_thr >= 0.f)) return -1;
   if (!boxes || !cand_row || !cand_label || !cand_score || !cand_rank || !counts || !ws || !dets_out ||
@@ -2455,13 +2476,13 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   int dblocks = drain_blocks(L.qstride, chip_wgs);
   if (dblocks > chip_wgs / B) dblocks = chip_wgs / B > 0 ? chip_wgs / B : 1;  // B images share the chip
   const dim3 dgrid(dblocks, 1, B);
-  if (geom == 3 && !have_extent)  // (reads the raw counts and clamps them itself: the clamped copy is written by the next kernel)
+  if (geom == 3 && scale_parts <= 0)  // (reads the raw counts and clamps them itself: the clamped copy is written by the next kernel)
     hipLaunchKernelGGL(mc_hbb_extent_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, S, counts, cap, L.extent);
   (void)cand_rank;  // (scratch of the three-launch form of round 2; kept in the signature)
 #define R3_MC(GEOM, LABEL, SCALE)                                                                                  \
   hipLaunchKernelGGL(mc_sort_prepare_kernel<GEOM>, pgrid, dim3(256), 0, stream, boxes, n, cand_row, cand_label,   \
                      cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.rlab,       \
-                     L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16);                  \
+                     L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16, scale_parts);     \
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, L.gqueue,      \
                      (unsigned)L.qcap, L.counter, L.redo, bt);                                                    \
   if (g_r3_clip_impl == 0)                                                                                         \
@@ -2471,7 +2492,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, false>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb,       \
                        iou_thr, L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt)
   if (geom == 1) { R3_MC(1, false, maxc); }
-  else if (geom == 3) { R3_MC(3, false, L.extent); }
+  else if (geom == 3) { R3_MC(3, false, scale_parts > 0 ? maxc : L.extent); }
   else { R3_MC(2, true, (const float*)nullptr); }
 #undef R3_MC
   counts = L.ccounts;
@@ -2511,32 +2532,36 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
 // pipeline (row = 0..n-1, label, count = n) and the wrapper's `bboxes.max()` are produced by one small kernel
 // instead of five framework launches (arange, zeros, full, to(int32), max), then the B = 1 pipeline runs.
 namespace {
+constexpr int RB_WGS = 16;  // at most; one per 2048 rows (one workgroup: 3.7 us at n = 2000, 7.3 at 8576; five there: 5.0)
 __global__ __launch_bounds__(1024) void rnms_begin_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ inds,
                                                           int n, int* __restrict__ row, int* __restrict__ lab,
-                                                          int* __restrict__ cnt, float* __restrict__ maxc,
-                                                          float* __restrict__ extent) {
-  __shared__ float part[16];
+                                                          int* __restrict__ cnt, float* __restrict__ part, int v3) {
+  // part: v1 -- gridDim.x partial maxima of bboxes.max() (a workgroup that saw a NaN writes NaN: torch.max propagates it);
+  // v3 -- as many minima, then maxima, of the circumscribed horizontal boxes (mc_hbb_extent_kernel's arithmetic over
+  // rows 0 .. n-1); mc_sort_prepare_kernel reduces them (sparts = gridDim.x)
+  __shared__ float s0[16], s1[16];
   __shared__ int anynan[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < n; i += 1024) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+  const int G = (int)gridDim.x, stride = G * 1024;
+  for (int i = g * 1024 + tid; i < n; i += stride) {
     row[i] = i;
     lab[i] = inds ? (int)inds[i] : 0;
   }
-  if (extent) {
-    // v3 (round 5): the class offsets' extent -- mc_hbb_extent_kernel's arithmetic over rows 0 .. n-1 -- here instead of
-    // in a launch of its own behind this one (6 us + its gap; the box maximum below is batched_rnms's, not needed)
-    float lo = INFINITY, hi = -INFINITY;
-    for (int i0 = tid; i0 < n; i0 += 4 * 1024) {
+  if (g == 0 && tid == 0) cnt[0] = n;
+  float lo = INFINITY, hi = -INFINITY;
+  int bad = 0;
+  if (v3) {
+    for (int i0 = g * 1024 + tid; i0 < n; i0 += 4 * stride) {
       float b[4][5];
 #pragma unroll
       for (int u = 0; u < 4; u++) {  // (four boxes' loads in flight)
-        const int i = min(i0 + u * 1024, n - 1);
+        const int i = min(i0 + u * stride, n - 1);
 #pragma unroll
         for (int k = 0; k < 5; k++) b[u][k] = boxes[(size_t)i * 5 + k];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        if (i0 + u * 1024 >= n) continue;
+        if (i0 + u * stride >= n) continue;
         const float cs = cosf(b[u][4]), sn = sinf(b[u][4]);
         const float xb = fabsf(b[u][2] / 2 * cs) + fabsf(b[u][3] / 2 * sn);
         const float yb = fabsf(b[u][2] / 2 * sn) + fabsf(b[u][3] / 2 * cs);
@@ -2544,51 +2569,43 @@ __global__ __launch_bounds__(1024) void rnms_begin_kernel(const float* __restric
         hi = fmaxf(hi, fmaxf(b[u][0] + xb, b[u][1] + yb));
       }
     }
+  } else {
+    hi = -3.4028235e38f;
+    for (int i0 = g * 1024 + tid; i0 < 5 * n; i0 += 8 * stride) {  // torch.max over all five columns
+      float v[8];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      lo = fminf(lo, __shfl_xor(lo, d));
-      hi = fmaxf(hi, __shfl_xor(hi, d));
-    }
-    __shared__ float smin[16], smax[16];
-    if (lane == 0) {
-      smin[wave] = lo;
-      smax[wave] = hi;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < 16; w++) {
-        lo = fminf(lo, smin[w]);
-        hi = fmaxf(hi, smax[w]);
+      for (int u = 0; u < 8; u++) v[u] = boxes[min(i0 + u * stride, 5 * n - 1)];  // eight loads in flight
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        bad |= v[u] != v[u];
+        hi = fmaxf(hi, v[u]);
       }
-      extent[0] = hi - lo + 1.f;
-      maxc[0] = 0.f;
-      cnt[0] = n;
-    }
-    return;
-  }
-  float m = -3.4028235e38f;
-  int bad = 0;
-  for (int i0 = tid; i0 < 5 * n; i0 += 8 * 1024) {  // torch.max over all five columns; NaN propagates as in torch
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = boxes[min(i0 + u * 1024, 5 * n - 1)];  // eight loads in flight
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      bad |= v[u] != v[u];
-      m = fmaxf(m, v[u]);
     }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
-    m = fmaxf(m, __shfl_xor(m, d));
+    lo = fminf(lo, __shfl_xor(lo, d));
+    hi = fmaxf(hi, __shfl_xor(hi, d));
     bad |= __shfl_xor(bad, d);
   }
-  if (lane == 0) { part[wave] = m; anynan[wave] = bad; }
+  if (lane == 0) {
+    s0[wave] = lo;
+    s1[wave] = hi;
+    anynan[wave] = bad;
+  }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 16; w++) { m = fmaxf(m, part[w]); bad |= anynan[w]; }
-    maxc[0] = bad ? __builtin_nanf("") : m;
-    cnt[0] = n;
+    for (int w = 1; w < 16; w++) {
+      lo = fminf(lo, s0[w]);
+      hi = fmaxf(hi, s1[w]);
+      bad |= anynan[w];
+    }
+    if (v3) {
+      part[g] = lo;
+      part[G + g] = hi;
+    } else {
+      part[g] = bad ? __builtin_nanf("") : hi;
+    }
   }
 }
 
@@ -2607,7 +2624,7 @@ inline size_t rnms_layout(int n, void* ws, RnmsLayout* L) {
   char* lab = take((size_t)n * 4);
   char* rank = take((size_t)n * 4);
   char* cnt = take(4);
-  char* mx = take(4);
+  char* mx = take(4 * 2 * RB_WGS);  // (the begin kernel's partial results)
   char* lo = take((size_t)n * 8);
   char* mc = take(r3k_mcnms_workspace_bytes(1, cap));
   if (L) {
@@ -2630,13 +2647,12 @@ int r3k_batched_nms(int geom, const float* boxes, const float* scores, const int
   RnmsLayout L;
   rnms_layout(n, ws, &L);
   const int cap = (n + 63) / 64 * 64;
-  McLayout ML;
-  mc_layout(1, cap, L.mc, &ML);
-  hipLaunchKernelGGL(rnms_begin_kernel, dim3(1), dim3(1024), 0, stream, boxes, inds, n, L.row, L.lab, L.cnt, L.maxc,
-                     geom == 3 ? ML.extent : (float*)nullptr);
+  const int bwgs = std::min(RB_WGS, (n + 2047) / 2048);
+  hipLaunchKernelGGL(rnms_begin_kernel, dim3(bwgs), dim3(1024), 0, stream, boxes, inds, n, L.row, L.lab, L.cnt, L.maxc,
+                     geom == 3 ? 1 : 0);
   return r3k_mcnms_run(geom, boxes, 1, n, 1, L.row, L.lab, scores, L.rank, L.cnt, L.maxc, cap, thr, n, L.mc,
                        r3k_mcnms_workspace_bytes(1, cap), dets_out, L.labels_out, keep_out, kept_out, stream, nullptr,
-                       geom == 3);
+                       bwgs);
 }
 
 
