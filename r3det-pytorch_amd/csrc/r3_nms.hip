@@ -2061,7 +2061,7 @@ __global__ __launch_bounds__(1024) void mc_hbb_extent_kernel(const float* __rest
 // per thread (measured at 8576: 256 candidates per workgroup, one thread each = 34 workgroups: 84 us; 32 candidates
 // x 8 threads = 268 workgroups: 22 us).  Then the records go to their
 // ranks; on the way the grid zeroes the overflow masks + side tables and the queue counters the next kernels expect.
-constexpr int RP_TJ = 1024;  // keys per LDS tile (measured at n = 2000 / 8576, round 5: 512 -> 5.5 / 16.1 us, 1024 -> 5.6 / 16.8, 2048 -> 7.9 / 21.9, 4096 -> 8.4 / 28.8)
+constexpr int RP_TJ = 1024;  // keys per LDS tile (measured at n = 2000 / 8576, round 5: 512 -> 5.5 / 16.1 us, 1024 -> 5.6 / 16.8, 2048 -> 7.9 / 21.9, 4096 -> 8.4 / 28.8; without the ranking loop the kernel takes 6.1 us at 8576: zero fill + records)
 constexpr int RP_C = 8;      // candidates per workgroup
 constexpr int RP_P = 32;     // threads per candidate
 
