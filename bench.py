@@ -17,7 +17,11 @@ GPU, 128 synthetic GT per image): forward_train (fused MaxIoU assignment of 196 
 through autograd), backward, SGD; N > 1: DistributedDataParallel over RCCL.
 --mode rretinanet: BASELINE configs[1] -- rretinanet_obb_r50_fpn v1 inference, batch 2 x 1024^2.
 
-Rank 0 prints ONE JSON line.  `value` = images/s over all ranks.  `hot_path` repeats the
+Rank 0 prints ONE JSON line of at most 1 800 characters (`headline`: metric, value, timing, config,
+roofline, cpu_baseline) as the last line of stdout; everything else below is the detail record
+bench_detail.json written next to this file (and under gpurun_out/).  stderr stays a few lines
+(R3DET_BENCH_VERBOSE=1: the phase trace; R3DET_BENCH_DETAIL_STDERR=1: the detail record too).
+`value` = images/s over all ranks.  `hot_path` repeats the
 measurement for the custom ops alone (same shapes, no convs).  `roofline` is for the dominant
 HBM-bound hand-written kernel (FR forward, level 0), timed with HIP events attached to the launch
 inside the timed region.  `cpu_baseline` times the oracle / oracle/_ref on a bounded sample of the
@@ -669,11 +673,94 @@ def dist_info():
 _T0 = time.perf_counter()
 
 
+_PHASES = []
+
+
 def phase(name):
-    """Wall-clock trace of the run on stderr (the driver clocks the whole command; this says where it went)."""
+    """Wall-clock trace of the run (the driver clocks the whole command; this says where it went): kept for the detail
+    record; on stderr only with R3DET_BENCH_VERBOSE=1 -- the driver's 2 000-character tail is stdout + stderr, and the
+    headline has to stay inside it."""
     if int(os.environ.get("RANK", "0")) == 0:
-        sys.stderr.write(f"[bench {time.perf_counter() - _T0:7.1f} s] {name}\n")
-        sys.stderr.flush()
+        _PHASES.append([round(time.perf_counter() - _T0, 1), name])
+        if os.environ.get("R3DET_BENCH_VERBOSE", "0") == "1":
+            sys.stderr.write(f"[bench {time.perf_counter() - _T0:7.1f} s] {name}\n")
+            sys.stderr.flush()
+
+
+# ------------------------------------------------------------------------------------ the contract line
+HEADLINE_MAX = 1800   # the driver keeps a 2 000-character tail of stdout + stderr; round 5's 22.8 KB line was not parsed
+DETAIL_FILE = "bench_detail.json"
+_HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "traffic", "alg_bytes_per_launch")
+_CPU_KEYS = ("value", "unit", "cores", "cpu_model", "kind", "sample")
+_CFG_KEYS = ("workload", "batch_per_gpu", "global_batch", "nms_type")
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def headline(line, detail_file=DETAIL_FILE):
+    """The ONE stdout line of the contract, cut down to what the driver reads (<= HEADLINE_MAX characters): metric,
+    value, timing, config, roofline, cpu_baseline.  Everything else the run measured (ops, hot_path, by_pool, train,
+    rretinanet, per-op CPU rows, the notes) is the detail record `write_detail` puts next to bench.py.  The protocol
+    the figure follows is the reference's tools/analysis_tools/benchmark.py:99-130 (one img/s figure)."""
+    out = {k: line[k] for k in _HEAD_KEYS if k in line}
+    cfg = line.get("config") or {}
+    out["config"] = {k: cfg[k] for k in _CFG_KEYS if k in cfg}
+    out["config"]["workload"] = _short(cfg.get("workload_short") or cfg.get("workload", ""), 160)
+    roof = line.get("roofline")
+    if roof is not None:
+        r = {k: roof.get(k) for k in _ROOF_KEYS}
+        r["kernel"] = _short(str(roof.get("kernel", "")).split(" = ")[0].split(" ")[0], 60)   # the symbol only
+        out["roofline"] = r
+    cpu = line.get("cpu_baseline")
+    if cpu is not None:
+        c = {k: cpu.get(k) for k in _CPU_KEYS}
+        c["cpu_model"] = _short(c.get("cpu_model") or "", 48)
+        c["sample"] = _short(c.get("sample") or "", 150)
+        out["cpu_baseline"] = c
+    for k in ("rccl_ranks", "per_rank_ms_per_step"):
+        if k in line:
+            out[k] = line[k]
+    if isinstance(out.get("per_rank_ms_per_step"), list) and len(out["per_rank_ms_per_step"]) > 8:
+        out["per_rank_ms_per_step"] = out["per_rank_ms_per_step"][:8]
+    out["detail_file"] = detail_file
+    text = json.dumps(out, separators=(", ", ": "))
+    if len(text) > HEADLINE_MAX or "\n" in text:
+        raise RuntimeError(f"bench headline is {len(text)} characters (limit {HEADLINE_MAX})")
+    return text
+
+
+def write_detail(line, name=DETAIL_FILE):
+    """The full record (what rounds 1-5 printed as one line) as a file next to bench.py and, where the directory
+    exists or can be made, under gpurun_out/ (the directory gpurun carries back).  Returns the paths written."""
+    text = json.dumps(line, indent=1)
+    done = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, name), "w") as f:
+                f.write(text + "\n")
+            done.append(os.path.join(d, name))
+        except OSError:
+            pass
+    return done
+
+
+def emit(line):
+    """Detail to the file, its location (one short line) to stderr, the compact headline as the LAST stdout line."""
+    line = dict(line, phases_s=list(_PHASES))
+    paths = write_detail(line)
+    text = headline(line)
+    sys.stderr.write(f"[bench] detail ({len(json.dumps(line))} B): {', '.join(os.path.relpath(p, ROOT) for p in paths)}\n")
+    if os.environ.get("R3DET_BENCH_DETAIL_STDERR", "0") == "1":
+        sys.stderr.write(json.dumps(line) + "\n")
+    sys.stderr.flush()
+    sys.stdout.write(text + "\n")
+    sys.stdout.flush()
 
 
 def main():
@@ -719,7 +806,9 @@ def main():
             line = dict(common, metric="img/s, R3Det R50-FPN 1024x1024 training step (r3det_r50_fpn_1x v1)",
                         value=round(world * TRAIN_BATCH * args.steps / elapsed, 2), unit="img/s",
                         ms_per_step=round(ms, 3), per_rank_ms_per_step=ranks, **dist_info(),
-                        config={"workload": "BASELINE configs[4]: r3det_r50_fpn_1x v1 training step, batch=2 x 1024x1024 per "
+                        config={"workload_short": "BASELINE configs[4]: r3det_r50_fpn_1x v1 training step, batch 2 x 1024x1024 "
+                                                  "per GPU, 128 GT per image, synthetic",
+                                "workload": "BASELINE configs[4]: r3det_r50_fpn_1x v1 training step, batch=2 x 1024x1024 per "
                                             "GPU, 128 synthetic GT per image: forward_train (fused MaxIoU assignment, focal + "
                                             "smooth-L1, FR forward + backward), backward, SGD(momentum); random-init "
                                             "weights; norm_eval, frozen stem + layer1 as in the config",
@@ -732,7 +821,7 @@ def main():
                                     "assign_ms": round(ta, 3), "fr_fwd_bwd_ms": round(tf, 3),
                                     "share_of_step": round((ta + tf) / ms, 4),
                                     "detail": getattr(train_custom_op_ms, "detail", None)})
-            print(json.dumps(line))
+            emit(line)
         if world > 1:
             di.barrier(device)
             torch.distributed.destroy_process_group()
@@ -745,14 +834,16 @@ def main():
         counts = torch.tensor(whole.counts())
         ranks = per_rank_ms(mine, args.steps, device, world)
         if rank == 0:
-            print(json.dumps(dict(
+            emit(dict(
                 common, metric="img/s, rretinanet_obb_r50_fpn v1 1024x1024 inference",
                 value=round(world * RRETINA_BATCH * args.steps / elapsed, 2), unit="img/s",
                 ms_per_step=round(elapsed / args.steps * 1e3, 3), per_rank_ms_per_step=ranks, **dist_info(),
-                config={"workload": "BASELINE configs[1]: rretinanet_obb_r50_fpn v1, batch=2 x 1024x1024 per GPU, inference "
+                config={"workload_short": "BASELINE configs[1]: rretinanet_obb_r50_fpn v1, batch 2 x 1024x1024 per GPU, "
+                                          "inference, synthetic",
+                        "workload": "BASELINE configs[1]: rretinanet_obb_r50_fpn v1, batch=2 x 1024x1024 per GPU, inference "
                                     "(9 anchors / position, nms_pre 2000 per level -> 8576-box pools, nms v1)",
                         "batch_per_gpu": RRETINA_BATCH, "global_batch": RRETINA_BATCH * world},
-                kept_per_image=[int(c) for c in counts.tolist()])))
+                kept_per_image=[int(c) for c in counts.tolist()]))
         if world > 1:
             di.barrier(device)
             torch.distributed.destroy_process_group()
@@ -934,7 +1025,9 @@ def main():
             "unit": "img/s",
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "per_rank_ms_per_step": ranks, **dist_info(),
-            "config": {"workload": "BASELINE configs[2] (the single-GPU case of the metric's model): "
+            "config": {"workload_short": "BASELINE configs[2]: r3det_r50_fpn_1x v1 + FeatureRefineModule, batch 4 x 1024x1024 "
+                                         "per GPU, full inference, synthetic",
+                       "workload": "BASELINE configs[2] (the single-GPU case of the metric's model): "
                                    "r3det_r50_fpn_1x v1 + FeatureRefineModule, batch=4 x 1024x1024 per GPU, "
                                    "full inference incl. backbone, random-init weights, score bias calibrated "
                                    "to ~1 % candidates",
@@ -1066,7 +1159,7 @@ def main():
             phase("cpu baseline")
             line["cpu_baseline"] = cpu_baseline()
         phase("done")
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         di.barrier(device)
         torch.distributed.destroy_process_group()

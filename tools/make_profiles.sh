@@ -107,7 +107,11 @@ ORDERS="-1 31 0 3 8" bash tools/iou_order_ab.sh gpurun_out/profiles_$TAG/${TAG}_
 bash tools/assign_emit_ab.sh gpurun_out/profiles_$TAG/${TAG}_assign_emit_ab.txt > /dev/null 2>&1
 bash tools/mc_select_ab.sh gpurun_out/profiles_$TAG/${TAG}_mc_select_ab.txt > /dev/null 2>&1
 bash tools/iou_dyn_ab.sh gpurun_out/profiles_$TAG/${TAG}_iou_dyn_ab.txt > /dev/null 2>&1
-# 8. the bench lines themselves (no profiler attached)
-python3 $R/bench.py --steps 30 --warmup 5 > $O/${TAG}_bench.json 2> /dev/null
-python3 $R/bench.py --mode train --steps 10 --warmup 3 > $O/${TAG}_train.json 2> /dev/null
-python3 $R/bench.py --mode rretinanet --steps 20 --warmup 5 > $O/${TAG}_rretinanet.json 2> /dev/null
+# 8. the bench records themselves (no profiler attached): <tag>_bench_line.json = the compact stdout line of the contract,
+#    <tag>_bench.json = the detail record bench.py writes next to itself (bench_detail.json)
+python3 $R/bench.py --steps 30 --warmup 5 > $O/${TAG}_bench_line.json 2> /dev/null
+cp $R/bench_detail.json $O/${TAG}_bench.json
+python3 $R/bench.py --mode train --steps 10 --warmup 3 > /dev/null 2>&1
+cp $R/bench_detail.json $O/${TAG}_train.json
+python3 $R/bench.py --mode rretinanet --steps 20 --warmup 5 > /dev/null 2>&1
+cp $R/bench_detail.json $O/${TAG}_rretinanet.json
