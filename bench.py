@@ -108,8 +108,9 @@ def model_step(model, img, batch_size=None):
 class WholeStep:
     """The timed inference step: R3Det.simple_test as ONE HIP graph (network, decoding, pool, multiclass NMS, padded
     result: models/detectors.py::GraphedStep) + the step's one exchange on the buffer the graph wrote
-    (dist_infer.gather_padded).  No host synchronisation inside; the capacity's overflow flags are looked at one step
-    late (a step that overflowed is run again, inside the timed region, after the graph was recorded anew)."""
+    (dist_infer.gather_padded).  The capacity's overflow flags are looked at two steps late (GraphedStep, lag 2): the
+    host only ever waits for a step the GPU finished a whole step ago, so it stays one step ahead of the device; a step
+    that overflowed is run again, inside the timed region, after the graph was recorded anew."""
 
     def __init__(self, model, img):
         from r3det.models.detectors import GraphedStep
@@ -120,13 +121,18 @@ class WholeStep:
     def __call__(self):
         from r3det import dist_infer as di
         out, redo = self.g.step(self.img)
-        if redo:  # the previous step's pool outgrew the capacity: that step again (the graph now has twice the room)
-            self.redone += 1
-            out, _ = self.g.step(self.img)
+        if redo:  # one of the last `redo` steps outgrew the capacity (the graph now has twice the room): those steps again,
+            #       inside the timed region -- the image is the same every step, so "again" is `redo` more steps
+            self.redone += redo
+            for _ in range(redo):
+                out, _ = self.g.step(self.img)
         di.gather_padded(out)
         return out
 
     def counts(self):
+        if self.g.flush():               # (the last steps of the loop were not looked at yet)
+            self.redone += 1
+            self.g.step(self.img)
         return [int(c) for c in self.g.static_out[:, -1, 0].tolist()]
 
 

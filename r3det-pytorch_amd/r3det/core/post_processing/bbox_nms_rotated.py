@@ -208,8 +208,9 @@ class PaddedNms:
     ``nms.overflow`` (B,) int32 is 1 where an image had more candidates than the fixed capacity: its rows are then the
     result for its first ``cap`` candidates.  Both calls of the pipeline (r3det_mcnms_select, r3det_mcnms_padded) are
     plain enqueues on the current stream with every buffer allocated up front, so the step can be recorded in a HIP
-    graph.  The caller looks at ``overflow`` when it next touches the host anyway (``check()``: a pinned 4 * B byte
-    copy made behind the step, read one step late) and ``grow()``s + repeats that step in the rare case.
+    graph.  The caller looks at ``overflow`` when it next touches the host anyway (``post_flags()`` behind a step: a
+    pinned 4 * B byte copy; ``check(lag)`` one or two steps later; ``read()`` where the counts are read) and
+    ``grow()``s + repeats that step in the rare case.
 
     Rows and values equal ``multiclass_nms_rotated_batch``'s lists (tests/test_gpu_mcnms.py)."""
 
@@ -222,8 +223,8 @@ class PaddedNms:
         self.score_thr, self.iou_thr = float(score_thr), float(_get(nms, 'iou_thr'))
         self.device = device
         self._alloc(cap)
-        self.flags_host = torch.zeros(B, dtype=torch.int32).pin_memory()
-        self.flags_event = None
+        self._pending = []      # [(pinned flags, event)] of the steps whose flags were posted and not looked at yet
+        self._free = []         # pinned buffers to use again
 
     def _alloc(self, cap):
         L = _C.lib()
@@ -233,7 +234,7 @@ class PaddedNms:
         with torch.cuda.device(dev):
             self.sel_bytes = int(L.r3det_mcnms_select_workspace_bytes(B, n))
             self.ws_bytes = int(L.r3det_mcnms_workspace_bytes(B, self.cap))
-            words = 4 * B * S + 2 * B + B
+            words = 4 * B * S + 4 * B
             pad = (-words) % 64
             sel_room = (self.sel_bytes + 255) // 256 * 256  # (the suppression workspace behind it stays 256-byte aligned)
             blob = torch.empty(4 * (words + pad) + sel_room + self.ws_bytes, dtype=torch.uint8, device=dev)
@@ -241,13 +242,15 @@ class PaddedNms:
         self.cand_row, self.cand_label, self.cand_rank = (i32[k * B * S:(k + 1) * B * S] for k in (0, 1, 2))
         self.cand_score = i32[3 * B * S:4 * B * S].view(torch.float32)
         self.counts = i32[4 * B * S:4 * B * S + B]        # detections kept
-        self.cand_counts = i32[4 * B * S + B:4 * B * S + 2 * B]
-        self.maxc = i32[4 * B * S + 2 * B:words].view(torch.float32)
+        self.overflow = i32[4 * B * S + B:4 * B * S + 2 * B]   # (next to the counts: lists() reads both in one copy)
+        self.overflow.zero_()
+        self._counts_flags = i32[4 * B * S:4 * B * S + 2 * B]
+        self.cand_counts = i32[4 * B * S + 2 * B:4 * B * S + 3 * B]
+        self.maxc = i32[4 * B * S + 3 * B:words].view(torch.float32)
         self.sel_ws = blob[4 * (words + pad):4 * (words + pad) + self.sel_bytes]
         self.ws = blob[4 * (words + pad) + sel_room:]
         self._blob = blob
         self.out = torch.zeros((B, self.max_num + 1, 7), dtype=torch.float32, device=dev)
-        self.overflow = torch.zeros(B, dtype=torch.int32, device=dev)
 
     def grow(self, factor=2.0):
         """A larger candidate capacity (after ``check()`` reported an overflow).  New buffers: a graph that recorded
@@ -279,22 +282,39 @@ class PaddedNms:
         return out
 
     def post_flags(self):
-        """Behind a step (outside a graph): start the 4 * B byte copy of the overflow flags to pinned memory."""
-        self.flags_host.copy_(self.overflow, non_blocking=True)
-        self.flags_event = torch.cuda.Event()
-        self.flags_event.record()
+        """Behind a step (outside a graph): start the 4 * B byte copy of the overflow flags to pinned memory.  Every
+        posted step keeps its own pinned buffer and event until ``check`` has looked at it."""
+        host = self._free.pop() if self._free else torch.zeros(self.B, dtype=torch.int32).pin_memory()
+        host.copy_(self.overflow, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((host, ev))
 
-    def check(self):
-        """True when the step whose flags were last posted overflowed the capacity (waits for THAT copy only -- one
-        step late, it has long arrived)."""
-        if self.flags_event is None:
-            return False
-        self.flags_event.synchronize()
-        self.flags_event = None
-        return bool(self.flags_host.any())
+    def check(self, lag=1):
+        """True when a posted step that is at least ``lag`` posts old overflowed the capacity.  lag = 1: every posted
+        step is looked at (the host waits for the newest copy, i.e. for the step just enqueued); lag = 2: the newest
+        post stays pending, so the host never waits for the step it enqueued last -- in a back-to-back loop the wait
+        is for a step the GPU finished a whole step ago."""
+        over = False
+        while len(self._pending) >= max(1, lag):
+            host, ev = self._pending.pop(0)
+            ev.synchronize()
+            over |= bool(host.any())
+            self._free.append(host)
+        return over
+
+    def pending(self):
+        """How many posted steps ``check`` has not looked at yet."""
+        return len(self._pending)
+
+    def read(self):
+        """(kept counts, overflow flags) of the last call as Python lists: ONE device-to-host copy (a host
+        synchronisation)."""
+        both = self._counts_flags.tolist()
+        return both[:self.B], both[self.B:]
 
     def lists(self):
         """The reference's per-image return values from the padded result (reads the counts: a host synchronisation;
         for tests and for callers that want ``multiclass_nms_rotated``'s lists)."""
-        kept = self.counts.tolist()
+        kept, _ = self.read()
         return [(self.out[i, :k, :6], self.out[i, :k, 6].long()) for i, k in enumerate(kept)]

@@ -262,14 +262,18 @@ class GraphedStep:
     candidate capacity: nothing in the step looks at a count, the result is the (B, max_per_img + 1, 7) buffer
     ``dist_infer.gather_padded`` sends (rows of [cx, cy, w, h, theta, score, label], the count in the extra row).
 
-    ``step(img)`` replays the graph and returns that buffer; the capacity's overflow flags are copied to pinned memory
-    behind the replay and looked at one step late: the rare step whose pool outgrew the capacity is reported by the
-    NEXT call (``redo`` = True in its return), after the graph has been recorded again with twice the capacity -- the
-    caller repeats the step it had just run.  Reference semantics: models/detectors/r3det.py:112-143."""
+    ``step(img)`` replays the graph and returns that buffer.  The capacity's overflow flags are copied to pinned memory
+    behind every replay and looked at ``lag`` steps late (default 2: the host never waits for the step it has just
+    enqueued, so it stays one whole step ahead of the GPU): the rare step whose pool outgrew the capacity is reported
+    by a LATER call -- ``redo`` = how many of the most recent steps to run again (0 almost always), after the graph has
+    been recorded again with twice the capacity.  A loop over ``step`` ends with ``flush()`` (the last ``lag`` steps
+    have not been looked at yet).  ``simple_test`` checks its own step before it returns.  Reference semantics:
+    models/detectors/r3det.py:112-143."""
 
-    def __init__(self, model, example, cap=None, warmup=3):
+    def __init__(self, model, example, cap=None, warmup=3, lag=2):
         from ..core.post_processing import PaddedNms
         self.model = model
+        self.lag = max(1, int(lag))
         self.static_in = example.clone(memory_format=torch.preserve_format)
         cfg = model.test_cfg
         dev = example.device
@@ -301,15 +305,21 @@ class GraphedStep:
             boxes, scores = self.model.dense_test(self.static_in)
             self.static_out = self.nms(boxes.contiguous(), scores.contiguous())
 
+    def _regrow(self):
+        """An overflow was seen: every step still pending ran on the same short capacity -- drop their flags (the
+        caller repeats them all), double the capacity, record the graph again.  -> how many steps to repeat."""
+        again = 1 + self.nms.pending()
+        self.nms.check(1)
+        self.nms.grow()
+        self._record()
+        return again
+
     @torch.no_grad()
     def step(self, img):
-        """-> (out (B, max_per_img + 1, 7), redo).  ``redo``: the PREVIOUS step overflowed the candidate capacity
-        (its result covered its first ``cap`` candidates only); the graph now has twice the capacity -- run that step
-        again."""
-        redo = self.nms.check()
-        if redo:
-            self.nms.grow()
-            self._record()
+        """-> (out (B, max_per_img + 1, 7), redo).  ``redo`` > 0: one of the last ``redo`` steps BEFORE this one
+        overflowed the candidate capacity (its result covered its first ``cap`` candidates only); the graph now has
+        twice the capacity -- run those ``redo`` steps again."""
+        redo = self._regrow() if self.nms.check(self.lag) else 0
         if img.data_ptr() != self.static_in.data_ptr():
             self.static_in.copy_(img)
         self.graph.replay()
@@ -317,10 +327,31 @@ class GraphedStep:
         return self.static_out, redo
 
     @torch.no_grad()
+    def flush(self):
+        """After the last ``step`` of a loop: wait for the steps not looked at yet.  -> ``redo`` as ``step`` returns it
+        (how many of the most recent steps overflowed the capacity's graph and have to be run again)."""
+        n = self.nms.pending()
+        if self.nms.check(1):
+            self.nms.grow()
+            self._record()
+            return n
+        return 0
+
+    @torch.no_grad()
     def simple_test(self, img):
-        """The reference's per-image (dets, labels) lists (reads the counts: one host synchronisation)."""
-        self.step(img)
-        return self.nms.lists()
+        """The reference's per-image (dets, labels) lists (reads the counts: one host synchronisation).  The counts
+        come back together with this step's overflow flags: a pool beyond the capacity is run again on a graph with
+        room for it BEFORE anything is returned, so the lists always equal ``multiclass_nms_rotated``'s."""
+        self.flush()                      # (earlier ``step`` calls: their redo is the ``step`` caller's business)
+        if img.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(img)
+        while True:
+            self.graph.replay()
+            _, over = self.nms.read()
+            if not any(over):
+                return self.nms.lists()
+            self.nms.grow()
+            self._record()
 
 
 for _c in (R3Det, RRetinaNet):

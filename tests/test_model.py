@@ -425,7 +425,8 @@ def test_whole_step_in_one_hip_graph_without_host_synchronisation():
 
 
 @pytest.mark.gpu
-def test_graphed_step_recovers_from_a_short_capacity():
+@pytest.mark.parametrize("lag", [1, 2])
+def test_graphed_step_recovers_from_a_short_capacity(lag):
     from r3det.models import R3Det
     from r3det.models.detectors import GraphedStep, calibrate_score_bias
     torch.manual_seed(12)
@@ -433,18 +434,75 @@ def test_graphed_step_recovers_from_a_short_capacity():
     m = R3Det().eval().to(dev)
     img = torch.randn(1, 3, 256, 256, device=dev)
     calibrate_score_bias(m, img, frac=0.05)
-    g = GraphedStep(m, img, cap=64)       # far too small
+    g = GraphedStep(m, img, cap=64, lag=lag)       # far too small
     out, redo = g.step(img)
     assert not redo
     short = int(out[0, -1, 0])
-    redone = False
-    for _ in range(12):                   # the next steps report it, grow the capacity and record again
+    redone = 0
+    for _ in range(16):                   # the next steps report it, grow the capacity and record again
         out, redo = g.step(img)
-        redone |= redo
-        if not redo and redone:
+        assert redo in (0, lag)           # `redo` = how many of the most recent steps to run again
+        redone += redo
+        if not redo and redone and not g.flush():
             break
     assert redone and g.nms.cap > 64
+    assert g.flush() == 0 and g.nms.pending() == 0
     assert int(out[0, -1, 0]) >= short and int(g.nms.overflow[0]) == 0
+
+
+@pytest.mark.gpu
+def test_graphed_step_flush_reports_the_last_steps_of_a_loop():
+    """the last step of a step() loop was never checked.  flush() looks at every step still pending."""
+    from r3det.models import R3Det
+    from r3det.models.detectors import GraphedStep, calibrate_score_bias
+    torch.manual_seed(12)
+    dev = torch.device('cuda')
+    m = R3Det().eval().to(dev)
+    img = torch.randn(1, 3, 256, 256, device=dev)
+    calibrate_score_bias(m, img, frac=0.05)
+    g = GraphedStep(m, img, cap=64, lag=2)
+    out, redo = g.step(img)
+    assert redo == 0 and g.nms.pending() == 1
+    assert g.flush() == 1 and g.nms.cap > 64 and g.nms.pending() == 0     # that one step has to be run again
+    while True:                                                              # ... until the capacity holds the pool
+        g.step(img)
+        if not g.flush():
+            break
+    assert int(g.nms.overflow[0]) == 0
+
+
+@pytest.mark.gpu
+def test_graphed_simple_test_with_a_short_capacity_equals_the_list_form():
+    """simple_test must not return the result of a pool that outgrew the capacity -- the lists equal
+    multiclass_nms_rotated's (models/detectors/r3det.py:112-143, core/post_processing/bbox_nms_rotated.py:7-77) on the
+    same dense outputs although the graph was recorded with room for 64 candidates."""
+    from r3det.core.post_processing import multiclass_nms_rotated_batch
+    from r3det.models import R3Det
+    from r3det.models.detectors import GraphedStep, calibrate_score_bias
+    torch.manual_seed(14)
+    dev = torch.device('cuda')
+    m = R3Det().eval().to(dev)
+    img = torch.randn(2, 3, 256, 256, device=dev)
+    calibrate_score_bias(m, img, frac=0.05)
+    g = GraphedStep(m, img, cap=64)
+    res = g.simple_test(img)
+    assert g.nms.cap > 64 and g.nms.overflow.tolist() == [0, 0] and g.nms.pending() == 0
+    cfg = m.test_cfg
+    boxes, scores = m.dense_test(img)
+    n_cand = (scores[..., :-1] > cfg['score_thr']).flatten(1).sum(1)
+    assert int(n_cand.min()) > 64          # every image's pool is beyond the capacity the graph was first recorded with
+    lists = multiclass_nms_rotated_batch(boxes, scores, cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+    for (d, lab), (d2, lab2) in zip(lists, res):
+        # (the convs are not run-to-run bit-stable: a few scores cross the threshold between two passes)
+        assert d.size(0) > 0 and abs(d.size(0) - d2.size(0)) <= max(2, d.size(0) // 50)
+        k = min(d.size(0), d2.size(0), 20)
+        assert torch.allclose(d[:k, 5], d2[:k, 5], atol=1e-4)      # the same top detections, in the same order
+    # a second call on the grown graph: no further growth, the same lists
+    cap = g.nms.cap
+    res2 = g.simple_test(img)
+    assert g.nms.cap == cap
+    for r, r2 in zip(res, res2):
+        assert abs(r[0].size(0) - r2[0].size(0)) <= max(2, r[0].size(0) // 50)
 
 
 @pytest.mark.gpu
