@@ -363,6 +363,21 @@ int r3det_feature_refine_module_levels_nhwc(int levels, const float* const* conv
                                             const float* const* best_bboxes, int N, int C, const int* H, const int* W,
                                             const float* spatial_scales, int points, float* const* outputs, void* stream);
 
+/* The TAIL of FeatureRefineModule.forward for all NCHW levels of a pass in one call (fr/feature_refine_module.py:
+ * 108-127: per level `feat = conv_5_1(conv_1_5(x)) + conv_1_1(x)`, `out = x + fr(feat, boxes)` -- two elementwise passes
+ * around the sampler, level by level), points = 1: outputs[l] = residual[l] + (P + sample(P)), P = conv_a[l] + conv_b[l],
+ * element for element the three-step form.  The coarse levels are ONE grid (the plane sampler with both adds folded in)
+ * that also builds the tap tables of the 128 x 128 / 64 x 64 levels, each of which is then one fused launch
+ * (r3det_feature_refine_module_prepared's): 3 launches for a 1024^2 pyramid instead of 13.  Used by training steps (the
+ * autograd node's forward) and NCHW inference alike.  ws: r3det_fr_module_levels_workspace_bytes() bytes, left holding
+ * the tables.  R3DET_EINVAL: a level takes neither form (nothing was launched: run it level by level).  Pointer / shape
+ * arrays are HOST arrays of `levels` <= 8 entries; all maps (N, C, H, W) contiguous, 16-byte aligned, W % 4 == 0. */
+size_t r3det_fr_module_levels_workspace_bytes(int levels, int N, const int* H, const int* W);
+int r3det_feature_refine_module_levels(int levels, const float* const* conv_a, const float* const* conv_b,
+                                       const float* const* residual, const float* const* best_bboxes, int N, int C,
+                                       const int* H, const int* W, const float* spatial_scales, int points,
+                                       float* const* outputs, void* ws, size_t ws_bytes, void* stream);
+
 /* The per-level loop of FeatureRefineModule.forward (fr/feature_refine_module.py:115-127) in one call:
  * `levels` sampler launches enqueued back to back (from Python each level costs ~10 us of host time, more
  * than the kernels of the three coarse levels).  features / best_bboxes / outputs: HOST arrays of `levels`
@@ -460,6 +475,39 @@ int r3det_feature_refine_backward_nhwc_levels_indexed(int levels, const float* c
                                                       const int* H, const int* W, int points,
                                                       float* const* bottom_grads, int overwrite, void* ws,
                                                       size_t ws_bytes, void* stream);
+
+/* Training steps (round 6): the backward's index as a by-product of the forward launch.  The reference's backward
+ * (fr/src/feature_refine_kernel.cu:165-230) scatters with atomics and needs no index; this library's deterministic
+ * gather does, and building it from the 20-byte box records pulls 327 KB per image through every index workgroup for
+ * one float in five.  A TAP TABLE of a level is, per image, [y: H*W floats][x: H*W floats]: the clamped sample point
+ * of every position (the clamps of bilinear_interpolate, feature_refine_kernel.cu:22-47, applied once; a sample
+ * outside the map = row H + 1) -- r3det_fr_tap_table_bytes(N, H, W) = 8 bytes per position, any shape, points = 1.
+ *   - the _tab forms of the channels_last forward calls WRITE tables[l] (non-NULL entries) from the sampler launches
+ *     themselves: the wave that owns a position stores two floats; no extra launch, same outputs;
+ *   - r3det_feature_refine_prepare's table (NCHW) IS a tap table of its level;
+ *   - the _tab forms of the index calls READ tables[l] where non-NULL (a NULL entry: that level from its boxes): the
+ *     scan is 4 contiguous bytes per source.  The table must come from the same boxes and spatial_scale; the index is
+ *     byte for byte the one the box form builds.  best_bboxes stay required (a band beyond the sorted form's capacity
+ *     falls back to them).
+ * tables: HOST array of `levels` device pointers (16-byte aligned). */
+size_t r3det_fr_tap_table_bytes(int N, int H, int W);
+int r3det_feature_refine_forward_levels_nhwc_tab(int levels, const float* const* features,
+                                                 const float* const* best_bboxes, int N, int C, const int* H,
+                                                 const int* W, const float* spatial_scales, int points,
+                                                 float* const* outputs, float* const* tables, void* stream);
+int r3det_feature_refine_module_levels_nhwc_tab(int levels, const float* const* conv_a, const float* const* conv_b,
+                                                const float* bias_a, const float* bias_b, const float* const* residual,
+                                                const float* const* best_bboxes, int N, int C, const int* H, const int* W,
+                                                const float* spatial_scales, int points, float* const* outputs,
+                                                float* const* tables, void* stream);
+int r3det_feature_refine_backward_index_levels_tab(int levels, const float* const* best_bboxes,
+                                                   const float* const* tables, int N, int C, const int* H, const int* W,
+                                                   const float* spatial_scales, int points, void* ws, size_t ws_bytes,
+                                                   void* stream);
+int r3det_feature_refine_backward_nhwc_index_levels_tab(int levels, const float* const* best_bboxes,
+                                                        const float* const* tables, int N, const int* H, const int* W,
+                                                        const float* spatial_scales, int points, void* ws,
+                                                        size_t ws_bytes, void* stream);
 
 /* Producer of the FR boxes: RRetinaHead.filter_bboxes
  * (models/dense_heads/rotate_retina_head.py:117-179) and, with num_anchors = 1 and

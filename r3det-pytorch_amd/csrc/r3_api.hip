@@ -406,13 +406,34 @@ int r3det_feature_refine_module_nhwc(const float* conv_a, const float* conv_b, c
                                 points, output, S(stream)));
 }
 
+namespace {
+// (tables: null, or per level a device pointer / null -- the tap tables the launches also write, points = 1)
+int fr_levels_nhwc(int levels, const float* const* a, const float* const* b, const float* bias_a, const float* bias_b,
+                   const float* const* res, const float* const* best_bboxes, int N, int C, const int* H, const int* W,
+                   const float* spatial_scales, int points, float* const* outputs, float* const* tables, void* stream) {
+  if (tables && points != 1) return R3DET_EINVAL;
+  return rc(r3k_fr_forward_nhwc_levels(levels, a, b, bias_a, bias_b, res, best_bboxes, N, C, H, W, spatial_scales, points,
+                                       outputs, S(stream), tables));
+}
+}  // namespace
+
 int r3det_feature_refine_forward_levels_nhwc(int levels, const float* const* features, const float* const* best_bboxes,
                                              int N, int C, const int* H, const int* W, const float* spatial_scales,
                                              int points, float* const* outputs, void* stream) {
   const DeviceGuard guard(stream);
   if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5)) return R3DET_EINVAL;
-  return rc(r3k_fr_forward_nhwc_levels(levels, features, nullptr, nullptr, nullptr, nullptr, best_bboxes, N, C, H, W,
-                                       spatial_scales, points, outputs, S(stream)));
+  return fr_levels_nhwc(levels, features, nullptr, nullptr, nullptr, nullptr, best_bboxes, N, C, H, W, spatial_scales,
+                        points, outputs, nullptr, stream);
+}
+
+int r3det_feature_refine_forward_levels_nhwc_tab(int levels, const float* const* features,
+                                                 const float* const* best_bboxes, int N, int C, const int* H,
+                                                 const int* W, const float* spatial_scales, int points,
+                                                 float* const* outputs, float* const* tables, void* stream) {
+  const DeviceGuard guard(stream);
+  if (levels < 0 || N <= 0 || C <= 0 || points != 1 || !tables) return R3DET_EINVAL;
+  return fr_levels_nhwc(levels, features, nullptr, nullptr, nullptr, nullptr, best_bboxes, N, C, H, W, spatial_scales,
+                        points, outputs, tables, stream);
 }
 
 int r3det_feature_refine_module_levels_nhwc(int levels, const float* const* conv_a, const float* const* conv_b,
@@ -424,8 +445,52 @@ int r3det_feature_refine_module_levels_nhwc(int levels, const float* const* conv
     return R3DET_EINVAL;
   for (int l = 0; l < levels; l++)
     if (!conv_a[l] || !residual[l] || (conv_b && conv_b[0] && !conv_b[l])) return R3DET_EINVAL;
-  return rc(r3k_fr_forward_nhwc_levels(levels, conv_a, conv_b, bias_a, bias_b, residual, best_bboxes, N, C, H, W,
-                                       spatial_scales, points, outputs, S(stream)));
+  return fr_levels_nhwc(levels, conv_a, conv_b, bias_a, bias_b, residual, best_bboxes, N, C, H, W, spatial_scales, points,
+                        outputs, nullptr, stream);
+}
+
+int r3det_feature_refine_module_levels_nhwc_tab(int levels, const float* const* conv_a, const float* const* conv_b,
+                                                const float* bias_a, const float* bias_b, const float* const* residual,
+                                                const float* const* best_bboxes, int N, int C, const int* H, const int* W,
+                                                const float* spatial_scales, int points, float* const* outputs,
+                                                float* const* tables, void* stream) {
+  const DeviceGuard guard(stream);
+  if (levels < 0 || N <= 0 || C <= 0 || points != 1 || !tables || (levels > 0 && (!conv_a || !residual)))
+    return R3DET_EINVAL;
+  for (int l = 0; l < levels; l++)
+    if (!conv_a[l] || !residual[l] || (conv_b && conv_b[0] && !conv_b[l])) return R3DET_EINVAL;
+  return fr_levels_nhwc(levels, conv_a, conv_b, bias_a, bias_b, residual, best_bboxes, N, C, H, W, spatial_scales, points,
+                        outputs, tables, stream);
+}
+
+size_t r3det_fr_tap_table_bytes(int N, int H, int W) { return r3k_fr_tap_table_bytes(N, H, W); }
+
+size_t r3det_fr_module_levels_workspace_bytes(int levels, int N, const int* H, const int* W) {
+  if (levels < 0 || !H || !W) return 0;
+  size_t total = 0;
+  for (int l = 0; l < levels; l++) total += (r3k_fr_table_bytes(N, H[l], W[l]) + 255) & ~(size_t)255;
+  return total;
+}
+
+int r3det_feature_refine_module_levels(int levels, const float* const* conv_a, const float* const* conv_b,
+                                       const float* const* residual, const float* const* best_bboxes, int N, int C,
+                                       const int* H, const int* W, const float* spatial_scales, int points,
+                                       float* const* outputs, void* ws, size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
+  if (levels < 1 || levels > 8 || N <= 0 || C <= 0 || points != 1 || !conv_a || !conv_b || !residual || !best_bboxes || !H ||
+      !W || !spatial_scales || !outputs)
+    return R3DET_EINVAL;
+  const size_t need = r3det_fr_module_levels_workspace_bytes(levels, N, H, W);
+  if (ws_bytes < need || (need && !ws)) return R3DET_EWS;
+  float* tables[8];
+  char* p = static_cast<char*>(ws);
+  for (int l = 0; l < levels; l++) {
+    const size_t part = (r3k_fr_table_bytes(N, H[l], W[l]) + 255) & ~(size_t)255;
+    tables[l] = part ? reinterpret_cast<float*>(p) : nullptr;
+    p += part;
+  }
+  return rc(r3k_fr_module_levels(levels, conv_a, conv_b, residual, best_bboxes, N, C, H, W, spatial_scales, outputs, tables,
+                                 S(stream)));
 }
 
 size_t r3det_fr_levels_workspace_bytes(int levels, int N, const int* H, const int* W, int points) {
@@ -503,12 +568,11 @@ size_t r3det_fr_backward_levels_workspace_bytes(int levels, int N, const int* H,
   return total;
 }
 
-int r3det_feature_refine_backward_index_levels(int levels, const float* const* best_bboxes, int N, int C, const int* H,
-                                               const int* W, const float* spatial_scales, int points, void* ws,
-                                               size_t ws_bytes, void* stream) {
-  const DeviceGuard guard(stream);
+namespace {
+int frn_index_levels(int levels, const float* const* best_bboxes, const float* const* tables, int N, int C, const int* H,
+                     const int* W, const float* spatial_scales, int points, void* ws, size_t ws_bytes, void* stream) {
   if (levels < 0 || N <= 0 || C <= 0 || (points != 1 && points != 5) ||
-      (levels > 0 && (!best_bboxes || !H || !W || !spatial_scales)))
+      (levels > 0 && (!best_bboxes || !H || !W || !spatial_scales)) || (tables && points != 1))
     return R3DET_EINVAL;
   if (ws_bytes < r3det_fr_backward_levels_workspace_bytes(levels, N, H, W, points)) return R3DET_EWS;
   char* p = static_cast<char*>(ws);
@@ -520,18 +584,36 @@ int r3det_feature_refine_backward_index_levels(int levels, const float* const* b
       wl[l] = q, wb[l] = lvl_bytes(N, H[l], W[l], points);
       q += wb[l];
     }
-    const int k = r3k_frn_index_levels(levels, best_bboxes, N, C, H, W, spatial_scales, points, wl, wb, S(stream));
+    const int k = r3k_frn_index_levels(levels, best_bboxes, N, C, H, W, spatial_scales, points, wl, wb, S(stream), tables);
     if (k <= 0) return rc(k);
   }
   for (int l = 0; l < levels; l++) {
     const size_t part = lvl_bytes(N, H[l], W[l], points);
     if (part) {  // (a level without a gather form has no index: its gradient pass reads the boxes)
-      const int k = r3k_frn_index(best_bboxes[l], N, C, H[l], W[l], spatial_scales[l], points, p, part, S(stream));
+      const int k = r3k_frn_index(best_bboxes[l], N, C, H[l], W[l], spatial_scales[l], points, p, part, S(stream),
+                                  tables ? tables[l] : nullptr);
       if (k != 0 && k != -1) return rc(k);
     }
     p += part;
   }
   return R3DET_OK;
+}
+}  // namespace
+
+int r3det_feature_refine_backward_index_levels(int levels, const float* const* best_bboxes, int N, int C, const int* H,
+                                               const int* W, const float* spatial_scales, int points, void* ws,
+                                               size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
+  return frn_index_levels(levels, best_bboxes, nullptr, N, C, H, W, spatial_scales, points, ws, ws_bytes, stream);
+}
+
+int r3det_feature_refine_backward_index_levels_tab(int levels, const float* const* best_bboxes,
+                                                   const float* const* tables, int N, int C, const int* H, const int* W,
+                                                   const float* spatial_scales, int points, void* ws, size_t ws_bytes,
+                                                   void* stream) {
+  const DeviceGuard guard(stream);
+  if (!tables) return R3DET_EINVAL;
+  return frn_index_levels(levels, best_bboxes, tables, N, C, H, W, spatial_scales, points, ws, ws_bytes, stream);
 }
 
 int r3det_feature_refine_backward_levels_indexed(int levels, const float* const* top_grads,
@@ -613,11 +695,11 @@ size_t r3det_fr_backward_nhwc_levels_workspace_bytes(int levels, int N, const in
   return total;
 }
 
-int r3det_feature_refine_backward_nhwc_index_levels(int levels, const float* const* best_bboxes, int N, const int* H,
-                                                    const int* W, const float* spatial_scales, int points, void* ws,
-                                                    size_t ws_bytes, void* stream) {
-  const DeviceGuard guard(stream);
-  if (levels < 0 || N <= 0 || (points != 1 && points != 5) || (levels > 0 && (!best_bboxes || !H || !W || !spatial_scales)))
+namespace {
+int frb_index_levels(int levels, const float* const* best_bboxes, const float* const* tables, int N, const int* H,
+                     const int* W, const float* spatial_scales, int points, void* ws, size_t ws_bytes, void* stream) {
+  if (levels < 0 || N <= 0 || (points != 1 && points != 5) || (levels > 0 && (!best_bboxes || !H || !W || !spatial_scales)) ||
+      (tables && points != 1))
     return R3DET_EINVAL;
   const size_t need = r3det_fr_backward_nhwc_levels_workspace_bytes(levels, N, H, W, points);
   if (levels > 0 && need == 0) return R3DET_EINVAL;
@@ -631,13 +713,31 @@ int r3det_feature_refine_backward_nhwc_index_levels(int levels, const float* con
     p += part_bytes[l];
   }
   const int k = r3k_frb_index_levels(levels, best_bboxes, N, H, W, spatial_scales, points, parts.data(), part_bytes.data(),
-                                     S(stream));
+                                     S(stream), tables);
   if (k <= 0) return rc(k);
   for (int l = 0; l < levels; l++) {  // (not every level takes the sorted form: level by level)
-    const int k2 = r3k_frb_index(best_bboxes[l], N, H[l], W[l], spatial_scales[l], points, parts[l], part_bytes[l], S(stream));
+    const int k2 = r3k_frb_index(best_bboxes[l], N, H[l], W[l], spatial_scales[l], points, parts[l], part_bytes[l], S(stream),
+                                 tables ? tables[l] : nullptr);
     if (k2) return rc(k2);
   }
   return R3DET_OK;
+}
+}  // namespace
+
+int r3det_feature_refine_backward_nhwc_index_levels(int levels, const float* const* best_bboxes, int N, const int* H,
+                                                    const int* W, const float* spatial_scales, int points, void* ws,
+                                                    size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
+  return frb_index_levels(levels, best_bboxes, nullptr, N, H, W, spatial_scales, points, ws, ws_bytes, stream);
+}
+
+int r3det_feature_refine_backward_nhwc_index_levels_tab(int levels, const float* const* best_bboxes,
+                                                        const float* const* tables, int N, const int* H, const int* W,
+                                                        const float* spatial_scales, int points, void* ws,
+                                                        size_t ws_bytes, void* stream) {
+  const DeviceGuard guard(stream);
+  if (!tables) return R3DET_EINVAL;
+  return frb_index_levels(levels, best_bboxes, tables, N, H, W, spatial_scales, points, ws, ws_bytes, stream);
 }
 
 int r3det_feature_refine_backward_nhwc_levels_indexed(int levels, const float* const* top_grads, int N, int C,

@@ -119,19 +119,25 @@ constexpr int FRP_LDS_FLOATS = 17 * 1024;  // 68 KB: a 128 x 129 plane (66 KB) f
 constexpr int FRP_STAGE_UNROLL = 4;
 
 // global (contiguous nc planes of HW floats) -> LDS planes with row pitch W+1
-template <bool VEC>
+// (src2: a second addend of the planes, or null -- the module's conv_5_1(conv_1_5(x)) + conv_1_1(x), summed on the way in)
+template <bool VEC, bool TWO = false>
 __device__ __forceinline__ void stage_planes(const float* __restrict__ src, float* lds, int nc, int HW,
-                                             int W, int pitch, int psz, const int tid, const int T) {
+                                             int W, int pitch, int psz, const int tid, const int T,
+                                             const float* __restrict__ src2 = nullptr) {
   const int total = nc * HW;
   if (VEC) {
     const float4* s4 = reinterpret_cast<const float4*>(src);
+    const float4* t4 = reinterpret_cast<const float4*>(src2);
     const int total4 = total >> 2;
     for (int base = tid; base < total4; base += T * FRP_STAGE_UNROLL) {
-      float4 v[FRP_STAGE_UNROLL];
+      float4 v[FRP_STAGE_UNROLL], u[FRP_STAGE_UNROLL];
 #pragma unroll
       for (int k = 0; k < FRP_STAGE_UNROLL; k++) {
         int i = base + k * T;
-        if (i < total4) v[k] = s4[i];
+        if (i < total4) {
+          v[k] = s4[i];
+          if (TWO) u[k] = t4[i];
+        }
       }
 #pragma unroll
       for (int k = 0; k < FRP_STAGE_UNROLL; k++) {
@@ -141,7 +147,8 @@ __device__ __forceinline__ void stage_planes(const float* __restrict__ src, floa
           int ch = e / HW, r = e - ch * HW;
           int y = r / W, x = r - y * W;
           float* d = lds + ch * psz + y * pitch + x;
-          d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+          if (TWO) { d[0] = v[k].x + u[k].x; d[1] = v[k].y + u[k].y; d[2] = v[k].z + u[k].z; d[3] = v[k].w + u[k].w; }
+          else { d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w; }
         }
       }
     }
@@ -149,7 +156,7 @@ __device__ __forceinline__ void stage_planes(const float* __restrict__ src, floa
     for (int e = tid; e < total; e += T) {
       int ch = e / HW, r = e - ch * HW;
       int y = r / W, x = r - y * W;
-      lds[ch * psz + y * pitch + x] = src[e];
+      lds[ch * psz + y * pitch + x] = TWO ? src[e] + src2[e] : src[e];
     }
   }
 }
@@ -158,13 +165,16 @@ __device__ __forceinline__ void stage_planes(const float* __restrict__ src, floa
 // has ONE in-order vmcnt queue for loads and stores, so "wait for the next quad's boxes" also
 // waits for every store issued before them unless the boxes were requested BEFORE those stores
 // and the compiler can count the younger stores (s_waitcnt vmcnt(NC) instead of vmcnt(0)).
-template <int POINTS, bool VEC, int NC>
+// FUSED (VEC only): the module's tail, out = res + (P + sample(P)) with P = feat + feat2 (feature_refine_module.py:121-126)
+template <int POINTS, bool VEC, int NC, bool FUSED = false>
 // (tid, T: the thread's index among the T threads that work on this (image, channel group) -- the whole workgroup
 // for the per-level launches, a quarter of it in the levels grid; lds_off: where their planes start)
 __device__ __forceinline__ void fr_forward_plane_body(const float* __restrict__ feat, const float* __restrict__ boxes,
                                                       int C, int H, int W, float scale, int cpb,
                                                       float* __restrict__ out, const int bx, const int n, const int tid,
-                                                      const int T, const int lds_off) {
+                                                      const int T, const int lds_off,
+                                                      const float* __restrict__ feat2 = nullptr,
+                                                      const float* __restrict__ res = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   float* lds = lds_all + lds_off;
   const int HW = H * W;
@@ -182,7 +192,9 @@ __device__ __forceinline__ void fr_forward_plane_body(const float* __restrict__ 
 #pragma unroll
       for (int k = 0; k < 5; k++) nb[k] = bx4[tid * 5 + k];
     }
-    stage_planes<true>(src, lds, nc, HW, W, pitch, psz, tid, T);
+    if (FUSED) stage_planes<true, true>(src, lds, nc, HW, W, pitch, psz, tid, T, feat2 + ((size_t)n * C + c0) * HW);
+    else stage_planes<true>(src, lds, nc, HW, W, pitch, psz, tid, T);
+    const float* rsd = FUSED ? res + ((size_t)n * C + c0) * HW : nullptr;
     __syncthreads();
     for (int qd = tid; qd < quads; qd += T) {
       float bq[20];
@@ -212,6 +224,10 @@ __device__ __forceinline__ void fr_forward_plane_body(const float* __restrict__ 
 #pragma unroll
             for (int p = 0; p < POINTS; p++) v += tap_value(taps[j][p], plane);
             r[j] = v;
+          }
+          if (FUSED) {  // (the residual: x + (P + sample(P)), the module's last add)
+            const float4 x4 = *reinterpret_cast<const float4*>(rsd + (size_t)c2 * HW + hw0);
+            r[0] = x4.x + r[0]; r[1] = x4.y + r[1]; r[2] = x4.z + r[2]; r[3] = x4.w + r[3];
           }
           *reinterpret_cast<float4*>(dst + (size_t)c2 * HW + hw0) = make_float4(r[0], r[1], r[2], r[3]);
         }
@@ -253,6 +269,8 @@ constexpr int FRPL_T = 256;      // threads per (image, channel group) in the le
 constexpr int FRPL_BLOCK = 256;  // threads per workgroup of the levels grid
 struct FrPlaneLevel {
   const float* feat;
+  const float* feat2;  // FUSED grids: the second addend and the residual of the module tail
+  const float* res;
   const float* boxes;
   float* out;
   float scale;
@@ -267,6 +285,11 @@ struct FrPlaneLevels {
   float* table;
   float tscale;
   int tN, tH, tW, tfirst;
+  // (the module-tail grid carries the tables of BOTH cell levels: a second job of the same kind behind the first)
+  const float* t2boxes;
+  float* table2;
+  float t2scale;
+  int t2H, t2W, t2first;
 };
 
 // sample coordinates (row y <- x_ctr * scale, column x <- y_ctr * scale) -> the tap the cell kernel
@@ -287,6 +310,25 @@ __device__ __forceinline__ void cell_tap(float y, float x, int H, int W, float& 
 }
 
 typedef float fr_f2 __attribute__((ext_vector_type(2)));
+
+// Round 6: a channels_last sampler launch that runs in a training step also WRITES the level's tap table -- per image
+// [y: HW floats][x: HW floats], the clamped sample point of every position (cell_tap; fr_cell_table_kernel's layout) --
+// as a by-product: the wave that owns position q has its box in scalar registers anyway, one lane stores two floats.
+// The backward's index kernel (r3_frb.hip, TAB form) then scans 4 contiguous bytes per source instead of the 20-byte
+// box records.  (The reference's backward needs no index: it scatters with atomics, feature_refine_kernel.cu:165-230.)
+// (At the kernel's start, before its row loads are in flight: lanes 0 .. cnt - 1 of the wave take one position each --
+// in the position loop the few temporaries of the clamps pushed the module-tail kernel past its 64 registers.)
+__device__ __forceinline__ void fr_emit_tab(float* __restrict__ tabI, const float* __restrict__ bxI, const int HW,
+                                            const unsigned q0, const int cnt, const int lane, const float scale,
+                                            const int H, const int W) {
+  if (lane < cnt) {
+    const unsigned q = q0 + (unsigned)lane;
+    float y_, x_;
+    cell_tap(bxI[q * 5u] * scale, bxI[q * 5u + 1u] * scale, H, W, y_, x_);  // sic: row <- x_ctr, column <- y_ctr
+    tabI[q] = y_;
+    tabI[HW + q] = x_;
+  }
+}
 
 // points = 5 (feature_refine_kernel.cu:137-151: the centre and the four corners of the box), NCHW, the cell kernel's
 // plane layout -- whole plane in LDS, pitch W + 1, the last column and row staged twice so that the upper taps are
@@ -443,7 +485,12 @@ __device__ __forceinline__ void fr_cell_table_body(const float* __restrict__ box
   table[(size_t)n * 2 * HW + HW + p] = x;
 }
 
+template <bool FUSED = false>
 __global__ __launch_bounds__(FRPL_BLOCK) void fr_forward_plane_levels(const FrPlaneLevels A, int C) {
+  if (FUSED && A.t2first >= 0 && (int)blockIdx.x >= A.t2first) {
+    fr_cell_table_body(A.t2boxes, A.tN, A.t2H, A.t2W, A.t2scale, A.table2, ((int)blockIdx.x - A.t2first) * FRPL_BLOCK + (int)threadIdx.x);
+    return;
+  }
   if (A.tfirst >= 0 && (int)blockIdx.x >= A.tfirst) {
     fr_cell_table_body(A.tboxes, A.tN, A.tH, A.tW, A.tscale, A.table, ((int)blockIdx.x - A.tfirst) * FRPL_BLOCK + (int)threadIdx.x);
     return;
@@ -464,9 +511,12 @@ __global__ __launch_bounds__(FRPL_BLOCK) void fr_forward_plane_levels(const FrPl
   }
   const int off = (int)(threadIdx.x / FRPL_T) * L.cpb * L.H * (L.W + 1);
   // (planes per unit at compile time where it is 1 or 2, as the per-level launches have it)
-  if (L.cpb == 1) fr_forward_plane_body<1, true, 1>(L.feat, L.boxes, C, L.H, L.W, L.scale, 1, L.out, bx, n, tid, FRPL_T, off);
-  else if (L.cpb == 2) fr_forward_plane_body<1, true, 2>(L.feat, L.boxes, C, L.H, L.W, L.scale, 2, L.out, bx, n, tid, FRPL_T, off);
-  else fr_forward_plane_body<1, true, 0>(L.feat, L.boxes, C, L.H, L.W, L.scale, L.cpb, L.out, bx, n, tid, FRPL_T, off);
+  if (L.cpb == 1)
+    fr_forward_plane_body<1, true, 1, FUSED>(L.feat, L.boxes, C, L.H, L.W, L.scale, 1, L.out, bx, n, tid, FRPL_T, off, L.feat2, L.res);
+  else if (L.cpb == 2)
+    fr_forward_plane_body<1, true, 2, FUSED>(L.feat, L.boxes, C, L.H, L.W, L.scale, 2, L.out, bx, n, tid, FRPL_T, off, L.feat2, L.res);
+  else
+    fr_forward_plane_body<1, true, 0, FUSED>(L.feat, L.boxes, C, L.H, L.W, L.scale, L.cpb, L.out, bx, n, tid, FRPL_T, off, L.feat2, L.res);
 }
 
 // backward: accumulate the plane's gradient in LDS (ds_add_f32), then one coalesced
@@ -888,11 +938,12 @@ __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_pipe(
 // So: no register pipeline: a wave requests the identity rows of its four positions at once and there are 16
 // waves per CU; and most tap rows never pass through the L1 at all (see the kernel's first comment).
 // VAR bit 0: boxes prefetched in phase 1; bit 1: non-temporal res / out; bit 2: 32-bit index arithmetic
-template <bool FUSED, bool PAIRED, int VAR = 0>
+template <bool FUSED, bool PAIRED, int VAR = 0, bool EMIT = false>  // EMIT: the launch also writes the level's tap table
 __device__ __forceinline__ void fr_forward_nhwc_occ_body(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
     const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
-    float scale, int tiles_xs, int tiles_per_img, int T, float* __restrict__ out, const unsigned block) {
+    float scale, int tiles_xs, int tiles_per_img, int T, float* __restrict__ out, const unsigned block,
+    float* __restrict__ tab = nullptr) {
   const int tiles_x = tiles_xs & 0xfffff, strip = tiles_xs >> 20;  // (the pair walk's strip height rides in the top bits)
   // The sampled map P = (a + bias_a) + (b + bias_b) of the workgroup's own positions is shared through LDS: each
   // wave computes P for its 4 positions once (their identity term), the barrier publishes the two 4 x 4 tiles, and
@@ -955,6 +1006,7 @@ __device__ __forceinline__ void fr_forward_nhwc_occ_body(
     const int own = half * 16 + wave * 4, halfX = PAIRED ? half << 4 : 0;
     float4 (*Pf)[64] = &Ps[0][0];  // slot (half * 16 + row of the tile * 4 + column) x lane
     const int ty4 = ty * NH_ROWS, tx4 = tx * 4, oy4 = oy * NH_ROWS, ox4 = ox * 4;
+    if (EMIT && tab) fr_emit_tab(tab + (size_t)n * 2 * HW, bxI, HW, q0, cnt, lane, scale, H, W);
     for (int c0 = 0; c0 < C4; c0 += 64) {  // (wave-uniform trip count: the barriers are inside)
       const bool cl = c0 + lane < C4;
       const unsigned laneB = (unsigned)(c0 + lane) * 16u;
@@ -1091,6 +1143,8 @@ __device__ __forceinline__ void fr_forward_nhwc_occ_body(
   float4* o4 = reinterpret_cast<float4*>(out);
   const bool two = FUSED && b != nullptr, has_res = FUSED && res != nullptr;
   const int w0 = tx * 4, cnt = idle ? 0 : min(4, W - w0);
+  if (EMIT && tab)  // (images of 4 GB and more have fewer than 2^32 positions all the same)
+    fr_emit_tab(tab + (size_t)n * 2 * HW, boxes + img * 5, HW, idle ? 0u : (unsigned)(h * W + w0), cnt, lane, scale, H, W);
   for (int c0 = 0; c0 < C4; c0 += 64) {  // (wave-uniform trip count: the barriers are inside)
     const int c4 = c0 + lane;
     const bool cl = c4 < C4;
@@ -1192,13 +1246,13 @@ __device__ __forceinline__ void fr_forward_nhwc_occ_body(
   }
 }
 
-template <bool FUSED, bool PAIRED, int VAR = 0>
+template <bool FUSED, bool PAIRED, int VAR = 0, bool EMIT = false>
 __global__ __launch_bounds__(PAIRED ? 512 : 256) void fr_forward_nhwc_occ(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
     const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
-    float scale, int tiles_xs, int tiles_per_img, int T, float* __restrict__ out) {
-  fr_forward_nhwc_occ_body<FUSED, PAIRED, VAR>(a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_xs, tiles_per_img, T,
-                                               out, blockIdx.x);
+    float scale, int tiles_xs, int tiles_per_img, int T, float* __restrict__ out, float* __restrict__ tab = nullptr) {
+  fr_forward_nhwc_occ_body<FUSED, PAIRED, VAR, EMIT>(a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_xs, tiles_per_img,
+                                                     T, out, blockIdx.x, tab);
 }
 
 // Several pyramid levels of the channels_last sampler / module tail as ONE grid (the levels in kernel arguments, a
@@ -1209,6 +1263,7 @@ constexpr int FRL_MAX = 8;
 struct FrNhwcLevel {
   const float *a, *b, *res, *boxes;
   float* out;
+  float* tab;  // the level's tap table to write (training) or null
   float scale;
   int H, W, tiles_xs, tiles_per_img, T, first;
 };
@@ -1217,7 +1272,7 @@ struct FrNhwcLevels {
   int n;
 };
 
-template <bool FUSED>
+template <bool FUSED, bool EMIT = false>
 __global__ __launch_bounds__(512) void fr_forward_nhwc_occ_levels(const FrNhwcLevels A, const float* __restrict__ bias_a,
                                                                   const float* __restrict__ bias_b, int C) {
   int lv = 0;
@@ -1225,8 +1280,8 @@ __global__ __launch_bounds__(512) void fr_forward_nhwc_occ_levels(const FrNhwcLe
   for (int i = 1; i < FRL_MAX; i++)
     if (i < A.n && (int)blockIdx.x >= A.l[i].first) lv = i;
   const FrNhwcLevel& L = A.l[lv];
-  fr_forward_nhwc_occ_body<FUSED, true, 14>(L.a, L.b, bias_a, bias_b, L.res, L.boxes, C, L.H, L.W, L.scale, L.tiles_xs,
-                                            L.tiles_per_img, L.T, L.out, blockIdx.x - (unsigned)L.first);
+  fr_forward_nhwc_occ_body<FUSED, true, 14, EMIT>(L.a, L.b, bias_a, bias_b, L.res, L.boxes, C, L.H, L.W, L.scale, L.tiles_xs,
+                                                  L.tiles_per_img, L.T, L.out, blockIdx.x - (unsigned)L.first, L.tab);
 }
 
 // "Wide" form of the kernel above for square maps whose side is a multiple of 8: 64 positions and 16 waves per
@@ -1244,11 +1299,12 @@ __global__ __launch_bounds__(512) void fr_forward_nhwc_occ_levels(const FrNhwcLe
 // written HBM traffic FETCH x 2 + WRITE 317 -> 288 MB = 1.07 x algorithmic, but 55.8 - 57.6 us against 53.9 - 55.0 for
 // the 4 x 4 pairs; with the residual rows and boxes requested in front of the barrier (below) 53.4 - 55.1 us, the same
 // as the pairs, at 311 MB = 1.15 x (more rows in flight turn the L2 over faster: some of the saved re-fetches return).
-template <bool FUSED, bool TWO = false, bool RES = false>  // TWO: a second addend b; RES: a residual (both FUSED only)
+// EMIT: the launch also writes the level's tap table (training steps; fr_emit_tab)
+template <bool FUSED, bool TWO = false, bool RES = false, bool EMIT = false>  // TWO: a second addend b; RES: a residual (both FUSED only)
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void fr_forward_nhwc_wide(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias_a,
     const float* __restrict__ bias_b, const float* __restrict__ res, const float* __restrict__ boxes, int C, int H, int W,
-    float scale, int S_strip, int per_img, int T, float* __restrict__ out) {
+    float scale, int S_strip, int per_img, int T, float* __restrict__ out, float* __restrict__ tab = nullptr) {
   __shared__ float4 Pw[64][64];  // slot x lane
   const int S = S_strip & 0xfffff, strip = S_strip >> 20;  // super-blocks per side; the pair walk's strip height
   const int lane = threadIdx.x & 63;
@@ -1288,6 +1344,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   const float* bxI = boxes + (size_t)n * HW * 5;
   const unsigned rowB = (unsigned)C * 4u;
   const unsigned q0 = (unsigned)(py * W + px0);
+  if (EMIT && tab) fr_emit_tab(tab + (size_t)n * 2 * HW, bxI, HW, q0, 4, lane, scale, H, W);
   for (int c0 = 0; c0 < C4; c0 += 64) {  // (wave-uniform trip count: the barriers are inside)
     const bool cl = c0 + lane < C4;
     const unsigned laneB = (unsigned)(c0 + lane) * 16u;
@@ -1797,6 +1854,7 @@ int r3k_fr_forward_levels(int levels, const float* const* feat, const float* con
     if (cell_shape || cpb <= 0 || !vec || (FRPL_BLOCK / FRPL_T) * H[l] * (W[l] + 1) > FRP_LDS_FLOATS) continue;
     FrPlaneLevel& L = A.l[A.n++];
     L.feat = feat[l], L.boxes = boxes[l], L.out = out[l], L.scale = scales[l], L.H = H[l], L.W = W[l], L.cpb = cpb;
+    L.feat2 = L.res = nullptr;
     grouped[l] = true;
   }
   // a level that takes the cell kernel with a tap table (128 x 128): its table rides in the grid
@@ -1834,6 +1892,7 @@ int r3k_fr_forward_levels(int levels, const float* const* feat, const float* con
     lds = std::max(lds, (size_t)U * cpb * L.H * (L.W + 1) * sizeof(float));
   }
   A.tfirst = -1, A.tboxes = nullptr, A.table = nullptr, A.tscale = 0.f, A.tN = A.tH = A.tW = 0;
+  A.t2first = -1, A.t2boxes = nullptr, A.table2 = nullptr, A.t2scale = 0.f, A.t2H = A.t2W = 0;
   if (tl >= 0) {
     A.tfirst = blocks, A.tboxes = boxes[tl], A.table = reinterpret_cast<float*>(tws), A.tscale = scales[tl];
     A.tN = N, A.tH = H[tl], A.tW = W[tl];
@@ -1842,8 +1901,8 @@ int r3k_fr_forward_levels(int levels, const float* const* feat, const float* con
   if (A.n) {  // (first: the cell kernel below reads the table)
     for (int i = A.n; i < FRPL_MAX; i++) A.l[i] = A.l[A.n - 1];
     static R3DeviceOnce once;
-    if (once.first()) allow_big_lds(fr_forward_plane_levels, FRP_LDS_FLOATS * 4);
-    hipLaunchKernelGGL(fr_forward_plane_levels, dim3(blocks), dim3(FRPL_BLOCK), lds, stream, A, C);
+    if (once.first()) allow_big_lds(fr_forward_plane_levels<false>, FRP_LDS_FLOATS * 4);
+    hipLaunchKernelGGL(fr_forward_plane_levels<false>, dim3(blocks), dim3(FRPL_BLOCK), lds, stream, A, C);
     if (hipGetLastError() != hipSuccess) return -2;
   }
   char* p = static_cast<char*>(ws);
@@ -1909,13 +1968,92 @@ int r3k_fr_forward_prepared(const float* feat, const float* feat2, const float* 
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// The module tail of ALL levels of an NCHW pass, out_l = res_l + (P_l + sample(P_l)), P_l = a_l + b_l
+// (feature_refine_module.py:108-127: the loop over the levels with its two elementwise passes per level), points = 1:
+// ONE grid for the coarse levels (the float4 plane kernel with the two adds folded in) that also carries the tap tables
+// of the cell levels (128 x 128 / 64 x 64), then one fused cell launch per cell level: 3 launches for a 1024^2 pyramid
+// where the per-level form took 2 table + 2 cell launches and 3 x (add, sampler, add).  tables[l]: r3k_fr_table_bytes
+// of storage for a cell level (left holding the level's tap table), ignored elsewhere.  -1: a level takes neither form
+// (nothing was launched; the caller runs level by level).
+int r3k_fr_module_levels(int levels, const float* const* a, const float* const* b, const float* const* res,
+                         const float* const* boxes, int N, int C, const int* H, const int* W, const float* scales,
+                         float* const* out, float* const* tables, hipStream_t stream) {
+  if (levels < 1 || levels > FRPL_MAX || !a || !b || !res || !boxes || !H || !W || !scales || !out || !tables || N <= 0 ||
+      C <= 0 || g_r3_fr_impl != 0 || r3_fr_dbg() != 0)
+    return -1;
+  FrPlaneLevels A;
+  A.n = 0;
+  int cell[2] = {-1, -1}, ncell = 0;
+  int G = 1;
+  while (G * 2 <= 16 && C % (G * 2) == 0 && (size_t)N * C / (G * 2) >= (size_t)cu_count()) G *= 2;
+  for (int l = 0; l < levels; l++) {
+    if (!a[l] || !b[l] || !res[l] || !boxes[l] || !out[l] || H[l] <= 0 || W[l] <= 0 || !aligned16(a[l]) || !aligned16(b[l]) ||
+        !aligned16(res[l]) || !aligned16(out[l]) || !aligned16(boxes[l]))
+      return -1;
+    if (r3k_fr_table_bytes(N, H[l], W[l])) {
+      if (G < 2 || ncell == 2 || !tables[l] || !aligned16(tables[l]) || (long long)N * H[l] * W[l] >= (1LL << 30)) return -1;
+      cell[ncell++] = l;
+      continue;
+    }
+    const int cpb = plane_cpb(C, H[l], W[l]);
+    if (cpb <= 0 || (W[l] & 3) || (FRPL_BLOCK / FRPL_T) * H[l] * (W[l] + 1) > FRP_LDS_FLOATS) return -1;
+    FrPlaneLevel& L = A.l[A.n++];
+    L.feat = a[l], L.feat2 = b[l], L.res = res[l], L.boxes = boxes[l], L.out = out[l], L.scale = scales[l], L.H = H[l],
+    L.W = W[l], L.cpb = cpb;
+  }
+  int blocks = 0;
+  size_t lds = 0;
+  for (int i = 0; i < A.n; i++) {
+    FrPlaneLevel& L = A.l[i];
+    int cpb = L.cpb;
+    constexpr int U = FRPL_BLOCK / FRPL_T;
+    while (cpb > 1 && ((size_t)N * ((C + cpb - 1) / cpb) < 512 || C % cpb || U * cpb * L.H * (L.W + 1) > FRP_LDS_FLOATS))
+      cpb = (cpb + 1) / 2;
+    if (C % cpb) return -1;
+    L.cpb = cpb, L.gx = C / cpb, L.first = blocks, L.N = N;
+    blocks += (L.gx * N + U - 1) / U;
+    lds = std::max(lds, (size_t)U * cpb * L.H * (L.W + 1) * sizeof(float));
+  }
+  A.tfirst = A.t2first = -1, A.tboxes = A.t2boxes = nullptr, A.table = A.table2 = nullptr, A.tscale = A.t2scale = 0.f;
+  A.tN = N, A.tH = A.tW = A.t2H = A.t2W = 0;
+  if (ncell >= 1) {
+    const int l = cell[0];
+    A.tfirst = blocks, A.tboxes = boxes[l], A.table = tables[l], A.tscale = scales[l], A.tH = H[l], A.tW = W[l];
+    blocks += (N * H[l] * W[l] + FRPL_BLOCK - 1) / FRPL_BLOCK;
+  }
+  if (ncell == 2) {
+    const int l = cell[1];
+    A.t2first = blocks, A.t2boxes = boxes[l], A.table2 = tables[l], A.t2scale = scales[l], A.t2H = H[l], A.t2W = W[l];
+    blocks += (N * H[l] * W[l] + FRPL_BLOCK - 1) / FRPL_BLOCK;
+  }
+  if (blocks) {
+    if (A.n == 0) {  // (tables only: the struct's level slots still have to be readable)
+      FrPlaneLevel& L = A.l[0];
+      L.feat = L.feat2 = L.res = L.boxes = nullptr, L.out = nullptr, L.scale = 0.f, L.H = L.W = L.cpb = L.gx = 1, L.N = 0;
+      L.first = 0;
+    }
+    for (int i = std::max(A.n, 1); i < FRPL_MAX; i++) A.l[i] = A.l[std::max(A.n, 1) - 1];
+    static R3DeviceOnce once;
+    if (once.first()) allow_big_lds(fr_forward_plane_levels<true>, FRP_LDS_FLOATS * 4);
+    hipLaunchKernelGGL(fr_forward_plane_levels<true>, dim3(blocks), dim3(FRPL_BLOCK), lds, stream, A, C);
+    if (hipGetLastError() != hipSuccess) return -2;
+  }
+  for (int i = 0; i < ncell; i++) {
+    const int l = cell[i];
+    const int k = r3k_fr_forward_prepared(a[l], b[l], res[l], tables[l], N, C, H[l], W[l], out[l], stream);
+    if (k) return k == -1 ? -2 : k;  // (the grid already ran: not a "nothing launched" answer)
+  }
+  return 0;
+}
+
 // channels_last sampler: feat / out are (N, H, W, C) contiguous.  b, biases, res null: out = feat + sample(feat)
 // (r3det_feature_refine_forward on NHWC memory); otherwise the module tail
 // out = res + (P + sample(P)), P = (a + bias_a) + (b + bias_b).  C % 4 == 0 and 16-byte aligned pointers.
 int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, const float* bias_b, const float* res,
                         const float* boxes, int N, int C, int H, int W, float scale, int points, float* out,
-                        hipStream_t stream) {
+                        hipStream_t stream, float* tab) {
   if (!a || !boxes || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (points != 1 && points != 5)) return -1;
+  if (tab && (points != 1 || !aligned16(tab))) return -1;  // (the table is the points = 1 sample point)
   if ((C & 3) || !aligned16(a) || !aligned16(out) || (b && !aligned16(b)) || (res && !aligned16(res)) ||
       (bias_a && !aligned16(bias_a)) || (bias_b && !aligned16(bias_b)))
     return -1;
@@ -1924,6 +2062,7 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
   // switches the pairing off for A/B runs); points = 5: the simple kernel
   const int dbg = r3_fr_dbg();  // (read once per call)
   const bool occ = points == 1 && dbg != 2;  // fr_dbg 2 (probes builds): the register-pipelined kernel
+  if (tab && !occ) return -1;                // (only the shipped kernels write the table)
   const int kw = 4, kh = NH_ROWS;
   const int tiles_x = (W + kw - 1) / kw, tiles_y = (H + kh - 1) / kh;
   const bool paired = points == 1 && tiles_x == tiles_y && dbg != 1;
@@ -1946,8 +2085,14 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     const dim3 gw((unsigned)Tw), bw(1024);
     const int s_strip = S | (g_r3_fr_walk << 20);
 #define R3_WIDE(F, T2, RS) \
-  hipExtLaunchKernelGGL((fr_forward_nhwc_wide<F, T2, RS>), gw, bw, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, boxes, C, H, \
-                        W, scale, s_strip, S * S, (int)Tw, out)
+  do { \
+    if (tab) \
+      hipExtLaunchKernelGGL((fr_forward_nhwc_wide<F, T2, RS, true>), gw, bw, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, \
+                            boxes, C, H, W, scale, s_strip, S * S, (int)Tw, out, tab); \
+    else \
+      hipExtLaunchKernelGGL((fr_forward_nhwc_wide<F, T2, RS>), gw, bw, 0, stream, e0, e1, 0, a, b, bias_a, bias_b, res, boxes, \
+                            C, H, W, scale, s_strip, S * S, (int)Tw, out, (float*)nullptr); \
+  } while (0)
     if (!fused) R3_WIDE(false, false, false);
     else if (b && res) R3_WIDE(true, true, true);
     else if (b) R3_WIDE(true, true, false);
@@ -1972,7 +2117,7 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     const bool big = (unsigned long long)H * W * C * 4ull >= (1ull << 32);  // (32-bit byte offsets inside an image)
     const int var = (dbg == 3 || big) ? 0 : dbg == 4 ? 1 : dbg == 5 ? 2 : dbg == 6 ? 6 : 14;
 #undef R3_ARGS
-#define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x | (g_r3_fr_walk << 20), tpi, (int)T, out
+#define R3_ARGS a, b, bias_a, bias_b, res, boxes, C, H, W, scale, tiles_x | (g_r3_fr_walk << 20), tpi, (int)T, out, tab
 #ifdef R3_PROBES  // (the variants measured on the way, tools/fr_nhwc_ab.py / fr_fwd_var_ab.py)
 #define R3_OCC(F, P) \
   do { \
@@ -1989,6 +2134,19 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
     else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 14>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
   } while (0)
 #endif
+    if (tab) {  // (training: the same kernels, also writing the level's tap table)
+#define R3_OCCT(F, P) \
+  do { \
+    if (var == 0) hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 0, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+    else hipExtLaunchKernelGGL((fr_forward_nhwc_occ<F, P, 14, true>), grid, block, 0, stream, e0, e1, 0, R3_ARGS); \
+  } while (0)
+      if (paired) {
+        if (fused) R3_OCCT(true, true); else R3_OCCT(false, true);
+      } else {
+        if (fused) R3_OCCT(true, false); else R3_OCCT(false, false);
+      }
+#undef R3_OCCT
+    } else
     if (paired) {
       if (fused) R3_OCC(true, true); else R3_OCC(false, true);
     } else {
@@ -2029,8 +2187,9 @@ int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, con
 int r3k_fr_forward_nhwc_levels(int levels, const float* const* a, const float* const* b, const float* bias_a,
                                const float* bias_b, const float* const* res, const float* const* boxes, int N, int C,
                                const int* H, const int* W, const float* scales, int points, float* const* out,
-                               hipStream_t stream) {
+                               hipStream_t stream, float* const* tabs) {
   if (levels < 0 || !a || !boxes || !out || !H || !W || !scales) return -1;
+  if (tabs && points != 1) return -1;
   FrNhwcLevels A;
   A.n = 0;
   int blocks = 0;
@@ -2044,11 +2203,13 @@ int r3k_fr_forward_nhwc_levels(int levels, const float* const* a, const float* c
     const bool ok = points == 1 && r3_fr_dbg() == 0 && tiles_x == tiles_y && !wide && !big && N > 0 && C > 0 && !(C & 3) &&
                     a[l] && boxes[l] && out[l] && aligned16(a[l]) && aligned16(out[l]) &&
                     (!has_b || (b[l] && aligned16(b[l]))) && (!has_res || (res[l] && aligned16(res[l]))) &&
-                    (!bias_a || aligned16(bias_a)) && (!bias_b || aligned16(bias_b));
+                    (!bias_a || aligned16(bias_a)) && (!bias_b || aligned16(bias_b)) &&
+                    (!tabs || !tabs[l] || aligned16(tabs[l]));
     if (!ok) continue;
     const int tpi = tiles_x * (tiles_x - 1) / 2 + (tiles_x + 1) / 2;
     FrNhwcLevel& L = A.l[A.n++];
     L.a = a[l], L.b = has_b ? b[l] : nullptr, L.res = has_res ? res[l] : nullptr, L.boxes = boxes[l], L.out = out[l];
+    L.tab = tabs ? tabs[l] : nullptr;
     L.scale = scales[l], L.H = H[l], L.W = W[l], L.tiles_xs = tiles_x | (g_r3_fr_walk << 20), L.tiles_per_img = tpi;
     L.T = tpi * N, L.first = blocks;
     blocks += L.T;
@@ -2061,12 +2222,17 @@ int r3k_fr_forward_nhwc_levels(int levels, const float* const* a, const float* c
   for (int l = 0; l < levels; l++) {
     if (l < FRL_MAX && grouped[l]) continue;
     const int k = r3k_fr_forward_nhwc(a[l], has_b ? b[l] : nullptr, bias_a, bias_b, has_res ? res[l] : nullptr, boxes[l], N, C,
-                                      H[l], W[l], scales[l], points, out[l], stream);
+                                      H[l], W[l], scales[l], points, out[l], stream, tabs ? tabs[l] : nullptr);
     if (k) return k;
   }
   if (A.n) {
     for (int i = A.n; i < FRL_MAX; i++) A.l[i] = A.l[A.n - 1];
-    if (fused)
+    if (tabs) {
+      if (fused)
+        hipLaunchKernelGGL((fr_forward_nhwc_occ_levels<true, true>), dim3(blocks), dim3(512), 0, stream, A, bias_a, bias_b, C);
+      else
+        hipLaunchKernelGGL((fr_forward_nhwc_occ_levels<false, true>), dim3(blocks), dim3(512), 0, stream, A, bias_a, bias_b, C);
+    } else if (fused)
       hipLaunchKernelGGL(fr_forward_nhwc_occ_levels<true>, dim3(blocks), dim3(512), 0, stream, A, bias_a, bias_b, C);
     else
       hipLaunchKernelGGL(fr_forward_nhwc_occ_levels<false>, dim3(blocks), dim3(512), 0, stream, A, bias_a, bias_b, C);

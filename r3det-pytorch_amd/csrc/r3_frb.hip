@@ -401,11 +401,19 @@ __device__ __forceinline__ void frb_sell_slice(const int2* __restrict__ cellinfo
 // dropped with their taps in phase B): the scan loads one float per source instead of two.  A band with a list longer
 // than the SELL capacity takes the general form, which writes the CSR lists of ITS cells (the gather reads them for
 // exactly those cells).
-template <bool CSR>
+// TAB (round 6): the sources' sample points come from the level's TAP TABLE -- per image [y: HW floats][x: HW floats],
+// the clamped sample point of every position (cell_tap: r3_fr.hip; an invalid sample = row H + 1), written by the
+// forward pass of the same boxes (fr_cell_table_kernel, or the channels_last samplers' `tab` output) -- instead of
+// from the 20-byte box records: the scan reads 4 contiguous bytes per source (64 KB per image at level 0, coalesced)
+// where the box form pulls all 327 KB of records through the compute unit for one float in five, and needs no scale,
+// no validity test and no column.  make_tap_yx is idempotent on its own clamps (the table's (y, x) give the same cells
+// and bit-identical weights), and the sources are walked in the same order: the index is byte-identical to the box
+// form's (tests/test_gpu_fr_keys.py).
+template <bool CSR, bool TAB = false>
 __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ boxes, float scale, int H, int W, int R,
                                                     int2* __restrict__ cellinfo, int2* __restrict__ entries,
                                                     const FrbSellOut& so, const int band, const int bands, const int n,
-                                                    u64* __restrict__ stamps) {
+                                                    u64* __restrict__ stamps, const float* __restrict__ tab = nullptr) {
   extern __shared__ __attribute__((aligned(16))) int ix[];
   IxsLds& S = *reinterpret_cast<IxsLds*>(ix);
   // (tools/probes/frb_index_probe.hip: clock stamps of one workgroup at the phase boundaries)
@@ -420,6 +428,12 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
   const int r0 = band * R, r1 = min(H, r0 + R);
   const int HW = H * W, CB = (r1 - r0) * W;
   const float* bx = boxes + (size_t)n * HW * 5;
+  const float* ty_g = TAB ? tab + (size_t)n * 2 * HW : nullptr;  // [y: HW][x: HW] of this image
+  // the sample point of source s as make_tap_yx takes it (row, column)
+  auto tap_of = [&](const int s) -> TapYX {
+    if (TAB) return make_tap_yx(H, W, ty_g[s], ty_g[HW + s]);
+    return make_tap_yx(H, W, bx[(size_t)s * 5] * scale, bx[(size_t)s * 5 + 1] * scale);
+  };
   int2* ci = cellinfo + (size_t)n * HW;
   int2* en = entries + (size_t)n * HW * 4;
   if (tid == 0) S.over = 0;
@@ -434,7 +448,9 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
                          // compute unit: a round is one L2 latency).  The phase is bound by its ~28 instructions per
                          // source at 4 waves per SIMD (16.0 k cycles with guarded loads and a validity branch ->
                          // 13.3 k with clamped unconditional loads and a branch-free body; a pre-pass that stored the
-                         // sample rows as one int per source made it no shorter).
+                         // sample rows as one int per source made it no shorter; round 6, table form: all 16 of a
+                         // level-0 map in one round trip: 14.5 -> 14.1 us, inside the run-to-run spread -- the phase
+                         // is its instruction issue: ~15 per source and wave at 4 waves per SIMD).
   for (int s0 = 0; s0 < HW; s0 += IX_T * UA) {
     float yv[UA], xv[UA];
 #pragma unroll
@@ -442,6 +458,12 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
       // (unconditional loads at a clamped index: behind `if (s < HW)` every load waited for itself -- 16 L2 round
       // trips in a row, the whole of this phase)
       const int s = s0 + u * IX_T + tid;
+      if (TAB) {
+        const float y = ty_g[min(s, HW - 1)];  // (a wavefront: 256 contiguous bytes)
+        yv[u] = s < HW ? y : 3.0e38f;          // (beyond the map: as an invalid sample, below every band's upper end)
+        xv[u] = 0.f;
+        continue;
+      }
       const float* bp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bx) + (unsigned)min(s, HW - 1) * 20u);
       const float y = bp[0], x = CSR ? bp[1] : 0.f;
       yv[u] = s < HW ? y : -3.0e38f;  // (beyond the map: out of range below)
@@ -459,7 +481,23 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
       // (the CSR form also counts the entries in earlier rows and tests the column: there the integer form below is
       // the shorter one -- 13.2 k against 14.8 k clocks for the phase)
       bool pass;
-      if (!CSR) {
+      if (TAB) {
+        // the table's y is the clamped sample row (0 <= y <= H - 1, or H + 1 for a sample outside the map in y OR x):
+        // yl = (int)y, yh = min(yl + 1, H - 1)
+        // (a NaN stays "valid" and samples row 0, as in the box form and the reference)
+        if (!CSR) {
+          const float yc = __builtin_fmaxf(yv[u], 0.f);
+          pass = yc >= band_lo && yc < band_hi;
+        } else {
+          // (measured and not kept: the count of entries in earlier rows as two float compares, 2 [yc < r0] + 2 [yc <
+          // r0 - 1] -- 14.2-14.6 us against 13.3-13.6 for this integer form)
+          const float yc = yv[u];
+          const int yl = (int)yc, yh = min(yl + 1, H - 1);
+          const bool valid = !(yc > (float)H);
+          before += valid ? (yl < r0 ? 2 : 0) + (yh < r0 ? 2 : 0) : 0;
+          pass = valid && yl < r1 && yh >= r0;
+        }
+      } else if (!CSR) {
         const float y = yv[u] * scale;
         const float yc = __builtin_fmaxf(y, 0.f);
         pass = !(y < -1.0f) && yc >= band_lo && yc < band_hi;
@@ -499,7 +537,7 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
   int s_first = 0;
   if (lane < wcc) {
     s_first = S.seg[wave * IXS_SEG + lane];
-    t_first = make_tap_yx(H, W, bx[(size_t)s_first * 5] * scale, bx[(size_t)s_first * 5 + 1] * scale);
+    t_first = tap_of(s_first);
   }
   for (int i0 = 0; i0 < wcc; i0 += 64) {
     const int i = i0 + lane;
@@ -508,7 +546,7 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
       t.valid = false;
       if (i < wcc) {
         const int s = S.seg[wave * IXS_SEG + i];
-        t = make_tap_yx(H, W, bx[(size_t)s * 5] * scale, bx[(size_t)s * 5 + 1] * scale);
+        t = tap_of(s);
       }
     }
 #pragma unroll
@@ -526,20 +564,25 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
     total += c;
   }
   if (!S.over && total <= IXS_CAP) {
-    for (int i0 = 0; i0 < wcc; i0 += 64) {
-      const int i = i0 + lane;
-      TapYX t = t_first;
-      int s = s_first;
-      if (i0 > 0) {
-        t.valid = false;
-        s = 0;
-        if (i < wcc) {
-          s = S.seg[wave * IXS_SEG + i];
-          t = make_tap_yx(H, W, bx[(size_t)s * 5] * scale, bx[(size_t)s * 5 + 1] * scale);
-        }
-      }
+    // A wave's entries in (tap, position in its source list) order -- the tap outermost, so that the order does not
+    // depend on where the list's 64-source chunks begin: sources that reach the band with their row but turn out to
+    // have no valid sample (the box form's scan does not look at the column; the table form never lists them) take
+    // list slots without contributing entries, and the two forms must still build the same index.  (Up to 64 sources
+    // -- nearly always -- the taps are the registers of t_first; a longer list computes a chunk's taps once per tap.)
 #pragma unroll
-      for (int d = 0; d < 4; d++) {
+    for (int d = 0; d < 4; d++) {
+      for (int i0 = 0; i0 < wcc; i0 += 64) {
+        const int i = i0 + lane;
+        TapYX t = t_first;
+        int s = s_first;
+        if (i0 > 0) {
+          t.valid = false;
+          s = 0;
+          if (i < wcc) {
+            s = S.seg[wave * IXS_SEG + i];
+            t = tap_of(s);
+          }
+        }
         const int y = (d >> 1) ? t.yh : t.yl, x = (d & 1) ? t.xh : t.xl;
         const bool in = t.valid && y >= r0 && y < r1;
         const u64 m = __ballot(in);
@@ -641,12 +684,14 @@ __device__ __forceinline__ void frb_index_sort_body(const float* __restrict__ bo
 #endif
 }
 
-template <bool CSR>
+template <bool CSR, bool TAB = false>
 __global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __restrict__ boxes, float scale, int H, int W,
                                                               int R, int2* __restrict__ cellinfo,
                                                               int2* __restrict__ entries, FrbSellOut so,
-                                                              u64* __restrict__ stamps = nullptr) {
-  frb_index_sort_body<CSR>(boxes, scale, H, W, R, cellinfo, entries, so, blockIdx.x, gridDim.x, blockIdx.y, stamps);
+                                                              u64* __restrict__ stamps = nullptr,
+                                                              const float* __restrict__ tab = nullptr) {
+  frb_index_sort_body<CSR, TAB>(boxes, scale, H, W, R, cellinfo, entries, so, blockIdx.x, gridDim.x, blockIdx.y, stamps,
+                                tab);
 }
 
 // The bands of ALL pyramid levels of a FeatureRefineModule pass as one grid (levels in kernel arguments; a block finds
@@ -655,6 +700,7 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_kernel(const float* __res
 constexpr int FRB_MAX_LEVELS = 8;
 struct FrbLevelArgs {
   const float* boxes;
+  const float* tab;  // the level's tap table (TAB kernels; null: this level from its boxes)
   int2* cellinfo;
   int2* entries;
   FrbSellOut so;
@@ -666,7 +712,7 @@ struct FrbLevelsArgs {
   int n;
 };
 
-template <bool CSR>
+template <bool CSR, bool TAB = false>
 __global__ __launch_bounds__(IX_T) void frb_index_sort_levels_kernel(const FrbLevelsArgs A) {
   int lv = 0;
 #pragma unroll
@@ -675,8 +721,10 @@ __global__ __launch_bounds__(IX_T) void frb_index_sort_levels_kernel(const FrbLe
   // (a uniform index into the by-value argument block: scalar loads)
   const FrbLevelArgs& L = A.l[lv];
   const int bands = (lv + 1 < A.n ? A.l[lv + 1].first : (int)gridDim.x) - L.first;
-  frb_index_sort_body<CSR>(L.boxes, L.scale, L.H, L.W, L.R, L.cellinfo, L.entries, L.so, (int)blockIdx.x - L.first, bands,
-                           blockIdx.y, nullptr);
+  // (TAB: every level has its table -- the launcher takes the box kernel when one is missing: both bodies in one kernel
+  // cost the latency-bound workgroups more than the table saves)
+  frb_index_sort_body<CSR, TAB>(L.boxes, L.scale, L.H, L.W, L.R, L.cellinfo, L.entries, L.so, (int)blockIdx.x - L.first,
+                                bands, blockIdx.y, nullptr, L.tab);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1373,21 +1421,23 @@ inline bool frb_fuses_sell(int H, int W, int points) {
   return (R * W) % 64 == 0 && R * W <= 256 && (H * W) % 64 == 0;  // (a last, shorter band is whole slices too)
 }
 int frb_index_launch(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
-                     const FrbSellOut& so, hipStream_t stream);
+                     const FrbSellOut& so, hipStream_t stream, const float* tab);
 }  // namespace
 
+// tab: the level's tap table (r3k_fr_table_any_bytes: [N][y: HW][x: HW], written by the forward pass of the SAME boxes
+// and scale) or null; the sort form then scans the table instead of the box records (the general form reads the boxes)
 int r3k_frb_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
-                  hipStream_t stream) {
+                  hipStream_t stream, const float* tab) {
   FrbSellOut none;
   none.hdr = nullptr, none.rows = nullptr, none.ascale = none.cap = none.pitch = none.slices = 0;
-  return frb_index_launch(boxes, N, H, W, scale, points, ws, ws_bytes, none, stream);
+  return frb_index_launch(boxes, N, H, W, scale, points, ws, ws_bytes, none, stream, tab);
 }
 
 namespace {
 int frb_index_launch(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
-                     const FrbSellOut& so, hipStream_t stream) {
+                     const FrbSellOut& so, hipStream_t stream, const float* tab) {
   const size_t need = r3k_frb_workspace_bytes(N, H, W, points);
-  if (need == 0 || !boxes || !ws || !aligned16(ws)) return -1;
+  if (need == 0 || !boxes || !ws || !aligned16(ws) || (tab && !aligned16(tab))) return -1;
   if (ws_bytes < need) return -3;
   const FrbLayout L = frb_layout(ws, N, H, W, points);
   if (frb_sort_form(H, W, points)) {
@@ -1395,16 +1445,19 @@ int frb_index_launch(const float* boxes, int N, int H, int W, float scale, int p
     if (once.first()) {
       allow_big_lds(frb_index_sort_kernel<true>, (int)sizeof(IxsLds));
       allow_big_lds(frb_index_sort_kernel<false>, (int)sizeof(IxsLds));
+      allow_big_lds((frb_index_sort_kernel<true, true>), (int)sizeof(IxsLds));
+      allow_big_lds((frb_index_sort_kernel<false, true>), (int)sizeof(IxsLds));
     }
     const int R = sort_band_rows(H, W);
     const dim3 grid((H + R - 1) / R, N);
     // (frb_impl 5: SELL rows AND the CSR lists from the one launch; tests)
-    if (so.hdr && g_r3_frb_impl != 5)
-      hipLaunchKernelGGL(frb_index_sort_kernel<false>, grid, dim3(IX_T), sizeof(IxsLds), stream, boxes, scale, H, W, R,
-                         L.cellinfo, L.entries, so, (u64*)nullptr);
-    else
-      hipLaunchKernelGGL(frb_index_sort_kernel<true>, grid, dim3(IX_T), sizeof(IxsLds), stream, boxes, scale, H, W, R,
-                         L.cellinfo, L.entries, so, (u64*)nullptr);
+    const bool sell = so.hdr && g_r3_frb_impl != 5;
+#define R3_IX(CSRF, TABF) \
+  hipLaunchKernelGGL((frb_index_sort_kernel<CSRF, TABF>), grid, dim3(IX_T), sizeof(IxsLds), stream, boxes, scale, H, W, R, \
+                     L.cellinfo, L.entries, so, (u64*)nullptr, tab)
+    if (sell) { if (tab) R3_IX(false, true); else R3_IX(false, false); }
+    else { if (tab) R3_IX(true, true); else R3_IX(true, false); }
+#undef R3_IX
     return hipGetLastError() == hipSuccess ? 0 : -2;
   }
   const int R = general_band_rows(H, W);
@@ -1430,7 +1483,7 @@ int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, in
   // (32-bit byte offsets inside an IMAGE, 64-bit image bases; tested before anything is launched: -1 = nothing ran)
   if ((unsigned long long)H * W * C * 4ull >= (1ull << 32)) return -1;
   if (!index_ready) {
-    const int rc = r3k_frb_index(boxes, N, H, W, scale, points, ws, ws_bytes, stream);
+    const int rc = r3k_frb_index(boxes, N, H, W, scale, points, ws, ws_bytes, stream, nullptr);
     if (rc) return rc;
   } else if (!ws || !aligned16(ws) || !r3k_frb_workspace_bytes(N, H, W, points) ||
              ws_bytes < r3k_frb_workspace_bytes(N, H, W, points)) {
@@ -1540,7 +1593,7 @@ size_t r3k_frn_workspace_bytes(int N, int H, int W, int points) {
 // the index of the boxes for gradients of C channels (C decides how many channels the gather interleaves, and the
 // entries carry byte offsets of that layout)
 int r3k_frn_index(const float* boxes, int N, int C, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
-                  hipStream_t stream) {
+                  hipStream_t stream, const float* tab) {
   const size_t need = r3k_frn_workspace_bytes(N, H, W, points);
   int K, cp;
   if (need == 0 || !boxes || !ws || !aligned16(ws) || !frn_config(C, H, W, K, cp)) return -1;
@@ -1551,7 +1604,7 @@ int r3k_frn_index(const float* boxes, int N, int C, int H, int W, float scale, i
   so.slices = L.slices;
   const bool fused = frb_fuses_sell(H, W, points);
   if (!fused) so.hdr = nullptr;
-  const int rc = frb_index_launch(boxes, N, H, W, scale, points, ws, L.csr.bytes, so, stream);
+  const int rc = frb_index_launch(boxes, N, H, W, scale, points, ws, L.csr.bytes, so, stream, tab);
   if (rc || fused) return rc;
   hipLaunchKernelGGL(frb_sell_kernel, dim3((L.slices + 3) / 4, N), dim3(256), 0, stream, L.csr.cellinfo, L.csr.entries,
                      H * W, W, L.pitch, H * L.pitch, 4 * L.cp, H * W * 4 * points, L.cap, L.slices, L.slicehdr, L.sell);
@@ -1561,11 +1614,13 @@ int r3k_frn_index(const float* boxes, int N, int C, int H, int W, float scale, i
 // The indexes of several levels (each with its own workspace, as r3k_frn_index would fill it) from ONE launch; 1 when
 // the levels do not all take the fused sort form (the caller then indexes level by level), else 0 / -2.
 int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, const int* H, const int* W,
-                         const float* scales, int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream) {
+                         const float* scales, int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream,
+                         const float* const* tabs) {
   if (levels < 1 || levels > FRB_MAX_LEVELS || g_r3_frb_impl == 5 || g_r3_frb_impl == 6) return 1;  // (6: per level; tests)
   FrbLevelsArgs A;
   A.n = levels;
   int blocks = 0;
+  bool all_tab = true;  // (the table kernel only when every level brings its table)
   for (int l = 0; l < levels; l++) {
     int K, cp;
     const size_t need = r3k_frn_workspace_bytes(N, H[l], W[l], points);
@@ -1575,6 +1630,9 @@ int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, co
     const FrnLayout L = frn_layout(ws[l], N, C, H[l], W[l], points);
     FrbLevelArgs& a = A.l[l];
     a.boxes = boxes[l], a.cellinfo = L.csr.cellinfo, a.entries = L.csr.entries;
+    a.tab = tabs ? tabs[l] : nullptr;
+    if (a.tab && !aligned16(a.tab)) return -1;
+    all_tab &= a.tab != nullptr;
     a.so.hdr = L.slicehdr, a.so.rows = reinterpret_cast<int2*>(L.sell), a.so.ascale = 4 * L.cp, a.so.cap = L.cap,
     a.so.pitch = L.pitch, a.so.slices = L.slices;
     a.scale = scales[l], a.H = H[l], a.W = W[l], a.R = sort_band_rows(H[l], W[l]), a.first = blocks;
@@ -1582,18 +1640,26 @@ int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, co
   }
   for (int l = levels; l < FRB_MAX_LEVELS; l++) A.l[l] = A.l[levels - 1];
   static R3DeviceOnce once;
-  if (once.first()) allow_big_lds(frb_index_sort_levels_kernel<false>, (int)sizeof(IxsLds));
-  hipLaunchKernelGGL(frb_index_sort_levels_kernel<false>, dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
+  if (once.first()) {
+    allow_big_lds(frb_index_sort_levels_kernel<false>, (int)sizeof(IxsLds));
+    allow_big_lds((frb_index_sort_levels_kernel<false, true>), (int)sizeof(IxsLds));
+  }
+  if (all_tab)
+    hipLaunchKernelGGL((frb_index_sort_levels_kernel<false, true>), dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
+  else
+    hipLaunchKernelGGL(frb_index_sort_levels_kernel<false>, dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // The same for the channels_last gather's CSR lists (r3k_frb_index per level): ws[l] as r3k_frb_workspace_bytes sizes it.
 int r3k_frb_index_levels(int levels, const float* const* boxes, int N, const int* H, const int* W, const float* scales,
-                         int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream) {
+                         int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream,
+                         const float* const* tabs) {
   if (levels < 1 || levels > FRB_MAX_LEVELS || g_r3_frb_impl == 6) return 1;
   FrbLevelsArgs A;
   A.n = levels;
   int blocks = 0;
+  bool all_tab = true;  // (the table kernel only when every level brings its table)
   for (int l = 0; l < levels; l++) {
     const size_t need = r3k_frb_workspace_bytes(N, H[l], W[l], points);
     if (need == 0 || !boxes[l] || !ws[l] || !aligned16(ws[l]) || ws_bytes[l] < need || !frb_sort_form(H[l], W[l], points))
@@ -1601,14 +1667,23 @@ int r3k_frb_index_levels(int levels, const float* const* boxes, int N, const int
     const FrbLayout L = frb_layout(ws[l], N, H[l], W[l], points);
     FrbLevelArgs& a = A.l[l];
     a.boxes = boxes[l], a.cellinfo = L.cellinfo, a.entries = L.entries;
+    a.tab = tabs ? tabs[l] : nullptr;
+    if (a.tab && !aligned16(a.tab)) return -1;
+    all_tab &= a.tab != nullptr;
     a.so.hdr = nullptr, a.so.rows = nullptr, a.so.ascale = a.so.cap = a.so.pitch = a.so.slices = 0;
     a.scale = scales[l], a.H = H[l], a.W = W[l], a.R = sort_band_rows(H[l], W[l]), a.first = blocks;
     blocks += (H[l] + a.R - 1) / a.R;
   }
   for (int l = levels; l < FRB_MAX_LEVELS; l++) A.l[l] = A.l[levels - 1];
   static R3DeviceOnce once;
-  if (once.first()) allow_big_lds(frb_index_sort_levels_kernel<true>, (int)sizeof(IxsLds));
-  hipLaunchKernelGGL(frb_index_sort_levels_kernel<true>, dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
+  if (once.first()) {
+    allow_big_lds(frb_index_sort_levels_kernel<true>, (int)sizeof(IxsLds));
+    allow_big_lds((frb_index_sort_levels_kernel<true, true>), (int)sizeof(IxsLds));
+  }
+  if (all_tab)
+    hipLaunchKernelGGL((frb_index_sort_levels_kernel<true, true>), dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
+  else
+    hipLaunchKernelGGL(frb_index_sort_levels_kernel<true>, dim3(blocks, N), dim3(IX_T), sizeof(IxsLds), stream, A);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

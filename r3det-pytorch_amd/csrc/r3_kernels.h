@@ -130,14 +130,18 @@ int r3k_fr_backward(const float* top_grad, const float* boxes, int N, int C, int
                     int index_ready, hipStream_t stream);
 // NCHW gather backward (r3_frb.hip): index = CSR + SELL-64 of the boxes, then the gather alone
 size_t r3k_frn_workspace_bytes(int N, int H, int W, int points);
+// tab / tabs[l]: the level's tap table ([N][y: HW][x: HW] floats, r3k_fr_tap_table_bytes; written by the forward pass
+// of the same boxes) or null -- the index kernel's scan then reads 4 contiguous bytes per source instead of the boxes
 int r3k_frn_index(const float* boxes, int N, int C, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
-                  hipStream_t stream);
+                  hipStream_t stream, const float* tab = nullptr);
 int r3k_frn_index_levels(int levels, const float* const* boxes, int N, int C, const int* H, const int* W,
-                         const float* scales, int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream);
+                         const float* scales, int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream,
+                         const float* const* tabs = nullptr);
 int r3k_frn_gather(const float* top_grad, int N, int C, int H, int W, int points, float* bottom_grad, int overwrite,
                    void* ws, size_t ws_bytes, hipStream_t stream);
 int r3k_frb_index_levels(int levels, const float* const* boxes, int N, const int* H, const int* W, const float* scales,
-                         int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream);
+                         int points, void* const* ws, const size_t* ws_bytes, hipStream_t stream,
+                         const float* const* tabs = nullptr);
 int r3k_frb_gather_levels(int levels, const float* const* top_grad, int N, int C, const int* H, const int* W, int points,
                           float* const* bottom_grad, int overwrite, void* const* ws, const size_t* ws_bytes,
                           hipStream_t stream);
@@ -190,22 +194,33 @@ int r3k_fr_prepare(const float* boxes, int N, int H, int W, float scale, float* 
 int r3k_fr_forward_prepared(const float* feat, const float* feat2, const float* res, const float* table, int N, int C,
                             int H, int W, float* out, hipStream_t stream);
 
+// the module tail of all NCHW levels of a pass (points = 1): one grid for the coarse levels + the cell levels' tables,
+// one fused cell launch per cell level; tables[l]: r3k_fr_table_bytes of storage per cell level.  -1: nothing launched
+int r3k_fr_module_levels(int levels, const float* const* a, const float* const* b, const float* const* res,
+                         const float* const* boxes, int N, int C, const int* H, const int* W, const float* scales,
+                         float* const* out, float* const* tables, hipStream_t stream);
+size_t r3k_fr_table_bytes(int N, int H, int W);
+
 // channels_last (N, H, W, C) sampler; b / biases / res non-null: the module tail out = res + (P + sample(P)),
 // P = (a + bias_a) + (b + bias_b)
+// tab (points = 1 only): the launch also writes the level's tap table (r3k_fr_tap_table_bytes) for the backward's index
 int r3k_fr_forward_nhwc(const float* a, const float* b, const float* bias_a, const float* bias_b, const float* res,
                         const float* boxes, int N, int C, int H, int W, float scale, int points, float* out,
-                        hipStream_t stream);
+                        hipStream_t stream, float* tab = nullptr);
+inline size_t r3k_fr_tap_table_bytes(int N, int H, int W) {
+  return (N > 0 && H > 0 && W > 0) ? (size_t)N * H * W * 2 * sizeof(float) : 0;
+}
 
 // ... all pyramid levels of a pass: levels without the wide form as ONE grid (host arrays of device pointers)
 int r3k_fr_forward_nhwc_levels(int levels, const float* const* a, const float* const* b, const float* bias_a,
                                const float* bias_b, const float* const* res, const float* const* boxes, int N, int C,
                                const int* H, const int* W, const float* scales, int points, float* const* out,
-                               hipStream_t stream);
+                               hipStream_t stream, float* const* tabs = nullptr);
 
 // channels_last backward (r3_frb.hip): inverse tap index of the boxes + gather; points 1 or 5, any H x W with W <= 4096
 size_t r3k_frb_workspace_bytes(int N, int H, int W, int points);
 int r3k_frb_index(const float* boxes, int N, int H, int W, float scale, int points, void* ws, size_t ws_bytes,
-                  hipStream_t stream);
+                  hipStream_t stream, const float* tab = nullptr);
 int r3k_frb_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W, float scale, int points,
                      float* bottom_grad, int overwrite, void* ws, size_t ws_bytes, int index_ready,
                      hipStream_t stream);

@@ -65,6 +65,12 @@ SIGNATURES = {
     "r3det_feature_refine_forward_levels_nhwc": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "r3det_feature_refine_module_levels_nhwc": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "r3det_feature_refine_backward_index_levels": [_i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp],
+    "r3det_feature_refine_module_levels": [_i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp],
+    "r3det_feature_refine_forward_levels_nhwc_tab": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "r3det_feature_refine_module_levels_nhwc_tab": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp,
+                                                    _vp],
+    "r3det_feature_refine_backward_index_levels_tab": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp],
+    "r3det_feature_refine_backward_nhwc_index_levels_tab": [_i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "r3det_feature_refine_backward_nhwc_index_levels": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "r3det_feature_refine_backward_nhwc_levels_indexed": [_i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp],
     "r3det_feature_refine_backward_levels_indexed": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp],
@@ -106,6 +112,10 @@ def lib():
         L.r3det_levels_pool_workspace_bytes.restype = _sz
         L.r3det_fr_table_bytes.argtypes = [_i, _i, _i]
         L.r3det_fr_table_bytes.restype = _sz
+        L.r3det_fr_module_levels_workspace_bytes.argtypes = [_i, _i, _vp, _vp]
+        L.r3det_fr_module_levels_workspace_bytes.restype = _sz
+        L.r3det_fr_tap_table_bytes.argtypes = [_i, _i, _i]
+        L.r3det_fr_tap_table_bytes.restype = _sz
         L.r3det_fr_workspace_bytes.argtypes = [_i, _i, _i, _i]
         L.r3det_fr_workspace_bytes.restype = _sz
         L.r3det_fr_levels_workspace_bytes.argtypes = [_i, _i, _vp, _vp, _i]

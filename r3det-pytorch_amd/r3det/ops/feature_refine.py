@@ -189,9 +189,23 @@ def _ptr_array(ts):
     return (ctypes.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts])
 
 
-def fr_forward_levels_nhwc(features, best_rbboxes, spatial_scales, points, outputs):
+def tap_tables(N, shapes, device):
+    """One tap table per level ((H, W) in ``shapes``) carved from ONE allocation: per level ``N * 2 * H * W`` floats
+    (r3det_fr_tap_table_bytes), 256-byte aligned.  The channels_last forward calls write them (``tables=``), the
+    backward's index calls read them instead of the box records."""
+    sizes = [((N * 2 * h * w + 63) // 64) * 64 for h, w in shapes]
+    blob = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    out, at = [], 0
+    for sz, (h, w) in zip(sizes, shapes):
+        out.append(blob[at:at + N * 2 * h * w])
+        at += sz
+    return out
+
+
+def fr_forward_levels_nhwc(features, best_rbboxes, spatial_scales, points, outputs, tables=None):
     """The channels_last sampler of all pyramid levels in one library call
     (r3det_feature_refine_forward_levels_nhwc): the level that takes the wide form alone, all others as ONE launch.
+    ``tables`` (points = 1): per level a tap table (``tap_tables``) the launches also write, or None.
     False when nothing was launched (argument shapes the library does not take)."""
     fs = [_need_cl(f, "features") for f in features]
     os_ = [_need_cl(o, "output") for o in outputs]
@@ -200,16 +214,24 @@ def fr_forward_levels_nhwc(features, best_rbboxes, spatial_scales, points, outpu
     for f, b, o in zip(fs, bs, os_):
         if f.shape[:2] != (N, C) or b.numel() != N * f.size(2) * f.size(3) * 5 or o.shape != f.shape:
             raise RuntimeError("levels must share N and C, bring N*H*W x 5 boxes and outputs of the features' shape")
-    H, W, sc, _ = _lvl_arrays(fs, spatial_scales)
+    P = _plan(N, 0, [tuple(f.shape[2:]) for f in fs], spatial_scales, points)
+    H, W, sc = P.H, P.W, P.sc
     with torch.cuda.device(fs[0].device):
-        rc = _C.lib().r3det_feature_refine_forward_levels_nhwc(len(fs), _ptr_array(fs), _ptr_array(bs), N, C, H, W, sc,
-                                                               int(points), _ptr_array(os_), _C.stream())
+        if tables is not None:
+            rc = _C.lib().r3det_feature_refine_forward_levels_nhwc_tab(
+                len(fs), _ptr_array(fs), _ptr_array(bs), N, C, H, W, sc, int(points), _ptr_array(os_),
+                _ptr_array(tables), _C.stream())
+        else:
+            rc = _C.lib().r3det_feature_refine_forward_levels_nhwc(len(fs), _ptr_array(fs), _ptr_array(bs), N, C, H, W,
+                                                                   sc, int(points), _ptr_array(os_), _C.stream())
     return _taken(rc, "fr_forward_levels_nhwc")
 
 
-def fr_module_levels_nhwc(conv_a, conv_b, bias_a, bias_b, residual, best_rbboxes, spatial_scales, points, outputs):
+def fr_module_levels_nhwc(conv_a, conv_b, bias_a, bias_b, residual, best_rbboxes, spatial_scales, points, outputs,
+                          tables=None):
     """The FeatureRefineModule tail of all pyramid levels in one library call
-    (r3det_feature_refine_module_levels_nhwc); per level as ``fr_module_nhwc``.  ``conv_b`` may be None."""
+    (r3det_feature_refine_module_levels_nhwc); per level as ``fr_module_nhwc``.  ``conv_b`` may be None.  ``tables``
+    (points = 1): per level a tap table (``tap_tables``) the launches also write."""
     as_ = [_need_cl(t, "conv_a") for t in conv_a]
     rs = [_need_cl(t, "residual") for t in residual]
     os_ = [_need_cl(t, "output") for t in outputs]
@@ -223,12 +245,78 @@ def fr_module_levels_nhwc(conv_a, conv_b, bias_a, bias_b, residual, best_rbboxes
     for t, nm in ((bias_a, "bias_a"), (bias_b, "bias_b")):
         if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.numel() != C or not t.is_contiguous()):
             raise RuntimeError(f"{nm} must be a contiguous fp32 CUDA tensor of C values")
-    H, W, sc, _ = _lvl_arrays(as_, spatial_scales)
+    P = _plan(N, 0, [tuple(a.shape[2:]) for a in as_], spatial_scales, points)
+    H, W, sc = P.H, P.W, P.sc
     with torch.cuda.device(as_[0].device):
-        rc = _C.lib().r3det_feature_refine_module_levels_nhwc(
-            len(as_), _ptr_array(as_), _ptr_array(cbs) if cbs is not None else None, _C.ptr(bias_a), _C.ptr(bias_b),
-            _ptr_array(rs), _ptr_array(bs), N, C, H, W, sc, int(points), _ptr_array(os_), _C.stream())
+        if tables is not None:
+            rc = _C.lib().r3det_feature_refine_module_levels_nhwc_tab(
+                len(as_), _ptr_array(as_), _ptr_array(cbs) if cbs is not None else None, _C.ptr(bias_a), _C.ptr(bias_b),
+                _ptr_array(rs), _ptr_array(bs), N, C, H, W, sc, int(points), _ptr_array(os_), _ptr_array(tables),
+                _C.stream())
+        else:
+            rc = _C.lib().r3det_feature_refine_module_levels_nhwc(
+                len(as_), _ptr_array(as_), _ptr_array(cbs) if cbs is not None else None, _C.ptr(bias_a), _C.ptr(bias_b),
+                _ptr_array(rs), _ptr_array(bs), N, C, H, W, sc, int(points), _ptr_array(os_), _C.stream())
     return _taken(rc, "fr_module_levels_nhwc")
+
+
+class _LevelsPlan:
+    """What a levels call needs besides the tensors, computed once per (N, C, shapes, scales, points): the ctypes shape
+    arrays and the library's workspace sizes (every call of the training nodes rebuilt its ctypes arrays
+    and asked the library for three sizes)."""
+    __slots__ = ("n", "H", "W", "sc", "shapes", "module_ws", "bwd_ws", "bwd_nhwc_ws")
+
+    def __init__(self, N, C, shapes, scales, points):
+        import ctypes
+        n = self.n = len(shapes)
+        arr_i = ctypes.c_int * n
+        self.shapes = tuple(shapes)
+        self.H, self.W = arr_i(*[h for h, _ in shapes]), arr_i(*[w for _, w in shapes])
+        self.sc = (ctypes.c_float * n)(*[float(s) for s in scales])
+        L = _C.lib()
+        self.module_ws = int(L.r3det_fr_module_levels_workspace_bytes(n, N, self.H, self.W))
+        self.bwd_ws = int(L.r3det_fr_backward_levels_workspace_bytes(n, N, self.H, self.W, int(points)))
+        self.bwd_nhwc_ws = int(L.r3det_fr_backward_nhwc_levels_workspace_bytes(n, N, self.H, self.W, int(points)))
+
+
+_PLANS = {}
+
+
+def _plan(N, C, shapes, scales, points):
+    key = (N, C, tuple(shapes), tuple(float(s) for s in scales), int(points))
+    p = _PLANS.get(key)
+    if p is None:
+        if len(_PLANS) >= 32:          # (a handful of pyramids per process: drop everything rather than track use)
+            _PLANS.clear()
+        p = _PLANS[key] = _LevelsPlan(N, C, shapes, scales, points)
+    return p
+
+
+def fr_module_levels(conv_a, conv_b, residual, best_rbboxes, spatial_scales, points, outputs):
+    """The FeatureRefineModule tail of all NCHW pyramid levels in one library call
+    (r3det_feature_refine_module_levels): ``outputs[l] = residual[l] + fr(conv_a[l] + conv_b[l], boxes[l])``, the two
+    elementwise passes of feature_refine_module.py:121-126 folded into the sampler launches -- 3 launches for a 1024^2
+    pyramid.  -> the workspace (it holds the tap tables of the 128 / 64 levels), or None when the library does not take
+    these levels in this form (nothing was launched)."""
+    if int(points) != 1:
+        return None
+    as_ = [_C.need_hip(t, "conv_a") for t in conv_a]
+    bs_ = [_C.need_hip(t, "conv_b") for t in conv_b]
+    rs = [_C.need_hip(t, "residual") for t in residual]
+    os_ = [_C.need_hip(t, "output") for t in outputs]
+    bx = [_C.need_hip(t, "best_bboxes") for t in best_rbboxes]
+    N, C = as_[0].shape[:2]
+    for a, b, r, o, q in zip(as_, bs_, rs, os_, bx):
+        if a.shape[:2] != (N, C) or b.shape != a.shape or r.shape != a.shape or o.shape != a.shape or \
+                q.numel() != N * a.size(2) * a.size(3) * 5:
+            raise RuntimeError("per level: conv_a, conv_b, residual and output of one shape; best_bboxes N*H*W x 5")
+    P = _plan(N, 0, [tuple(a.shape[2:]) for a in as_], spatial_scales, 1)
+    with torch.cuda.device(as_[0].device):
+        ws = torch.empty(max(P.module_ws, 16), dtype=torch.uint8, device=as_[0].device)
+        rc = _C.lib().r3det_feature_refine_module_levels(
+            P.n, _ptr_array(as_), _ptr_array(bs_), _ptr_array(rs), _ptr_array(bx), N, C, P.H, P.W, P.sc, 1,
+            _ptr_array(os_), _C.ptr(ws), P.module_ws, _C.stream())
+    return ws if _taken(rc, "fr_module_levels") else None
 
 
 def fr_backward(top_grad, best_rbboxes, spatial_scale, points, bottom_grad, overwrite=False):
@@ -341,6 +429,52 @@ def fr_backward_nhwc_index(best_rbboxes, N, H, W, spatial_scale, points=1):
     return ws if _taken(rc, "fr_backward_nhwc_index") else None
 
 
+def fr_backward_nhwc_index_levels(best_rbboxes, N, shapes, spatial_scales, points=1, tables=None):
+    """The CSR indexes of all levels for the channels_last gathers (r3det_feature_refine_backward_nhwc_index_levels;
+    with ``tables`` -- per level a tap table of the same boxes or None -- the _tab form, whose scan reads the tables).
+    -> (workspace, bytes) for ``r3det_feature_refine_backward_nhwc_levels_indexed``, or None (a level has no form)."""
+    bs = [_C.need_hip(b, "best_bboxes") for b in best_rbboxes]
+    P = _plan(N, 0, shapes, spatial_scales, points)
+    wsb = P.bwd_nhwc_ws
+    if wsb == 0:
+        return None
+    L = _C.lib()
+    with torch.cuda.device(bs[0].device):
+        ws = torch.empty(wsb, dtype=torch.uint8, device=bs[0].device)
+        if tables is not None and int(points) == 1 and any(t is not None for t in tables):
+            _C.check(L.r3det_feature_refine_backward_nhwc_index_levels_tab(
+                P.n, _ptr_array(bs), _ptr_array(tables), N, P.H, P.W, P.sc, 1, _C.ptr(ws), wsb, _C.stream()),
+                "fr_backward_nhwc_index_levels_tab")
+        else:
+            _C.check(L.r3det_feature_refine_backward_nhwc_index_levels(
+                P.n, _ptr_array(bs), N, P.H, P.W, P.sc, int(points), _C.ptr(ws), wsb, _C.stream()),
+                "fr_backward_nhwc_index_levels")
+    return ws, wsb
+
+
+def fr_backward_index_levels(best_rbboxes, N, C, shapes, spatial_scales, points=1, tables=None):
+    """The indexes of all levels for the NCHW gathers (r3det_feature_refine_backward_index_levels / _tab as above;
+    ``fr_prepare``'s table of a level is a tap table).  -> (workspace, bytes)."""
+    bs = [_C.need_hip(b, "best_bboxes") for b in best_rbboxes]
+    P = _plan(N, 0, shapes, spatial_scales, points)
+    wsb = P.bwd_ws
+    L = _C.lib()
+    with torch.cuda.device(bs[0].device):
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=bs[0].device)
+        if tables is not None and int(points) == 1 and any(t is not None for t in tables):
+            _C.check(L.r3det_feature_refine_backward_index_levels_tab(
+                P.n, _ptr_array(bs), _ptr_array(tables), N, C, P.H, P.W, P.sc, 1, _C.ptr(ws), wsb, _C.stream()),
+                "fr_backward_index_levels_tab")
+        else:
+            _C.check(L.r3det_feature_refine_backward_index_levels(
+                P.n, _ptr_array(bs), N, C, P.H, P.W, P.sc, int(points), _C.ptr(ws), wsb, _C.stream()),
+                "fr_backward_index_levels")
+    return ws, wsb
+
+
+# training: the forward launches also write the levels' tap tables and the backward's index is built from them (round
+# 6; False: the index kernels scan the box records, rounds 3-5 -- tests and tools flip it for the A/B)
+TRAIN_TAP_TABLES = True
 NHWC_ONLY = False  # tests: fail instead of falling back when a channels_last module input does not take the NHWC launch
 # training: FeatureRefineModule's tail (add, samplers, residual add) as one autograd node (False: the three-step form of
 # rounds 1-4 around FeatureRefineLevelsFunction; tests and tools/train_hot_path.py flip it for the A/B)
@@ -398,6 +532,14 @@ class FeatureRefineFunction(Function):
             # channels_last pipelines (training included): sampler and its backward on (N, H, W, C) memory, no
             # layout switch around them
             output = torch.empty_like(features)  # (preserves channels_last)
+            if ctx.needs_input_grad[0] and points == 1 and TRAIN_TAP_TABLES:
+                # the sampler launch also writes the level's tap table; the backward's index is built from it
+                tabs = tap_tables(N, [(H, W)], features.device)
+                if fr_forward_levels_nhwc([features], [boxes], [spatial_scale], 1, [output], tabs):
+                    ctx.nhwc = True
+                    idx = fr_backward_nhwc_index_levels([boxes], N, [(H, W)], [spatial_scale], 1, tabs)
+                    ctx.index = idx[0] if idx is not None else None
+                    return output
             if fr_forward_nhwc(features, boxes, spatial_scale, points, output):
                 ctx.nhwc = True
                 if ctx.needs_input_grad[0]:
@@ -405,10 +547,16 @@ class FeatureRefineFunction(Function):
                 return output
         features = features.contiguous()
         output = torch.empty_like(features)  # the kernel overwrites every element
-        if table is None or not fr_forward_prepared(features, table, output):
+        prepared = table is not None and fr_forward_prepared(features, table, output)
+        if not prepared:
             fr_forward(features, boxes, spatial_scale, points, output)
         if ctx.needs_input_grad[0]:
-            ctx.index = fr_backward_index(boxes, N, C, H, W, spatial_scale, points)
+            if prepared and points == 1 and TRAIN_TAP_TABLES and \
+                    int(_C.lib().r3det_fr_backward_workspace_bytes(N, H, W, 1)):
+                # (the caller's table is the level's tap table: the index kernel scans it instead of the box records)
+                ctx.index = fr_backward_index_levels([boxes], N, C, [(H, W)], [spatial_scale], 1, [table])[0]
+            else:
+                ctx.index = fr_backward_index(boxes, N, C, H, W, spatial_scale, points)
         return output
 
     @staticmethod
@@ -435,6 +583,33 @@ class FeatureRefineFunction(Function):
 feature_refine = FeatureRefineFunction.apply
 
 
+def _levels_gather(ctx, grads):
+    """The gathers of all levels over the index the forward pass built (both levels nodes' backward): -> (the incoming
+    gradients in the node's layout, the gathered gradients)."""
+    n, boxes = ctx.n, ctx.saved_tensors
+    fmt = torch.channels_last if ctx.nhwc else torch.contiguous_format
+    gs = []
+    for g, shp in zip(grads, ctx.shape):
+        if g is None:
+            g = torch.zeros(shp, device=boxes[0].device)
+        gs.append(g if g.is_contiguous(memory_format=fmt) else g.contiguous(memory_format=fmt))
+    ds = [torch.empty_like(g) for g in gs]  # (preserves the layout)
+    N, C = ctx.shape[0][:2]
+    P = _plan(N, 0, [shp[2:] for shp in ctx.shape], ctx.scales, ctx.points)
+    L = _C.lib()
+    ws, wsb = ctx.index
+    with torch.cuda.device(gs[0].device):
+        if ctx.nhwc:
+            _C.check(L.r3det_feature_refine_backward_nhwc_levels_indexed(
+                n, _ptr_array(gs), N, C, P.H, P.W, int(ctx.points), _ptr_array(ds), 1, _C.ptr(ws), wsb, _C.stream()),
+                "fr_backward_nhwc_levels_indexed")
+        else:
+            _C.check(L.r3det_feature_refine_backward_levels_indexed(
+                n, _ptr_array(gs), _ptr_array(boxes), N, C, P.H, P.W, P.sc, int(ctx.points), _ptr_array(ds), 1,
+                _C.ptr(ws), wsb, _C.stream()), "fr_backward_levels_indexed")
+    return gs, ds
+
+
 class FeatureRefineLevelsFunction(Function):
     """The sampler of ALL pyramid levels as one autograd node: one library call for the samplers
     (r3det_feature_refine_forward_levels), one for the backward's indexes of the boxes -- built here, where the boxes
@@ -453,35 +628,24 @@ class FeatureRefineLevelsFunction(Function):
         ctx.save_for_backward(*boxes)
         ctx.index = None
         ctx.nhwc = False
-        L = _C.lib()
         if all(_is_cl(f) for f in tensors[:n]) and C % 4 == 0:
             feats = list(tensors[:n])
-            H, W, sc, arr_p = _lvl_arrays(feats, spatial_scales)
-            wsb = int(L.r3det_fr_backward_nhwc_levels_workspace_bytes(n, N, H, W, int(points)))
+            shapes = [tuple(f.shape[2:]) for f in feats]
+            wsb = _plan(N, 0, shapes, spatial_scales, points).bwd_nhwc_ws
             outs = [torch.empty_like(f) for f in feats]  # (preserves channels_last)
-            if wsb and fr_forward_levels_nhwc(feats, boxes, spatial_scales, points, outs):
+            need = any(ctx.needs_input_grad[3:3 + n])
+            # the sampler launches also write the levels' tap tables when a gradient will be asked for
+            tables = tap_tables(N, shapes, feats[0].device) if (need and wsb and points == 1 and TRAIN_TAP_TABLES) else None
+            if wsb and fr_forward_levels_nhwc(feats, boxes, spatial_scales, points, outs, tables):
                 ctx.nhwc = True
-                if any(ctx.needs_input_grad[3:3 + n]):
-                    with torch.cuda.device(feats[0].device):
-                        ws = torch.empty(wsb, dtype=torch.uint8, device=feats[0].device)
-                        _C.check(L.r3det_feature_refine_backward_nhwc_index_levels(
-                            n, arr_p(*[b.data_ptr() for b in boxes]), N, H, W, sc, int(points), _C.ptr(ws), wsb,
-                            _C.stream()), "fr_backward_nhwc_index_levels")
-                    ctx.index = (ws, wsb)
+                if need:
+                    ctx.index = fr_backward_nhwc_index_levels(boxes, N, shapes, spatial_scales, points, tables)
                 return tuple(outs)
         feats = [t.contiguous() for t in tensors[:n]]
         outs = [torch.empty_like(f) for f in feats]
         fr_forward_levels(feats, boxes, spatial_scales, points, outs)
         if any(ctx.needs_input_grad[3:3 + n]):
-            L = _C.lib()
-            H, W, sc, arr_p = _lvl_arrays(feats, spatial_scales)
-            with torch.cuda.device(feats[0].device):
-                wsb = int(L.r3det_fr_backward_levels_workspace_bytes(n, N, H, W, int(points)))
-                ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=feats[0].device)
-                _C.check(L.r3det_feature_refine_backward_index_levels(
-                    n, arr_p(*[b.data_ptr() for b in boxes]), N, C, H, W, sc, int(points), _C.ptr(ws), wsb, _C.stream()),
-                    "fr_backward_index_levels")
-            ctx.index = (ws, wsb)
+            ctx.index = fr_backward_index_levels(boxes, N, C, [tuple(f.shape[2:]) for f in feats], spatial_scales, points)
         return tuple(outs)
 
     @staticmethod
@@ -490,26 +654,7 @@ class FeatureRefineLevelsFunction(Function):
         n, boxes = ctx.n, ctx.saved_tensors
         if ctx.index is None:
             return (None, None, None) + (None,) * (2 * n)
-        fmt = torch.channels_last if ctx.nhwc else torch.contiguous_format
-        gs = [(g if g is not None else torch.zeros(shp, device=boxes[0].device)).contiguous(memory_format=fmt)
-              for g, shp in zip(grads, ctx.shape)]
-        outs = [torch.empty_like(g) for g in gs]  # (preserves the layout)
-        N, C = gs[0].shape[:2]
-        L = _C.lib()
-        H, W, sc, arr_p = _lvl_arrays(gs, ctx.scales)
-        ws, wsb = ctx.index
-        if ctx.nhwc:
-            with torch.cuda.device(gs[0].device):
-                _C.check(L.r3det_feature_refine_backward_nhwc_levels_indexed(
-                    n, arr_p(*[g.data_ptr() for g in gs]), N, C, H, W, int(ctx.points),
-                    arr_p(*[o.data_ptr() for o in outs]), 1, _C.ptr(ws), wsb, _C.stream()),
-                    "fr_backward_nhwc_levels_indexed")
-            return (None, None, None) + tuple(outs) + (None,) * n
-        with torch.cuda.device(gs[0].device):
-            _C.check(L.r3det_feature_refine_backward_levels_indexed(
-                n, arr_p(*[g.data_ptr() for g in gs]), arr_p(*[b.data_ptr() for b in boxes]), N, C, H, W, sc,
-                int(ctx.points), arr_p(*[o.data_ptr() for o in outs]), 1, _C.ptr(ws), wsb, _C.stream()),
-                "fr_backward_levels_indexed")
+        _, outs = _levels_gather(ctx, grads)
         return (None, None, None) + tuple(outs) + (None,) * n
 
 
@@ -534,41 +679,34 @@ class FeatureRefineModuleLevelsFunction(Function):
         ctx.save_for_backward(*boxes)
         ctx.index, ctx.nhwc = None, False
         need = any(ctx.needs_input_grad[3:3 + 3 * n])
-        L = _C.lib()
         if all(_is_cl(f) for f in a_in + b_in + x_in) and C % 4 == 0:
-            H, W, sc, arr_p = _lvl_arrays(list(x_in), spatial_scales)
-            wsb = int(L.r3det_fr_backward_nhwc_levels_workspace_bytes(n, N, H, W, int(points)))
+            shapes = [tuple(f.shape[2:]) for f in x_in]
+            wsb = _plan(N, 0, shapes, spatial_scales, points).bwd_nhwc_ws
             outs = [torch.empty_like(f) for f in x_in]  # (preserves channels_last)
+            # the module launches also write the levels' tap tables when a gradient will be asked for: the index
+            # kernel below scans those (4 contiguous bytes per source) instead of the box records
+            tables = tap_tables(N, shapes, x_in[0].device) if (need and wsb and points == 1 and TRAIN_TAP_TABLES) else None
             if wsb and fr_module_levels_nhwc(list(a_in), list(b_in), None, None, list(x_in), boxes, spatial_scales,
-                                             points, outs):
+                                             points, outs, tables):
                 ctx.nhwc = True
                 if need:
-                    with torch.cuda.device(x_in[0].device):
-                        ws = torch.empty(wsb, dtype=torch.uint8, device=x_in[0].device)
-                        _C.check(L.r3det_feature_refine_backward_nhwc_index_levels(
-                            n, arr_p(*[b.data_ptr() for b in boxes]), N, H, W, sc, int(points), _C.ptr(ws), wsb,
-                            _C.stream()), "fr_backward_nhwc_index_levels")
-                    ctx.index = (ws, wsb)
+                    ctx.index = fr_backward_nhwc_index_levels(boxes, N, shapes, spatial_scales, points, tables)
                 return tuple(outs)
         a_c, b_c, x_c = ([t.contiguous() for t in ts] for ts in (a_in, b_in, x_in))
-        outs = []
-        for a, b, x, bx, s in zip(a_c, b_c, x_c, boxes, spatial_scales):
-            o = torch.empty_like(x)
-            table = fr_prepare(bx, x.size(0), x.size(2), x.size(3), s, points)
-            if table is None or not fr_module_prepared(a, b, x, table, o):
-                m = a + b
-                fr_forward(m, bx, s, points, o)
-                o += x
-            outs.append(o)
+        outs = [torch.empty_like(x) for x in x_c]
+        # one library call for the whole tail (round 6): the coarse levels one grid that also builds the cell levels'
+        # tap tables, one fused launch per cell level -- where rounds 3-5 looped over the levels from Python
+        if fr_module_levels(a_c, b_c, x_c, boxes, spatial_scales, points, outs) is None:
+            for a, b, x, bx, s, o in zip(a_c, b_c, x_c, boxes, spatial_scales, outs):
+                table = fr_prepare(bx, x.size(0), x.size(2), x.size(3), s, points)
+                if table is None or not fr_module_prepared(a, b, x, table, o):
+                    m = a + b
+                    fr_forward(m, bx, s, points, o)
+                    o += x
         if need:
-            H, W, sc, arr_p = _lvl_arrays(x_c, spatial_scales)
-            with torch.cuda.device(x_c[0].device):
-                wsb = int(L.r3det_fr_backward_levels_workspace_bytes(n, N, H, W, int(points)))
-                ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=x_c[0].device)
-                _C.check(L.r3det_feature_refine_backward_index_levels(
-                    n, arr_p(*[b.data_ptr() for b in boxes]), N, C, H, W, sc, int(points), _C.ptr(ws), wsb, _C.stream()),
-                    "fr_backward_index_levels")
-            ctx.index = (ws, wsb)
+            # (the NCHW gathers' index scans the box records: its SELL form gains nothing from the tap tables --
+            # 13.4 against 13.5 us at level 0, profiles/r06_fr_backward_index_ab.txt)
+            ctx.index = fr_backward_index_levels(boxes, N, C, [tuple(f.shape[2:]) for f in x_c], spatial_scales, points)
         return tuple(outs)
 
     @staticmethod
@@ -577,25 +715,7 @@ class FeatureRefineModuleLevelsFunction(Function):
         n, boxes = ctx.n, ctx.saved_tensors
         if ctx.index is None:
             return (None, None, None) + (None,) * (4 * n)
-        fmt = torch.channels_last if ctx.nhwc else torch.contiguous_format
-        gs = [(g if g is not None else torch.zeros(shp, device=boxes[0].device)).contiguous(memory_format=fmt)
-              for g, shp in zip(grads, ctx.shape)]
-        ds = [torch.empty_like(g) for g in gs]  # (preserves the layout)
-        N, C = gs[0].shape[:2]
-        L = _C.lib()
-        H, W, sc, arr_p = _lvl_arrays(gs, ctx.scales)
-        ws, wsb = ctx.index
-        with torch.cuda.device(gs[0].device):
-            if ctx.nhwc:
-                _C.check(L.r3det_feature_refine_backward_nhwc_levels_indexed(
-                    n, arr_p(*[g.data_ptr() for g in gs]), N, C, H, W, int(ctx.points),
-                    arr_p(*[o.data_ptr() for o in ds]), 1, _C.ptr(ws), wsb, _C.stream()),
-                    "fr_backward_nhwc_levels_indexed")
-            else:
-                _C.check(L.r3det_feature_refine_backward_levels_indexed(
-                    n, arr_p(*[g.data_ptr() for g in gs]), arr_p(*[b.data_ptr() for b in boxes]), N, C, H, W, sc,
-                    int(ctx.points), arr_p(*[o.data_ptr() for o in ds]), 1, _C.ptr(ws), wsb, _C.stream()),
-                    "fr_backward_levels_indexed")
+        gs, ds = _levels_gather(ctx, grads)
         ds = tuple(ds)
         return (None, None, None) + ds + ds + tuple(gs) + (None,) * n
 
@@ -699,6 +819,17 @@ class FeatureRefineModule(nn.Module):
                     return fused
             if NHWC_ONLY:
                 raise RuntimeError("channels_last FR module path not taken")
+        if no_grad and not any(is_cl(f) for f in x) and len({f.shape[:2] for f in x}) == 1 and \
+                all(fr.points == 1 for fr in self.fr) and all(f.is_cuda and f.dtype == torch.float32 for f in x):
+            # NCHW inference: the module tail of ALL levels in one library call (r3det_feature_refine_module_levels:
+            # the coarse levels one grid that also builds the 128 / 64 levels' tap tables, one fused launch each for those)
+            a_all = [self.conv_5_1(self.conv_1_5(f)).contiguous() for f in x]
+            b_all = [self.conv_1_1(f).contiguous() for f in x]
+            x_all = [f.contiguous() for f in x]
+            fused = [torch.empty_like(f) for f in x_all]
+            if fr_module_levels(a_all, b_all, x_all, [b.contiguous() for b in per_level],
+                                [fr.spatial_scale for fr in self.fr], 1, fused) is not None:
+                return fused
         # tap tables of the NCHW levels first: each sampler call below is then a single launch with no
         # dependent launch in front of it (the channels_last launch derives its taps from the boxes itself)
         # (channels_last training levels take the NHWC sampler, which needs no table either)

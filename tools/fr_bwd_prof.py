@@ -61,3 +61,16 @@ sets = [tuple(torch.randn(N, C, H, H, device=dev) for _ in range(2)) for _ in ra
 timed("fr_backward NCHW (index + gather)", lambda g, o: fr_backward(g, boxes, 1.0 / stride, 1, o, overwrite=True), sets)
 ix = fr_backward_index(boxes, N, C, H, H, 1.0 / stride, 1)
 timed("fr_backward NCHW (gather alone)", lambda g, o: fr_backward_indexed(g, 1, o, ix), sets)
+
+# ---- round 6: the index alone, from the box records against from the level's tap table (what a training step's forward
+# launch leaves behind: r3det_feature_refine_*_levels_nhwc_tab / r3det_feature_refine_prepare)
+from r3det.ops.feature_refine import (fr_backward_index_levels, fr_backward_nhwc_index_levels,  # noqa: E402
+                                      fr_forward_levels_nhwc, tap_tables)
+
+tabs = tap_tables(N, [(H, H)], dev)
+f0 = torch.randn(N, 8, H, H, device=dev).contiguous(memory_format=cl)
+assert fr_forward_levels_nhwc([f0], [boxes], [1.0 / stride], 1, [torch.empty_like(f0)], tabs)
+one = [(None, None)]
+for what, tb in (("boxes", None), ("tap table", tabs)):
+    timed(f"index alone, CSR (nhwc), {what}", lambda a, b: fr_backward_nhwc_index_levels([boxes], N, [(H, H)], [1.0 / stride], 1, tb), one)
+    timed(f"index alone, SELL (nchw), {what}", lambda a, b: fr_backward_index_levels([boxes], N, C, [(H, H)], [1.0 / stride], 1, tb), one)
