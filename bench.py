@@ -262,7 +262,25 @@ def train_custom_op_ms(tr, device):
             torch.cuda.synchronize()
             out.append((time.perf_counter() - t) / reps)
         return out
-    sa, sf, s3 = samples(assign), samples(fr), samples(fr_three_step)
+    class _NullNode(torch.autograd.Function):
+        """A node of the SAME signature with no library call (outputs and gradients allocated, nothing launched): what
+        torch's autograd machinery costs for fr() -- apply with 23 arguments, the engine's thread hand-off, 15 leaf
+        accumulations -- i.e. the floor under fr_fwd_bwd_ms_wall that no host code of this repository can go below."""
+        @staticmethod
+        def forward(ctx, scales_, points_, n, *tensors):
+            ctx.n = n
+            return tuple(torch.empty_like(t) for t in tensors[2 * n:3 * n])
+
+        @staticmethod
+        def backward(ctx, *grads):
+            ds = tuple(torch.empty_like(g) for g in grads)
+            return (None, None, None) + ds + ds + tuple(grads) + (None,) * ctx.n
+
+    def fr_null():
+        for t in xs + as_ + bs_:
+            t.grad = None
+        torch.autograd.backward(_NullNode.apply(tuple(scales), 1, len(xs), *as_, *bs_, *xs, *boxes), gs)
+    sa, sf, s3, s0 = samples(assign), samples(fr), samples(fr_three_step), samples(fr_null)
     detail = {"what": "wall = launch-wait-launch loops of 5 calls, median / min / max of 9; device = GPU time of the same "
                       "calls with the stream kept busy while the host enqueues them (HIP events): the difference is the "
                       "host's share",
@@ -270,6 +288,9 @@ def train_custom_op_ms(tr, device):
               "fr_fwd_bwd_ms_wall": spread_stats(sf), "fr_fwd_bwd_ms_device": round(device_time_ms(fr, reps=5), 3),
               "fr_what": "module tail of the five levels (add, samplers, residual add; backward: the gathers) as one autograd "
                          "node; three_step = the same work as rounds 3-4 ran it (elementwise adds outside the node)",
+              "fr_null_node_ms_wall": spread_stats(s0),
+              "fr_null_node_what": "an autograd node of the same signature that launches nothing: torch's own cost for this "
+                                   "call pattern (the floor under fr_fwd_bwd_ms_wall)",
               "fr_three_step_ms_wall": spread_stats(s3),
               "fr_three_step_ms_device": round(device_time_ms(fr_three_step, reps=5), 3)}
     train_custom_op_ms.detail = detail

@@ -169,6 +169,18 @@ int r3det_rbbox_assign_prepared(int geom, const float* gts, int n_gt, const floa
                                 float* max_overlaps, int64_t* argmax_overlaps, float* gt_max_overlaps,
                                 int64_t* gt_argmax_overlaps, void* ws, size_t ws_bytes, void* stream);
 
+/* The same call (prepared may be NULL: then r3det_rbbox_assign) that also writes mmdet's assigned LABELS: -1, and
+ * gt_labels[assigned_gt_inds - 1] at the positives (mmdet 2.19 max_iou_assigner.py, the last lines of
+ * assign_wrt_overlaps; called from r3det/models/dense_heads/rotate_anchor_head.py:220-231) from the kernel that writes
+ * assigned_gt_inds -- the host-side form costs four elementwise launches per call.  gt_labels (n_gt,) int64 and
+ * assigned_labels (n_boxes,) int64: both or neither. */
+int r3det_rbbox_assign_labeled(int geom, const float* gts, int n_gt, const float* boxes, int n_boxes, const void* prepared,
+                               float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
+                               int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps,
+                               int64_t* argmax_overlaps, float* gt_max_overlaps, int64_t* gt_argmax_overlaps,
+                               const int64_t* gt_labels, int64_t* assigned_labels, void* ws, size_t ws_bytes,
+                               void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Batched post-processing: multiclass_nms_rotated for all images of a step.
  * Replaces, for nms type 'v1' and boxes shared by the classes, the per-image Python sequence

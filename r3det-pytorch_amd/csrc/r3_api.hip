@@ -227,6 +227,20 @@ int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes,
                            gt_max_overlaps, gt_argmax_overlaps, ws, ws_bytes, S(stream)));
 }
 
+int r3det_rbbox_assign_labeled(int geom, const float* gts, int n_gt, const float* boxes, int n_boxes, const void* prepared,
+                               float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
+                               int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps,
+                               int64_t* argmax_overlaps, float* gt_max_overlaps, int64_t* gt_argmax_overlaps,
+                               const int64_t* gt_labels, int64_t* assigned_labels, void* ws, size_t ws_bytes,
+                               void* stream) {
+  const DeviceGuard guard(stream);
+  if ((gt_labels == nullptr) != (assigned_labels == nullptr)) return R3DET_EINVAL;
+  if (prepared && prepared_mismatch(prepared, geom, n_boxes)) return R3DET_EINVAL;
+  return rc(r3k_iou_assign(geom, gts, n_gt, boxes, n_boxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality,
+                           gt_max_assign_all, assigned_gt_inds, max_overlaps, argmax_overlaps, gt_max_overlaps,
+                           gt_argmax_overlaps, ws, ws_bytes, S(stream), prepared, gt_labels, assigned_labels));
+}
+
 size_t r3det_nms_workspace_bytes(int n) { return r3k_nms_workspace_bytes(n); }
 
 int r3det_rnms(const float* dets6, const int64_t* order, int n, float thr, int sort_ascending,

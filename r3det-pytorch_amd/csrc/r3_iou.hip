@@ -1097,7 +1097,9 @@ __global__ __launch_bounds__(256) void assign_final_kernel(const u64k* __restric
                                                            int assign_all, int64_t* __restrict__ assigned,
                                                            float* __restrict__ max_overlaps,
                                                            int64_t* __restrict__ argmax,
-                                                           float* __restrict__ gt_max, int64_t* __restrict__ gt_argmax) {
+                                                           float* __restrict__ gt_max, int64_t* __restrict__ gt_argmax,
+                                                           const int64_t* __restrict__ gt_labels,
+                                                           int64_t* __restrict__ labels) {
   __shared__ int zmax;  // largest gt index whose best IoU is 0 (it matches every anchor with IoU 0 = all)
   if (threadIdx.x == 0) zmax = -1;
   __syncthreads();
@@ -1128,6 +1130,8 @@ __global__ __launch_bounds__(256) void assign_final_kernel(const u64k* __restric
   assigned[j] = a;
   max_overlaps[j] = mo;
   if (argmax) argmax[j] = key_idx(ck);
+  // (mmdet's assigned_labels: -1, and gt_labels[assigned - 1] at the positives -- max_iou_assigner.py's last lines)
+  if (labels) labels[j] = a > 0 ? gt_labels[a - 1] : -1;
 }
 
 // vec_iou_iof_kernel (rbbox_geo_kernel.cu:271-309): out[i] = f(b1[i % n1], b2[i % n2]).
@@ -1383,9 +1387,18 @@ struct AssignLayout {
 
 // Two forms share one workspace size (the larger): the tile queue of the matrix path (tile counts, one 8 KB slot and
 // 8192 IoUs per 8 x 1024 tile), taken when the matrix has at most P_MAX_TILES tiles, else the global queue of rounds 2-4.
-inline bool assign_tiled(int n1, int n2) {
+inline size_t assign_layout(int n1, int n2, void* ws, AssignLayout* L, const bool tiled);
+// (a tile costs 40 KB however empty it is -- a skinny problem, n1 < 8 or few columns, needed several times
+// the global queue's bytes.  The tile form is taken only where its layout is no larger than the global queue's, or
+// small in absolute terms; the workspace size follows the same rule, so callers that sized it once stay valid.)
+inline bool assign_tiled_fits(int n1, int n2) {
   const long long tx = ((long long)n2 + T_COLS - 1) / T_COLS, ty = ((long long)n1 + P_ROWS - 1) / P_ROWS;
-  return tx * ty <= P_MAX_TILES && g_r3_iou_impl != 3;  // (iou_impl 3: the global-queue form whatever the size, for the A/B)
+  if (tx * ty > P_MAX_TILES) return false;
+  const size_t tiled = assign_layout(n1, n2, nullptr, nullptr, true), global_q = assign_layout(n1, n2, nullptr, nullptr, false);
+  return tiled <= std::max(global_q, (size_t)1 << 20);
+}
+inline bool assign_tiled(int n1, int n2) {
+  return assign_tiled_fits(n1, n2) && g_r3_iou_impl != 3;  // (iou_impl 3: the global-queue form whatever the size, for the A/B)
 }
 
 inline size_t assign_layout(int n1, int n2, void* ws, AssignLayout* L, const bool tiled) {
@@ -1493,16 +1506,16 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
 size_t r3k_iou_assign_workspace_bytes(int n1, int n2) {
   if (n1 <= 0 || n2 <= 0) return 256;
   // (either form must fit: the option that picks the form may change between this query and the call)
-  const long long tx = ((long long)n2 + T_COLS - 1) / T_COLS, ty = ((long long)n1 + P_ROWS - 1) / P_ROWS;
   const size_t global_q = assign_layout(n1, n2, nullptr, nullptr, false);
-  return tx * ty <= P_MAX_TILES ? std::max(global_q, assign_layout(n1, n2, nullptr, nullptr, true)) : global_q;
+  return assign_tiled_fits(n1, n2) ? std::max(global_q, assign_layout(n1, n2, nullptr, nullptr, true)) : global_q;
 }
 
 int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n2, float pos_thr, float neg_thr,
                    float min_pos_iou, int match_low, int assign_all, int64_t* assigned, float* max_overlaps,
                    int64_t* argmax, float* gt_max, int64_t* gt_argmax, void* ws, size_t ws_bytes,
-                   hipStream_t stream, const void* prepared) {
+                   hipStream_t stream, const void* prepared, const int64_t* gt_labels, int64_t* labels) {
   if (n1 <= 0 || n2 <= 0 || !gts || !boxes || !assigned || !max_overlaps || !ws) return -1;
+  if ((gt_labels == nullptr) != (labels == nullptr)) return -1;
   if ((gt_max == nullptr) != (gt_argmax == nullptr)) return -1;
   if ((unsigned long long)n1 * (unsigned long long)n2 >= 0xffffffffULL) return -1;
   if (ws_bytes < r3k_iou_assign_workspace_bytes(n1, n2)) return -3;
@@ -1517,7 +1530,7 @@ int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n
   const int nmax = n1 > n2 ? n1 : n2;
   hipLaunchKernelGGL(assign_final_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, L.rowkey, n1, L.colkey, L.lowq,
                      n2, pos_thr, neg_thr, min_pos_iou, match_low, assign_all, assigned, max_overlaps, argmax, gt_max,
-                     gt_argmax);
+                     gt_argmax, gt_labels, labels);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -78,7 +78,8 @@ size_t r3k_iou_assign_workspace_bytes(int n1, int n2);
 int r3k_iou_assign(int geom, const float* gts, int n1, const float* boxes, int n2, float pos_thr, float neg_thr,
                    float min_pos_iou, int match_low, int assign_all, int64_t* assigned, float* max_overlaps,
                    int64_t* argmax, float* gt_max, int64_t* gt_argmax, void* ws, size_t ws_bytes,
-                   hipStream_t stream, const void* prepared = nullptr);
+                   hipStream_t stream, const void* prepared = nullptr, const int64_t* gt_labels = nullptr,
+                   int64_t* labels = nullptr);  // gt_labels / labels: both or neither -- mmdet's assigned_labels too
 
 size_t r3k_nms_workspace_bytes(int n);
 // dets: (n, det_stride) original order; labels: int64 (n,) or null; order: int64 (n,)

@@ -33,6 +33,9 @@ class AssignResult:
         return len(self.gt_inds)
 
 
+_ASSIGN_PLANS = {}   # (n_gt, n_boxes) -> (workspace bytes, offsets of the result views in the call's one allocation)
+
+
 class MaxIoUAssigner:
     def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True, ignore_iof_thr=-1,
                  ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1,
@@ -78,18 +81,35 @@ class MaxIoUAssigner:
                     ign = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)[0]
                 overlaps[:, ign > self.ignore_iof_thr] = -1
             return self.assign_wrt_overlaps(overlaps, gt_labels)
-        b = _C.need_hip(bboxes[:, :5].contiguous().float(), "bboxes")
-        g = _C.need_hip(gt_bboxes[:, :5].contiguous().float(), "gt_bboxes")
+        b = bboxes if bboxes.size(1) == 5 else bboxes[:, :5]
+        g = gt_bboxes if gt_bboxes.size(1) == 5 else gt_bboxes[:, :5]
+        b = _C.need_hip(b if b.is_contiguous() and b.dtype == torch.float32 else b.contiguous().float(), "bboxes")
+        g = _C.need_hip(g if g.is_contiguous() and g.dtype == torch.float32 else g.contiguous().float(), "gt_bboxes")
         n1, n2 = g.size(0), b.size(0)
         L = _C.lib()
+        lab = None
+        if gt_labels is not None:
+            lab = gt_labels if gt_labels.dtype == torch.int64 and gt_labels.is_contiguous() else gt_labels.long().contiguous()
         with torch.cuda.device(b.device):
-            nbytes = int(L.r3det_rbbox_assign_workspace_bytes(n1, n2))
+            # ONE allocation for the six results (the int64 ones first, then the floats) and one for the kernels' workspace
+            # -- its own, so that a caller who keeps the result does not keep the workspace's ~200 MB alive -- where
+            # there were six; sizes cached per (n1, n2)
+            plan = _ASSIGN_PLANS.get((n1, n2))
+            if plan is None:
+                if len(_ASSIGN_PLANS) >= 64:
+                    _ASSIGN_PLANS.clear()
+                nbytes = int(L.r3det_rbbox_assign_workspace_bytes(n1, n2))
+                o_lab = 8 * (2 * n2 + n1)
+                o_f = o_lab + 8 * n2
+                o_ws = o_f + 4 * (n2 + n1)
+                plan = _ASSIGN_PLANS[(n1, n2)] = (nbytes, o_lab, o_f, o_ws)
+            nbytes, o_lab, o_f, o_ws = plan
+            blob = torch.empty(o_ws, dtype=torch.uint8, device=b.device)
+            i64 = blob[:o_f].view(torch.int64)
+            gt_inds, argmax, gargmax, labels = i64[:n2], i64[n2:2 * n2], i64[2 * n2:2 * n2 + n1], i64[2 * n2 + n1:]
+            f32 = blob[o_f:o_f + 4 * (n2 + n1)].view(torch.float32)
+            max_ov, gmax = f32[:n2], f32[n2:]
             ws = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
-            gt_inds = torch.empty(n2, dtype=torch.int64, device=b.device)
-            max_ov = torch.empty(n2, dtype=torch.float32, device=b.device)
-            argmax = torch.empty(n2, dtype=torch.int64, device=b.device)
-            gmax = torch.empty(n1, dtype=torch.float32, device=b.device)
-            gargmax = torch.empty(n1, dtype=torch.int64, device=b.device)
             prep = None
             if shared_key is not None:
                 cache = self.__dict__.setdefault('_prepared_columns', {})
@@ -102,15 +122,14 @@ class MaxIoUAssigner:
                              "iou_prepare_columns")
                     cache.clear()  # (one anchor grid at a time)
                     cache[k] = prep
-            tail = (float(self.pos_iou_thr), float(self.neg_iou_thr), float(self.min_pos_iou),
-                    int(self.match_low_quality), int(self.gt_max_assign_all), _C.ptr(gt_inds), _C.ptr(max_ov),
-                    _C.ptr(argmax), _C.ptr(gmax), _C.ptr(gargmax), _C.ptr(ws), nbytes, _C.stream())
-            if prep is not None:
-                _C.check(L.r3det_rbbox_assign_prepared(geom, _C.ptr(g), n1, _C.ptr(b), n2, _C.ptr(prep), *tail),
-                         "r3det_rbbox_assign_prepared")
-            else:
-                _C.check(L.r3det_rbbox_assign(geom, _C.ptr(g), n1, _C.ptr(b), n2, *tail), "r3det_rbbox_assign")
-        res = AssignResult(n1, gt_inds, max_ov, self._labels(gt_inds, gt_labels))
+            # (the labels ride in the kernel that writes gt_inds: mmdet's four elementwise steps -- cat, cast, clamp,
+            # index -- were four launches per call and half of the call's host time)
+            _C.check(L.r3det_rbbox_assign_labeled(
+                geom, _C.ptr(g), n1, _C.ptr(b), n2, _C.ptr(prep), float(self.pos_iou_thr), float(self.neg_iou_thr),
+                float(self.min_pos_iou), int(self.match_low_quality), int(self.gt_max_assign_all), _C.ptr(gt_inds),
+                _C.ptr(max_ov), _C.ptr(argmax), _C.ptr(gmax), _C.ptr(gargmax), _C.ptr(lab),
+                _C.ptr(labels) if lab is not None else None, _C.ptr(ws), nbytes, _C.stream()), "r3det_rbbox_assign_labeled")
+        res = AssignResult(n1, gt_inds, max_ov, labels if lab is not None else None)
         if with_gt_stats:
             res.argmax_overlaps, res.gt_max_overlaps, res.gt_argmax_overlaps = argmax, gmax, gargmax
         return res

@@ -179,3 +179,36 @@ def test_drain_tickets_in_the_assignment_at_512_gts():
     for a, b in ((dyn.gt_inds, sta.gt_inds), (dyn.max_overlaps, sta.max_overlaps), (dyn.argmax_overlaps, sta.argmax_overlaps),
                  (dyn.gt_max_overlaps, sta.gt_max_overlaps), (dyn.gt_argmax_overlaps, sta.gt_argmax_overlaps)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("k,n", [(3, 200), (5, 21824), (1, 196416), (2000, 100), (10000, 100)])
+def test_skinny_shapes_keep_a_small_workspace_and_the_same_result(k, n):
+    """a tile of the tile-queue form costs 40 KB however empty it is -- n1 = 10000, n2 = 100 asked for ~50 MB
+    against the global queue's 8 MB.  The tile form is now taken only where its layout is no larger than the global
+    queue's (or small in absolute terms) and the workspace size follows: never more than max(global queue, 1 MB) + the
+    fixed parts; results unchanged."""
+    from r3det import _C
+    L = _C.lib()
+    ws = int(L.r3det_rbbox_assign_workspace_bytes(k, n))
+    fixed = 64 * (k + n) + 20 * (k + n) + 8 * 256          # records, keys, low-quality marks, alignment
+    assert ws <= max(8 * k * n, 1 << 20) + 40960 + fixed, (ws, k, n)
+    gts = dev(rand_boxes(k, 3 + k, span=400.))
+    boxes = dev(rand_boxes(n, 5 + n, span=400.))
+    if k * n <= 4_000_000:
+        check_same(make('RBboxOverlaps2D_v1'), boxes, gts, torch.randint(0, 15, (k,), device='cuda'))
+
+
+def test_labels_from_the_kernel_equal_mmdets_rule_incl_ignored_and_int32_labels():
+    """assigned_labels = -1, and gt_labels[gt_inds - 1] at the positives (mmdet max_iou_assigner.py, end of
+    assign_wrt_overlaps), written by the kernel that writes gt_inds (r3det_rbbox_assign_labeled)."""
+    gts = dev(rand_boxes(40, 1, span=300.))
+    boxes = dev(rand_boxes(6000, 2, span=300.))
+    asg = make('RBboxOverlaps2D_v1', pos_iou_thr=0.6, neg_iou_thr=0.3, match_low_quality=False)   # (IoU in [0.3, 0.6): -1 = ignored)
+    for labels in (torch.randint(0, 15, (40,), device='cuda'), torch.randint(0, 15, (40,), device='cuda', dtype=torch.int32)):
+        res = asg.assign(boxes, gts, gt_labels=labels)
+        want = torch.full_like(res.gt_inds, -1)
+        pos = res.gt_inds > 0
+        want[pos] = labels.long()[res.gt_inds[pos] - 1]
+        assert res.labels.dtype == torch.int64 and torch.equal(res.labels, want)
+        assert bool((res.gt_inds == -1).any()) and bool((res.gt_inds == 0).any()) and bool(pos.any())
+    assert asg.assign(boxes, gts).labels is None
