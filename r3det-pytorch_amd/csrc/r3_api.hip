@@ -14,6 +14,7 @@ R3Option g_r3_iou_small{0};
 R3Option g_r3_clip_impl{0};
 R3Option g_r3_iou_qcap{0};
 R3Option g_r3_iou_dwgs{0};
+R3Option g_r3_iou_nfill{0};  // (iou_impl 5) fill workgroups of the one-launch drain: 0 = one per compute unit
 R3Option g_r3_iou_order{8};  // (measured: 18.8-19.0 us against 19.3-19.5 with every workgroup early, three alternations on one box)
 R3Option g_r3_iou_dyn{1};
 R3Option g_r3_nms_impl{0};
@@ -837,6 +838,7 @@ int r3det_set_option(const char* name, int value) {
   else if (!strcmp(name, "iou_qcap")) g_r3_iou_qcap = value;
   else if (!strcmp(name, "iou_dwgs")) g_r3_iou_dwgs = value;
   else if (!strcmp(name, "iou_dyn")) g_r3_iou_dyn = value != 0;
+  else if (!strcmp(name, "iou_nfill")) g_r3_iou_nfill = value < 0 ? 0 : value;
   else if (!strcmp(name, "iou_order")) g_r3_iou_order = value < -1 ? -1 : value > 31 ? 31 : value;
   else if (!strcmp(name, "nms_impl")) g_r3_nms_impl = value;
   else if (!strcmp(name, "nms_qcap")) g_r3_nms_qcap = value;

@@ -484,14 +484,19 @@ struct AssignZero {
   int* lowq;                   // [n2]
 };
 
-template <int GEOM, bool VEC, bool PREP = false>
+// BITS (round 6, option iou_impl 5; VEC only): the tests alone -- no matrix stores -- plus, per tile and lane, which of
+// the lane's 8 x 4 elements SURVIVED (bit 4 r + c of bits[tile * 256 + tid]; a dense tile: all ones).  The zeros are
+// then written by the drain launch's fill blocks, which skip exactly those elements: fill and clip write disjoint
+// addresses and can share one launch with no ordering between them.
+template <int GEOM, bool VEC, bool PREP = false, bool BITS = false>
 __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __restrict__ b1, int n1,
                                                                 const float* __restrict__ b2, int n2,
                                                                 float* __restrict__ out, BoxRec* __restrict__ recsA,
                                                                 int* __restrict__ tcount,
                                                                 unsigned short* __restrict__ slots, int wcap,
                                                                 const ColPrep prep = ColPrep(), const int probe = 0, const int order = -1,
-                                                                const AssignZero az = AssignZero()) {
+                                                                const AssignZero az = AssignZero(),
+                                                                unsigned* __restrict__ bits = nullptr) {
   // (probe: probes build only, tools/iou_stream_phases.sh -- 1 leave after the zeros, 2 after the prologue, 3 before the
   // queue flush: what each part of the kernel adds to the plain fill)
   __shared__ __attribute__((aligned(16))) float rows[P_ROWS][12];  // cx, cy, rad, ex, ey, -, -, -, cx - ex, cx + ex, cy - ey, cy + ey
@@ -638,6 +643,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   unsigned short* wq = queue + wave * P_WSEG;
   int cnt = 0;
   bool full = false;
+  unsigned bm = 0;  // (BITS) this lane's survivors: bit 4 r + c
   __syncthreads();
   if (R3_HAS_PROBES && (probe & 15) == 2) {
     if (tid == 0) tcount[blockIdx.y * gridDim.x + bx] = bx0 + bx1 + by0 + by1 + cx[0] + cr[1] == 12345.f;  // (keeps the prologue alive)
@@ -657,6 +663,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
       bool apart = (dx * dx + dy * dy > rr * rr) | (fabsf(dx) > aex + cex[c]) | (fabsf(dy) > aey + cey[c]);
       pend[c] = cvalid[c] && !apart;
       any |= pend[c];
+      if (BITS) bm |= (pend[c] ? 1u : 0u) << (4 * r + c);
     }
     if (__ballot(any)) {
       if (cnt + 256 > wcap) {
@@ -682,6 +689,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   const int tile = (int)(blockIdx.y * gridDim.x) + bx;
   if (tid == 0) tcount[tile] = dense ? -1 : c0 + c1 + c2 + c3;
   zero_tile(true);
+  if (BITS) bits[(size_t)tile * T_THREADS + tid] = dense ? 0xffffffffu : bm;  // (a dense tile: the drain writes every element)
   if (dense) return;
   unsigned short* slot = slots + (size_t)tile * P_SLOT + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
   for (int q = lane; q < cnt; q += 64) slot[q] = wq[q];
@@ -706,7 +714,12 @@ struct AssignOut {
   int probe;       // (probes build, tools/assign_emit_ab.sh: 1 no column keys, 2 a look before the column atomic, 3 no siou, 4 no row keys, 5 no row flush, 6 a look before the flush's atomics)
 };
 
-template <int GEOM, bool FAST = false, bool ASSIGN = false>
+// FILL (round 6, option iou_impl 5, matrix form only): the launch also writes the matrix's zeros.  Its first `nfill`
+// workgroups begin as FILL blocks -- tile by tile, every element the stream kernel's survivor bits do not name -- and
+// then join the drain; clips write the named elements only, so the two kinds of store never meet and need no order.
+// Every workgroup has the drain's footprint (128 VGPRs, 18 KB of LDS: four per compute unit), so a fill block is a
+// drain block that starts late: the blocks behind a wavefront's first are then always dealt by ticket.
+template <int GEOM, bool FAST = false, bool ASSIGN = false, bool FILL = false>
 __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(const float* __restrict__ b1, int n1,
                                                                const float* __restrict__ b2, int n2, int iof,
                                                                const BoxRec* __restrict__ recsA,
@@ -715,7 +728,9 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
                                                                int tiles, float* __restrict__ out,
                                                                const BoxRec* __restrict__ recsB = nullptr,
                                                                unsigned long long* __restrict__ stamps = nullptr,
-                                                               const AssignOut ao = AssignOut(), const int dyn = 0) {
+                                                               const AssignOut ao = AssignOut(), const int dyn = 0,
+                                                               const unsigned* __restrict__ bits = nullptr,
+                                                               const int nfill = 0) {
   // (probes build, tools/iou_drain_stamps.py: wave 0 of every workgroup stamps its phases with the 100 MHz clock)
 #ifdef R3_PROBES
 #define R3_DSTAMP(k)                                                                             \
@@ -773,6 +788,45 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  if (FILL && (int)blockIdx.x < nfill) {
+    // (n2 % 4 == 0 and a 16-byte aligned matrix: the launcher; a lane's word = the stream kernel's four columns)
+    // The bits and counts of FB tiles are requested together, THEN their zeros go out: gfx9 counts loads and stores in
+    // one in-order vmcnt, so a tile's loads issued behind the previous tile's stores waited for every one of them to be
+    // acknowledged -- one memory round trip per tile, 128 fill blocks ran 56 us where 256 ran 44.
+    constexpr int FB = 8;
+    for (int t0 = blockIdx.x; t0 < tiles; t0 += nfill * FB) {
+      unsigned bmv[FB];
+      int tcv[FB];
+#pragma unroll
+      for (int k = 0; k < FB; k++) {
+        const int t = t0 + k * nfill;
+        const int tc = min(t, tiles - 1);
+        bmv[k] = bits[(size_t)tc * T_THREADS + tid];
+        tcv[k] = tcount[tc];
+      }
+#pragma unroll
+      for (int k = 0; k < FB; k++) {
+        const int t = t0 + k * nfill;
+        if (t >= tiles || tcv[k] < 0) continue;  // dense tile: enumerated pair by pair below, every element written there
+        const int by = t / tiles_x, bx = t - by * tiles_x;
+        const int col0 = bx * T_COLS + tid * T_CPT, row0 = by * P_ROWS;
+        if (col0 >= n2) continue;
+#pragma unroll
+        for (int r = 0; r < P_ROWS; r++) {
+          if (row0 + r >= n1) break;
+          float* p = out + (size_t)(row0 + r) * n2 + col0;
+          const unsigned m = (bmv[k] >> (4 * r)) & 15u;
+          if (m == 0u) {
+            *reinterpret_cast<float4*>(p) = make_float4(0.f, 0.f, 0.f, 0.f);
+          } else {
+#pragma unroll
+            for (int c = 0; c < T_CPT; c++)
+              if (!((m >> c) & 1u)) p[c] = 0.f;
+          }
+        }
+      }
+    }
+  }
   // prefix over the tile counts in groups of G consecutive tiles; thread t owns groups P_GPT * t .. P_GPT * t + P_GPT - 1.
   // Round 5: a thread's counts are P_GPT * G consecutive ints -- at G = 1 (up to 3072 tiles) three 16-byte loads in
   // flight together; the loop of scalar loads it replaces was 12 L2 round trips one after the other, 2.4 us in front of
@@ -843,7 +897,7 @@ __global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(con
   // class's further blocks come from the class's counter)
   // (only where a wavefront has three blocks or more: at 1.7 blocks per wavefront -- 128 x 196 416 -- there is nothing to even
   // out, 23.3 us both ways; 512 x 196 416, 7 blocks: 104 -> 92-95 us; tools/iou_dyn_ab.sh)
-  unsigned* const ticket = (dyn && nwaves % P_TICKETS == 0 && total >= 3u * 64u * nwaves)
+  unsigned* const ticket = (dyn && nwaves % P_TICKETS == 0 && (FILL || total >= 3u * 64u * nwaves))
       ? reinterpret_cast<unsigned*>(const_cast<int*>(tcount)) + tcount_ints(tiles) + (wid % P_TICKETS) * 32 : nullptr;
   for (unsigned qb = wid * 64; qb < total;) {  // wave-uniform
     // the block after this one: by ticket (requested here, looked at behind the clip) or at the static stride
@@ -1198,6 +1252,7 @@ struct PipeLayout {
   int* tcount;
   BoxRec* recsA;
   unsigned short* slots;
+  unsigned* bits;  // [tiles][256] survivor bits (option iou_impl 5)
   int tiles_x, tiles_y;
 };
 
@@ -1210,8 +1265,9 @@ inline size_t pipe_layout(int n1, int n2, void* ws, PipeLayout* L) {
   char* tc = take((tcount_ints((long long)tx * ty) + P_TICKET_PAD) * 4);
   char* ra = take((size_t)n1 * sizeof(BoxRec));
   char* sl = take((size_t)tx * ty * P_SLOT * 2);
+  char* bt = take((size_t)tx * ty * T_THREADS * 4);
   if (L) {
-    L->tcount = (int*)tc; L->recsA = (BoxRec*)ra; L->slots = (unsigned short*)sl;
+    L->tcount = (int*)tc; L->recsA = (BoxRec*)ra; L->slots = (unsigned short*)sl; L->bits = (unsigned*)bt;
     L->tiles_x = tx; L->tiles_y = ty;
   }
   return off + 256;
@@ -1230,7 +1286,10 @@ template <int GEOM>
 int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float* out, void* ws,
                size_t ws_bytes, hipStream_t stream, const void* prepared = nullptr) {
   const bool vec = (n2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  if (g_r3_iou_impl == 1) {
+  // (every switch is read ONCE per call -- a concurrent r3det_set_option cannot pair one form's grid with
+  // the other form's kernel)
+  const int impl = g_r3_iou_impl, clip_impl = g_r3_clip_impl;
+  if (impl == 1) {
     dim3 grid((n2 + IOU_BLOCK - 1) / IOU_BLOCK, (n1 + IOU_ROWS - 1) / IOU_ROWS);
     hipLaunchKernelGGL(iou_mat_kernel<GEOM>, grid, dim3(IOU_BLOCK), 0, stream, b1, n1, b2, n2, iof, out);
     return 0;
@@ -1244,28 +1303,49 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   PipeLayout L;
   const size_t need = pipe_layout(n1, n2, ws, &L);
   const long long tiles = (long long)L.tiles_x * L.tiles_y;
-  const bool piped = ws && ws_bytes >= need && tiles <= P_MAX_TILES && g_r3_iou_impl != 2 &&
-                     (n2 >= wide || g_r3_iou_impl == 4);
+  const bool piped = ws && ws_bytes >= need && tiles <= P_MAX_TILES && impl != 2 &&
+                     (n2 >= wide || impl == 4 || impl == 5);  // (5: the pipeline always, in its one-launch form where it applies)
   if (!piped) {
-    if (g_r3_iou_impl == 2) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);
+    if (impl == 2) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);
     else if (n2 <= 512) launch_compact<GEOM, 1, 8>(vec, iof, b1, n1, b2, n2, out, stream);
     else if (pairs > 2000000ULL) launch_compact<GEOM, 4, 32>(vec, iof, b1, n1, b2, n2, out, stream);  // (no workspace)
     else launch_compact<GEOM, 4, 8>(vec, iof, b1, n1, b2, n2, out, stream);
     return 0;
   }
-  const int wcap = g_r3_iou_qcap > 0 && g_r3_iou_qcap < P_WSEG ? g_r3_iou_qcap : P_WSEG;
+  const int qcap_o = g_r3_iou_qcap;
+  const int wcap = qcap_o > 0 && qcap_o < P_WSEG ? qcap_o : P_WSEG;
   const dim3 grid(L.tiles_x, L.tiles_y);
   // drain: enough workgroups to fill the chip at the kernel's occupancy (6 per CU measured best: 1024 -> 33 us, 1536 -> 28, 1792 and more -> 32); grid-stride inside
   int blocks = (int)((pairs + T_THREADS - 1) / T_THREADS);
   // (round 5, straight-line clip: 4 waves per SIMD of registers => 4 workgroups per CU are resident; a larger grid's
   // second wave of workgroups pays the 6 us prefix / lookup / record-load preamble again: 1024 -> 23.4 us of stamps, 1536 -> 26.7)
-  const bool fast = g_r3_clip_impl == 0;
-  const int maxb = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : fast ? 4 * r3_cu_count() : 1536;
+  const bool fast = clip_impl == 0;
+  const int dwgs = g_r3_iou_dwgs;
+  const int maxb = dwgs > 0 ? dwgs : fast ? 4 * r3_cu_count() : 1536;
   if (blocks > maxb) blocks = maxb;
   ColPrep P = ColPrep();
   if (prepared) colprep_layout(n2, prepared, &P);
   const int sorder = (int)g_r3_iou_order;
   const int sprobe = R3_HAS_PROBES ? (int)g_r3_fr_walk - 1000 : 0;  // (probes build: option fr_walk 1001 / 1002 / 1003 = stream phase probe)
+  // (probes build: the stamp buffer named by the frn_stamps_lo / _hi options, shared with the FR gather's probe)
+  unsigned long long* const dstamps = R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps.get()) : nullptr;
+  if (impl == 5 && vec && fast && blocks >= 8) {
+    // Round 6, option iou_impl 5: fill and clip in ONE launch on disjoint addresses.  K1 = the
+    // tests alone (no matrix stores) + the survivor bits; K2 = the drain whose first `nfill` workgroups write every
+    // element the bits do not name before they start clipping.  A/B: profiles/r06_iou_one_launch_ab.txt.
+    const int nf_o = g_r3_iou_nfill;
+    const int nfill = std::min(blocks / 2, nf_o > 0 ? nf_o : r3_cu_count());
+    if (prepared)
+      hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, true, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2,
+                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap, P, 0, -1, AssignZero(), L.bits);
+    else
+      hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, false, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2,
+                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap, P, 0, -1, AssignZero(), L.bits);
+    hipLaunchKernelGGL((iou_drain3_kernel<GEOM, true, false, true>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2,
+                       iof, L.recsA, L.tcount, L.slots, L.tiles_x, (int)tiles, out,
+                       prepared ? P.rec : (const BoxRec*)nullptr, dstamps, AssignOut(), 1, L.bits, nfill);
+    return 0;
+  }
   if (vec && prepared)
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
                        L.tcount, L.slots, wcap, P, sprobe, sorder);
@@ -1275,9 +1355,7 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   else
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
                        L.tcount, L.slots, wcap, P, sprobe, sorder);
-  // (probes build: the stamp buffer named by the frn_stamps_lo / _hi options, shared with the FR gather's probe)
-  unsigned long long* const dstamps = R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps.get()) : nullptr;
-  if (g_r3_clip_impl == 0)
+  if (fast)
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, true>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
                        L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps, AssignOut(),
                        (int)g_r3_iou_dyn);
@@ -1446,7 +1524,8 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
     // (iou_stream_kernel + one global queue behind an atomic counter: 37 us of stream at 128 x 196 416, this: ~20)
     const int tiles = L.tiles_x * L.tiles_y;
     const dim3 sgrid(L.tiles_x, L.tiles_y);
-    const int wcap3 = g_r3_iou_qcap > 0 && g_r3_iou_qcap < P_WSEG ? g_r3_iou_qcap : P_WSEG;  // (small: the dense-tile path)
+    const int qcap3 = g_r3_iou_qcap;  // (one read per call)
+    const int wcap3 = qcap3 > 0 && qcap3 < P_WSEG ? qcap3 : P_WSEG;  // (small: the dense-tile path)
     const AssignZero az{L.rowkey, L.colkey, L.lowq};  // (round 5: assign_init_kernel's work, one launch less)
     if (prepared && n2 % 4 == 0)
       hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, true>), sgrid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
@@ -1457,7 +1536,8 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
     const bool fast = g_r3_clip_impl == 0;
     unsigned long long pairs3 = (unsigned long long)n1 * n2;
     int blocks3 = (int)((pairs3 + T_THREADS - 1) / T_THREADS);
-    const int maxb3 = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : fast ? 4 * r3_cu_count() : 1536;
+    const int dwgs3 = g_r3_iou_dwgs;  // (one read per call)
+    const int maxb3 = dwgs3 > 0 ? dwgs3 : fast ? 4 * r3_cu_count() : 1536;
     if (blocks3 > maxb3) blocks3 = maxb3;
     const int n1_lds3 = n1 < 2048 ? n1 : 2048;
     const AssignOut ao{L.siou, L.rowkey, L.colkey, n1_lds3, R3_HAS_PROBES ? (int)g_r3_fr_walk - 2000 : 0};
@@ -1487,8 +1567,10 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
   // columns: 243 us instead of 55 -- a few hundred addresses take every pair's update.)
   const int n1_lds = n1 < 2048 ? n1 : 2048;
   // (LDS-list clip, measured: 512 -> 62 us, 1024 -> 58, 1536 -> 55, 2048 -> 53; the straight-line clip holds 4 workgroups per CU)
-  const int dmax = g_r3_iou_dwgs > 0 ? g_r3_iou_dwgs : (GEOM == 1 && g_r3_clip_impl == 0) ? 4 * r3_cu_count() : 2048;
-  if (GEOM == 1 && g_r3_clip_impl == 0)
+  const bool fast_g = GEOM == 1 && g_r3_clip_impl == 0;  // (one read per call)
+  const int dwgs_g = g_r3_iou_dwgs;
+  const int dmax = dwgs_g > 0 ? dwgs_g : fast_g ? 4 * r3_cu_count() : 2048;
+  if (fast_g)
     hipLaunchKernelGGL((assign_drain_kernel<GEOM, GEOM == 1>), dim3(blocks < dmax ? blocks : dmax), dim3(T_THREADS),
                        (size_t)n1_lds * sizeof(u64k), stream, L.recsA, recsB, n2, L.gqueue, L.counter, L.qiou, L.rowkey,
                        L.colkey, n1_lds);

@@ -244,6 +244,7 @@ extern R3Option g_r3_frb_impl;  // 0 auto; 1 general index form always; 2 unpair
 extern R3Option g_r3_iou_impl;  // 0 auto, 1 one thread per pair, 2 one-launch compact kernel, 4 prep + stream + drain pipeline always
 extern R3Option g_r3_clip_impl; // v1 pair clip of the drains: 0 straight-line form (r3_clip.h), 1 the LDS-list form (r3_geom_lds.h, rounds 2-4)
 extern R3Option g_r3_iou_dyn;   // drain: 1 a wavefront's blocks behind its first are handed out by an atomic ticket | 0 static stride
+extern R3Option g_r3_iou_nfill; // (iou_impl 5) fill workgroups of the one-launch drain; 0: one per compute unit
 extern R3Option g_r3_iou_order; // stream kernel: -1 all workgroups zero their tile early; b >= 0: those with bit b of the linear index
 extern R3Option g_r3_iou_dwgs;  // 0 default (2048); > 0: workgroups of the IoU drain kernel (tuning)
 extern R3Option g_r3_iou_qcap;  // 0 default; > 0 caps the IoU pipeline's global pair queue (tests the overflow path)

@@ -1708,6 +1708,7 @@ template <int GEOM, bool LABEL>
 int run_nms(const float* dets, int det_stride, const int64_t* labels, const int64_t* order, int n,
             float thr, const Layout& L, int64_t* keep_out, int32_t* count_out, hipStream_t stream) {
   const int cb = L.cb;
+  const bool clip_fast = g_r3_clip_impl == 0;  // (one read per call)
   const bool tiles = (g_r3_nms_impl == 1) || !(thr >= 0.f) || n >= 65536;
   hipLaunchKernelGGL((nms_prepare_kernel<GEOM>), dim3((n + 255) / 256), dim3(256), 0, stream, dets,
                      det_stride, labels, order, n, L.recs, tiles ? nullptr : L.counter);
@@ -1725,7 +1726,7 @@ int run_nms(const float* dets, int det_stride, const int64_t* labels, const int6
   if (r3k_zero_async(L.mask, zbytes, stream) != 0) return -2;
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, n, cb, L.gqueue, L.qcap,
                      L.counter, L.redo, single_problem(n));
-  if (g_r3_clip_impl == 0)
+  if (clip_fast)
     hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, true>), dim3(drain_blocks((size_t)L.qcap * Q_NREG, 4 * r3_cu_count())), dim3(256), 0, stream, L.recs, n, cb,
                        thr, L.gqueue, L.qcap, L.counter, L.redo, L.mask, L.nz, single_problem(n));
   else
@@ -2472,7 +2473,8 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   // (mask + side tables are adjacent and 256-byte aligned: zeroed by the begin kernel, whose grid is widened so that
   // the fill runs at memory speed)
   const dim3 pgrid((cap + RP_C - 1) / RP_C, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
-  const int chip_wgs = g_r3_clip_impl == 0 ? 4 * r3_cu_count() : 2048;
+  const bool clip_fast = g_r3_clip_impl == 0;  // (one read per call -- the grid and the kernel form go together)
+  const int chip_wgs = clip_fast ? 4 * r3_cu_count() : 2048;
   int dblocks = drain_blocks(L.qstride, chip_wgs);
   if (dblocks > chip_wgs / B) dblocks = chip_wgs / B > 0 ? chip_wgs / B : 1;  // B images share the chip
   const dim3 dgrid(dblocks, 1, B);
@@ -2485,7 +2487,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
                      L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16, scale_parts);     \
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, L.gqueue,      \
                      (unsigned)L.qcap, L.counter, L.redo, bt);                                                    \
-  if (g_r3_clip_impl == 0)                                                                                         \
+  if (clip_fast)                                                                                                   \
     hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, true>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb,        \
                        iou_thr, L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt);                  \
   else                                                                                                             \

@@ -106,6 +106,36 @@ def test_odd_shapes_and_unaligned(iou_impl):
         assert same(run(O.V3, a, b), want), (m, n)
 
 
+@pytest.mark.parametrize("geom", [O.V1, O.V3])
+@pytest.mark.parametrize("qcap", [0, 100], ids=["queued", "dense-tiles"])
+@pytest.mark.parametrize("nfill", [0, 3, 64])
+def test_one_launch_form_bit_exact(geom, qcap, nfill):
+    """Round 6, option iou_impl 5: K1 = the tests alone + one survivor bit per element, K2 = the drain
+    whose first workgroups write every element the bits do not name -- fill and clip on disjoint addresses in one launch.
+    Bit for bit the twin oracle (rbbox_geo_kernel.cu:231-268) and the shipped stream -> drain pair: aligned shapes of one
+    and several tiles, partial last tiles and rows, tiles marked dense (written whole by the drain), 1 / 3 / 64 fill
+    blocks; the result buffer holds NaNs before the call, so an element neither kind of store reaches would show."""
+    from r3det import _C
+    for (m, n) in [(700, 332), (37, 2052), (130, 4096), (9, 1024), (64, 12288)]:
+        a = rand_boxes(m, 61 + m, span=150.0, amin=-np.pi, amax=np.pi)
+        b = rand_boxes(n, 62 + n, span=150.0)
+        with O.twin():
+            want = O.iou_mat(geom, a, b, threads=8)
+        try:
+            _C.set_option("iou_impl", 5)
+            _C.set_option("iou_qcap", qcap)
+            _C.set_option("iou_nfill", nfill)
+            for _ in range(2):
+                poison = torch.full((m, n), float('nan'), device='cuda')   # (the caching allocator hands this block to the
+                del poison                                                 #  call's torch.empty: an unwritten element shows)
+                got = run(geom, a, b)
+                assert same(got, want), (m, n)
+        finally:
+            _C.set_option("iou_impl", 0)
+            _C.set_option("iou_qcap", 0)
+            _C.set_option("iou_nfill", 0)
+
+
 def test_assignment_shape_full_size():
     """Config 5 shape: 128 GT x 196 416 grid anchors (theta = 0).  Checked three ways:
     sampled columns bit-exact vs the twin oracle, range, and zero pattern == circle test
