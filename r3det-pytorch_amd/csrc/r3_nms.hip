@@ -2066,7 +2066,12 @@ constexpr int RP_TJ = 1024;  // keys per LDS tile (measured at n = 2000 / 8576, 
 constexpr int RP_C = 8;      // candidates per workgroup
 constexpr int RP_P = 32;     // threads per candidate
 
-template <int GEOM>
+// CT (round 6): candidates per thread.  A tile's keys are read from LDS once per thread whatever CT is, so the LDS
+// traffic of the ranking loop falls by CT; pools beyond 16 384 candidates take CT = 4 (M = 32 768: 4096 workgroups
+// pulling all keys through LDS for 8 candidates each -> 1024 for 32).  Measured: 109 -> 100 us only -- at that size the
+// kernel is the 134 MB zero fill of the dense M x M / 64 suppressor mask it carries (the reducer's input), not the
+// ranking; a pool of that size wants sparse suppressor lists instead of the mask.
+template <int GEOM, int CT = 1>
 __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
     const float* __restrict__ boxes, int n, const int* __restrict__ cand_row, const int* __restrict__ cand_label,
     const float* __restrict__ cand_score, int cand_stride, const int* __restrict__ counts_raw, int cap,
@@ -2074,7 +2079,7 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
     int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab,
     unsigned* __restrict__ counter, size_t counter_stride, uint4* __restrict__ zero, size_t zero16, int sparts) {
   __shared__ __attribute__((aligned(16))) unsigned keys[RP_TJ];
-  __shared__ int partial[RP_P][RP_C];
+  __shared__ int partial[RP_P][RP_C * CT];
   const int img = blockIdx.y, tid = threadIdx.x;
   const int M = min(counts_raw[img], cap);  // (an image with more candidates than cap is its first cap candidates)
   if (blockIdx.x == 0 && tid == 0) ccounts[img] = M;
@@ -2084,15 +2089,21 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
       zero[k] = make_uint4(0u, 0u, 0u, 0u);
   }
   for (int k = blockIdx.x * 256 + tid; k < Q_CTL_WORDS; k += gridDim.x * 256) counter[img * counter_stride + k] = 0;
-  const int i0 = blockIdx.x * RP_C;
+  constexpr int WC = RP_C * CT;  // candidates of a workgroup
+  const int i0 = blockIdx.x * WC;
   if (i0 >= M) return;
   const size_t cbase = (size_t)img * cand_stride;
   const float* sc = cand_score + cbase;
   const int ci = tid & (RP_C - 1), part = tid / RP_C;
-  const int c = i0 + ci;
-  const bool live = c < M;
-  const unsigned ui = live ? order_key(sc[c]) : 0xffffffffu;
-  int cnt = 0;
+  // the thread's candidates: i0 + ci + k * RP_C
+  unsigned ui[CT];
+  int cnt[CT];
+#pragma unroll
+  for (int k = 0; k < CT; k++) {
+    const int ck = i0 + ci + k * RP_C;
+    ui[k] = ck < M ? order_key(sc[ck]) : 0xffffffffu;
+    cnt[k] = 0;
+  }
   constexpr int SL4 = RP_TJ / RP_P / 4;  // uint4 reads of a thread per tile
   const uint4* k4 = reinterpret_cast<const uint4*>(keys) + part * SL4;
   // (the next tile's scores are requested before the current tile is counted: a tile is 4 keys per thread)
@@ -2117,35 +2128,44 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
 #pragma unroll 8
       for (int q = 0; q < SL4; q++) {  // (half-wave broadcast b128 reads: 4 keys per LDS instruction)
         const uint4 u = k4[q];
-        cnt += (u.x >= ui) + (u.y >= ui) + (u.z >= ui) + (u.w >= ui);
+#pragma unroll
+        for (int k = 0; k < CT; k++) cnt[k] += (u.x >= ui[k]) + (u.y >= ui[k]) + (u.z >= ui[k]) + (u.w >= ui[k]);
       }
-    } else if (j0 >= i0 + RP_C) {
+    } else if (j0 >= i0 + WC) {
 #pragma unroll 8
       for (int q = 0; q < SL4; q++) {
         const uint4 u = k4[q];
-        cnt += (u.x > ui) + (u.y > ui) + (u.z > ui) + (u.w > ui);
+#pragma unroll
+        for (int k = 0; k < CT; k++) cnt[k] += (u.x > ui[k]) + (u.y > ui[k]) + (u.z > ui[k]) + (u.w > ui[k]);
       }
     } else {
-      const int before = c - j0 - part * (RP_TJ / RP_P);  // j < before  <=>  this slice's key j precedes c
+      int before[CT];  // j < before[k]  <=>  this slice's key j precedes candidate k
+#pragma unroll
+      for (int k = 0; k < CT; k++) before[k] = (i0 + ci + k * RP_C) - j0 - part * (RP_TJ / RP_P);
 #pragma unroll 4
       for (int q = 0; q < SL4; q++) {
         const uint4 u = k4[q];
         const int j = q * 4;
-        cnt += (u.x > ui) | ((u.x == ui) & (j < before));
-        cnt += (u.y > ui) | ((u.y == ui) & (j + 1 < before));
-        cnt += (u.z > ui) | ((u.z == ui) & (j + 2 < before));
-        cnt += (u.w > ui) | ((u.w == ui) & (j + 3 < before));
+#pragma unroll
+        for (int k = 0; k < CT; k++) {
+          cnt[k] += (u.x > ui[k]) | ((u.x == ui[k]) & (j < before[k]));
+          cnt[k] += (u.y > ui[k]) | ((u.y == ui[k]) & (j + 1 < before[k]));
+          cnt[k] += (u.z > ui[k]) | ((u.z == ui[k]) & (j + 2 < before[k]));
+          cnt[k] += (u.w > ui[k]) | ((u.w == ui[k]) & (j + 3 < before[k]));
+        }
       }
     }
   }
-  partial[part][ci] = cnt;
-  __syncthreads();
-  if (part != 0) return;
-  cnt = 0;
 #pragma unroll
-  for (int q = 0; q < RP_P; q++) cnt += partial[q][ci];
-  if (!live) return;
-  const int pos = cnt;
+  for (int k = 0; k < CT; k++) partial[part][ci + k * RP_C] = cnt[k];
+  __syncthreads();
+  if (tid >= WC) return;        // (one thread per candidate from here on: thread t = candidate i0 + t)
+  int total_before = 0;
+#pragma unroll
+  for (int q = 0; q < RP_P; q++) total_before += partial[q][tid];
+  const int c = i0 + tid;
+  if (c >= M) return;
+  const int pos = total_before;
   const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
   const float lab = (float)cand_label[cbase + c];
   float d[5] = {b[0], b[1], b[2], b[3], b[4]};
@@ -2472,7 +2492,9 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   // or checks them afterwards and calls again)
   // (mask + side tables are adjacent and 256-byte aligned: zeroed by the begin kernel, whose grid is widened so that
   // the fill runs at memory speed)
-  const dim3 pgrid((cap + RP_C - 1) / RP_C, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
+  const bool big_pool = cap > 16384;  // (the ranking loop with 4 candidates per thread: mc_sort_prepare_kernel<., 4>)
+  const int pwc = big_pool ? RP_C * 4 : RP_C;
+  const dim3 pgrid((cap + pwc - 1) / pwc, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
   const bool clip_fast = g_r3_clip_impl == 0;  // (one read per call -- the grid and the kernel form go together)
   const int chip_wgs = clip_fast ? 4 * r3_cu_count() : 2048;
   int dblocks = drain_blocks(L.qstride, chip_wgs);
@@ -2482,9 +2504,16 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     hipLaunchKernelGGL(mc_hbb_extent_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, S, counts, cap, L.extent);
   (void)cand_rank;  // (scratch of the three-launch form of round 2; kept in the signature)
 #define R3_MC(GEOM, LABEL, SCALE)                                                                                  \
-  hipLaunchKernelGGL(mc_sort_prepare_kernel<GEOM>, pgrid, dim3(256), 0, stream, boxes, n, cand_row, cand_label,   \
-                     cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead, L.rlab,       \
-                     L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16, scale_parts);     \
+  if (big_pool)                                                                                                    \
+    hipLaunchKernelGGL((mc_sort_prepare_kernel<GEOM, 4>), pgrid, dim3(256), 0, stream, boxes, n, cand_row,         \
+                       cand_label, cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead,  \
+                       L.rlab, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
+                       scale_parts);                                                                                \
+  else                                                                                                             \
+    hipLaunchKernelGGL((mc_sort_prepare_kernel<GEOM, 1>), pgrid, dim3(256), 0, stream, boxes, n, cand_row,         \
+                       cand_label, cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead,  \
+                       L.rlab, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
+                       scale_parts);                                                                                \
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, L.gqueue,      \
                      (unsigned)L.qcap, L.counter, L.redo, bt);                                                    \
   if (clip_fast)                                                                                                   \

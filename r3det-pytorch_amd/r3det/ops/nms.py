@@ -162,9 +162,10 @@ def batched_rnms(bboxes, scores, inds, nms_thr, class_agnostic=False):
 
 _RNMS_WS = {}
 # Largest pool the one-call forms take.  The library holds up to 65 472 rows, but its workspace carries a dense
-# n x n/64 suppressor mask (540 MB, zero-filled per call, at 65 k rows): beyond 16 384 rows (33 MB) the op-by-op
-# wrapper is the faster form (measured at 32 768 in round 2), so the crossover stays there.
-FAST_MAX_N = 16384
+# n x n/64 suppressor mask (540 MB, zero-filled per call, at 65 k rows).  Measured in round 6 (us per call, op-by-op
+# wrapper / one call): 16 000: 163 / 163, 24 576: 398 / 362, 32 768: 611 / 525 (then 4 candidates per thread in the
+# ranking loop), 49 152: 1035 / 1078, 65 000: 1997 / 2169 -- the crossover lies between 32 768 and 49 152.
+FAST_MAX_N = 32768
 
 
 def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry="r3det_batched_rnms"):

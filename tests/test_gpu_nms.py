@@ -337,3 +337,29 @@ def test_one_call_wrapper_large_pool():
     d1, k1 = M.batched_rnms(b[:100], s[:100], lab[:100].float(), 0.1)
     d2, k2 = M.batched_rnms(b[:100], s[:100], lab[:100], 0.1)
     assert torch.equal(k1, k2) and torch.equal(d1, d2)
+
+
+def test_one_call_form_at_32768_rows_exact_vs_the_twin_oracle():
+    """SURVEY 8d names n = 32 768 (the reference reduces it on the host: nms_rotated_cuda.cu:117-128; rnms_kernel.cu:229-335).
+    Round 6: pools up to 32 768 rows take the one-call form (FAST_MAX_N), whose ranking loop runs with four candidates
+    per thread beyond 16 384 (mc_sort_prepare_kernel<., 4>): the keep list equals the twin oracle's on the offset boxes
+    (ties in the scores included) and the op-by-op wrapper's."""
+    import r3det.ops.nms as M
+    n = 32768
+    assert M.FAST_MAX_N >= n
+    b = rand_boxes(n, 3, span=1500.0)
+    r = np.random.default_rng(1)
+    s = r.uniform(0.05, 1, n).astype(np.float32)
+    s[::11] = s[5]                                  # ties: the stable order decides
+    lab = r.integers(0, 15, n)
+    shifted = b.copy()
+    shifted[:, :2] += (lab * (b.max() + 1)).astype(np.float32)[:, None]
+    with O.twin():
+        want = O.nms(O.V1, shifted, s, 0.1, strict=True, ascending=True)
+    tb, ts, tl = (torch.from_numpy(x).cuda() for x in (b, s, lab))
+    fast = M._batched_rnms_device(tb, ts, tl, 0.1, False)
+    assert fast is not None
+    dets, keep = fast
+    assert 5000 < keep.numel() < 20000
+    assert np.array_equal(keep.cpu().numpy(), want)
+    assert torch.equal(dets[:, :5], tb[keep]) and torch.equal(dets[:, 5], ts[keep])

@@ -21,6 +21,9 @@ if os.environ.get("NMS_PROF_clip_impl"):  # A/B: 1 = the LDS-list clip of rounds
 if os.environ.get("NMS_PROF_nms_impl"):   # A/B: 4 = the walk reducer
     _C.set_option("nms_impl", int(os.environ["NMS_PROF_nms_impl"]))
 
+if os.environ.get("NMS_PROF_FAST_MAX_N"):  # A/B: the one-call form's crossover (r3det/ops/nms.py)
+    import r3det.ops.nms as _nms
+    _nms.FAST_MAX_N = int(os.environ["NMS_PROF_FAST_MAX_N"])
 sizes = [os.environ["NMS_PROF_N"]] if os.environ.get("NMS_PROF_N") else [2000, 5344, 8576]
 for n in sizes:
     if str(n).startswith("v3_"):  # the v3 family (nms_rotated_ext.nms_rotated behind obb_batched_nms)
