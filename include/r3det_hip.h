@@ -155,12 +155,17 @@ int r3det_rbbox_assign(int geom, const float* gts, int n_gt, const float* boxes,
  * used as columns -- the exact per-box records, the data of the conservative disjointness test, the bounding box of
  * every 256 consecutive columns -- ONCE into `prepared` (r3det_iou_prepared_bytes(n) bytes, 16-byte aligned); the
  * _prepared entry points take it next to the boxes themselves and give bit for bit the results of the plain ones.
- * geom: R3DET_GEOM_V1 / _V2 / _V3, the same in the prepare call and in every use: the library remembers (on the host, per
- * buffer address) what it prepared a buffer for, and the _prepared entry points return R3DET_EINVAL for another geometry or
- * column count; an address it has not prepared itself is taken as it is.  mode of r3det_iou_mat_prepared: as the
- * plain entry of the geometry takes it (v1 / v2: 1 = iof; v3: 0 = iof). */
+ * geom: R3DET_GEOM_V1 / _V2 / _V3, the same in the prepare call and in every use.  The buffer begins with a 16-byte
+ * header {magic, geometry, n, check} (round 6; no host-side state): every workgroup of a consumer compares it with its
+ * own launch before reading anything else, and a buffer prepared for another geometry or column count -- or one that
+ * was never prepared -- is NOT used: the call answers in its data, r3det_iou_mat_prepared with a matrix of NaN,
+ * the assignment with max_overlaps = NaN and every box ignored (-1).  r3det_iou_prepared_check gives the same answer
+ * on the host (R3DET_OK / R3DET_EINVAL; it copies the header back: a stream synchronisation -- once after preparing,
+ * not per call).  A copy of a prepared buffer is a prepared buffer.  mode of r3det_iou_mat_prepared: as the plain
+ * entry of the geometry takes it (v1 / v2: 1 = iof; v3: 0 = iof). */
 size_t r3det_iou_prepared_bytes(int n);
 int r3det_iou_prepare_columns(int geom, const float* boxes, int n, void* prepared, size_t prepared_bytes, void* stream);
+int r3det_iou_prepared_check(const void* prepared, int geom, int n, void* stream);
 int r3det_iou_mat_prepared(int geom, const float* b1, int n1, const float* b2, int n2, const void* prepared, int mode,
                            float* out, void* ws, size_t ws_bytes, void* stream);
 int r3det_rbbox_assign_prepared(int geom, const float* gts, int n_gt, const float* boxes, int n_boxes,

@@ -1,7 +1,5 @@
 // r3_api.hip -- extern "C" entry points declared in include/r3det_hip.h.
 // Argument validation + dispatch only; kernels live in r3_iou.hip / r3_nms.hip / r3_fr.hip.
-#include <mutex>
-#include <unordered_map>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -163,38 +161,33 @@ int r3det_mmcv_box_iou_rotated(const float* b1, int n1, const float* b2, int n2,
 
 size_t r3det_iou_prepared_bytes(int n) { return r3k_iou_prepared_bytes(n); }
 
-// What a prepared buffer was built for (the buffer is opaque device memory, a mismatched one silently gave wrong
-// IoUs): the library remembers (geometry, column count) per buffer address on the host -- nothing is read back from the
-// device -- and the two consumers refuse a buffer that was prepared for something else.  An address the library has not
-// seen (a copy of a prepared buffer, say) passes unchecked.
-namespace {
-struct PreparedFor { int geom, n; };
-std::mutex g_prepared_mu;
-std::unordered_map<const void*, PreparedFor> g_prepared;
-bool prepared_mismatch(const void* p, int geom, int n) {
-  std::lock_guard<std::mutex> lk(g_prepared_mu);
-  const auto it = g_prepared.find(p);
-  return it != g_prepared.end() && (it->second.geom != geom || it->second.n != n);
-}
-}  // namespace
-
+// What a prepared buffer was built for (the buffer is opaque device memory, a mismatched one silently gave
+// wrong IoUs).  Round 6: the buffer carries a 16-byte header {magic, geometry, n, check} written by the prepare kernel;
+// every workgroup of the consumers' stream kernel compares it with its own launch before it reads anything else and, on
+// a mismatch, answers in the DATA -- a NaN matrix, NaN max_overlaps with every anchor ignored -- instead of using the
+// buffer.  No host-side state (rounds 4-5: a process-global map keyed by the device address, fooled by a freed and
+// reused address).  r3det_iou_prepared_check is the host-side answer for callers who want one: it copies
+// the header back (a stream synchronisation: once after preparing, not per call).
 int r3det_iou_prepare_columns(int geom, const float* boxes, int n, void* prepared, size_t prepared_bytes, void* stream) {
   const DeviceGuard guard(stream);
   if (geom < 1 || geom > 3) return R3DET_EINVAL;
-  const int r = r3k_iou_prepare_columns(geom, boxes, n, prepared, prepared_bytes, S(stream));
-  if (r == 0 && prepared) {
-    std::lock_guard<std::mutex> lk(g_prepared_mu);
-    if (g_prepared.size() > 4096) g_prepared.clear();  // (addresses come and go with the caller's allocator)
-    g_prepared[prepared] = PreparedFor{geom, n};
-  }
-  return rc(r);
+  return rc(r3k_iou_prepare_columns(geom, boxes, n, prepared, prepared_bytes, S(stream)));
+}
+
+int r3det_iou_prepared_check(const void* prepared, int geom, int n, void* stream) {
+  const DeviceGuard guard(stream);
+  if (!prepared || geom < 1 || geom > 3 || n <= 0) return R3DET_EINVAL;
+  int h[4] = {0, 0, 0, 0};
+  if (hipMemcpyAsync(h, prepared, sizeof(h), hipMemcpyDeviceToHost, S(stream)) != hipSuccess) return R3DET_ELAUNCH;
+  if (hipStreamSynchronize(S(stream)) != hipSuccess) return R3DET_ELAUNCH;
+  const int magic = 0x52335043;  // "R3PC" (csrc/r3_iou.hip: COLPREP_MAGIC)
+  return (h[0] == magic && h[1] == geom && h[2] == n && h[3] == (magic ^ geom ^ n)) ? R3DET_OK : R3DET_EINVAL;
 }
 
 int r3det_iou_mat_prepared(int geom, const float* b1, int n1, const float* b2, int n2, const void* prepared, int mode,
                            float* out, void* ws, size_t ws_bytes, void* stream) {
   const DeviceGuard guard(stream);
   if (bad_iou_args(b1, n1, b2, n2, out) || geom < 1 || geom > 3 || (n2 > 0 && !prepared)) return R3DET_EINVAL;
-  if (prepared_mismatch(prepared, geom, n2)) return R3DET_EINVAL;
   // (mode: as the reference entry of the geometry takes it -- v1 / v2: 1 = iof; v3: 0 = iof)
   const int iof = geom == 3 ? (mode == 0) : (mode != 0);
   return rc(r3k_iou_mat(geom, iof, b1, n1, b2, n2, out, ws, ws_bytes, S(stream), prepared));
@@ -207,7 +200,6 @@ int r3det_rbbox_assign_prepared(int geom, const float* gts, int n_gt, const floa
                                 int64_t* gt_argmax_overlaps, void* ws, size_t ws_bytes, void* stream) {
   const DeviceGuard guard(stream);
   if (n_boxes > 0 && !prepared) return R3DET_EINVAL;
-  if (prepared_mismatch(prepared, geom, n_boxes)) return R3DET_EINVAL;
   return rc(r3k_iou_assign(geom, gts, n_gt, boxes, n_boxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality,
                            gt_max_assign_all, assigned_gt_inds, max_overlaps, argmax_overlaps, gt_max_overlaps,
                            gt_argmax_overlaps, ws, ws_bytes, S(stream), prepared));
@@ -236,7 +228,6 @@ int r3det_rbbox_assign_labeled(int geom, const float* gts, int n_gt, const float
                                void* stream) {
   const DeviceGuard guard(stream);
   if ((gt_labels == nullptr) != (assigned_labels == nullptr)) return R3DET_EINVAL;
-  if (prepared && prepared_mismatch(prepared, geom, n_boxes)) return R3DET_EINVAL;
   return rc(r3k_iou_assign(geom, gts, n_gt, boxes, n_boxes, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality,
                            gt_max_assign_all, assigned_gt_inds, max_overlaps, argmax_overlaps, gt_max_overlaps,
                            gt_argmax_overlaps, ws, ws_bytes, S(stream), prepared, gt_labels, assigned_labels));

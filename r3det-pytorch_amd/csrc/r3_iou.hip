@@ -223,8 +223,19 @@ __device__ __forceinline__ void compact_tile(const int bx, const int by, const f
   }
 }
 
+// (R3_COMPACT_WAVES / R3_VEC_WAVES: minimum waves per SIMD asked of the compiler for the v1 forms.  Without a bound they
+// take 185 / 188 registers = occupancy 2; bounded to 3 they compile to 168 registers with no scratch.  Measured
+// (profiles/r06_iou_occupancy_ab.txt): the one-launch tile kernel at 1000 x 128 9.94 us either way -- its 125 workgroups
+// are a latency chain, not an occupancy problem --, the aligned form over 196 416 pairs 13.1 -> 12.4 us.  The 32-row
+// tile form (212 registers) keeps its occupancy 2: bounded it spills 180 B / lane.)
+#ifndef R3_COMPACT_WAVES
+#define R3_COMPACT_WAVES 3
+#endif
+#ifndef R3_VEC_WAVES
+#define R3_VEC_WAVES 3
+#endif
 template <int GEOM, bool VEC, int CPT, int ROWS>
-__global__ __launch_bounds__(T_THREADS) void iou_mat_compact_kernel(const float* __restrict__ b1, int n1,
+__global__ __launch_bounds__(T_THREADS, (GEOM == 1 && ROWS == 8) ? R3_COMPACT_WAVES : 1) void iou_mat_compact_kernel(const float* __restrict__ b1, int n1,
                                                                     const float* __restrict__ b2, int n2,
                                                                     int iof, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float rows[ROWS][R3_REC];
@@ -414,7 +425,15 @@ __device__ __forceinline__ void reject_data(const float x, const float y, const 
 // and the bounding box of every 256 consecutive columns (a stream wavefront's columns) are computed ONCE
 // (r3det_iou_prepare_columns) and read back by every call -- the stream kernel's per-wavefront prologue was 45 % of its
 // instructions, the drain rebuilt a column's record for every surviving pair.
+// Round 6: the buffer begins with a 16-byte HEADER {magic, geometry, n, magic ^ geometry ^ n} written by the prepare
+// kernel and looked at by every workgroup of the consumers' stream kernel (one scalar load): a buffer prepared for another
+// geometry or another column count -- or not prepared at all -- is refused ON THE DEVICE, before a byte of it is used:
+// the matrix form fills its tile with NaN, the assignment's keys become NaN (max_overlaps NaN, every anchor ignored).
+// No host-side state (rounds 4-5 kept a process-global map keyed by the device address, which a freed and reused
+// address could fool: ADVICE r5); r3det_iou_prepared_check copies the header back for callers who want a host answer.
+constexpr int COLPREP_MAGIC = 0x52335043;  // "R3PC"
 struct ColPrep {
+  const int4* hdr;     // {magic, geom, n, magic ^ geom ^ n}
   const BoxRec* rec;   // [n2]
   const float4* rej;   // [n2] cx, cy, inflated AABB half extents (= rec.f[9], f[10], f[12], f[13])
   const float* rad;    // [n2] inflated circumscribed radius (= rec.f[11])
@@ -423,10 +442,11 @@ struct ColPrep {
 
 inline size_t colprep_layout(int n2, const void* p, ColPrep* L) {
   const size_t nw = ((size_t)n2 + 255) / 256;
-  const size_t o_rec = 0, o_rej = (o_rec + (size_t)n2 * sizeof(BoxRec) + 255) & ~(size_t)255;
+  const size_t o_rec = 256, o_rej = (o_rec + (size_t)n2 * sizeof(BoxRec) + 255) & ~(size_t)255;
   const size_t o_rad = (o_rej + (size_t)n2 * 16 + 255) & ~(size_t)255, o_wb = (o_rad + (size_t)n2 * 4 + 255) & ~(size_t)255;
   if (L) {
     const char* c = static_cast<const char*>(p);
+    L->hdr = reinterpret_cast<const int4*>(c);
     L->rec = reinterpret_cast<const BoxRec*>(c + o_rec);
     L->rej = reinterpret_cast<const float4*>(c + o_rej);
     L->rad = reinterpret_cast<const float*>(c + o_rad);
@@ -438,10 +458,11 @@ inline size_t colprep_layout(int n2, const void* p, ColPrep* L) {
 template <int GEOM>
 __global__ __launch_bounds__(256) void iou_prepare_kernel(const float* __restrict__ b2, int n2, BoxRec* __restrict__ rec,
                                                           float4* __restrict__ rej, float* __restrict__ rad,
-                                                          float4* __restrict__ wbox) {
+                                                          float4* __restrict__ wbox, int4* __restrict__ hdr) {
   __shared__ float red[4][4];
   __shared__ int bad;
   const int c = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *hdr = make_int4(COLPREP_MAGIC, GEOM, n2, COLPREP_MAGIC ^ GEOM ^ n2);
   if (threadIdx.x == 0) bad = 0;
   __syncthreads();
   float x0 = 3.0e38f, x1 = -3.0e38f, y0 = 3.0e38f, y1 = -3.0e38f;
@@ -549,6 +570,26 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
         if (col0 + c < n2) az.colkey[col0 + c] = 0xffffffffULL, az.lowq[col0 + c] = 0;
     }
     if (blockIdx.x == 0 && tid < nrows) az.rowkey[row0 + tid] = 0xffffffffULL;
+  }
+  if (PREP) {
+    // the buffer's header against this launch (uniform: one scalar load per workgroup)
+    const int4 h = *prep.hdr;
+    if (h.x != COLPREP_MAGIC || h.y != GEOM || h.z != n2 || h.w != (COLPREP_MAGIC ^ GEOM ^ n2)) {
+      const float nan = __builtin_nanf("");
+      if (out && col0 < n2) {  // (VEC: n2 % 4 == 0)
+        for (int r = 0; r < nrows; r++) *reinterpret_cast<float4*>(out + (size_t)(row0 + r) * n2 + col0) = make_float4(nan, nan, nan, nan);
+      }
+      if (az.colkey) {  // the assignment: NaN keys -> max_overlaps NaN, every anchor ignored (-1)
+        const unsigned long long nk = ((unsigned long long)__float_as_uint(nan) << 32) | 0xffffffffULL;
+        if (blockIdx.y == 0)
+          for (int c = 0; c < T_CPT; c++)
+            if (col0 + c < n2) az.colkey[col0 + c] = nk, az.lowq[col0 + c] = 0;
+        if (blockIdx.x == 0 && tid < nrows) az.rowkey[row0 + tid] = nk;
+      }
+      if (tid == 0) tcount[blockIdx.y * gridDim.x + bx] = 0;  // nothing for the drain
+      if (BITS) bits[(size_t)(blockIdx.y * gridDim.x + bx) * T_THREADS + tid] = 0xffffffffu;
+      return;
+    }
   }
   float rowraw[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (tid < nrows) {
@@ -719,8 +760,13 @@ struct AssignOut {
 // then join the drain; clips write the named elements only, so the two kinds of store never meet and need no order.
 // Every workgroup has the drain's footprint (128 VGPRs, 18 KB of LDS: four per compute unit), so a fill block is a
 // drain block that starts late: the blocks behind a wavefront's first are then always dealt by ticket.
+// (the v3 hull form at 4 waves per SIMD = 128 registers spilled 12 B / lane; bounded to 3 it takes 164 registers and no
+// scratch: 28.1 against 28.6 us at 128 x 196 416, profiles/r06_iou_occupancy_ab.txt)
+#ifndef R3_DRAIN3_V3_WAVES
+#define R3_DRAIN3_V3_WAVES 3
+#endif
 template <int GEOM, bool FAST = false, bool ASSIGN = false, bool FILL = false>
-__global__ __launch_bounds__(T_THREADS, FAST ? 4 : 1) void iou_drain3_kernel(const float* __restrict__ b1, int n1,
+__global__ __launch_bounds__(T_THREADS, FAST ? (GEOM == 3 ? R3_DRAIN3_V3_WAVES : 4) : 1) void iou_drain3_kernel(const float* __restrict__ b1, int n1,
                                                                const float* __restrict__ b2, int n2, int iof,
                                                                const BoxRec* __restrict__ recsA,
                                                                const int* __restrict__ tcount,
@@ -1190,7 +1236,7 @@ __global__ __launch_bounds__(256) void assign_final_kernel(const u64k* __restric
 
 // vec_iou_iof_kernel (rbbox_geo_kernel.cu:271-309): out[i] = f(b1[i % n1], b2[i % n2]).
 template <int GEOM>
-__global__ __launch_bounds__(256) void iou_vec_kernel(const float* __restrict__ b1, int n1,
+__global__ __launch_bounds__(256, GEOM == 1 ? R3_VEC_WAVES : 1) void iou_vec_kernel(const float* __restrict__ b1, int n1,
                                                       const float* __restrict__ b2, int n2,
                                                       int iof, float* __restrict__ out) {
   // v1: the straight-line clip (9 slots), the exact list form (16) for what it flags; hull: 12 of the 24 slots in
@@ -1323,13 +1369,14 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   const int dwgs = g_r3_iou_dwgs;
   const int maxb = dwgs > 0 ? dwgs : fast ? 4 * r3_cu_count() : 1536;
   if (blocks > maxb) blocks = maxb;
+  if (!vec) prepared = nullptr;  // (the buffer is read only behind the stream kernel that checks its header: the VEC form)
   ColPrep P = ColPrep();
   if (prepared) colprep_layout(n2, prepared, &P);
   const int sorder = (int)g_r3_iou_order;
   const int sprobe = R3_HAS_PROBES ? (int)g_r3_fr_walk - 1000 : 0;  // (probes build: option fr_walk 1001 / 1002 / 1003 = stream phase probe)
   // (probes build: the stamp buffer named by the frn_stamps_lo / _hi options, shared with the FR gather's probe)
   unsigned long long* const dstamps = R3_HAS_PROBES ? reinterpret_cast<unsigned long long*>(g_r3_frn_stamps.get()) : nullptr;
-  if (impl == 5 && vec && fast && blocks >= 8) {
+  if (impl == 5 && vec && fast && blocks >= 8 && !prepared) {
     // Round 6, option iou_impl 5: fill and clip in ONE launch on disjoint addresses.  K1 = the
     // tests alone (no matrix stores) + the survivor bits; K2 = the drain whose first `nfill` workgroups write every
     // element the bits do not name before they start clipping.  A/B: profiles/r06_iou_one_launch_ab.txt.
@@ -1435,7 +1482,8 @@ int r3k_iou_prepare_columns(int geom, const float* b2, int n2, void* prepared, s
   const dim3 grid((n2 + 255) / 256), block(256);
 #define R3_PREP(G) \
   hipLaunchKernelGGL(iou_prepare_kernel<G>, grid, block, 0, stream, b2, n2, const_cast<BoxRec*>(P.rec), \
-                     const_cast<float4*>(P.rej), const_cast<float*>(P.rad), const_cast<float4*>(P.wbox))
+                     const_cast<float4*>(P.rej), const_cast<float*>(P.rad), const_cast<float4*>(P.wbox), \
+                     const_cast<int4*>(P.hdr))
   switch (geom) {
     case 1: R3_PREP(1); break;
     case 2: R3_PREP(2); break;
@@ -1511,9 +1559,12 @@ inline size_t assign_layout(int n1, int n2, void* ws, AssignLayout* L, const boo
 template <int GEOM>
 void launch_assign(const float* gts, int n1, const float* boxes, int n2, const AssignLayout& L, float min_pos_iou,
                    int match_low, int assign_all, hipStream_t stream, const void* prepared) {
+  // (the prepared buffer is read only behind the stream kernel that checks its header: the tile form with n2 % 4 == 0;
+  // the other forms rebuild the columns' data from the boxes)
+  const bool use_prep = prepared && L.tiled && n2 % 4 == 0;
   ColPrep P = ColPrep();
-  if (prepared) colprep_layout(n2, prepared, &P);
-  const BoxRec* recsB = prepared ? P.rec : L.recsB;
+  if (use_prep) colprep_layout(n2, prepared, &P);
+  const BoxRec* recsB = L.recsB;
   const int nmax = n1 > n2 ? n1 : n2;
   if (!L.tiled)
     hipLaunchKernelGGL(assign_init_kernel, dim3((nmax + 255) / 256), dim3(256), 0, stream, L.rowkey, n1, L.colkey,
@@ -1527,7 +1578,7 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
     const int qcap3 = g_r3_iou_qcap;  // (one read per call)
     const int wcap3 = qcap3 > 0 && qcap3 < P_WSEG ? qcap3 : P_WSEG;  // (small: the dense-tile path)
     const AssignZero az{L.rowkey, L.colkey, L.lowq};  // (round 5: assign_init_kernel's work, one launch less)
-    if (prepared && n2 % 4 == 0)
+    if (use_prep)
       hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, true>), sgrid, dim3(T_THREADS), 0, stream, gts, n1, boxes, n2,
                          (float*)nullptr, L.recsA, L.tcount, L.slots, wcap3, P, 0, -1, az);
     else
@@ -1545,12 +1596,12 @@ void launch_assign(const float* gts, int n1, const float* boxes, int n2, const A
       // (v3 with the keys as its result: the straight-line form spills 12 B per lane at 128 registers -- the list form there)
       hipLaunchKernelGGL((iou_drain3_kernel<GEOM, GEOM != 3, true>), dim3(blocks3), dim3(T_THREADS),
                          (size_t)n1_lds3 * sizeof(u64k), stream, gts, n1, boxes, n2, 0, L.recsA, L.tcount, L.slots,
-                         L.tiles_x, tiles, (float*)nullptr, prepared ? P.rec : (const BoxRec*)nullptr,
+                         L.tiles_x, tiles, (float*)nullptr, use_prep ? P.rec : (const BoxRec*)nullptr,
                          (unsigned long long*)nullptr, ao, (int)g_r3_iou_dyn);
     else
       hipLaunchKernelGGL((iou_drain3_kernel<GEOM, false, true>), dim3(blocks3), dim3(T_THREADS),
                          (size_t)n1_lds3 * sizeof(u64k), stream, gts, n1, boxes, n2, 0, L.recsA, L.tcount, L.slots,
-                         L.tiles_x, tiles, (float*)nullptr, prepared ? P.rec : (const BoxRec*)nullptr,
+                         L.tiles_x, tiles, (float*)nullptr, use_prep ? P.rec : (const BoxRec*)nullptr,
                          (unsigned long long*)nullptr, ao, (int)g_r3_iou_dyn);
     if (match_low)
       hipLaunchKernelGGL(assign_lowq3_kernel, dim3(tiles, 4), dim3(256), 0, stream, L.tcount, L.slots, L.tiles_x, L.siou, n1,

@@ -26,6 +26,7 @@ SIGNATURES = {
     "r3det_iou_prepare_columns": [_i, _vp, _i, _vp, _sz, _vp],
     "r3det_iou_mat_prepared": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp],
     "r3det_rbbox_assign_prepared": [_i, _vp, _i, _vp, _i, _vp, _f, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "r3det_iou_prepared_check": [_vp, _i, _i, _vp],
     "r3det_rbbox_assign_labeled": [_i, _vp, _i, _vp, _i, _vp, _f, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                    _vp],
     "r3det_rnms": [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp],

@@ -38,7 +38,16 @@ def prepare_columns(boxes, version='v1'):
         if n:
             _C.check(L.r3det_iou_prepare_columns(GEOM[version], _C.ptr(b), n, _C.ptr(buf), nbytes, _C.stream()),
                      "iou_prepare_columns")
+    # (what it was prepared for rides on the tensor object: the wrappers refuse another geometry / column count on
+    # the host, without a device read; the buffer's own header is what the kernels check)
+    buf.r3_prepared_for = (GEOM[version], n)
     return buf
+
+
+def _check_prepared(prepared, geom, n):
+    want = getattr(prepared, "r3_prepared_for", None)
+    if want is not None and want != (geom, n):
+        raise ValueError(f"prepared columns were built for (geometry, n) = {want}, this call has {(geom, n)}")
 
 
 def rbbox_iou(rb1, rb2, vec=False, iof=False, prepared=None):
@@ -63,6 +72,7 @@ def rbbox_iou(rb1, rb2, vec=False, iof=False, prepared=None):
             if n1 and n2:
                 ws, wsb = _C.iou_workspace(n1, n2, rb1.device)
                 if prepared is not None:
+                    _check_prepared(prepared, 1, n2)
                     _C.check(L.r3det_iou_mat_prepared(1, _C.ptr(rb1), n1, _C.ptr(rb2), n2, _C.ptr(prepared),
                                                       int(bool(iof)), _C.ptr(out), _C.ptr(ws), wsb, _C.stream()),
                              "iou_mat_prepared")

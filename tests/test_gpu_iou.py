@@ -291,10 +291,13 @@ def test_prepared_columns_give_the_same_matrix_bit_for_bit(version, shape):
 
 
 def test_prepared_buffer_refused_for_another_shape():
-    """A buffer prepared for (geometry, n2) is refused by the consumers for any other (it used to give wrong IoUs
-    silently); the library remembers what it prepared per buffer address, on the host."""
+    """A buffer prepared for (geometry, n2) is refused by the consumers for any other (it used to give wrong
+    IoUs silently).  Round 6: the buffer carries a header the kernels check on the DEVICE -- a mismatch answers in the data
+    (a matrix of NaN; max_overlaps NaN and every box ignored) and nothing of the buffer is used; on the host
+    r3det_iou_prepared_check gives the same verdict, and the Python wrapper refuses before it launches."""
     from r3det import _C
     from r3det import synthetic as syn
+    from r3det.ops.iou import prepare_columns
     L = _C.lib()
     dev = torch.device("cuda")
     cols = syn.rand_rboxes(2048, 3, device=dev)
@@ -302,16 +305,96 @@ def test_prepared_buffer_refused_for_another_shape():
     pb = int(L.r3det_iou_prepared_bytes(2048))
     prep = torch.empty(pb, dtype=torch.uint8, device=dev)
     _C.check(L.r3det_iou_prepare_columns(1, _C.ptr(cols), 2048, _C.ptr(prep), pb, _C.stream()), "prepare")
+    assert L.r3det_iou_prepared_check(_C.ptr(prep), 1, 2048, _C.stream()) == 0
     out = torch.empty(16, 2048, device=dev)
     wsb = int(L.r3det_iou_workspace_bytes(16, 2048))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     ok = L.r3det_iou_mat_prepared(1, _C.ptr(rows), 16, _C.ptr(cols), 2048, _C.ptr(prep), 0, _C.ptr(out), _C.ptr(ws), wsb, _C.stream())
-    assert ok == 0
-    for geom, n2 in ((1, 2044), (3, 2048)):
-        rc = L.r3det_iou_mat_prepared(geom, _C.ptr(rows), 16, _C.ptr(cols), n2, _C.ptr(prep), 0, _C.ptr(out), _C.ptr(ws), wsb,
+    assert ok == 0 and not bool(torch.isnan(out).any()) and torch.equal(out, rbbox_iou_t(rows, cols))
+    for geom, n2 in ((1, 2044), (3, 2048), (2, 2048), (1, 1024)):
+        assert L.r3det_iou_prepared_check(_C.ptr(prep), geom, n2, _C.stream()) != 0
+        o2 = torch.zeros(16, n2, device=dev)
+        rc = L.r3det_iou_mat_prepared(geom, _C.ptr(rows), 16, _C.ptr(cols), n2, _C.ptr(prep), 0, _C.ptr(o2), _C.ptr(ws), wsb,
                                       _C.stream())
-        assert rc != 0
+        assert rc == 0 and bool(torch.isnan(o2).all())
+    # a buffer that was never prepared: refused as well (whatever bytes it holds)
+    junk = torch.randint(0, 255, (pb,), dtype=torch.uint8, device=dev)
+    assert L.r3det_iou_prepared_check(_C.ptr(junk), 1, 2048, _C.stream()) != 0
+    o3 = torch.zeros(16, 2048, device=dev)
+    assert L.r3det_iou_mat_prepared(1, _C.ptr(rows), 16, _C.ptr(cols), 2048, _C.ptr(junk), 0, _C.ptr(o3), _C.ptr(ws), wsb,
+                                    _C.stream()) == 0 and bool(torch.isnan(o3).all())
+    # the Python wrapper knows what its buffer was prepared for and raises on the host
+    from r3det.ops import rbbox_iou
+    p = prepare_columns(cols, 'v1')
+    with pytest.raises(ValueError):
+        rbbox_iou(rows, cols[:1024].contiguous(), prepared=p)
     torch.cuda.synchronize()
+
+
+def rbbox_iou_t(a, b):
+    from r3det.ops import rbbox_iou
+    return rbbox_iou(a, b)
+
+
+def test_prepared_buffer_at_a_reused_address_and_as_a_copy():
+    """rounds 4-5 kept a host map keyed by the device ADDRESS -- a freed buffer's address handed out again by
+    the allocator kept the stale (geometry, n), and a copy of a prepared buffer passed unchecked.  The header travels
+    with the bytes: the new tenant of an address is judged by what it holds, and a copy is as good as the original."""
+    from r3det import _C
+    from r3det import synthetic as syn
+    L = _C.lib()
+    dev = torch.device("cuda")
+    cols_a, cols_b = syn.rand_rboxes(2048, 3, device=dev), syn.rand_rboxes(1024, 5, device=dev)
+    rows = syn.rand_rboxes(16, 4, device=dev)
+    pa, pb_ = int(L.r3det_iou_prepared_bytes(2048)), int(L.r3det_iou_prepared_bytes(1024))
+    prep_b = torch.empty(pb_, dtype=torch.uint8, device=dev)
+    _C.check(L.r3det_iou_prepare_columns(1, _C.ptr(cols_b), 1024, _C.ptr(prep_b), pb_, _C.stream()), "prepare b")
+    prep_a = torch.empty(pa, dtype=torch.uint8, device=dev)
+    _C.check(L.r3det_iou_prepare_columns(1, _C.ptr(cols_a), 2048, _C.ptr(prep_a), pa, _C.stream()), "prepare a")
+    addr = prep_a.data_ptr()
+    torch.cuda.synchronize()
+    del prep_a
+    # the allocator hands the freed block out again: a COPY of buffer b now lives at a's old address
+    again = torch.empty(pa, dtype=torch.uint8, device=dev)
+    assert again.data_ptr() == addr, "the caching allocator did not reuse the block (the test needs that)"
+    again[:pb_].copy_(prep_b)
+    want = rbbox_iou_t(rows, cols_b)
+    wsb = int(L.r3det_iou_workspace_bytes(16, 2048))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    out = torch.zeros(16, 1024, device=dev)
+    assert L.r3det_iou_prepared_check(_C.ptr(again), 1, 1024, _C.stream()) == 0
+    assert L.r3det_iou_mat_prepared(1, _C.ptr(rows), 16, _C.ptr(cols_b), 1024, _C.ptr(again), 0, _C.ptr(out), _C.ptr(ws), wsb,
+                                    _C.stream()) == 0
+    assert torch.equal(out, want)
+    # ... and it is no longer a buffer for a's shape
+    assert L.r3det_iou_prepared_check(_C.ptr(again), 1, 2048, _C.stream()) != 0
+    o2 = torch.zeros(16, 2048, device=dev)
+    assert L.r3det_iou_mat_prepared(1, _C.ptr(rows), 16, _C.ptr(cols_a), 2048, _C.ptr(again), 0, _C.ptr(o2), _C.ptr(ws), wsb,
+                                    _C.stream()) == 0 and bool(torch.isnan(o2).all())
+
+
+def test_assignment_with_a_mismatched_prepared_buffer_answers_in_its_data():
+    from r3det import _C
+    from r3det import synthetic as syn
+    L = _C.lib()
+    dev = torch.device("cuda")
+    anchors = syn.rand_rboxes(4096, 3, device=dev)
+    gts = syn.rand_rboxes(20, 4, device=dev)
+    pb = int(L.r3det_iou_prepared_bytes(4096))
+    prep = torch.empty(pb, dtype=torch.uint8, device=dev)
+    _C.check(L.r3det_iou_prepare_columns(3, _C.ptr(anchors), 4096, _C.ptr(prep), pb, _C.stream()), "prepare")   # for v3
+    n1, n2 = 20, 4096
+    wsb = int(L.r3det_rbbox_assign_workspace_bytes(n1, n2))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    gi = torch.zeros(n2, dtype=torch.int64, device=dev)
+    mo = torch.zeros(n2, device=dev)
+    am = torch.zeros(n2, dtype=torch.int64, device=dev)
+    gm = torch.zeros(n1, device=dev)
+    ga = torch.zeros(n1, dtype=torch.int64, device=dev)
+    rc = L.r3det_rbbox_assign_prepared(1, _C.ptr(gts), n1, _C.ptr(anchors), n2, _C.ptr(prep), 0.5, 0.4, 0.0, 1, 1, _C.ptr(gi),
+                                       _C.ptr(mo), _C.ptr(am), _C.ptr(gm), _C.ptr(ga), _C.ptr(ws), wsb, _C.stream())
+    assert rc == 0
+    assert bool(torch.isnan(mo).all()) and bool((gi == -1).all())
 
 
 def test_drain_tickets_equal_static_stride_at_512_rows():

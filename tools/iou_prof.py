@@ -26,6 +26,20 @@ a, g = syn.rand_rboxes(1000, 0, device=dev), syn.rand_rboxes(128, 1, device=dev)
 from r3det.ops import obb_overlaps  # noqa: E402
 
 gt512 = syn.dota_like_rboxes(512, 6, device=dev)
+if which == "vec":  # the aligned form (rbbox_geo_kernel.cu:271-309): 196 416 pairs, anchors against jittered copies
+    jit = anchors.clone()
+    jit[:, :2] += torch.randn_like(jit[:, :2]) * 4
+    jit[:, 4] = -0.3
+    for _ in range(3):
+        rbbox_iou(anchors, jit, True)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        out = rbbox_iou(anchors, jit, True)
+    e.record()
+    torch.cuda.synchronize()
+    print(f"rbbox_iou vec 196416: {s.elapsed_time(e) * 1e3 / 20:8.1f} us per call  nnz {int((out > 0).sum())}", flush=True)
 for name, b1, b2 in (("128x196416", gt, anchors), ("512x196416", gt512, anchors), ("128x21824", gt, refined),
                      ("1000x128", a, g), ("v3_128x196416", gt, anchors)):
     if which not in ("all", name):
