@@ -1,5 +1,8 @@
+"""Host time of the training-side FR node (FeatureRefineModuleLevelsFunction, five levels, N = 2, C = 256): per call host /
+wall time, the forward alone, cProfile of 50 calls, and an autograd node of the same signature that launches nothing --
+torch's own cost for the call pattern (bench.py reports the same floor as fr_null_node_ms_wall).  CL=1: channels_last."""
 import os, sys, time, cProfile, pstats
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "r3det-pytorch_amd")):
     sys.path.insert(0, p)
 import torch
