@@ -466,10 +466,11 @@ def fr_rates(device):
     cl = torch.channels_last
     out = {}
 
-    def run(name, N, lvls, points, fn, nhwc, reps=10):
+    def run(name, N, lvls, points, fn, nhwc, reps=10, prep=None, what=None):
         feats, boxes = syn.fr_pyramid(N, C, 31, device=device)
         feats, boxes = [feats[i] for i in lvls], [boxes[i] for i in lvls]
         scales = [1.0 / syn.STRIDES[i] for i in lvls]
+        extra = prep(feats, boxes, scales) if prep else None
         per_set = 2 * 4 * sum(f.numel() for f in feats)
         nset = max(2, min(16, int(6e8 // per_set) + 1))
         sets = []
@@ -483,12 +484,17 @@ def fr_rates(device):
         def call():
             xs, os_ = sets[state[0] % nset]
             state[0] += 1
-            fn(xs, boxes, scales, points, os_)
+            if prep:
+                fn(xs, boxes, scales, points, os_, extra)
+            else:
+                fn(xs, boxes, scales, points, os_)
         dt = timeit(call, reps)
         hw = sum(f.shape[-1] * f.shape[-2] for f in feats)
         nb = b_fr(N, hw, points)
         out[name] = {"us_per_call": round(dt * 1e6, 1), "alg_bytes": nb, "library_calls": 1 if len(lvls) > 1 else len(lvls),
                      "rotating_MB": round(per_set * nset / 1e6), "roofline": _roof(nb, dt)}
+        if what:
+            out[name]["what"] = what
         del sets
 
     # one level: the per-level entry points; the five levels: ONE library call (what FeatureRefineModule runs)
@@ -516,6 +522,26 @@ def fr_rates(device):
         else:
             FRM.fr_backward_levels_nhwc(xs, bs, scs, p, os_)
 
+    # round 6: the backward as a TRAINING step runs it on channels_last memory -- the forward launches of the same boxes
+    # left the levels' tap tables behind (r3det_feature_refine_*_levels_nhwc_tab; built once here, outside the timed
+    # calls, as the forward pass is), the index kernel scans those, then the gathers
+    def tables_of(feats, boxes, scales):
+        fcl = [f.contiguous(memory_format=cl) for f in feats]
+        shapes = [tuple(f.shape[2:]) for f in fcl]
+        tabs = FRM.tap_tables(fcl[0].size(0), shapes, device)
+        assert FRM.fr_forward_levels_nhwc(fcl, boxes, scales, 1, [torch.empty_like(f) for f in fcl], tabs)
+        return tabs
+
+    def bwd_nhwc_train(xs, bs, scs, p, os_, tabs):
+        from r3det import _C as C_
+        N_ = xs[0].size(0)
+        shapes = [tuple(x.shape[2:]) for x in xs]
+        ws, wsb = FRM.fr_backward_nhwc_index_levels(bs, N_, shapes, scs, 1, tabs)
+        P = FRM._plan(N_, 0, shapes, scs, 1)
+        C_.check(C_.lib().r3det_feature_refine_backward_nhwc_levels_indexed(
+            len(xs), FRM._ptr_array(xs), N_, xs[0].size(1), P.H, P.W, 1, FRM._ptr_array(os_), 1, C_.ptr(ws), wsb,
+            C_.stream()), "fr_backward_nhwc_levels_indexed")
+
     fwd, bwd = {False: fwd_nchw, True: fwd_nhwc}, {False: bwd_nchw, True: bwd_nhwc}
     for nhwc, lay in ((False, "nchw"), (True, "nhwc")):
         for points in (1, 5):
@@ -526,6 +552,11 @@ def fr_rates(device):
         for N in (2, 4):
             for lvls, tag in (([0], "L0"), ([1], "L1"), (list(range(5)), "5lvl")):
                 run(f"fr_bwd_{lay}_p1_N{N}_{tag}", N, lvls, 1, bwd[nhwc], nhwc)
+    for N in (2, 4):
+        for lvls, tag in (([0], "L0"), (list(range(5)), "5lvl")):
+            run(f"fr_bwd_nhwc_p1_N{N}_{tag}_train", N, lvls, 1, bwd_nhwc_train, True, prep=tables_of,
+                what="the backward as a training step runs it: index from the tap tables the forward launches wrote "
+                     "(2 library calls: index, gathers)")
     return out
 
 
@@ -975,7 +1006,7 @@ def main():
             alone_rec = {"avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
                          "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
             # The same launch on other box fields: how far the boxes sample from their own cell decides how many tap
-            # rows leave the workgroup's regions -- the headline field is the survey's (centres
+            # rows leave the workgroup's regions (DESIGN_HISTORY 4.3 item 7) -- the headline field is the survey's (centres
             # jittered by 0.4 cells); "trained": every 4 x 4 block of positions regresses to one centre, what a
             # trained detector produces around objects; sigma 4: the random-weight bench model's own stage-1 boxes
             by_field = {"survey_sigma_0.4_cells": {"avg_launch_us": alone_rec["avg_launch_us"], "frac": alone_rec["frac"]}}

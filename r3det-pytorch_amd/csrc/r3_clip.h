@@ -12,7 +12,7 @@
 //     nt(i,j+1) = nt(i,j) - D(i,j), D = -cross(A_i, B_j).  So 0 <= ns/D < 1 <=> ns(i,j), ns(i+1,j) have opposite
 //     signs, and likewise for nt.  In floating point this holds whenever all 32 numerators are larger in magnitude
 //     than 3 delta, delta = 8.2 u max(|C|,|E|) |E| the rounding-error bound of a numerator / of D (u = 2^-24; |C|
-//     the largest vertex difference, |E| the largest edge component) -- proof in DESIGN 4.1.  Such a pair has no
+//     the largest vertex difference, |E| the largest edge component) -- proof in DESIGN_HISTORY 4.1.  Such a pair has no
 //     coincident vertices (C == 0 => ns == 0), no parallel-and-collinear edges (D == 0 needs nt == 0 to produce a
 //     point) and no quotient near 0 or 1, i.e. none of the reference's special branches (:99-103, :118-139) can fire.
 //     A pair with a smaller numerator is FLAGGED (`redo`) and the caller runs the exact form on it.

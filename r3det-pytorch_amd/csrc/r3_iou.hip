@@ -376,7 +376,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream_kernel(const float* __re
 //   drain  : every workgroup rebuilds the prefix over the tile counts (grouped, <= 1024 groups in LDS), then
 //            grid-strides over the concatenated entries, one pair per lane, balanced over the chip; a dense
 //            tile counts as its 8 x 1024 pairs, each tested with the exact records and clipped or zeroed.
-// Measured and NOT shipped: a single persistent kernel in which workgroups alternate between
+// Measured and NOT shipped (DESIGN_HISTORY 4.1): a single persistent kernel in which workgroups alternate between
 // streaming tiles and clipping chunks published by other workgroups (tickets in global memory).  On gfx950 an
 // agent-scope release / acquire is an L2 write-back / invalidate of the whole XCD (the eight L2s are not
 // coherent with each other), so every published tile flushed the freshly written zeros: 725 us instead of 75.

@@ -3,7 +3,7 @@
     python tools/fr_chan_ablate.py tools/probes/abl/lib0.so tools/probes/abl/lib1.so ...
 
 Each library runs in its own child process (a ctypes library cannot be swapped in place).
-The ablation builds are made by hand from a patched copy of r3_fr.hip (see DESIGN.md 4.3);
+The ablation builds are made by hand from a patched copy of r3_fr.hip (see DESIGN_HISTORY.md 4.3);
 they give wrong results on purpose and are never committed.
 """
 import os

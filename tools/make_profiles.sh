@@ -3,9 +3,9 @@
 # of the bench step, the training step, configs[1], the IoU and NMS ops, and the PMC passes (separate runs,
 # --kernel-trace only) of the roofline kernel and of the IoU / NMS kernels.  Output: gpurun_out/profiles_<tag>/,
 # copied into profiles/ by hand (tracked).
-#   bash tools/make_profiles.sh r05
+#   bash tools/make_profiles.sh r06
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$(pwd)
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p $O
@@ -15,7 +15,7 @@ kt() {  # kt <outfile> <header> <program args...>: kernel trace + stats of one c
   local out=$1 hdr=$2; shift 2
   rm -rf /tmp/kt_run
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_run -o t -- "$@" > /tmp/kt_run.log 2>&1
-  { echo "# rocprofv3 --kernel-trace --stats -- $hdr"; grep -v "^W2\|^E2\|^I2" /tmp/kt_run.log | tail -14 | sed 's/^/# /'; } > $out
+  { echo "# rocprofv3 --kernel-trace --stats -- $hdr"; grep -v "^W2\|^E2\|^I2" /tmp/kt_run.log | tail -18 | sed 's/^/# /'; } > $out
 }
 # 1. bench step (R3Det inference, configs[2])
 kt $O/${TAG}_bench_kernel_stats.txt "python3 bench.py --steps 10 --warmup 4 --model-only" python3 $R/bench.py --steps 10 --warmup 4 --model-only
@@ -107,6 +107,10 @@ ORDERS="-1 31 0 3 8" bash tools/iou_order_ab.sh gpurun_out/profiles_$TAG/${TAG}_
 bash tools/assign_emit_ab.sh gpurun_out/profiles_$TAG/${TAG}_assign_emit_ab.txt > /dev/null 2>&1
 bash tools/mc_select_ab.sh gpurun_out/profiles_$TAG/${TAG}_mc_select_ab.txt > /dev/null 2>&1
 bash tools/iou_dyn_ab.sh gpurun_out/profiles_$TAG/${TAG}_iou_dyn_ab.txt > /dev/null 2>&1
+# 7d. round 6: the IoU matrix with fill and clip in one launch against the shipped pair (kernel stats per form + the
+#     same-process A/B), the FR node's host time against torch's own floor for the call pattern (both layouts)
+bash tools/iou_one_launch_ab.sh gpurun_out/profiles_$TAG/${TAG}_iou_one_launch_ab.txt > /dev/null 2>&1
+{ python3 tools/fr_host_prof.py 2>&1 | grep -E "host|wall"; echo "# channels_last:"; CL=1 python3 tools/fr_host_prof.py 2>&1 | grep -E "host|wall"; } | grep -v "fr_host_prof.py" > $O/${TAG}_fr_host_time.txt
 # 8. the bench records themselves (no profiler attached): <tag>_bench_line.json = the compact stdout line of the contract,
 #    <tag>_bench.json = the detail record bench.py writes next to itself (bench_detail.json)
 python3 $R/bench.py --steps 30 --warmup 5 > $O/${TAG}_bench_line.json 2> /dev/null
