@@ -1679,7 +1679,8 @@ inline size_t layout(int n, void* ws, Layout* L) {
     L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz; L->counter = (unsigned*)counter;
     L->gqueue = (unsigned*)gq; L->redo = (unsigned*)rd; L->qcap = (unsigned)(queue_entries(n) / Q_NREG); L->flags = (uint8_t*)flags;
     // test hook: a tiny capacity forces the redo path of the stream / drain kernels
-    if (g_r3_nms_qcap > 0 && (unsigned)g_r3_nms_qcap < L->qcap) L->qcap = (unsigned)g_r3_nms_qcap;
+    const int qcap_o = g_r3_nms_qcap;  // (one read)
+    if (qcap_o > 0 && (unsigned)qcap_o < L->qcap) L->qcap = (unsigned)qcap_o;
     L->cb = (int)cb;
   }
   return off + 256;
@@ -2423,7 +2424,8 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
     L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->redo = (unsigned*)rd; L->keep = (int64_t*)keep;
     L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->rlab = (uint8_t*)rlab; L->kbits = (u64*)kbits; L->fbits = (u64*)fbits; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
     L->qcap = qcap / Q_NREG; L->qstride = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb;
-    if (g_r3_nms_qcap > 0 && (size_t)g_r3_nms_qcap < L->qcap) L->qcap = (size_t)g_r3_nms_qcap;
+    const int qcap_o = g_r3_nms_qcap;  // (one read)
+    if (qcap_o > 0 && (size_t)qcap_o < L->qcap) L->qcap = (size_t)qcap_o;
   }
   return off + 256;
 }
@@ -2530,8 +2532,9 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   {
     // one reducer workgroup per (image, label group = label mod 16) when the pool is small enough for its LDS; the
     // kernel itself falls back to one workgroup per image when the drain saw an edge between two groups
-    const int groups = (cap <= RG_MAXN && g_r3_nms_impl != 2) ? RG_GROUPS : 1;
-    if (cap <= WALK_MAXN && g_r3_nms_impl == 4) {
+    const int nms_impl = g_r3_nms_impl;  // (one read per call)
+    const int groups = (cap <= RG_MAXN && nms_impl != 2) ? RG_GROUPS : 1;
+    if (cap <= WALK_MAXN && nms_impl == 4) {
       // (round 5, measured and NOT the default: one wavefront per (image, label group) walks its rows in score order --
       // 13.1 us against the round reducer's 9.7 at n = 2000, 54.6 against 16.4 at 8576, 64 against 65 on the random-weight
       // model's own pool (chains 90 deep, 10 % of the rows with > 32 suppressors): a block of 64 rows costs the walk three
