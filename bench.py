@@ -786,10 +786,20 @@ def headline(line, detail_file=DETAIL_FILE):
     if isinstance(out.get("per_rank_ms_per_step"), list) and len(out["per_rank_ms_per_step"]) > 8:
         out["per_rank_ms_per_step"] = out["per_rank_ms_per_step"][:8]
     out["detail_file"] = detail_file
-    text = json.dumps(out, separators=(", ", ": "))
-    if len(text) > HEADLINE_MAX or "\n" in text:
-        raise RuntimeError(f"bench headline is {len(text)} characters (limit {HEADLINE_MAX})")
-    return text
+    # (never lose the line to its own size: shed the free text first, then the per-rank list -- the numbers stay)
+    for shed in (None, ("cpu_baseline", "sample"), ("cpu_baseline", "cpu_model"), ("config", "workload"),
+                 ("per_rank_ms_per_step",), ("metric",)):
+        if shed is not None:
+            if len(shed) == 2 and isinstance(out.get(shed[0]), dict) and shed[1] in out[shed[0]]:
+                out[shed[0]][shed[1]] = _short(out[shed[0]][shed[1]], 40)
+            elif len(shed) == 1 and shed[0] == "per_rank_ms_per_step" and isinstance(out.get(shed[0]), list):
+                out[shed[0]] = out[shed[0]][:2]
+            elif len(shed) == 1 and shed[0] in out:
+                out[shed[0]] = _short(out[shed[0]], 80)
+        text = json.dumps(out, separators=(", ", ": ")).replace("\n", " ")
+        if len(text) <= HEADLINE_MAX:
+            return text
+    return text[:HEADLINE_MAX]  # (unreachable with the fields above; a cut line is still better than none)
 
 
 def write_detail(line, name=DETAIL_FILE):

@@ -93,3 +93,16 @@ def test_the_committed_round_5_record_fits():
     got = json.loads(text)
     assert got["value"] == rec["value"] and got["roofline"]["frac"] == rec["roofline"]["frac"]
     assert got["cpu_baseline"]["value"] == rec["cpu_baseline"]["value"]
+
+
+def test_headline_sheds_text_instead_of_failing():
+    """A record whose short fields are themselves oversized still yields one valid line under the limit, numbers intact."""
+    rec = stub()
+    rec["config"]["workload_short"] = "w" * 3000
+    rec["metric"] = "m" * 3000
+    rec["cpu_baseline"]["cpu_model"] = "c" * 500
+    text = bench.headline(rec)
+    assert len(text) <= 1800 and "\n" not in text
+    got = json.loads(text)
+    assert got["value"] == rec["value"] and got["roofline"]["frac"] == rec["roofline"]["frac"]
+    assert got["cpu_baseline"]["value"] == rec["cpu_baseline"]["value"] and got["ms_per_step"] == rec["ms_per_step"]
