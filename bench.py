@@ -745,6 +745,29 @@ def phase(name):
             sys.stderr.flush()
 
 
+_ERRORS = {}
+
+
+class section:
+    """A part of the run that is NOT the timed region (op rates, the bounded train / rretinanet entries, the CPU baseline):
+    traced like `phase`, and an exception inside is recorded in the detail record (`errors`) instead of costing the run its
+    contract line -- the headline then carries what was measured before it."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        phase(self.name)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and issubclass(et, Exception):
+            _ERRORS[self.name] = repr(ev)[:300]
+            sys.stderr.write(f"[bench] section '{self.name}' failed: {repr(ev)[:200]}\n")
+            return True
+        return False
+
+
 # ------------------------------------------------------------------------------------ the contract line
 HEADLINE_MAX = 1800   # the driver keeps a 2 000-character tail of stdout + stderr; round 5's 22.8 KB line was not parsed
 DETAIL_FILE = "bench_detail.json"
@@ -821,6 +844,8 @@ def write_detail(line, name=DETAIL_FILE):
 def emit(line):
     """Detail to the file, its location (one short line) to stderr, the compact headline as the LAST stdout line."""
     line = dict(line, phases_s=list(_PHASES))
+    if _ERRORS:
+        line["errors"] = dict(_ERRORS)
     paths = write_detail(line)
     text = headline(line)
     sys.stderr.write(f"[bench] detail ({len(json.dumps(line))} B): {', '.join(os.path.relpath(p, ROOT) for p in paths)}\n")
@@ -928,126 +953,126 @@ def main():
     # empty_cache()` and twice met one ~85 ms host-side launch stall right there: tools/hip_trace_slow.py)
     hot, alone_rec, ops = None, None, None
     if rank == 0 and not args.model_only:
-        phase("hot path (custom ops alone)")
-        wl = build_hot_workload(device, seed=7)
-        per, allocs = [], []
-        for i in range(3 + 30):
-            s0 = torch.cuda.memory_stats(device)["num_device_alloc"]
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            hot_path_step(wl)
-            torch.cuda.synchronize()
-            if i >= 3:
-                per.append(time.perf_counter() - t)
-                allocs.append(torch.cuda.memory_stats(device)["num_device_alloc"] - s0)
-        worst = max(range(len(per)), key=lambda i: per[i])
-        srt = sorted(per)
-        dt = srt[len(srt) // 2]
-        hot = {"what": "the custom ops of one R3Det.simple_test step, alone, same shapes (N=4, C=256, channels_last): "
-                       "FeatureRefineModule tail x5 levels (fr_module_nhwc) + refine-head pool x5 levels "
-                       "(r3det_levels_pool, 5344 rows / image) + batched multiclass_nms_rotated (v1)",
-               "ms_per_step": round(dt * 1e3, 3), "img_s": round(BATCH / dt, 1),
-               "ms_per_step_mean": round(sum(per) / len(per) * 1e3, 3), "steps": len(per),
-               "slowest_step": {"index": worst, "ms": round(per[worst] * 1e3, 3), "device_allocs_in_it": allocs[worst]},
-               "measured": "before the model is built",
-               "ms_per_step_spread": spread_stats(per)}
-        # the same step without the host in it: padded NMS result (no count read), wall and device time
-        hot_path_step_sync_free(wl)
-        sf = []
-        for i in range(3 + 15):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
+        with section("hot path (custom ops alone)"):
+            wl = build_hot_workload(device, seed=7)
+            per, allocs = [], []
+            for i in range(3 + 30):
+                s0 = torch.cuda.memory_stats(device)["num_device_alloc"]
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                hot_path_step(wl)
+                torch.cuda.synchronize()
+                if i >= 3:
+                    per.append(time.perf_counter() - t)
+                    allocs.append(torch.cuda.memory_stats(device)["num_device_alloc"] - s0)
+            worst = max(range(len(per)), key=lambda i: per[i])
+            srt = sorted(per)
+            dt = srt[len(srt) // 2]
+            hot = {"what": "the custom ops of one R3Det.simple_test step, alone, same shapes (N=4, C=256, channels_last): "
+                           "FeatureRefineModule tail x5 levels (fr_module_nhwc) + refine-head pool x5 levels "
+                           "(r3det_levels_pool, 5344 rows / image) + batched multiclass_nms_rotated (v1)",
+                   "ms_per_step": round(dt * 1e3, 3), "img_s": round(BATCH / dt, 1),
+                   "ms_per_step_mean": round(sum(per) / len(per) * 1e3, 3), "steps": len(per),
+                   "slowest_step": {"index": worst, "ms": round(per[worst] * 1e3, 3), "device_allocs_in_it": allocs[worst]},
+                   "measured": "before the model is built",
+                   "ms_per_step_spread": spread_stats(per)}
+            # the same step without the host in it: padded NMS result (no count read), wall and device time
             hot_path_step_sync_free(wl)
-            torch.cuda.synchronize()
-            if i >= 3:
-                sf.append(time.perf_counter() - t)
-        hot["sync_free"] = {"what": "the same calls with r3det_mcnms_padded (PaddedNms): nothing reads a count; wall = one "
-                                    "step, launched and waited for; device = GPU time per step with the stream kept busy "
-                                    "while the host enqueues 10 steps (HIP events) -- what the step costs inside the "
-                                    "whole-step graph",
-                            "ms_per_step_wall": spread_stats(sf),
-                            "ms_per_step_device": round(device_time_ms(lambda: hot_path_step_sync_free(wl)), 3)}
-        # ... and as what it is inside GraphedStep: ONE HIP graph, replayed and waited for (wall clock per replay)
-        try:
-            side = torch.cuda.Stream(device=device)
-            side.wait_stream(torch.cuda.current_stream(device))
-            with torch.cuda.stream(side):
-                hot_path_step_sync_free(wl)
-            torch.cuda.current_stream(device).wait_stream(side)
-            torch.cuda.synchronize(device)
-            hg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(hg, capture_error_mode="thread_local"):
-                hot_path_step_sync_free(wl)
-            sg = []
+            sf = []
             for i in range(3 + 15):
                 torch.cuda.synchronize()
                 t = time.perf_counter()
-                hg.replay()
+                hot_path_step_sync_free(wl)
                 torch.cuda.synchronize()
                 if i >= 3:
-                    sg.append(time.perf_counter() - t)
-            hot["sync_free"]["ms_per_step_graph"] = spread_stats(sg)
-            hot["sync_free"]["graph_what"] = ("the same calls captured once in a HIP graph (torch.cuda.CUDAGraph), one replay "
-                                              "launched and waited for per figure: the form the step has inside GraphedStep")
-            del hg
-        except Exception as e:  # (a capture failure must not cost the bench line)
-            hot["sync_free"]["ms_per_step_graph"] = None
-            hot["sync_free"]["graph_error"] = repr(e)[:200]
-        # the roofline kernel alone, rotating over three buffer sets (3 x 268 MB): every launch reads and
-        # writes lines that are NOT in the 256 MiB Infinity Cache -> an HBM figure
-        from r3det.ops.feature_refine import fr_module_nhwc
-        cl = torch.channels_last
-        lv0 = wl["levels"][0]
-        sets = [tuple(torch.randn(lv0["a"].shape, device=device).contiguous(memory_format=cl) for _ in range(4))
-                for _ in range(3)]
-        state = [0]
+                    sf.append(time.perf_counter() - t)
+            hot["sync_free"] = {"what": "the same calls with r3det_mcnms_padded (PaddedNms): nothing reads a count; wall = one "
+                                        "step, launched and waited for; device = GPU time per step with the stream kept busy "
+                                        "while the host enqueues 10 steps (HIP events) -- what the step costs inside the "
+                                        "whole-step graph",
+                                "ms_per_step_wall": spread_stats(sf),
+                                "ms_per_step_device": round(device_time_ms(lambda: hot_path_step_sync_free(wl)), 3)}
+            # ... and as what it is inside GraphedStep: ONE HIP graph, replayed and waited for (wall clock per replay)
+            try:
+                side = torch.cuda.Stream(device=device)
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    hot_path_step_sync_free(wl)
+                torch.cuda.current_stream(device).wait_stream(side)
+                torch.cuda.synchronize(device)
+                hg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(hg, capture_error_mode="thread_local"):
+                    hot_path_step_sync_free(wl)
+                sg = []
+                for i in range(3 + 15):
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    hg.replay()
+                    torch.cuda.synchronize()
+                    if i >= 3:
+                        sg.append(time.perf_counter() - t)
+                hot["sync_free"]["ms_per_step_graph"] = spread_stats(sg)
+                hot["sync_free"]["graph_what"] = ("the same calls captured once in a HIP graph (torch.cuda.CUDAGraph), one replay "
+                                                  "launched and waited for per figure: the form the step has inside GraphedStep")
+                del hg
+            except Exception as e:  # (a capture failure must not cost the bench line)
+                hot["sync_free"]["ms_per_step_graph"] = None
+                hot["sync_free"]["graph_error"] = repr(e)[:200]
+            # the roofline kernel alone, rotating over three buffer sets (3 x 268 MB): every launch reads and
+            # writes lines that are NOT in the 256 MiB Infinity Cache -> an HBM figure
+            from r3det.ops.feature_refine import fr_module_nhwc
+            cl = torch.channels_last
+            lv0 = wl["levels"][0]
+            sets = [tuple(torch.randn(lv0["a"].shape, device=device).contiguous(memory_format=cl) for _ in range(4))
+                    for _ in range(3)]
+            state = [0]
 
-        def rot():
-            a, b, r, o = sets[state[0] % 3]
-            state[0] += 1
-            fr_module_nhwc(a, b, wl["bias"], wl["bias"], r, lv0["boxes"], 1.0 / 8, 1, o)
-        _C.fr_profile_read()
-        _C.set_option("fr_profile", 2)
-        timeit(rot, 20, warm=3)
-        _C.set_option("fr_profile", 0)
-        alone = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
-        if alone:
-            us = sum(r[4] for r in alone) / len(alone)
-            alone_rec = {"avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
-                         "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
-            # The same launch on other box fields: how far the boxes sample from their own cell decides how many tap
-            # rows leave the workgroup's regions (DESIGN_HISTORY 4.3 item 7) -- the headline field is the survey's (centres
-            # jittered by 0.4 cells); "trained": every 4 x 4 block of positions regresses to one centre, what a
-            # trained detector produces around objects; sigma 4: the random-weight bench model's own stage-1 boxes
-            by_field = {"survey_sigma_0.4_cells": {"avg_launch_us": alone_rec["avg_launch_us"], "frac": alone_rec["frac"]}}
-            base = lv0["boxes"]
-            st = 8.0
-            trained = base.clone()
-            g = (base[:, :2] / (4 * st)).floor() * (4 * st) + 2 * st
-            trained[:, :2] = g + torch.randn_like(g) * 0.3 * st
-            far = base.clone()
-            far[:, :2] = base[:, :2] + torch.randn_like(g) * 4 * st
-            for name, bx in (("trained_piles_4x4", trained), ("sigma_4_cells", far)):
-                def rot2():
-                    a, b, r, o = sets[state[0] % 3]
-                    state[0] += 1
-                    fr_module_nhwc(a, b, wl["bias"], wl["bias"], r, bx, 1.0 / 8, 1, o)
-                _C.fr_profile_read()
-                _C.set_option("fr_profile", 2)
-                timeit(rot2, 10, warm=2)
-                _C.set_option("fr_profile", 0)
-                rec = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
-                if rec:
-                    u2 = sum(r[4] for r in rec) / len(rec)
-                    by_field[name] = {"avg_launch_us": round(u2, 2), "frac": round(alg_bytes / u2 / 1e3 / HBM_PEAK_GBS, 4)}
-            alone_rec["by_field"] = by_field
-        del sets, wl
-        if not args.no_ops:
-            phase("op rates")
-            ops = op_rates(device)
-        import gc
-        gc.collect()
-        torch.cuda.empty_cache()
+            def rot():
+                a, b, r, o = sets[state[0] % 3]
+                state[0] += 1
+                fr_module_nhwc(a, b, wl["bias"], wl["bias"], r, lv0["boxes"], 1.0 / 8, 1, o)
+            _C.fr_profile_read()
+            _C.set_option("fr_profile", 2)
+            timeit(rot, 20, warm=3)
+            _C.set_option("fr_profile", 0)
+            alone = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
+            if alone:
+                us = sum(r[4] for r in alone) / len(alone)
+                alone_rec = {"avg_launch_us": round(us, 2), "achieved": round(alg_bytes / us / 1e3, 1),
+                             "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "launches_timed": len(alone)}
+                # The same launch on other box fields: how far the boxes sample from their own cell decides how many tap
+                # rows leave the workgroup's regions (DESIGN_HISTORY 4.3 item 7) -- the headline field is the survey's (centres
+                # jittered by 0.4 cells); "trained": every 4 x 4 block of positions regresses to one centre, what a
+                # trained detector produces around objects; sigma 4: the random-weight bench model's own stage-1 boxes
+                by_field = {"survey_sigma_0.4_cells": {"avg_launch_us": alone_rec["avg_launch_us"], "frac": alone_rec["frac"]}}
+                base = lv0["boxes"]
+                st = 8.0
+                trained = base.clone()
+                g = (base[:, :2] / (4 * st)).floor() * (4 * st) + 2 * st
+                trained[:, :2] = g + torch.randn_like(g) * 0.3 * st
+                far = base.clone()
+                far[:, :2] = base[:, :2] + torch.randn_like(g) * 4 * st
+                for name, bx in (("trained_piles_4x4", trained), ("sigma_4_cells", far)):
+                    def rot2():
+                        a, b, r, o = sets[state[0] % 3]
+                        state[0] += 1
+                        fr_module_nhwc(a, b, wl["bias"], wl["bias"], r, bx, 1.0 / 8, 1, o)
+                    _C.fr_profile_read()
+                    _C.set_option("fr_profile", 2)
+                    timeit(rot2, 10, warm=2)
+                    _C.set_option("fr_profile", 0)
+                    rec = [r for r in _C.fr_profile_read() if r[0] == BATCH and r[1] == 128]
+                    if rec:
+                        u2 = sum(r[4] for r in rec) / len(rec)
+                        by_field[name] = {"avg_launch_us": round(u2, 2), "frac": round(alg_bytes / u2 / 1e3 / HBM_PEAK_GBS, 4)}
+                alone_rec["by_field"] = by_field
+            del sets, wl
+            if not args.no_ops:
+                phase("op rates")
+                ops = op_rates(device)
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
 
     phase("infer: build + calibrate")
     model, img = build_model(device, seed=100 + rank)
@@ -1145,32 +1170,32 @@ def main():
                 "candidate_capacity": None if whole is None else whole.g.nms.cap},
         })
         if whole is not None and not args.model_only:
-            phase("infer: the two candidate pools")
+            with section("infer: the two candidate pools"):
 
-            def pool_record(ws, ms):
-                boxes, scores = ws.g.model.dense_test(ws.g.static_in)
-                boxes, scores = boxes.contiguous(), scores.contiguous()
-                per_class = (scores[..., :-1] > SCORE_THR).sum((0, 1)).float()
-                nms_ms = device_time_ms(lambda: ws.g.nms(boxes, scores))
-                return {"ms_per_step": round(ms, 3), "img_s": round(BATCH / ms * 1e3, 2),
-                        "candidates_per_image": int(per_class.sum().item() / BATCH),
-                        "largest_class_share": round(float(per_class.max() / per_class.sum().clamp(min=1)), 3),
-                        "kept_per_image": ws.counts(),
-                        "nms_device_us": round(nms_ms * 1e3, 1)}
-            by_pool = {"what": "the same step on the two calibrations of the random-weight model's score bias; "
-                               "nms_device_us = r3det_mcnms_select + r3det_mcnms_padded on the step's own pool, GPU time "
-                               "with the queue kept full (no host in it)",
-                       "spread_15_classes": dict(pool_record(whole, elapsed / args.steps * 1e3),
-                                                 note="the headline: one bias shift per class, equal shares (SURVEY 8d)")}
-            if world == 1:
-                m1, i1 = build_model(device, seed=100 + rank, spread=False)
-                w1 = WholeStep(m1, i1)
-                e1, _, _ = timed_region(w1, side, device, di)
-                by_pool["one_label"] = dict(pool_record(w1, e1 / side.steps * 1e3),
-                                            note="rounds 1-4's pool: ONE common shift (bounded: "
-                                                 f"{side.steps} steps)")
-                del m1, i1, w1
-            line["by_pool"] = by_pool
+                def pool_record(ws, ms):
+                    boxes, scores = ws.g.model.dense_test(ws.g.static_in)
+                    boxes, scores = boxes.contiguous(), scores.contiguous()
+                    per_class = (scores[..., :-1] > SCORE_THR).sum((0, 1)).float()
+                    nms_ms = device_time_ms(lambda: ws.g.nms(boxes, scores))
+                    return {"ms_per_step": round(ms, 3), "img_s": round(BATCH / ms * 1e3, 2),
+                            "candidates_per_image": int(per_class.sum().item() / BATCH),
+                            "largest_class_share": round(float(per_class.max() / per_class.sum().clamp(min=1)), 3),
+                            "kept_per_image": ws.counts(),
+                            "nms_device_us": round(nms_ms * 1e3, 1)}
+                by_pool = {"what": "the same step on the two calibrations of the random-weight model's score bias; "
+                                   "nms_device_us = r3det_mcnms_select + r3det_mcnms_padded on the step's own pool, GPU time "
+                                   "with the queue kept full (no host in it)",
+                           "spread_15_classes": dict(pool_record(whole, elapsed / args.steps * 1e3),
+                                                     note="the headline: one bias shift per class, equal shares (SURVEY 8d)")}
+                if world == 1:
+                    m1, i1 = build_model(device, seed=100 + rank, spread=False)
+                    w1 = WholeStep(m1, i1)
+                    e1, _, _ = timed_region(w1, side, device, di)
+                    by_pool["one_label"] = dict(pool_record(w1, e1 / side.steps * 1e3),
+                                                note="rounds 1-4's pool: ONE common shift (bounded: "
+                                                     f"{side.steps} steps)")
+                    del m1, i1, w1
+                line["by_pool"] = by_pool
         if hot is not None:
             line["hot_path"] = hot
         if ops is not None:
@@ -1182,50 +1207,50 @@ def main():
         if world == 1 and not args.no_extras:
             torch.cuda.empty_cache()
             ex = argparse.Namespace(steps=5, warmup=3)
-            phase("extra: rretinanet (configs[1])")
-            m2, i2 = build_model(device, 200, "RRetinaNet", RRETINA_BATCH)
-            w2 = WholeStep(m2, i2)
-            e2, _, _ = timed_region(w2, ex, device, di)
-            c2 = torch.tensor(w2.counts())
-            ee2, _, _ = timed_region(lambda: model_step(m2, i2), ex, device, di)
-            line["rretinanet"] = {"workload": "BASELINE configs[1]: rretinanet_obb_r50_fpn v1, batch=2 x 1024x1024, "
-                                              "inference, 8576-box pools per image, nms v1 (bounded: 5 steps; --mode "
-                                              "rretinanet times it as the main region)",
-                                  "img_s": round(RRETINA_BATCH * ex.steps / e2, 2),
-                                  "ms_per_step": round(e2 / ex.steps * 1e3, 3),
-                                  "ms_per_step_eager": round(ee2 / ex.steps * 1e3, 3),
-                                  "timed_step": "the whole step as one HIP graph + gather_padded (as the headline)",
-                                  "kept_per_image": [int(c) for c in c2.tolist()]}
-            del m2, i2, w2
-            torch.cuda.empty_cache()
-            phase("extra: train (configs[4])")
-            tr = build_train(device, 300, 1)
-            e3, _, loss = timed_region(lambda: train_step(tr), ex, device, di)
-            ta, tf = train_custom_op_ms(tr, device)
-            ms3 = e3 / ex.steps * 1e3
-            line["train"] = {"workload": "BASELINE configs[4] on one GPU: r3det_r50_fpn_1x v1 training step, batch=2 x "
-                                         "1024x1024, 128 GT per image (bounded: 5 steps; --mode train times it as the main "
-                                         "region, with DDP at N > 1)",
-                             "img_s": round(TRAIN_BATCH * ex.steps / e3, 2), "ms_per_step": round(ms3, 3),
-                             "final_loss": round(float(loss), 4),
-                             "layout": "channels_last" if TRAIN_CHANNELS_LAST else "NCHW",
-                             "custom_ops_isolated": {"assign_ms": round(ta, 3), "fr_fwd_bwd_ms": round(tf, 3),
-                                                     "share_of_step": round((ta + tf) / ms3, 4),
-                                                     "detail": getattr(train_custom_op_ms, "detail", None)}}
-            del tr
-            torch.cuda.empty_cache()
-            # the same step in the other layout (3 steps): channels_last runs the FR sampler + backward on NHWC memory
-            tr = build_train(device, 300, 1, channels_last=not TRAIN_CHANNELS_LAST)
-            ex3 = argparse.Namespace(steps=3, warmup=2)
-            e4, _, _ = timed_region(lambda: train_step(tr), ex3, device, di)
-            _, tf4 = train_custom_op_ms(tr, device)
-            line["train"]["other_layout"] = {"layout": "NCHW" if TRAIN_CHANNELS_LAST else "channels_last",
-                                             "ms_per_step": round(e4 / ex3.steps * 1e3, 3),
-                                             "fr_fwd_bwd_ms_isolated": round(tf4, 3)}
-            del tr
+            with section("extra: rretinanet (configs[1])"):
+                m2, i2 = build_model(device, 200, "RRetinaNet", RRETINA_BATCH)
+                w2 = WholeStep(m2, i2)
+                e2, _, _ = timed_region(w2, ex, device, di)
+                c2 = torch.tensor(w2.counts())
+                ee2, _, _ = timed_region(lambda: model_step(m2, i2), ex, device, di)
+                line["rretinanet"] = {"workload": "BASELINE configs[1]: rretinanet_obb_r50_fpn v1, batch=2 x 1024x1024, "
+                                                  "inference, 8576-box pools per image, nms v1 (bounded: 5 steps; --mode "
+                                                  "rretinanet times it as the main region)",
+                                      "img_s": round(RRETINA_BATCH * ex.steps / e2, 2),
+                                      "ms_per_step": round(e2 / ex.steps * 1e3, 3),
+                                      "ms_per_step_eager": round(ee2 / ex.steps * 1e3, 3),
+                                      "timed_step": "the whole step as one HIP graph + gather_padded (as the headline)",
+                                      "kept_per_image": [int(c) for c in c2.tolist()]}
+                del m2, i2, w2
+                torch.cuda.empty_cache()
+            with section("extra: train (configs[4])"):
+                tr = build_train(device, 300, 1)
+                e3, _, loss = timed_region(lambda: train_step(tr), ex, device, di)
+                ta, tf = train_custom_op_ms(tr, device)
+                ms3 = e3 / ex.steps * 1e3
+                line["train"] = {"workload": "BASELINE configs[4] on one GPU: r3det_r50_fpn_1x v1 training step, batch=2 x "
+                                             "1024x1024, 128 GT per image (bounded: 5 steps; --mode train times it as the main "
+                                             "region, with DDP at N > 1)",
+                                 "img_s": round(TRAIN_BATCH * ex.steps / e3, 2), "ms_per_step": round(ms3, 3),
+                                 "final_loss": round(float(loss), 4),
+                                 "layout": "channels_last" if TRAIN_CHANNELS_LAST else "NCHW",
+                                 "custom_ops_isolated": {"assign_ms": round(ta, 3), "fr_fwd_bwd_ms": round(tf, 3),
+                                                         "share_of_step": round((ta + tf) / ms3, 4),
+                                                         "detail": getattr(train_custom_op_ms, "detail", None)}}
+                del tr
+                torch.cuda.empty_cache()
+                # the same step in the other layout (3 steps): channels_last runs the FR sampler + backward on NHWC memory
+                tr = build_train(device, 300, 1, channels_last=not TRAIN_CHANNELS_LAST)
+                ex3 = argparse.Namespace(steps=3, warmup=2)
+                e4, _, _ = timed_region(lambda: train_step(tr), ex3, device, di)
+                _, tf4 = train_custom_op_ms(tr, device)
+                line["train"]["other_layout"] = {"layout": "NCHW" if TRAIN_CHANNELS_LAST else "channels_last",
+                                                 "ms_per_step": round(e4 / ex3.steps * 1e3, 3),
+                                                 "fr_fwd_bwd_ms_isolated": round(tf4, 3)}
+                del tr
         if world == 1 and not args.no_cpu_baseline:
-            phase("cpu baseline")
-            line["cpu_baseline"] = cpu_baseline()
+            with section("cpu baseline"):
+                line["cpu_baseline"] = cpu_baseline()
         phase("done")
         emit(line)
     if world > 1:

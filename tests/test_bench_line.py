@@ -106,3 +106,25 @@ def test_headline_sheds_text_instead_of_failing():
     got = json.loads(text)
     assert got["value"] == rec["value"] and got["roofline"]["frac"] == rec["roofline"]["frac"]
     assert got["cpu_baseline"]["value"] == rec["cpu_baseline"]["value"] and got["ms_per_step"] == rec["ms_per_step"]
+
+
+def test_a_failing_side_section_does_not_cost_the_line(tmp_path, monkeypatch, capsys):
+    """op rates, the bounded train / rretinanet entries and the CPU baseline run inside `section`: an exception there is
+    recorded in the detail record and the headline still goes out with what was measured."""
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "_ERRORS", {})
+    rec = stub()
+    del rec["cpu_baseline"]
+    with bench.section("cpu baseline"):
+        raise RuntimeError("oracle library missing")
+    with bench.section("fine"):
+        rec["rretinanet"] = {"img_s": 1.0}
+    bench.emit(rec)
+    cap = capsys.readouterr()
+    got = json.loads(cap.out.splitlines()[-1])
+    assert got["value"] == rec["value"] and "roofline" in got and "cpu_baseline" not in got
+    full = json.load(open(tmp_path / bench.DETAIL_FILE))
+    assert list(full["errors"]) == ["cpu baseline"] and "oracle library missing" in full["errors"]["cpu baseline"]
+    with pytest.raises(KeyboardInterrupt):          # only Exceptions are swallowed
+        with bench.section("interrupted"):
+            raise KeyboardInterrupt
