@@ -429,6 +429,12 @@ def op_rates(device):
                                  "alg_bytes": b_nms(k),
                                  "what": f"{fn.__name__} (15 classes) incl. its host read of the count",
                                  "roofline": _roof(b_nms(k), dt, "hbm (latency-bound in practice)")}
+        # the same library call without the host read of the count (r3det.ops.nms.batched_rnms_padded): back-to-back
+        # calls keep the queue full, so this is the call's GPU time + launch gaps -- what it costs inside a pipeline
+        from r3det.ops.nms import batched_rnms_padded
+        if batched_rnms_padded(b, s, l, 0.1, version=tag) is not None:
+            dtp = timeit(lambda: batched_rnms_padded(b, s, l, 0.1, version=tag), 10)
+            out[f"nms_{tag}_{k}"]["us_per_call_padded"] = round(dtp * 1e6, 1)
     out.update(pool_rates(device))
     out.update(fr_rates(device))
     return out

@@ -168,7 +168,7 @@ _RNMS_WS = {}
 FAST_MAX_N = 32768
 
 
-def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry="r3det_batched_rnms"):
+def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry="r3det_batched_rnms", padded=False):
     """The same result from ONE library call (r3det_batched_rnms: candidate arrays and the wrapper's bboxes.max()
     from one small kernel, stable score sort by counting, class offsets, suppression, ascending keep and the gather
     on the device) instead of arange / zeros / max / mul / clone / add / cat / sort / rnms / index launches.  None
@@ -198,8 +198,20 @@ def _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry="r
         _C.check(getattr(L, entry)(_C.ptr(b), _C.ptr(sc), _C.ptr(lab) if lab is not None else None, n,
                                    float(nms_thr), _C.ptr(ws), ws_bytes, _C.ptr(dets), _C.ptr(keep), _C.ptr(kept),
                                    _C.stream()), entry)
+        if padded:  # (no host read: the caller slices by ``kept`` when it next touches the host)
+            return dets, keep, kept
         k = int(kept.item())
     return dets[:k], keep[:k]
+
+
+def batched_rnms_padded(bboxes, scores, inds, nms_thr, class_agnostic=False, version='v1'):
+    """``batched_rnms`` / ``obb_batched_nms`` (rnms_wrapper.py:34-69, nms_rotated_wrapper.py:78-98) WITHOUT the host read of
+    the count: -> ``(dets (n, 6), keep (n,), kept (1,) int32)`` -- rows ``[:kept]`` of ``dets`` / ``keep`` are the
+    reference's return values, the rest is unspecified.  The one library call of the list form, enqueued and returned:
+    for pipelines that consume the result on the device (the padded multiclass form, a HIP graph).  None when the input
+    does not qualify for the one-call form."""
+    entry = {"v1": "r3det_batched_rnms", "v3": "r3det_obb_batched_nms"}[version]
+    return _batched_rnms_device(bboxes, scores, inds, nms_thr, class_agnostic, entry=entry, padded=True)
 
 
 def obb2hbb(obboxes):

@@ -363,3 +363,21 @@ def test_one_call_form_at_32768_rows_exact_vs_the_twin_oracle():
     assert 5000 < keep.numel() < 20000
     assert np.array_equal(keep.cpu().numpy(), want)
     assert torch.equal(dets[:, :5], tb[keep]) and torch.equal(dets[:, 5], ts[keep])
+
+
+@pytest.mark.parametrize("version", ["v1", "v3"])
+def test_padded_one_pool_form_equals_the_list_form(version):
+    """batched_rnms_padded: the one library call of batched_rnms / obb_batched_nms without the host read of the count --
+    rows [:kept] are the list form's return values (rnms_wrapper.py:34-69, nms_rotated_wrapper.py:78-98)."""
+    import r3det.ops.nms as M
+    from r3det.ops import batched_rnms, obb_batched_nms
+    n = 3000
+    b = torch.from_numpy(rand_boxes(n, 7, span=700.0)).cuda()
+    g = torch.Generator().manual_seed(2)
+    s = torch.rand(n, generator=g).cuda()
+    lab = torch.randint(0, 15, (n,), generator=g).cuda()
+    dets, keep, kept = M.batched_rnms_padded(b, s, lab, 0.1, version=version)
+    want_d, want_k = (batched_rnms if version == "v1" else obb_batched_nms)(b, s, lab, 0.1)
+    k = int(kept.item())
+    assert k == want_k.numel() and dets.shape == (n, 6) and keep.shape == (n,)
+    assert torch.equal(keep[:k], want_k) and torch.equal(dets[:k], want_d)
