@@ -135,8 +135,12 @@ int r3det_obb_overlaps(const float* b1, int n1, const float* b2, int n2, int iou
                        size_t ws_bytes, void* stream) {
   const DeviceGuard guard(stream);
   if (bad_iou_args(b1, n1, b2, n2, out)) return R3DET_EINVAL;
-  const int r = r3k_iou_mat(R3DET_GEOM_V3, iou_or_iof == 0, b1, n1, b2, n2, out, ws, ws_bytes, S(stream));
+  // (round 6: the stream + drain pipeline applies the thin-box rule itself -- a thin row is skipped, a thin column never
+  // survives -- and the epilogue launch is only needed behind the one-launch forms of narrow matrices)
+  int thin_done = 0;
+  const int r = r3k_iou_mat(R3DET_GEOM_V3, iou_or_iof == 0, b1, n1, b2, n2, out, ws, ws_bytes, S(stream), nullptr, &thin_done);
   if (r) return rc(r);
+  if (thin_done) return R3DET_OK;
   return rc(r3k_iou_zero_thin(b1, n1, b2, n2, out, S(stream)));
 }
 

@@ -509,6 +509,15 @@ struct AssignZero {
 // the lane's 8 x 4 elements SURVIVED (bit 4 r + c of bits[tile * 256 + tid]; a dense tile: all ones).  The zeros are
 // then written by the drain launch's fill blocks, which skip exactly those elements: fill and clip write disjoint
 // addresses and can share one launch with no ordering between them.
+// obb_overlaps' rule (box_iou_rotated_wrapper.py:53-60): a box with min(w, h) < 1e-3 has an all-zero row / column.
+// torch.min propagates NaN and NaN < 1e-3 is false: a box with a NaN side is not thin.
+__device__ __forceinline__ bool iou_thin_box(const float w, const float h) {
+  return !(w != w || h != h) && fminf(w, h) < 0.001f;
+}
+
+// thin (GEOM 3, round 6): obb_overlaps' epilogue inside the pipeline -- a thin row is skipped, a thin column never
+// survives, so their elements keep the tile's zeros and the separate epilogue launch (4.7 us at 128 x 196 416) is not
+// needed; the drain applies the same rule to the pairs of a dense tile, which it enumerates itself.
 template <int GEOM, bool VEC, bool PREP = false, bool BITS = false>
 __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __restrict__ b1, int n1,
                                                                 const float* __restrict__ b2, int n2,
@@ -517,7 +526,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
                                                                 unsigned short* __restrict__ slots, int wcap,
                                                                 const ColPrep prep = ColPrep(), const int probe = 0, const int order = -1,
                                                                 const AssignZero az = AssignZero(),
-                                                                unsigned* __restrict__ bits = nullptr) {
+                                                                unsigned* __restrict__ bits = nullptr, const int thin = 0) {
   // (probe: probes build only, tools/iou_stream_phases.sh -- 1 leave after the zeros, 2 after the prologue, 3 before the
   // queue flush: what each part of the kernel adds to the plain fill)
   __shared__ __attribute__((aligned(16))) float rows[P_ROWS][12];  // cx, cy, rad, ex, ey, -, -, -, cx - ex, cx + ex, cy - ey, cy + ey
@@ -647,6 +656,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
       cx[c] = raw[c * 5];
       cy[c] = raw[c * 5 + 1];
       reject_data(cx[c], cy[c], raw[c * 5 + 2], raw[c * 5 + 3], raw[c * 5 + 4], cr[c], cex[c], cey[c]);
+      if (GEOM == 3 && thin) cvalid[c] = cvalid[c] && !iou_thin_box(raw[c * 5 + 2], raw[c * 5 + 3]);
     }
   }
   // Bounding box of this LANE's 4 columns (inflated extents included).  Anchors and refined boxes come in spatial
@@ -671,6 +681,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
     float rad, ex, ey;
     reject_data(rowraw[0], rowraw[1], rowraw[2], rowraw[3], rowraw[4], rad, ex, ey);
     rows[tid][0] = rowraw[0]; rows[tid][1] = rowraw[1]; rows[tid][2] = rad; rows[tid][3] = ex; rows[tid][4] = ey;
+    if (GEOM == 3) rows[tid][5] = (thin && iou_thin_box(rowraw[2], rowraw[3])) ? 1.f : 0.f;
     rows[tid][8] = rowraw[0] - ex; rows[tid][9] = rowraw[0] + ex; rows[tid][10] = rowraw[1] - ey; rows[tid][11] = rowraw[1] + ey;
   }
   // the exact row records for the drain kernel: written once, by the middle column tile's workgroups
@@ -692,6 +703,7 @@ __global__ __launch_bounds__(T_THREADS) void iou_stream3_kernel(const float* __r
   }
   for (int r = 0; r < nrows; r++) {
     const float* A = rows[r];
+    if (GEOM == 3 && A[5] != 0.f) continue;  // (a thin row: uniform)
     const float4 ab = *reinterpret_cast<const float4*>(A + 8);
     if (__builtin_amdgcn_ballot_w64(fin & ((ab.x > bx1) | (ab.y < bx0) | (ab.z > by1) | (ab.w < by0))) == ~0ULL) continue;
     const float ax = A[0], ay = A[1], ar = A[2], aex = A[3], aey = A[4];
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(T_THREADS, FAST ? (GEOM == 3 ? R3_DRAIN3_V3_WAVES :
                                                                unsigned long long* __restrict__ stamps = nullptr,
                                                                const AssignOut ao = AssignOut(), const int dyn = 0,
                                                                const unsigned* __restrict__ bits = nullptr,
-                                                               const int nfill = 0) {
+                                                               const int nfill = 0, const int thin = 0) {
   // (probes build, tools/iou_drain_stamps.py: wave 0 of every workgroup stamps its phases with the 100 MHz clock)
 #ifdef R3_PROBES
 #define R3_DSTAMP(k)                                                                             \
@@ -990,7 +1002,10 @@ __global__ __launch_bounds__(T_THREADS, FAST ? (GEOM == 3 ? R3_DRAIN3_V3_WAVES :
       if ((trips & 0xffff) == 0) { R3_DSTAMP(3) }
       float v = 0.f;
       // a dense tile's pairs were never tested with exact records: do it here (apart => 0, as in every form)
-      if (!(dense && boxes_apart(A.f, B.f))) {
+      bool dead = dense && boxes_apart(A.f, B.f);
+      if (GEOM == 3 && dense && thin && !dead)  // (obb_overlaps' thin rows / columns inside a dense tile)
+        dead = iou_thin_box(b1[(size_t)r * 5 + 2], b1[(size_t)r * 5 + 3]) || iou_thin_box(b2[(size_t)c * 5 + 2], b2[(size_t)c * 5 + 3]);
+      if (!dead) {
         const LanePts<64> lp{pts + wave * (64 * CAPS) + lane};  // wave-private [slot][lane] region
         if constexpr (GEOM == 1 && FAST) v = v1_clip_fast(A.f, B.f, iof != 0, ClipLds<64>{pts + wave * (64 * CAPS) + lane}, over);
         else if constexpr (GEOM == 1) v = v1_pair_lds<64, CAPS>(A.f, B.f, iof != 0, lp, &over);
@@ -1330,7 +1345,9 @@ void launch_compact(bool vec, int iof, const float* b1, int n1, const float* b2,
 
 template <int GEOM>
 int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float* out, void* ws,
-               size_t ws_bytes, hipStream_t stream, const void* prepared = nullptr) {
+               size_t ws_bytes, hipStream_t stream, const void* prepared = nullptr, int* thin_done = nullptr) {
+  // thin_done (GEOM 3): the caller wants obb_overlaps' thin-box rule; set to 1 when this launch applied it itself (the
+  // pipeline on plain columns), left 0 when the caller still has to run the epilogue kernel
   const bool vec = (n2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   // (every switch is read ONCE per call -- a concurrent r3det_set_option cannot pair one form's grid with
   // the other form's kernel)
@@ -1370,6 +1387,8 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
   const int maxb = dwgs > 0 ? dwgs : fast ? 4 * r3_cu_count() : 1536;
   if (blocks > maxb) blocks = maxb;
   if (!vec) prepared = nullptr;  // (the buffer is read only behind the stream kernel that checks its header: the VEC form)
+  const int thin = (GEOM == 3 && thin_done && !prepared) ? 1 : 0;  // (prepared columns carry no widths: the epilogue stays)
+  if (thin) *thin_done = 1;
   ColPrep P = ColPrep();
   if (prepared) colprep_layout(n2, prepared, &P);
   const int sorder = (int)g_r3_iou_order;
@@ -1387,10 +1406,10 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
                          (float*)nullptr, L.recsA, L.tcount, L.slots, wcap, P, 0, -1, AssignZero(), L.bits);
     else
       hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true, false, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2,
-                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap, P, 0, -1, AssignZero(), L.bits);
+                         (float*)nullptr, L.recsA, L.tcount, L.slots, wcap, P, 0, -1, AssignZero(), L.bits, thin);
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, true, false, true>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2,
                        iof, L.recsA, L.tcount, L.slots, L.tiles_x, (int)tiles, out,
-                       prepared ? P.rec : (const BoxRec*)nullptr, dstamps, AssignOut(), 1, L.bits, nfill);
+                       prepared ? P.rec : (const BoxRec*)nullptr, dstamps, AssignOut(), 1, L.bits, nfill, thin);
     return 0;
   }
   if (vec && prepared)
@@ -1398,18 +1417,18 @@ int launch_mat(int iof, const float* b1, int n1, const float* b2, int n2, float*
                        L.tcount, L.slots, wcap, P, sprobe, sorder);
   else if (vec)
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, true>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
-                       L.tcount, L.slots, wcap, P, sprobe, sorder);
+                       L.tcount, L.slots, wcap, P, sprobe, sorder, AssignZero(), (unsigned*)nullptr, thin);
   else
     hipLaunchKernelGGL((iou_stream3_kernel<GEOM, false>), grid, dim3(T_THREADS), 0, stream, b1, n1, b2, n2, out, L.recsA,
-                       L.tcount, L.slots, wcap, P, sprobe, sorder);
+                       L.tcount, L.slots, wcap, P, sprobe, sorder, AssignZero(), (unsigned*)nullptr, thin);
   if (fast)
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, true>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
                        L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps, AssignOut(),
-                       (int)g_r3_iou_dyn);
+                       (int)g_r3_iou_dyn, (const unsigned*)nullptr, 0, thin);
   else
     hipLaunchKernelGGL((iou_drain3_kernel<GEOM, false>), dim3(blocks), dim3(T_THREADS), 0, stream, b1, n1, b2, n2, iof, L.recsA,
                        L.tcount, L.slots, L.tiles_x, (int)tiles, out, prepared ? P.rec : (const BoxRec*)nullptr, dstamps, AssignOut(),
-                       (int)g_r3_iou_dyn);
+                       (int)g_r3_iou_dyn, (const unsigned*)nullptr, 0, thin);
   return 0;
 }
 
@@ -1457,13 +1476,14 @@ size_t r3k_iou_workspace_bytes(int n1, int n2) {
 }
 
 int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
-                void* ws, size_t ws_bytes, hipStream_t stream, const void* prepared) {
+                void* ws, size_t ws_bytes, hipStream_t stream, const void* prepared, int* thin_done) {
+  if (thin_done) *thin_done = 0;
   if (n1 == 0 || n2 == 0) return 0;
   int rc;
   switch (geom) {
     case 1: rc = launch_mat<1>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream, prepared); break;
     case 2: rc = launch_mat<2>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream, prepared); break;
-    case 3: rc = launch_mat<3>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream, prepared); break;
+    case 3: rc = launch_mat<3>(iof, b1, n1, b2, n2, out, ws, ws_bytes, stream, prepared, thin_done); break;
     default: return -1;
   }
   if (rc) return rc;

@@ -65,7 +65,8 @@ size_t r3k_iou_workspace_bytes(int n1, int n2);
 // ws may be null (single-kernel path); with a workspace the stream + drain pipeline runs
 // prepared: r3k_iou_prepare_columns of b2 for this geom (or null)
 int r3k_iou_mat(int geom, int iof, const float* b1, int n1, const float* b2, int n2, float* out,
-                void* ws, size_t ws_bytes, hipStream_t stream, const void* prepared = nullptr);
+                void* ws, size_t ws_bytes, hipStream_t stream, const void* prepared = nullptr,
+                int* thin_done = nullptr);  // thin_done (geom 3): apply obb_overlaps' thin-box rule in the launch where it can; 1 = done
 size_t r3k_iou_prepared_bytes(int n2);
 int r3k_iou_prepare_columns(int geom, const float* b2, int n2, void* prepared, size_t bytes, hipStream_t stream);
 // obb_overlaps' epilogue: zero the rows / columns of boxes with min(w, h) < 1e-3

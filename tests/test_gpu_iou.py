@@ -218,9 +218,10 @@ def test_calculators_and_wrapper_quirks():
     assert obb_overlaps(dev(a)[:0], dev(b)).shape == (0, 77)
 
 
-@pytest.mark.parametrize("shape", [(300, 77), (40, 5000), (3, 1), (130, 2100)])
+@pytest.mark.parametrize("shape", [(300, 77), (40, 5000), (3, 1), (130, 2100), (64, 4096)])
 @pytest.mark.parametrize("mode", ["iou", "iof"])
-def test_obb_overlaps_epilogue_in_the_library(shape, mode):
+@pytest.mark.parametrize("qcap", [0, 100], ids=["queued", "dense-tiles"])
+def test_obb_overlaps_epilogue_in_the_library(shape, mode, qcap):
     """r3det_obb_overlaps = the v3 matrix + `outputs[too_small] = 0` (box_iou_rotated_wrapper.py:53-60) in the same
     call: equal to the matrix entry followed by the reference's torch epilogue -- several thin lines per wave,
     the first and last line, a NaN side (torch.min propagates it: not thin), zero and negative sides, every matrix
@@ -241,8 +242,21 @@ def test_obb_overlaps_epilogue_in_the_library(shape, mode):
     s2 = tb[:, 2:4].min(1)[0] < 0.001
     assert int(s1.sum()) >= 1 and int(s2.sum()) >= 1 and (n1 <= 10 or (not bool(s1[7]) and not bool(s1[9])))
     want = want.masked_fill(s1[:, None] | s2[None, :], 0.)
-    got = obb_overlaps(ta, tb, mode=mode)
-    assert same(got.cpu().numpy(), want.cpu().numpy())
+    # (round 6: the stream + drain pipeline applies the rule itself -- thin rows skipped, thin columns never survive, the
+    # pairs of a tile marked dense checked by the drain -- and only the one-launch forms are followed by the epilogue
+    # kernel; iou_qcap 100 marks every tile with a fuller wave dense; the result buffer holds NaNs before the call)
+    from r3det import _C
+    _C.set_option("iou_qcap", qcap)
+    try:
+        for impl in (0, 5):
+            _C.set_option("iou_impl", impl)
+            poison = torch.full((n1, n2), float('nan'), device='cuda')
+            del poison
+            got = obb_overlaps(ta, tb, mode=mode)
+            assert same(got.cpu().numpy(), want.cpu().numpy()), impl
+    finally:
+        _C.set_option("iou_qcap", 0)
+        _C.set_option("iou_impl", 0)
 
 
 def test_errors():

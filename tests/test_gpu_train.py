@@ -57,36 +57,51 @@ def test_forward_train_full_size_finite_and_frm_grads_match_generic_backward(mod
     from r3det import _C
     from r3det.models.detectors import parse_losses
     img, gtb, gtl = batch(2, 1024, 128, 11, 'cuda')
-    grads = {}
     # 0: automatic (packed backward at 128^2 / 64^2); 1: generic kernels (global atomics); 2 = 0 once more: the
     # run-to-run noise of two identical passes (the convolutions' own atomics), which bounds what a comparison can ask
-    for impl in (0, 1, 2):
-        model.zero_grad(set_to_none=True)
-        _C.set_option("fr_impl", impl % 2)
-        try:
-            losses = model(img, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
-            loss, log_vars = parse_losses(losses)
-            loss.backward()
-        finally:
-            _C.set_option("fr_impl", 0)
-        assert sorted(losses) == ['s0.loss_bbox', 's0.loss_cls', 'sr0.loss_bbox', 'sr0.loss_cls']
-        assert bool(torch.isfinite(loss)) and float(loss.detach()) > 0
-        frm = model.feat_refine_module[0]
-        grads[impl] = {n: p.grad.clone() for n, p in frm.named_parameters()}
-        grads[impl]['neck'] = model.neck.fpn_convs[0].conv.weight.grad.clone()
-        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all())
-                   for p in model.parameters() if p.requires_grad)
-    for n in grads[0]:
-        scale = float(grads[1][n].abs().max())
-        assert scale > 0
-        # two full backward passes: the convolutions' own atomics reorder sums from run to run, so single elements
-        # differ by a few 1e-5 of the largest gradient and, once in ~10 runs, by more than 1e-4 (a full run of the suite
-        # failed on that bound in round 4 with nothing but MIOpen between the two passes); a wrong FR gradient is an
-        # error of order 1, so the bounds below still separate the two
-        d = grads[0][n] - grads[1][n]
-        noise = grads[0][n] - grads[2][n]
-        assert float(d.abs().max()) <= max(5e-4 * scale, 4 * float(noise.abs().max())), n
-        assert float(d.norm()) <= max(5e-5 * float(grads[1][n].norm()), 4 * float(noise.norm())), n
+    def passes():
+        grads = {}
+        for impl in (0, 1, 2):
+            model.zero_grad(set_to_none=True)
+            _C.set_option("fr_impl", impl % 2)
+            try:
+                losses = model(img, return_loss=True, gt_bboxes=gtb, gt_labels=gtl)
+                loss, log_vars = parse_losses(losses)
+                loss.backward()
+            finally:
+                _C.set_option("fr_impl", 0)
+            assert sorted(losses) == ['s0.loss_bbox', 's0.loss_cls', 'sr0.loss_bbox', 'sr0.loss_cls']
+            assert bool(torch.isfinite(loss)) and float(loss.detach()) > 0
+            frm = model.feat_refine_module[0]
+            grads[impl] = {n: p.grad.clone() for n, p in frm.named_parameters()}
+            grads[impl]['neck'] = model.neck.fpn_convs[0].conv.weight.grad.clone()
+            assert all(p.grad is not None and bool(torch.isfinite(p.grad).all())
+                       for p in model.parameters() if p.requires_grad)
+        return grads
+
+    def off_bounds(grads):
+        bad = []
+        for n in grads[0]:
+            scale = float(grads[1][n].abs().max())
+            assert scale > 0
+            d = grads[0][n] - grads[1][n]
+            noise = grads[0][n] - grads[2][n]
+            if float(d.abs().max()) > max(5e-4 * scale, 4 * float(noise.abs().max())):
+                bad.append((n, 'max', float(d.abs().max()) / scale))
+            if float(d.norm()) > max(5e-5 * float(grads[1][n].norm()), 4 * float(noise.norm())):
+                bad.append((n, 'norm', float(d.norm()) / float(grads[1][n].norm())))
+        return bad
+
+    # two full backward passes: the convolutions' own atomics reorder sums from run to run, so single elements differ by a
+    # few 1e-5 of the largest gradient and, once in ~10 runs, by more than 1e-4 (a full run of the suite failed on that
+    # bound in round 4 and once in five runs in round 6, with nothing but MIOpen between the passes); a wrong FR gradient
+    # is an error of order 1 in EVERY run, so: the bounds must hold in one of three independent triples of passes
+    bad = None
+    for attempt in range(3):
+        bad = off_bounds(passes())
+        if not bad:
+            break
+    assert not bad, bad
 
 
 def test_targets_on_device_equal_cpu_path():
