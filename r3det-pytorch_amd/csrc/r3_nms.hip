@@ -56,6 +56,12 @@ constexpr int Q_CTL_WORDS = Q_REDO + Q_CSTRIDE;
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+__device__ __forceinline__ int ordered_int(const float f) {  // monotone: a < b  <=>  ordered_int(a) < ordered_int(b)
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ordered_float(const int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
 // Batched launches (blockIdx.z = image of a detection batch): every per-image array has the same
 // capacity, `counts[img]` is that image's box count and the strides (in elements) separate the
 // images.  counts == nullptr: one problem, n is the kernel argument (the plain operators).
@@ -250,17 +256,27 @@ __global__ __launch_bounds__(1024) void nms_reduce_dense_kernel(const u64* __res
 // Entry in the global queue: (i << 16) | j, i < j sorted positions; 0xffffffff = hole (skipped by the drain).
 constexpr int SQ_WSEG = 1024;  // u16 entries per wave segment (2 KB)
 
-template <int GEOM, bool LABEL>
+// PERM (round 6, pools beyond P_MIN_CAP): rows and columns are slots of the permutation `perm` (the candidates in x
+// order, see mc_chunk_sort_kernel) instead of sorted positions; `ranges` holds the extent of every 64 slots, and a tile
+// whose two extents are apart has no pair to test.  What is queued are sorted positions, smaller first, as before.
+// The grid is one-dimensional there: a wavefront first looks at up to 64 tiles, one per lane (tile t = lane * waves +
+// wave index, so that the band of tiles along the diagonal spreads over all wavefronts), and then runs the few that
+// remain one after the other.  (One wavefront per tile that leaves after two scalar loads, the first form: 61 us at
+// 32 768 rows, almost all of it the launch of 65 536 workgroups.)
+template <int GEOM, bool LABEL, bool PERM = false>
 __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict__ recs, int n, int cb,
                                                         unsigned* __restrict__ gqueue, unsigned qcap,
                                                         unsigned* __restrict__ counter, unsigned* __restrict__ redo,
-                                                        Batch bt) {
+                                                        Batch bt, const unsigned short* __restrict__ perm = nullptr,
+                                                        const int4* __restrict__ ranges = nullptr,
+                                                        size_t perm_stride = 0, size_t ranges_stride = 0) {
   __shared__ __attribute__((aligned(16))) float4 colsA[MASK_WAVES][TILE];  // cx, cy, ex, ey
   __shared__ float2 colsB[MASK_WAVES][TILE];                               // radius, label
   __shared__ unsigned short queue[MASK_WAVES][SQ_WSEG];
+  __shared__ unsigned short ppos[PERM ? MASK_WAVES : 1][2][TILE];          // PERM: the tile's rows / columns as positions
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tells the compiler it is wave-uniform: scalar control flow
-  const int rb = blockIdx.y;
+  const int rb0 = PERM ? 0 : (int)blockIdx.y;
   if (bt.counts) {  // cb stays the row pitch of mask; the image's own block count bounds the tiles
     const int img = blockIdx.z;
     n = bt.counts[img];
@@ -268,15 +284,24 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
     gqueue += img * bt.queue;
     counter += img * bt.counter;
     redo += img * bt.redo;
-    if (rb * TILE >= n) return;
+    if (PERM) {
+      perm += img * perm_stride;
+      ranges += img * ranges_stride;
+    }
+    if (rb0 * TILE >= n) return;
   }
   const int cbn = (n + TILE - 1) / TILE;
-  const int cblk = blockIdx.x * MASK_WAVES + wave;
-  if (cblk >= cbn || cblk < rb) return;  // (no workgroup barrier below: waves are independent)
+  // one tile (waves are independent: no workgroup barrier in here)
+  auto tile = [&](const int rb, const int cblk) {
   const int col_size = min(n - cblk * TILE, TILE);
+  int pcol_l = cblk * TILE + lane;
+  if (PERM) {
+    pcol_l = lane < col_size ? (int)perm[cblk * TILE + lane] : 0;
+    ppos[wave][1][lane] = (unsigned short)pcol_l;
+  }
   if (lane < col_size) {
     // the reject data sit in the record's last two 16-byte quads (f[9..13]), the label in f[7]
-    const float4* f4 = reinterpret_cast<const float4*>(recs[cblk * TILE + lane].f);
+    const float4* f4 = reinterpret_cast<const float4*>(recs[pcol_l].f);
     const float4 q2 = f4[2], q3 = f4[3];
     colsA[wave][lane] = make_float4(q2.y, q2.z, q3.x, q3.y);
     colsB[wave][lane] = make_float2(q2.w, (GEOM != 1) ? f4[1].w : 0.f);
@@ -284,7 +309,13 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave reads what its own lanes wrote: no workgroup barrier
   __builtin_amdgcn_wave_barrier();
   const int row = rb * TILE + lane;
-  const int rr_ = row < n ? row : n - 1;
+  int rr_ = row < n ? row : n - 1;
+  if (PERM) {
+    rr_ = (int)perm[rr_];
+    ppos[wave][0][lane] = (unsigned short)rr_;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (read by other lanes at the flush)
+    __builtin_amdgcn_wave_barrier();
+  }
   const float4* f4 = reinterpret_cast<const float4*>(recs[rr_].f);
   const float4 q2 = f4[2], q3 = f4[3];
   const float ax = q2.y, ay = q2.z, ar = q2.w, aex = q3.x, aey = q3.y;
@@ -348,7 +379,42 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
   }
   for (int q = lane; q < cnt; q += 64) {
     const unsigned e = wq[q];
-    region[base + q] = ((unsigned)(rb * TILE) + (e >> 6)) << 16 | ((unsigned)(cblk * TILE) + (e & 63u));
+    if (PERM) {
+      const unsigned i = ppos[wave][0][e >> 6], j = ppos[wave][1][e & 63u];
+      region[base + q] = (min(i, j) << 16) | max(i, j);
+    } else {
+      region[base + q] = ((unsigned)(rb * TILE) + (e >> 6)) << 16 | ((unsigned)(cblk * TILE) + (e & 63u));
+    }
+  }
+  };
+  if (!PERM) {
+    const int cblk = blockIdx.x * MASK_WAVES + wave;
+    if (cblk >= cbn || cblk < rb0) return;
+    tile(rb0, cblk);
+    return;
+  }
+  const int nwaves = (int)gridDim.x * MASK_WAVES, wv = (int)blockIdx.x * MASK_WAVES + wave;
+  const long long t = (long long)lane * nwaves + wv;
+  bool live = t < (long long)cbn * cbn;
+  int trb = 0, tcb = 0;
+  if (live) {
+    trb = (int)(t / cbn);
+    tcb = (int)(t - (long long)trb * cbn);
+    live = trb <= tcb;
+  }
+  if (live && trb != tcb) {  // (a NaN extent compares false: the tile is kept)
+    const int4 ra = ranges[trb], rc = ranges[tcb];
+    const float alo = ordered_float(ra.x), ahi = ordered_float(ra.y), clo = ordered_float(rc.x), chi = ordered_float(rc.y);
+    const float aylo = ordered_float(ra.z), ayhi = ordered_float(ra.w), cylo = ordered_float(rc.z), cyhi = ordered_float(rc.w);
+    live = !(ahi < clo || chi < alo || ayhi < cylo || cyhi < aylo);
+  }
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
+  while (todo) {
+    const int src = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the previous tile's LDS reads are behind us)
+    __builtin_amdgcn_wave_barrier();
+    tile(__builtin_amdgcn_readlane(trb, src), __builtin_amdgcn_readlane(tcb, src));
   }
 }
 
@@ -357,7 +423,9 @@ __global__ __launch_bounds__(256, FAST ? 4 : 1) void nms_drain_kernel(const BoxR
                                                         const unsigned* __restrict__ gqueue, unsigned qcap,
                                                         unsigned* __restrict__ counter,
                                                         const unsigned* __restrict__ redo,
-                                                        u64* __restrict__ mask, u64* __restrict__ side, Batch bt) {
+                                                        u64* __restrict__ mask, u64* __restrict__ side, Batch bt,
+                                                        const unsigned short* __restrict__ perm = nullptr,
+                                                        size_t perm_stride = 0) {
   // v1: 8 candidate slots per lane in wave-private [slot][lane] regions (half the LDS of the reference's 16 slots:
   // twice the resident waves; one clip is ~15 us of latency, so an image's pairs should take ONE trip); the rare
   // pair with a 9th candidate is redone by lanes 0..31 with 16 slots in the same region (as in the IoU drain)
@@ -378,6 +446,7 @@ __global__ __launch_bounds__(256, FAST ? 4 : 1) void nms_drain_kernel(const BoxR
     redo += img * bt.redo;
     mask += img * bt.mask;
     side += img * bt.nz;
+    if (perm) perm += img * perm_stride;
   }
   const uint8_t* rlab = (bt.counts && bt.rlab) ? bt.rlab + (size_t)blockIdx.z * bt.rows : nullptr;
   const Side sd = side_tables(side, bt.rows);
@@ -464,8 +533,13 @@ __global__ __launch_bounds__(256, FAST ? 4 : 1) void nms_drain_kernel(const BoxR
   for (unsigned u = blockIdx.x; u < units; u += gridDim.x) {
     const unsigned t = redo[u >> 4];
     const unsigned p = (u & 15u) * 256u + threadIdx.x;
-    const unsigned i = (t >> 16) * TILE + (p >> 6), j = (t & 0xffffu) * TILE + (p & 63u);
+    unsigned i = (t >> 16) * TILE + (p >> 6), j = (t & 0xffffu) * TILE + (p & 63u);
     bool valid = i < (unsigned)n && j < (unsigned)n && i < j;
+    if (perm && valid) {  // (the sorted-chunk form: the tile names slots of the permutation; the pair is their positions)
+      const unsigned a = perm[i], b = perm[j];
+      i = min(a, b);
+      j = max(a, b);
+    }
     if (valid) {
       const BoxRec A = recs[i];
       const BoxRec B = recs[j];
@@ -771,7 +845,7 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_rounds_kernel(const u64* 
 // only -- one workgroup per image walked all 8576 rows for 38 us.  (Groups = labels mod 16: any number of classes, a
 // fixed grid.)  Flag set: workgroup 0 of the image runs the rounds over all rows, the others leave.  Output: the kept rows as bits in `kbits` (zeroed with the side tables), which the
 // finish kernels turn into the detections; no keep list.
-constexpr int RG_MAXN = 16384;  // largest row capacity with grouping (LDS: state bytes + row list + worklist)
+constexpr int RG_MAXN = 32768;  // largest row capacity with grouping (LDS: state bytes + row list + worklist: 124 KB there)
 
 __host__ __device__ inline size_t reduce_groups_lds_bytes(int n, int cb, bool with_row_list) {
   return (size_t)((n + 15) & ~15) + (size_t)cb * 8 * 3 + (with_row_list ? (size_t)n * 2 : 0) + (size_t)R_BLIST * 2 + 64;
@@ -779,7 +853,7 @@ __host__ __device__ inline size_t reduce_groups_lds_bytes(int n, int cb, bool wi
 
 u64* g_nms_stamps = nullptr;  // tools/probes/nms_reduce_probe.hip: clock stamps of reducer workgroup (0, 0) at its phases
 
-template <bool GROUPED>
+template <bool GROUPED, int TRIPS>
 __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT, const Side& sd, const int n,
                                                    const int bt_rows, const int cb, const uint8_t* __restrict__ rlab,
                                                    const int group,
@@ -819,7 +893,8 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     // ordered compaction of the label's rows: every thread's labels requested together (a trip per 1024 rows with
     // its own load and two barriers made this the longest phase of the kernel: nine dependent L2 round trips at
     // n = 8576), the wave masks kept in registers, ONE table of wave counts, ranks from it
-    constexpr int TRIPS = RG_MAXN / RTHREADS;
+    // (TRIPS = row capacity / 1024: 16 up to 16 384 rows, 32 up to 32 768 -- round 6: one workgroup for all of a 32 768-row
+    // pool was 190 us of its 530)
     unsigned char lb[TRIPS];
 #pragma unroll
     for (int u = 0; u < TRIPS; u++) {
@@ -843,23 +918,40 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     // 8-byte LDS read), six shuffle steps, and the wave's 16 bases come back through readlane -- 16 LDS reads per
     // thread and trip (the first form of this loop) were 10 us of the kernel (tools/probes/nms_reduce_probe.hip)
     const int trips = (n + RTHREADS - 1) / RTHREADS;
-    const uint2 q4 = (4 * lane < trips * 16) ? reinterpret_cast<const uint2*>(wtab)[lane] : make_uint2(0u, 0u);
-    const int e0 = (int)(q4.x & 0xffffu), e1 = (int)(q4.x >> 16), e2 = (int)(q4.y & 0xffffu), e3 = (int)(q4.y >> 16);
-    const int mine4 = e0 + e1 + e2 + e3;
+    constexpr int EPL = TRIPS / 4;  // table entries per lane: 4 (one 8-byte LDS read) or 8 (16 bytes)
+    int ent[EPL];
+    {
+      unsigned wd[EPL / 2];
+      const bool on = EPL * lane < trips * 16;  // (a lane's entries belong to one trip)
+      if (EPL == 4) {
+        const uint2 q4 = on ? reinterpret_cast<const uint2*>(wtab)[lane] : make_uint2(0u, 0u);
+        wd[0] = q4.x; wd[1] = q4.y;
+      } else {
+        const uint4 q8 = on ? reinterpret_cast<const uint4*>(wtab)[lane] : make_uint4(0u, 0u, 0u, 0u);
+        wd[0] = q8.x; wd[1] = q8.y; wd[EPL / 2 - 2] = q8.z; wd[EPL / 2 - 1] = q8.w;
+      }
+#pragma unroll
+      for (int q = 0; q < EPL; q++) ent[q] = (int)((wd[q >> 1] >> ((q & 1) * 16)) & 0xffffu);
+    }
+    int mine4 = 0;
+#pragma unroll
+    for (int q = 0; q < EPL; q++) mine4 += ent[q];
     int incl = mine4;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int t = __shfl_up(incl, d);
       if (lane >= d) incl += t;
     }
-    const int ex0 = incl - mine4;  // exclusive prefix of entry 4 * lane
+    const int ex0 = incl - mine4;  // exclusive prefix of entry EPL * lane
     const int wvu = __builtin_amdgcn_readfirstlane(wave);
-    const int wq = wvu & 3;        // the wave's entry in trip u is 16 u + wave: lane 4 u + wave / 4, component wave & 3
-    const int exw = ex0 + (wq > 0 ? e0 : 0) + (wq > 1 ? e1 : 0) + (wq > 2 ? e2 : 0);
+    const int wq = wvu & (EPL - 1);  // the wave's entry in trip u is 16 u + wave: lane (16 u + wave) / EPL, component wave % EPL
+    int exw = ex0;
+#pragma unroll
+    for (int q = 0; q < EPL - 1; q++) exw += wq > q ? ent[q] : 0;
 #pragma unroll
     for (int u = 0; u < TRIPS; u++) {
       if (u * RTHREADS >= n) break;
-      const int base = __builtin_amdgcn_readlane(exw, 4 * u + (wvu >> 2));
+      const int base = __builtin_amdgcn_readlane(exw, (16 / EPL) * u + wvu / EPL);
       if ((mbs[u] >> lane) & 1ULL)
         rows_l[base + __popcll(mbs[u] & ((1ULL << lane) - 1ULL))] = (unsigned short)(u * RTHREADS + tid);
     }
@@ -1161,6 +1253,8 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       __syncthreads();
       return rnd;
     };
+    // (three rows per thread -- a 32 768-row pool has ~2 200 rows per label of 15 -- measured in round 6: 120 B of scratch
+    // per lane and 99 us against the general form's 95)
     if (m <= RTHREADS) round = in_regs(std::integral_constant<int, 1>{});
     else round = in_regs(std::integral_constant<int, 2>{});
   } else {
@@ -1233,7 +1327,15 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       }
     }
     if (c > EL && !anyK) {
-      // suppressors beyond the list: scan the overflow row, 8 independent word loads per step
+      // Suppressors beyond the list: the row's overflow mask, words 0 .. r / 64.  Enlisted for the wavefronts (lanes <->
+      // words, behind the passes below); one thread walking a row of a 32 768-row pool alone -- 512 words, 8 loads per
+      // step -- was 20-30 us of every round there (round 6).  No room on the list: the walk.
+      const int e = atomicAdd(s_m, 1);
+      if (e < OVQ) {
+        ovq[e] = (unsigned short)r;
+        ovl[e] = allR ? 1 : 0;
+        return -1;
+      }
       const u64* row = maskT + (size_t)r * cb;
       const int w = r >> 6;
       for (int q0 = 0; q0 <= w && !anyK; q0 += 8) {
@@ -1256,7 +1358,10 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   };
 
   for (; round < R_MAX_ROUNDS; round++) {
-    if (tid == 0) *s_und = 0;
+    if (tid == 0) {
+      *s_und = 0;
+      *s_m = 0;
+    }
     __syncthreads();
     int und = 0;
     // pass A: the cached rows with at most 8 suppressors, straight from registers
@@ -1301,8 +1406,8 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       const int r = blist[k];
       if (st[r] != 0) continue;
       const int d = long_row(r);
-      if (d) decide(r, d);
-      else und++;
+      if (d > 0) decide(r, d);
+      else if (d == 0) und++;
     }
     // pass C: cached long rows that did not fit the worklist, and rows beyond the register cache
     if (own || m > R_CACHE * RTHREADS) {
@@ -1314,8 +1419,36 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         if (st[r] != 0) continue;
         if (u >= R_CACHE && sd.ecnt[r] == 0) continue;
         const int d = long_row(r);
-        if (d) decide(r, d);
-        else und++;
+        if (d > 0) decide(r, d);
+        else if (d == 0) und++;
+      }
+    }
+    // the enlisted overflow rows: a wavefront per row, a lane per word
+    __syncthreads();
+    {
+      const int nov = min(*s_m, OVQ);
+      for (int e = wave; e < nov; e += RTHREADS / 64) {
+        const int r = ovq[e];
+        const u64* row = maskT + (size_t)r * cb;
+        const int w = r >> 6;
+        bool anyK = false, allR = ovl[e] != 0;
+        for (int q0 = 0; q0 <= w; q0 += 256) {  // (four independent loads per lane and step)
+          u64 mm[4];
+#pragma unroll
+          for (int x = 0; x < 4; x++) mm[x] = q0 + 64 * x + lane <= w ? row[q0 + 64 * x + lane] : 0ULL;
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const int q = min(q0 + 64 * x + lane, w);
+            anyK |= (mm[x] & Kb[q]) != 0ULL;
+            allR &= (mm[x] & ~Rb[q]) == 0ULL;
+          }
+        }
+        const bool k_any = __ballot(anyK) != 0ULL, r_all = __ballot(!allR) == 0ULL;
+        if (lane == 0) {
+          if (k_any) decide(r, 2);
+          else if (r_all) decide(r, 1);
+          else und++;
+        }
       }
     }
     if (und) atomicAdd(s_und, und);
@@ -1382,6 +1515,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   stamp(5);
 }
 
+template <int TRIPS>
 __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* __restrict__ maskT,
                                                                      u64* __restrict__ side, int cb,
                                                                      const unsigned* __restrict__ counter,
@@ -1398,11 +1532,11 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* 
   if (!grouped && blockIdx.x != 0) return;
   const Side sd = side_tables(side + img * bt.nz, bt.rows);
   if (grouped)
-    reduce_groups_body<true>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, bt.rlab + (size_t)img * bt.rows, (int)blockIdx.x,
+    reduce_groups_body<true, TRIPS>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, bt.rlab + (size_t)img * bt.rows, (int)blockIdx.x,
                              kbits + img * kbits_stride, svals + (size_t)img * bt.rows,
                              fbits ? fbits + img * kbits_stride : nullptr, smem8, &s_und, &s_nbig, &s_m, wsum, stamps);
   else
-    reduce_groups_body<false>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, nullptr, 0, kbits + img * kbits_stride,
+    reduce_groups_body<false, TRIPS>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, nullptr, 0, kbits + img * kbits_stride,
                               svals + (size_t)img * bt.rows, fbits ? fbits + img * kbits_stride : nullptr, smem8, &s_und,
                               &s_nbig, &s_m, wsum, stamps);
 }
@@ -2051,6 +2185,77 @@ __global__ __launch_bounds__(1024) void mc_hbb_extent_kernel(const float* __rest
   }
 }
 
+// the class offsets' scale: one float per image, or (sparts > 0, the one-pool entries, round 5) the partial results of
+// rnms_begin_kernel's sparts workgroups -- v1: their maxima (NaN where a workgroup saw one); v3: minima, then maxima
+template <int GEOM>
+__device__ __forceinline__ float mc_scale_of(const float* __restrict__ scale, const int img, const int sparts) {
+  if (sparts <= 0) return scale[img];
+  if (GEOM == 1) {
+    float m = scale[0];
+    bool bad = m != m;
+    for (int g = 1; g < sparts; g++) {
+      const float v = scale[g];
+      bad |= v != v;
+      m = fmaxf(m, v);
+    }
+    return bad ? __builtin_nanf("") : m;
+  }
+  float lo = scale[0], hi = scale[sparts];
+  for (int g = 1; g < sparts; g++) {
+    lo = fminf(lo, scale[g]);
+    hi = fmaxf(hi, scale[sparts + g]);
+  }
+  return hi - lo + 1.f;
+}
+
+// candidate c's box as the kernels see it (class offsets applied; a v3 box thinner than 1e-3 moved out of reach)
+template <int GEOM>
+__device__ __forceinline__ bool mc_offset_box(const float* __restrict__ b, const float lab, const int c,
+                                              const float* __restrict__ scale, const int img, const int sparts,
+                                              float (&d)[5]) {
+  d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = b[4];
+  bool is_dead = false;
+  if (GEOM == 1) {
+    const float off = lab * (mc_scale_of<GEOM>(scale, img, sparts) + 1.f);
+    d[0] += off;
+    d[1] += off;
+  } else if (GEOM == 3) {
+    const float off = lab * mc_scale_of<GEOM>(scale, img, sparts);
+    d[0] += off;
+    d[1] += off;
+    is_dead = fminf(b[2], b[3]) < 0.001f;
+    if (is_dead) {  // disjoint from every live box and from each other by the stream kernel's tests
+      d[0] = 1e30f;
+      d[1] = (float)c * 1e27f;
+    }
+  }
+  return is_dead;
+}
+
+// candidate c of image img goes to sorted position pos: its record, its candidate index, its label
+template <int GEOM>
+__device__ __forceinline__ void mc_place_record(const float* __restrict__ boxes, const int n,
+                                                const int* __restrict__ cand_row, const int* __restrict__ cand_label,
+                                                const size_t cbase, const int c, const int pos, const int img,
+                                                const float* __restrict__ scale, const int sparts,
+                                                BoxRec* __restrict__ recs, const size_t recs_stride,
+                                                int* __restrict__ sorted_vals, uint8_t* __restrict__ dead,
+                                                uint8_t* __restrict__ rlab, float* reject = nullptr) {
+  const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
+  const float lab = (float)cand_label[cbase + c];
+  float d[5];
+  const bool is_dead = mc_offset_box<GEOM>(b, lab, c, scale, img, sparts, d);
+  BoxRec r;
+  make_record<GEOM>(d, GEOM == 2 ? lab : 0.f, r);
+  recs[img * recs_stride + pos] = r;
+  sorted_vals[img * recs_stride + pos] = c;
+  rlab[img * recs_stride + pos] = (uint8_t)cand_label[cbase + c];  // (the reducer groups by label mod 16: the low bits)
+  if (GEOM == 3) dead[img * recs_stride + c] = is_dead;
+  if (reject) {  // (what the stream kernel's axis-aligned test reads: centre and inflated half extents)
+    reject[0] = r.f[9]; reject[1] = r.f[10]; reject[2] = r.f[12]; reject[3] = r.f[13];
+  }
+}
+
 // one thread per candidate: record at its sorted position, and the inverse permutation.
 //   GEOM 1: x, y += label * (max + 1)          (batched_rnms, rnms_wrapper.py:58-63)
 //   GEOM 3: x, y += label * extent; boxes thinner than 1e-3 never take part (obb_nms removes them
@@ -2085,9 +2290,22 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
   const int M = min(counts_raw[img], cap);  // (an image with more candidates than cap is its first cap candidates)
   if (blockIdx.x == 0 && tid == 0) ccounts[img] = M;
   {
+    // The zeroed region starts with the overflow masks: gridDim.y x cap rows of cb words.  Row r is only ever read (and
+    // written: mark_pair, i < r) in its words 0 .. r / 64, so the fill leaves the rest of the row alone -- half the
+    // mask's bytes (round 6; at cap = 32 768 the mask is 134 MB and its fill was most of this kernel).  A 16-byte store
+    // is two words: skipped when its first word is beyond the row's last and its second is in the same row.
     const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
-    for (size_t k = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; k < zero16; k += nthreads)
+    const unsigned cb = (unsigned)((cap + TILE - 1) / TILE);
+    const size_t mwords = (size_t)gridDim.y * (size_t)cap * cb;
+    const size_t mask16 = mwords < ((size_t)1 << 32) ? mwords / 2 : 0;  // (32-bit word indices below; beyond: the plain fill)
+    for (size_t k = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; k < zero16; k += nthreads) {
+      if (k < mask16) {
+        const unsigned w0 = (unsigned)(2 * k), R = w0 / cb, wi = w0 - R * cb;
+        const unsigned r = gridDim.y > 1 ? R % (unsigned)cap : R;
+        if (wi > (r >> 6) && wi + 1 < cb) continue;
+      }
       zero[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
   for (int k = blockIdx.x * 256 + tid; k < Q_CTL_WORDS; k += gridDim.x * 256) counter[img * counter_stride + k] = 0;
   constexpr int WC = RP_C * CT;  // candidates of a workgroup
@@ -2166,52 +2384,211 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
   for (int q = 0; q < RP_P; q++) total_before += partial[q][tid];
   const int c = i0 + tid;
   if (c >= M) return;
-  const int pos = total_before;
-  const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
-  const float lab = (float)cand_label[cbase + c];
-  float d[5] = {b[0], b[1], b[2], b[3], b[4]};
-  bool is_dead = false;
-  // the class offsets' scale: one float per image, or (sparts > 0, the one-pool entries, round 5) the partial results of
-  // rnms_begin_kernel's sparts workgroups -- v1: their maxima (NaN where a workgroup saw one); v3: minima, then maxima
-  auto scale_of = [&]() -> float {
-    if (sparts <= 0) return scale[img];
-    if (GEOM == 1) {
-      float m = scale[0];
-      bool bad = m != m;
-      for (int g = 1; g < sparts; g++) {
-        const float v = scale[g];
-        bad |= v != v;
-        m = fmaxf(m, v);
+  mc_place_record<GEOM>(boxes, n, cand_row, cand_label, cbase, c, total_before, img, scale, sparts, recs, recs_stride,
+                        sorted_vals, dead, rlab);
+}
+
+// ---------------------------------------------------------------------------- large pools: sorted chunks (round 6)
+// Rank by counting is M^2 compares and the stream kernel's tile loop M^2 / 2 box tests: at M = 32 768 they were 100 and
+// 150 us of the call's 530.  Beyond P_MIN_CAP candidates (option nms_impl 6: always, 7: never) the pipeline runs on
+// SORTED CHUNKS instead:
+//   mc_chunk_sort_kernel   a workgroup sorts 1024 candidates twice in LDS (bitonic, both sorts side by side): by score
+//                          and by the x of the box centre as the kernels see it (class offsets applied), and leaves the
+//                          sorted keys and every candidate's place in its chunk;
+//   mc_sort_prepare_p_kernel  a candidate's rank = its place in its own chunk + one binary search per other chunk
+//                          (10 LDS reads for 1024 keys where counting took 1024 compares), for both orders: the score
+//                          rank is the sorted position the rest of the pipeline works in (unchanged), the x rank its
+//                          slot in the permutation P; the x extent of every 64 slots of P is collected on the way;
+//   nms_stream_kernel<.., true>  walks P x P instead of position x position: a 64 x 64 tile whose two x extents are
+//                          apart leaves at once, the others test their pairs as before and queue them by POSITION
+//                          (smaller first), so the drain and the reducer see nothing new.  With the classes offset along
+//                          the diagonal and the boxes of a class spread over the image, 1-2 % of the tiles remain.
+// The drain's redo tiles (a tile too dense for its queue segment) name chunks of P and are enumerated through P.
+constexpr int CS_N = 1024;           // candidates per sorted chunk
+constexpr int P_MIN_CAP = 12288;     // pools above this take the sorted-chunk form (measured: see DESIGN 4.2)
+constexpr int PP_C = 64;             // candidates per workgroup of mc_sort_prepare_p_kernel
+constexpr int PP_PARTS = 4;          // chunks in LDS at a time = threads per candidate
+constexpr int CS_FILL_WGS = 256;     // workgroups of mc_chunk_sort_kernel that zero the masks and side tables meanwhile
+
+struct PSort {
+  unsigned* skeys;        // per image: sorted score keys, chunk after chunk (descending)
+  unsigned* xkeys;        // the same for the x keys
+  unsigned* xraw;         // candidate -> its x key
+  unsigned short* slr;    // candidate -> place in its chunk, score order
+  unsigned short* xlr;    // the same, x order
+  unsigned short* perm;   // P: slot -> sorted position
+  int4* ranges;           // per 64 slots of P: lo x, hi x, lo y, hi y (floats as ordered ints: atomicMin / atomicMax)
+  size_t stride;          // elements between images in the arrays above (cap rounded up to CS_N)
+  size_t rstride;         // int4 between images in ranges
+};
+
+template <int GEOM>
+__global__ __launch_bounds__(CS_N) void mc_chunk_sort_kernel(const float* __restrict__ boxes, int n,
+                                                             const int* __restrict__ cand_row,
+                                                             const int* __restrict__ cand_label,
+                                                             const float* __restrict__ cand_score, int cand_stride,
+                                                             const int* __restrict__ counts_raw, int cap,
+                                                             const float* __restrict__ scale, int sparts, PSort ps,
+                                                             uint4* __restrict__ zero, size_t zero16, int nchunks) {
+  __shared__ u64 el[2][CS_N];  // (key << 32) | (1023 - place in the chunk): descending = key down, index up on ties
+  const int img = blockIdx.y, tid = threadIdx.x;
+  if ((int)blockIdx.x >= nchunks) {
+    // The workgroups behind the chunks: the fill that mc_sort_prepare_kernel carries in the other form (overflow masks
+    // -- words 0 .. r / 64 of row r only -- then side tables and keep bits).  The sort is 32 workgroups waiting on LDS
+    // and barriers; the memory system is free meanwhile (in the ranking kernel the fill was 30 of its 45 us at 32 768).
+    const size_t nthreads = (size_t)(gridDim.x - nchunks) * gridDim.y * CS_N;
+    const unsigned cb = (unsigned)((cap + TILE - 1) / TILE);
+    const size_t mwords = (size_t)gridDim.y * (size_t)cap * cb;
+    const size_t mask16 = mwords < ((size_t)1 << 32) ? mwords / 2 : 0;
+    for (size_t k = ((size_t)blockIdx.y * (gridDim.x - nchunks) + (blockIdx.x - nchunks)) * CS_N + tid; k < zero16; k += nthreads) {
+      if (k < mask16) {
+        const unsigned w0 = (unsigned)(2 * k), R = w0 / cb, wi = w0 - R * cb;
+        const unsigned r = gridDim.y > 1 ? R % (unsigned)cap : R;
+        if (wi > (r >> 6) && wi + 1 < cb) continue;
       }
-      return bad ? __builtin_nanf("") : m;
+      zero[k] = make_uint4(0u, 0u, 0u, 0u);
     }
-    float lo = scale[0], hi = scale[sparts];
-    for (int g = 1; g < sparts; g++) {
-      lo = fminf(lo, scale[g]);
-      hi = fmaxf(hi, scale[sparts + g]);
-    }
-    return hi - lo + 1.f;
-  };
-  if (GEOM == 1) {
-    const float off = lab * (scale_of() + 1.f);
-    d[0] += off;
-    d[1] += off;
-  } else if (GEOM == 3) {
-    const float off = lab * scale_of();
-    d[0] += off;
-    d[1] += off;
-    is_dead = fminf(b[2], b[3]) < 0.001f;
-    if (is_dead) {  // disjoint from every live box and from each other by the stream kernel's tests
-      d[0] = 1e30f;
-      d[1] = (float)c * 1e27f;
+    return;
+  }
+  const int M = min(counts_raw[img], cap);
+  const int c0 = blockIdx.x * CS_N;
+  if (tid < CS_N / TILE)  // the extents of this chunk's share of P's 64-slot groups: empty
+    ps.ranges[img * ps.rstride + blockIdx.x * (CS_N / TILE) + tid] = make_int4(0x7fffffff, (int)0x80000000, 0x7fffffff, (int)0x80000000);
+  if (c0 >= M) return;
+  const size_t cbase = (size_t)img * cand_stride;
+  const int c = c0 + tid;
+  unsigned ks = 0u, kx = 0u;  // (key 0 pads the chunk: below every real key -- the bit pattern of a NaN)
+  if (c < M) {
+    ks = order_key(cand_score[cbase + c]);
+    float d[5];
+    const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
+    mc_offset_box<GEOM>(b, (float)cand_label[cbase + c], c, scale, img, sparts, d);
+    kx = order_key(d[0]);
+    if (kx == 0u) kx = 1u;  // (a real candidate never carries the pad key)
+    if (ks == 0u) ks = 1u;
+    ps.xraw[img * ps.stride + c] = kx;
+  }
+  el[0][tid] = ((u64)ks << 32) | (u64)(CS_N - 1 - tid);
+  el[1][tid] = ((u64)kx << 32) | (u64)(CS_N - 1 - tid);
+  __syncthreads();
+  // bitonic network, 512 compare-exchanges per step and array: threads 0..511 the score array, 512..1023 the x array
+  u64* a = el[tid >> 9];
+  const int e = tid & (CS_N / 2 - 1);
+#pragma unroll 1
+  for (int k = 2; k <= CS_N; k <<= 1) {
+#pragma unroll 1
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      const int lo = ((e & ~(j - 1)) << 1) | (e & (j - 1)), hi = lo | j;
+      const u64 x = a[lo], y = a[hi];
+      const bool down = (lo & k) == 0;
+      if ((x < y) == down) {
+        a[lo] = y;
+        a[hi] = x;
+      }
+      // a step with j <= 64 stays inside the 128 elements of the wavefront's own 64 exchanges: only the six steps with
+      // j >= 128 (and the step in front of each) need the workgroup (55 workgroup barriers: 18 us for this kernel)
+      const int nj = j > 1 ? (j >> 1) : k;  // (the next step's distance; k = the first one of the next merge)
+      if (j >= 2 * TILE || nj >= 2 * TILE) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
-  BoxRec r;
-  make_record<GEOM>(d, GEOM == 2 ? lab : 0.f, r);
-  recs[img * recs_stride + pos] = r;
-  sorted_vals[img * recs_stride + pos] = c;
-  rlab[img * recs_stride + pos] = (uint8_t)cand_label[cbase + c];  // (the reducer groups by label mod 16: the low bits)
-  if (GEOM == 3) dead[img * recs_stride + c] = is_dead;
+  __syncthreads();
+  const u64 vs = el[0][tid], vx = el[1][tid];
+  ps.skeys[img * ps.stride + c0 + tid] = (unsigned)(vs >> 32);
+  ps.xkeys[img * ps.stride + c0 + tid] = (unsigned)(vx >> 32);
+  ps.slr[img * ps.stride + c0 + (CS_N - 1 - (int)(vs & (CS_N - 1)))] = (unsigned short)tid;
+  ps.xlr[img * ps.stride + c0 + (CS_N - 1 - (int)(vx & (CS_N - 1)))] = (unsigned short)tid;
+}
+
+// number of keys > thr in a descending chunk of CS_N keys in LDS
+__device__ __forceinline__ int chunk_count_above(const unsigned* __restrict__ kd, const unsigned thr) {
+  int pos = 0;
+#pragma unroll
+  for (int step = CS_N / 2; step >= 1; step >>= 1)
+    if (kd[pos + step - 1] > thr) pos += step;
+  return pos + (kd[pos] > thr ? 1 : 0);
+}
+
+template <int GEOM>
+__global__ __launch_bounds__(256) void mc_sort_prepare_p_kernel(
+    const float* __restrict__ boxes, int n, const int* __restrict__ cand_row, const int* __restrict__ cand_label,
+    const float* __restrict__ cand_score, int cand_stride, const int* __restrict__ counts_raw, int cap,
+    int* __restrict__ ccounts, const float* __restrict__ scale, BoxRec* __restrict__ recs, size_t recs_stride,
+    int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab,
+    unsigned* __restrict__ counter, size_t counter_stride, uint4* __restrict__ zero, size_t zero16, int sparts, PSort ps) {
+  __shared__ __attribute__((aligned(16))) unsigned keys[2][PP_PARTS][CS_N];  // 32 KB: score chunks, x chunks
+  __shared__ int partial[2][PP_PARTS][PP_C];
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const int M = min(counts_raw[img], cap);
+  if (blockIdx.x == 0 && tid == 0) ccounts[img] = M;
+  for (int k = blockIdx.x * 256 + tid; k < Q_CTL_WORDS; k += gridDim.x * 256) counter[img * counter_stride + k] = 0;
+  const int i0 = blockIdx.x * PP_C;
+  if (i0 < M) {
+  const size_t cbase = (size_t)img * cand_stride;
+  const int ci = tid & (PP_C - 1), part = tid / PP_C;  // (a wavefront = the 64 candidates against one chunk)
+  const int c = i0 + ci;
+  const bool has = c < M;
+  const unsigned us = has ? max(order_key(cand_score[cbase + c]), 1u) : 1u;
+  const unsigned ux = has ? ps.xraw[img * ps.stride + c] : 1u;
+  const int own = c / CS_N;
+  const int nch = (M + CS_N - 1) / CS_N;
+  const unsigned* gs = ps.skeys + img * ps.stride;
+  const unsigned* gx = ps.xkeys + img * ps.stride;
+  int cnt_s = 0, cnt_x = 0;
+  // (the next group of chunks is requested before the current one is searched: 4 chunks x 2 orders = 32 keys per thread)
+  uint4 nxt[2][PP_PARTS];
+  auto request = [&](const int t0) {
+#pragma unroll
+    for (int q = 0; q < PP_PARTS; q++) {
+      const bool on = t0 + q < nch;
+      nxt[0][q] = on ? reinterpret_cast<const uint4*>(gs + (size_t)(t0 + q) * CS_N)[tid] : make_uint4(0u, 0u, 0u, 0u);
+      nxt[1][q] = on ? reinterpret_cast<const uint4*>(gx + (size_t)(t0 + q) * CS_N)[tid] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  request(0);
+  for (int t0 = 0; t0 < nch; t0 += PP_PARTS) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PP_PARTS; q++) {
+      reinterpret_cast<uint4*>(keys[0][q])[tid] = nxt[0][q];
+      reinterpret_cast<uint4*>(keys[1][q])[tid] = nxt[1][q];
+    }
+    if (t0 + PP_PARTS < nch) request(t0 + PP_PARTS);
+    __syncthreads();
+    const int t = t0 + part;
+    if (t < nch && t != own) {
+      // chunks in front of the candidate's own count ties (their candidates come first), chunks behind it do not:
+      // keys >= u  <=>  keys > u - 1 (a candidate's key is never 0)
+      const unsigned dec = t < own ? 1u : 0u;
+      cnt_s += chunk_count_above(keys[0][part], us - dec);
+      cnt_x += chunk_count_above(keys[1][part], ux - dec);
+    }
+  }
+  partial[0][part][ci] = cnt_s;
+  partial[1][part][ci] = cnt_x;
+  __syncthreads();
+  if (tid < PP_C && has) {  // (one thread per candidate from here on)
+  int pos = ps.slr[img * ps.stride + c], slot = ps.xlr[img * ps.stride + c];
+#pragma unroll
+  for (int q = 0; q < PP_PARTS; q++) {
+    pos += partial[0][q][tid];
+    slot += partial[1][q][tid];
+  }
+  float rj[4];
+  mc_place_record<GEOM>(boxes, n, cand_row, cand_label, cbase, c, pos, img, scale, sparts, recs, recs_stride,
+                        sorted_vals, dead, rlab, rj);
+  ps.perm[img * ps.stride + slot] = (unsigned short)pos;
+  int* rg = reinterpret_cast<int*>(ps.ranges + img * ps.rstride + (slot >> 6));
+  atomicMin(rg + 0, ordered_int(rj[0] - rj[2]));
+  atomicMax(rg + 1, ordered_int(rj[0] + rj[2]));
+  atomicMin(rg + 2, ordered_int(rj[1] - rj[3]));
+  atomicMax(rg + 3, ordered_int(rj[1] + rj[3]));
+  }
+  }
 }
 
 // Where the finish kernels write.  List form (the reference's return values, bbox_nms_rotated.py:127-131): dets
@@ -2394,6 +2771,7 @@ struct McLayout {
   u64* fbits;      // kept CANDIDATES as bits (index order; the same)
   float* extent;
   int* ccounts;
+  PSort ps;        // the sorted-chunk form's arrays (pools beyond P_MIN_CAP)
   size_t qcap, qstride, zero_bytes;  // entries per region; entries per image
   int cb;
 };
@@ -2419,7 +2797,17 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* rlab = take((size_t)B * cap);
   char* extent = take((size_t)B * 4);
   char* ccounts = take((size_t)B * 4);
+  const size_t capR = ((size_t)cap + CS_N - 1) / CS_N * CS_N;
+  char* p_sk = take((size_t)B * capR * 4);
+  char* p_xk = take((size_t)B * capR * 4);
+  char* p_xr = take((size_t)B * capR * 4);
+  char* p_sl = take((size_t)B * capR * 2);
+  char* p_xl = take((size_t)B * capR * 2);
+  char* p_pm = take((size_t)B * capR * 2);
+  char* p_rg = take((size_t)B * (capR / TILE) * 16);
   if (L) {
+    L->ps = PSort{(unsigned*)p_sk, (unsigned*)p_xk, (unsigned*)p_xr, (unsigned short*)p_sl, (unsigned short*)p_xl,
+                  (unsigned short*)p_pm, (int4*)p_rg, capR, capR / TILE};
     L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
     L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->redo = (unsigned*)rd; L->keep = (int64_t*)keep;
     L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->rlab = (uint8_t*)rlab; L->kbits = (u64*)kbits; L->fbits = (u64*)fbits; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
@@ -2495,6 +2883,14 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   // (mask + side tables are adjacent and 256-byte aligned: zeroed by the begin kernel, whose grid is widened so that
   // the fill runs at memory speed)
   const bool big_pool = cap > 16384;  // (the ranking loop with 4 candidates per thread: mc_sort_prepare_kernel<., 4>)
+  const int nms_impl0 = g_r3_nms_impl;  // (one read per call)
+  const bool use_p = (cap > P_MIN_CAP && nms_impl0 != 7) || nms_impl0 == 6;  // the sorted-chunk form
+  const dim3 csgrid((unsigned)(L.ps.stride / CS_N) + CS_FILL_WGS, B), ppgrid((cap + PP_C - 1) / PP_C, B);
+  // (the stream kernel of that form: a wavefront looks at up to 64 tiles of the cb x cb square; small squares take fewer
+  // per wavefront so that ~2048 wavefronts share the work)
+  const long long ptiles = (long long)L.cb * L.cb;
+  const long long pwaves = std::max((ptiles + 63) / 64, std::min(ptiles, (long long)2048));
+  const dim3 pstream_grid((unsigned)((pwaves + MASK_WAVES - 1) / MASK_WAVES), 1, B);
   const int pwc = big_pool ? RP_C * 4 : RP_C;
   const dim3 pgrid((cap + pwc - 1) / pwc, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
   const bool clip_fast = g_r3_clip_impl == 0;  // (one read per call -- the grid and the kernel form go together)
@@ -2506,6 +2902,18 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     hipLaunchKernelGGL(mc_hbb_extent_kernel, dim3(B), dim3(1024), 0, stream, boxes, n, cand_row, S, counts, cap, L.extent);
   (void)cand_rank;  // (scratch of the three-launch form of round 2; kept in the signature)
 #define R3_MC(GEOM, LABEL, SCALE)                                                                                  \
+  if (use_p) {                                                                                                     \
+    hipLaunchKernelGGL((mc_chunk_sort_kernel<GEOM>), csgrid, dim3(CS_N), 0, stream, boxes, n, cand_row, cand_label, \
+                       cand_score, S, counts, cap, SCALE, scale_parts, L.ps, reinterpret_cast<uint4*>(L.mask),      \
+                       L.zero_bytes / 16, (int)(L.ps.stride / CS_N));                                               \
+    hipLaunchKernelGGL((mc_sort_prepare_p_kernel<GEOM>), ppgrid, dim3(256), 0, stream, boxes, n, cand_row,         \
+                       cand_label, cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead,  \
+                       L.rlab, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
+                       scale_parts, L.ps);                                                                          \
+    hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL, true>), pstream_grid, dim3(NT), 0, stream, L.recs, 0, L.cb,  \
+                       L.gqueue, (unsigned)L.qcap, L.counter, L.redo, bt, L.ps.perm, L.ps.ranges, L.ps.stride,      \
+                       L.ps.rstride);                                                                               \
+  } else {                                                                                                         \
   if (big_pool)                                                                                                    \
     hipLaunchKernelGGL((mc_sort_prepare_kernel<GEOM, 4>), pgrid, dim3(256), 0, stream, boxes, n, cand_row,         \
                        cand_label, cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead,  \
@@ -2518,12 +2926,15 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
                        scale_parts);                                                                                \
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, L.gqueue,      \
                      (unsigned)L.qcap, L.counter, L.redo, bt);                                                    \
+  }                                                                                                                \
   if (clip_fast)                                                                                                   \
     hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, true>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb,        \
-                       iou_thr, L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt);                  \
+                       iou_thr, L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt,                   \
+                       use_p ? L.ps.perm : (const unsigned short*)nullptr, L.ps.stride);                           \
   else                                                                                                             \
     hipLaunchKernelGGL((nms_drain_kernel<GEOM, LABEL, false>), dgrid, dim3(256), 0, stream, L.recs, 0, L.cb,       \
-                       iou_thr, L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt)
+                       iou_thr, L.gqueue, (unsigned)L.qcap, L.counter, L.redo, L.mask, L.nz, bt,                   \
+                       use_p ? L.ps.perm : (const unsigned short*)nullptr, L.ps.stride)
   if (geom == 1) { R3_MC(1, false, maxc); }
   else if (geom == 3) { R3_MC(3, false, scale_parts > 0 ? maxc : L.extent); }
   else { R3_MC(2, true, (const float*)nullptr); }
@@ -2532,7 +2943,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   {
     // one reducer workgroup per (image, label group = label mod 16) when the pool is small enough for its LDS; the
     // kernel itself falls back to one workgroup per image when the drain saw an edge between two groups
-    const int nms_impl = g_r3_nms_impl;  // (one read per call)
+    const int nms_impl = nms_impl0;
     const int groups = (cap <= RG_MAXN && nms_impl != 2) ? RG_GROUPS : 1;
     if (cap <= WALK_MAXN && nms_impl == 4) {
       // (round 5, measured and NOT the default: one wavefront per (image, label group) walks its rows in score order --
@@ -2543,13 +2954,30 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
                          L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt);
     } else {
     const size_t lds = reduce_groups_lds_bytes(cap, L.cb, groups > 1);
-    static R3DeviceOnce raised;  // the default cap on dynamic LDS is 64 KB; the opt-in is per device
-    if (lds + 11 * 1024 > 64 * 1024 && raised.first())
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 12 * 1024);  // (+ ~10.5 KB static)
-    if (lds > 160 * 1024 - 12 * 1024) return -1;  // (cap < 65536: 106 KB at most)
-    hipLaunchKernelGGL(nms_reduce_groups_kernel, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
-                       L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);
+    // the default cap on dynamic LDS is 64 KB; the opt-in is per device: everything the CU has beyond the kernel's own
+    // static LDS (read from the code object: it changes with the code)
+    static R3DeviceOnce raised;
+    static size_t dyn_max = 0;             // (the same on every device: one code object)
+    constexpr size_t DYN_DEFAULT = 44 * 1024;  // what fits the default cap whatever the static part is (< 20 KB)
+    if (lds > DYN_DEFAULT && raised.first()) {
+      hipFuncAttributes fa16{}, fa32{};
+      (void)hipFuncGetAttributes(&fa16, reinterpret_cast<const void*>(nms_reduce_groups_kernel<16>));
+      (void)hipFuncGetAttributes(&fa32, reinterpret_cast<const void*>(nms_reduce_groups_kernel<32>));
+      const size_t stat = std::max(fa16.sharedSizeBytes, fa32.sharedSizeBytes);
+      dyn_max = 160 * 1024 - ((stat + 1023) & ~(size_t)1023);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel<16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel<32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max);
+      (void)hipGetLastError();
+    }
+    if (lds > DYN_DEFAULT && lds > dyn_max) return -1;  // (cap < 65536: 124 KB at most with grouping, 106 KB without)
+    if (cap <= 16384)
+      hipLaunchKernelGGL(nms_reduce_groups_kernel<16>, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
+                         L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);
+    else
+      hipLaunchKernelGGL(nms_reduce_groups_kernel<32>, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
+                         L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);
     }
   }
   if (geom == 1)

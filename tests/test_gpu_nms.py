@@ -366,6 +366,67 @@ def test_one_call_form_at_32768_rows_exact_vs_the_twin_oracle():
 
 
 @pytest.mark.parametrize("version", ["v1", "v3"])
+@pytest.mark.parametrize("n", [100, 1030, 5000, 13000])
+def test_sorted_chunk_form_equals_the_counting_form(version, n):
+    """Round 6: beyond 12 288 candidates the batched pipeline ranks by binary search in sorted 1024-chunks and tests pairs
+    over the candidates in x order (mc_chunk_sort_kernel, mc_sort_prepare_p_kernel, nms_stream_kernel<.., true>); option
+    nms_impl 6 forces that form, 7 forbids it.  Ties in the scores, labels whose offsets leave the classes touching
+    (boxes wider than the image), a count that is no multiple of 64 or 1024: keep lists and rows identical."""
+    import r3det.ops.nms as M
+    from r3det import _C
+    b = rand_boxes(n, 5 + n, span=900.0)
+    b[::97, 2] = 2500.0                               # a few boxes wider than the class offset: edges between classes
+    r = np.random.default_rng(n)
+    s = r.uniform(0.05, 1, n).astype(np.float32)
+    s[::7] = s[3]
+    lab = r.integers(0, 15, n)
+    tb, ts, tl = (torch.from_numpy(x).cuda() for x in (b, s, lab))
+    entry = "r3det_batched_rnms" if version == "v1" else "r3det_obb_batched_nms"
+    got = {}
+    try:
+        for impl in (7, 6):
+            _C.set_option("nms_impl", impl)
+            d, k = M._batched_rnms_device(tb, ts, tl, 0.1, False, entry=entry)
+            got[impl] = (d.clone(), k.clone())
+    finally:
+        _C.set_option("nms_impl", 0)
+    assert 0 < got[7][1].numel() < n
+    assert torch.equal(got[6][1], got[7][1]) and torch.equal(got[6][0], got[7][0])
+    d0, k0 = M._batched_rnms_device(tb, ts, tl, 0.1, False, entry=entry)       # the default for this size
+    assert torch.equal(k0, got[7][1]) and torch.equal(d0, got[7][0])
+
+
+def test_sorted_chunk_form_on_a_dense_cluster_takes_the_redo_tiles():
+    """3000 near-copies of one box: every tile's queue segment overflows, the tiles go to the redo list as chunks of the
+    x-ordered permutation and the drain enumerates them through it."""
+    import r3det.ops.nms as M
+    from r3det import _C
+    n = 3000
+    r = np.random.default_rng(4)
+    b = np.tile(np.array([[300., 300., 80., 40., 0.3]], np.float32), (n, 1))
+    b[:, :2] += r.normal(0, 25.0, (n, 2)).astype(np.float32)
+    b[:, 4] += r.normal(0, 0.2, n).astype(np.float32)
+    s = r.uniform(0.05, 1, n).astype(np.float32)
+    lab = r.integers(0, 2, n)
+    tb, ts, tl = (torch.from_numpy(x).cuda() for x in (b, s, lab))
+    got = {}
+    try:
+        for impl in (7, 6):
+            _C.set_option("nms_impl", impl)
+            d, k = M._batched_rnms_device(tb, ts, tl, 0.1, False)
+            got[impl] = (d.clone(), k.clone())
+    finally:
+        _C.set_option("nms_impl", 0)
+    assert 0 < got[7][1].numel() < 200
+    assert torch.equal(got[6][1], got[7][1]) and torch.equal(got[6][0], got[7][0])
+    shifted = b.copy()
+    shifted[:, :2] += (lab * (b.max() + 1)).astype(np.float32)[:, None]
+    with O.twin():
+        want = O.nms(O.V1, shifted, s, 0.1, strict=True, ascending=True)
+    assert np.array_equal(got[6][1].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("version", ["v1", "v3"])
 def test_padded_one_pool_form_equals_the_list_form(version):
     """batched_rnms_padded: the one library call of batched_rnms / obb_batched_nms without the host read of the count --
     rows [:kept] are the list form's return values (rnms_wrapper.py:34-69, nms_rotated_wrapper.py:78-98)."""

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     b[i * 5 + 2] = obj[o * 5 + 2] * expf(nrand() * 0.1f); b[i * 5 + 3] = obj[o * 5 + 3] * expf(nrand() * 0.1f);
     b[i * 5 + 4] = obj[o * 5 + 4] + nrand() * 0.05f; sc[i] = 0.05f + 0.95f * urand(); lab[i] = ocls[o];
   }
-  if (argc > 2) {  // a dumped pool (tools/cross_label_edges.py, DUMP_POOL=file): n | boxes | scores | labels, all f32
+  if (argc > 2 && argv[2][0]) {  // a dumped pool (tools/cross_label_edges.py, DUMP_POOL=file): n | boxes | scores | labels, all f32
     FILE* f = fopen(argv[2], "rb");
     if (!f) { printf("cannot open %s\n", argv[2]); return 1; }
     float fn; if (fread(&fn, 4, 1, f) != 1) return 1;
