@@ -1258,11 +1258,16 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     if (m <= RTHREADS) round = in_regs(std::integral_constant<int, 1>{});
     else round = in_regs(std::integral_constant<int, 2>{});
   } else {
+  // (two forms of the general reducer, round 6: up to 3 rows per thread -- every grouped launch of a multi-class pool --
+  // the worklist's rows stay in registers too; beyond, the register cache of 9 rows per thread needs those registers)
+  auto general = [&](auto rc_tag, auto wl_tag) {
+  constexpr int RC = decltype(rc_tag)::value;
+  constexpr bool WL = decltype(wl_tag)::value;
   // prologue: counts and first chunks of this workgroup's rows (all loads in flight together)
-  int cnt[R_CACHE];
-  uint4 c0[R_CACHE];
+  int cnt[RC];
+  uint4 c0[RC];
 #pragma unroll
-  for (int u = 0; u < R_CACHE; u++) {
+  for (int u = 0; u < RC; u++) {
     const int k = tid + u * RTHREADS;
     const int rr = k < m ? row_of(k) : 0;
     cnt[u] = sd.ecnt[rr];
@@ -1270,7 +1275,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   }
   unsigned own = 0;  // cached rows with a long list that did not fit the worklist
 #pragma unroll
-  for (int u = 0; u < R_CACHE; u++) {
+  for (int u = 0; u < RC; u++) {
     const int k = tid + u * RTHREADS;
     const int r = k < m ? row_of(k) : 0;
     const bool kept0 = k < m && cnt[u] == 0;
@@ -1294,7 +1299,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       }
     }
   }
-  for (int u = R_CACHE; wave * 64 + u * RTHREADS < m; u++) {  // rows beyond the register cache
+  for (int u = RC; wave * 64 + u * RTHREADS < m; u++) {  // rows beyond the register cache
     const int k = tid + u * RTHREADS;
     const int r = k < m ? row_of(k) : 0;
     const bool kept0 = k < m && sd.ecnt[r] == 0;
@@ -1305,13 +1310,9 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   stamp(2);
   const int nbig = min(*s_nbig, R_BLIST);
 
-  // one row against the K / R sets; returns 0 undecided, 1 kept, 2 removed
-  auto long_row = [&](const int r) -> int {
-    const unsigned ms = 65535u - (unsigned)sd.msup[r];  // its highest-scored suppressor first
-    if (ms < 65535u && st[ms] == 1) return 2;
-    const int c = sd.ecnt[r];
-    const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
-    const uint4 t[4] = {lp[0], lp[1], lp[2], lp[3]};
+  // one row against the K / R sets; returns 0 undecided, 1 kept, 2 removed (-1: enlisted for the overflow pass)
+  auto long_row_core = [&](const int r, const unsigned ms, const int c, const uint4 (&t)[4]) -> int {
+    if (ms < 65535u && st[ms] == 1) return 2;  // its highest-scored suppressor first
     const int listed = min(c, EL);
     bool anyK = false, allR = true;
 #pragma unroll
@@ -1352,6 +1353,27 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     }
     return anyK ? 2 : (allR ? 1 : 0);
   };
+  auto long_row = [&](const int r) -> int {
+    const unsigned ms = 65535u - (unsigned)sd.msup[r];
+    if (ms < 65535u && st[ms] == 1) return 2;
+    const int c = sd.ecnt[r];
+    const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)r * EL);
+    const uint4 t[4] = {lp[0], lp[1], lp[2], lp[3]};
+    return long_row_core(r, ms, c, t);
+  };
+  // The worklist's first 1024 rows -- all of it in a grouped launch -- keep suppressor, count and list in registers for
+  // every round (round 6: two dependent trips to memory per long row and round were most of a round at 32 768 rows,
+  // 450 long rows per label group there)
+  int wl_r = 0, wl_c = 0;
+  unsigned wl_ms = 65535u;
+  uint4 wl_t[4] = {};
+  if (WL && tid < nbig) {
+    wl_r = blist[tid];
+    wl_ms = 65535u - (unsigned)sd.msup[wl_r];
+    wl_c = sd.ecnt[wl_r];
+    const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)wl_r * EL);
+    wl_t[0] = lp[0]; wl_t[1] = lp[1]; wl_t[2] = lp[2]; wl_t[3] = lp[3];
+  }
   auto decide = [&](const int r, const int d) {
     st[r] = (unsigned char)d;
     set_bit(d == 1 ? Kb : Rb, r);
@@ -1364,9 +1386,10 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     }
     __syncthreads();
     int und = 0;
+    if (stamp_on && round < 8) stamps[16 + 4 * round] = __builtin_amdgcn_s_memtime();
     // pass A: the cached rows with at most 8 suppressors, straight from registers
 #pragma unroll
-    for (int u = 0; u < R_CACHE; u++) {
+    for (int u = 0; u < RC; u++) {
       const int k = tid + u * RTHREADS;
       const int r = k < m ? row_of(k) : 0;
       const bool act = k < m && cnt[u] <= 8 && cnt[u] > 0 && st[r] == 0;
@@ -1401,8 +1424,14 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         }
       }
     }
+    if (stamp_on && round < 8) stamps[17 + 4 * round] = __builtin_amdgcn_s_memtime();
     // pass B: the worklist of long rows, one per thread
-    for (int k = tid; k < nbig; k += RTHREADS) {
+    if (WL && tid < nbig && st[wl_r] == 0) {
+      const int d = long_row_core(wl_r, wl_ms, wl_c, wl_t);
+      if (d > 0) decide(wl_r, d);
+      else if (d == 0) und++;
+    }
+    for (int k = tid + (WL ? RTHREADS : 0); k < nbig; k += RTHREADS) {
       const int r = blist[k];
       if (st[r] != 0) continue;
       const int d = long_row(r);
@@ -1410,20 +1439,21 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       else if (d == 0) und++;
     }
     // pass C: cached long rows that did not fit the worklist, and rows beyond the register cache
-    if (own || m > R_CACHE * RTHREADS) {
+    if (own || m > RC * RTHREADS) {
       for (int u = 0; wave * 64 + u * RTHREADS < m; u++) {
         const int k = tid + u * RTHREADS;
-        const bool mine = u < R_CACHE ? ((own >> u) & 1u) : true;
+        const bool mine = u < RC ? ((own >> u) & 1u) : true;
         if (!(k < m && mine)) continue;
         const int r = row_of(k);
         if (st[r] != 0) continue;
-        if (u >= R_CACHE && sd.ecnt[r] == 0) continue;
+        if (u >= RC && sd.ecnt[r] == 0) continue;
         const int d = long_row(r);
         if (d > 0) decide(r, d);
         else if (d == 0) und++;
       }
     }
     // the enlisted overflow rows: a wavefront per row, a lane per word
+    if (stamp_on && round < 8) stamps[18 + 4 * round] = __builtin_amdgcn_s_memtime();
     __syncthreads();
     {
       const int nov = min(*s_m, OVQ);
@@ -1453,10 +1483,14 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     }
     if (und) atomicAdd(s_und, und);
     __syncthreads();
+    if (stamp_on && round < 8) stamps[19 + 4 * round] = __builtin_amdgcn_s_memtime();
     const int left = *s_und;
     __syncthreads();
     if (left == 0) break;
   }
+  };
+  if (m <= 3 * RTHREADS) general(std::integral_constant<int, 3>{}, std::true_type{});
+  else general(std::integral_constant<int, R_CACHE>{}, std::false_type{});
   }
   stamp(3);
   if (stamp_on) stamps[7] = (u64)round;

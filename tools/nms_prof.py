@@ -33,6 +33,13 @@ for n in sizes:
     sc, lab = ms[:, :-1].max(1)
     idx = torch.nonzero(sc > 0.05).squeeze(1)[:n]
     b, s, l = mb[idx].contiguous(), sc[idx].contiguous(), lab[idx].contiguous()
+    if os.environ.get("DUMP_POOL"):  # for tools/probes/nms_reduce_probe.hip: n | boxes | scores | labels, all f32
+        import numpy as np
+        with open(os.environ["DUMP_POOL"], "wb") as f:
+            np.array([b.size(0)], np.float32).tofile(f)
+            b.cpu().numpy().astype(np.float32).tofile(f)
+            s.cpu().numpy().astype(np.float32).tofile(f)
+            l.cpu().numpy().astype(np.float32).tofile(f)
     for _ in range(3):
         batched_rnms(b, s, l, 0.1)
     torch.cuda.synchronize()

@@ -63,8 +63,9 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     u64 s[64]; int kept; CK(hipMemcpy(s, st, 512, hipMemcpyDeviceToHost));
     if (it == 2) for (int r = 0; r < 8 && s[16 + 4 * r]; r++)
-      printf("  round %d: rows %llu  barrier+count %llu  (this workgroup's thread 0)\n", r, s[18 + 4 * r] - s[16 + 4 * r],
-             s[19 + 4 * r] - s[18 + 4 * r]); CK(hipMemcpy(&kept, dc, 4, hipMemcpyDeviceToHost));
+      printf("  round %d: stamps +%llu +%llu +%llu  (in-register form: rows | - | barrier + count; general form: pass A | passes B, C | "
+             "overflow rows + barriers; this workgroup's thread 0)\n", r, s[17 + 4 * r] > s[16 + 4 * r] ? s[17 + 4 * r] - s[16 + 4 * r] : 0,
+             s[18 + 4 * r] - (s[17 + 4 * r] > s[16 + 4 * r] ? s[17 + 4 * r] : s[16 + 4 * r]), s[19 + 4 * r] - s[18 + 4 * r]); CK(hipMemcpy(&kept, dc, 4, hipMemcpyDeviceToHost));
     printf("n %d rc %d kept %d | cycles: compaction %llu  prologue %llu  rounds %llu (%llu rounds)  tail %llu  bits %llu  total %llu\n", n, rc,
            kept, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[7], s[4] - s[3], s[5] - s[4], s[5] - s[0]);
   }
