@@ -56,11 +56,6 @@ constexpr int Q_CTL_WORDS = Q_REDO + Q_CSTRIDE;
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-__device__ __forceinline__ int ordered_int(const float f) {  // monotone: a < b  <=>  ordered_int(a) < ordered_int(b)
-  const int i = __float_as_int(f);
-  return i >= 0 ? i : i ^ 0x7fffffff;
-}
-__device__ __forceinline__ float ordered_float(const int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
 // Batched launches (blockIdx.z = image of a detection batch): every per-image array has the same
 // capacity, `counts[img]` is that image's box count and the strides (in elements) separate the
@@ -268,7 +263,7 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
                                                         unsigned* __restrict__ gqueue, unsigned qcap,
                                                         unsigned* __restrict__ counter, unsigned* __restrict__ redo,
                                                         Batch bt, const unsigned short* __restrict__ perm = nullptr,
-                                                        const int4* __restrict__ ranges = nullptr,
+                                                        const float4* __restrict__ ranges = nullptr,
                                                         size_t perm_stride = 0, size_t ranges_stride = 0) {
   __shared__ __attribute__((aligned(16))) float4 colsA[MASK_WAVES][TILE];  // cx, cy, ex, ey
   __shared__ float2 colsB[MASK_WAVES][TILE];                               // radius, label
@@ -403,10 +398,8 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
     live = trb <= tcb;
   }
   if (live && trb != tcb) {  // (a NaN extent compares false: the tile is kept)
-    const int4 ra = ranges[trb], rc = ranges[tcb];
-    const float alo = ordered_float(ra.x), ahi = ordered_float(ra.y), clo = ordered_float(rc.x), chi = ordered_float(rc.y);
-    const float aylo = ordered_float(ra.z), ayhi = ordered_float(ra.w), cylo = ordered_float(rc.z), cyhi = ordered_float(rc.w);
-    live = !(ahi < clo || chi < alo || ayhi < cylo || cyhi < aylo);
+    const float4 ra = ranges[trb], rc = ranges[tcb];
+    live = !(ra.y < rc.x || rc.y < ra.x || ra.w < rc.z || rc.w < ra.z);
   }
   unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
   while (todo) {
@@ -2266,7 +2259,33 @@ __device__ __forceinline__ bool mc_offset_box(const float* __restrict__ b, const
   return is_dead;
 }
 
-// candidate c of image img goes to sorted position pos: its record, its candidate index, its label
+// candidate c of image img: its record (class offsets applied), whether it is a dead v3 box, its label
+template <int GEOM>
+__device__ __forceinline__ void mc_build_record(const float* __restrict__ boxes, const int n,
+                                                const int* __restrict__ cand_row, const int* __restrict__ cand_label,
+                                                const size_t cbase, const int c, const int img,
+                                                const float* __restrict__ scale, const int sparts, BoxRec& r,
+                                                bool& is_dead, int& label) {
+  const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
+  label = cand_label[cbase + c];
+  const float lab = (float)label;
+  float d[5];
+  is_dead = mc_offset_box<GEOM>(b, lab, c, scale, img, sparts, d);
+  make_record<GEOM>(d, GEOM == 2 ? lab : 0.f, r);
+}
+
+// ... goes to sorted position pos
+template <int GEOM>
+__device__ __forceinline__ void mc_store_record(const BoxRec& r, const bool is_dead, const int label, const int c,
+                                                const int pos, const int img, BoxRec* __restrict__ recs,
+                                                const size_t recs_stride, int* __restrict__ sorted_vals,
+                                                uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab) {
+  recs[img * recs_stride + pos] = r;
+  sorted_vals[img * recs_stride + pos] = c;
+  rlab[img * recs_stride + pos] = (uint8_t)label;  // (the reducer groups by label mod 16: the low bits)
+  if (GEOM == 3) dead[img * recs_stride + c] = is_dead;
+}
+
 template <int GEOM>
 __device__ __forceinline__ void mc_place_record(const float* __restrict__ boxes, const int n,
                                                 const int* __restrict__ cand_row, const int* __restrict__ cand_label,
@@ -2274,20 +2293,12 @@ __device__ __forceinline__ void mc_place_record(const float* __restrict__ boxes,
                                                 const float* __restrict__ scale, const int sparts,
                                                 BoxRec* __restrict__ recs, const size_t recs_stride,
                                                 int* __restrict__ sorted_vals, uint8_t* __restrict__ dead,
-                                                uint8_t* __restrict__ rlab, float* reject = nullptr) {
-  const float* b = boxes + ((size_t)img * n + cand_row[cbase + c]) * 5;
-  const float lab = (float)cand_label[cbase + c];
-  float d[5];
-  const bool is_dead = mc_offset_box<GEOM>(b, lab, c, scale, img, sparts, d);
+                                                uint8_t* __restrict__ rlab) {
   BoxRec r;
-  make_record<GEOM>(d, GEOM == 2 ? lab : 0.f, r);
-  recs[img * recs_stride + pos] = r;
-  sorted_vals[img * recs_stride + pos] = c;
-  rlab[img * recs_stride + pos] = (uint8_t)cand_label[cbase + c];  // (the reducer groups by label mod 16: the low bits)
-  if (GEOM == 3) dead[img * recs_stride + c] = is_dead;
-  if (reject) {  // (what the stream kernel's axis-aligned test reads: centre and inflated half extents)
-    reject[0] = r.f[9]; reject[1] = r.f[10]; reject[2] = r.f[12]; reject[3] = r.f[13];
-  }
+  bool is_dead;
+  int label;
+  mc_build_record<GEOM>(boxes, n, cand_row, cand_label, cbase, c, img, scale, sparts, r, is_dead, label);
+  mc_store_record<GEOM>(r, is_dead, label, c, pos, img, recs, recs_stride, sorted_vals, dead, rlab);
 }
 
 // one thread per candidate: record at its sorted position, and the inverse permutation.
@@ -2440,8 +2451,12 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
 // The drain's redo tiles (a tile too dense for its queue segment) name chunks of P and are enumerated through P.
 constexpr int CS_N = 1024;           // candidates per sorted chunk
 constexpr int P_MIN_CAP = 12288;     // pools above this take the sorted-chunk form (measured: see DESIGN 4.2)
-constexpr int PP_C = 64;             // candidates per workgroup of mc_sort_prepare_p_kernel
+#ifndef R3_PP_C
+#define R3_PP_C 64
+#endif
+constexpr int PP_CANDS = R3_PP_C;    // candidates per workgroup of mc_sort_prepare_p_kernel (x PP_PARTS threads)
 constexpr int PP_PARTS = 4;          // chunks in LDS at a time = threads per candidate
+constexpr size_t PP_LDS_BYTES = (size_t)2 * 2 * PP_PARTS * CS_N * 4;  // two buffers of score + x chunks
 constexpr int CS_FILL_WGS = 256;     // workgroups of mc_chunk_sort_kernel that zero the masks and side tables meanwhile
 
 struct PSort {
@@ -2451,10 +2466,23 @@ struct PSort {
   unsigned short* slr;    // candidate -> place in its chunk, score order
   unsigned short* xlr;    // the same, x order
   unsigned short* perm;   // P: slot -> sorted position
-  int4* ranges;           // per 64 slots of P: lo x, hi x, lo y, hi y (floats as ordered ints: atomicMin / atomicMax)
+  float4* ranges;         // per 64 slots of P: lo x, hi x, lo y, hi y of the boxes' inflated axis-aligned bounds
+  float4* slotbox;        // per slot of P: the same four numbers of its one box (mc_ranges_kernel reduces them)
   size_t stride;          // elements between images in the arrays above (cap rounded up to CS_N)
   size_t rstride;         // int4 between images in ranges
+  u64* stamps;            // (probe, tools/probes/nms_reduce_probe.hip: clock stamps of workgroup (0, 0) of the ranking kernel)
 };
+
+// Where sorted place p of a chunk is stored: places 0 .. CS_N - 2 as a complete binary search tree in LEVEL ORDER (root
+// = place 511, then 255 and 767, ...), place CS_N - 1 last.  A binary search over the sorted array itself reads, at every
+// level, addresses that differ by a multiple of the level's stride -- 64 lanes on one or two LDS banks: up to 32-way
+// conflicts, ~100 ns per read, 2.5 us for the two searches of a group (stamps).  In level order a level's pivots are
+// neighbours.
+__device__ __forceinline__ int chunk_tree_index(const int p) {
+  if (p == CS_N - 1) return CS_N - 1;
+  const int q = p + 1, tz = __builtin_ctz(q);
+  return (CS_N >> (tz + 1)) - 1 + (q >> (tz + 1));
+}
 
 template <int GEOM>
 __global__ __launch_bounds__(CS_N) void mc_chunk_sort_kernel(const float* __restrict__ boxes, int n,
@@ -2464,7 +2492,7 @@ __global__ __launch_bounds__(CS_N) void mc_chunk_sort_kernel(const float* __rest
                                                              const int* __restrict__ counts_raw, int cap,
                                                              const float* __restrict__ scale, int sparts, PSort ps,
                                                              uint4* __restrict__ zero, size_t zero16, int nchunks) {
-  __shared__ u64 el[2][CS_N];  // (key << 32) | (1023 - place in the chunk): descending = key down, index up on ties
+  __shared__ u64 el[2][2][CS_N];  // the exchange buffers of the steps across wavefronts (double-buffered), per order
   const int img = blockIdx.y, tid = threadIdx.x;
   if ((int)blockIdx.x >= nchunks) {
     // The workgroups behind the chunks: the fill that mc_sort_prepare_kernel carries in the other form (overflow masks
@@ -2486,8 +2514,6 @@ __global__ __launch_bounds__(CS_N) void mc_chunk_sort_kernel(const float* __rest
   }
   const int M = min(counts_raw[img], cap);
   const int c0 = blockIdx.x * CS_N;
-  if (tid < CS_N / TILE)  // the extents of this chunk's share of P's 64-slot groups: empty
-    ps.ranges[img * ps.rstride + blockIdx.x * (CS_N / TILE) + tid] = make_int4(0x7fffffff, (int)0x80000000, 0x7fffffff, (int)0x80000000);
   if (c0 >= M) return;
   const size_t cbase = (size_t)img * cand_stride;
   const int c = c0 + tid;
@@ -2502,65 +2528,90 @@ __global__ __launch_bounds__(CS_N) void mc_chunk_sort_kernel(const float* __rest
     if (ks == 0u) ks = 1u;
     ps.xraw[img * ps.stride + c] = kx;
   }
-  el[0][tid] = ((u64)ks << 32) | (u64)(CS_N - 1 - tid);
-  el[1][tid] = ((u64)kx << 32) | (u64)(CS_N - 1 - tid);
-  __syncthreads();
-  // bitonic network, 512 compare-exchanges per step and array: threads 0..511 the score array, 512..1023 the x array
-  u64* a = el[tid >> 9];
-  const int e = tid & (CS_N / 2 - 1);
+  // Bitonic network with one element of each order per thread: a step whose partner is within the wavefront (distance
+  // < 64: 45 of the 55 steps) is two shuffles per element, the ten others go through LDS, double-buffered -- one
+  // workgroup barrier each.  (The first form kept both arrays in LDS with a compare-exchange per thread and a barrier
+  // per step: 18 us for a kernel of 32 workgroups; with the wavefront-local steps behind a wavefront fence: 15.7.)
+  u64 vs = ((u64)ks << 32) | (u64)(CS_N - 1 - tid);  // (key << 32) | (1023 - place): descending = key down, index up on ties
+  u64 vx = ((u64)kx << 32) | (u64)(CS_N - 1 - tid);
+  auto sx = [&](const u64 v, const int j) -> u64 {
+    const unsigned lo = __shfl_xor((unsigned)v, j), hi = __shfl_xor((unsigned)(v >> 32), j);
+    return ((u64)hi << 32) | lo;
+  };
+  int cur = 0;
 #pragma unroll 1
   for (int k = 2; k <= CS_N; k <<= 1) {
+    const bool down = (tid & k) == 0;
 #pragma unroll 1
     for (int j = k >> 1; j >= 1; j >>= 1) {
-      const int lo = ((e & ~(j - 1)) << 1) | (e & (j - 1)), hi = lo | j;
-      const u64 x = a[lo], y = a[hi];
-      const bool down = (lo & k) == 0;
-      if ((x < y) == down) {
-        a[lo] = y;
-        a[hi] = x;
-      }
-      // a step with j <= 64 stays inside the 128 elements of the wavefront's own 64 exchanges: only the six steps with
-      // j >= 128 (and the step in front of each) need the workgroup (55 workgroup barriers: 18 us for this kernel)
-      const int nj = j > 1 ? (j >> 1) : k;  // (the next step's distance; k = the first one of the next merge)
-      if (j >= 2 * TILE || nj >= 2 * TILE) {
+      u64 os, ox;
+      if (j >= TILE) {
+        el[cur][0][tid] = vs;
+        el[cur][1][tid] = vx;
         __syncthreads();
+        os = el[cur][0][tid ^ j];
+        ox = el[cur][1][tid ^ j];
+        cur ^= 1;
       } else {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        os = sx(vs, j);
+        ox = sx(vx, j);
       }
+      const bool keep_max = ((tid & j) == 0) == down;  // (the lower index of a pair in a descending block keeps the larger)
+      vs = keep_max ? (vs > os ? vs : os) : (vs < os ? vs : os);
+      vx = keep_max ? (vx > ox ? vx : ox) : (vx < ox ? vx : ox);
     }
   }
-  __syncthreads();
-  const u64 vs = el[0][tid], vx = el[1][tid];
-  ps.skeys[img * ps.stride + c0 + tid] = (unsigned)(vs >> 32);
-  ps.xkeys[img * ps.stride + c0 + tid] = (unsigned)(vx >> 32);
+  ps.skeys[img * ps.stride + c0 + chunk_tree_index(tid)] = (unsigned)(vs >> 32);  // (the ranking kernel's search tree)
+  ps.xkeys[img * ps.stride + c0 + chunk_tree_index(tid)] = (unsigned)(vx >> 32);
   ps.slr[img * ps.stride + c0 + (CS_N - 1 - (int)(vs & (CS_N - 1)))] = (unsigned short)tid;
   ps.xlr[img * ps.stride + c0 + (CS_N - 1 - (int)(vx & (CS_N - 1)))] = (unsigned short)tid;
 }
 
-// number of keys > thr in a descending chunk of CS_N keys in LDS
-__device__ __forceinline__ int chunk_count_above(const unsigned* __restrict__ kd, const unsigned thr) {
-  int pos = 0;
+// numbers of keys > thr in two descending chunks of CS_N keys in LDS (tree layout), searched side by side
+__device__ __forceinline__ void chunk_counts_above(const unsigned* __restrict__ ka, const unsigned ta,
+                                                   const unsigned* __restrict__ kb, const unsigned tb, int& ca, int& cb) {
+  int ia = 0, ib = 0;
 #pragma unroll
-  for (int step = CS_N / 2; step >= 1; step >>= 1)
-    if (kd[pos + step - 1] > thr) pos += step;
-  return pos + (kd[pos] > thr ? 1 : 0);
+  for (int level = 0; level < 10; level++) {  // (CS_N = 2^10)
+    const unsigned va = ka[ia], vb = kb[ib];
+    ia = 2 * ia + 1 + (va > ta ? 1 : 0);  // a key above the threshold: everything in front of it is too -- to the right
+    ib = 2 * ib + 1 + (vb > tb ? 1 : 0);
+  }
+  ca = ia - (CS_N - 1);  // the leaf's number = keys above among the first CS_N - 1
+  cb = ib - (CS_N - 1);
+  if (ca == CS_N - 1) ca += ka[CS_N - 1] > ta ? 1 : 0;
+  if (cb == CS_N - 1) cb += kb[CS_N - 1] > tb ? 1 : 0;
 }
 
-template <int GEOM>
-__global__ __launch_bounds__(256) void mc_sort_prepare_p_kernel(
+// workgroup barrier for LDS traffic alone: global loads in flight stay in flight (__syncthreads waits for them: the
+// next group's keys, requested right in front of it, cost 1.2 us of waiting per group)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int GEOM, int PP_C>
+__global__ __launch_bounds__(PP_C * PP_PARTS) void mc_sort_prepare_p_kernel(
     const float* __restrict__ boxes, int n, const int* __restrict__ cand_row, const int* __restrict__ cand_label,
     const float* __restrict__ cand_score, int cand_stride, const int* __restrict__ counts_raw, int cap,
     int* __restrict__ ccounts, const float* __restrict__ scale, BoxRec* __restrict__ recs, size_t recs_stride,
     int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab,
     unsigned* __restrict__ counter, size_t counter_stride, uint4* __restrict__ zero, size_t zero16, int sparts, PSort ps) {
-  __shared__ __attribute__((aligned(16))) unsigned keys[2][PP_PARTS][CS_N];  // 32 KB: score chunks, x chunks
+  // dynamic LDS, 64 KB: [2 buffers][score | x][PP_PARTS chunks][CS_N keys] -- a group of chunks is searched while the next
+  // one lands in the other buffer (one buffer: two barriers per group and the wait for its keys in between, 3.1 us per
+  // group of which 1.3 were the searches)
+  extern __shared__ __attribute__((aligned(16))) unsigned keys_dyn[];
   __shared__ int partial[2][PP_PARTS][PP_C];
+  auto kbuf = [&](const int b, const int o) -> unsigned* { return keys_dyn + (size_t)(b * 2 + o) * PP_PARTS * CS_N; };
   const int img = blockIdx.y, tid = threadIdx.x;
   const int M = min(counts_raw[img], cap);
   if (blockIdx.x == 0 && tid == 0) ccounts[img] = M;
-  for (int k = blockIdx.x * 256 + tid; k < Q_CTL_WORDS; k += gridDim.x * 256) counter[img * counter_stride + k] = 0;
+  constexpr int NTH = PP_C * PP_PARTS;
+  constexpr int LPT = PP_PARTS * CS_N / 4 / NTH;  // 16-byte loads per thread, array and group of chunks
+  for (int k = blockIdx.x * NTH + tid; k < Q_CTL_WORDS; k += gridDim.x * NTH) counter[img * counter_stride + k] = 0;
   const int i0 = blockIdx.x * PP_C;
+  const bool stamp_on = ps.stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  auto stamp = [&](const int k) {
+    if (stamp_on) ps.stamps[k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   if (i0 < M) {
   const size_t cbase = (size_t)img * cand_stride;
   const int ci = tid & (PP_C - 1), part = tid / PP_C;  // (a wavefront = the 64 candidates against one chunk)
@@ -2574,34 +2625,64 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_p_kernel(
   const unsigned* gx = ps.xkeys + img * ps.stride;
   int cnt_s = 0, cnt_x = 0;
   // (the next group of chunks is requested before the current one is searched: 4 chunks x 2 orders = 32 keys per thread)
-  uint4 nxt[2][PP_PARTS];
+  uint4 nxt[2][LPT];
   auto request = [&](const int t0) {
 #pragma unroll
-    for (int q = 0; q < PP_PARTS; q++) {
-      const bool on = t0 + q < nch;
-      nxt[0][q] = on ? reinterpret_cast<const uint4*>(gs + (size_t)(t0 + q) * CS_N)[tid] : make_uint4(0u, 0u, 0u, 0u);
-      nxt[1][q] = on ? reinterpret_cast<const uint4*>(gx + (size_t)(t0 + q) * CS_N)[tid] : make_uint4(0u, 0u, 0u, 0u);
+    for (int q = 0; q < LPT; q++) {
+      const int idx = tid + q * NTH;  // 16-byte element of the group: chunk idx / 256, element idx % 256
+      const bool on = t0 + idx / (CS_N / 4) < nch;
+      nxt[0][q] = on ? reinterpret_cast<const uint4*>(gs + (size_t)t0 * CS_N)[idx] : make_uint4(0u, 0u, 0u, 0u);
+      nxt[1][q] = on ? reinterpret_cast<const uint4*>(gx + (size_t)t0 * CS_N)[idx] : make_uint4(0u, 0u, 0u, 0u);
     }
   };
-  request(0);
-  for (int t0 = 0; t0 < nch; t0 += PP_PARTS) {
-    __syncthreads();
+  // (the workgroups start at different groups of chunks: all of them asking for the same 32 KB at the same time queue
+  // up at the few L2 channels that hold it)
+  const int ngrp = (nch + PP_PARTS - 1) / PP_PARTS;
+  const int rot = (int)(blockIdx.x % (unsigned)ngrp);
+  auto group_of = [&](const int g) { const int x = g + rot; return (x >= ngrp ? x - ngrp : x) * PP_PARTS; };
+  auto store = [&](const int b) {
 #pragma unroll
-    for (int q = 0; q < PP_PARTS; q++) {
-      reinterpret_cast<uint4*>(keys[0][q])[tid] = nxt[0][q];
-      reinterpret_cast<uint4*>(keys[1][q])[tid] = nxt[1][q];
+    for (int q = 0; q < LPT; q++) {
+      reinterpret_cast<uint4*>(kbuf(b, 0))[tid + q * NTH] = nxt[0][q];
+      reinterpret_cast<uint4*>(kbuf(b, 1))[tid + q * NTH] = nxt[1][q];
     }
-    if (t0 + PP_PARTS < nch) request(t0 + PP_PARTS);
-    __syncthreads();
+  };
+  stamp(1);
+  request(group_of(0));
+  // (the candidate's record is built by its first thread BEFORE the ranks are known, under the first keys' flight -- box, class offset, trigonometry:
+  // two dependent trips to memory that used to follow the searches -- and only stored behind them)
+  BoxRec rec;
+  bool rec_dead = false;
+  int rec_label = 0;
+  if (part == 0 && has)
+    mc_build_record<GEOM>(boxes, n, cand_row, cand_label, cbase, c, img, scale, sparts, rec, rec_dead, rec_label);
+  store(0);
+  if (ngrp > 1) request(group_of(1));
+  lds_barrier();
+  stamp(2);
+  for (int g = 0; g < ngrp; g++) {
+    const int t0 = group_of(g);
+    if (g == 2) stamp(5);
+    if (g + 1 < ngrp) {
+      store((g + 1) & 1);  // (last searched in the previous turn, behind its barrier)
+      if (g + 2 < ngrp) request(group_of(g + 2));
+    }
+    if (g == 2) stamp(6);
     const int t = t0 + part;
     if (t < nch && t != own) {
       // chunks in front of the candidate's own count ties (their candidates come first), chunks behind it do not:
       // keys >= u  <=>  keys > u - 1 (a candidate's key is never 0)
       const unsigned dec = t < own ? 1u : 0u;
-      cnt_s += chunk_count_above(keys[0][part], us - dec);
-      cnt_x += chunk_count_above(keys[1][part], ux - dec);
+      int a_s, a_x;
+      chunk_counts_above(kbuf(g & 1, 0) + part * CS_N, us - dec, kbuf(g & 1, 1) + part * CS_N, ux - dec, a_s, a_x);
+      cnt_s += a_s;
+      cnt_x += a_x;
     }
+    if (g == 2) stamp(7);
+    lds_barrier();
+    if (g == 2) stamp(8);
   }
+  stamp(3);
   partial[0][part][ci] = cnt_s;
   partial[1][part][ci] = cnt_x;
   __syncthreads();
@@ -2612,17 +2693,36 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_p_kernel(
     pos += partial[0][q][tid];
     slot += partial[1][q][tid];
   }
-  float rj[4];
-  mc_place_record<GEOM>(boxes, n, cand_row, cand_label, cbase, c, pos, img, scale, sparts, recs, recs_stride,
-                        sorted_vals, dead, rlab, rj);
+  mc_store_record<GEOM>(rec, rec_dead, rec_label, c, pos, img, recs, recs_stride, sorted_vals, dead, rlab);
+  const float rj[4] = {rec.f[9], rec.f[10], rec.f[12], rec.f[13]};  // (what the stream kernel's axis-aligned test reads)
   ps.perm[img * ps.stride + slot] = (unsigned short)pos;
-  int* rg = reinterpret_cast<int*>(ps.ranges + img * ps.rstride + (slot >> 6));
-  atomicMin(rg + 0, ordered_int(rj[0] - rj[2]));
-  atomicMax(rg + 1, ordered_int(rj[0] + rj[2]));
-  atomicMin(rg + 2, ordered_int(rj[1] - rj[3]));
-  atomicMax(rg + 3, ordered_int(rj[1] + rj[3]));
+  // (the extents of every 64 slots come from these in mc_ranges_kernel.  Collected here with atomicMin / atomicMax they
+  // were 14 of this kernel's 31 us at 32 768 candidates: a group's 64 candidates sit in 64 workgroups that all finish
+  // together, and their 256 atomics on one 16-byte line are served one after the other)
+  ps.slotbox[img * ps.stride + slot] = make_float4(rj[0] - rj[2], rj[0] + rj[2], rj[1] - rj[3], rj[1] + rj[3]);
   }
+  stamp(4);
   }
+}
+
+// the extents of every 64 slots of P: a wavefront per group, a lane per slot (fminf / fmaxf drop a NaN: such a box has no
+// pair that matters, and the others' extent stands)
+__global__ __launch_bounds__(256) void mc_ranges_kernel(const int* __restrict__ counts, PSort ps) {
+  const int img = blockIdx.y, lane = threadIdx.x & 63;
+  const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int M = counts[img];  // (the clamped counts: written by the ranking kernel)
+  if (grp * TILE >= M) return;
+  const int slot = grp * TILE + lane;
+  const float inf = __builtin_inff();
+  float4 v = slot < M ? ps.slotbox[img * ps.stride + slot] : make_float4(inf, -inf, inf, -inf);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    v.x = fminf(v.x, __shfl_xor(v.x, d));
+    v.y = fmaxf(v.y, __shfl_xor(v.y, d));
+    v.z = fminf(v.z, __shfl_xor(v.z, d));
+    v.w = fmaxf(v.w, __shfl_xor(v.w, d));
+  }
+  if (lane == 0) ps.ranges[img * ps.rstride + grp] = v;
 }
 
 // Where the finish kernels write.  List form (the reference's return values, bbox_nms_rotated.py:127-131): dets
@@ -2839,9 +2939,10 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* p_xl = take((size_t)B * capR * 2);
   char* p_pm = take((size_t)B * capR * 2);
   char* p_rg = take((size_t)B * (capR / TILE) * 16);
+  char* p_sb = take((size_t)B * capR * 16);
   if (L) {
     L->ps = PSort{(unsigned*)p_sk, (unsigned*)p_xk, (unsigned*)p_xr, (unsigned short*)p_sl, (unsigned short*)p_xl,
-                  (unsigned short*)p_pm, (int4*)p_rg, capR, capR / TILE};
+                  (unsigned short*)p_pm, (float4*)p_rg, (float4*)p_sb, capR, capR / TILE, nullptr};
     L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
     L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->redo = (unsigned*)rd; L->keep = (int64_t*)keep;
     L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->rlab = (uint8_t*)rlab; L->kbits = (u64*)kbits; L->fbits = (u64*)fbits; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
@@ -2918,8 +3019,12 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   // the fill runs at memory speed)
   const bool big_pool = cap > 16384;  // (the ranking loop with 4 candidates per thread: mc_sort_prepare_kernel<., 4>)
   const int nms_impl0 = g_r3_nms_impl;  // (one read per call)
+  L.ps.stamps = g_nms_stamps ? g_nms_stamps + 48 : nullptr;
   const bool use_p = (cap > P_MIN_CAP && nms_impl0 != 7) || nms_impl0 == 6;  // the sorted-chunk form
-  const dim3 csgrid((unsigned)(L.ps.stride / CS_N) + CS_FILL_WGS, B), ppgrid((cap + PP_C - 1) / PP_C, B);
+  // (its ranking kernel's 64 KB of dynamic LDS + 2 KB static are beyond the default cap: the opt-in, once per device and geometry)
+  static R3DeviceOnce pp_once[3];
+  const bool pp_raise = use_p && pp_once[geom - 1].first();
+  const dim3 csgrid((unsigned)(L.ps.stride / CS_N) + CS_FILL_WGS, B), ppgrid((cap + PP_CANDS - 1) / PP_CANDS, B);
   // (the stream kernel of that form: a wavefront looks at up to 64 tiles of the cb x cb square; small squares take fewer
   // per wavefront so that ~2048 wavefronts share the work)
   const long long ptiles = (long long)L.cb * L.cb;
@@ -2940,10 +3045,16 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     hipLaunchKernelGGL((mc_chunk_sort_kernel<GEOM>), csgrid, dim3(CS_N), 0, stream, boxes, n, cand_row, cand_label, \
                        cand_score, S, counts, cap, SCALE, scale_parts, L.ps, reinterpret_cast<uint4*>(L.mask),      \
                        L.zero_bytes / 16, (int)(L.ps.stride / CS_N));                                               \
-    hipLaunchKernelGGL((mc_sort_prepare_p_kernel<GEOM>), ppgrid, dim3(256), 0, stream, boxes, n, cand_row,         \
+    if (pp_raise)                                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mc_sort_prepare_p_kernel<GEOM, PP_CANDS>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS_BYTES);                     \
+    hipLaunchKernelGGL((mc_sort_prepare_p_kernel<GEOM, PP_CANDS>), ppgrid, dim3(PP_CANDS * PP_PARTS), PP_LDS_BYTES, stream, \
+                       boxes, n, cand_row,                                                                          \
                        cand_label, cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead,  \
                        L.rlab, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
                        scale_parts, L.ps);                                                                          \
+    hipLaunchKernelGGL(mc_ranges_kernel, dim3((unsigned)(L.ps.rstride + 3) / 4, B), dim3(256), 0, stream,           \
+                       L.ccounts, L.ps);                                                                            \
     hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL, true>), pstream_grid, dim3(NT), 0, stream, L.recs, 0, L.cb,  \
                        L.gqueue, (unsigned)L.qcap, L.counter, L.redo, bt, L.ps.perm, L.ps.ranges, L.ps.stride,      \
                        L.ps.rstride);                                                                               \
