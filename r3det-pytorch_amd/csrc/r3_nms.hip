@@ -264,7 +264,8 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
                                                         unsigned* __restrict__ counter, unsigned* __restrict__ redo,
                                                         Batch bt, const unsigned short* __restrict__ perm = nullptr,
                                                         const float4* __restrict__ ranges = nullptr,
-                                                        size_t perm_stride = 0, size_t ranges_stride = 0) {
+                                                        size_t perm_stride = 0, size_t ranges_stride = 0,
+                                                        int tile_waves = 0) {
   __shared__ __attribute__((aligned(16))) float4 colsA[MASK_WAVES][TILE];  // cx, cy, ex, ey
   __shared__ float2 colsB[MASK_WAVES][TILE];                               // radius, label
   __shared__ unsigned short queue[MASK_WAVES][SQ_WSEG];
@@ -388,14 +389,20 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
     tile(rb0, cblk);
     return;
   }
-  const int nwaves = (int)gridDim.x * MASK_WAVES, wv = (int)blockIdx.x * MASK_WAVES + wave;
-  const long long t = (long long)lane * nwaves + wv;
-  bool live = t < (long long)cbn * cbn;
+  // Tiles are numbered DIAGONAL BY DIAGONAL (t = (column chunk - row chunk) * cbn + row chunk): in x order the tiles
+  // that remain hug the diagonal, so they are the first few cbn numbers and t = lane * waves + wave index deals them out
+  // evenly.  (Row by row, the diagonal's tiles are cbn + 1 apart and pile up on the wavefronts whose count shares a
+  // factor with that: cbn = 191 and 2048 wavefronts left 288 busy with six dense tiles each -- 50 us instead of 13.)
+  const int nwaves = tile_waves, wv = (int)blockIdx.x * MASK_WAVES + wave;
+  if (wv >= nwaves) return;
+  const unsigned t = (unsigned)lane * (unsigned)nwaves + (unsigned)wv;  // (cbn <= 1024: below 2^20 + 64 * waves)
+  bool live = t < (unsigned)(cbn * cbn);
   int trb = 0, tcb = 0;
   if (live) {
-    trb = (int)(t / cbn);
-    tcb = (int)(t - (long long)trb * cbn);
-    live = trb <= tcb;
+    const int d = (int)(t / (unsigned)cbn);
+    trb = (int)(t - (unsigned)d * (unsigned)cbn);
+    tcb = trb + d;
+    live = tcb < cbn;
   }
   if (live && trb != tcb) {  // (a NaN extent compares false: the tile is kept)
     const float4 ra = ranges[trb], rc = ranges[tcb];
@@ -2435,7 +2442,7 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
 
 // ---------------------------------------------------------------------------- large pools: sorted chunks (round 6)
 // Rank by counting is M^2 compares and the stream kernel's tile loop M^2 / 2 box tests: at M = 32 768 they were 100 and
-// 150 us of the call's 530.  Beyond P_MIN_CAP candidates (option nms_impl 6: always, 7: never) the pipeline runs on
+// 150 us of the call's 530.  Beyond P_MIN_CAP = 10 240 candidates (option nms_impl 6: always, 7: never) the pipeline runs on
 // SORTED CHUNKS instead:
 //   mc_chunk_sort_kernel   a workgroup sorts 1024 candidates twice in LDS (bitonic, both sorts side by side): by score
 //                          and by the x of the box centre as the kernels see it (class offsets applied), and leaves the
@@ -2450,7 +2457,7 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
 //                          the diagonal and the boxes of a class spread over the image, 1-2 % of the tiles remain.
 // The drain's redo tiles (a tile too dense for its queue segment) name chunks of P and are enumerated through P.
 constexpr int CS_N = 1024;           // candidates per sorted chunk
-constexpr int P_MIN_CAP = 12288;     // pools above this take the sorted-chunk form (measured: see DESIGN 4.2)
+constexpr int P_MIN_CAP = 10240;     // pools above this take the sorted-chunk form (measured, per call: 8576 99 ↔ 108 us, 10 240 106 ↔ 108, 12 211 129 ↔ 120, 16 384 173 ↔ 134)
 #ifndef R3_PP_C
 #define R3_PP_C 64
 #endif
@@ -3026,9 +3033,9 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   const bool pp_raise = use_p && pp_once[geom - 1].first();
   const dim3 csgrid((unsigned)(L.ps.stride / CS_N) + CS_FILL_WGS, B), ppgrid((cap + PP_CANDS - 1) / PP_CANDS, B);
   // (the stream kernel of that form: a wavefront looks at up to 64 tiles of the cb x cb square; small squares take fewer
-  // per wavefront so that ~2048 wavefronts share the work)
+  // per wavefront so that ~4096 wavefronts share the work)
   const long long ptiles = (long long)L.cb * L.cb;
-  const long long pwaves = std::max((ptiles + 63) / 64, std::min(ptiles, (long long)2048));
+  const long long pwaves = std::max((ptiles + 63) / 64, std::min(ptiles, (long long)4096));
   const dim3 pstream_grid((unsigned)((pwaves + MASK_WAVES - 1) / MASK_WAVES), 1, B);
   const int pwc = big_pool ? RP_C * 4 : RP_C;
   const dim3 pgrid((cap + pwc - 1) / pwc, B), grid((L.cb + MASK_WAVES - 1) / MASK_WAVES, L.cb, B);
@@ -3057,7 +3064,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
                        L.ccounts, L.ps);                                                                            \
     hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL, true>), pstream_grid, dim3(NT), 0, stream, L.recs, 0, L.cb,  \
                        L.gqueue, (unsigned)L.qcap, L.counter, L.redo, bt, L.ps.perm, L.ps.ranges, L.ps.stride,      \
-                       L.ps.rstride);                                                                               \
+                       L.ps.rstride, (int)pwaves);                                                                  \
   } else {                                                                                                         \
   if (big_pool)                                                                                                    \
     hipLaunchKernelGGL((mc_sort_prepare_kernel<GEOM, 4>), pgrid, dim3(256), 0, stream, boxes, n, cand_row,         \

@@ -356,7 +356,7 @@ def reducer(request):
     """nms_impl 4: one wavefront per (image, label group) walks its rows in score order (nms_reduce_walk_kernel, round 5:
     measured, not the default); 0: the dependency-round reducer.  Greedy NMS has one answer: both must give it.
     6 (round 6): the sorted-chunk form of the front of the pipeline -- ranks by binary search in sorted chunks, the
-    pair tests over the candidates in x order with whole tiles skipped by their extents -- which pools beyond 12 288
+    pair tests over the candidates in x order with whole tiles skipped by their extents -- which pools beyond 10 240
     candidates take by themselves, forced here on small ones: same records, same queue contents, same answer."""
     from r3det import _C
     _C.set_option("nms_impl", request.param)

@@ -368,7 +368,7 @@ def test_one_call_form_at_32768_rows_exact_vs_the_twin_oracle():
 @pytest.mark.parametrize("version", ["v1", "v3"])
 @pytest.mark.parametrize("n", [100, 1030, 5000, 13000])
 def test_sorted_chunk_form_equals_the_counting_form(version, n):
-    """Round 6: beyond 12 288 candidates the batched pipeline ranks by binary search in sorted 1024-chunks and tests pairs
+    """Round 6: beyond 10 240 candidates the batched pipeline ranks by binary search in sorted 1024-chunks and tests pairs
     over the candidates in x order (mc_chunk_sort_kernel, mc_sort_prepare_p_kernel, nms_stream_kernel<.., true>); option
     nms_impl 6 forces that form, 7 forbids it.  Ties in the scores, labels whose offsets leave the classes touching
     (boxes wider than the image), a count that is no multiple of 64 or 1024: keep lists and rows identical."""
