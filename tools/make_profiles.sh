@@ -42,13 +42,22 @@ unset IOU_PROF_SHAPE
 python3 $R/tools/iou_prepared_ab.py > $O/${TAG}_iou_prepared_ab.txt 2>&1
 # 5. NMS op, per size, and the batched pipeline
 : > $O/${TAG}_nms_kernel_stats.txt
-for n in 2000 5344 8576 32768 v3_8576; do
+for n in 2000 5344 8576 16384 32768 v3_8576; do
   export NMS_PROF_N=$n
   kt /tmp/kt_one.txt "python3 tools/nms_prof.py  (NMS_PROF_N=$n)" python3 $R/tools/nms_prof.py
   cat /tmp/kt_one.txt >> $O/${TAG}_nms_kernel_stats.txt
   python3 $R/tools/kstats.py /tmp/kt_run nms_ mc_ fill >> $O/${TAG}_nms_kernel_stats.txt
 done
 unset NMS_PROF_N
+# 5b. round 6, large pools: the sorted-chunk form (nms_impl 6) against the counting form (7) per size, no profiler; the
+#     suppressor counts of those pools; the reducer's and the ranking kernel's phase stamps at 32 768 rows (probe build)
+cd $R
+{ for n in 8576 10240 12288 14336 16384 20000 24576 32768; do for impl in 7 6; do echo -n "nms_impl $impl: "; NMS_PROF_nms_impl=$impl NMS_PROF_N=$n python3 tools/nms_prof.py 2>&1 | grep batched; done; done; } > $O/${TAG}_nms_sorted_chunks_ab.txt
+python3 tools/nms_suppressor_stats.py 8576 16384 32768 2>&1 | grep "^n=" > $O/${TAG}_nms_suppressors.txt
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I r3det-pytorch_amd/csrc -I include -o /tmp/nrp tools/probes/nms_reduce_probe.hip > /dev/null 2>&1
+DUMP_POOL=/tmp/pool32k.bin NMS_PROF_N=32768 python3 tools/nms_prof.py > /dev/null 2>&1
+{ echo "# tools/probes/nms_reduce_probe 32768 <the pool of tools/nms_prof.py> <label group>: s_memtime stamps of one reducer workgroup and of workgroup 0 of the ranking kernel"; for g in 0 5 9; do echo "# label group $g"; /tmp/nrp 32768 /tmp/pool32k.bin $g 2>&1 | tail -8; done; } > $O/${TAG}_nms_reduce_stamps.txt
+cd /tmp
 # 6. the roofline kernel alone (rotating buffers) + its PMC traffic passes
 kt $O/${TAG}_fr_nhwc_kernel_stats.txt "python3 tools/fr_nhwc_prof.py" python3 $R/tools/fr_nhwc_prof.py
 python3 $R/tools/kstats.py /tmp/kt_run fr_forward >> $O/${TAG}_fr_nhwc_kernel_stats.txt
