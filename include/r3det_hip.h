@@ -592,7 +592,9 @@ int r3det_bias_act(float* y, const float* bias, const float* residual, long long
  *   ("iou_small", columns from which the pipeline runs), ("iou_qcap", n: per-wave survivor capacity, small values
  *   force the dense-tile path), ("iou_dwgs", drain workgroups), ("nms_impl", 0 | 1 tiles | 2 one reducer workgroup | 4 the batched
  *   pipeline's reducer as a walk in score order, one wavefront per image and label group | 5 the candidate selection as
- *   the two launches of rounds 2-4 (count, then write) instead of one),
+ *   the two launches of rounds 2-4 (count, then write) instead of one | 6 the batched pipeline's sorted-chunk form
+ *   (ranks by search in sorted 1024-chunks, pair tests in x order with tiles dropped by their extents) whatever the pool's
+ *   size | 7 never that form; by itself it runs beyond 10 240 candidates; same results),
  *   ("nms_qcap", n: entries per queue region, small values force the redo-tile path),
  *   ("clip_impl", 0 the straight-line v1 pair clip of the drains (round 5, csrc/r3_clip.h) | 1 the LDS-list form of
  *                 rounds 2-4: same results bit for bit, kept for the A/B in tools/clip_ab.sh),
