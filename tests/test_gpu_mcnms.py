@@ -331,8 +331,20 @@ def test_padded_form_equals_the_lists_and_the_reference_golden(max_num, nms_type
         assert torch.equal(d, d2) and torch.equal(lab, lab2)
 
 
-def test_padded_form_flags_a_short_capacity_and_recovers(nms_type):
+@pytest.mark.parametrize("front", [0, 6], ids=["counting", "sorted-chunks"])
+def test_padded_form_flags_a_short_capacity_and_recovers(nms_type, front):
+    """(front 6: the sorted-chunk form of ranking and pair tests forced on these small pools -- an image with more
+    candidates than the capacity is its first `cap` candidates there too)"""
+    from r3det import _C
     from r3det.core.post_processing import PaddedNms, multiclass_nms_rotated_batch
+    _C.set_option("nms_impl", front)
+    try:
+        _short_capacity(nms_type, PaddedNms, multiclass_nms_rotated_batch)
+    finally:
+        _C.set_option("nms_impl", 0)
+
+
+def _short_capacity(nms_type, PaddedNms, multiclass_nms_rotated_batch):
     boxes, scores = pools(2, 3000, 77)
     cfg = dict(type=nms_type, iou_thr=0.1)
     n_cand = (scores[..., :-1] > 0.05).flatten(1).sum(1)
