@@ -426,6 +426,23 @@ def test_sorted_chunk_form_on_a_dense_cluster_takes_the_redo_tiles():
     assert np.array_equal(got[6][1].cpu().numpy(), want)
 
 
+def test_sorted_chunk_form_fuzz():
+    """tools/nms_fuzz.py, 40 random pools (sizes 1 .. 20 000, 1 .. 40 classes, spread / clustered / piled / oversized
+    boxes, NaN / inf / zero entries, tied scores), v1 and v3 entries: nms_impl 6 and 7 give identical rows."""
+    import os
+    import runpy
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "nms_fuzz.py")
+    argv = sys.argv
+    sys.argv = [tool, "40", "5"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            runpy.run_path(tool, run_name="__main__")
+        assert e.value.code == 0
+    finally:
+        sys.argv = argv
+
+
 @pytest.mark.parametrize("version", ["v1", "v3"])
 def test_padded_one_pool_form_equals_the_list_form(version):
     """batched_rnms_padded: the one library call of batched_rnms / obb_batched_nms without the host read of the count --
