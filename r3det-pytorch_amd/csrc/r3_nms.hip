@@ -1004,8 +1004,9 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       int xs[RPT], xl[RPT];
       unsigned short* ext = blist;  // (the long-row worklist of the general form: unused here)
       // one such row: a wavefront, lanes <-> mask words -- counts the entries, reserves their place in ext, writes them
-      auto convert_rows = [&](const int (&rowi)[8], const int (&srcl)[8], int (&res_base)[8], int (&res_total)[8]) {
-        constexpr int OB = 8;
+      constexpr int CVB = 8;  // overflow rows a wavefront converts together
+      auto convert_rows = [&](const int (&rowi)[CVB], const int (&srcl)[CVB], int (&res_base)[CVB], int (&res_total)[CVB]) {
+        constexpr int OB = CVB;
         u64 w0d[OB];
 #pragma unroll
         for (int b = 0; b < OB; b++) {
@@ -1058,88 +1059,102 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       // (round 5, second half) The rows are ENLISTED for the whole workgroup and converted by all sixteen wavefronts, eight
       // rows per step each: a 218-row class lives in the first four wavefronts, which converted its 71 overflow rows alone
       // (18 rows per wavefront, ~1000 cycles each: 45-73 k cycles in front of the first round on the bench model's pool).
-      int myov[RPT];
+      // Round 6: a look at the HEADS first.  A heavy row is nearly always a member of a cluster whose head -- its
+      // highest-scored suppressor -- has no suppressor itself and is kept from the start: such a row is removed here,
+      // before anything is converted.  Converting every row with more than 32 suppressors, the model's own pool paid 17 k
+      // clocks in its heaviest label group (322 such rows in the image) for lists of which a handful were ever read.
 #pragma unroll
       for (int u = 0; u < RPT; u++) {
-        xs[u] = 0;
+        xs[u] = -1;  // ("cannot be kept yet": overwritten by the conversion)
         xl[u] = 0;
-        myov[u] = -1;
-        const bool want = state[u] == 0 && c[u] > EL;
-        const u64 need = __ballot(want);
-        if (need) {
-          int base = 0;
-          if (lane == 0) base = atomicAdd(s_m, __popcll(need));
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (want) {
-            const int e = base + __popcll(need & ((1ULL << lane) - 1ULL));
-            if (e < OVQ) {
-              ovq[e] = (unsigned short)rr[u];
-              myov[u] = e;
-            } else {
-              myov[u] = -2;  // (no room on the list: this wavefront converts it itself below)
-            }
-          }
-        }
-      }
-      __syncthreads();
-      {
-        const int nov = min(*s_m, OVQ);
-        for (int e0 = wave * 8; e0 < nov; e0 += (RTHREADS / 64) * 8) {
-          int rowi[8], srcl[8], rb[8], rt[8];
-#pragma unroll
-          for (int b = 0; b < 8; b++) {
-            srcl[b] = e0 + b < nov ? 0 : -1;
-            rowi[b] = e0 + b < nov ? (int)ovq[e0 + b] : 0;
-          }
-          convert_rows(rowi, srcl, rb, rt);
-          if (lane < 8 && e0 + lane < nov) {
-            int vb = rb[0], vt = rt[0];
-#pragma unroll
-            for (int b = 1; b < 8; b++) {
-              vb = lane == b ? rb[b] : vb;
-              vt = lane == b ? rt[b] : vt;
-            }
-            ovx[e0 + lane] = vb;
-            ovl[e0 + lane] = vt;
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < RPT; u++) {
-        if (myov[u] >= 0) {
-          xs[u] = ovx[myov[u]];
-          xl[u] = ovl[myov[u]];
-        }
-        u64 need = __ballot(myov[u] == -2);  // (beyond the list's capacity: the owner's wavefront, as before)
-        while (need) {
-          int srcl[8], rowi[8], rb[8], rt[8];
-#pragma unroll
-          for (int b = 0; b < 8; b++) {
-            srcl[b] = need ? __builtin_ctzll(need) : -1;
-            need &= need - 1;  // (0 stays 0)
-            rowi[b] = srcl[b] >= 0 ? __shfl(rr[u], srcl[b]) : 0;
-          }
-          convert_rows(rowi, srcl, rb, rt);
-#pragma unroll
-          for (int b = 0; b < 8; b++)
-            if (srcl[b] >= 0 && lane == srcl[b]) {
-              xs[u] = rb[b];
-              xl[u] = rt[b];
-            }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < RPT; u++) {
         if (state[u] == 0 && c[u] == 0) state[u] = 1;
         if (state[u] != 3) st[rr[u]] = (unsigned char)state[u];
       }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < RPT; u++)
+        if (state[u] == 0 && ms[u] < 65535u && st[ms[u]] == 1) {
+          state[u] = 2;
+          st[rr[u]] = 2;
+        }
+      auto convert_undecided = [&]() {
+      int myov[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+          myov[u] = -1;
+          const bool want = state[u] == 0 && c[u] > EL;
+          const u64 need = __ballot(want);
+          if (need) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(s_m, __popcll(need));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (want) {
+              const int e = base + __popcll(need & ((1ULL << lane) - 1ULL));
+              if (e < OVQ) {
+                ovq[e] = (unsigned short)rr[u];
+                myov[u] = e;
+              } else {
+                myov[u] = -2;  // (no room on the list: this wavefront converts it itself below)
+              }
+            }
+          }
+        }
+        __syncthreads();
+        {
+          const int nov = min(*s_m, OVQ);
+          for (int e0 = wave * CVB; e0 < nov; e0 += (RTHREADS / 64) * CVB) {
+            int rowi[CVB], srcl[CVB], rb[CVB], rt[CVB];
+#pragma unroll
+            for (int b = 0; b < CVB; b++) {
+              srcl[b] = e0 + b < nov ? 0 : -1;
+              rowi[b] = e0 + b < nov ? (int)ovq[e0 + b] : 0;
+            }
+            convert_rows(rowi, srcl, rb, rt);
+            if (lane < CVB && e0 + lane < nov) {
+              int vb = rb[0], vt = rt[0];
+#pragma unroll
+              for (int b = 1; b < CVB; b++) {
+                vb = lane == b ? rb[b] : vb;
+                vt = lane == b ? rt[b] : vt;
+              }
+              ovx[e0 + lane] = vb;
+              ovl[e0 + lane] = vt;
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+          if (myov[u] >= 0) {
+            xs[u] = ovx[myov[u]];
+            xl[u] = ovl[myov[u]];
+          }
+          u64 need = __ballot(myov[u] == -2);  // (beyond the list's capacity: the owner's wavefront, as before)
+          while (need) {
+            int srcl[CVB], rowi[CVB], rb[CVB], rt[CVB];
+#pragma unroll
+            for (int b = 0; b < CVB; b++) {
+              srcl[b] = need ? __builtin_ctzll(need) : -1;
+              need &= need - 1;  // (0 stays 0)
+              rowi[b] = srcl[b] >= 0 ? __shfl(rr[u], srcl[b]) : 0;
+            }
+            convert_rows(rowi, srcl, rb, rt);
+#pragma unroll
+            for (int b = 0; b < CVB; b++)
+              if (srcl[b] >= 0 && lane == srcl[b]) {
+                xs[u] = rb[b];
+                xl[u] = rt[b];
+              }
+          }
+        }
+      };
       __syncthreads();
       stamp(2);
       // (no K / R bit sets in this loop: 64 lanes deciding rows of one or two mask words are 64 same-address LDS
       // atomics; the sets are rebuilt from the state bytes once, behind the loop)
       int rnd = 0, left_before = -1;
-      for (;; rnd++) {
+      // one round; true: the loop is over (every row decided, or stuck / out of budget: rnd = R_MAX_ROUNDS, the tail below)
+      auto one_round = [&]() -> bool {
         bool und = false;
         if (stamp_on && rnd < 8) stamps[16 + 4 * rnd] = __builtin_amdgcn_s_memtime();
         // What a round costs is LDS reads of scattered state bytes (bank conflicts: ~12 cycles per wave read, 16 waves
@@ -1223,9 +1238,24 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
 #pragma unroll
         for (int w = 0; w < RTHREADS / 64; w++) left += wtab2[(rnd & 1) * 16 + w];
         if (stamp_on && rnd < 8) stamps[19 + 4 * rnd] = __builtin_amdgcn_s_memtime();
-        if (left == 0) break;                                                     // every row decided
-        if (left == left_before || rnd >= R_MAX_ROUNDS) { rnd = R_MAX_ROUNDS; break; }  // stuck or out of budget: the tail below
+        if (left == 0) return true;                                               // every row decided
+        if (left == left_before || rnd >= R_MAX_ROUNDS) { rnd = R_MAX_ROUNDS; return true; }  // stuck or out of budget
         left_before = left;
+        return false;
+      };
+      // Round 0 runs on the lists alone (a row with more than 32 suppressors can be removed by what its list shows, not
+      // kept); the rows still undecided are converted then, the lists -- not needed across the conversion, whose eight
+      // mask rows per wavefront want the registers -- are fetched again (L2), and the rounds go on.  Converted up front,
+      // the model's own pool paid 17 k clocks in its heaviest label group for lists of which a handful were ever read.
+      if (!one_round()) {
+        rnd = 1;
+        convert_undecided();
+#pragma unroll
+        for (int u = 0; u < RPT; u++) {
+          const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)rr[u] * EL);
+          t[u][0] = lp[0]; t[u][1] = lp[1]; t[u][2] = lp[2]; t[u][3] = lp[3];
+        }
+        while (!one_round()) rnd++;
       }
       // K / R as bits, from the state bytes of this workgroup's rows (8 bytes at a time: byte == 1 / == 2 -> one bit)
       for (int b = tid; b < cbn; b += RTHREADS) {
