@@ -66,6 +66,10 @@ struct Batch {
   size_t redo;  // stride of the redo-tile lists
   size_t rows;  // row capacity of one image's arrays (= n for a single problem); `nz` = stride of the side tables
   const uint8_t* rlab;  // batched runs: label of every sorted row (stride `rows`), or nullptr
+  u64* gbits;           // batched runs: per image RG_GROUPS bitmaps of cb words -- bit p of bitmap g: sorted row p has label
+                        // group g -- or nullptr.  Written for the reducer: by the stream kernel's diagonal tiles (a
+                        // word per 64 rows and group, plain stores) or, in the sorted-chunk form, by the ranking
+                        // kernel (atomicOr into words the chunk-sort kernel zeroed)
 };
 
 inline Batch single_problem(int n) {
@@ -289,6 +293,19 @@ __global__ __launch_bounds__(NT) void nms_stream_kernel(const BoxRec* __restrict
   const int cbn = (n + TILE - 1) / TILE;
   // one tile (waves are independent: no workgroup barrier in here)
   auto tile = [&](const int rb, const int cblk) {
+  if (!PERM && rb == cblk && bt.counts && bt.gbits && bt.rlab) {
+    // the diagonal tile of a block of 64 rows also leaves the block's word of every label group's row bitmap (what the
+    // reducer's workgroups start from): 16 ballots, a plain store by lane g -- every word written once, nothing to zero
+    const int r = rb * TILE + lane;
+    const int lg = r < n ? (int)(bt.rlab[(size_t)blockIdx.z * bt.rows + r] & (RG_GROUPS - 1)) : -1;
+    u64 mine = 0;
+#pragma unroll
+    for (int g = 0; g < RG_GROUPS; g++) {
+      const u64 mg = __ballot(lg == g);
+      if (lane == g) mine = mg;
+    }
+    if (lane < RG_GROUPS) bt.gbits[((size_t)blockIdx.z * RG_GROUPS + lane) * cb + rb] = mine;
+  }
   const int col_size = min(n - cblk * TILE, TILE);
   int pcol_l = cblk * TILE + lane;
   if (PERM) {
@@ -853,9 +870,9 @@ __host__ __device__ inline size_t reduce_groups_lds_bytes(int n, int cb, bool wi
 
 u64* g_nms_stamps = nullptr;  // tools/probes/nms_reduce_probe.hip: clock stamps of reducer workgroup (0, 0) at its phases
 
-template <bool GROUPED, int TRIPS>
+template <bool GROUPED>
 __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT, const Side& sd, const int n,
-                                                   const int bt_rows, const int cb, const uint8_t* __restrict__ rlab,
+                                                   const int bt_rows, const int cb, const u64* __restrict__ gbm,
                                                    const int group,
                                                    u64* __restrict__ kbits, const int* __restrict__ svals,
                                                    u64* __restrict__ fbits, unsigned char* smem8, int* s_und,
@@ -890,72 +907,32 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   __syncthreads();
   int m = n;
   if (GROUPED) {
-    // ordered compaction of the label's rows: every thread's labels requested together (a trip per 1024 rows with
-    // its own load and two barriers made this the longest phase of the kernel: nine dependent L2 round trips at
-    // n = 8576), the wave masks kept in registers, ONE table of wave counts, ranks from it
-    // (TRIPS = row capacity / 1024: 16 up to 16 384 rows, 32 up to 32 768 -- round 6: one workgroup for all of a 32 768-row
-    // pool was 190 us of its 530)
-    unsigned char lb[TRIPS];
-#pragma unroll
-    for (int u = 0; u < TRIPS; u++) {
-      const int r = u * RTHREADS + tid;
-      lb[u] = r < n ? rlab[r] : (unsigned char)0;
-    }
-    u64 mbs[TRIPS];
-    unsigned short* wtab = blist;  // [TRIPS][16] wave counts (the worklist is not in use yet)
-#pragma unroll
-    for (int u = 0; u < TRIPS; u++) {
-      const int r = u * RTHREADS + tid;
-      const bool mine = r < n && (lb[u] & (RG_GROUPS - 1)) == group;
-      mbs[u] = __ballot(mine);
-      if (lane == 0 && u * RTHREADS < n) {
-        wtab[u * 16 + wave] = (unsigned short)__popcll(mbs[u]);
-        if (mbs[u]) Own[r >> 6] = mbs[u];  // (a wave's 64 rows are one mask word)
-      }
-    }
-    __syncthreads();
-    // exclusive scan over the (trip, wave) table, by every wave for itself: lane l takes entries 4l .. 4l+3 (one
-    // 8-byte LDS read), six shuffle steps, and the wave's 16 bases come back through readlane -- 16 LDS reads per
-    // thread and trip (the first form of this loop) were 10 us of the kernel (tools/probes/nms_reduce_probe.hip)
-    const int trips = (n + RTHREADS - 1) / RTHREADS;
-    constexpr int EPL = TRIPS / 4;  // table entries per lane: 4 (one 8-byte LDS read) or 8 (16 bytes)
-    int ent[EPL];
-    {
-      unsigned wd[EPL / 2];
-      const bool on = EPL * lane < trips * 16;  // (a lane's entries belong to one trip)
-      if (EPL == 4) {
-        const uint2 q4 = on ? reinterpret_cast<const uint2*>(wtab)[lane] : make_uint2(0u, 0u);
-        wd[0] = q4.x; wd[1] = q4.y;
-      } else {
-        const uint4 q8 = on ? reinterpret_cast<const uint4*>(wtab)[lane] : make_uint4(0u, 0u, 0u, 0u);
-        wd[0] = q8.x; wd[1] = q8.y; wd[EPL / 2 - 2] = q8.z; wd[EPL / 2 - 1] = q8.w;
-      }
-#pragma unroll
-      for (int q = 0; q < EPL; q++) ent[q] = (int)((wd[q >> 1] >> ((q & 1) * 16)) & 0xffffu);
-    }
-    int mine4 = 0;
-#pragma unroll
-    for (int q = 0; q < EPL; q++) mine4 += ent[q];
-    int incl = mine4;
+    // The label group's rows, ascending, from its BITMAP (round 6; gbm: bit p of word p / 64 = sorted row p belongs to
+    // this group -- one atomicOr by the kernel that placed the record): a thread per word, the words' popcounts scanned
+    // over the workgroup, every thread writes its word's rows.  (Until then every group's workgroup read ALL rows'
+    // labels, 1024 per trip with a ballot each: 26 k of a group's 70-90 k clocks at 32 768 rows, a third of the kernel at
+    // every size.)  The bitmap is also `Own`.
+    const u64 w = tid < cbn ? gbm[tid] : 0ULL;  // (cbn <= 512: RG_MAXN rows)
+    if (tid < cbn) Own[tid] = w;
+    const int pc = __popcll(w);
+    int incl = pc;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int t = __shfl_up(incl, d);
       if (lane >= d) incl += t;
     }
-    const int ex0 = incl - mine4;  // exclusive prefix of entry EPL * lane
-    const int wvu = __builtin_amdgcn_readfirstlane(wave);
-    const int wq = wvu & (EPL - 1);  // the wave's entry in trip u is 16 u + wave: lane (16 u + wave) / EPL, component wave % EPL
-    int exw = ex0;
+    int* wtab = reinterpret_cast<int*>(blist);  // 16 wave totals (the worklist is not in use yet)
+    if (lane == 63) wtab[wave] = incl;
+    __syncthreads();
+    int o = incl - pc, total = 0;
 #pragma unroll
-    for (int q = 0; q < EPL - 1; q++) exw += wq > q ? ent[q] : 0;
-#pragma unroll
-    for (int u = 0; u < TRIPS; u++) {
-      if (u * RTHREADS >= n) break;
-      const int base = __builtin_amdgcn_readlane(exw, (16 / EPL) * u + wvu / EPL);
-      if ((mbs[u] >> lane) & 1ULL)
-        rows_l[base + __popcll(mbs[u] & ((1ULL << lane) - 1ULL))] = (unsigned short)(u * RTHREADS + tid);
+    for (int q = 0; q < RTHREADS / 64; q++) {
+      const int t = wtab[q];
+      o += q < wave ? t : 0;
+      total += t;
     }
-    m = __builtin_amdgcn_readlane(incl, 63);
+    for (u64 x = w; x; x &= x - 1) rows_l[o++] = (unsigned short)(tid * 64 + __builtin_ctzll(x));
+    m = total;
     __syncthreads();
   }
   stamp(1);
@@ -1579,7 +1556,6 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   stamp(5);
 }
 
-template <int TRIPS>
 __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* __restrict__ maskT,
                                                                      u64* __restrict__ side, int cb,
                                                                      const unsigned* __restrict__ counter,
@@ -1592,15 +1568,16 @@ __global__ __launch_bounds__(RTHREADS) void nms_reduce_groups_kernel(const u64* 
   __shared__ int wsum[2 * RTHREADS / 64];
   const int img = blockIdx.z;
   const int n = bt.counts[img];
-  const bool grouped = gridDim.x > 1 && bt.rlab && counter[img * bt.counter + Q_XFLAG] == 0u;
+  const bool grouped = gridDim.x > 1 && bt.gbits && counter[img * bt.counter + Q_XFLAG] == 0u;
   if (!grouped && blockIdx.x != 0) return;
   const Side sd = side_tables(side + img * bt.nz, bt.rows);
   if (grouped)
-    reduce_groups_body<true, TRIPS>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, bt.rlab + (size_t)img * bt.rows, (int)blockIdx.x,
+    reduce_groups_body<true>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb,
+                             bt.gbits + ((size_t)img * RG_GROUPS + blockIdx.x) * cb, (int)blockIdx.x,
                              kbits + img * kbits_stride, svals + (size_t)img * bt.rows,
                              fbits ? fbits + img * kbits_stride : nullptr, smem8, &s_und, &s_nbig, &s_m, wsum, stamps);
   else
-    reduce_groups_body<false, TRIPS>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, nullptr, 0, kbits + img * kbits_stride,
+    reduce_groups_body<false>(maskT + img * bt.mask, sd, n, (int)bt.rows, cb, nullptr, 0, kbits + img * kbits_stride,
                               svals + (size_t)img * bt.rows, fbits ? fbits + img * kbits_stride : nullptr, smem8, &s_und,
                               &s_nbig, &s_m, wsum, stamps);
 }
@@ -2316,10 +2293,18 @@ template <int GEOM>
 __device__ __forceinline__ void mc_store_record(const BoxRec& r, const bool is_dead, const int label, const int c,
                                                 const int pos, const int img, BoxRec* __restrict__ recs,
                                                 const size_t recs_stride, int* __restrict__ sorted_vals,
-                                                uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab) {
+                                                uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab,
+                                                u64* __restrict__ gbits, const int cap) {
   recs[img * recs_stride + pos] = r;
   sorted_vals[img * recs_stride + pos] = c;
-  rlab[img * recs_stride + pos] = (uint8_t)label;  // (the reducer groups by label mod 16: the low bits)
+  rlab[img * recs_stride + pos] = (uint8_t)label;  // (the drain's cross-group test reads the low bits)
+  if (gbits) {
+    // the row in its label group's bitmap (sorted-chunk form only: there the words were zeroed by the launch in front.
+    // The counting form zeroes them in ITS OWN launch -- an atomicOr here would race with another workgroup's fill --
+    // and leaves the bitmaps to the stream kernel's diagonal tiles.)
+    const size_t cbw = (size_t)((cap + TILE - 1) / TILE);
+    atomicOr(&gbits[((size_t)img * RG_GROUPS + (label & (RG_GROUPS - 1))) * cbw + (pos >> 6)], 1ULL << (pos & 63));
+  }
   if (GEOM == 3) dead[img * recs_stride + c] = is_dead;
 }
 
@@ -2330,12 +2315,12 @@ __device__ __forceinline__ void mc_place_record(const float* __restrict__ boxes,
                                                 const float* __restrict__ scale, const int sparts,
                                                 BoxRec* __restrict__ recs, const size_t recs_stride,
                                                 int* __restrict__ sorted_vals, uint8_t* __restrict__ dead,
-                                                uint8_t* __restrict__ rlab) {
+                                                uint8_t* __restrict__ rlab, u64* __restrict__ gbits, const int cap) {
   BoxRec r;
   bool is_dead;
   int label;
   mc_build_record<GEOM>(boxes, n, cand_row, cand_label, cbase, c, img, scale, sparts, r, is_dead, label);
-  mc_store_record<GEOM>(r, is_dead, label, c, pos, img, recs, recs_stride, sorted_vals, dead, rlab);
+  mc_store_record<GEOM>(r, is_dead, label, c, pos, img, recs, recs_stride, sorted_vals, dead, rlab, gbits, cap);
 }
 
 // one thread per candidate: record at its sorted position, and the inverse permutation.
@@ -2364,7 +2349,7 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
     const float* __restrict__ boxes, int n, const int* __restrict__ cand_row, const int* __restrict__ cand_label,
     const float* __restrict__ cand_score, int cand_stride, const int* __restrict__ counts_raw, int cap,
     int* __restrict__ ccounts, const float* __restrict__ scale, BoxRec* __restrict__ recs, size_t recs_stride,
-    int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab,
+    int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab, u64* __restrict__ gbits,
     unsigned* __restrict__ counter, size_t counter_stride, uint4* __restrict__ zero, size_t zero16, int sparts) {
   __shared__ __attribute__((aligned(16))) unsigned keys[RP_TJ];
   __shared__ int partial[RP_P][RP_C * CT];
@@ -2467,7 +2452,7 @@ __global__ __launch_bounds__(256) void mc_sort_prepare_kernel(
   const int c = i0 + tid;
   if (c >= M) return;
   mc_place_record<GEOM>(boxes, n, cand_row, cand_label, cbase, c, total_before, img, scale, sparts, recs, recs_stride,
-                        sorted_vals, dead, rlab);
+                        sorted_vals, dead, rlab, nullptr, cap);
 }
 
 // ---------------------------------------------------------------------------- large pools: sorted chunks (round 6)
@@ -2629,7 +2614,7 @@ __global__ __launch_bounds__(PP_C * PP_PARTS) void mc_sort_prepare_p_kernel(
     const float* __restrict__ boxes, int n, const int* __restrict__ cand_row, const int* __restrict__ cand_label,
     const float* __restrict__ cand_score, int cand_stride, const int* __restrict__ counts_raw, int cap,
     int* __restrict__ ccounts, const float* __restrict__ scale, BoxRec* __restrict__ recs, size_t recs_stride,
-    int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab,
+    int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab, u64* __restrict__ gbits,
     unsigned* __restrict__ counter, size_t counter_stride, uint4* __restrict__ zero, size_t zero16, int sparts, PSort ps) {
   // dynamic LDS, 64 KB: [2 buffers][score | x][PP_PARTS chunks][CS_N keys] -- a group of chunks is searched while the next
   // one lands in the other buffer (one buffer: two barriers per group and the wait for its keys in between, 3.1 us per
@@ -2730,7 +2715,7 @@ __global__ __launch_bounds__(PP_C * PP_PARTS) void mc_sort_prepare_p_kernel(
     pos += partial[0][q][tid];
     slot += partial[1][q][tid];
   }
-  mc_store_record<GEOM>(rec, rec_dead, rec_label, c, pos, img, recs, recs_stride, sorted_vals, dead, rlab);
+  mc_store_record<GEOM>(rec, rec_dead, rec_label, c, pos, img, recs, recs_stride, sorted_vals, dead, rlab, gbits, cap);
   const float rj[4] = {rec.f[9], rec.f[10], rec.f[12], rec.f[13]};  // (what the stream kernel's axis-aligned test reads)
   ps.perm[img * ps.stride + slot] = (unsigned short)pos;
   // (the extents of every 64 slots come from these in mc_ranges_kernel.  Collected here with atomicMin / atomicMax they
@@ -2940,6 +2925,7 @@ struct McLayout {
   uint8_t* rlab;   // label of every sorted row
   u64* kbits;      // kept rows as bits (cb words per image; zeroed with the masks)
   u64* fbits;      // kept CANDIDATES as bits (index order; the same)
+  u64* gbits;      // per image and label group: its rows as bits (the same)
   float* extent;
   int* ccounts;
   PSort ps;        // the sorted-chunk form's arrays (pools beyond P_MIN_CAP)
@@ -2958,6 +2944,7 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
   char* nz = take((size_t)B * side_words((size_t)cap) * 8);  // per image: side tables
   char* kbits = take((size_t)B * cb * 8);                    // (still inside the zeroed region)
   char* fbits = take((size_t)B * cb * 8);                    // (the same)
+  char* gbits = take((size_t)B * RG_GROUPS * cb * 8);        // (the same: the label groups' row bitmaps)
   char* counter = take((size_t)B * Q_CTL_WORDS * 4);
   char* gq = take((size_t)B * qcap * 4);
   char* rd = take((size_t)B * cb * cb * 4);  // redo-tile lists
@@ -2982,7 +2969,7 @@ inline size_t mc_layout(int B, int cap, void* ws, McLayout* L) {
                   (unsigned short*)p_pm, (float4*)p_rg, (float4*)p_sb, capR, capR / TILE, nullptr};
     L->svals = (int*)svals; L->recs = (BoxRec*)recs; L->mask = (u64*)mask; L->nz = (u64*)nz;
     L->counter = (unsigned*)counter; L->gqueue = (unsigned*)gq; L->redo = (unsigned*)rd; L->keep = (int64_t*)keep;
-    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->rlab = (uint8_t*)rlab; L->kbits = (u64*)kbits; L->fbits = (u64*)fbits; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
+    L->kept = (int32_t*)kept; L->flags = (uint8_t*)flags; L->dead = (uint8_t*)dead; L->rlab = (uint8_t*)rlab; L->kbits = (u64*)kbits; L->fbits = (u64*)fbits; L->gbits = (u64*)gbits; L->extent = (float*)extent; L->ccounts = (int*)ccounts;
     L->qcap = qcap / Q_NREG; L->qstride = qcap; L->zero_bytes = (size_t)(counter - mask); L->cb = (int)cb;
     const int qcap_o = g_r3_nms_qcap;  // (one read)
     if (qcap_o > 0 && (size_t)qcap_o < L->qcap) L->qcap = (size_t)qcap_o;
@@ -3047,7 +3034,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   mc_layout(B, cap, ws, &L);
   const size_t cbq = (size_t)L.cb;
   Batch bt{L.ccounts, (size_t)cap, (size_t)cap * cbq, side_words((size_t)cap), (size_t)Q_CTL_WORDS, L.qstride,
-           (size_t)cap, cbq * cbq, (size_t)cap, L.rlab};
+           (size_t)cap, cbq * cbq, (size_t)cap, L.rlab, L.gbits};
   // the rank kernel accumulates into cand_rank: zeroed here so that a caller's stale scratch cannot send
   // records out of bounds; and the counts are clamped to cap for the same reason (an image with more
   // candidates than cap is processed as its first cap candidates: the caller sizes cap from the counts,
@@ -3088,7 +3075,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     hipLaunchKernelGGL((mc_sort_prepare_p_kernel<GEOM, PP_CANDS>), ppgrid, dim3(PP_CANDS * PP_PARTS), PP_LDS_BYTES, stream, \
                        boxes, n, cand_row,                                                                          \
                        cand_label, cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead,  \
-                       L.rlab, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
+                       L.rlab, L.gbits, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
                        scale_parts, L.ps);                                                                          \
     hipLaunchKernelGGL(mc_ranges_kernel, dim3((unsigned)(L.ps.rstride + 3) / 4, B), dim3(256), 0, stream,           \
                        L.ccounts, L.ps);                                                                            \
@@ -3099,12 +3086,12 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
   if (big_pool)                                                                                                    \
     hipLaunchKernelGGL((mc_sort_prepare_kernel<GEOM, 4>), pgrid, dim3(256), 0, stream, boxes, n, cand_row,         \
                        cand_label, cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead,  \
-                       L.rlab, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
+                       L.rlab, L.gbits, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
                        scale_parts);                                                                                \
   else                                                                                                             \
     hipLaunchKernelGGL((mc_sort_prepare_kernel<GEOM, 1>), pgrid, dim3(256), 0, stream, boxes, n, cand_row,         \
                        cand_label, cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead,  \
-                       L.rlab, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
+                       L.rlab, L.gbits, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
                        scale_parts);                                                                                \
   hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL>), grid, dim3(NT), 0, stream, L.recs, 0, L.cb, L.gqueue,      \
                      (unsigned)L.qcap, L.counter, L.redo, bt);                                                    \
@@ -3142,24 +3129,16 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     static size_t dyn_max = 0;             // (the same on every device: one code object)
     constexpr size_t DYN_DEFAULT = 44 * 1024;  // what fits the default cap whatever the static part is (< 20 KB)
     if (lds > DYN_DEFAULT && raised.first()) {
-      hipFuncAttributes fa16{}, fa32{};
-      (void)hipFuncGetAttributes(&fa16, reinterpret_cast<const void*>(nms_reduce_groups_kernel<16>));
-      (void)hipFuncGetAttributes(&fa32, reinterpret_cast<const void*>(nms_reduce_groups_kernel<32>));
-      const size_t stat = std::max(fa16.sharedSizeBytes, fa32.sharedSizeBytes);
-      dyn_max = 160 * 1024 - ((stat + 1023) & ~(size_t)1023);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel<16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel<32>),
+      hipFuncAttributes fa{};
+      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(nms_reduce_groups_kernel));
+      dyn_max = 160 * 1024 - ((fa.sharedSizeBytes + 1023) & ~(size_t)1023);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_reduce_groups_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max);
       (void)hipGetLastError();
     }
     if (lds > DYN_DEFAULT && lds > dyn_max) return -1;  // (cap < 65536: 124 KB at most with grouping, 106 KB without)
-    if (cap <= 16384)
-      hipLaunchKernelGGL(nms_reduce_groups_kernel<16>, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
-                         L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);
-    else
-      hipLaunchKernelGGL(nms_reduce_groups_kernel<32>, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
-                         L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);
+    hipLaunchKernelGGL(nms_reduce_groups_kernel, dim3(groups, 1, B), dim3(RTHREADS), lds, stream, L.mask, L.nz, L.cb,
+                       L.counter, L.kbits, cbq, L.svals, geom == 1 ? L.fbits : (u64*)nullptr, bt, g_nms_stamps);
     }
   }
   if (geom == 1)
