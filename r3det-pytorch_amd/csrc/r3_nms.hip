@@ -2615,7 +2615,7 @@ __global__ __launch_bounds__(PP_C * PP_PARTS) void mc_sort_prepare_p_kernel(
     const float* __restrict__ cand_score, int cand_stride, const int* __restrict__ counts_raw, int cap,
     int* __restrict__ ccounts, const float* __restrict__ scale, BoxRec* __restrict__ recs, size_t recs_stride,
     int* __restrict__ sorted_vals, uint8_t* __restrict__ dead, uint8_t* __restrict__ rlab, u64* __restrict__ gbits,
-    unsigned* __restrict__ counter, size_t counter_stride, uint4* __restrict__ zero, size_t zero16, int sparts, PSort ps) {
+    unsigned* __restrict__ counter, size_t counter_stride, int sparts, PSort ps) {
   // dynamic LDS, 64 KB: [2 buffers][score | x][PP_PARTS chunks][CS_N keys] -- a group of chunks is searched while the next
   // one lands in the other buffer (one buffer: two barriers per group and the wait for its keys in between, 3.1 us per
   // group of which 1.3 were the searches)
@@ -3075,8 +3075,7 @@ int r3k_mcnms_run(int geom, const float* boxes, int B, int n, int K, const int* 
     hipLaunchKernelGGL((mc_sort_prepare_p_kernel<GEOM, PP_CANDS>), ppgrid, dim3(PP_CANDS * PP_PARTS), PP_LDS_BYTES, stream, \
                        boxes, n, cand_row,                                                                          \
                        cand_label, cand_score, S, counts, cap, L.ccounts, SCALE, L.recs, bt.recs, L.svals, L.dead,  \
-                       L.rlab, L.gbits, L.counter, bt.counter, reinterpret_cast<uint4*>(L.mask), L.zero_bytes / 16,          \
-                       scale_parts, L.ps);                                                                          \
+                       L.rlab, L.gbits, L.counter, bt.counter, scale_parts, L.ps);                                 \
     hipLaunchKernelGGL(mc_ranges_kernel, dim3((unsigned)(L.ps.rstride + 3) / 4, B), dim3(256), 0, stream,           \
                        L.ccounts, L.ps);                                                                            \
     hipLaunchKernelGGL((nms_stream_kernel<GEOM, LABEL, true>), pstream_grid, dim3(NT), 0, stream, L.recs, 0, L.cb,  \
