@@ -886,6 +886,8 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   constexpr int OVQ = 1024;  // overflow rows a workgroup converts together (grouped form)
   __shared__ unsigned short ovq[OVQ];
   __shared__ int ovx[OVQ], ovl[OVQ];
+  __shared__ int hcnt[2];    // rows enlisted for the wavefronts' pass of a round (in-register form), per round parity
+  __shared__ int hdec[RTHREADS / 64];  // ... and how many of them each wavefront decided
   const int cbn = (n + TILE - 1) / TILE;
   const int nb = (n + 15) & ~15;
   unsigned char* st = smem8;                               // row state: 0 undecided, 1 kept, 2 removed
@@ -903,6 +905,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   if (tid == 0) {
     *s_nbig = 0;
     *s_m = 0;
+    hcnt[0] = hcnt[1] = 0;
   }
   __syncthreads();
   int m = n;
@@ -983,6 +986,10 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       // one such row: a wavefront, lanes <-> mask words -- counts the entries, reserves their place in ext, writes them
       constexpr int CVB = 8;  // overflow rows a wavefront converts together
       auto convert_rows = [&](const int (&rowi)[CVB], const int (&srcl)[CVB], int (&res_base)[CVB], int (&res_total)[CVB]) {
+        // The CVB rows side by side: the scan of a row's 64 word popcounts is six DEPENDENT cross-lane steps (~120 clocks
+        // each), and one row after the other -- count, reservation, scan, bits -- took ~2 k clocks per row: 17 k for the
+        // 13 heavy rows of the model pool's heaviest label group, a quarter of that workgroup's time (stamps).  In
+        // lockstep the steps of the rows overlap, and one reservation serves them all.
         constexpr int OB = CVB;
         u64 w0d[OB];
 #pragma unroll
@@ -990,47 +997,70 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
           const u64* row = maskT + (size_t)rowi[b] * cb;
           w0d[b] = (srcl[b] >= 0 && lane <= (rowi[b] >> 6)) ? row[lane] : 0ULL;
         }
+        int pc0[OB], incl0[OB];
+#pragma unroll
+        for (int b = 0; b < OB; b++) incl0[b] = pc0[b] = __popcll(w0d[b]);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+          for (int b = 0; b < OB; b++) {
+            const int v = __shfl_up(incl0[b], d);
+            if (lane >= d) incl0[b] += v;
+          }
+        }
+        int total[OB], sum = 0;
+#pragma unroll
+        for (int b = 0; b < OB; b++) {
+          total[b] = __builtin_amdgcn_readlane(incl0[b], 63);
+          const int nw = (rowi[b] >> 6) + 1;
+          if (srcl[b] >= 0 && nw > 64) {  // (rows beyond 4096: their further words, one chunk of 64 after the other)
+            const u64* row = maskT + (size_t)rowi[b] * cb;
+            for (int w0 = 64; w0 < nw; w0 += 64) {
+              int pc = (w0 + lane < nw) ? __popcll(row[w0 + lane]) : 0;
+#pragma unroll
+              for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
+              total[b] += pc;
+            }
+          }
+          if (srcl[b] < 0) total[b] = 0;
+          sum += total[b];
+        }
+        int running = 0;
+        if (lane == 0 && sum > 0) running = atomicAdd(s_nbig, sum);
+        running = __builtin_amdgcn_readfirstlane(running);
 #pragma unroll
         for (int b = 0; b < OB; b++) {
           res_base[b] = -1;
           res_total[b] = 0;
           if (srcl[b] < 0) continue;  // (wave-uniform)
-          const int r = rowi[b];
-          const u64* row = maskT + (size_t)r * cb;
-          const int nw = (r >> 6) + 1;
-          int total = 0;
-          for (int w0 = 0; w0 < nw; w0 += 64) {  // (the number of entries; words 64.. only for rows beyond 4096)
-            const u64 wd = w0 == 0 ? w0d[b] : ((w0 + lane < nw) ? row[w0 + lane] : 0ULL);
-            int pc = __popcll(wd);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
-            total += pc;
-          }
-          int base = 0;
-          if (lane == 0) base = atomicAdd(s_nbig, total);
-          base = __builtin_amdgcn_readfirstlane(base);
-          const bool fits = base + total <= R_BLIST;
+          const int base = running;
+          running += total[b];
+          const bool fits = base + total[b] <= R_BLIST;
           if (fits) {
-            int at = base;
-            for (int w0 = 0; w0 < nw; w0 += 64) {
-              u64 wd = w0 == 0 ? w0d[b] : ((w0 + lane < nw) ? row[w0 + lane] : 0ULL);
-              const int pc = __popcll(wd);
-              int incl = pc;
+            int o = base + incl0[b] - pc0[b];
+            for (u64 wd = w0d[b]; wd; wd &= wd - 1) ext[o++] = (unsigned short)(lane * 64 + __builtin_ctzll(wd));
+            const int r = rowi[b];
+            const int nw = (r >> 6) + 1;
+            if (nw > 64) {
+              const u64* row = maskT + (size_t)r * cb;
+              int at = base + __builtin_amdgcn_readlane(incl0[b], 63);
+              for (int w0 = 64; w0 < nw; w0 += 64) {
+                u64 wd = (w0 + lane < nw) ? row[w0 + lane] : 0ULL;
+                const int pc = __popcll(wd);
+                int incl = pc;
 #pragma unroll
-              for (int d = 1; d < 64; d <<= 1) {
-                const int v = __shfl_up(incl, d);
-                if (lane >= d) incl += v;
+                for (int d = 1; d < 64; d <<= 1) {
+                  const int v = __shfl_up(incl, d);
+                  if (lane >= d) incl += v;
+                }
+                int o2 = at + incl - pc;
+                for (; wd; wd &= wd - 1) ext[o2++] = (unsigned short)((w0 + lane) * 64 + __builtin_ctzll(wd));
+                at += __builtin_amdgcn_readlane(incl, 63);
               }
-              int o = at + incl - pc;
-              while (wd) {
-                ext[o++] = (unsigned short)((w0 + lane) * 64 + __builtin_ctzll(wd));
-                wd &= wd - 1;
-              }
-              at += __builtin_amdgcn_readlane(incl, 63);
             }
           }
           res_base[b] = fits ? base : -1;
-          res_total[b] = total;
+          res_total[b] = total[b];
         }
       };
       // (round 5, second half) The rows are ENLISTED for the whole workgroup and converted by all sixteen wavefronts, eight
@@ -1054,7 +1084,8 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
           state[u] = 2;
           st[rr[u]] = 2;
         }
-      auto convert_undecided = [&]() {
+      auto convert_undecided = [&]() -> bool {  // false: no row wanted it (uniform)
+      stamp(9);
       int myov[RPT];
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
@@ -1077,8 +1108,10 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
           }
         }
         __syncthreads();
+        stamp(10);
         {
           const int nov = min(*s_m, OVQ);
+          if (stamp_on) stamps[8] = (u64)nov;
           for (int e0 = wave * CVB; e0 < nov; e0 += (RTHREADS / 64) * CVB) {
             int rowi[CVB], srcl[CVB], rb[CVB], rt[CVB];
 #pragma unroll
@@ -1099,6 +1132,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
             }
           }
         }
+        stamp(11);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
@@ -1124,6 +1158,9 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
               }
           }
         }
+      __syncthreads();  // (the rounds reuse ovq / ovx / ovl for the rows they enlist: every result has been read)
+      stamp(12);
+      return true;
       };
       __syncthreads();
       stamp(2);
@@ -1131,15 +1168,22 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       // atomics; the sets are rebuilt from the state bytes once, behind the loop)
       int rnd = 0, left_before = -1;
       // one round; true: the loop is over (every row decided, or stuck / out of budget: rnd = R_MAX_ROUNDS, the tail below)
+      bool had_pass = false;  // (uniform) the last round had a wavefronts' pass: owners look their rows up again
+      int heavy_left = 0;     // (uniform) undecided rows with more than EL suppressors behind the round just run
       auto one_round = [&]() -> bool {
-        bool und = false;
+        bool und = false, heavy = false;
         if (stamp_on && rnd < 8) stamps[16 + 4 * rnd] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) hcnt[(rnd + 1) & 1] = 0;  // (last used a round ago, behind that round's barriers)
         // What a round costs is LDS reads of scattered state bytes (bank conflicts: ~12 cycles per wave read, 16 waves
         // on one LDS) and the slowest wave in front of the barrier.  So: a wave whose rows are all decided reads
         // nothing; the best suppressor and the first 8 entries are read together (most rows have fewer than 8);
         // entries 8..31 in one batch, only in waves with an undecided row that long; the overflow entries 16 at a time.
 #pragma unroll
         for (int u = 0; u < RPT; u++) {
+          if (had_pass && state[u] == 0) {  // (a row the wavefronts' pass of the last round decided: its owner learns it here)
+            const unsigned char s0 = st[rr[u]];
+            if (s0) state[u] = s0;
+          }
           const bool act = state[u] == 0;
           if (__ballot(act) == 0ULL) continue;
           if (rnd >= R_MAX_ROUNDS) { und |= act; continue; }
@@ -1153,6 +1197,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
             for (int q = 0; q < 8; q++) v8[q] = st[q < listed ? ((wv[q >> 1] >> ((q & 1) * 16)) & 0xffffu) : r];
           }
           bool aK = act && ms[u] < 65535u && v0 == 1, aR = true;  // its highest-scored suppressor first
+          bool pending = false;                                   // (left to the wavefronts' pass below)
 #pragma unroll
           for (int q = 0; q < 8; q++) {
             aK |= q < listed && v8[q] == 1;
@@ -1175,7 +1220,25 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
             const bool ovf = act && !aK && c[u] > EL;
             if (__ballot(ovf) != 0ULL) {
               if (ovf && xs[u] < 0) aR = false;  // (the LDS list was full: left to the tail below)
-              const int len = (ovf && xs[u] >= 0) ? xl[u] : 0;
+              // Suppressors beyond the list: the row is ENLISTED for the pass below, where a wavefront takes a row and a
+              // lane an entry.  (Its owner walking the LDS entries alone, sixteen per step -- the loop below, still the
+              // way of a row that finds the list full -- kept the whole workgroup waiting at the round's barrier: 6-10 k
+              // clocks per round for the 13 heavy rows of the model pool's heaviest label group, stamps.)
+              const bool want = ovf && xs[u] >= 0;
+              const u64 need = __ballot(want);
+              if (need) {
+                int hb = 0;
+                if (lane == 0) hb = atomicAdd(&hcnt[rnd & 1], __popcll(need));
+                hb = __builtin_amdgcn_readfirstlane(hb);
+                const int he = hb + __popcll(need & ((1ULL << lane) - 1ULL));
+                if (want && he < OVQ) {
+                  ovq[he] = (unsigned short)r;
+                  ovx[he] = xs[u];
+                  ovl[he] = (xl[u] << 1) | (aR ? 1 : 0);
+                  pending = true;
+                }
+              }
+              const int len = (want && !pending) ? xl[u] : 0;
               // suppressors beyond the list: their LDS entries, SIXTEEN per step (round 5; four per step were two dependent
               // LDS round trips per four entries: 18 steps for a row with 70 of them, 4-9 k cycles of a dense class's round),
               // and no further once every such row of the wavefront has met a kept suppressor
@@ -1196,24 +1259,55 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
             }
           }
           if (act) {
-            if (aK || aR) {
+            if (!pending && (aK || aR)) {
               state[u] = aK ? 2 : 1;
               st[r] = (unsigned char)state[u];
             } else {
-              und = true;
+              und = true;  // (an enlisted row counts as undecided until the pass below says otherwise)
+              heavy |= c[u] > EL;
             }
           }
         }
-        if (stamp_on && rnd < 8) stamps[18 + 4 * rnd] = __builtin_amdgcn_s_memtime();
+        if (stamp_on && rnd < 8) stamps[17 + 4 * rnd] = __builtin_amdgcn_s_memtime();
         // undecided rows of the workgroup: wave popcounts through a double-buffered table, ONE barrier per round
         // (__syncthreads_count costs ~1900 cycles however little the waves do)
         int* wtab2 = wsum;  // (2 x 16 ints)
-        const int wund = __popcll(__ballot(und));
+        const int wund = __popcll(__ballot(und)) | (__ballot(heavy) != 0ULL ? 1 << 16 : 0);  // (+ "a heavy row is left")
         if (lane == 0) wtab2[(rnd & 1) * 16 + wave] = wund;
         __syncthreads();
         int left = 0;
 #pragma unroll
         for (int w = 0; w < RTHREADS / 64; w++) left += wtab2[(rnd & 1) * 16 + w];
+        heavy_left = left >> 16;
+        left &= 0xffff;
+        // the enlisted rows, if the round has any (uniform): a wavefront per row, a lane per entry of its LDS list; two
+        // more barriers, in such rounds only
+        const int nh = min(hcnt[rnd & 1], OVQ);
+        had_pass = nh > 0;
+        if (nh > 0) {
+          int dec_h = 0;
+          for (int e = wave; e < nh; e += RTHREADS / 64) {
+            const int hr = ovq[e], hx = ovx[e], hl = ovl[e] >> 1;
+            bool hK = false, hR = (ovl[e] & 1) != 0;
+            for (int e0 = 0; e0 < hl && __ballot(hK) == 0ULL; e0 += 64) {
+              const int i = e0 + lane;
+              const unsigned char v = i < hl ? st[ext[hx + i]] : (unsigned char)2;
+              hK |= v == 1;
+              hR &= v == 2;
+            }
+            const bool k_any = __ballot(hK) != 0ULL, r_all = __ballot(!hR) == 0ULL;
+            if (lane == 0 && (k_any || r_all)) {
+              st[hr] = k_any ? 2 : 1;
+              dec_h++;
+            }
+          }
+          if (lane == 0) hdec[wave] = dec_h;
+          __syncthreads();
+#pragma unroll
+          for (int w = 0; w < RTHREADS / 64; w++) left -= hdec[w];
+          __syncthreads();  // (hdec is written again in the next such round)
+        }
+        if (stamp_on && rnd < 8) stamps[18 + 4 * rnd] = __builtin_amdgcn_s_memtime();
         if (stamp_on && rnd < 8) stamps[19 + 4 * rnd] = __builtin_amdgcn_s_memtime();
         if (left == 0) return true;                                               // every row decided
         if (left == left_before || rnd >= R_MAX_ROUNDS) { rnd = R_MAX_ROUNDS; return true; }  // stuck or out of budget
@@ -1226,11 +1320,13 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       // the model's own pool paid 17 k clocks in its heaviest label group for lists of which a handful were ever read.
       if (!one_round()) {
         rnd = 1;
-        convert_undecided();
+        if (heavy_left) {  // (most pools: none -- no conversion, none of its barriers, the lists stay where they are)
+          convert_undecided();
 #pragma unroll
-        for (int u = 0; u < RPT; u++) {
-          const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)rr[u] * EL);
-          t[u][0] = lp[0]; t[u][1] = lp[1]; t[u][2] = lp[2]; t[u][3] = lp[3];
+          for (int u = 0; u < RPT; u++) {
+            const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)rr[u] * EL);
+            t[u][0] = lp[0]; t[u][1] = lp[1]; t[u][2] = lp[2]; t[u][3] = lp[3];
+          }
         }
         while (!one_round()) rnd++;
       }
@@ -1253,8 +1349,10 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       }
       if (fbits && rnd < R_MAX_ROUNDS) {  // kept candidates as bits, from the registers (the tail's rows: below)
 #pragma unroll
-        for (int u = 0; u < RPT; u++)
+        for (int u = 0; u < RPT; u++) {
+          if (state[u] == 0) state[u] = st[rr[u]];  // (decided by the wavefronts' pass of the last round)
           if (state[u] == 1) atomicOr(&fbits[sv[u] >> 6], 1ULL << (sv[u] & 63));
+        }
         fbits_done = true;
       }
       __syncthreads();

@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
     if (s[52] > s[48]) printf("  ranking kernel (sorted chunks), workgroup 0: record built %llu  first group of chunks %llu  the other groups %llu  records out %llu\n",
                               s[49] - s[48], s[50] - s[49], s[51] - s[50], s[52] - s[51]);
     if (s[56] > s[53]) printf("    its third group: next keys to LDS + request %llu  two searches %llu  barrier %llu\n", s[54] - s[53], s[55] - s[54], s[56] - s[55]);
+    if (s[12] > s[9]) printf("  conversion of %llu overflow rows behind round 0: enlist %llu  rows to LDS lists %llu  results %llu\n", s[8], s[10] - s[9], s[11] - s[10], s[12] - s[11]);
     printf("n %d rc %d kept %d | cycles: compaction %llu  prologue %llu  rounds %llu (%llu rounds)  tail %llu  bits %llu  total %llu\n", n, rc,
            kept, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[7], s[4] - s[3], s[5] - s[4], s[5] - s[0]);
   }
