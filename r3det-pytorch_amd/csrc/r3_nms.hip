@@ -885,7 +885,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   stamp(0);
   constexpr int OVQ = 1024;  // overflow rows a workgroup converts together (grouped form)
   __shared__ unsigned short ovq[OVQ];
-  __shared__ int ovx[OVQ], ovl[OVQ];
+  __shared__ int ovl[OVQ];
   __shared__ int hcnt[2];    // rows enlisted for the wavefronts' pass of a round (in-register form), per round parity
   __shared__ int hdec[RTHREADS / 64];  // ... and how many of them each wavefront decided
   const int cbn = (n + TILE - 1) / TILE;
@@ -976,104 +976,18 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         ms[u] = has ? 65535u - (unsigned)ms_l : 65535u;
         state[u] = has ? 0 : 3;
       }
-      // Rows with more suppressors than the 32-entry list (mark_pair keeps the rest as bits of the row's overflow
-      // mask): the bits are turned into u16 entries of an LDS list ONCE, a wave per row (lanes <-> words, one round
-      // trip), so that the rounds never leave the LDS.  (Re-scanning the mask row from global memory in every
-      // round -- up to 17 dependent batches of 8 words -- made a dozen such rows cost 30 us of a 48 us kernel on the
-      // bench model's pool.)  xs < 0: the list is full, that row keeps the per-round scan.
-      int xs[RPT], xl[RPT];
-      unsigned short* ext = blist;  // (the long-row worklist of the general form: unused here)
-      // one such row: a wavefront, lanes <-> mask words -- counts the entries, reserves their place in ext, writes them
-      constexpr int CVB = 8;  // overflow rows a wavefront converts together
-      auto convert_rows = [&](const int (&rowi)[CVB], const int (&srcl)[CVB], int (&res_base)[CVB], int (&res_total)[CVB]) {
-        // The CVB rows side by side: the scan of a row's 64 word popcounts is six DEPENDENT cross-lane steps (~120 clocks
-        // each), and one row after the other -- count, reservation, scan, bits -- took ~2 k clocks per row: 17 k for the
-        // 13 heavy rows of the model pool's heaviest label group, a quarter of that workgroup's time (stamps).  In
-        // lockstep the steps of the rows overlap, and one reservation serves them all.
-        constexpr int OB = CVB;
-        u64 w0d[OB];
-#pragma unroll
-        for (int b = 0; b < OB; b++) {
-          const u64* row = maskT + (size_t)rowi[b] * cb;
-          w0d[b] = (srcl[b] >= 0 && lane <= (rowi[b] >> 6)) ? row[lane] : 0ULL;
-        }
-        int pc0[OB], incl0[OB];
-#pragma unroll
-        for (int b = 0; b < OB; b++) incl0[b] = pc0[b] = __popcll(w0d[b]);
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-          for (int b = 0; b < OB; b++) {
-            const int v = __shfl_up(incl0[b], d);
-            if (lane >= d) incl0[b] += v;
-          }
-        }
-        int total[OB], sum = 0;
-#pragma unroll
-        for (int b = 0; b < OB; b++) {
-          total[b] = __builtin_amdgcn_readlane(incl0[b], 63);
-          const int nw = (rowi[b] >> 6) + 1;
-          if (srcl[b] >= 0 && nw > 64) {  // (rows beyond 4096: their further words, one chunk of 64 after the other)
-            const u64* row = maskT + (size_t)rowi[b] * cb;
-            for (int w0 = 64; w0 < nw; w0 += 64) {
-              int pc = (w0 + lane < nw) ? __popcll(row[w0 + lane]) : 0;
-#pragma unroll
-              for (int d = 32; d >= 1; d >>= 1) pc += __shfl_xor(pc, d);
-              total[b] += pc;
-            }
-          }
-          if (srcl[b] < 0) total[b] = 0;
-          sum += total[b];
-        }
-        int running = 0;
-        if (lane == 0 && sum > 0) running = atomicAdd(s_nbig, sum);
-        running = __builtin_amdgcn_readfirstlane(running);
-#pragma unroll
-        for (int b = 0; b < OB; b++) {
-          res_base[b] = -1;
-          res_total[b] = 0;
-          if (srcl[b] < 0) continue;  // (wave-uniform)
-          const int base = running;
-          running += total[b];
-          const bool fits = base + total[b] <= R_BLIST;
-          if (fits) {
-            int o = base + incl0[b] - pc0[b];
-            for (u64 wd = w0d[b]; wd; wd &= wd - 1) ext[o++] = (unsigned short)(lane * 64 + __builtin_ctzll(wd));
-            const int r = rowi[b];
-            const int nw = (r >> 6) + 1;
-            if (nw > 64) {
-              const u64* row = maskT + (size_t)r * cb;
-              int at = base + __builtin_amdgcn_readlane(incl0[b], 63);
-              for (int w0 = 64; w0 < nw; w0 += 64) {
-                u64 wd = (w0 + lane < nw) ? row[w0 + lane] : 0ULL;
-                const int pc = __popcll(wd);
-                int incl = pc;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                  const int v = __shfl_up(incl, d);
-                  if (lane >= d) incl += v;
-                }
-                int o2 = at + incl - pc;
-                for (; wd; wd &= wd - 1) ext[o2++] = (unsigned short)((w0 + lane) * 64 + __builtin_ctzll(wd));
-                at += __builtin_amdgcn_readlane(incl, 63);
-              }
-            }
-          }
-          res_base[b] = fits ? base : -1;
-          res_total[b] = total[b];
-        }
-      };
-      // (round 5, second half) The rows are ENLISTED for the whole workgroup and converted by all sixteen wavefronts, eight
-      // rows per step each: a 218-row class lives in the first four wavefronts, which converted its 71 overflow rows alone
-      // (18 rows per wavefront, ~1000 cycles each: 45-73 k cycles in front of the first round on the bench model's pool).
+      // Rows with more suppressors than the 32-entry list (mark_pair keeps the rest as bits of the row's overflow mask)
+      // are ENLISTED in a round that leaves them undecided, and a wavefront takes each: a lane per mask word, the K / R
+      // bits of the word's 64 rows rebuilt from their state bytes (8 LDS reads).  History: the owner re-scanning the mask
+      // row from global memory in every round (round 4: a dozen such rows cost 30 us of a 48 us kernel on the bench
+      // model's pool); the bits turned into u16 LDS lists once, up front (round 5: 45-73 k clocks in front of the first
+      // round), then behind round 0 and for undecided rows only (round 6: still 5-11 k clocks per label group -- the
+      // conversion is a round trip to the mask plus two dependent cross-lane scans per row -- and the owner walking its
+      // list alone kept the workgroup at the round's barrier for 6-10 k clocks).
       // Round 6: a look at the HEADS first.  A heavy row is nearly always a member of a cluster whose head -- its
-      // highest-scored suppressor -- has no suppressor itself and is kept from the start: such a row is removed here,
-      // before anything is converted.  Converting every row with more than 32 suppressors, the model's own pool paid 17 k
-      // clocks in its heaviest label group (322 such rows in the image) for lists of which a handful were ever read.
+      // highest-scored suppressor -- has no suppressor itself and is kept from the start: such a row is removed here.
 #pragma unroll
       for (int u = 0; u < RPT; u++) {
-        xs[u] = -1;  // ("cannot be kept yet": overwritten by the conversion)
-        xl[u] = 0;
         if (state[u] == 0 && c[u] == 0) state[u] = 1;
         if (state[u] != 3) st[rr[u]] = (unsigned char)state[u];
       }
@@ -1084,84 +998,6 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
           state[u] = 2;
           st[rr[u]] = 2;
         }
-      auto convert_undecided = [&]() -> bool {  // false: no row wanted it (uniform)
-      stamp(9);
-      int myov[RPT];
-#pragma unroll
-        for (int u = 0; u < RPT; u++) {
-          myov[u] = -1;
-          const bool want = state[u] == 0 && c[u] > EL;
-          const u64 need = __ballot(want);
-          if (need) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(s_m, __popcll(need));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (want) {
-              const int e = base + __popcll(need & ((1ULL << lane) - 1ULL));
-              if (e < OVQ) {
-                ovq[e] = (unsigned short)rr[u];
-                myov[u] = e;
-              } else {
-                myov[u] = -2;  // (no room on the list: this wavefront converts it itself below)
-              }
-            }
-          }
-        }
-        __syncthreads();
-        stamp(10);
-        {
-          const int nov = min(*s_m, OVQ);
-          if (stamp_on) stamps[8] = (u64)nov;
-          for (int e0 = wave * CVB; e0 < nov; e0 += (RTHREADS / 64) * CVB) {
-            int rowi[CVB], srcl[CVB], rb[CVB], rt[CVB];
-#pragma unroll
-            for (int b = 0; b < CVB; b++) {
-              srcl[b] = e0 + b < nov ? 0 : -1;
-              rowi[b] = e0 + b < nov ? (int)ovq[e0 + b] : 0;
-            }
-            convert_rows(rowi, srcl, rb, rt);
-            if (lane < CVB && e0 + lane < nov) {
-              int vb = rb[0], vt = rt[0];
-#pragma unroll
-              for (int b = 1; b < CVB; b++) {
-                vb = lane == b ? rb[b] : vb;
-                vt = lane == b ? rt[b] : vt;
-              }
-              ovx[e0 + lane] = vb;
-              ovl[e0 + lane] = vt;
-            }
-          }
-        }
-        stamp(11);
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < RPT; u++) {
-          if (myov[u] >= 0) {
-            xs[u] = ovx[myov[u]];
-            xl[u] = ovl[myov[u]];
-          }
-          u64 need = __ballot(myov[u] == -2);  // (beyond the list's capacity: the owner's wavefront, as before)
-          while (need) {
-            int srcl[CVB], rowi[CVB], rb[CVB], rt[CVB];
-#pragma unroll
-            for (int b = 0; b < CVB; b++) {
-              srcl[b] = need ? __builtin_ctzll(need) : -1;
-              need &= need - 1;  // (0 stays 0)
-              rowi[b] = srcl[b] >= 0 ? __shfl(rr[u], srcl[b]) : 0;
-            }
-            convert_rows(rowi, srcl, rb, rt);
-#pragma unroll
-            for (int b = 0; b < CVB; b++)
-              if (srcl[b] >= 0 && lane == srcl[b]) {
-                xs[u] = rb[b];
-                xl[u] = rt[b];
-              }
-          }
-        }
-      __syncthreads();  // (the rounds reuse ovq / ovx / ovl for the rows they enlist: every result has been read)
-      stamp(12);
-      return true;
-      };
       __syncthreads();
       stamp(2);
       // (no K / R bit sets in this loop: 64 lanes deciding rows of one or two mask words are 64 same-address LDS
@@ -1169,9 +1005,11 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       int rnd = 0, left_before = -1;
       // one round; true: the loop is over (every row decided, or stuck / out of budget: rnd = R_MAX_ROUNDS, the tail below)
       bool had_pass = false;  // (uniform) the last round had a wavefronts' pass: owners look their rows up again
-      int heavy_left = 0;     // (uniform) undecided rows with more than EL suppressors behind the round just run
       auto one_round = [&]() -> bool {
-        bool und = false, heavy = false;
+        int wund = 0;  // undecided ROWS of this wavefront (uniform).  (Threads with an undecided row, the count until the
+                       // wavefronts' pass subtracted the ROWS it decides: a thread with two enlisted rows counted once,
+                       // both decided by the pass took the count of a pile of near-duplicates to zero with rows left --
+                       // two keeps missing in one call of ten)
         if (stamp_on && rnd < 8) stamps[16 + 4 * rnd] = __builtin_amdgcn_s_memtime();
         if (tid == 0) hcnt[(rnd + 1) & 1] = 0;  // (last used a round ago, behind that round's barriers)
         // What a round costs is LDS reads of scattered state bytes (bank conflicts: ~12 cycles per wave read, 16 waves
@@ -1186,7 +1024,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
           }
           const bool act = state[u] == 0;
           if (__ballot(act) == 0ULL) continue;
-          if (rnd >= R_MAX_ROUNDS) { und |= act; continue; }
+          if (rnd >= R_MAX_ROUNDS) { wund += __popcll(__ballot(act)); continue; }
           const unsigned r = (unsigned)rr[u];
           const int listed = act ? min(c[u], EL) : 0;
           unsigned char v0, v8[8];
@@ -1219,12 +1057,9 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
             }
             const bool ovf = act && !aK && c[u] > EL;
             if (__ballot(ovf) != 0ULL) {
-              if (ovf && xs[u] < 0) aR = false;  // (the LDS list was full: left to the tail below)
-              // Suppressors beyond the list: the row is ENLISTED for the pass below, where a wavefront takes a row and a
-              // lane an entry.  (Its owner walking the LDS entries alone, sixteen per step -- the loop below, still the
-              // way of a row that finds the list full -- kept the whole workgroup waiting at the round's barrier: 6-10 k
-              // clocks per round for the 13 heavy rows of the model pool's heaviest label group, stamps.)
-              const bool want = ovf && xs[u] >= 0;
+              // (round 0 enlists nothing: most heavy rows fall to what their lists show in rounds 0 and 1; a row that
+              // finds the list full stays undecided and asks again)
+              const bool want = ovf && rnd > 0;
               const u64 need = __ballot(want);
               if (need) {
                 int hb = 0;
@@ -1233,67 +1068,59 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
                 const int he = hb + __popcll(need & ((1ULL << lane) - 1ULL));
                 if (want && he < OVQ) {
                   ovq[he] = (unsigned short)r;
-                  ovx[he] = xs[u];
-                  ovl[he] = (xl[u] << 1) | (aR ? 1 : 0);
-                  pending = true;
+                  ovl[he] = aR ? 1 : 0;
                 }
               }
-              const int len = (want && !pending) ? xl[u] : 0;
-              // suppressors beyond the list: their LDS entries, SIXTEEN per step (round 5; four per step were two dependent
-              // LDS round trips per four entries: 18 steps for a row with 70 of them, 4-9 k cycles of a dense class's round),
-              // and no further once every such row of the wavefront has met a kept suppressor
-              constexpr int XE = 16;
-              for (int e0 = 0; __ballot(e0 < len && !aK) != 0ULL; e0 += XE) {
-                unsigned short xi[XE];
-                unsigned char xv[XE];
-#pragma unroll
-                for (int e = 0; e < XE; e++) xi[e] = e0 + e < len ? ext[xs[u] + e0 + e] : (unsigned short)r;
-#pragma unroll
-                for (int e = 0; e < XE; e++) xv[e] = st[xi[e]];
-#pragma unroll
-                for (int e = 0; e < XE; e++) {
-                  aK |= e0 + e < len && xv[e] == 1;
-                  aR &= !(e0 + e < len) || xv[e] == 2;
-                }
-              }
+              pending = ovf;  // (never decided by its owner: its list is not all of its suppressors)
             }
           }
+          bool row_und = false;
           if (act) {
             if (!pending && (aK || aR)) {
               state[u] = aK ? 2 : 1;
               st[r] = (unsigned char)state[u];
             } else {
-              und = true;  // (an enlisted row counts as undecided until the pass below says otherwise)
-              heavy |= c[u] > EL;
+              row_und = true;  // (an enlisted row counts as undecided until the pass below says otherwise)
             }
           }
+          wund += __popcll(__ballot(row_und));
         }
         if (stamp_on && rnd < 8) stamps[17 + 4 * rnd] = __builtin_amdgcn_s_memtime();
         // undecided rows of the workgroup: wave popcounts through a double-buffered table, ONE barrier per round
         // (__syncthreads_count costs ~1900 cycles however little the waves do)
         int* wtab2 = wsum;  // (2 x 16 ints)
-        const int wund = __popcll(__ballot(und)) | (__ballot(heavy) != 0ULL ? 1 << 16 : 0);  // (+ "a heavy row is left")
         if (lane == 0) wtab2[(rnd & 1) * 16 + wave] = wund;
         __syncthreads();
         int left = 0;
 #pragma unroll
         for (int w = 0; w < RTHREADS / 64; w++) left += wtab2[(rnd & 1) * 16 + w];
-        heavy_left = left >> 16;
-        left &= 0xffff;
-        // the enlisted rows, if the round has any (uniform): a wavefront per row, a lane per entry of its LDS list; two
-        // more barriers, in such rounds only
+        // the enlisted rows, if the round has any (uniform): a wavefront per row, a lane per word of its overflow mask;
+        // two more barriers, in such rounds only
         const int nh = min(hcnt[rnd & 1], OVQ);
         had_pass = nh > 0;
         if (nh > 0) {
           int dec_h = 0;
           for (int e = wave; e < nh; e += RTHREADS / 64) {
-            const int hr = ovq[e], hx = ovx[e], hl = ovl[e] >> 1;
-            bool hK = false, hR = (ovl[e] & 1) != 0;
-            for (int e0 = 0; e0 < hl && __ballot(hK) == 0ULL; e0 += 64) {
-              const int i = e0 + lane;
-              const unsigned char v = i < hl ? st[ext[hx + i]] : (unsigned char)2;
-              hK |= v == 1;
-              hR &= v == 2;
+            const int hr = ovq[e];
+            const u64* row = maskT + (size_t)hr * cb;
+            const int nw = (hr >> 6) + 1;
+            bool hK = false, hR = ovl[e] != 0;
+            for (int q0 = 0; q0 < nw && __ballot(hK) == 0ULL; q0 += 64) {
+              const int q = q0 + lane;
+              const u64 mm = q < nw ? row[q] : 0ULL;
+              if (mm) {  // (few words of a row carry bits: the others cost their lane nothing)
+                const u64* sp = reinterpret_cast<const u64*>(st + (size_t)q * 64);
+                u64 kw = 0, rw = 0;
+#pragma unroll
+                for (int b8 = 0; b8 < 8; b8++) {
+                  const u64 x = sp[b8];
+                  const u64 k1 = x & ~(x >> 1) & 0x0101010101010101ULL, r1 = (x >> 1) & ~x & 0x0101010101010101ULL;
+                  kw |= ((k1 * 0x0102040810204080ULL) >> 56) << (8 * b8);
+                  rw |= ((r1 * 0x0102040810204080ULL) >> 56) << (8 * b8);
+                }
+                hK |= (mm & kw) != 0ULL;
+                hR &= (mm & ~rw) == 0ULL;
+              }
             }
             const bool k_any = __ballot(hK) != 0ULL, r_all = __ballot(!hR) == 0ULL;
             if (lane == 0 && (k_any || r_all)) {
@@ -1314,22 +1141,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         left_before = left;
         return false;
       };
-      // Round 0 runs on the lists alone (a row with more than 32 suppressors can be removed by what its list shows, not
-      // kept); the rows still undecided are converted then, the lists -- not needed across the conversion, whose eight
-      // mask rows per wavefront want the registers -- are fetched again (L2), and the rounds go on.  Converted up front,
-      // the model's own pool paid 17 k clocks in its heaviest label group for lists of which a handful were ever read.
-      if (!one_round()) {
-        rnd = 1;
-        if (heavy_left) {  // (most pools: none -- no conversion, none of its barriers, the lists stay where they are)
-          convert_undecided();
-#pragma unroll
-          for (int u = 0; u < RPT; u++) {
-            const uint4* lp = reinterpret_cast<const uint4*>(sd.elist + (size_t)rr[u] * EL);
-            t[u][0] = lp[0]; t[u][1] = lp[1]; t[u][2] = lp[2]; t[u][3] = lp[3];
-          }
-        }
-        while (!one_round()) rnd++;
-      }
+      while (!one_round()) rnd++;
       // K / R as bits, from the state bytes of this workgroup's rows (8 bytes at a time: byte == 1 / == 2 -> one bit)
       for (int b = tid; b < cbn; b += RTHREADS) {
         const u64 own = Own[b];

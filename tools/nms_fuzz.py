@@ -50,6 +50,10 @@ for case in range(cases):
             got[impl] = (d.clone(), k.clone())
         _C.set_option("nms_impl", 0)
         same = torch.equal(got[6][1], got[7][1]) and torch.equal(got[6][0].nan_to_num(123.0), got[7][0].nan_to_num(123.0))
+        if same and kind in ("one_pile", "clusters") and n <= 4000:  # (dense pools: the same answer call after call)
+            for _ in range(6):
+                d, k = M._batched_rnms_device(tb, ts, tl, thr, False, entry=entry)
+                same = same and torch.equal(k, got[7][1])
         if not same:
             bad += 1
             print(f"MISMATCH case {case} {entry} n={n} K={K} kind={kind} span={span} thr={thr}: kept {got[7][1].numel()} vs {got[6][1].numel()}", flush=True)
