@@ -886,8 +886,8 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
   constexpr int OVQ = 1024;  // overflow rows a workgroup converts together (grouped form)
   __shared__ unsigned short ovq[OVQ];
   __shared__ int ovl[OVQ];
-  __shared__ int hcnt[2];    // rows enlisted for the wavefronts' pass of a round (in-register form), per round parity
-  __shared__ int hdec[RTHREADS / 64];  // ... and how many of them each wavefront decided
+  __shared__ int hcnt[2];    // [0]: rows handed over to the wavefronts' pass (in-register form; they stay on its list)
+  __shared__ int hdec[RTHREADS / 64];  // ... and how many of them each wavefront left undecided in the round
   const int cbn = (n + TILE - 1) / TILE;
   const int nb = (n + 15) & ~15;
   unsigned char* st = smem8;                               // row state: 0 undecided, 1 kept, 2 removed
@@ -1005,13 +1005,15 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
       int rnd = 0, left_before = -1;
       // one round; true: the loop is over (every row decided, or stuck / out of budget: rnd = R_MAX_ROUNDS, the tail below)
       bool had_pass = false;  // (uniform) the last round had a wavefronts' pass: owners look their rows up again
+      bool hv[RPT];           // the row was handed over to the wavefronts' pass: its owner only waits for the answer
+#pragma unroll
+      for (int u = 0; u < RPT; u++) hv[u] = false;
       auto one_round = [&]() -> bool {
         int wund = 0;  // undecided ROWS of this wavefront (uniform).  (Threads with an undecided row, the count until the
                        // wavefronts' pass subtracted the ROWS it decides: a thread with two enlisted rows counted once,
                        // both decided by the pass took the count of a pile of near-duplicates to zero with rows left --
                        // two keeps missing in one call of ten)
         if (stamp_on && rnd < 8) stamps[16 + 4 * rnd] = __builtin_amdgcn_s_memtime();
-        if (tid == 0) hcnt[(rnd + 1) & 1] = 0;  // (last used a round ago, behind that round's barriers)
         // What a round costs is LDS reads of scattered state bytes (bank conflicts: ~12 cycles per wave read, 16 waves
         // on one LDS) and the slowest wave in front of the barrier.  So: a wave whose rows are all decided reads
         // nothing; the best suppressor and the first 8 entries are read together (most rows have fewer than 8);
@@ -1022,7 +1024,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
             const unsigned char s0 = st[rr[u]];
             if (s0) state[u] = s0;
           }
-          const bool act = state[u] == 0;
+          const bool act = state[u] == 0 && !hv[u];  // (a handed-over row: looked at, and counted, by the pass)
           if (__ballot(act) == 0ULL) continue;
           if (rnd >= R_MAX_ROUNDS) { wund += __popcll(__ballot(act)); continue; }
           const unsigned r = (unsigned)rr[u];
@@ -1057,18 +1059,21 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
             }
             const bool ovf = act && !aK && c[u] > EL;
             if (__ballot(ovf) != 0ULL) {
-              // (round 0 enlists nothing: most heavy rows fall to what their lists show in rounds 0 and 1; a row that
-              // finds the list full stays undecided and asks again)
+              // HANDED OVER in round 1 (most heavy rows fall to what their lists show in rounds 0 and 1): from then on
+              // the pass below looks at the row -- list and overflow mask -- and its owner only waits for the answer.
+              // (The owner walking its 32 entries every round on top of the pass: 2-3 k clocks per round in the
+              // wavefronts with heavy rows, the ones the others wait for.)  No room on the pass's list: the row stays
+              // with its owner, who cannot keep it -- the rounds get stuck and the tail takes over.
               const bool want = ovf && rnd > 0;
               const u64 need = __ballot(want);
               if (need) {
                 int hb = 0;
-                if (lane == 0) hb = atomicAdd(&hcnt[rnd & 1], __popcll(need));
+                if (lane == 0) hb = atomicAdd(&hcnt[0], __popcll(need));
                 hb = __builtin_amdgcn_readfirstlane(hb);
                 const int he = hb + __popcll(need & ((1ULL << lane) - 1ULL));
                 if (want && he < OVQ) {
                   ovq[he] = (unsigned short)r;
-                  ovl[he] = aR ? 1 : 0;
+                  hv[u] = true;
                 }
               }
               pending = ovf;  // (never decided by its owner: its list is not all of its suppressors)
@@ -1080,7 +1085,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
               state[u] = aK ? 2 : 1;
               st[r] = (unsigned char)state[u];
             } else {
-              row_und = true;  // (an enlisted row counts as undecided until the pass below says otherwise)
+              row_und = !hv[u];  // (a row handed over in this round is counted by the pass)
             }
           }
           wund += __popcll(__ballot(row_und));
@@ -1094,20 +1099,25 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
         int left = 0;
 #pragma unroll
         for (int w = 0; w < RTHREADS / 64; w++) left += wtab2[(rnd & 1) * 16 + w];
-        // the enlisted rows, if the round has any (uniform): a wavefront per row, a lane per word of its overflow mask;
-        // two more barriers, in such rounds only
-        const int nh = min(hcnt[rnd & 1], OVQ);
+        // The handed-over rows, once there are any (uniform): a wavefront per row -- lanes 0 .. 31 an entry of its list
+        // each, every lane a word of its overflow mask (the K / R bits of the word's 64 rows rebuilt from their state
+        // bytes) -- and two more barriers, in the rounds of such label groups only.
+        const int nh = min(hcnt[0], OVQ);
         had_pass = nh > 0;
         if (nh > 0) {
-          int dec_h = 0;
+          int und_h = 0;
           for (int e = wave; e < nh; e += RTHREADS / 64) {
             const int hr = ovq[e];
+            if (st[hr] != 0) continue;  // (decided in an earlier round; uniform)
             const u64* row = maskT + (size_t)hr * cb;
             const int nw = (hr >> 6) + 1;
-            bool hK = false, hR = ovl[e] != 0;
+            const unsigned ent = lane < EL ? (unsigned)sd.elist[(size_t)hr * EL + lane] : 0u;  // (more than EL suppressors: the list is full)
+            const u64 m0 = lane < nw ? row[lane] : 0ULL;
+            const unsigned char lv = lane < EL ? st[ent] : (unsigned char)2;
+            bool hK = lv == 1, hR = lv == 2;
             for (int q0 = 0; q0 < nw && __ballot(hK) == 0ULL; q0 += 64) {
               const int q = q0 + lane;
-              const u64 mm = q < nw ? row[q] : 0ULL;
+              const u64 mm = q0 == 0 ? m0 : (q < nw ? row[q] : 0ULL);
               if (mm) {  // (few words of a row carry bits: the others cost their lane nothing)
                 const u64* sp = reinterpret_cast<const u64*>(st + (size_t)q * 64);
                 u64 kw = 0, rw = 0;
@@ -1123,16 +1133,16 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
               }
             }
             const bool k_any = __ballot(hK) != 0ULL, r_all = __ballot(!hR) == 0ULL;
-            if (lane == 0 && (k_any || r_all)) {
-              st[hr] = k_any ? 2 : 1;
-              dec_h++;
+            if (lane == 0) {
+              if (k_any || r_all) st[hr] = k_any ? 2 : 1;
+              else und_h++;
             }
           }
-          if (lane == 0) hdec[wave] = dec_h;
+          if (lane == 0) hdec[wave] = und_h;
           __syncthreads();
 #pragma unroll
-          for (int w = 0; w < RTHREADS / 64; w++) left -= hdec[w];
-          __syncthreads();  // (hdec is written again in the next such round)
+          for (int w = 0; w < RTHREADS / 64; w++) left += hdec[w];
+          __syncthreads();  // (hdec is written again in the next round)
         }
         if (stamp_on && rnd < 8) stamps[18 + 4 * rnd] = __builtin_amdgcn_s_memtime();
         if (stamp_on && rnd < 8) stamps[19 + 4 * rnd] = __builtin_amdgcn_s_memtime();
