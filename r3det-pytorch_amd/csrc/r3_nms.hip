@@ -884,7 +884,7 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
-  constexpr int OVQ = 1024;  // overflow rows a workgroup converts together (grouped form)
+  constexpr int OVQ = 1024;  // rows with more than EL suppressors the wavefronts' pass can take (grouped form)
   __shared__ unsigned short ovq[OVQ];
   __shared__ int ovl[OVQ];
   __shared__ int hcnt[2];    // [0]: rows handed over to the wavefronts' pass (in-register form; they stay on its list)

@@ -63,13 +63,12 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     u64 s[64]; int kept; CK(hipMemcpy(s, st, 512, hipMemcpyDeviceToHost));
     if (it == 2) for (int r = 0; r < 8 && s[16 + 4 * r]; r++)
-      printf("  round %d: stamps +%llu +%llu +%llu  (in-register form: rows | - | barrier + count; general form: pass A | passes B, C | "
-             "overflow rows + barriers; this workgroup's thread 0)\n", r, s[17 + 4 * r] > s[16 + 4 * r] ? s[17 + 4 * r] - s[16 + 4 * r] : 0,
+      printf("  round %d: stamps +%llu +%llu +%llu  (in-register form: its rows | barrier (= the slowest wavefront) + the handed-over rows' pass | -; general form: pass A | "
+             "passes B, C | overflow rows + barriers; this workgroup's thread 0)\n", r, s[17 + 4 * r] > s[16 + 4 * r] ? s[17 + 4 * r] - s[16 + 4 * r] : 0,
              s[18 + 4 * r] - (s[17 + 4 * r] > s[16 + 4 * r] ? s[17 + 4 * r] : s[16 + 4 * r]), s[19 + 4 * r] - s[18 + 4 * r]); CK(hipMemcpy(&kept, dc, 4, hipMemcpyDeviceToHost));
     if (s[52] > s[48]) printf("  ranking kernel (sorted chunks), workgroup 0: record built %llu  first group of chunks %llu  the other groups %llu  records out %llu\n",
                               s[49] - s[48], s[50] - s[49], s[51] - s[50], s[52] - s[51]);
     if (s[56] > s[53]) printf("    its third group: next keys to LDS + request %llu  two searches %llu  barrier %llu\n", s[54] - s[53], s[55] - s[54], s[56] - s[55]);
-    if (s[12] > s[9]) printf("  conversion of %llu overflow rows behind round 0: enlist %llu  rows to LDS lists %llu  results %llu\n", s[8], s[10] - s[9], s[11] - s[10], s[12] - s[11]);
     printf("n %d rc %d kept %d | cycles: compaction %llu  prologue %llu  rounds %llu (%llu rounds)  tail %llu  bits %llu  total %llu\n", n, rc,
            kept, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[7], s[4] - s[3], s[5] - s[4], s[5] - s[0]);
   }
