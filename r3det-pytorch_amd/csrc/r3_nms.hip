@@ -884,9 +884,9 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
     if (stamp_on) stamps[k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
-  constexpr int OVQ = 1024;  // rows with more than EL suppressors the wavefronts' pass can take (grouped form)
+  constexpr int OVQ = 2048;  // rows with more than EL suppressors the wavefronts' pass can take: every row of an in-register label group
   __shared__ unsigned short ovq[OVQ];
-  __shared__ int ovl[OVQ];
+  __shared__ unsigned char ovl[OVQ];  // (general form: what the row's list said -- all of its entries removed)
   __shared__ int hcnt[2];    // [0]: rows handed over to the wavefronts' pass (in-register form; they stay on its list)
   __shared__ int hdec[RTHREADS / 64];  // ... and how many of them each wavefront left undecided in the round
   const int cbn = (n + TILE - 1) / TILE;
