@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256, FAST ? 4 : 1) void nms_drain_kernel(const BoxR
 // and wave 0 finishes adversarial inputs row by row in score order.
 constexpr int RTHREADS = 1024;
 constexpr int R_MAX_ROUNDS = 32;
-constexpr int R_HANDOVER = 2;  // (in-register form of the label-group reducer) rows beyond their list go to the wavefronts' pass behind this round
+constexpr int R_HANDOVER = 3;  // (in-register form of the label-group reducer) rows beyond their list go to the wavefronts' pass behind this round
 constexpr int R_CACHE = 9;     // rows per thread whose count and first 8 suppressors stay in registers (n <= 9216)
 constexpr int R_BLIST = 8192;  // rows on the long-list worklist (u16 each)
 
@@ -1063,7 +1063,8 @@ __device__ __forceinline__ void reduce_groups_body(const u64* __restrict__ maskT
             if (__ballot(ovf) != 0ULL) {
               // HANDED OVER behind round R_HANDOVER (most heavy rows fall to what their lists show in the first rounds;
               // measured on the model's own pool: the NMS chain 93.0 us handing over from round 0, 90.9 from 1, 89.4
-              // from 2, 88.4 from 3, 87.8 from 4) or as soon as a round decides nothing: from then on
+              // from 2, 88.4 from 3, 87.8 from 4; with the stall rule, one box: 89.2 / 88.0 / 88.4 from 2 / 3 / 4) or as soon as a
+              // round decides nothing: from then on
               // the pass below looks at the row -- list and overflow mask -- and its owner only waits for the answer.
               // (The owner walking its 32 entries every round on top of the pass: 2-3 k clocks per round in the
               // wavefronts with heavy rows, the ones the others wait for.)  No room on the pass's list: the row stays
